@@ -1,0 +1,48 @@
+// Internal helpers shared by the gfx950 kernels of libasrhip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/asr_hip.h"
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define ASR_WAVE 64
+
+void asr_set_error(const char* what, hipError_t e);
+
+#define ASR_CHECK_LAUNCH(name)                                   \
+    do {                                                         \
+        hipError_t e__ = hipGetLastError();                      \
+        if (e__ != hipSuccess) {                                 \
+            asr_set_error(name, e__);                            \
+            return ASR_ERR_LAUNCH;                               \
+        }                                                        \
+    } while (0)
+
+static inline int asr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// Bijective XCD-aware remap: consecutive logical tiles land on the same XCD (blocks are
+// dealt round-robin over the 8 XCDs), so neighbouring tiles share halo rows / weight
+// panels in that XCD's L2.  Speed only; any placement is correct.
+__device__ __forceinline__ int asr_xcd_swizzle(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+
+__device__ __forceinline__ float asr_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double asr_wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float asr_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,625 @@
+// HBM-bound pieces of the DFCNN cells (everything that is not a contraction):
+//   * first cell (Cin = 1): conv3x3 + bias + ReLU + frozen-BN affine + 2x2 pool in one pass,
+//     backward recomputes the pre-pool activations from the spectrogram;
+//   * pool forward, cell backward prologue (pool-bwd + BN-bwd + ReLU-bwd + channel sums);
+//   * squeeze-excitation forward/backward;
+// All channel reductions are block partials + a fixed-order column sum (reduce.h).
+#include "asr_common.h"
+#include "reduce.h"
+
+namespace {
+
+__device__ __forceinline__ bool interior(long p, int HPWP, int WP, int H, int W, int& b, int& hh, int& ww) {
+    b = (int)(p / HPWP);
+    const int r = (int)(p - (long)b * HPWP);
+    hh = r / WP;
+    ww = r - hh * WP;
+    return hh >= 1 && hh <= H && ww >= 1 && ww <= W;
+}
+
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ void st4(float* p, float4 v) { *(float4*)p = v; }
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+
+// ------------------------------------------------------------------ first cell
+template <int POOL, bool BWD>
+__global__ __launch_bounds__(256) void cell1_kernel(const float* __restrict__ x, int B, int T, int F, int C,
+                                                    const float* __restrict__ w, const float* __restrict__ bias,
+                                                    const float* __restrict__ sc, const float* __restrict__ sh,
+                                                    float* __restrict__ y, const float* __restrict__ dy,
+                                                    float* __restrict__ partials, int RPB) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int FP = F + 2;
+    float* xs = smem;                    // [4][F+2]
+    const int H2 = T / 2, W2 = F / 2, WP2 = W2 + 2, HP2 = H2 + 2;
+    const int tid = threadIdx.x;
+    const int c = tid % C, slot = tid / C, nslots = 256 / C;
+    const int b = blockIdx.y;
+    float wr[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wr[k] = w[k * C + c];
+    const float bs = bias[c], s = sc[c], h = sh[c];
+    float gsum[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) gsum[k] = 0.f;
+
+    const int h2beg = blockIdx.x * RPB;
+    const int h2end = (h2beg + RPB < H2) ? h2beg + RPB : H2;
+    for (int h2 = h2beg; h2 < h2end; ++h2) {
+        __syncthreads();
+        for (int i = tid; i < 4 * FP; i += 256) {
+            const int r = i / FP, col = i - r * FP - 1;
+            const int row = 2 * h2 - 1 + r;
+            float v = 0.f;
+            if (row >= 0 && row < T && col >= 0 && col < F) v = x[((long)b * T + row) * F + col];
+            xs[i] = v;
+        }
+        __syncthreads();
+        for (int w2 = slot; w2 < W2; w2 += nslots) {
+            float p[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) p[r][q] = xs[r * FP + 2 * w2 + q];
+            float a[4], yv[4];
+#pragma unroll
+            for (int pos = 0; pos < 4; ++pos) {
+                const int dyy = pos >> 1, dxx = pos & 1;
+                float z = bs;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) z = fmaf(p[dyy + kh][dxx + kw], wr[kh * 3 + kw], z);
+                a[pos] = fmaxf(z, 0.f);
+                yv[pos] = fmaf(s, a[pos], h);
+            }
+            const long po = (((long)b * HP2 + h2 + 1) * WP2 + w2 + 1) * C + c;
+            if (!BWD) {
+                float o;
+                if (POOL == 1) o = 0.25f * ((yv[0] + yv[1]) + (yv[2] + yv[3]));
+                else o = fmaxf(fmaxf(yv[0], yv[1]), fmaxf(yv[2], yv[3]));
+                y[po] = o;
+            } else {
+                const float dp = dy[po];
+                int arg = 0;
+                if (POOL == 2) {
+                    float m = yv[0];
+#pragma unroll
+                    for (int pos = 1; pos < 4; ++pos) if (yv[pos] > m) { m = yv[pos]; arg = pos; }
+                }
+#pragma unroll
+                for (int pos = 0; pos < 4; ++pos) {
+                    const int dyy = pos >> 1, dxx = pos & 1;
+                    const float gy = (POOL == 1) ? 0.25f * dp : (pos == arg ? dp : 0.f);
+                    gsum[11] += gy;                       // dshift
+                    gsum[10] = fmaf(gy, a[pos], gsum[10]); // dscale
+                    const float dz = (a[pos] > 0.f) ? gy * s : 0.f;
+                    gsum[9] += dz;                        // dbias
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw)
+                            gsum[kh * 3 + kw] = fmaf(p[dyy + kh][dxx + kw], dz, gsum[kh * 3 + kw]);
+                }
+            }
+        }
+    }
+    if (BWD) {
+        __syncthreads();
+        float* red = smem;               // [nslots][12][C]
+#pragma unroll
+        for (int k = 0; k < 12; ++k) red[(slot * 12 + k) * C + c] = gsum[k];
+        __syncthreads();
+        float* out = partials + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 12 * C;
+        for (int i = tid; i < 12 * C; i += 256) {
+            float sum = 0.f;
+            for (int sl = 0; sl < nslots; ++sl) sum += red[sl * 12 * C + i];
+            out[i] = sum;
+        }
+    }
+}
+
+constexpr int kCell1RPB = 8;
+
+// ------------------------------------------------------------------ pool forward
+template <int POOL>
+__global__ void pool_fwd_kernel(const float* __restrict__ a, int B, int H, int W, int C,
+                                const float* __restrict__ sc, const float* __restrict__ sh,
+                                float* __restrict__ y) {
+    const int C4 = C >> 2, H2 = H >> 1, W2 = W >> 1;
+    const long total = (long)B * H2 * W2 * C4;
+    const int WP = W + 2, HP = H + 2, WP2 = W2 + 2, HP2 = H2 + 2;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % C4);
+        long pix = idx / C4;
+        const int w2 = (int)(pix % W2); pix /= W2;
+        const int h2 = (int)(pix % H2);
+        const int b = (int)(pix / H2);
+        const float4 s = ld4(sc + cg * 4), h = ld4(sh + cg * 4);
+        const long pin = ((long)b * HP + 2 * h2 + 1) * WP + 2 * w2 + 1;
+        const float4 v0 = fma4(s, ld4(a + pin * C + cg * 4), h);
+        const float4 v1 = fma4(s, ld4(a + (pin + 1) * C + cg * 4), h);
+        const float4 v2 = fma4(s, ld4(a + (pin + WP) * C + cg * 4), h);
+        const float4 v3 = fma4(s, ld4(a + (pin + WP + 1) * C + cg * 4), h);
+        float4 o;
+        if (POOL == 1) {
+            o = make_float4(0.25f * ((v0.x + v1.x) + (v2.x + v3.x)), 0.25f * ((v0.y + v1.y) + (v2.y + v3.y)),
+                            0.25f * ((v0.z + v1.z) + (v2.z + v3.z)), 0.25f * ((v0.w + v1.w) + (v2.w + v3.w)));
+        } else {
+            o = make_float4(fmaxf(fmaxf(v0.x, v1.x), fmaxf(v2.x, v3.x)), fmaxf(fmaxf(v0.y, v1.y), fmaxf(v2.y, v3.y)),
+                            fmaxf(fmaxf(v0.z, v1.z), fmaxf(v2.z, v3.z)), fmaxf(fmaxf(v0.w, v1.w), fmaxf(v2.w, v3.w)));
+        }
+        st4(y + (((long)b * HP2 + h2 + 1) * WP2 + w2 + 1) * C + cg * 4, o);
+    }
+}
+
+// ------------------------------------------------------------------ cell backward prologue
+__device__ __forceinline__ float pick_max_grad(float y0, float y1, float y2, float y3, int mine, float dp) {
+    int arg = 0; float m = y0;
+    if (y1 > m) { m = y1; arg = 1; }
+    if (y2 > m) { m = y2; arg = 2; }
+    if (y3 > m) { m = y3; arg = 3; }
+    return arg == mine ? dp : 0.f;
+}
+
+constexpr int kPrePPB = 2048;   // padded pixels per block
+
+template <int POOL>
+__global__ __launch_bounds__(256) void cell_bwd_pre_kernel(const float* __restrict__ dy, int layout,
+                                                           const float* __restrict__ a, int B, int H, int W, int C,
+                                                           const float* __restrict__ sc, const float* __restrict__ sh,
+                                                           float* __restrict__ dz, float* __restrict__ partials) {
+    __shared__ float red[256 * 12];
+    const int C4 = C >> 2;
+    const int tid = threadIdx.x;
+    const int cg = tid % C4, slot = tid / C4, nslots = 256 / C4;
+    const int WP = W + 2, HPWP = (H + 2) * WP;
+    const long NP = (long)B * HPWP;
+    const long pbeg = (long)blockIdx.x * kPrePPB;
+    const long pend = (pbeg + kPrePPB < NP) ? pbeg + kPrePPB : NP;
+    const float4 s = ld4(sc + cg * 4), h = ld4(sh + cg * 4);
+    float4 s_shift = f4(0.f), s_scale = f4(0.f), s_bias = f4(0.f);
+    const int H2 = H >> 1, W2 = W >> 1;
+    for (long p = pbeg + slot; p < pend; p += nslots) {
+        int b, hh, ww;
+        if (!interior(p, HPWP, WP, H, W, b, hh, ww)) continue;
+        const float4 av = ld4(a + p * C + cg * 4);
+        float4 g;
+        if (POOL == 0) {
+            g = (layout == 0) ? ld4(dy + p * C + cg * 4)
+                              : ld4(dy + (((long)b * H + hh - 1) * W + ww - 1) * C + cg * 4);
+        } else {
+            const int hi = hh - 1, wi = ww - 1, h2 = hi >> 1, w2 = wi >> 1;
+            if (h2 < H2 && w2 < W2) {
+                const float4 dp = ld4(dy + (((long)b * (H2 + 2) + h2 + 1) * (W2 + 2) + w2 + 1) * C + cg * 4);
+                if (POOL == 1) {
+                    g = make_float4(0.25f * dp.x, 0.25f * dp.y, 0.25f * dp.z, 0.25f * dp.w);
+                } else {
+                    const long q = ((long)b * (H + 2) + 2 * h2 + 1) * WP + 2 * w2 + 1;
+                    const float4 y0 = fma4(s, ld4(a + q * C + cg * 4), h);
+                    const float4 y1 = fma4(s, ld4(a + (q + 1) * C + cg * 4), h);
+                    const float4 y2 = fma4(s, ld4(a + (q + WP) * C + cg * 4), h);
+                    const float4 y3 = fma4(s, ld4(a + (q + WP + 1) * C + cg * 4), h);
+                    const int mine = (hi & 1) * 2 + (wi & 1);
+                    g = make_float4(pick_max_grad(y0.x, y1.x, y2.x, y3.x, mine, dp.x),
+                                    pick_max_grad(y0.y, y1.y, y2.y, y3.y, mine, dp.y),
+                                    pick_max_grad(y0.z, y1.z, y2.z, y3.z, mine, dp.z),
+                                    pick_max_grad(y0.w, y1.w, y2.w, y3.w, mine, dp.w));
+                }
+            } else {
+                g = f4(0.f);
+            }
+        }
+        s_shift = add4(s_shift, g);
+        s_scale = fma4(g, av, s_scale);
+        float4 d = mul4(g, s);
+        d.x = av.x > 0.f ? d.x : 0.f; d.y = av.y > 0.f ? d.y : 0.f;
+        d.z = av.z > 0.f ? d.z : 0.f; d.w = av.w > 0.f ? d.w : 0.f;
+        s_bias = add4(s_bias, d);
+        st4(dz + p * C + cg * 4, d);
+    }
+    // block reduction over the pixel slots: red[tid][12]
+    float* mine = red + tid * 12;
+    mine[0] = s_scale.x; mine[1] = s_scale.y; mine[2] = s_scale.z; mine[3] = s_scale.w;
+    mine[4] = s_shift.x; mine[5] = s_shift.y; mine[6] = s_shift.z; mine[7] = s_shift.w;
+    mine[8] = s_bias.x;  mine[9] = s_bias.y;  mine[10] = s_bias.z; mine[11] = s_bias.w;
+    __syncthreads();
+    float* out = partials + (long)blockIdx.x * 3 * C;
+    for (int i = tid; i < 3 * C; i += 256) {
+        const int which = i / C, c = i - which * C;
+        const int g4 = c >> 2, e = c & 3;
+        float sum = 0.f;
+        for (int sl = 0; sl < nslots; ++sl) sum += red[(sl * C4 + g4) * 12 + which * 4 + e];
+        out[i] = sum;
+    }
+}
+
+// ------------------------------------------------------------------ squeeze-excitation
+constexpr int kSePPB = 2048;
+
+// partial[b][split][C] = sum over a pixel range of image b of x (MODE 0) or dout*(sc*x+sh) (MODE 1)
+template <int MODE>
+__global__ __launch_bounds__(256) void se_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                        int H, int W, int C, const float* __restrict__ sc,
+                                                        const float* __restrict__ sh, float* __restrict__ partials) {
+    __shared__ float red[256 * 4];
+    const int C4 = C >> 2;
+    const int tid = threadIdx.x;
+    const int cg = tid % C4, slot = tid / C4, nslots = 256 / C4;
+    const int WP = W + 2, HPWP = (H + 2) * WP;
+    const int b = blockIdx.y;
+    const long base = (long)b * HPWP;
+    const int pbeg = blockIdx.x * kSePPB;
+    const int pend = (pbeg + kSePPB < HPWP) ? pbeg + kSePPB : HPWP;
+    float4 acc = f4(0.f);
+    float4 s = f4(1.f), h = f4(0.f);
+    if (MODE == 1) { s = ld4(sc + cg * 4); h = ld4(sh + cg * 4); }
+    for (int r = pbeg + slot; r < pend; r += nslots) {
+        const int hh = r / WP, ww = r - hh * WP;
+        if (hh < 1 || hh > H || ww < 1 || ww > W) continue;
+        const float4 xv = ld4(x + (base + r) * C + cg * 4);
+        if (MODE == 0) acc = add4(acc, xv);
+        else acc = fma4(ld4(dout + (base + r) * C + cg * 4), fma4(s, xv, h), acc);
+    }
+    float* mine = red + tid * 4;
+    mine[0] = acc.x; mine[1] = acc.y; mine[2] = acc.z; mine[3] = acc.w;
+    __syncthreads();
+    float* out = partials + ((long)b * gridDim.x + blockIdx.x) * C;
+    for (int c = tid; c < C; c += 256) {
+        float sum = 0.f;
+        for (int sl = 0; sl < nslots; ++sl) sum += red[(sl * C4 + (c >> 2)) * 4 + (c & 3)];
+        out[c] = sum;
+    }
+}
+
+// one block per image: fold the split partials, run the 2-layer excitation MLP
+__global__ __launch_bounds__(256) void se_excite_kernel(const float* __restrict__ partials, int nsplit, int H, int W,
+                                                        int C, int hid, const float* __restrict__ sc,
+                                                        const float* __restrict__ sh, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1, const float* __restrict__ w2,
+                                                        const float* __restrict__ b2, float* __restrict__ st_s,
+                                                        float* __restrict__ st_r, float* __restrict__ st_e) {
+    extern __shared__ float sm[];
+    float* s = sm;            // [C]
+    float* r = sm + C;        // [hid]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float inv = 1.f / (float)(H * W);
+    for (int c = tid; c < C; c += 256) {
+        float sum = 0.f;
+        for (int k = 0; k < nsplit; ++k) sum += partials[((long)b * nsplit + k) * C + c];
+        const float v = fmaf(sc[c], sum * inv, sh[c]);
+        s[c] = v; st_s[(long)b * C + c] = v;
+    }
+    __syncthreads();
+    for (int j = tid; j < hid; j += 256) {
+        float u = b1[j];
+        for (int c = 0; c < C; ++c) u = fmaf(s[c], w1[(long)c * hid + j], u);
+        u = fmaxf(u, 0.f);
+        r[j] = u; st_r[(long)b * hid + j] = u;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float v = b2[c];
+        for (int j = 0; j < hid; ++j) v = fmaf(r[j], w2[(long)j * C + c], v);
+        st_e[(long)b * C + c] = 1.f / (1.f + expf(-v));
+    }
+}
+
+__global__ void se_apply_kernel(const float* __restrict__ main_in, const float* __restrict__ x, int B, int H, int W,
+                                int C, const float* __restrict__ sc, const float* __restrict__ sh,
+                                const float* __restrict__ e, float* __restrict__ out) {
+    const int C4 = C >> 2, WP = W + 2, HPWP = (H + 2) * WP;
+    const long total = (long)B * HPWP * C4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % C4);
+        const long p = idx / C4;
+        int b, hh, ww;
+        if (!interior(p, HPWP, WP, H, W, b, hh, ww)) continue;
+        const float4 xt = fma4(ld4(sc + cg * 4), ld4(x + p * C + cg * 4), ld4(sh + cg * 4));
+        st4(out + p * C + cg * 4, fma4(xt, ld4(e + (long)b * C + cg * 4), ld4(main_in + p * C + cg * 4)));
+    }
+}
+
+// one block per image: backward of the excitation MLP.
+// out_b (per image, later summed over b): [dw1 C*hid][db1 hid][dw2 hid*C][db2 C];  dsb[b][C] = ds/(H*W)
+__global__ __launch_bounds__(256) void se_bwd_mlp_kernel(const float* __restrict__ partials, int nsplit, int H, int W,
+                                                         int C, int hid, const float* __restrict__ w1,
+                                                         const float* __restrict__ w2, const float* __restrict__ st_s,
+                                                         const float* __restrict__ st_r, const float* __restrict__ st_e,
+                                                         float* __restrict__ out_b, float* __restrict__ dsb) {
+    extern __shared__ float sm[];
+    float* dv = sm;            // [C]
+    float* du = sm + C;        // [hid]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const long per = (long)C * hid + hid + (long)hid * C + C;
+    float* o = out_b + (long)b * per;
+    float* o_dw1 = o; float* o_db1 = o + (long)C * hid; float* o_dw2 = o_db1 + hid; float* o_db2 = o_dw2 + (long)hid * C;
+    for (int c = tid; c < C; c += 256) {
+        float de = 0.f;
+        for (int k = 0; k < nsplit; ++k) de += partials[((long)b * nsplit + k) * C + c];
+        const float e = st_e[(long)b * C + c];
+        const float v = de * e * (1.f - e);
+        dv[c] = v; o_db2[c] = v;
+    }
+    __syncthreads();
+    for (int j = tid; j < hid; j += 256) {
+        float dr = 0.f;
+        for (int c = 0; c < C; ++c) dr = fmaf(dv[c], w2[(long)j * C + c], dr);
+        const float rj = st_r[(long)b * hid + j];
+        const float u = rj > 0.f ? dr : 0.f;
+        du[j] = u; o_db1[j] = u;
+    }
+    __syncthreads();
+    for (int i = tid; i < hid * C; i += 256) {
+        const int j = i / C, c = i - j * C;
+        o_dw2[i] = st_r[(long)b * hid + j] * dv[c];
+    }
+    for (int i = tid; i < C * hid; i += 256) {
+        const int c = i / hid, j = i - c * hid;
+        o_dw1[i] = st_s[(long)b * C + c] * du[j];
+    }
+    const float inv = 1.f / (float)(H * W);
+    for (int c = tid; c < C; c += 256) {
+        float ds = 0.f;
+        for (int j = 0; j < hid; ++j) ds = fmaf(du[j], w1[(long)c * hid + j], ds);
+        dsb[(long)b * C + c] = ds * inv;
+    }
+}
+
+constexpr int kSeApplyPPB = 2048;
+
+// dxt = dout*e + dsb; dx = dxt*sc (+ dout when add_dout); channel sums dshift = sum dxt, dscale = sum dxt*x
+__global__ __launch_bounds__(256) void se_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ x,
+                                                           int B, int H, int W, int C, const float* __restrict__ sc,
+                                                           const float* __restrict__ e, const float* __restrict__ dsb,
+                                                           int add_dout, float* __restrict__ dx,
+                                                           float* __restrict__ partials) {
+    __shared__ float red[256 * 8];
+    const int C4 = C >> 2;
+    const int tid = threadIdx.x;
+    const int cg = tid % C4, slot = tid / C4, nslots = 256 / C4;
+    const int WP = W + 2, HPWP = (H + 2) * WP;
+    const long NP = (long)B * HPWP;
+    const long pbeg = (long)blockIdx.x * kSeApplyPPB;
+    const long pend = (pbeg + kSeApplyPPB < NP) ? pbeg + kSeApplyPPB : NP;
+    const float4 s = ld4(sc + cg * 4);
+    float4 s_shift = f4(0.f), s_scale = f4(0.f);
+    for (long p = pbeg + slot; p < pend; p += nslots) {
+        int b, hh, ww;
+        if (!interior(p, HPWP, WP, H, W, b, hh, ww)) continue;
+        const float4 g = ld4(dout + p * C + cg * 4);
+        const float4 xv = ld4(x + p * C + cg * 4);
+        const float4 dxt = fma4(g, ld4(e + (long)b * C + cg * 4), ld4(dsb + (long)b * C + cg * 4));
+        s_shift = add4(s_shift, dxt);
+        s_scale = fma4(dxt, xv, s_scale);
+        float4 d = mul4(dxt, s);
+        if (add_dout) d = add4(d, g);
+        st4(dx + p * C + cg * 4, d);
+    }
+    float* mine = red + tid * 8;
+    mine[0] = s_scale.x; mine[1] = s_scale.y; mine[2] = s_scale.z; mine[3] = s_scale.w;
+    mine[4] = s_shift.x; mine[5] = s_shift.y; mine[6] = s_shift.z; mine[7] = s_shift.w;
+    __syncthreads();
+    float* out = partials + (long)blockIdx.x * 2 * C;
+    for (int i = tid; i < 2 * C; i += 256) {
+        const int which = i / C, c = i - which * C;
+        float sum = 0.f;
+        for (int sl = 0; sl < nslots; ++sl) sum += red[(sl * C4 + (c >> 2)) * 8 + which * 4 + (c & 3)];
+        out[i] = sum;
+    }
+}
+
+__global__ void axpy_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n, float alpha, int accumulate) {
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= n) {
+            float4 v = ld4(src + i);
+            v = make_float4(alpha * v.x, alpha * v.y, alpha * v.z, alpha * v.w);
+            if (accumulate) v = add4(v, ld4(dst + i));
+            st4(dst + i, v);
+        } else {
+            for (size_t j = i; j < n; ++j) dst[j] = alpha * src[j] + (accumulate ? dst[j] : 0.f);
+        }
+    }
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ h, size_t n, float* __restrict__ dz) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dz[i] = h[i] > 0.f ? dy[i] : 0.f;
+}
+
+inline bool chan_ok(int C) { return C >= 4 && (C & 3) == 0 && (256 % (C / 4)) == 0 && C <= 1024; }
+inline int grid_for(long total, int threads) {
+    long b = (total + threads - 1) / threads;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+// ===================================================================== C ABI
+extern "C" int asr_cell1_fwd(const float* x, int B, int T, int F, int C, const float* w, const float* bias,
+                             const float* bn_scale, const float* bn_shift, int pool, float* y, void* stream) {
+    if (!x || !w || !bias || !bn_scale || !bn_shift || !y) return ASR_ERR_BAD_ARG;
+    if (C < 1 || C > 256 || (256 % C) != 0 || T < 2 || F < 2 || (pool != 1 && pool != 2)) return ASR_ERR_BAD_ARG;
+    const int H2 = T / 2;
+    dim3 grid(asr_cdiv(H2, kCell1RPB), B);
+    const size_t lds = (size_t)4 * (F + 2) * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (pool == 1)
+        hipLaunchKernelGGL((cell1_kernel<1, false>), grid, dim3(256), lds, st, x, B, T, F, C, w, bias, bn_scale, bn_shift, y, (const float*)nullptr, (float*)nullptr, kCell1RPB);
+    else
+        hipLaunchKernelGGL((cell1_kernel<2, false>), grid, dim3(256), lds, st, x, B, T, F, C, w, bias, bn_scale, bn_shift, y, (const float*)nullptr, (float*)nullptr, kCell1RPB);
+    ASR_CHECK_LAUNCH("cell1_fwd");
+    return ASR_OK;
+}
+
+extern "C" size_t asr_cell1_bwd_workspace(int B, int T, int F, int C) {
+    const size_t nblk = (size_t)asr_cdiv(T / 2, kCell1RPB) * B;
+    return (nblk * 12 * C + asr_reduce::colsum_tmp_floats((int)nblk, 12 * C)) * sizeof(float);
+}
+
+extern "C" int asr_cell1_bwd(const float* x, int B, int T, int F, int C, const float* w, const float* bias,
+                             const float* bn_scale, const float* bn_shift, int pool, const float* dy,
+                             float* dw, float* db, float* dscale, float* dshift, float* partials, void* stream) {
+    if (!x || !w || !bias || !bn_scale || !bn_shift || !dy || !dw || !db || !dscale || !dshift || !partials)
+        return ASR_ERR_BAD_ARG;
+    if (C < 1 || C > 256 || (256 % C) != 0 || T < 2 || F < 2 || (pool != 1 && pool != 2)) return ASR_ERR_BAD_ARG;
+    const int H2 = T / 2;
+    dim3 grid(asr_cdiv(H2, kCell1RPB), B);
+    const int nblk = grid.x * grid.y;
+    size_t lds = (size_t)4 * (F + 2) * sizeof(float);
+    const size_t red = (size_t)(256 / C) * 12 * C * sizeof(float);
+    if (red > lds) lds = red;
+    hipStream_t st = (hipStream_t)stream;
+    if (pool == 1)
+        hipLaunchKernelGGL((cell1_kernel<1, true>), grid, dim3(256), lds, st, x, B, T, F, C, w, bias, bn_scale, bn_shift, (float*)nullptr, dy, partials, kCell1RPB);
+    else
+        hipLaunchKernelGGL((cell1_kernel<2, true>), grid, dim3(256), lds, st, x, B, T, F, C, w, bias, bn_scale, bn_shift, (float*)nullptr, dy, partials, kCell1RPB);
+    ASR_CHECK_LAUNCH("cell1_bwd");
+    float* tmp = partials + (size_t)nblk * 12 * C;
+    int rc;
+    if ((rc = asr_reduce::colsum(partials, nblk, 9 * C, 12 * C, dw, tmp, st))) return rc;
+    if ((rc = asr_reduce::colsum(partials + 9 * C, nblk, C, 12 * C, db, tmp, st))) return rc;
+    if ((rc = asr_reduce::colsum(partials + 10 * C, nblk, C, 12 * C, dscale, tmp, st))) return rc;
+    if ((rc = asr_reduce::colsum(partials + 11 * C, nblk, C, 12 * C, dshift, tmp, st))) return rc;
+    return ASR_OK;
+}
+
+extern "C" int asr_pool_fwd(const float* a, int B, int H, int W, int C, const float* bn_scale,
+                            const float* bn_shift, int pool, float* y, void* stream) {
+    if (!a || !bn_scale || !bn_shift || !y || (C & 3) || H < 2 || W < 2 || (pool != 1 && pool != 2)) return ASR_ERR_BAD_ARG;
+    const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+    hipStream_t st = (hipStream_t)stream;
+    if (pool == 1) hipLaunchKernelGGL(pool_fwd_kernel<1>, dim3(grid_for(total, 256)), dim3(256), 0, st, a, B, H, W, C, bn_scale, bn_shift, y);
+    else hipLaunchKernelGGL(pool_fwd_kernel<2>, dim3(grid_for(total, 256)), dim3(256), 0, st, a, B, H, W, C, bn_scale, bn_shift, y);
+    ASR_CHECK_LAUNCH("pool_fwd");
+    return ASR_OK;
+}
+
+extern "C" size_t asr_cell_bwd_pre_workspace(int B, int H, int W, int C) {
+    const long NP = (long)B * (H + 2) * (W + 2);
+    const size_t nblk = (size_t)asr_cdiv(NP, kPrePPB);
+    return (nblk * 3 * C + asr_reduce::colsum_tmp_floats((int)nblk, 3 * C)) * sizeof(float);
+}
+
+extern "C" int asr_cell_bwd_pre(const float* dy, int dy_layout, const float* a, int B, int H, int W, int C,
+                                const float* bn_scale, const float* bn_shift, int pool,
+                                float* dz, float* dscale, float* dshift, float* dbias,
+                                float* partials, void* stream) {
+    if (!dy || !a || !bn_scale || !bn_shift || !dz || !dscale || !dshift || !dbias || !partials) return ASR_ERR_BAD_ARG;
+    if (!chan_ok(C) || pool < 0 || pool > 2) return ASR_ERR_BAD_ARG;
+    if ((pool != 0) != (dy_layout == 1)) return ASR_ERR_BAD_ARG;
+    if (dy_layout < 0 || dy_layout > 2) return ASR_ERR_BAD_ARG;
+    const long NP = (long)B * (H + 2) * (W + 2);
+    const int nblk = asr_cdiv(NP, kPrePPB);
+    hipStream_t st = (hipStream_t)stream;
+    if (pool == 0) hipLaunchKernelGGL(cell_bwd_pre_kernel<0>, dim3(nblk), dim3(256), 0, st, dy, dy_layout, a, B, H, W, C, bn_scale, bn_shift, dz, partials);
+    else if (pool == 1) hipLaunchKernelGGL(cell_bwd_pre_kernel<1>, dim3(nblk), dim3(256), 0, st, dy, dy_layout, a, B, H, W, C, bn_scale, bn_shift, dz, partials);
+    else hipLaunchKernelGGL(cell_bwd_pre_kernel<2>, dim3(nblk), dim3(256), 0, st, dy, dy_layout, a, B, H, W, C, bn_scale, bn_shift, dz, partials);
+    ASR_CHECK_LAUNCH("cell_bwd_pre");
+    float* tmp = partials + (size_t)nblk * 3 * C;
+    int rc;
+    if ((rc = asr_reduce::colsum(partials, nblk, C, 3 * C, dscale, tmp, st))) return rc;
+    if ((rc = asr_reduce::colsum(partials + C, nblk, C, 3 * C, dshift, tmp, st))) return rc;
+    if ((rc = asr_reduce::colsum(partials + 2 * C, nblk, C, 3 * C, dbias, tmp, st))) return rc;
+    return ASR_OK;
+}
+
+extern "C" size_t asr_se_state_floats(int B, int C, int hid) { return (size_t)B * (2 * C + hid); }
+
+static inline int se_nsplit(int H, int W) { return asr_cdiv((long)(H + 2) * (W + 2), kSePPB); }
+
+extern "C" size_t asr_se_fwd_workspace(int B, int H, int W, int C) {
+    return ((size_t)B * se_nsplit(H, W) * C + 64) * sizeof(float);
+}
+
+extern "C" size_t asr_se_bwd_workspace(int B, int H, int W, int C, int hid) {
+    const size_t per = (size_t)C * hid + hid + (size_t)hid * C + C;
+    const long NP = (long)B * (H + 2) * (W + 2);
+    const size_t nblk = (size_t)asr_cdiv(NP, kSeApplyPPB);
+    const size_t fl = (size_t)B * se_nsplit(H, W) * C + (size_t)B * per + (size_t)B * C + nblk * 2 * C
+                    + asr_reduce::colsum_tmp_floats((int)nblk, 2 * C) + 64;
+    return fl * sizeof(float);
+}
+
+extern "C" int asr_se_fwd(const float* main_in, const float* x, int B, int H, int W, int C, int hid,
+                          const float* bn_scale, const float* bn_shift, const float* w1, const float* b1,
+                          const float* w2, const float* b2, float* state, float* partials, float* out,
+                          void* stream) {
+    if (!main_in || !x || !bn_scale || !bn_shift || !w1 || !b1 || !w2 || !b2 || !state || !partials || !out)
+        return ASR_ERR_BAD_ARG;
+    if (!chan_ok(C) || hid < 1 || hid > 1024) return ASR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = se_nsplit(H, W);
+    float* st_s = state; float* st_r = st_s + (size_t)B * C; float* st_e = st_r + (size_t)B * hid;
+    hipLaunchKernelGGL(se_reduce_kernel<0>, dim3(ns, B), dim3(256), 0, st, x, (const float*)nullptr, H, W, C, bn_scale, bn_shift, partials);
+    hipLaunchKernelGGL(se_excite_kernel, dim3(B), dim3(256), (size_t)(C + hid) * sizeof(float), st, (const float*)partials, ns, H, W, C, hid, bn_scale, bn_shift, w1, b1, w2, b2, st_s, st_r, st_e);
+    const long total = (long)B * (H + 2) * (W + 2) * (C / 4);
+    hipLaunchKernelGGL(se_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, main_in, x, B, H, W, C, bn_scale, bn_shift, (const float*)st_e, out);
+    ASR_CHECK_LAUNCH("se_fwd");
+    return ASR_OK;
+}
+
+extern "C" int asr_se_bwd(const float* dout, const float* x, int B, int H, int W, int C, int hid,
+                          const float* bn_scale, const float* bn_shift, const float* w1, const float* w2,
+                          const float* state, int add_dout, float* dx, float* dscale, float* dshift,
+                          float* dw1, float* db1, float* dw2, float* db2, float* partials, void* stream) {
+    if (!dout || !x || !bn_scale || !bn_shift || !w1 || !w2 || !state || !dx || !dscale || !dshift || !dw1 ||
+        !db1 || !dw2 || !db2 || !partials)
+        return ASR_ERR_BAD_ARG;
+    if (!chan_ok(C) || hid < 1 || hid > 1024) return ASR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const int ns = se_nsplit(H, W);
+    const size_t per = (size_t)C * hid + hid + (size_t)hid * C + C;
+    const long NP = (long)B * (H + 2) * (W + 2);
+    const int nblk = asr_cdiv(NP, kSeApplyPPB);
+    float* part_red = partials;
+    float* mlp_out = part_red + (size_t)B * ns * C;
+    float* dsb = mlp_out + (size_t)B * per;
+    float* part_apply = dsb + (size_t)B * C;
+    float* tmp = part_apply + (size_t)nblk * 2 * C;
+    const float* st_s = state; const float* st_r = st_s + (size_t)B * C; const float* st_e = st_r + (size_t)B * hid;
+    hipLaunchKernelGGL(se_reduce_kernel<1>, dim3(ns, B), dim3(256), 0, st, x, dout, H, W, C, bn_scale, bn_shift, part_red);
+    hipLaunchKernelGGL(se_bwd_mlp_kernel, dim3(B), dim3(256), (size_t)(C + hid) * sizeof(float), st, (const float*)part_red, ns, H, W, C, hid, w1, w2, st_s, st_r, st_e, mlp_out, dsb);
+    ASR_CHECK_LAUNCH("se_bwd_mlp");
+    int rc;
+    if ((rc = asr_reduce::colsum(mlp_out, B, C * hid, (long)per, dw1, tmp, st))) return rc;
+    if ((rc = asr_reduce::colsum(mlp_out + (size_t)C * hid, B, hid, (long)per, db1, tmp, st))) return rc;
+    if ((rc = asr_reduce::colsum(mlp_out + (size_t)C * hid + hid, B, hid * C, (long)per, dw2, tmp, st))) return rc;
+    if ((rc = asr_reduce::colsum(mlp_out + (size_t)C * hid + hid + (size_t)hid * C, B, C, (long)per, db2, tmp, st))) return rc;
+    hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(nblk), dim3(256), 0, st, dout, x, B, H, W, C, bn_scale, st_e, (const float*)dsb, add_dout, dx, part_apply);
+    ASR_CHECK_LAUNCH("se_bwd_apply");
+    if ((rc = asr_reduce::colsum(part_apply, nblk, C, 2 * C, dscale, tmp, st))) return rc;
+    if ((rc = asr_reduce::colsum(part_apply + C, nblk, C, 2 * C, dshift, tmp, st))) return rc;
+    return ASR_OK;
+}
+
+extern "C" int asr_axpy(float* dst, const float* src, size_t n, float alpha, int accumulate, void* stream) {
+    if (!dst || !src) return ASR_ERR_BAD_ARG;
+    if (n == 0) return ASR_OK;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for((long)((n + 3) / 4), 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n, alpha, accumulate);
+    ASR_CHECK_LAUNCH("axpy");
+    return ASR_OK;
+}
+
+extern "C" int asr_relu_bwd(const float* dy, const float* h, size_t n, float* dz, void* stream) {
+    if (!dy || !h || !dz) return ASR_ERR_BAD_ARG;
+    if (n == 0) return ASR_OK;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for((long)n, 256)), dim3(256), 0, (hipStream_t)stream, dy, h, n, dz);
+    ASR_CHECK_LAUNCH("relu_bwd");
+    return ASR_OK;
+}
+
+extern "C" size_t asr_colsum_workspace(int rows, int cols) {
+    return (asr_reduce::colsum_tmp_floats(rows, cols) + 4) * sizeof(float);
+}
+
+extern "C" int asr_colsum(const float* x, int rows, int cols, int ldx, float* out, float* partials, void* stream) {
+    if (!x || !out || rows < 1 || cols < 1) return ASR_ERR_BAD_ARG;
+    if (rows > asr_reduce::kSplits && !partials) return ASR_ERR_BAD_ARG;
+    return asr_reduce::colsum(x, rows, cols, ldx, out, partials, (hipStream_t)stream);
+}

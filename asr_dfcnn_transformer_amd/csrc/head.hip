@@ -1,0 +1,411 @@
+// Loss head of the acoustic model: softmax -> log(p + eps) (time-major), CTC loss and
+// gradient (alpha/beta in float64, one workgroup per utterance, lattice inputs gathered
+// into LDS once), greedy decoding, normalised edit distance, and the TF-form Adam update.
+// All of these are HBM/latency-bound row kernels: one wave per (t, b) row, wave-level
+// reductions, no MFMA.
+#include "asr_common.h"
+#include <math.h>
+
+namespace {
+
+// ------------------------------------------------------------------ softmax + log, fwd / bwd
+__global__ __launch_bounds__(256) void softmax_log_fwd_kernel(const float* __restrict__ d, int B, int T, int V,
+                                                              float eps, float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // row = b*T + t
+    if (row >= B * T) return;
+    const int lane = threadIdx.x & 63;
+    const int b = row / T, t = row - b * T;
+    const float* x = d + (long)row * V;
+    float m = -INFINITY;
+    for (int k = lane; k < V; k += 64) m = fmaxf(m, x[k]);
+    m = asr_wave_max(m);
+    float s = 0.f;
+    for (int k = lane; k < V; k += 64) s += expf(x[k] - m);
+    s = asr_wave_sum(s);
+    const float inv = 1.f / s;
+    float* o = out + ((long)t * B + b) * V;
+    for (int k = lane; k < V; k += 64) o[k] = logf(expf(x[k] - m) * inv + eps);
+}
+
+__global__ __launch_bounds__(256) void softmax_log_bwd_kernel(const float* __restrict__ li, const float* __restrict__ g,
+                                                              int B, int T, int V, float eps, float gscale,
+                                                              float* __restrict__ dd) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // row = t*B + b
+    if (row >= B * T) return;
+    const int lane = threadIdx.x & 63;
+    const int t = row / B, b = row - t * B;
+    const float* l = li + (long)row * V;
+    const float* gr = g + (long)row * V;
+    float inner = 0.f;
+    for (int k = lane; k < V; k += 64) {
+        const float pe = expf(l[k]);               // p + eps
+        inner += (pe - eps) * (gr[k] / pe);
+    }
+    inner = asr_wave_sum(inner);
+    float* o = dd + ((long)b * T + t) * V;
+    for (int k = lane; k < V; k += 64) {
+        const float pe = expf(l[k]);
+        o[k] = (pe - eps) * (gr[k] / pe - inner) * gscale;
+    }
+}
+
+// ------------------------------------------------------------------ CTC
+__global__ void ctc_check_kernel(const int32_t* __restrict__ labels, int max_label, const int32_t* __restrict__ label_len,
+                                 const int32_t* __restrict__ seq_len, int T, int B, int32_t* __restrict__ status) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int L = label_len[b], Tb = seq_len[b];
+    int bad = (L < 0 || L > max_label || Tb <= 0 || Tb > T) ? 1 : 0;
+    if (!bad) {
+        int rep = 0;
+        for (int i = 1; i < L; ++i) rep += labels[(long)b * max_label + i] == labels[(long)b * max_label + i - 1];
+        if (Tb < L + rep) bad = 1;
+    }
+    status[b] = bad;
+}
+
+// one wave per (t,b) row: lse of the row (TF's own log-softmax) and the dense part of the
+// gradient, softmax(logits); rows at t >= seq_len or of infeasible utterances are zero.
+__global__ __launch_bounds__(256) void ctc_rows_kernel(const float* __restrict__ logits, int T, int B, int V,
+                                                       const int32_t* __restrict__ seq_len, const int32_t* __restrict__ status,
+                                                       double* __restrict__ lse, float* __restrict__ grad) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // row = t*B + b
+    if (row >= T * B) return;
+    const int lane = threadIdx.x & 63;
+    const int t = row / B, b = row - t * B;
+    float* gr = grad + (long)row * V;
+    if (status[b] != 0 || t >= seq_len[b]) {
+        for (int k = lane; k < V; k += 64) gr[k] = 0.f;
+        if (lane == 0) lse[row] = 0.0;
+        return;
+    }
+    const float* x = logits + (long)row * V;
+    float m = -INFINITY;
+    for (int k = lane; k < V; k += 64) m = fmaxf(m, x[k]);
+    m = asr_wave_max(m);
+    double s = 0.0;
+    for (int k = lane; k < V; k += 64) s += (double)expf(x[k] - m);
+    s = asr_wave_sum_d(s);
+    const double l = (double)m + log(s);
+    if (lane == 0) lse[row] = l;
+    const float lf = (float)l;
+    for (int k = lane; k < V; k += 64) gr[k] = expf(x[k] - lf);
+}
+
+__device__ __forceinline__ double lse3(double a, double b, double c) {
+    const double m = fmax(a, fmax(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    return m + log(exp(a - m) + exp(b - m) + exp(c - m));
+}
+
+// One workgroup per utterance; thread s owns lattice state s of the blank-extended label.
+__global__ __launch_bounds__(256) void ctc_lattice_kernel(const float* __restrict__ logits, int T, int B, int V,
+                                                          const int32_t* __restrict__ labels, int max_label,
+                                                          const int32_t* __restrict__ label_len,
+                                                          const int32_t* __restrict__ seq_len, int blank,
+                                                          const int32_t* __restrict__ status, const double* __restrict__ lse,
+                                                          double* __restrict__ alpha_ws, float* __restrict__ loss,
+                                                          float* __restrict__ grad) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    const int b = blockIdx.x, s = threadIdx.x;
+    if (status[b] != 0) {
+        if (s == 0) loss[b] = INFINITY;
+        return;
+    }
+    const int L = label_len[b], Tb = seq_len[b], S = 2 * L + 1;
+    const int SMAX = 2 * max_label + 1;
+    double* buf0 = (double*)smraw;              // [SMAX + 2]  (two leading -inf sentinels)
+    double* buf1 = buf0 + SMAX + 4;
+    double* occ = buf1 + SMAX + 4;              // [SMAX + 1]
+    double* lse_t = occ + SMAX + 3;             // [T]
+    int* ext = (int*)(lse_t + T);               // [SMAX]
+    int* nxt = ext + SMAX + 1;                  // [SMAX]
+    float* lg = (float*)(nxt + SMAX + 1);       // [Tb][S]
+
+    if (s < S) ext[s] = (s & 1) ? labels[(long)b * max_label + (s >> 1)] : blank;
+    for (int t = s; t < Tb; t += 256) lse_t[t] = lse[(long)t * B + b];
+    __syncthreads();
+    int my = blank; bool skip_f = false, skip_b = false; int leader = 0;
+    if (s < S) {
+        my = ext[s];
+        skip_f = (s >= 2) && (my != blank) && (my != ext[s - 2]);
+        skip_b = (s + 2 < S) && (my != blank) && (my != ext[s + 2]);
+        int n = -1;
+        if (s & 1) {
+            leader = 1;
+            for (int j = 1; j < s; j += 2) if (ext[j] == my) { leader = 0; break; }
+            for (int j = s + 2; j < S; j += 2) if (ext[j] == my) { n = j; break; }
+        }
+        nxt[s] = n;
+    }
+    // gather the lattice inputs: lg[t][s] = logits[t][b][ext[s]]
+    for (int i = s; i < Tb * S; i += 256) {
+        const int t = i / S, q = i - t * S;
+        lg[i] = logits[((long)t * B + b) * V + ext[q]];
+    }
+    __syncthreads();
+
+    double* prev = buf0 + 2; double* cur = buf1 + 2;
+    if (s < 2) { buf0[s] = -INFINITY; buf1[s] = -INFINITY; }
+    double* aw = alpha_ws + (long)b * T * SMAX;
+    // ---- alpha
+    if (s < S) {
+        const double v = (s < 2) ? (double)lg[s] - lse_t[0] : -INFINITY;
+        prev[s] = v; aw[s] = v;
+    }
+    for (int t = 1; t < Tb; ++t) {
+        __syncthreads();
+        if (s < S) {
+            const double a0 = prev[s], a1 = prev[s - 1], a2 = skip_f ? prev[s - 2] : -INFINITY;
+            const double v = lse3(a0, a1, a2) + ((double)lg[t * S + s] - lse_t[t]);
+            cur[s] = v; aw[(long)t * SMAX + s] = v;
+        }
+        double* tmp = prev; prev = cur; cur = tmp;
+    }
+    __syncthreads();
+    const double ll = (S > 1) ? lse3(prev[S - 1], prev[S - 2], -INFINITY) : prev[0];
+    if (s == 0) loss[b] = (float)(-ll);
+    __syncthreads();
+    // ---- beta + gradient (beta buffers get trailing -inf sentinels)
+    double* bp = buf0 + 2; double* bc = buf1 + 2;
+    if (s < 2) { bp[S + s] = -INFINITY; bc[S + s] = -INFINITY; }
+    double a_next = 0.0;
+    if (s < S) {
+        const int t = Tb - 1;
+        bp[s] = (s >= S - 2) ? (double)lg[t * S + s] - lse_t[t] : -INFINITY;
+        a_next = aw[(long)t * SMAX + s];
+    }
+    for (int t = Tb - 1; t >= 0; --t) {
+        __syncthreads();
+        double bcur = -INFINITY, a_t = a_next;
+        if (s < S) {
+            const double lp = (double)lg[t * S + s] - lse_t[t];
+            if (t == Tb - 1) {
+                bcur = bp[s];
+            } else {
+                const double b0 = bp[s], b1 = bp[s + 1], b2 = skip_b ? bp[s + 2] : -INFINITY;
+                bcur = lse3(b0, b1, b2) + lp;
+                bc[s] = bcur;
+            }
+            if (t > 0) a_next = aw[(long)(t - 1) * SMAX + s];
+            const double ab = a_t + bcur;
+            occ[s] = (ab == -INFINITY) ? 0.0 : exp(ab - lp - ll);
+        }
+        __syncthreads();
+        float* gr = grad + ((long)t * B + b) * V;
+        if (s < 64) {                       // wave 0: all blank states (even s)
+            double sum = 0.0;
+            for (int q = 2 * s; q < S; q += 128) sum += occ[q];
+            sum = asr_wave_sum_d(sum);
+            if (s == 0) gr[blank] -= (float)sum;
+        }
+        if (s < S && leader) {
+            double sum = occ[s];
+            for (int q = nxt[s]; q >= 0; q = nxt[q]) sum += occ[q];
+            gr[my] -= (float)sum;
+        }
+        if (t != Tb - 1) { double* tmp = bp; bp = bc; bc = tmp; }
+    }
+}
+
+// ------------------------------------------------------------------ greedy decode
+__global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict__ logits, int T, int B, int V,
+                                                         const int32_t* __restrict__ seq_len, int blank,
+                                                         int32_t* __restrict__ out_ids, int32_t* __restrict__ out_len,
+                                                         float* __restrict__ neg_sum) {
+    extern __shared__ int sm_i[];
+    int* best_k = sm_i;                     // [T]
+    float* best_v = (float*)(sm_i + T);     // [T]
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int Tb = seq_len[b];
+    if (Tb > T) Tb = T;
+    if (Tb < 0) Tb = 0;
+    for (int t = wave; t < Tb; t += 4) {
+        const float* x = logits + ((long)t * B + b) * V;
+        float bv = -INFINITY; int bk = 0x7fffffff;
+        for (int k = lane; k < V; k += 64) {
+            const float v = x[k];
+            if (v > bv || (bk == 0x7fffffff)) { if (v > bv || bk == 0x7fffffff) { bv = v; bk = k; } }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o, 64);
+            const int ok = __shfl_xor(bk, o, 64);
+            if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+        }
+        if (lane == 0) { best_k[t] = bk; best_v[t] = bv; }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T; i += 256) out_ids[(long)b * T + i] = -1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0, prev = -1;
+        float acc = 0.f;
+        for (int t = 0; t < Tb; ++t) {
+            const int k = best_k[t];
+            acc += -best_v[t];
+            if (k != blank && k != prev) out_ids[(long)b * T + n++] = k;
+            prev = k;
+        }
+        out_len[b] = n;
+        neg_sum[b] = acc;
+    }
+}
+
+// ------------------------------------------------------------------ edit distance (one wave per pair)
+__global__ __launch_bounds__(64) void edit_distance_kernel(const int32_t* __restrict__ hyp, int hyp_pitch,
+                                                           const int32_t* __restrict__ hyp_len,
+                                                           const int32_t* __restrict__ truth, int truth_pitch,
+                                                           const int32_t* __restrict__ truth_len, int B,
+                                                           float* __restrict__ dist) {
+    extern __shared__ int sm_e[];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = truth_len[b], m = hyp_len[b];
+    int* prev = sm_e;                 // [n+1]
+    int* tr = sm_e + truth_pitch + 1; // [n]
+    for (int j = lane; j <= n; j += 64) prev[j] = j;
+    for (int j = lane; j < n; j += 64) tr[j] = truth[(long)b * truth_pitch + j];
+    __syncthreads();
+    // Row i of the Levenshtein table from row i-1 (prev):  D[i][0] = i,
+    //   t[j] = min(prev[j] + 1, prev[j-1] + cost(i,j)),  D[i][j] = min(t[j], D[i][j-1] + 1)
+    // which unrolls to D[i][j] = j + min(i, min_{1<=k<=j}(t[k] - k)): a prefix-min per row.
+    for (int i = 1; i <= m; ++i) {
+        const int hi = hyp[(long)b * hyp_pitch + i - 1];
+        int run = i;          // running min of (t[k] - k), k = 0 term is D[i][0] - 0
+        int diag = i - 1;     // old prev[j0 - 1] for the first lane of the chunk (D[i-1][0] = i-1)
+        for (int j0 = 1; j0 <= n; j0 += 64) {
+            const int j = j0 + lane;
+            const int pj = (j <= n) ? prev[j] : 0;
+            int pjm1 = __shfl_up(pj, 1, 64);
+            if (lane == 0) pjm1 = diag;
+            diag = __shfl(pj, 63, 64);
+            int u = 0x3fffffff;
+            if (j <= n) u = min(pj + 1, pjm1 + (tr[j - 1] != hi ? 1 : 0)) - j;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int v = __shfl_up(u, o, 64);
+                if (lane >= o) u = min(u, v);
+            }
+            u = min(u, run);
+            run = __shfl(u, 63, 64);
+            if (j <= n) prev[j] = u + j;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        const int d = (n == 0) ? m : prev[n];
+        dist[b] = (n == 0) ? (m > 0 ? INFINITY : 0.f) : (float)d / (float)n;
+    }
+}
+
+// ------------------------------------------------------------------ Adam (TF form)
+__global__ void adam_tf_kernel(float* __restrict__ theta, const float* __restrict__ grad, float* __restrict__ m,
+                               float* __restrict__ v, size_t n, float lr_t, float b1, float b2, float eps, float gscale) {
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= n) {
+            const float4 g4 = *(const float4*)(grad + i);
+            float4 m4 = *(const float4*)(m + i), v4 = *(const float4*)(v + i), t4 = *(const float4*)(theta + i);
+            const float g[4] = {g4.x * gscale, g4.y * gscale, g4.z * gscale, g4.w * gscale};
+            float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, tt[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                mm[j] = b1 * mm[j] + (1.f - b1) * g[j];
+                vv[j] = b2 * vv[j] + (1.f - b2) * g[j] * g[j];
+                tt[j] = tt[j] - lr_t * mm[j] / (sqrtf(vv[j]) + eps);
+            }
+            *(float4*)(m + i) = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            *(float4*)(v + i) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            *(float4*)(theta + i) = make_float4(tt[0], tt[1], tt[2], tt[3]);
+        } else {
+            for (size_t j = i; j < n; ++j) {
+                const float g = grad[j] * gscale;
+                const float mj = b1 * m[j] + (1.f - b1) * g;
+                const float vj = b2 * v[j] + (1.f - b2) * g * g;
+                m[j] = mj; v[j] = vj;
+                theta[j] = theta[j] - lr_t * mj / (sqrtf(vj) + eps);
+            }
+        }
+    }
+}
+
+inline size_t ctc_lds_bytes(int T, int max_label) {
+    const size_t SMAX = 2 * (size_t)max_label + 1;
+    return (2 * (SMAX + 4) + (SMAX + 3) + (size_t)T) * sizeof(double) + 2 * (SMAX + 1) * sizeof(int) +
+           (size_t)T * SMAX * sizeof(float) + 16;
+}
+
+}  // namespace
+
+extern "C" int asr_softmax_log_fwd(const float* d, int B, int T, int V, float eps, float* logits_tm, void* stream) {
+    if (!d || !logits_tm || B < 1 || T < 1 || V < 1) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(softmax_log_fwd_kernel, dim3(asr_cdiv((long)B * T, 4)), dim3(256), 0, (hipStream_t)stream, d, B, T, V, eps, logits_tm);
+    ASR_CHECK_LAUNCH("softmax_log_fwd");
+    return ASR_OK;
+}
+
+extern "C" int asr_softmax_log_bwd(const float* logits_tm, const float* g_tm, int B, int T, int V, float eps,
+                                   float gscale, float* dd, void* stream) {
+    if (!logits_tm || !g_tm || !dd || B < 1 || T < 1 || V < 1) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(softmax_log_bwd_kernel, dim3(asr_cdiv((long)B * T, 4)), dim3(256), 0, (hipStream_t)stream, logits_tm, g_tm, B, T, V, eps, gscale, dd);
+    ASR_CHECK_LAUNCH("softmax_log_bwd");
+    return ASR_OK;
+}
+
+extern "C" size_t asr_ctc_workspace(int T, int B, int max_label) {
+    const size_t SMAX = 2 * (size_t)max_label + 1;
+    return ((size_t)T * B + (size_t)B * T * SMAX) * sizeof(double) + 64;
+}
+
+extern "C" int asr_ctc_loss(const float* logits_tm, int T, int B, int V, const int32_t* labels, int max_label,
+                            const int32_t* label_len, const int32_t* seq_len, int blank,
+                            float* loss, float* grad, int32_t* status, void* workspace, void* stream) {
+    if (!logits_tm || !labels || !label_len || !seq_len || !loss || !grad || !status || !workspace) return ASR_ERR_BAD_ARG;
+    if (T < 1 || B < 1 || V < 1 || blank < 0 || blank >= V) return ASR_ERR_BAD_ARG;
+    if (max_label < 1 || max_label > 127) return ASR_ERR_UNSUPPORTED;
+    const size_t lds = ctc_lds_bytes(T, max_label);
+    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    double* lse = (double*)workspace;
+    double* alpha_ws = lse + (size_t)T * B;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)ctc_lattice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ctc_check_kernel, dim3(asr_cdiv(B, 64)), dim3(64), 0, st, labels, max_label, label_len, seq_len, T, B, status);
+    hipLaunchKernelGGL(ctc_rows_kernel, dim3(asr_cdiv((long)T * B, 4)), dim3(256), 0, st, logits_tm, T, B, V, seq_len, (const int32_t*)status, lse, grad);
+    hipLaunchKernelGGL(ctc_lattice_kernel, dim3(B), dim3(256), lds, st, logits_tm, T, B, V, labels, max_label, label_len, seq_len, blank, (const int32_t*)status, (const double*)lse, alpha_ws, loss, grad);
+    ASR_CHECK_LAUNCH("ctc_loss");
+    return ASR_OK;
+}
+
+extern "C" int asr_ctc_greedy(const float* logits_tm, int T, int B, int V, const int32_t* seq_len, int blank,
+                              int32_t* out_ids, int32_t* out_len, float* neg_sum_logits, void* stream) {
+    if (!logits_tm || !seq_len || !out_ids || !out_len || !neg_sum_logits) return ASR_ERR_BAD_ARG;
+    if (T < 1 || T > 8192 || B < 1 || V < 1) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(ctc_greedy_kernel, dim3(B), dim3(256), (size_t)T * 8, (hipStream_t)stream, logits_tm, T, B, V, seq_len, blank, out_ids, out_len, neg_sum_logits);
+    ASR_CHECK_LAUNCH("ctc_greedy");
+    return ASR_OK;
+}
+
+extern "C" int asr_edit_distance(const int32_t* hyp, int hyp_pitch, const int32_t* hyp_len,
+                                 const int32_t* truth, int truth_pitch, const int32_t* truth_len,
+                                 int B, float* dist, void* stream) {
+    if (!hyp || !hyp_len || !truth || !truth_len || !dist || B < 1 || truth_pitch < 1 || truth_pitch > 4096) return ASR_ERR_BAD_ARG;
+    const size_t lds = (size_t)(2 * truth_pitch + 2) * sizeof(int);
+    hipLaunchKernelGGL(edit_distance_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, hyp, hyp_pitch, hyp_len, truth, truth_pitch, truth_len, B, dist);
+    ASR_CHECK_LAUNCH("edit_distance");
+    return ASR_OK;
+}
+
+extern "C" int asr_adam_tf(float* theta, const float* grad, float* m, float* v, size_t n,
+                           float lr_t, float beta1, float beta2, float eps, float gscale, void* stream) {
+    if (!theta || !grad || !m || !v) return ASR_ERR_BAD_ARG;
+    if (n == 0) return ASR_OK;
+    long blocks = (long)((n + 3) / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_tf_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, theta, grad, m, v, n, lr_t, beta1, beta2, eps, gscale);
+    ASR_CHECK_LAUNCH("adam_tf");
+    return ASR_OK;
+}

@@ -1,0 +1,253 @@
+// Weight gradient of the tap-GEMM family on the fp32 MFMA pipe:
+//
+//   dW[tap][k][n] = sum_m A[m + off(tap)][k] * dZ[m][n]
+//
+// The contraction runs over pixels (hundreds of thousands), the output is tiny
+// (ntaps*K*N), so the grid splits the pixel axis into chunks; every block keeps ALL
+// nine tap accumulators of its (32-channel k-tile x n-tile) in registers (9 x 16 fp32
+// per lane) and walks its chunk in LDS-staged runs of PS pixels: one staged run of A
+// (with its halo) feeds all nine taps, one staged run of dZ feeds all k-tiles.
+// Chunk partials go to a slab and are summed by a second, fixed-order pass, so the
+// result is bitwise reproducible (no float atomics).
+#include "asr_common.h"
+
+namespace {
+
+struct WgradArgs {
+    const float* A; const float* Z; float* out;   // out: dW (nchunks == 1) or the partial slab
+    int M, K, N, lda, ldz;
+    int WP, halo;
+    long rmin, rmax;
+    int pch;                                      // pixels per chunk (multiple of PS)
+    long slab;                                    // floats per chunk partial = ntaps*K*N
+};
+
+template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS>
+__global__ __launch_bounds__(256, 2) void tap_wgrad_kernel(WgradArgs g) {
+    constexpr int WAVES_P = 4 / WAVES_N;
+    constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32;
+    constexpr int NACC = NTAPS * TKW * TNW;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int halo = g.halo;
+    const int arows = PS + 2 * halo;
+    float* As = smem;                 // [arows][KT]
+    float* Zs = As + arows * KT;      // [PS][NT]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = tid >> 6, wn = wave % WAVES_N, wp = wave / WAVES_N;
+    const int chunk = blockIdx.x;
+    const int k0 = blockIdx.y * KT, n0 = blockIdx.z * NT;
+    const long cbeg = (long)chunk * g.pch;
+    const long cend = (cbeg + g.pch < g.M) ? cbeg + g.pch : g.M;
+
+    floatx16 acc[NTAPS][TKW][TNW];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int a = 0; a < TKW; ++a)
+#pragma unroll
+            for (int b = 0; b < TNW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
+
+    for (long ps0 = cbeg; ps0 < cend; ps0 += PS) {
+        __syncthreads();
+        for (int f = tid; f < arows * (KT / 4); f += 256) {
+            const int row = f / (KT / 4), c4 = f - row * (KT / 4);
+            const long grow = ps0 - halo + row;
+            const int kk = k0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grow >= g.rmin && grow < g.rmax && kk < g.K)
+                v = *(const float4*)(g.A + grow * g.lda + kk);
+            *(float4*)(As + row * KT + c4 * 4) = v;
+        }
+        for (int f = tid; f < PS * (NT / 4); f += 256) {
+            const int row = f / (NT / 4), n4 = f - row * (NT / 4);
+            const long grow = ps0 + row;
+            const int nn = n0 + n4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grow < cend && nn < g.N)
+                v = *(const float4*)(g.Z + grow * g.ldz + nn);
+            *(float4*)(Zs + row * NT + n4 * 4) = v;
+        }
+        __syncthreads();
+        for (int r = 2 * wp; r < PS; r += 2 * WAVES_P) {
+            float bz[TNW];
+#pragma unroll
+            for (int b = 0; b < TNW; ++b) bz[b] = Zs[(r + lh) * NT + (wn * TNW + b) * 32 + li];
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                const int off = (NTAPS == 9) ? ((t / 3) - 1) * g.WP + (t % 3) - 1 : 0;
+                const float* ar = As + (r + lh + halo + off) * KT + li;
+#pragma unroll
+                for (int a = 0; a < TKW; ++a) {
+                    const float av = ar[a * 32];
+#pragma unroll
+                    for (int b = 0; b < TNW; ++b)
+                        acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bz[b], acc[t][a][b], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // fold the pixel-split waves of this block through LDS, one tap at a time (keeps the
+    // transfer at 16 registers per lane) and in a fixed order wp = 1, 2, ...
+    if (WAVES_P > 1) {
+        float* red = smem;   // [WAVES_P-1][WAVES_N][TKW*TNW*16][64]
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            __syncthreads();
+            if (wp > 0) {
+                float* dst = red + (((wp - 1) * WAVES_N + wn) * (TKW * TNW * 16)) * 64 + lane;
+#pragma unroll
+                for (int a = 0; a < TKW; ++a)
+#pragma unroll
+                    for (int b = 0; b < TNW; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            dst[((a * TNW + b) * 16 + r) * 64] = acc[t][a][b][r];
+            }
+            __syncthreads();
+            if (wp == 0) {
+                for (int src = 1; src < WAVES_P; ++src) {
+                    const float* sp = red + (((src - 1) * WAVES_N + wn) * (TKW * TNW * 16)) * 64 + lane;
+#pragma unroll
+                    for (int a = 0; a < TKW; ++a)
+#pragma unroll
+                        for (int b = 0; b < TNW; ++b)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                acc[t][a][b][r] += sp[((a * TNW + b) * 16 + r) * 64];
+                }
+            }
+        }
+    }
+    if (wp != 0) return;
+
+    float* out = g.out + (long)chunk * g.slab;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int a = 0; a < TKW; ++a)
+#pragma unroll
+            for (int b = 0; b < TNW; ++b) {
+                const int n = n0 + (wn * TNW + b) * 32 + li;
+                if (n >= g.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = k0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (k < g.K) out[((long)t * g.K + k) * g.N + n] = acc[t][a][b][r];
+                }
+            }
+}
+
+__global__ void sum_chunks_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                  long n, int nchunks) {
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        float4 s = *(const float4*)(part + i);
+        for (int c = 1; c < nchunks; ++c) {
+            const float4 v = *(const float4*)(part + (long)c * n + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *(float4*)(out + i) = s;
+    } else {
+        for (long j = i; j < n; ++j) {
+            float s = part[j];
+            for (int c = 1; c < nchunks; ++c) s += part[(long)c * n + j];
+            out[j] = s;
+        }
+    }
+}
+
+struct Plan { int ktile, ntile, ps, nchunks, pch; };
+
+Plan make_plan(const asr_gemm_desc* d) {
+    Plan p;
+    if (d->ntaps == 9) {
+        p.ktile = 32;
+        p.ntile = d->N > 64 ? 128 : (d->N > 32 ? 64 : 32);
+        p.ps = d->N > 32 ? 64 : 128;
+    } else {
+        p.ktile = 128; p.ntile = 128; p.ps = 64;
+    }
+    const long tiles = (long)asr_cdiv(d->K, p.ktile) * asr_cdiv(d->N, p.ntile);
+    long want = 768 / tiles;
+    if (want < 1) want = 1;
+    const long slab_bytes = (long)d->ntaps * d->K * d->N * 4;
+    const long cap = (64L << 20) / slab_bytes;
+    if (want > cap) want = cap < 1 ? 1 : cap;
+    const long maxc = asr_cdiv(d->M, 4 * p.ps);
+    if (want > maxc) want = maxc;
+    if (want < 1) want = 1;
+    long pch = ((long)asr_cdiv(d->M, want) + p.ps - 1) / p.ps * p.ps;
+    p.pch = (int)pch;
+    p.nchunks = asr_cdiv(d->M, pch);
+    return p;
+}
+
+template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS>
+int launch_wgrad(const WgradArgs& a, const Plan& p, int K, int N, hipStream_t st) {
+    auto kern = tap_wgrad_kernel<NTAPS, TKW, WAVES_N, TNW, PS>;
+    constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32, NACC = NTAPS * TKW * TNW;
+    size_t lds = ((size_t)(PS + 2 * a.halo) * KT + (size_t)PS * NT) * sizeof(float);
+    const size_t red = (size_t)(4 / WAVES_N - 1) * WAVES_N * TKW * TNW * 16 * 64 * sizeof(float);
+    if (red > lds) lds = red;
+    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nchunks, asr_cdiv(K, KT), asr_cdiv(N, NT)), dim3(256), lds, st, a);
+    ASR_CHECK_LAUNCH("tap_wgrad");
+    return ASR_OK;
+}
+
+}  // namespace
+
+extern "C" size_t asr_tap_wgrad_workspace(const asr_gemm_desc* d) {
+    if (!d) return 0;
+    const Plan p = make_plan(d);
+    if (p.nchunks <= 1) return 16;
+    return (size_t)p.nchunks * d->ntaps * d->K * d->N * sizeof(float);
+}
+
+extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz,
+                             float* dW, float* partials, void* stream) {
+    if (!d || !A || !dZ || !dW) return ASR_ERR_BAD_ARG;
+    if (d->ntaps != 1 && d->ntaps != 9) return ASR_ERR_BAD_ARG;
+    if ((d->K & 3) || (d->N & 3) || (d->lda & 3) || (ldz & 3)) return ASR_ERR_BAD_ARG;
+    if (d->ntaps == 9 && d->H <= 0) return ASR_ERR_BAD_ARG;
+    const Plan p = make_plan(d);
+    if (p.nchunks > 1 && !partials) return ASR_ERR_BAD_ARG;
+    WgradArgs a;
+    a.A = A; a.Z = dZ; a.out = (p.nchunks > 1) ? partials : dW;
+    a.M = d->M; a.K = d->K; a.N = d->N; a.lda = d->lda; a.ldz = ldz;
+    a.WP = d->W + 2;
+    a.halo = (d->ntaps == 9) ? a.WP + 1 : 0;
+    a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
+    a.pch = p.pch;
+    a.slab = (long)d->ntaps * d->K * d->N;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (d->ntaps == 9) {
+        if (d->N > 64) rc = launch_wgrad<9, 1, 4, 1, 64>(a, p, d->K, d->N, st);
+        else if (d->N > 32) rc = launch_wgrad<9, 1, 2, 1, 64>(a, p, d->K, d->N, st);
+        else rc = launch_wgrad<9, 1, 1, 1, 128>(a, p, d->K, d->N, st);
+    } else {
+        rc = launch_wgrad<1, 4, 4, 1, 64>(a, p, d->K, d->N, st);
+    }
+    if (rc != ASR_OK) return rc;
+    if (p.nchunks > 1) {
+        const long n = a.slab;
+        const int threads = 256;
+        const int blocks = asr_cdiv(asr_cdiv(n, 4), threads);
+        hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks), dim3(threads), 0, st, partials, dW, n, p.nchunks);
+        ASR_CHECK_LAUNCH("sum_chunks");
+    }
+    return ASR_OK;
+}

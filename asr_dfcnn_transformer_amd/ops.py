@@ -1,0 +1,184 @@
+"""Thin Python layer over the C ABI: torch tensors are used as device allocations only
+(``data_ptr()`` + the current HIP stream); every computation below runs in libasrhip.so."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import GemmDesc, check
+
+
+def _ptr(t):
+    return C.c_void_p(0) if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Plane:
+    """A padded NHWC plane [B][H+2][W+2][C] with zero border and (W+3)-pixel zero guards
+    on both ends (include/asr_hip.h).  Kernels only write the interior."""
+
+    def __init__(self, B, H, W, C, device='cuda'):
+        self.B, self.H, self.W, self.C = B, H, W, C
+        self.HP, self.WP = H + 2, W + 2
+        self.NP = B * self.HP * self.WP
+        self.G = W + 3
+        self.buf = torch.zeros((self.NP + 2 * self.G) * C, dtype=torch.float32, device=device)
+        self.body = self.buf[self.G * C:(self.G + self.NP) * C]      # pixel 0 .. NP-1
+
+    @property
+    def ptr(self):
+        return C.c_void_p(self.body.data_ptr())
+
+    def view(self):
+        return self.body.view(self.B, self.HP, self.WP, self.C)
+
+    def interior(self):
+        return self.view()[:, 1:-1, 1:-1, :]
+
+    def set_interior(self, x):
+        self.interior().copy_(x)
+
+    def zero_(self):
+        self.buf.zero_()
+
+
+def gemm_desc(M, K, N, lda, ldw, ldo_a=0, ldo_y=0, ntaps=1, B=0, H=0, W=0, wmode=0, relu=0,
+              accumulate=0, y_unpadded=0):
+    return GemmDesc(M, K, N, lda, ldw, ldo_a, ldo_y, ntaps, B, H, W, wmode, relu, accumulate, y_unpadded)
+
+
+def tap_gemm(desc, A, W, bias=None, scale=None, shift=None, out_a=None, out_y=None):
+    lib = _lib.load()
+    pa = A.ptr if isinstance(A, Plane) else _ptr(A)
+    po_a = out_a.ptr if isinstance(out_a, Plane) else _ptr(out_a)
+    po_y = out_y.ptr if isinstance(out_y, Plane) else _ptr(out_y)
+    check(lib.asr_tap_gemm(C.byref(desc), pa, _ptr(W), _ptr(bias), _ptr(scale), _ptr(shift), po_a, po_y, _stream()),
+          'asr_tap_gemm')
+
+
+def tap_wgrad_workspace(desc):
+    return _lib.load().asr_tap_wgrad_workspace(C.byref(desc))
+
+
+def tap_wgrad(desc, A, dZ, ldz, dW, partials):
+    lib = _lib.load()
+    pa = A.ptr if isinstance(A, Plane) else _ptr(A)
+    pz = dZ.ptr if isinstance(dZ, Plane) else _ptr(dZ)
+    check(lib.asr_tap_wgrad(C.byref(desc), pa, pz, ldz, _ptr(dW), _ptr(partials), _stream()), 'asr_tap_wgrad')
+
+
+def cell1_fwd(x, w, bias, sc, sh, pool, y):
+    B, T, F = x.shape[0], x.shape[1], x.shape[2]
+    check(_lib.load().asr_cell1_fwd(_ptr(x), B, T, F, y.C, _ptr(w), _ptr(bias), _ptr(sc), _ptr(sh), pool, y.ptr,
+                                    _stream()), 'asr_cell1_fwd')
+
+
+def cell1_bwd_workspace(B, T, F, Cc):
+    return _lib.load().asr_cell1_bwd_workspace(B, T, F, Cc)
+
+
+def cell1_bwd(x, w, bias, sc, sh, pool, dy, dw, db, dscale, dshift, partials):
+    B, T, F = x.shape[0], x.shape[1], x.shape[2]
+    check(_lib.load().asr_cell1_bwd(_ptr(x), B, T, F, dy.C, _ptr(w), _ptr(bias), _ptr(sc), _ptr(sh), pool, dy.ptr,
+                                    _ptr(dw), _ptr(db), _ptr(dscale), _ptr(dshift), _ptr(partials), _stream()),
+          'asr_cell1_bwd')
+
+
+def pool_fwd(a, sc, sh, pool, y):
+    check(_lib.load().asr_pool_fwd(a.ptr, a.B, a.H, a.W, a.C, _ptr(sc), _ptr(sh), pool, y.ptr, _stream()),
+          'asr_pool_fwd')
+
+
+def cell_bwd_pre_workspace(B, H, W, Cc):
+    return _lib.load().asr_cell_bwd_pre_workspace(B, H, W, Cc)
+
+
+def cell_bwd_pre(dy, dy_layout, a, sc, sh, pool, dz, dscale, dshift, dbias, partials):
+    pdy = dy.ptr if isinstance(dy, Plane) else _ptr(dy)
+    check(_lib.load().asr_cell_bwd_pre(pdy, dy_layout, a.ptr, a.B, a.H, a.W, a.C, _ptr(sc), _ptr(sh), pool, dz.ptr,
+                                       _ptr(dscale), _ptr(dshift), _ptr(dbias), _ptr(partials), _stream()),
+          'asr_cell_bwd_pre')
+
+
+def se_state_floats(B, Cc, hid):
+    return _lib.load().asr_se_state_floats(B, Cc, hid)
+
+
+def se_fwd_workspace(B, H, W, Cc):
+    return _lib.load().asr_se_fwd_workspace(B, H, W, Cc)
+
+
+def se_bwd_workspace(B, H, W, Cc, hid):
+    return _lib.load().asr_se_bwd_workspace(B, H, W, Cc, hid)
+
+
+def se_fwd(main_in, x, hid, sc, sh, w1, b1, w2, b2, state, partials, out):
+    check(_lib.load().asr_se_fwd(main_in.ptr, x.ptr, x.B, x.H, x.W, x.C, hid, _ptr(sc), _ptr(sh), _ptr(w1), _ptr(b1),
+                                 _ptr(w2), _ptr(b2), _ptr(state), _ptr(partials), out.ptr, _stream()), 'asr_se_fwd')
+
+
+def se_bwd(dout, x, hid, sc, sh, w1, w2, state, add_dout, dx, dscale, dshift, dw1, db1, dw2, db2, partials):
+    check(_lib.load().asr_se_bwd(dout.ptr, x.ptr, x.B, x.H, x.W, x.C, hid, _ptr(sc), _ptr(sh), _ptr(w1), _ptr(w2),
+                                 _ptr(state), add_dout, dx.ptr, _ptr(dscale), _ptr(dshift), _ptr(dw1), _ptr(db1),
+                                 _ptr(dw2), _ptr(db2), _ptr(partials), _stream()), 'asr_se_bwd')
+
+
+def axpy(dst, src, alpha=1.0, accumulate=False):
+    check(_lib.load().asr_axpy(_ptr(dst), _ptr(src), dst.numel(), alpha, int(accumulate), _stream()), 'asr_axpy')
+
+
+def softmax_log_fwd(d, B, T, V, eps, logits_tm):
+    check(_lib.load().asr_softmax_log_fwd(_ptr(d), B, T, V, eps, _ptr(logits_tm), _stream()), 'asr_softmax_log_fwd')
+
+
+def softmax_log_bwd(logits_tm, g_tm, B, T, V, eps, gscale, dd):
+    check(_lib.load().asr_softmax_log_bwd(_ptr(logits_tm), _ptr(g_tm), B, T, V, eps, gscale, _ptr(dd), _stream()),
+          'asr_softmax_log_bwd')
+
+
+def relu_bwd(dy, h, dz):
+    check(_lib.load().asr_relu_bwd(_ptr(dy), _ptr(h), dy.numel(), _ptr(dz), _stream()), 'asr_relu_bwd')
+
+
+def colsum_workspace(rows, cols):
+    return _lib.load().asr_colsum_workspace(rows, cols)
+
+
+def colsum(x, rows, cols, ldx, out, partials):
+    check(_lib.load().asr_colsum(_ptr(x), rows, cols, ldx, _ptr(out), _ptr(partials), _stream()), 'asr_colsum')
+
+
+def ctc_workspace(T, B, max_label):
+    return _lib.load().asr_ctc_workspace(T, B, max_label)
+
+
+def ctc_loss(logits_tm, T, B, V, labels, max_label, label_len, seq_len, blank, loss, grad, status, workspace):
+    check(_lib.load().asr_ctc_loss(_ptr(logits_tm), T, B, V, _ptr(labels), max_label, _ptr(label_len), _ptr(seq_len),
+                                   blank, _ptr(loss), _ptr(grad), _ptr(status), _ptr(workspace), _stream()),
+          'asr_ctc_loss')
+
+
+def ctc_greedy(logits_tm, T, B, V, seq_len, blank, out_ids, out_len, neg_sum):
+    check(_lib.load().asr_ctc_greedy(_ptr(logits_tm), T, B, V, _ptr(seq_len), blank, _ptr(out_ids), _ptr(out_len),
+                                     _ptr(neg_sum), _stream()), 'asr_ctc_greedy')
+
+
+def edit_distance(hyp, hyp_pitch, hyp_len, truth, truth_pitch, truth_len, B, dist):
+    check(_lib.load().asr_edit_distance(_ptr(hyp), hyp_pitch, _ptr(hyp_len), _ptr(truth), truth_pitch,
+                                        _ptr(truth_len), B, _ptr(dist), _stream()), 'asr_edit_distance')
+
+
+def adam_tf(theta, grad, m, v, lr_t, beta1, beta2, eps, gscale=1.0):
+    check(_lib.load().asr_adam_tf(_ptr(theta), _ptr(grad), _ptr(m), _ptr(v), theta.numel(), lr_t, beta1, beta2, eps,
+                                  gscale, _stream()), 'asr_adam_tf')
+
+
+def fbank(signal, nsamples, frame_len, frame_step, nfft, preemph, nfilt, fb_start, fb_count, fb_weight, fb_width,
+          twiddle, logfb, max_frames, out, t_pad, frames):
+    B, max_samples = signal.shape
+    check(_lib.load().asr_fbank(_ptr(signal), _ptr(nsamples), B, max_samples, frame_len, frame_step, nfft, preemph,
+                                nfilt, _ptr(fb_start), _ptr(fb_count), _ptr(fb_weight), fb_width, _ptr(twiddle),
+                                _ptr(logfb), max_frames, _ptr(out), t_pad, _ptr(frames), _stream()), 'asr_fbank')

@@ -1,0 +1,218 @@
+/*
+ * libasrhip -- C ABI of the MI355X (gfx950) kernels behind the DFCNN(+SE)+CTC /
+ * Transformer hot path of 786440445/ASR_DFCNN_Transformer.
+ *
+ * The reference has no FFI of its own: its hot path is the set of TensorFlow-1.x /
+ * Keras / python_speech_features calls listed in SURVEY.md section 2.2.  Each entry
+ * point below replaces one of those calls; the reference call site is cited as
+ * file:line under the reference checkout.  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is CALLER-OWNED DEVICE memory unless marked "host"; the library
+ *     never allocates, frees or synchronises;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*), asynchronously;
+ *   - return value: 0 = enqueued, negative asr_status on a bad descriptor;
+ *   - reductions run in a fixed order: repeated calls give bit-identical results;
+ *   - activations are fp32, NHWC.  A "padded plane" is the layout
+ *         float [B][H+2][W+2][C]   (zero border, interior at [h+1][w+1])
+ *     preceded and followed by at least (W+3) zero guard pixels; kernels only ever
+ *     write the interior, so borders/guards stay zero once the buffer was zeroed.
+ *     `x` arguments of padded planes point at pixel 0 (after the leading guard).
+ */
+#ifndef ASR_HIP_H
+#define ASR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ASR_OK = 0,
+    ASR_ERR_BAD_ARG = -1,      /* shape/stride/alignment the kernels do not support */
+    ASR_ERR_LAUNCH = -2,       /* hipLaunch reported an error                        */
+    ASR_ERR_UNSUPPORTED = -3
+} asr_status;
+
+int asr_version(void);
+/* Last HIP error string seen by the library on this thread (host pointer, static). */
+const char* asr_last_error(void);
+
+/* ------------------------------------------------------------------ K1 fbank
+ * Replaces python_speech_features.logfbank + sklearn.preprocessing.scale as called by
+ * compute_fbank_from_api (util/wav_util.py:22-31).  float64 arithmetic on device.
+ *   signal   [B][max_samples] f32, utterance b uses nsamples[b] samples
+ *   nsamples [B] i32 (device)
+ *   fb_start/fb_count [nfilt] i32, fb_weight [nfilt][fb_width] f64: the banded mel
+ *            filterbank over the nfft/2+1 power-spectrum bins: filter j covers bins
+ *            fb_start[j] .. fb_start[j]+fb_count[j]-1 (host code builds them)
+ *   twiddle  [nfft/2][2] f64: cos/sin(-2*pi*k/nfft)
+ *   logfb    [B][max_frames][nfilt] f64 workspace (log filterbank energies)
+ *   out      [B][t_pad][nfilt] f32: standardised features, rows >= frames(b) are zero
+ *   frames   [B] i32 out: number of frames of each utterance
+ */
+int asr_fbank(const float* signal, const int32_t* nsamples, int B, int max_samples,
+              int frame_len, int frame_step, int nfft, double preemph, int nfilt,
+              const int32_t* fb_start, const int32_t* fb_count, const double* fb_weight, int fb_width,
+              const double* twiddle, double* logfb, int max_frames,
+              float* out, int t_pad, int32_t* frames, void* stream);
+
+/* ------------------------------------------------------------------ K2/K6 tap-GEMM
+ * One kernel family serves conv3x3/conv1x1 forward, their data-gradient, and dense
+ * layers (tf.layers.conv2d / tf.layers.dense: lm_and_am/model/acoustic_model2.py:102-121):
+ *
+ *   acc[m][n] = sum_tap sum_k  A[m + off(tap)][k] * Wt(tap,k,n)
+ *   v = acc + bias[n];  if relu: v = max(v,0);          out_a[row_a(m)][n] = v
+ *   y = scale[n]*v + shift[n];  out_y[row_y(m)][n] (+)= y
+ *
+ * ntaps = 9: A is a padded plane [B][H+2][W+2][K] (m = padded pixel index,
+ *            off = dh*(W+2)+dw), rows at border positions are not written;
+ * ntaps = 1: A is a plain [M][K] matrix when H == 0 (dense), or a padded plane
+ *            (1x1 conv) when H > 0.
+ * wmode 0: Wt(tap,k,n) = W[(tap*K + k)*ldw + n]          (HWIO as stored by the model)
+ * wmode 1: Wt(tap,k,n) = W[((ntaps-1-tap)*N + n)*ldw + k] (data-gradient: transposed,
+ *          taps mirrored) -- no separate packed copy of the weights is needed.
+ * y_unpadded: out_y rows are [B][H][W] (feeds the dense head) instead of padded.
+ * Requirements: K % 4 == 0, N % 4 == 0, lda/ldw/ldo % 4 == 0, 16-byte aligned bases.
+ * Arithmetic: fp32 MFMA (v_mfma_f32_32x32x2_f32), i.e. exact fp32 FMA chains.
+ */
+typedef struct {
+    int M;            /* rows: padded pixel count B*(H+2)*(W+2), or matrix rows     */
+    int K, N;
+    int lda, ldw;     /* row pitches of A and W in floats                          */
+    int ldo_a, ldo_y; /* row pitches of out_a / out_y                              */
+    int ntaps;        /* 1 or 9                                                    */
+    int B, H, W;      /* geometry of the padded plane (H == 0: plain matrix)       */
+    int wmode;        /* 0 | 1                                                     */
+    int relu;         /* apply max(.,0) after the bias                             */
+    int accumulate;   /* out_y += instead of =                                     */
+    int y_unpadded;   /* out_y is [B*H*W][ldo_y]                                   */
+} asr_gemm_desc;
+
+int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float* W,
+                 const float* bias, const float* scale, const float* shift,
+                 float* out_a, float* out_y, void* stream);
+
+/* Weight gradient of the same family:
+ *   dW[tap][k][n] = sum_m A[m + off(tap)][k] * dZ[m][n]
+ * dZ must be zero at border pixels (it is, when produced by asr_cell_bwd_pre).
+ * `partials` is a workspace of asr_tap_wgrad_workspace() bytes; the reduction over
+ * pixel chunks is a second, fixed-order pass (deterministic).  */
+size_t asr_tap_wgrad_workspace(const asr_gemm_desc* d);
+int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz,
+                  float* dW, float* partials, void* stream);
+
+/* ------------------------------------------------------------------ first cell (Cin = 1)
+ * cnn_cell(32, wav_input, pool=True): conv3x3(1->C) + bias + ReLU + frozen BN + 2x2 pool
+ * fused into one HBM pass (acoustic_model2.py:39,126-133; acoustic_model.py:39).
+ *   x [B][T][F] f32 (unpadded, single channel);  w [9][C]; y padded plane [B][T/2][F/2][C]
+ *   pool: 1 = average (acoustic_model2/3), 2 = max (acoustic_model, cnn_ctc)
+ * Backward recomputes the pre-pool activations from x instead of storing 1.3 GB:
+ *   dy padded plane (grad wrt y) -> grads[4][..] = dw[9][C], db[C], dgamma[C], dbeta[C]
+ * (bn_scale = gamma/sqrt(moving_var+eps), bn_shift = beta - moving_mean*bn_scale;
+ *  dgamma is returned w.r.t. bn_scale, the host divides by sqrt(var+eps).)
+ */
+int asr_cell1_fwd(const float* x, int B, int T, int F, int C, const float* w, const float* bias,
+                  const float* bn_scale, const float* bn_shift, int pool, float* y, void* stream);
+size_t asr_cell1_bwd_workspace(int B, int T, int F, int C);
+int asr_cell1_bwd(const float* x, int B, int T, int F, int C, const float* w, const float* bias,
+                  const float* bn_scale, const float* bn_shift, int pool, const float* dy,
+                  float* dw, float* db, float* dscale, float* dshift, float* partials, void* stream);
+
+/* ------------------------------------------------------------------ K3/K4 cell epilogue / prologue
+ * pool + BN affine of a cell whose conv ran with asr_tap_gemm (out_a = post-ReLU):
+ *   y[b][h/2][w/2][c] = pool2x2( bn_scale[c]*a + bn_shift[c] )      (padded planes)
+ */
+int asr_pool_fwd(const float* a, int B, int H, int W, int C, const float* bn_scale,
+                 const float* bn_shift, int pool, float* y, void* stream);
+
+/* Backward prologue of a cell: from dL/d(cell output) to dZ (grad at the conv output,
+ * before bias/ReLU), plus the per-channel sums
+ *   dshift = sum dy, dscale = sum dy*a, dbias = sum dz       (fixed-order reduction)
+ * dy_layout: 0 = padded plane at the cell's own resolution, 1 = padded plane at the
+ * pooled resolution (pool != 0), 2 = unpadded [B][H][W][C] (from the dense head).
+ */
+size_t asr_cell_bwd_pre_workspace(int B, int H, int W, int C);
+int asr_cell_bwd_pre(const float* dy, int dy_layout, const float* a, int B, int H, int W, int C,
+                     const float* bn_scale, const float* bn_shift, int pool,
+                     float* dz, float* dscale, float* dshift, float* dbias,
+                     float* partials, void* stream);
+
+/* ------------------------------------------------------------------ K5 squeeze-excitation
+ * squeeze_excitation_layer + residual add (acoustic_model2.py:41,141-148):
+ *   xt = bn_scale*x + bn_shift; s = mean_hw(xt); e = sigmoid(W2 relu(W1 s + b1) + b2)
+ *   out = main + xt * e
+ * state (f32, caller-owned): s[B][C], r[B][hid], e[B][C]  (asr_se_state_floats)
+ */
+size_t asr_se_state_floats(int B, int C, int hid);
+size_t asr_se_fwd_workspace(int B, int H, int W, int C);          /* bytes of `partials` */
+int asr_se_fwd(const float* main_in, const float* x, int B, int H, int W, int C, int hid,
+               const float* bn_scale, const float* bn_shift, const float* w1, const float* b1,
+               const float* w2, const float* b2, float* state, float* partials, float* out,
+               void* stream);
+/* dout = dL/d(out).  dL/d(main) IS dout (identity branch), so it is not produced here: the
+ * caller lets later contributions accumulate into the dout buffer.  dx = dL/dx (=; plus dout
+ * when add_dout, for the acoustic_model3 wiring where main == x), parameter grads (=). */
+size_t asr_se_bwd_workspace(int B, int H, int W, int C, int hid);
+int asr_se_bwd(const float* dout, const float* x, int B, int H, int W, int C, int hid,
+               const float* bn_scale, const float* bn_shift, const float* w1, const float* w2,
+               const float* state, int add_dout, float* dx, float* dscale, float* dshift,
+               float* dw1, float* db1, float* dw2, float* db2, float* partials, void* stream);
+/* dst (+)= src over the interior of a padded plane (residual gradient fan-in). */
+int asr_axpy(float* dst, const float* src, size_t n, float alpha, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ K7 softmax / log head
+ * logits = log(transpose(softmax(d), [1,0,2]) + 1e-7)  (acoustic_model2.py:67-68)
+ *   d [B][T][V] -> logits_tm [T][B][V];  backward: g_tm [T][B][V] -> dd [B][T][V] * gscale
+ */
+int asr_softmax_log_fwd(const float* d, int B, int T, int V, float eps, float* logits_tm, void* stream);
+int asr_softmax_log_bwd(const float* logits_tm, const float* g_tm, int B, int T, int V, float eps,
+                        float gscale, float* dd, void* stream);
+/* dense + ReLU backward helper: dz = dy * (h > 0) where h is the post-ReLU output. */
+int asr_relu_bwd(const float* dy, const float* h, size_t n, float* dz, void* stream);
+/* column sums of a [rows][cols] matrix (bias gradients), fixed order. */
+size_t asr_colsum_workspace(int rows, int cols);
+int asr_colsum(const float* x, int rows, int cols, int ldx, float* out, float* partials, void* stream);
+
+/* ------------------------------------------------------------------ K8 CTC loss + gradient
+ * tf.nn.ctc_loss_v2(sparse_labels, logits, ..., blank_index=V-1) (acoustic_model2.py:79-80):
+ * logits_tm are unnormalised; the op applies its own log-softmax.
+ *   labels [B][max_label] i32 (already without zeros: see dense_to_sparse), label_len [B],
+ *   seq_len [B];  loss [B] f32;  grad [T][B][V] f32 (zero for t >= seq_len[b]);
+ *   status [B] i32: 0 ok, 1 = "not enough time for target transition sequence"
+ *   (loss = +inf, grad = 0 for that utterance -- TF raises InvalidArgumentError).
+ * workspace: asr_ctc_workspace() bytes.  alpha/beta recursion runs in float64.
+ */
+size_t asr_ctc_workspace(int T, int B, int max_label);
+int asr_ctc_loss(const float* logits_tm, int T, int B, int V, const int32_t* labels, int max_label,
+                 const int32_t* label_len, const int32_t* seq_len, int blank,
+                 float* loss, float* grad, int32_t* status, void* workspace, void* stream);
+
+/* ------------------------------------------------------------------ K9 greedy decode, K10 edit distance
+ * tf.nn.ctc_greedy_decoder(logits, seq_len) (acoustic_model2.py:69): argmax (lowest index
+ * on ties), merge repeats, drop blank = V-1.
+ *   out_ids [B][T] i32 (-1 padded), out_len [B], neg_sum_logits [B] f32
+ * tf.edit_distance(decoded, sparse_labels, normalize=True) (acoustic_model2.py:72):
+ *   dist [B] f32 = levenshtein / len(truth)  (inf if truth empty and hyp not).
+ */
+int asr_ctc_greedy(const float* logits_tm, int T, int B, int V, const int32_t* seq_len, int blank,
+                   int32_t* out_ids, int32_t* out_len, float* neg_sum_logits, void* stream);
+int asr_edit_distance(const int32_t* hyp, int hyp_pitch, const int32_t* hyp_len,
+                      const int32_t* truth, int truth_pitch, const int32_t* truth_len,
+                      int B, float* dist, void* stream);
+
+/* ------------------------------------------------------------------ K11 Adam (TF form)
+ * tf.train.AdamOptimizer (acoustic_model2.py:90): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+ * theta -= lr_t * m / (sqrt(v) + eps).  One launch over the flat parameter buffer.
+ * `gscale` multiplies the gradient first (1/world after a sum all-reduce).
+ */
+int asr_adam_tf(float* theta, const float* grad, float* m, float* v, size_t n,
+                float lr_t, float beta1, float beta2, float eps, float gscale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASR_HIP_H */
