@@ -1,0 +1,143 @@
+"""Batch assembly for the acoustic model: the reference's ``DataLoader`` surface
+(lm_and_am/data_loader.py:19-41, 85-162, 246-280) on top of device fbank extraction.
+
+Vocabulary loading reproduces the reference's pandas calls, so sizes match SURVEY Q10
+(mixdict.txt -> 1536 incl. '_' blank, hanzi.txt -> 6345 incl. <pad>).  Audio decoding from
+disk (soundfile) is out of scope; utterances arrive as float arrays in [-1, 1) -- from a
+user-supplied ``read_audio`` callable or from the seeded synthetic source."""
+import math
+import os
+
+import numpy as np
+
+from .const import Const
+
+
+def load_acoustic_vocab(pinyin_dict):
+    """data_loader.py:85-92: first TSV column + '_' (the CTC blank, last id)."""
+    import pandas as pd
+    text = pd.read_table(pinyin_dict, header=None)
+    symbols = text.iloc[:, 0].tolist()
+    symbols.append('_')
+    return len(symbols), {s: i for i, s in enumerate(symbols)}, {i: s for i, s in enumerate(symbols)}
+
+
+def load_language_vocab(hanzi_dict):
+    """data_loader.py:95-103: '<pad>' + the characters of hanzi.txt."""
+    import pandas as pd
+    data = pd.read_csv(hanzi_dict, header=None)
+    words = [Const.PAD_FLAG] + data.T.values.tolist()[0]
+    return len(words), {w: i for i, w in enumerate(words)}, {i: w for i, w in enumerate(words)}
+
+
+def ctc_input_length(num_frames):
+    """data_loader.py:132: min(200, T//8 + 1)."""
+    return min(200, int(math.ceil(num_frames // 8 + 1)))
+
+
+class SyntheticSource:
+    """Seeded stand-in for DataUtil (util/data_util.py): 10 s / 16 kHz Gaussian 'audio' and
+    random pinyin ids, as BASELINE.md section 3 prescribes."""
+
+    def __init__(self, n_utts, seconds=10.0, sample_rate=16000, label_len=32, vocab=1536, seed=1234, shuffle=False):
+        self.n, self.ns, self.sr, self.L, self.V, self.seed = n_utts, int(seconds * sample_rate), sample_rate, label_len, vocab, seed
+        self.shuffle = shuffle
+        self.path_lst = ['synthetic_%06d' % i for i in range(n_utts)]
+        rng = np.random.default_rng(seed)
+        self.labels = rng.integers(1, vocab - 1, size=(n_utts, label_len))       # never 0 (Q6), never blank
+        self.pny_lst = [' '.join(str(v) for v in row) for row in self.labels]
+        self.han_lst = ['' for _ in range(n_utts)]
+
+    def read_audio(self, path):
+        i = int(path.rsplit('_', 1)[1])
+        rng = np.random.default_rng(self.seed + i)
+        return (0.1 * rng.standard_normal(self.ns)).astype(np.float32), self.sr
+
+
+class DataLoader:
+    def __init__(self, data_util, data_args, train_args, read_audio=None, device='cuda'):
+        self.am_batch_size = train_args.am_batch_size
+        self.lm_batch_size = train_args.lm_batch_size
+        self.feature_dim = train_args.feature_dim
+        self.feature_max_length = train_args.feature_max_length
+        root = Const.DictFolder
+        pd_path = data_args.pinyin_dict if os.path.isabs(data_args.pinyin_dict) else os.path.join(root, data_args.pinyin_dict)
+        hz_path = data_args.hanzi_dict if os.path.isabs(data_args.hanzi_dict) else os.path.join(root, data_args.hanzi_dict)
+        self.acoustic_vocab_size, self.pinyin2index, self.index2pinyin = load_acoustic_vocab(pd_path)
+        self.language_vocab_size, self.word2index, self.index2word = load_language_vocab(hz_path)
+        self.data = data_util
+        self.path_lst, self.pny_lst, self.han_lst = data_util.path_lst, data_util.pny_lst, data_util.han_lst
+        self.shuffle = data_util.shuffle
+        self.indexes = list(range(len(self.path_lst)))
+        self.read_audio = read_audio or data_util.read_audio
+        self.device = device
+        self._fbank = None
+
+    def pny2id(self, line):
+        try:
+            if isinstance(self.data, SyntheticSource):
+                return [int(t) for t in line.strip().split(' ')]
+            return [self.pinyin2index[p] for p in line.strip().split(' ')]
+        except Exception:
+            raise ValueError
+
+    def han2id(self, line):
+        try:
+            flags = {Const.PAD_FLAG: Const.PAD, Const.SOS_FLAG: Const.SOS, Const.EOS_FLAG: Const.EOS}
+            return [flags[h] if h in flags else self.word2index[h] for h in line.strip()]
+        except Exception:
+            raise ValueError
+
+    def __len__(self):
+        return len(self.path_lst) // self.am_batch_size
+
+    def data_generation(self, batch_datas, py_label_datas, han_label_datas):
+        """data_loader.py:105-162.  Returns (wav [B',1600,200,1] float32 CUDA tensor, input_length,
+        py labels [B',64], label_length, han labels [B',64], word_length); rows failing the
+        reference's checks (T > 1600, L > 64, L >= input_length) are dropped."""
+        import torch
+        from .wav_util import FbankExtractor, num_frames
+        if self._fbank is None:
+            self._fbank = FbankExtractor(nfilt=self.feature_dim, device=self.device)
+        keep, sigs, in_len, py, han = [], [], [], [], []
+        for i, path in enumerate(batch_datas):
+            try:
+                signal, sr = self.read_audio(path)
+                nf = num_frames(len(signal), self._fbank.frame_len, self._fbank.frame_step)
+                data_length = ctc_input_length(nf)
+                ids = self.pny2id(py_label_datas[i])
+                hz = self.han2id(han_label_datas[i])
+                if nf > self.feature_max_length or len(ids) > 64 or len(ids) >= data_length:
+                    raise ValueError
+                keep.append(i); sigs.append(np.asarray(signal, dtype=np.float32))
+                in_len.append(data_length); py.append(ids); han.append(hz)
+            except ValueError:
+                continue
+        n = len(keep)
+        batch_label = np.zeros((n, 64), dtype=np.int32)
+        batch_han = np.zeros((n, 64), dtype=np.int32)
+        for r in range(n):
+            batch_label[r, :len(py[r])] = py[r]
+            batch_han[r, :min(64, len(han[r]))] = han[r][:64]
+        if n == 0:
+            return None
+        mx = max(len(s) for s in sigs)
+        host = np.zeros((n, mx), dtype=np.float32)
+        for r, s in enumerate(sigs):
+            host[r, :len(s)] = s
+        sig = torch.from_numpy(host).to(self.device)
+        ns = torch.tensor([len(s) for s in sigs], dtype=torch.int32, device=self.device)
+        feat, _ = self._fbank.batch(sig, ns, self.feature_max_length)
+        return (feat.unsqueeze(-1), np.array(in_len), batch_label, np.array([len(p) for p in py]),
+                batch_han, np.array([len(p) for p in py]))
+
+    def __getitem__(self, index):
+        idx = self.indexes[index * self.am_batch_size:(index + 1) * self.am_batch_size]
+        return self.data_generation([self.path_lst[k] for k in idx], [self.pny_lst[k] for k in idx],
+                                    [self.han_lst[k] for k in idx])
+
+    def am_generator(self):
+        for i in range(len(self)):
+            item = self[i]
+            if item is not None:
+                yield item

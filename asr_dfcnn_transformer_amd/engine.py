@@ -1,0 +1,498 @@
+"""Host-side engine of the DFCNN(+SE)+CTC acoustic model: owns the flat parameter /
+gradient / Adam buffers and the activation planes, and enqueues the libasrhip kernels of
+one forward / backward / update on the current HIP stream.  No arithmetic happens here.
+
+Graphs follow the reference model files:
+  'm2'  lm_and_am/model/acoustic_model2.py:37-74   SE-DFCNN, "maxpool" = average pool
+  'm1'  lm_and_am/model/acoustic_model.py:37-62    plain DFCNN, max pool, NiN cell, 6400->128->V head
+  'm3'  lm_and_am/model/acoustic_model3.py:37-67   SE applied to the pooled cell itself, no BN in SE
+Every cell is conv -> +bias -> ReLU -> frozen-affine BN -> [pool].
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .ops import Plane
+
+BN_EPS = 1e-3                      # tf.layers.batch_normalization default
+RS = 1.0 / math.sqrt(1.0 + BN_EPS)  # moving_var = 1, never updated in the reference (Q1)
+K_EPSILON = 1e-7                   # keras.backend.epsilon()
+MAX_LABEL = 64                     # lm_and_am/data_loader.py:109
+
+
+def graph(model, vocab, widths=None, feat=200):
+    """Op list of a reference model.
+      ('cell', src, dst, cin, cout, ksize, pool)    pool in (None, 'avg', 'max')
+      ('se',   main, branch, dst, C, hidden, use_bn)   dst = main + SE(branch)
+      ('dense', src, dst, cin, cout, act)
+    """
+    if model == 'm2':
+        c1, c2, c3, c6 = widths or (32, 64, 128, 256)
+        g = [('cell', 'x', 'h1', 1, c1, 3, 'avg'), ('cell', 'h1', 'h1_1', c1, c1, 3, None),
+             ('se', 'h1', 'h1_1', 'h1s', c1, int(c1 / 1), True),
+             ('cell', 'h1s', 'h2', c1, c2, 3, 'avg'), ('cell', 'h2', 'h2_1', c2, c2, 3, None),
+             ('se', 'h2', 'h2_1', 'h2s', c2, int(c2 / 2), True),
+             ('cell', 'h2s', 'h3', c2, c3, 3, 'avg'), ('cell', 'h3', 'h3_1', c3, c3, 3, None),
+             ('se', 'h3', 'h3_1', 'h3s', c3, int(c3 / 2), True)]
+        prev = 'h3s'
+        for i in (4, 5):
+            g += [('cell', prev, 'h%d' % i, c3, c3, 3, None), ('cell', 'h%d' % i, 'h%d_1' % i, c3, c3, 3, None),
+                  ('se', 'h%d' % i, 'h%d_1' % i, 'h%ds' % i, c3, int(c3 / 2), True)]
+            prev = 'h%ds' % i
+        g += [('cell', prev, 'h6', c3, c6, 3, None), ('dense', 'h6', 'd', (feat // 8) * c6, vocab, 'softmax')]
+    elif model == 'm1':
+        c1, c2, c3, c5, nin, hid = widths or (32, 64, 128, 256, 32, 128)
+        g = [('cell', 'x', 'h1', 1, c1, 3, 'max'), ('cell', 'h1', 'h2', c1, c2, 3, 'max'),
+             ('cell', 'h2', 'h3', c2, c3, 3, 'max'), ('cell', 'h3', 'h4', c3, c3, 3, None),
+             ('cell', 'h4', 'h5a', c3, c5, 3, None), ('cell', 'h5a', 'h5n', c5, nin, 1, None),
+             ('cell', 'h5n', 'h5', nin, c5, 3, None),
+             ('dense', 'h5', 'h7', (feat // 8) * c5, hid, 'relu'), ('dense', 'h7', 'd', hid, vocab, 'softmax')]
+    elif model == 'm3':
+        c1, c2, c3, c6 = widths or (32, 64, 128, 256)
+        g = [('cell', 'x', 'h1', 1, c1, 3, 'avg'), ('se', 'h1', 'h1', 'h1s', c1, int(c1 / 1), False),
+             ('cell', 'h1s', 'h1b', c1, c1, 3, None),
+             ('cell', 'h1b', 'h2', c1, c2, 3, 'avg'), ('se', 'h2', 'h2', 'h2s', c2, int(c2 / 2), False),
+             ('cell', 'h2s', 'h2b', c2, c2, 3, None),
+             ('cell', 'h2b', 'h3', c2, c3, 3, 'avg'), ('se', 'h3', 'h3', 'h3s', c3, int(c3 / 2), False),
+             ('cell', 'h3s', 'h3b', c3, c3, 3, None),
+             ('cell', 'h3b', 'h6a', c3, c3, 3, None), ('cell', 'h6a', 'h6', c3, c6, 3, None),
+             ('dense', 'h6', 'd', (feat // 8) * c6, vocab, 'softmax')]
+    else:
+        raise ValueError('unknown model %r' % (model,))
+    return g
+
+
+def fwd_flops_per_utt(g, T, F):
+    """2*MACs of every conv/dense layer for one utterance (SURVEY.md 8d convention)."""
+    res = {'x': (T, F)}
+    total, first = 0.0, 0.0
+    for op in g:
+        if op[0] == 'cell':
+            _, src, dst, cin, cout, k, pool = op
+            H, W = res[src]
+            f = 2.0 * H * W * k * k * cin * cout
+            total += f
+            if src == 'x':
+                first = f
+            res[dst] = (H // 2, W // 2) if pool else (H, W)
+        elif op[0] == 'se':
+            res[op[3]] = res[op[1]]
+        elif op[0] == 'dense':
+            _, src, dst, cin, cout, act = op
+            H = res[src][0]
+            total += 2.0 * H * cin * cout
+            res[dst] = (H, 1)
+    return total, first
+
+
+def step_flops_per_utt(g, T, F):
+    """F_step = 3*F_fwd - F_c1 (no data gradient for the first conv)."""
+    total, first = fwd_flops_per_utt(g, T, F)
+    return 3.0 * total - first
+
+
+class DFCNNEngine:
+    def __init__(self, model='m2', vocab=1536, B=32, T=1600, F=200, widths=None, seed=0, device='cuda',
+                 lr=7e-4, decay_steps=5000, min_lr=1e-6, beta1=0.9, beta2=0.999, adam_eps=1e-8):
+        assert T % 8 == 0 and F >= 8
+        self.model, self.V, self.B, self.T, self.F = model, vocab, B, T, F
+        self.device = device
+        self.g = graph(model, vocab, widths, F)
+        self.lr0, self.decay_steps, self.min_lr = lr, decay_steps, min_lr
+        self.beta1, self.beta2, self.adam_eps = beta1, beta2, adam_eps
+        self.global_step = 0
+        self._layout_params()
+        self.init_params(seed)
+        self._alloc_buffers()
+
+    # ------------------------------------------------------------------ parameters
+    def _layout_params(self):
+        """Flat fp32 buffer: [all BN gammas][dense layers][everything else].  The gamma segment
+        lets one launch derive every bn_scale; the dense segment is the first gradient bucket
+        ready in backward (all-reduce overlaps the conv-stack backward)."""
+        ent = {}            # (layer, key) -> (offset, shape)
+        off = 0
+
+        def add(layer, key, shape):
+            nonlocal off
+            n = int(np.prod(shape))
+            ent[(layer, key)] = (off, tuple(shape))
+            off += (n + 3) // 4 * 4          # keep every tensor 16-byte aligned
+
+        for op in self.g:
+            if op[0] == 'cell':
+                add(op[2], 'gamma', (op[4],))
+            elif op[0] == 'se' and op[6]:
+                add(op[3], 'gamma', (op[4],))
+        self.n_gamma = off
+        for op in self.g:
+            if op[0] == 'dense':
+                add(op[2], 'w', (op[3], op[4]))
+                add(op[2], 'b', (op[4],))
+        self.dense_end = off
+        for op in self.g:
+            if op[0] == 'cell':
+                _, src, dst, cin, cout, k, pool = op
+                add(dst, 'w', (k, k, cin, cout)); add(dst, 'b', (cout,)); add(dst, 'beta', (cout,))
+            elif op[0] == 'se':
+                _, main, br, dst, Cc, hid, use_bn = op
+                if use_bn:
+                    add(dst, 'beta', (Cc,))
+                add(dst, 'w1', (Cc, hid)); add(dst, 'b1', (hid,)); add(dst, 'w2', (hid, Cc)); add(dst, 'b2', (Cc,))
+        self.entries = ent
+        self.n_params_padded = off
+        self.n_params = sum(int(np.prod(s)) for _, s in ent.values())
+        z = lambda: torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.theta, self.grad, self.adam_m, self.adam_v = z(), z(), z(), z()
+        self.bn_scale = torch.zeros(max(4, self.n_gamma), dtype=torch.float32, device=self.device)
+        self.dscale = torch.zeros(max(4, self.n_gamma), dtype=torch.float32, device=self.device)
+        self.ones = None
+
+    def _view(self, buf, layer, key):
+        off, shape = self.entries[(layer, key)]
+        return buf[off:off + int(np.prod(shape))]
+
+    def p(self, layer, key):
+        return self._view(self.theta, layer, key)
+
+    def gview(self, layer, key):
+        return self._view(self.grad, layer, key)
+
+    def scale_of(self, layer):
+        off, shape = self.entries[(layer, 'gamma')]
+        return self.bn_scale[off:off + shape[0]]
+
+    def dscale_of(self, layer):
+        off, shape = self.entries[(layer, 'gamma')]
+        return self.dscale[off:off + shape[0]]
+
+    def init_params(self, seed=0):
+        """tf.layers defaults (acoustic_model2.py:35 initializer=None): Glorot-uniform kernels,
+        zero biases, BN gamma = 1, beta = 0 (moving mean 0 / variance 1 stay frozen, Q1)."""
+        rng = np.random.default_rng(seed)
+        host = np.zeros(self.n_params_padded, dtype=np.float32)
+
+        def put(layer, key, val):
+            off, shape = self.entries[(layer, key)]
+            host[off:off + val.size] = val.astype(np.float32).ravel()
+
+        for op in self.g:
+            if op[0] == 'cell':
+                _, src, dst, cin, cout, k, pool = op
+                lim = math.sqrt(6.0 / (k * k * cin + k * k * cout))
+                put(dst, 'w', rng.uniform(-lim, lim, (k, k, cin, cout)))
+                put(dst, 'gamma', np.ones(cout))
+            elif op[0] == 'se':
+                _, main, br, dst, Cc, hid, use_bn = op
+                put(dst, 'w1', rng.uniform(-1, 1, (Cc, hid)) * math.sqrt(6.0 / (Cc + hid)))
+                put(dst, 'w2', rng.uniform(-1, 1, (hid, Cc)) * math.sqrt(6.0 / (Cc + hid)))
+                if use_bn:
+                    put(dst, 'gamma', np.ones(Cc))
+            elif op[0] == 'dense':
+                _, src, dst, cin, cout, act = op
+                put(dst, 'w', rng.uniform(-1, 1, (cin, cout)) * math.sqrt(6.0 / (cin + cout)))
+        self.theta.copy_(torch.from_numpy(host))
+        self.adam_m.zero_(); self.adam_v.zero_()
+        self.global_step = 0
+
+    def load_params(self, P):
+        """P: {layer: {key: ndarray}} in the reference's tensor layouts (HWIO kernels)."""
+        host = self.theta.cpu().numpy()
+        for (layer, key), (off, shape) in self.entries.items():
+            v = np.asarray(P[layer][key], dtype=np.float32)
+            assert tuple(v.shape) == shape, (layer, key, v.shape, shape)
+            host[off:off + v.size] = v.ravel()
+        self.theta.copy_(torch.from_numpy(host))
+
+    def params_dict(self, buf=None):
+        host = (self.theta if buf is None else buf).cpu().numpy()
+        out = {}
+        for (layer, key), (off, shape) in self.entries.items():
+            out.setdefault(layer, {})[key] = host[off:off + int(np.prod(shape))].reshape(shape).copy()
+        return out
+
+    def grads_dict(self):
+        return self.params_dict(self.grad)
+
+    # ------------------------------------------------------------------ buffers
+    def _alloc_buffers(self):
+        B, dev = self.B, self.device
+        self.res = {'x': (self.T, self.F, 1)}
+        self.y = {}          # name -> Plane (cell/SE outputs in padded layout)
+        self.a = {}          # cell name -> Plane of post-ReLU pre-pool activations
+        self.flat = {}       # name -> [rows, C] tensor (inputs/outputs of dense layers)
+        self.se_state = {}
+        self.dz_pool = {}    # geometry -> shared dZ plane
+        self.dy = {}         # name -> Plane gradient buffers (allocated lazily per geometry)
+        self.fdesc, self.bdesc, self.wdesc = {}, {}, {}
+        ws_bytes = 1 << 20
+        consumers = {}
+        for op in self.g:
+            srcs = [op[1]] if op[0] != 'se' else [op[1], op[2]]
+            for s in srcs:
+                consumers.setdefault(s, []).append(op)
+        self.consumers = consumers
+        for op in self.g:
+            if op[0] == 'cell':
+                _, src, dst, cin, cout, k, pool = op
+                H, W, _ = self.res[src]
+                Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+                self.res[dst] = (Ho, Wo, cout)
+                feeds_dense = any(c[0] == 'dense' for c in consumers.get(dst, []))
+                if src == 'x':
+                    self.y[dst] = Plane(B, Ho, Wo, cout, dev)
+                    ws_bytes = max(ws_bytes, ops.cell1_bwd_workspace(B, H, W, cout))
+                    continue
+                self.a[dst] = Plane(B, H, W, cout, dev)
+                NP = B * (H + 2) * (W + 2)
+                if feeds_dense:
+                    assert not pool
+                    self.flat[dst] = torch.zeros(B * H * W, cout, dtype=torch.float32, device=dev)
+                else:
+                    self.y[dst] = Plane(B, Ho, Wo, cout, dev)
+                nt = 9 if k == 3 else 1
+                self.fdesc[dst] = ops.gemm_desc(NP, cin, cout, cin, cout, cout, cout, ntaps=nt, B=B, H=H, W=W, relu=1,
+                                                y_unpadded=1 if feeds_dense else 0)
+                self.bdesc[dst] = ops.gemm_desc(NP, cout, cin, cout, cout, 0, cin, ntaps=nt, B=B, H=H, W=W, wmode=1)
+                self.wdesc[dst] = ops.gemm_desc(NP, cin, cout, cin, cout, ntaps=nt, B=B, H=H, W=W)
+                ws_bytes = max(ws_bytes, ops.tap_wgrad_workspace(self.wdesc[dst]),
+                               ops.cell_bwd_pre_workspace(B, H, W, cout))
+                geo = (H, W, cout)
+                if geo not in self.dz_pool:
+                    self.dz_pool[geo] = Plane(B, H, W, cout, dev)
+            elif op[0] == 'se':
+                _, main, br, dst, Cc, hid, use_bn = op
+                H, W, _ = self.res[main]
+                self.res[dst] = (H, W, Cc)
+                self.y[dst] = Plane(B, H, W, Cc, dev)
+                self.se_state[dst] = torch.zeros(ops.se_state_floats(B, Cc, hid), dtype=torch.float32, device=dev)
+                ws_bytes = max(ws_bytes, ops.se_fwd_workspace(B, H, W, Cc), ops.se_bwd_workspace(B, H, W, Cc, hid))
+            elif op[0] == 'dense':
+                _, src, dst, cin, cout, act = op
+                H = self.res[src][0]
+                rows = B * H
+                self.res[dst] = (H, 1, cout)
+                if src not in self.flat:
+                    raise ValueError('dense input %s must come from a cell or dense' % src)
+                self.flat[dst] = torch.zeros(rows, cout, dtype=torch.float32, device=dev)
+                self.fdesc[dst] = ops.gemm_desc(rows, cin, cout, cin, cout, 0, cout, ntaps=1, relu=1 if act == 'relu' else 0)
+                self.bdesc[dst] = ops.gemm_desc(rows, cout, cin, cout, cout, 0, cin, ntaps=1, wmode=1)
+                self.wdesc[dst] = ops.gemm_desc(rows, cin, cout, cin, cout, ntaps=1)
+                ws_bytes = max(ws_bytes, ops.tap_wgrad_workspace(self.wdesc[dst]), ops.colsum_workspace(rows, cout))
+        self.T8 = self.res[self.g[-1][2]][0]
+        T8, V = self.T8, self.V
+        self.logits = torch.zeros(T8, B, V, dtype=torch.float32, device=dev)      # self.logits of the reference
+        self.ctc_grad = torch.zeros(T8, B, V, dtype=torch.float32, device=dev)
+        self.dflat = {}       # gradients of flat tensors
+        for name, t in self.flat.items():
+            self.dflat[name] = torch.zeros_like(t)
+        self.loss = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.ctc_status = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.ctc_ws = torch.zeros(ops.ctc_workspace(T8, B, MAX_LABEL) // 8 + 8, dtype=torch.float64, device=dev)
+        self.dec_ids = torch.zeros(B, T8, dtype=torch.int32, device=dev)
+        self.dec_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.neg_sum = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.dist = torch.zeros(B, dtype=torch.float32, device=dev)
+        self.scalars = torch.zeros(8, dtype=torch.float32, device=dev)     # [0] sum loss, [1] sum dist
+        self.ws = torch.zeros(ws_bytes // 4 + 64, dtype=torch.float32, device=dev)
+        self.labels = torch.zeros(B, MAX_LABEL, dtype=torch.int32, device=dev)
+        self.label_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.seq_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        # gradient planes: one per named tensor that feeds a cell (except x) or an SE branch.
+        # dL/d(main) of an SE block IS dL/d(its output) (identity branch), so the two share one
+        # plane: later contributions to main accumulate into the block's dout buffer.
+        self.alias = {}
+        for op in self.g:
+            if op[0] == 'se' and op[1] != op[2]:
+                self.alias[op[1]] = op[3]
+        for op in self.g:
+            if op[0] == 'cell' and op[1] != 'x':
+                self._dplane(op[1])
+            if op[0] == 'se':
+                self._dplane(op[2])
+                self._dplane(op[3])
+
+    def _root(self, name):
+        while name in self.alias:
+            name = self.alias[name]
+        return name
+
+    def _dplane(self, name):
+        name = self._root(name)
+        if name not in self.dy:
+            H, W, Cc = self.res[name]
+            self.dy[name] = Plane(self.B, H, W, Cc, self.device)
+        return self.dy[name]
+
+    # ------------------------------------------------------------------ forward
+    def refresh_bn(self):
+        if self.n_gamma:
+            ops.axpy(self.bn_scale[:self.n_gamma], self.theta[:self.n_gamma], RS, False)
+
+    def forward(self, x):
+        """x: [B, T, F] float32 on the device (the wav_input placeholder without its last axis)."""
+        assert x.is_contiguous() and tuple(x.shape) == (self.B, self.T, self.F)
+        self.x = x
+        self.refresh_bn()
+        for op in self.g:
+            if op[0] == 'cell':
+                _, src, dst, cin, cout, k, pool = op
+                sc, sh = self.scale_of(dst), self.p(dst, 'beta')
+                pm = {None: 0, 'avg': 1, 'max': 2}[pool]
+                if src == 'x':
+                    ops.cell1_fwd(x, self.p(dst, 'w'), self.p(dst, 'b'), sc, sh, pm, self.y[dst])
+                    continue
+                out_y = None if pool else (self.flat[dst] if dst in self.flat else self.y[dst])
+                ops.tap_gemm(self.fdesc[dst], self.y[src], self.p(dst, 'w'), self.p(dst, 'b'), sc, sh,
+                             self.a[dst], out_y)
+                if pool:
+                    ops.pool_fwd(self.a[dst], sc, sh, pm, self.y[dst])
+            elif op[0] == 'se':
+                _, main, br, dst, Cc, hid, use_bn = op
+                sc, sh = self._se_affine(dst, Cc, use_bn)
+                ops.se_fwd(self.y[main], self.y[br], hid, sc, sh, self.p(dst, 'w1'), self.p(dst, 'b1'),
+                           self.p(dst, 'w2'), self.p(dst, 'b2'), self.se_state[dst], self.ws, self.y[dst])
+            elif op[0] == 'dense':
+                _, src, dst, cin, cout, act = op
+                ops.tap_gemm(self.fdesc[dst], self.flat[src], self.p(dst, 'w'), self.p(dst, 'b'), None, None,
+                             None, self.flat[dst])
+        ops.softmax_log_fwd(self.flat[self.g[-1][2]], self.B, self.T8, self.V, K_EPSILON, self.logits)
+        return self.logits
+
+    def _se_affine(self, dst, Cc, use_bn):
+        if use_bn:
+            return self.scale_of(dst), self.p(dst, 'beta')
+        if self.ones is None or self.ones.numel() < 2 * Cc:
+            self.ones = torch.cat([torch.ones(1024, device=self.device), torch.zeros(1024, device=self.device)])
+        return self.ones[:Cc], self.ones[1024:1024 + Cc]
+
+    # ------------------------------------------------------------------ loss / decode
+    def set_targets(self, logits_length, target_py):
+        """logits_length [B] ints, target_py [B, <=64] zero-padded ids.  Mirrors
+        tf.contrib.layers.dense_to_sparse (acoustic_model2.py:71): every 0 is dropped (Q6).
+        Raises ValueError where TF raises InvalidArgumentError (no valid CTC alignment)."""
+        tp = np.asarray(target_py)
+        lab = np.zeros((self.B, MAX_LABEL), dtype=np.int32)
+        ll = np.zeros(self.B, dtype=np.int32)
+        sl = np.asarray(logits_length, dtype=np.int32).reshape(self.B)
+        for b in range(self.B):
+            ids = tp[b][tp[b] != 0]
+            if len(ids) > MAX_LABEL:
+                raise ValueError('label longer than %d' % MAX_LABEL)
+            rep = int(np.sum(ids[1:] == ids[:-1]))
+            if sl[b] < len(ids) + rep or sl[b] <= 0 or sl[b] > self.T8:
+                raise ValueError('Not enough time for target transition sequence (required: %d, available: %d) '
+                                 'in batch %d' % (len(ids) + rep, sl[b], b))
+            lab[b, :len(ids)] = ids
+            ll[b] = len(ids)
+        self.labels.copy_(torch.from_numpy(lab), non_blocking=True)
+        self.label_len.copy_(torch.from_numpy(ll), non_blocking=True)
+        self.seq_len.copy_(torch.from_numpy(sl), non_blocking=True)
+        self._host_labels = [lab[b, :ll[b]].tolist() for b in range(self.B)]
+
+    def loss_and_decode(self):
+        B, T8, V = self.B, self.T8, self.V
+        ops.ctc_loss(self.logits, T8, B, V, self.labels, MAX_LABEL, self.label_len, self.seq_len, V - 1,
+                     self.loss, self.ctc_grad, self.ctc_status, self.ctc_ws)
+        ops.ctc_greedy(self.logits, T8, B, V, self.seq_len, V - 1, self.dec_ids, self.dec_len, self.neg_sum)
+        ops.edit_distance(self.dec_ids, T8, self.dec_len, self.labels, MAX_LABEL, self.label_len, B, self.dist)
+        ops.colsum(self.loss, B, 1, 1, self.scalars[0:1], self.ws)
+        ops.colsum(self.dist, B, 1, 1, self.scalars[1:2], self.ws)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, on_dense_grads_ready=None):
+        B, T8, V = self.B, self.T8, self.V
+        last = self.g[-1][2]
+        ops.softmax_log_bwd(self.logits, self.ctc_grad, B, T8, V, K_EPSILON, 1.0 / B, self.dflat[last])
+        ready = set()          # gradient planes that already hold a value this step
+
+        def grad_target(name):
+            name = self._root(name)
+            acc = name in ready
+            ready.add(name)
+            return self.dy[name], acc
+
+        dense_pending = sum(1 for op in self.g if op[0] == 'dense')
+        for op in reversed(self.g):
+            if op[0] == 'dense':
+                _, src, dst, cin, cout, act = op
+                dz = self.dflat[dst]
+                if act == 'relu':
+                    ops.relu_bwd(dz, self.flat[dst], dz)
+                rows = dz.shape[0]
+                ops.tap_wgrad(self.wdesc[dst], self.flat[src], dz, cout, self.gview(dst, 'w'), self.ws)
+                ops.colsum(dz, rows, cout, cout, self.gview(dst, 'b'), self.ws)
+                ops.tap_gemm(self.bdesc[dst], dz, self.p(dst, 'w'), None, None, None, None, self.dflat[src])
+                dense_pending -= 1
+                if dense_pending == 0 and on_dense_grads_ready is not None:
+                    on_dense_grads_ready()
+            elif op[0] == 'se':
+                _, main, br, dst, Cc, hid, use_bn = op
+                dout = self._dplane(dst)
+                sc, sh = self._se_affine(dst, Cc, use_bn)
+                if use_bn:
+                    dsc, dsh = self.dscale_of(dst), self.gview(dst, 'beta')
+                else:
+                    dsc, dsh = self.ws[-2048:-1024], self.ws[-1024:]
+                same = (main == br)
+                dx, acc = grad_target(br)
+                assert not acc
+                ops.se_bwd(dout, self.y[br], hid, sc, sh, self.p(dst, 'w1'), self.p(dst, 'w2'), self.se_state[dst],
+                           1 if same else 0, dx, dsc, dsh, self.gview(dst, 'w1'), self.gview(dst, 'b1'),
+                           self.gview(dst, 'w2'), self.gview(dst, 'b2'), self.ws[:-2048])
+                # when main != branch, dL/d(main) = dout lives in the same plane (self.alias)
+            elif op[0] == 'cell':
+                _, src, dst, cin, cout, k, pool = op
+                sc, sh = self.scale_of(dst), self.p(dst, 'beta')
+                pm = {None: 0, 'avg': 1, 'max': 2}[pool]
+                if src == 'x':
+                    H, W, _ = self.res['x']
+                    ops.cell1_bwd(self.x, self.p(dst, 'w'), self.p(dst, 'b'), sc, sh, pm, self._dplane(dst),
+                                  self.gview(dst, 'w'), self.gview(dst, 'b'), self.dscale_of(dst),
+                                  self.gview(dst, 'beta'), self.ws)
+                    continue
+                H, W, _ = self.res[src]
+                dz = self.dz_pool[(H, W, cout)]
+                if dst in self.dflat:
+                    dyv, layout = self.dflat[dst], 2
+                else:
+                    dyv, layout = self._dplane(dst), (1 if pool else 0)
+                ops.cell_bwd_pre(dyv, layout, self.a[dst], sc, sh, pm, dz, self.dscale_of(dst),
+                                 self.gview(dst, 'beta'), self.gview(dst, 'b'), self.ws)
+                ops.tap_wgrad(self.wdesc[dst], self.y[src], dz, cout, self.gview(dst, 'w'), self.ws)
+                dx, acc = grad_target(src)
+                d = self.bdesc[dst]
+                d.accumulate = 1 if acc else 0
+                ops.tap_gemm(d, dz, self.p(dst, 'w'), None, None, None, None, dx)
+        if self.n_gamma:
+            ops.axpy(self.grad[:self.n_gamma], self.dscale[:self.n_gamma], RS, False)
+
+    # ------------------------------------------------------------------ optimiser
+    def current_learning_rate(self, step=None):
+        """tf.train.polynomial_decay(lr, global_step, decay_steps, end, cycle=True, power=0.5)
+        (acoustic_model2.py:86-88, Appendix A10)."""
+        step = float(self.global_step if step is None else step)
+        ds = float(self.decay_steps)
+        mult = 1.0 if step == 0 else math.ceil(step / ds)
+        p = step / (ds * mult)
+        return (self.lr0 - self.min_lr) * math.sqrt(max(0.0, 1.0 - p)) + self.min_lr
+
+    def apply_adam(self, gscale=1.0):
+        lr = self.current_learning_rate()
+        t = self.global_step + 1
+        lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        ops.adam_tf(self.theta, self.grad, self.adam_m, self.adam_v, lr_t, self.beta1, self.beta2, self.adam_eps, gscale)
+        self.global_step += 1
+        return lr
+
+    # ------------------------------------------------------------------ fetches (host sync)
+    def fetch_scalars(self):
+        s = self.scalars.cpu().numpy()
+        return float(s[0]) / self.B, float(s[1]) / self.B
+
+    def decoded_lists(self):
+        ids = self.dec_ids.cpu().numpy()
+        n = self.dec_len.cpu().numpy()
+        return [ids[b, :n[b]].tolist() for b in range(self.B)]

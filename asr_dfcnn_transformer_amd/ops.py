@@ -45,6 +45,59 @@ class Plane:
         self.buf.zero_()
 
 
+class KernelTimer:
+    """Optional HIP-event timing of the contraction kernels, keyed by kernel instantiation
+    (family, ntaps, wmode, N-class).  bench.py uses it to price the dominant kernel inside
+    the timed region; events are recorded on the stream the kernels are launched on."""
+
+    def __init__(self, only=None):
+        self.only = only          # None: time every tap kernel; else a set of keys
+        self.records = {}         # key -> list of (flops, ev0, ev1)
+
+    def want(self, key):
+        return self.only is None or key in self.only
+
+    def add(self, key, flops, e0, e1):
+        self.records.setdefault(key, []).append((flops, e0, e1))
+
+    def summary(self):
+        """key -> dict(launches, total_ms, total_flops, tflops)  (call after a device sync)."""
+        out = {}
+        for key, recs in self.records.items():
+            ms = sum(e0.elapsed_time(e1) for _, e0, e1 in recs)
+            fl = sum(f for f, _, _ in recs)
+            out[key] = {'launches': len(recs), 'total_ms': ms, 'total_flops': fl,
+                        'avg_us': 1e3 * ms / len(recs), 'tflops': fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+        return out
+
+
+TIMER = None
+
+
+def _key(family, d):
+    ncls = 128 if d.N > 64 else (64 if d.N > 32 else 32)
+    return (family, d.ntaps, d.wmode, ncls)
+
+
+def _flops(d):
+    rows = d.B * d.H * d.W if d.H > 0 else d.M
+    return 2.0 * rows * d.K * d.N * d.ntaps
+
+
+def _timed(family, d, fn):
+    t = TIMER
+    if t is None:
+        return fn()
+    key = _key(family, d)
+    if not t.want(key):
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    t.add(key, _flops(d), e0, e1)
+
+
 def gemm_desc(M, K, N, lda, ldw, ldo_a=0, ldo_y=0, ntaps=1, B=0, H=0, W=0, wmode=0, relu=0,
               accumulate=0, y_unpadded=0):
     return GemmDesc(M, K, N, lda, ldw, ldo_a, ldo_y, ntaps, B, H, W, wmode, relu, accumulate, y_unpadded)
@@ -55,8 +108,9 @@ def tap_gemm(desc, A, W, bias=None, scale=None, shift=None, out_a=None, out_y=No
     pa = A.ptr if isinstance(A, Plane) else _ptr(A)
     po_a = out_a.ptr if isinstance(out_a, Plane) else _ptr(out_a)
     po_y = out_y.ptr if isinstance(out_y, Plane) else _ptr(out_y)
-    check(lib.asr_tap_gemm(C.byref(desc), pa, _ptr(W), _ptr(bias), _ptr(scale), _ptr(shift), po_a, po_y, _stream()),
-          'asr_tap_gemm')
+    _timed('tap_gemm', desc, lambda: check(
+        lib.asr_tap_gemm(C.byref(desc), pa, _ptr(W), _ptr(bias), _ptr(scale), _ptr(shift), po_a, po_y, _stream()),
+        'asr_tap_gemm'))
 
 
 def tap_wgrad_workspace(desc):
@@ -67,7 +121,8 @@ def tap_wgrad(desc, A, dZ, ldz, dW, partials):
     lib = _lib.load()
     pa = A.ptr if isinstance(A, Plane) else _ptr(A)
     pz = dZ.ptr if isinstance(dZ, Plane) else _ptr(dZ)
-    check(lib.asr_tap_wgrad(C.byref(desc), pa, pz, ldz, _ptr(dW), _ptr(partials), _stream()), 'asr_tap_wgrad')
+    _timed('tap_wgrad', desc, lambda: check(
+        lib.asr_tap_wgrad(C.byref(desc), pa, pz, ldz, _ptr(dW), _ptr(partials), _stream()), 'asr_tap_wgrad'))
 
 
 def cell1_fwd(x, w, bias, sc, sh, pool, y):

@@ -1,0 +1,62 @@
+"""Data parallelism for the acoustic model: one process per GPU, the flat fp32 gradient
+buffer is summed over ranks with RCCL (torch.distributed backend "nccl" on ROCm) in two
+buckets -- the dense head first (its gradients are ready before the conv-stack backward
+starts, so that all-reduce overlaps the rest of backward), the remainder at the end --
+and Adam divides by the world size.  The reference has no distributed code (SURVEY.md
+section 5); utterances are independent (frozen BN, per-sample SE and CTC), so equal
+shards + mean of gradients reproduce the single-GPU global-batch step (section 8e).
+
+Works on any torch.distributed backend, which is how the CPU tests cover it (gloo)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialises the default process group from RANK / WORLD_SIZE / MASTER_* when the
+    launcher set them.  Returns (rank, world, local_rank)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class BucketedAllReduce:
+    """Sum-all-reduce of a flat gradient tensor in contiguous buckets ``ranges`` =
+    [(lo, hi), ...], each launched asynchronously as soon as the caller says its range is
+    final (``launch(i)``); ``wait()`` joins them before the optimiser reads the buffer."""
+
+    def __init__(self, flat_grad, ranges, group=None):
+        self.flat = flat_grad
+        self.ranges = [(int(lo), int(hi)) for lo, hi in ranges]
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.pending = []
+
+    @property
+    def num_buckets(self):
+        return len(self.ranges)
+
+    def launch(self, i):
+        lo, hi = self.ranges[i]
+        if self.world == 1 or hi <= lo:
+            return
+        self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world

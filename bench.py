@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Benchmark of the DFCNN(+SE)+CTC training hot path on MI355X.
+
+A "step" = one pass of the hot path over one batch of synthetic 10 s / 16 kHz utterances
+that are already resident in HBM as raw audio:
+    fbank (K1) -> DFCNN forward -> softmax/log -> CTC loss+grad, greedy decode, edit distance
+    -> backward (dgrad + wgrad of every layer) -> [RCCL gradient all-reduce] -> TF-Adam.
+Workloads (BASELINE.json configs):
+    dfcnn     configs[1]: plain DFCNN  lm_and_am/model/acoustic_model.py,  batch 32, T_pad 1600  (default)
+    se_dfcnn  configs[2]: SE-DFCNN     lm_and_am/model/acoustic_model2.py, batch 32 per GPU
+Prints ONE JSON line (rank 0).  `python bench.py` = 1 GPU, a few minutes incl. the CPU baseline.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+FP32_PEAK_TFLOPS = 157.3        # MI355X dense fp32 (vector = matrix), MI355X_MICROARCH.md
+KERNEL_NAMES = {
+    ('tap_gemm', 9, 0): 'tap_gemm_kernel<.., NTAPS=9, WMODE=0> (conv3x3 forward)',
+    ('tap_gemm', 9, 1): 'tap_gemm_kernel<.., NTAPS=9, WMODE=1> (conv3x3 data-gradient)',
+    ('tap_gemm', 1, 0): 'tap_gemm_kernel<.., NTAPS=1, WMODE=0> (dense / conv1x1 forward)',
+    ('tap_gemm', 1, 1): 'tap_gemm_kernel<.., NTAPS=1, WMODE=1> (dense / conv1x1 data-gradient)',
+    ('tap_wgrad', 9, 0): 'tap_wgrad_kernel<NTAPS=9, ..> (conv3x3 weight-gradient)',
+    ('tap_wgrad', 1, 0): 'tap_wgrad_kernel<NTAPS=1, ..> (dense / conv1x1 weight-gradient)',
+}
+
+
+def cpu_baseline(variant, t_pad, vocab, seconds=10.0, budget_s=15.0):
+    """CPU restatement ("port": oracle/torch_ref.py on torch-CPU ops + the numpy fbank oracle)
+    of the identical step, timed on this host's cores on a bounded sample.  Stand-in for the
+    reference's TF-CPU path, which cannot run offline."""
+    from oracle import dfcnn as odf, fbank as ofb, torch_ref
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    torch.set_num_threads(cores)
+    Bc = 2
+    g = odf.graph(variant, vocab)
+    P = odf.init_params(g, seed=0)
+    tP = torch_ref.to_torch_params(P, dtype=torch.float32)
+    params = [t for d in tP.values() for t in d.values()]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    rng = np.random.default_rng(1234)
+    ns = int(seconds * 16000)
+    sig = [0.1 * rng.standard_normal(ns) for _ in range(Bc)]
+    labels = [list(rng.integers(1, vocab - 1, 32)) for _ in range(Bc)]
+
+    def step(t):
+        x = np.zeros((Bc, t_pad, 200, 1), dtype=np.float32)
+        for b in range(Bc):
+            f = ofb.compute_fbank_from_api(sig[b], 16000, nfilt=200)
+            x[b, :f.shape[0], :, 0] = f
+        for p in params:
+            p.grad = None
+        torch_ref.train_step(g, tP, torch.from_numpy(x), [125] * Bc, labels)
+        torch_ref.adam_tf_(params, [p.grad for p in params], m, v, 7e-4, t)
+
+    step(1)                                   # warm-up (allocations, oneDNN primitive caches)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step(n + 2)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or n >= 60:
+            break
+    return {'value': round(Bc * n / el, 4), 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
+            'sample': '%d timed steps of batch %d (same model, T_pad %d, 10 s audio, fbank+fwd+CTC+bwd+Adam, '
+                      'torch-CPU fp32 + numpy fbank) after 1 warm-up' % (n, Bc, t_pad)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='dfcnn', choices=['dfcnn', 'se_dfcnn'])
+    ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
+    ap.add_argument('--tpad', type=int, default=1600)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--kernel-table', action='store_true', help='also print per-kernel timings to stderr')
+    args = ap.parse_args()
+
+    from asr_dfcnn_transformer_amd import ops
+    from asr_dfcnn_transformer_amd.engine import DFCNNEngine, step_flops_per_utt, fwd_flops_per_utt
+    from asr_dfcnn_transformer_amd.parallel import init_from_env, BucketedAllReduce
+    from asr_dfcnn_transformer_amd.wav_util import FbankExtractor
+
+    rank, world, local = init_from_env()
+    if world != args.gpus and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    torch.cuda.set_device(local)
+    dev = 'cuda'
+    variant = 'm1' if args.workload == 'dfcnn' else 'm2'
+    B, T, F, V = args.batch, args.tpad, 200, 1536
+    eng = DFCNNEngine(model=variant, vocab=V, B=B, T=T, F=F, seed=0, device=dev)
+    red = BucketedAllReduce(eng.grad, [(eng.n_gamma, eng.dense_end), (0, eng.n_gamma), (eng.dense_end, eng.grad.numel())])
+    fb = FbankExtractor(nfilt=F, device=dev)
+
+    ns = 160000
+    host = np.stack([(0.1 * np.random.default_rng(1234 + rank * B + b).standard_normal(ns)).astype(np.float32)
+                     for b in range(B)])
+    signal = torch.from_numpy(host).to(dev)
+    nsamp = torch.full((B,), ns, dtype=torch.int32, device=dev)
+    lab_rng = np.random.default_rng(99 + rank)
+    target = np.zeros((B, 64), dtype=np.int32)
+    target[:, :32] = lab_rng.integers(1, V - 1, (B, 32))
+    seq = np.full(B, min(200, 999 // 8 + 1), dtype=np.int32)
+    feat = torch.empty(B, T, F, dtype=torch.float32, device=dev)
+
+    def step():
+        fb.batch(signal, nsamp, T, out=feat)
+        eng.forward(feat)
+        eng.set_targets(seq, target)
+        eng.loss_and_decode()
+        if world > 1:
+            eng.backward(on_dense_grads_ready=lambda: red.launch(0))
+            red.launch(1); red.launch(2)
+            red.wait()
+        else:
+            eng.backward()
+        eng.apply_adam(red.grad_scale)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    # warm-up; the first warm-up step also times every contraction kernel to find the dominant one
+    ops.TIMER = ops.KernelTimer()
+    for i in range(max(1, args.warmup)):
+        step()
+        if i == 0:
+            torch.cuda.synchronize()
+            table = ops.TIMER.summary()
+            ops.TIMER = None
+    fam = {}
+    for key, r in table.items():
+        k3 = key[:3]
+        f = fam.setdefault(k3, {'ms': 0.0, 'flops': 0.0, 'launches': 0})
+        f['ms'] += r['total_ms']; f['flops'] += r['total_flops']; f['launches'] += r['launches']
+    dom = max(fam, key=lambda k: fam[k]['ms'])
+    dom_keys = {k for k in table if k[:3] == dom}
+
+    ops.TIMER = ops.KernelTimer(only=dom_keys)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    timed = ops.TIMER.summary()
+    ops.TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    mean_loss, label_err = eng.fetch_scalars()
+
+    if rank == 0:
+        ms = sum(r['total_ms'] for r in timed.values())
+        fl = sum(r['total_flops'] for r in timed.values())
+        nl = sum(r['launches'] for r in timed.values())
+        achieved = fl / (ms * 1e-3) / 1e12
+        utt_s = world * B * args.steps / dt
+        fstep = step_flops_per_utt(eng.g, T, F)
+        out = {
+            'metric': 'utterances/sec (10 s audio, B=32) DFCNN+CTC fwd+bwd',
+            'value': round(utt_s, 3), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
+            'config': {'workload': ('plain DFCNN (acoustic_model.py) + CTC' if variant == 'm1' else
+                                    'SE-DFCNN (acoustic_model2.py) + CTC') +
+                                   ', fbank+fwd+CTC+greedy+bwd+Adam, 10 s/16 kHz audio, T_pad %d, V %d' % (T, V),
+                       'global_batch': world * B, 'batch_per_gpu': B, 't_pad': T, 'parallelism': 'dp%d' % world,
+                       'gflop_per_utt_fwd_bwd': round(fstep / 1e9, 3),
+                       'step_tflops': round(utt_s / world * fstep / 1e12, 2),
+                       'step_frac_of_fp32_peak': round(utt_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
+                       'mean_loss': round(mean_loss, 4)},
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / FP32_PEAK_TFLOPS, 4), 'traffic': None,
+                         'kernel': KERNEL_NAMES.get(dom, str(dom)),
+                         'launches_per_step': nl // args.steps, 'avg_launch_us': round(1e3 * ms / nl, 2),
+                         'flop_per_launch': round(fl / nl / 1e9, 3), 'flop_unit': 'GFLOP',
+                         'share_of_step_time': round(ms / args.steps / (1e3 * dt / args.steps), 3)},
+        }
+        if args.kernel_table:
+            for key, r in sorted(table.items(), key=lambda kv: -kv[1]['total_ms']):
+                print('%-28s launches %3d  total %8.3f ms  avg %9.1f us  %7.2f TFLOP/s' %
+                      (key, r['launches'], r['total_ms'], r['avg_us'], r['tflops']), file=sys.stderr)
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(variant, T, V)
+        print(json.dumps(out), flush=True)
+    barrier()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
