@@ -25,14 +25,21 @@ import torch
 import torch.distributed as dist
 
 FP32_PEAK_TFLOPS = 157.3        # MI355X dense fp32 (vector = matrix), MI355X_MICROARCH.md
-KERNEL_NAMES = {
-    ('tap_gemm', 9, 0): 'tap_gemm_kernel<.., NTAPS=9, WMODE=0> (conv3x3 forward)',
-    ('tap_gemm', 9, 1): 'tap_gemm_kernel<.., NTAPS=9, WMODE=1> (conv3x3 data-gradient)',
-    ('tap_gemm', 1, 0): 'tap_gemm_kernel<.., NTAPS=1, WMODE=0> (dense / conv1x1 forward)',
-    ('tap_gemm', 1, 1): 'tap_gemm_kernel<.., NTAPS=1, WMODE=1> (dense / conv1x1 data-gradient)',
-    ('tap_wgrad', 9, 0): 'tap_wgrad_kernel<NTAPS=9, ..> (conv3x3 weight-gradient)',
-    ('tap_wgrad', 1, 0): 'tap_wgrad_kernel<NTAPS=1, ..> (dense / conv1x1 weight-gradient)',
-}
+
+
+def kernel_name(key):
+    """The kernel symbol (as rocprofv3 --stats prints it) behind a KernelTimer key."""
+    fam, ntaps, wmode, ncls = key
+    if fam == 'tap_gemm':
+        cfg = {128: '128, 128, 2, 2', 64: '256, 64, 4, 1', 32: '256, 32, 4, 1'}[ncls]
+        what = {(9, 0): 'conv3x3 forward', (9, 1): 'conv3x3 data-gradient', (1, 0): 'dense/conv1x1 forward',
+                (1, 1): 'dense/conv1x1 data-gradient'}[(ntaps, wmode)]
+        return 'tap_gemm_kernel<%s, %d, %d> (%s)' % (cfg, ntaps, wmode, what)
+    if ntaps == 9:
+        cfg = {128: '9, 1, 4, 1, 64', 64: '9, 1, 2, 1, 64', 32: '9, 1, 1, 1, 128'}[ncls]
+        return 'tap_wgrad_kernel<%s> (conv3x3 weight-gradient)' % cfg
+    return 'tap_wgrad_kernel<1, 4, 4, 1, 64> (dense/conv1x1 weight-gradient)'
+
 
 
 def cpu_baseline(variant, t_pad, vocab, seconds=10.0, budget_s=15.0):
@@ -145,13 +152,8 @@ def main():
             torch.cuda.synchronize()
             table = ops.TIMER.summary()
             ops.TIMER = None
-    fam = {}
-    for key, r in table.items():
-        k3 = key[:3]
-        f = fam.setdefault(k3, {'ms': 0.0, 'flops': 0.0, 'launches': 0})
-        f['ms'] += r['total_ms']; f['flops'] += r['total_flops']; f['launches'] += r['launches']
-    dom = max(fam, key=lambda k: fam[k]['ms'])
-    dom_keys = {k for k in table if k[:3] == dom}
+    dom = max(table, key=lambda k: table[k]['total_ms'])     # one kernel symbol = one rocprof row
+    dom_keys = {dom}
 
     ops.TIMER = ops.KernelTimer(only=dom_keys)
     barrier(); torch.cuda.synchronize()
@@ -190,7 +192,7 @@ def main():
                        'mean_loss': round(mean_loss, 4)},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / FP32_PEAK_TFLOPS, 4), 'traffic': None,
-                         'kernel': KERNEL_NAMES.get(dom, str(dom)),
+                         'kernel': kernel_name(dom),
                          'launches_per_step': nl // args.steps, 'avg_launch_us': round(1e3 * ms / nl, 2),
                          'flop_per_launch': round(fl / nl / 1e9, 3), 'flop_unit': 'GFLOP',
                          'share_of_step_time': round(ms / args.steps / (1e3 * dt / args.steps), 3)},
