@@ -37,3 +37,21 @@ def test_banded_filterbank_matches_oracle():
             dense[j, st[j]:st[j] + cnt[j]] = w[j, :cnt[j]]
         assert np.array_equal(dense, fb)
     assert wav_util.num_frames(160000) == ofb.num_frames(160000) == 999
+
+
+def test_host_utils_match_oracle():
+    from asr_dfcnn_transformer_amd import utils
+    from oracle import fbank as ofb, ctc as octc
+    x = np.arange(33, dtype=np.float64).reshape(11, 3)
+    assert np.array_equal(utils.build_LFR_features(x, 4, 3), ofb.build_LFR_features(x, 4, 3))
+    assert utils.GetEditDistance('abcd', 'abxyd') == octc.get_edit_distance_difflib('abcd', 'abxyd') == 2
+    ind, val, shp = utils.sparse_tuple_from([[1, 2], [], [3]])
+    assert ind.tolist() == [[0, 0], [0, 1], [2, 0]] and val.tolist() == [1, 2, 3] and shp.tolist() == [3, 2]
+
+
+def test_hparams_surface():
+    from asr_dfcnn_transformer_amd.hparams import AmLmHparams, AmDataHparams
+    a = AmLmHparams().args
+    assert (a.am_lr, a.dacay_step, a.min_learning_rate, a.am_batch_size, a.feature_dim, a.feature_max_length) == \
+        (0.0007, 5000, 1e-6, 16, 200, 1600)
+    assert AmDataHparams.args.pinyin_dict == 'mixdict.txt' and AmDataHparams.args.lfr_m == 4

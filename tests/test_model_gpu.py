@@ -120,3 +120,34 @@ def test_step_is_bitwise_reproducible():
         torch.cuda.synchronize()
         outs.append(eng.grad.clone())
     assert torch.equal(outs[0], outs[1])
+
+
+def test_session_style_model_trains_and_checkpoints(tmp_path):
+    """CNNCTCModel.run with the reference's feed/fetch lists (lm_and_am/train.py:59-69): loss goes
+    down on a fixed synthetic batch, decode-only fetch works, checkpoint round-trips."""
+    from asr_dfcnn_transformer_amd.acoustic_model import CNNCTCModel
+    from asr_dfcnn_transformer_amd.hparams import AmLmHparams
+    from asr_dfcnn_transformer_amd import train as tr
+    hp = AmLmHparams().args
+    hp.feature_max_length, hp.feature_dim, hp.am_batch_size, hp.am_lr = 64, 16, 2, 1e-3
+    m = CNNCTCModel(hp, 12, 6345, widths=(8, 16, 32, 64))
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((2, 64, 16, 1)).astype(np.float32)
+    y = np.zeros((2, 64), dtype=np.int32)
+    y[:, :3] = rng.integers(1, 10, (2, 3))
+    feed = {m.wav_input: x, m.logits_length: np.array([8, 7]), m.target_py: y, m.target_length: np.array([3, 3]),
+            m.drop_rate: 0.5}
+    losses = []
+    for _ in range(25):
+        loss, mean_loss, lr, summary, label_err, _ = m.run(
+            [m.loss, m.mean_loss, m.current_learning, m.summary, m.label_err, m.train_op], feed_dict=feed)
+        losses.append(mean_loss)
+    assert loss.shape == (2, 1) and losses[-1] < 0.7 * losses[0], losses
+    assert m.global_step == 25 and 0 < lr <= 1e-3
+    dec = m.run(m.decoded[0], {m.wav_input: x, m.logits_length: np.array([8, 7])})
+    assert dec.dense_shape[0] == 2 and dec.indices.shape[1] == 2
+    p = str(tmp_path / 'ck.pt')
+    tr.save_checkpoint(m, p)
+    m2 = CNNCTCModel(hp, 12, 6345, widths=(8, 16, 32, 64), seed=5)
+    tr.load_checkpoint(m2, p)
+    assert torch.equal(m2.engine.theta, m.engine.theta) and m2.global_step == 25
