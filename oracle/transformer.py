@@ -1,0 +1,316 @@
+"""Oracle for the Transformer path (float64 numpy, hand-derived backward).  Test
+infrastructure only; parity unpinned (see oracle/__init__.py).
+
+Restates end2end/transformer.py:
+  layer_norm :4-27, embedding :30-55, mask :58-86, scaled_dot_product_attention :89-115,
+  multihead_attention :118-158, feedforward :204-231, label_smoothing :332-340
+and the live graphs of lm_and_am/model/language_model.py:22-78 and
+end2end/model.py:267-370 as SURVEY.md Q7-Q9 describe them: in every block loop the FFN
+output is stored in another attribute than the one the next block reads, so N stacked MHA
+sub-layers + ONE live FFN (of the last block) remain; projections are Dense(relu, no bias);
+key mask = rows of the per-head K whose sum is 0, fill value -2**32+1; query mask multiplies
+the post-softmax matrix; LayerNorm eps 1e-8 with biased variance.  Dropout is the identity
+here (parity runs use rate 0 / is_training False: SURVEY Q5).
+"""
+import numpy as np
+
+MASK_FILL = float(-2 ** 32 + 1)
+LN_EPS = 1e-8
+
+
+# ----------------------------------------------------------------- pieces
+def layer_norm(x, gamma, beta, eps=LN_EPS):
+    mu = x.mean(axis=-1, keepdims=True)
+    var = x.var(axis=-1, keepdims=True)
+    xh = (x - mu) / np.sqrt(var + eps)
+    return gamma * xh + beta, (xh, var)
+
+
+def layer_norm_bwd(cache, gamma, dy, eps=LN_EPS):
+    xh, var = cache
+    n = xh.shape[-1]
+    dg = (dy * xh).reshape(-1, n).sum(axis=0)
+    db = dy.reshape(-1, n).sum(axis=0)
+    dxh = dy * gamma
+    dx = (dxh - dxh.mean(axis=-1, keepdims=True) - xh * (dxh * xh).mean(axis=-1, keepdims=True)) / np.sqrt(var + eps)
+    return dx, dg, db
+
+
+def embedding(table, ids, zero_pad, scale):
+    """transformer.py:30-55: row 0 reads as zeros when zero_pad; output * sqrt(d) when scale."""
+    t = table.copy()
+    if zero_pad:
+        t[0] = 0.0
+    out = t[ids]
+    if scale:
+        out = out * (table.shape[1] ** 0.5)
+    return out
+
+
+def embedding_bwd(table_shape, ids, dout, zero_pad, scale):
+    g = np.zeros(table_shape)
+    d = dout * (table_shape[1] ** 0.5) if scale else dout
+    np.add.at(g, ids.reshape(-1), d.reshape(-1, table_shape[1]))
+    if zero_pad:
+        g[0] = 0.0
+    return g
+
+
+def _split(x, h):       # [N,T,C] -> [N,h,T,C/h]
+    N, T, C = x.shape
+    return x.reshape(N, T, h, C // h).transpose(0, 2, 1, 3)
+
+
+def _merge(x):          # [N,h,T,d] -> [N,T,h*d]
+    N, h, T, d = x.shape
+    return x.transpose(0, 2, 1, 3).reshape(N, T, h * d)
+
+
+def attention_core(Q, K, V, h, causal):
+    """scaled_dot_product_attention on head-split relu'd projections Q,K,V [N,T,C]."""
+    Qh, Kh, Vh = _split(Q, h), _split(K, h), _split(V, h)
+    d = Qh.shape[-1]
+    S = np.einsum('nhqd,nhkd->nhqk', Qh, Kh) / (d ** 0.5)
+    kmask = np.sign(np.abs(Kh.sum(axis=-1)))                       # [N,h,Tk]
+    keep = np.broadcast_to(kmask[:, :, None, :] != 0, S.shape).copy()
+    if causal:
+        Tq, Tk = S.shape[-2:]
+        keep &= np.tril(np.ones((Tq, Tk), dtype=bool))
+    Sm = np.where(keep, S, MASK_FILL)
+    m = Sm.max(axis=-1, keepdims=True)
+    e = np.exp(Sm - m)
+    P = e / e.sum(axis=-1, keepdims=True)
+    qmask = np.sign(np.abs(Qh).sum(axis=-1))                       # [N,h,Tq]
+    Pq = P * qmask[..., None]
+    O = np.einsum('nhqk,nhkd->nhqd', Pq, Vh)
+    return _merge(O), (Qh, Kh, Vh, P, keep, qmask)
+
+
+def attention_core_bwd(cache, dO):
+    Qh, Kh, Vh, P, keep, qmask = cache
+    h = Qh.shape[1]
+    d = Qh.shape[-1]
+    dOh = _split(dO, h)
+    Pq = P * qmask[..., None]
+    dV = np.einsum('nhqk,nhqd->nhkd', Pq, dOh)
+    dPq = np.einsum('nhqd,nhkd->nhqk', dOh, Vh)
+    dP = dPq * qmask[..., None]
+    dSm = P * (dP - (dP * P).sum(axis=-1, keepdims=True))
+    dS = np.where(keep, dSm, 0.0) / (d ** 0.5)                     # tf.where: no gradient into masked scores
+    dQ = np.einsum('nhqk,nhkd->nhqd', dS, Kh)
+    dK = np.einsum('nhqk,nhqd->nhkd', dS, Qh)
+    return _merge(dQ), _merge(dK), _merge(dV)
+
+
+def mha_fwd(q_in, k_in, p, h, causal):
+    """multihead_attention (transformer.py:118-158).  p: wq, wk, wv, wo [C,C], ln_g, ln_b."""
+    Q = np.maximum(q_in @ p['wq'], 0)
+    K = np.maximum(k_in @ p['wk'], 0)
+    V = np.maximum(k_in @ p['wv'], 0)
+    A, c_att = attention_core(Q, K, V, h, causal)
+    Z = np.maximum(A @ p['wo'], 0)
+    out, c_ln = layer_norm(Z + q_in, p['ln_g'], p['ln_b'])
+    return out, (q_in, k_in, Q, K, V, A, Z, c_att, c_ln)
+
+
+def mha_bwd(cache, p, dout, self_attn):
+    q_in, k_in, Q, K, V, A, Z, c_att, c_ln = cache
+    C = q_in.shape[-1]
+    dr, dg, db = layer_norm_bwd(c_ln, p['ln_g'], dout)
+    dq_in = dr.copy()
+    dZ = dr * (Z > 0)
+    g = {'ln_g': dg, 'ln_b': db, 'wo': A.reshape(-1, C).T @ dZ.reshape(-1, C)}
+    dA = dZ @ p['wo'].T
+    dQ, dK, dV = attention_core_bwd(c_att, dA)
+    dQ = dQ * (Q > 0); dK = dK * (K > 0); dV = dV * (V > 0)
+    g['wq'] = q_in.reshape(-1, C).T @ dQ.reshape(-1, C)
+    g['wk'] = k_in.reshape(-1, C).T @ dK.reshape(-1, C)
+    g['wv'] = k_in.reshape(-1, C).T @ dV.reshape(-1, C)
+    dq_in += dQ @ p['wq'].T
+    dk_in = dK @ p['wk'].T + dV @ p['wv'].T
+    if self_attn:
+        return dq_in + dk_in, None, g
+    return dq_in, dk_in, g
+
+
+def ffn_fwd(x, p):
+    """feedforward (transformer.py:204-231): conv1d(k=1) = dense with bias."""
+    H = np.maximum(x @ p['w1'] + p['b1'], 0)
+    Y = H @ p['w2'] + p['b2']
+    out, c_ln = layer_norm(Y + x, p['ln_g'], p['ln_b'])
+    return out, (x, H, c_ln)
+
+
+def ffn_bwd(cache, p, dout):
+    x, H, c_ln = cache
+    dr, dg, db = layer_norm_bwd(c_ln, p['ln_g'], dout)
+    C, Fh = p['w1'].shape
+    g = {'ln_g': dg, 'ln_b': db, 'w2': H.reshape(-1, Fh).T @ dr.reshape(-1, C), 'b2': dr.reshape(-1, C).sum(axis=0)}
+    dH = (dr @ p['w2'].T) * (H > 0)
+    g['w1'] = x.reshape(-1, C).T @ dH.reshape(-1, Fh)
+    g['b1'] = dH.reshape(-1, Fh).sum(axis=0)
+    return dr + dH @ p['w1'].T, g
+
+
+def smoothed_ce(logits, target, pad_id=0, eps=0.1):
+    """label_smoothing(one_hot(target)) + softmax_cross_entropy_with_logits_v2 + masked mean
+    (model.py:342-356, language_model.py:55-67).  target may hold -1 (IGNORE): one_hot is
+    all-zero there, yet the position counts because the mask is target != PAD."""
+    N, T, V = logits.shape
+    oh = np.zeros((N, T, V))
+    valid = (target >= 0) & (target < V)
+    n_i, t_i = np.nonzero(valid)
+    oh[n_i, t_i, target[valid]] = 1.0
+    ys = (1 - eps) * oh + eps / V
+    m = logits.max(axis=-1, keepdims=True)
+    lse = m + np.log(np.exp(logits - m).sum(axis=-1, keepdims=True))
+    logp = logits - lse
+    loss = -(ys * logp).sum(axis=-1)
+    ist = (target != pad_id).astype(np.float64)
+    mean_loss = (loss * ist).sum() / ist.sum()
+    preds = logits.argmax(axis=-1)
+    acc = ((preds == target) * ist).sum() / ist.sum()
+    dlogits = (np.exp(logp) * ys.sum(axis=-1, keepdims=True) - ys) * (ist / ist.sum())[..., None]
+    return mean_loss, acc, preds, loss, dlogits
+
+
+# ----------------------------------------------------------------- parameter init
+def _glorot(rng, shape):
+    lim = np.sqrt(6.0 / (shape[0] + shape[1]))
+    return rng.uniform(-lim, lim, size=shape)
+
+
+def init_mha(rng, C, perturb=False):
+    p = {k: _glorot(rng, (C, C)) for k in ('wq', 'wk', 'wv', 'wo')}
+    p['ln_g'], p['ln_b'] = np.ones(C), np.zeros(C)
+    if perturb:
+        p['ln_g'] = 1 + 0.1 * rng.standard_normal(C); p['ln_b'] = 0.1 * rng.standard_normal(C)
+    return p
+
+
+def init_ffn(rng, C, Fh, perturb=False):
+    p = {'w1': _glorot(rng, (C, Fh)), 'b1': np.zeros(Fh), 'w2': _glorot(rng, (Fh, C)), 'b2': np.zeros(C),
+         'ln_g': np.ones(C), 'ln_b': np.zeros(C)}
+    if perturb:
+        p['b1'] = 0.1 * rng.standard_normal(Fh); p['b2'] = 0.1 * rng.standard_normal(C)
+        p['ln_g'] = 1 + 0.1 * rng.standard_normal(C); p['ln_b'] = 0.1 * rng.standard_normal(C)
+    return p
+
+
+def init_lm(vin, vout, C, heads, blocks, pos_max, seed=0, perturb=False):
+    rng = np.random.default_rng(seed)
+    P = {'emb': _glorot(rng, (vin, C)), 'pos': _glorot(rng, (pos_max, C)),
+         'out_w': _glorot(rng, (C, vout)), 'out_b': np.zeros(vout)}
+    if perturb:
+        P['out_b'] = 0.1 * rng.standard_normal(vout)
+    for i in range(blocks):
+        P['mha%d' % i] = init_mha(rng, C, perturb)
+    P['ffn'] = init_ffn(rng, C, 4 * C, perturb)        # only the last block's FFN is live (Q7)
+    return P
+
+
+# ----------------------------------------------------------------- Language_Model (language_model.py:22-78)
+def lm_step(P, x, y, heads, blocks, want_grads=True):
+    C = P['emb'].shape[1]
+    N, T = x.shape
+    e = embedding(P['emb'], x, zero_pad=True, scale=True)
+    pos = np.broadcast_to(np.arange(T)[None, :], (N, T))
+    enc = e + embedding(P['pos'], pos, zero_pad=False, scale=False)
+    caches = []
+    for i in range(blocks):
+        enc, c = mha_fwd(enc, enc, P['mha%d' % i], heads, causal=True)
+        caches.append(c)
+    outputs, c_ffn = ffn_fwd(enc, P['ffn'])
+    logits = outputs @ P['out_w'] + P['out_b']
+    mean_loss, acc, preds, loss, dlogits = smoothed_ce(logits, y)
+    out = {'logits': logits, 'mean_loss': mean_loss, 'acc': acc, 'preds': preds, 'enc': enc}
+    if not want_grads:
+        return out
+    G = {'out_w': outputs.reshape(-1, C).T @ dlogits.reshape(N * T, -1), 'out_b': dlogits.reshape(N * T, -1).sum(axis=0)}
+    d = dlogits @ P['out_w'].T
+    d, G['ffn'] = ffn_bwd(c_ffn, P['ffn'], d)
+    for i in reversed(range(blocks)):
+        d, _, G['mha%d' % i] = mha_bwd(caches[i], P['mha%d' % i], d, self_attn=True)
+    G['emb'] = embedding_bwd(P['emb'].shape, x, d, zero_pad=True, scale=True)
+    G['pos'] = embedding_bwd(P['pos'].shape, pos, d, zero_pad=False, scale=False)
+    out['grads'] = G
+    return out
+
+
+# ----------------------------------------------------------------- end2end enc-dec (model.py:267-370)
+def init_e2e(din, vout, C, heads, blocks, pos_max, seed=0, perturb=False, tie=True):
+    rng = np.random.default_rng(seed)
+    P = {'in_w': _glorot(rng, (din, C)), 'in_b': np.zeros(C), 'in_ln_g': np.ones(C), 'in_ln_b': np.zeros(C),
+         'enc_pe': _glorot(rng, (pos_max, C)), 'dec_pe': _glorot(rng, (pos_max, C)), 'dec_input': _glorot(rng, (vout, C)),
+         'out_w': _glorot(rng, (C, vout)), 'out_b': np.zeros(vout)}
+    if perturb:
+        P['in_b'] = 0.1 * rng.standard_normal(C); P['out_b'] = 0.1 * rng.standard_normal(vout)
+        P['in_ln_g'] = 1 + 0.1 * rng.standard_normal(C); P['in_ln_b'] = 0.1 * rng.standard_normal(C)
+    for i in range(blocks):
+        P['enc%d' % i] = init_mha(rng, C, perturb)
+        d = init_mha(rng, C, perturb)
+        if tie:      # decoder block i re-uses encoder block i's dense kernels; LN params stay distinct
+            for k in ('wq', 'wk', 'wv', 'wo'):
+                d[k] = P['enc%d' % i][k]
+        P['dec%d' % i] = d
+    P['enc_ffn'] = init_ffn(rng, C, 4 * C, perturb)
+    P['dec_ffn'] = init_ffn(rng, C, 4 * C, perturb)
+    if tie:
+        for k in ('w1', 'b1', 'w2', 'b2'):
+            P['dec_ffn'][k] = P['enc_ffn'][k]
+    return P
+
+
+def e2e_step(P, x_feat, y_in, y_tgt, heads, blocks, tie=True, want_grads=True):
+    """x_feat [N,T,Din] (the flattened pre_net output fed to embedding_input), y_in/y_tgt [N,L]."""
+    N, T, Din = x_feat.shape
+    C = P['in_w'].shape[1]
+    L = y_in.shape[1]
+    u = np.maximum(x_feat @ P['in_w'] + P['in_b'], 0)
+    iv, c_inln = layer_norm(u, P['in_ln_g'], P['in_ln_b'])
+    posx = np.broadcast_to(np.arange(T)[None, :], (N, T))
+    enc = iv + embedding(P['enc_pe'], posx, False, False)
+    posy = np.broadcast_to(np.arange(L)[None, :], (N, L))
+    dec = embedding(P['dec_input'], y_in, False, False) + embedding(P['dec_pe'], posy, False, False)
+    ce = []
+    for i in range(blocks):
+        enc, c = mha_fwd(enc, enc, P['enc%d' % i], heads, causal=False)
+        ce.append(c)
+    memory, c_effn = ffn_fwd(enc, P['enc_ffn'])
+    cd = []
+    for i in range(blocks):
+        dec, c = mha_fwd(dec, memory, P['dec%d' % i], heads, causal=True)
+        cd.append(c)
+    outputs, c_dffn = ffn_fwd(dec, P['dec_ffn'])
+    logits = outputs @ P['out_w'] + P['out_b']
+    mean_loss, acc, preds, loss, dlogits = smoothed_ce(logits, y_tgt)
+    out = {'logits': logits, 'mean_loss': mean_loss, 'acc': acc, 'preds': preds, 'memory': memory}
+    if not want_grads:
+        return out
+    G = {'out_w': outputs.reshape(-1, C).T @ dlogits.reshape(N * L, -1), 'out_b': dlogits.reshape(N * L, -1).sum(axis=0)}
+    d = dlogits @ P['out_w'].T
+    d, G['dec_ffn'] = ffn_bwd(c_dffn, P['dec_ffn'], d)
+    dmem = np.zeros_like(memory)
+    for i in reversed(range(blocks)):
+        d, dk, G['dec%d' % i] = mha_bwd(cd[i], P['dec%d' % i], d, self_attn=False)
+        dmem += dk
+    G['dec_input'] = embedding_bwd(P['dec_input'].shape, y_in, d, False, False)
+    G['dec_pe'] = embedding_bwd(P['dec_pe'].shape, posy, d, False, False)
+    de, G['enc_ffn'] = ffn_bwd(c_effn, P['enc_ffn'], dmem)
+    for i in reversed(range(blocks)):
+        de, _, G['enc%d' % i] = mha_bwd(ce[i], P['enc%d' % i], de, self_attn=True)
+    G['enc_pe'] = embedding_bwd(P['enc_pe'].shape, posx, de, False, False)
+    du, G['in_ln_g'], G['in_ln_b'] = layer_norm_bwd(c_inln, P['in_ln_g'], de)
+    du = du * (u > 0)
+    G['in_w'] = x_feat.reshape(-1, Din).T @ du.reshape(-1, C)
+    G['in_b'] = du.reshape(-1, C).sum(axis=0)
+    if tie:          # shared tensors receive the sum of both uses
+        for i in range(blocks):
+            for k in ('wq', 'wk', 'wv', 'wo'):
+                s = G['enc%d' % i][k] + G['dec%d' % i][k]
+                G['enc%d' % i][k] = s; G['dec%d' % i][k] = s
+        for k in ('w1', 'b1', 'w2', 'b2'):
+            s = G['enc_ffn'][k] + G['dec_ffn'][k]
+            G['enc_ffn'][k] = s; G['dec_ffn'][k] = s
+    out['grads'] = G
+    return out
