@@ -1,0 +1,601 @@
+// Transformer pieces of end2end/transformer.py on gfx950:
+//   * fused multi-head attention forward / backward on the fp32 MFMA pipe with the reference's
+//     mask semantics (key mask = zero rows of the per-head K, fill value -2^32+1, optional
+//     lower-triangular mask, query mask applied after the softmax): scores never touch HBM;
+//   * (residual add +) LayerNorm forward / backward (eps 1e-8, biased variance);
+//   * embedding gather (+ sqrt(d) scale, zero_pad row, learned position table) and its
+//     deterministic scatter (sorted index lists from the host: no float atomics);
+//   * label-smoothed softmax cross-entropy with the reference's masking (-1 targets count).
+// The projection / FFN / vocabulary GEMMs are the 1-tap tap_gemm / tap_wgrad kernels.
+//
+// Attention layout trick: the score tile is computed TRANSPOSED, S^T = K.Q^T (keys in
+// registers, query on the lane), so the row max / row sum of the online softmax are
+// lane-local (+1 exchange between the two half-waves), and the P tile sits in exactly the
+// register layout the next MFMA needs as its B operand (contraction index = register
+// index): P never moves between lanes or through LDS.
+#include "asr_common.h"
+#include "reduce.h"
+#include <math.h>
+
+namespace {
+
+constexpr float MASK_FILL = -4294967296.0f;     // float32(-2**32 + 1)
+constexpr int DH = 64;                          // head width (hidden_units / num_heads = 512 / 8)
+constexpr int KP = DH + 4;                      // LDS pitch of tiles read with ds_read_b128
+
+__device__ __forceinline__ int rowidx(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
+
+// stage a [rows x 64] head slice of X[n][t][C] into LDS with pitch KP; rows beyond T are zero.
+// 16 consecutive lanes own one row, so a 16-lane xor-reduction gives per-row statistics.
+__device__ __forceinline__ void stage_tile(float* dst, const float* __restrict__ X, long base_row, int row0, int nrows,
+                                           int T, int C, int hoff, int tid, float scale, float* rowstat, int stat_mode) {
+    for (int f = tid; f < nrows * 16; f += 256) {
+        const int row = f >> 4, c4 = f & 15;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + row < T) v = *(const float4*)(X + (base_row + row0 + row) * C + hoff + c4 * 4);
+        if (rowstat) {
+            float s = (stat_mode == 0) ? (v.x + v.y + v.z + v.w) : (fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w));
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (c4 == 0) rowstat[row] = s;
+        }
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        *(float4*)(dst + row * KP + c4 * 4) = v;
+    }
+}
+
+// write a wave's transposed accumulator tile (rows = d in registers, column = token on the lane)
+// to X[n][tok][hoff + d] through an LDS transpose so the global stores are whole rows.
+__device__ __forceinline__ void store_tile_T(float* __restrict__ X, float* scratch, const floatx16 (&acc)[2], float mul_lane,
+                                             long base_row, int tok0, int T, int C, int hoff, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) scratch[li * 65 + dt * 32 + rowidx(r, lh)] = acc[dt][r] * mul_lane;
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes are done (wave-private region)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4), c4 = lane & 15;
+        if (tok0 + row < T) {
+            const float* s = scratch + row * 65 + c4 * 4;
+            *(float4*)(X + (base_row + tok0 + row) * C + hoff + c4 * 4) = make_float4(s[0], s[1], s[2], s[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ attention forward
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                       const float* __restrict__ V, float* __restrict__ O,
+                                                       float* __restrict__ lse, int Tq, int Tk, int C, int H) {
+    __shared__ __attribute__((aligned(16))) float kv_lds[2 * 64 * KP];   // also the epilogue's transpose scratch
+    float* Ks = kv_lds;
+    float* Vs = kv_lds + 64 * KP;
+    __shared__ float kstat[64];
+    static_assert(4 * 32 * 65 <= 2 * 64 * KP, "transpose scratch must fit in the K/V tiles");
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
+    const int head = blockIdx.y, n = blockIdx.z, hoff = head * DH;
+    const int q0 = blockIdx.x * 128 + wave * 32, q = q0 + li;
+    const long qbase = (long)n * Tq, kbase = (long)n * Tk;
+
+    float qreg[32];
+    float qabs = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < Tq) v = *(const float4*)(Q + (qbase + q) * C + hoff + 8 * g + 4 * lh);
+        qabs += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
+        qreg[g * 4 + 0] = v.x * 0.125f; qreg[g * 4 + 1] = v.y * 0.125f;
+        qreg[g * 4 + 2] = v.z * 0.125f; qreg[g * 4 + 3] = v.w * 0.125f;
+    }
+    qabs += __shfl_xor(qabs, 32, 64);
+    const float qmask = (qabs != 0.f) ? 1.f : 0.f;
+
+    floatx16 oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+
+    for (int k0 = 0; k0 < Tk; k0 += 64) {
+        __syncthreads();
+        stage_tile(Ks, K, kbase, k0, 64, Tk, C, hoff, tid, 1.f, kstat, 0);
+        stage_tile(Vs, V, kbase, k0, 64, Tk, C, hoff, tid, 1.f, nullptr, 0);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            floatx16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 kv = *(const float4*)(Ks + (sub * 32 + li) * KP + 8 * g + 4 * lh);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qreg[g * 4 + 0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qreg[g * 4 + 1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qreg[g * 4 + 2], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qreg[g * 4 + 3], s, 0, 0, 0);
+            }
+            float mt = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = sub * 32 + rowidx(r, lh), key = k0 + kl;
+                float v = s[r];
+                const bool keep = (kstat[kl] != 0.f) && (!CAUSAL || key <= q);
+                v = keep ? v : MASK_FILL;
+                v = (key < Tk) ? v : -INFINITY;
+                s[r] = v;
+                mt = fmaxf(mt, v);
+            }
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = expf(m_run - m_new);
+            float lt = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_new); lt += s[r]; }
+            lt += __shfl_xor(lt, 32, 64);
+            l_run = l_run * alpha + lt;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* vrow = Vs + (sub * 32 + rowidx(r, lh)) * KP + li;
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], s[r], oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], s[r], oacc[1], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    if (q < Tq && lh == 0) lse[((long)n * H + head) * Tq + q] = m_run + logf(l_run);
+    store_tile_T(O, Ks + wave * (32 * 65), oacc, qmask / l_run, qbase, q0, Tq, C, hoff, lane);
+}
+
+// delta[n][head][q] = sum_d dO*O  (one 16-lane group per (q, head))
+__global__ void attn_delta_kernel(const float* __restrict__ O, const float* __restrict__ dO, float* __restrict__ delta,
+                                  int N, int Tq, int C, int H) {
+    const long gid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int c4 = threadIdx.x & 15;
+    const long total = (long)N * Tq * H;
+    float s = 0.f;
+    if (gid < total) {
+        const int head = (int)(gid % H);
+        const long row = gid / H;                       // n*Tq + q
+        const float4 a = *(const float4*)(O + row * C + head * DH + c4 * 4);
+        const float4 b = *(const float4*)(dO + row * C + head * DH + c4 * 4);
+        s = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (gid < total && c4 == 0) {
+        const int head = (int)(gid % H);
+        const long row = gid / H;
+        const int n = (int)(row / Tq), q = (int)(row - (long)n * Tq);
+        delta[((long)n * H + head) * Tq + q] = s;
+    }
+}
+
+// ------------------------------------------------------------------ attention backward: dK, dV
+// One wave owns 32 keys (K, V in registers); the block walks the queries in tiles of 32.
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                          const float* __restrict__ V, const float* __restrict__ dO,
+                                                          const float* __restrict__ lse, const float* __restrict__ delta,
+                                                          float* __restrict__ dK, float* __restrict__ dV,
+                                                          int Tq, int Tk, int C, int H) {
+    __shared__ __attribute__((aligned(16))) float Qs[32 * KP];
+    __shared__ __attribute__((aligned(16))) float Ds[32 * KP];
+    __shared__ float qstat[32];
+    __shared__ float lse_s[32], del_s[32];
+    __shared__ float scratch[4 * 32 * 65];
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
+    const int head = blockIdx.y, n = blockIdx.z, hoff = head * DH;
+    const int k0 = blockIdx.x * 128 + wave * 32, key = k0 + li;
+    const long qbase = (long)n * Tq, kbase = (long)n * Tk;
+
+    float kreg[32], vreg[32];
+    float ksum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (key < Tk) {
+            a = *(const float4*)(K + (kbase + key) * C + hoff + 8 * g + 4 * lh);
+            b = *(const float4*)(V + (kbase + key) * C + hoff + 8 * g + 4 * lh);
+        }
+        ksum += a.x + a.y + a.z + a.w;
+        kreg[g * 4 + 0] = a.x; kreg[g * 4 + 1] = a.y; kreg[g * 4 + 2] = a.z; kreg[g * 4 + 3] = a.w;
+        vreg[g * 4 + 0] = b.x; vreg[g * 4 + 1] = b.y; vreg[g * 4 + 2] = b.z; vreg[g * 4 + 3] = b.w;
+    }
+    ksum += __shfl_xor(ksum, 32, 64);
+    const bool kkeep = (ksum != 0.f);
+
+    floatx16 dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+
+    for (int q0 = 0; q0 < Tq; q0 += 32) {
+        __syncthreads();
+        stage_tile(Qs, Q, qbase, q0, 32, Tq, C, hoff, tid, 1.f, qstat, 1);
+        if (tid < 32) {
+            const int q = q0 + tid;
+            lse_s[tid] = (q < Tq) ? lse[((long)n * H + head) * Tq + q] : INFINITY;
+            del_s[tid] = (q < Tq) ? delta[((long)n * H + head) * Tq + q] : 0.f;
+        }
+        __syncthreads();
+        // dO' = qmask * dO  (the query mask multiplies the post-softmax matrix)
+        for (int f = tid; f < 32 * 16; f += 256) {
+            const int row = f >> 4, c4 = f & 15;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q0 + row < Tq && qstat[row] != 0.f) v = *(const float4*)(dO + (qbase + q0 + row) * C + hoff + c4 * 4);
+            *(float4*)(Ds + row * KP + c4 * 4) = v;
+        }
+        __syncthreads();
+        floatx16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 qv = *(const float4*)(Qs + li * KP + 8 * g + 4 * lh);
+            const float4 dv4 = *(const float4*)(Ds + li * KP + 8 * g + 4 * lh);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.x, kreg[g * 4 + 0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.y, kreg[g * 4 + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.z, kreg[g * 4 + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.w, kreg[g * 4 + 3], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.x, vreg[g * 4 + 0], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.y, vreg[g * 4 + 1], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.z, vreg[g * 4 + 2], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.w, vreg[g * 4 + 3], dp, 0, 0, 0);
+        }
+        // rows of s/dp = queries rowidx(r, lh), column = this lane's key
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ql = rowidx(r, lh), q = q0 + ql;
+            const bool keep = kkeep && (!CAUSAL || key <= q);
+            const float sv = keep ? s[r] * 0.125f : MASK_FILL;
+            const float p = (key < Tk) ? expf(sv - lse_s[ql]) : 0.f;
+            const float ds = keep ? p * (dp[r] - del_s[ql]) * 0.125f : 0.f;
+            s[r] = p; dp[r] = ds;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float* drow = Ds + rowidx(r, lh) * KP + li;
+            const float* qrow = Qs + rowidx(r, lh) * KP + li;
+            dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[0], s[r], dv[0], 0, 0, 0);
+            dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[32], s[r], dv[1], 0, 0, 0);
+            dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[0], dp[r], dk[0], 0, 0, 0);
+            dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[32], dp[r], dk[1], 0, 0, 0);
+        }
+    }
+    store_tile_T(dK, scratch + wave * (32 * 65), dk, 1.f, kbase, k0, Tk, C, hoff, lane);
+    store_tile_T(dV, scratch + wave * (32 * 65), dv, 1.f, kbase, k0, Tk, C, hoff, lane);
+}
+
+// ------------------------------------------------------------------ attention backward: dQ
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+                                                         const float* __restrict__ V, const float* __restrict__ dO,
+                                                         const float* __restrict__ lse, const float* __restrict__ delta,
+                                                         float* __restrict__ dQ, int Tq, int Tk, int C, int H) {
+    __shared__ __attribute__((aligned(16))) float kv_lds[2 * 64 * KP];   // also the epilogue's transpose scratch
+    float* Ks = kv_lds;
+    float* Vs = kv_lds + 64 * KP;
+    __shared__ float kstat[64];
+    static_assert(4 * 32 * 65 <= 2 * 64 * KP, "transpose scratch must fit in the K/V tiles");
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
+    const int head = blockIdx.y, n = blockIdx.z, hoff = head * DH;
+    const int q0 = blockIdx.x * 128 + wave * 32, q = q0 + li;
+    const long qbase = (long)n * Tq, kbase = (long)n * Tk;
+
+    float qreg[32], doreg[32];
+    float qabs = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (q < Tq) {
+            a = *(const float4*)(Q + (qbase + q) * C + hoff + 8 * g + 4 * lh);
+            b = *(const float4*)(dO + (qbase + q) * C + hoff + 8 * g + 4 * lh);
+        }
+        qabs += fabsf(a.x) + fabsf(a.y) + fabsf(a.z) + fabsf(a.w);
+        qreg[g * 4 + 0] = a.x * 0.125f; qreg[g * 4 + 1] = a.y * 0.125f; qreg[g * 4 + 2] = a.z * 0.125f; qreg[g * 4 + 3] = a.w * 0.125f;
+        doreg[g * 4 + 0] = b.x; doreg[g * 4 + 1] = b.y; doreg[g * 4 + 2] = b.z; doreg[g * 4 + 3] = b.w;
+    }
+    qabs += __shfl_xor(qabs, 32, 64);
+    const float qmask = (qabs != 0.f) ? 1.f : 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) doreg[i] *= qmask;
+    const float my_lse = (q < Tq) ? lse[((long)n * H + head) * Tq + q] : INFINITY;
+    const float my_del = (q < Tq) ? delta[((long)n * H + head) * Tq + q] : 0.f;
+
+    floatx16 dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+
+    for (int k0 = 0; k0 < Tk; k0 += 64) {
+        __syncthreads();
+        stage_tile(Ks, K, kbase, k0, 64, Tk, C, hoff, tid, 1.f, kstat, 0);
+        stage_tile(Vs, V, kbase, k0, 64, Tk, C, hoff, tid, 1.f, nullptr, 0);
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            floatx16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 kv = *(const float4*)(Ks + (sub * 32 + li) * KP + 8 * g + 4 * lh);
+                const float4 vv = *(const float4*)(Vs + (sub * 32 + li) * KP + 8 * g + 4 * lh);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qreg[g * 4 + 0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qreg[g * 4 + 1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qreg[g * 4 + 2], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qreg[g * 4 + 3], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, doreg[g * 4 + 0], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.y, doreg[g * 4 + 1], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.z, doreg[g * 4 + 2], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.w, doreg[g * 4 + 3], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = sub * 32 + rowidx(r, lh), key = k0 + kl;
+                const bool keep = (kstat[kl] != 0.f) && (!CAUSAL || key <= q);
+                const float sv = keep ? s[r] : MASK_FILL;
+                const float p = (key < Tk) ? expf(sv - my_lse) : 0.f;
+                dp[r] = keep ? p * (dp[r] - my_del) * 0.125f : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* krow = Ks + (sub * 32 + rowidx(r, lh)) * KP + li;
+                dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[0], dp[r], dq[0], 0, 0, 0);
+                dq[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[32], dp[r], dq[1], 0, 0, 0);
+            }
+        }
+    }
+    __syncthreads();
+    store_tile_T(dQ, Ks + wave * (32 * 65), dq, 1.f, qbase, q0, Tq, C, hoff, lane);
+}
+
+// ------------------------------------------------------------------ (add +) LayerNorm
+// one wave per row; y = gamma * (x - mean) / sqrt(var + eps) + beta with x = a (+ b)
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         int rows, int C, float eps, float* __restrict__ y,
+                                                         float* __restrict__ xhat, float* __restrict__ rstd) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* pa = a + (long)row * C;
+    const float* pb = b ? b + (long)row * C : nullptr;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += pa[c] + (pb ? pb[c] : 0.f);
+    const float mean = asr_wave_sum(s) / (float)C;
+    float v = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = pa[c] + (pb ? pb[c] : 0.f) - mean; v += d * d; }
+    const float var = asr_wave_sum(v) / (float)C;
+    const float rs = 1.f / sqrtf(var + eps);
+    if (lane == 0) rstd[row] = rs;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (pa[c] + (pb ? pb[c] : 0.f) - mean) * rs;
+        xhat[(long)row * C + c] = xh;
+        y[(long)row * C + c] = gamma[c] * xh + beta[c];
+    }
+}
+
+constexpr int kLnRows = 64;     // rows per block in the backward (block partials for dgamma/dbeta)
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma;  partials[blk][2][C] = sum dy*xhat, sum dy
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                     int rows, int C, float* __restrict__ dx, int accumulate,
+                                                     float* __restrict__ partials) {
+    extern __shared__ float sm[];        // [4 waves][2][C]
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* mine = sm + wave * 2 * C;
+    for (int c = lane; c < 2 * C; c += 64) mine[c] = 0.f;
+    const int r0 = blockIdx.x * kLnRows;
+    for (int rr = wave; rr < kLnRows; rr += 4) {
+        const int row = r0 + rr;
+        if (row >= rows) break;
+        const float* pdy = dy + (long)row * C;
+        const float* pxh = xhat + (long)row * C;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = lane; c < C; c += 64) { const float g = pdy[c] * gamma[c]; s1 += g; s2 += g * pxh[c]; }
+        s1 = asr_wave_sum(s1) / (float)C;
+        s2 = asr_wave_sum(s2) / (float)C;
+        const float rs = rstd[row];
+        for (int c = lane; c < C; c += 64) {
+            const float d = pdy[c], xh = pxh[c];
+            float v = rs * (d * gamma[c] - s1 - xh * s2);
+            float* o = dx + (long)row * C + c;
+            if (accumulate) v += *o;
+            *o = v;
+            mine[c] += d * xh;
+            mine[C + c] += d;
+        }
+    }
+    __syncthreads();
+    float* out = partials + (long)blockIdx.x * 2 * C;
+    for (int c = threadIdx.x; c < 2 * C; c += 256) out[c] = (sm[c] + sm[2 * C + c]) + (sm[4 * C + c] + sm[6 * C + c]);
+}
+
+// ------------------------------------------------------------------ embedding
+__global__ void embed_fwd_kernel(const float* __restrict__ table, const int32_t* __restrict__ ids,
+                                 const float* __restrict__ pos, int N, int T, int C, int zero_pad, float scale,
+                                 float* __restrict__ out) {
+    const int C4 = C >> 2;
+    const long total = (long)N * T * C4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        const long row = i / C4;
+        const int t = (int)(row % T);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (table) {
+            const int id = ids[row];
+            if (!(zero_pad && id == 0)) v = *(const float4*)(table + (long)id * C + c4 * 4);
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        }
+        if (pos) {
+            const float4 p = *(const float4*)(pos + (long)t * C + c4 * 4);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        *(float4*)(out + row * C + c4 * 4) = v;
+    }
+}
+
+// dtable[uniq[u]] = scale * sum over the (sorted, fixed order) positions of that id
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ perm,
+                                                        const int32_t* __restrict__ uniq, const int32_t* __restrict__ seg,
+                                                        int C, int zero_pad, float scale, float* __restrict__ dtable) {
+    const int u = blockIdx.x;
+    const int id = uniq[u];
+    const int beg = seg[u], end = seg[u + 1];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int j = beg; j < end; ++j) s += dout[(long)perm[j] * C + c];
+        dtable[(long)id * C + c] = (zero_pad && id == 0) ? 0.f : s * scale;
+    }
+}
+
+// ------------------------------------------------------------------ label-smoothed CE
+// one wave per row.  loss = (sum ys)*lse - sum ys*logit, ys = (1-eps)*onehot + eps/V (onehot = 0 for ids outside
+// [0,V)); dlogits = ((sum ys)*softmax - ys) * w with w = (target != pad) * inv_count.  stats row: [loss*ist, correct*ist]
+__global__ __launch_bounds__(256) void smoothed_ce_kernel(const float* __restrict__ logits, int ld, const int32_t* __restrict__ target,
+                                                          int rows, int V, float eps, int pad_id, float inv_count,
+                                                          float* __restrict__ loss_rows, int32_t* __restrict__ preds,
+                                                          float* __restrict__ stats, float* __restrict__ dlogits) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float* x = logits + (long)row * ld;
+    const int tg = target[row];
+    float m = -INFINITY; int am = 0x7fffffff;
+    float sumx = 0.f;
+    for (int k = lane; k < V; k += 64) {
+        const float v = x[k];
+        sumx += v;
+        if (v > m || am == 0x7fffffff) { m = v; am = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(m, o, 64);
+        const int ok = __shfl_xor(am, o, 64);
+        if (ov > m || (ov == m && ok < am)) { m = ov; am = ok; }
+    }
+    sumx = asr_wave_sum(sumx);
+    float se = 0.f;
+    for (int k = lane; k < V; k += 64) se += expf(x[k] - m);
+    se = asr_wave_sum(se);
+    const float lse = m + logf(se);
+    const bool valid = tg >= 0 && tg < V;
+    const float ysum = (valid ? (1.f - eps) : 0.f) + eps;
+    const float xt = valid ? x[tg] : 0.f;
+    const float loss = ysum * lse - (valid ? (1.f - eps) * xt : 0.f) - (eps / (float)V) * sumx;
+    const float ist = (tg != pad_id) ? 1.f : 0.f;
+    if (lane == 0) {
+        loss_rows[row] = loss;
+        preds[row] = am;
+        stats[(long)row * 2] = loss * ist;
+        stats[(long)row * 2 + 1] = (am == tg) ? ist : 0.f;
+    }
+    if (dlogits) {
+        const float w = ist * inv_count;
+        float* d = dlogits + (long)row * ld;
+        for (int k = lane; k < ld; k += 64) {
+            float g = 0.f;
+            if (k < V) {
+                const float ys = eps / (float)V + ((valid && k == tg) ? (1.f - eps) : 0.f);
+                g = (ysum * expf(x[k] - lse) - ys) * w;
+            }
+            d[k] = g;
+        }
+    }
+}
+
+inline int grid_for(long total, int threads) {
+    long b = (total + threads - 1) / threads;
+    return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+// ===================================================================== C ABI
+extern "C" int asr_attention_fwd(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
+                                 int causal, float* O, float* lse, void* stream) {
+    if (!Q || !K || !V || !O || !lse || N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
+    dim3 grid(asr_cdiv(Tq, 128), H, N);
+    hipStream_t st = (hipStream_t)stream;
+    if (causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H);
+    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H);
+    ASR_CHECK_LAUNCH("attention_fwd");
+    return ASR_OK;
+}
+
+extern "C" int asr_attention_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                                 const float* lse, int N, int Tq, int Tk, int C, int H, int causal,
+                                 float* dQ, float* dK, float* dV, float* delta_ws, void* stream) {
+    if (!Q || !K || !V || !O || !dO || !lse || !dQ || !dK || !dV || !delta_ws) return ASR_ERR_BAD_ARG;
+    if (N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const long groups = (long)N * Tq * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3(asr_cdiv(groups * 16, 256)), dim3(256), 0, st, O, dO, delta_ws, N, Tq, C, H);
+    dim3 gkv(asr_cdiv(Tk, 128), H, N), gq(asr_cdiv(Tq, 128), H, N);
+    if (causal) {
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<true>, gkv, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dK, dV, Tq, Tk, C, H);
+        hipLaunchKernelGGL(attn_bwd_q_kernel<true>, gq, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dQ, Tq, Tk, C, H);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<false>, gkv, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dK, dV, Tq, Tk, C, H);
+        hipLaunchKernelGGL(attn_bwd_q_kernel<false>, gq, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dQ, Tq, Tk, C, H);
+    }
+    ASR_CHECK_LAUNCH("attention_bwd");
+    return ASR_OK;
+}
+
+extern "C" int asr_add_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, int rows, int C,
+                                     float eps, float* y, float* xhat, float* rstd, void* stream) {
+    if (!a || !gamma || !beta || !y || !xhat || !rstd || rows < 1 || C < 1) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(add_ln_fwd_kernel, dim3(asr_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, a, b, gamma, beta, rows, C, eps, y, xhat, rstd);
+    ASR_CHECK_LAUNCH("add_layernorm_fwd");
+    return ASR_OK;
+}
+
+extern "C" size_t asr_layernorm_bwd_workspace(int rows, int C) {
+    const size_t nblk = (size_t)asr_cdiv(rows, kLnRows);
+    return (nblk * 2 * C + asr_reduce::colsum_tmp_floats((int)nblk, 2 * C) + 16) * sizeof(float);
+}
+
+extern "C" int asr_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int C,
+                                 float* dx, int accumulate, float* dgamma, float* dbeta, float* partials, void* stream) {
+    if (!dy || !xhat || !rstd || !gamma || !dx || !dgamma || !dbeta || !partials || rows < 1 || C < 1) return ASR_ERR_BAD_ARG;
+    if ((size_t)8 * C * sizeof(float) > 64 * 1024) return ASR_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = asr_cdiv(rows, kLnRows);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials);
+    ASR_CHECK_LAUNCH("layernorm_bwd");
+    float* tmp = partials + (size_t)nblk * 2 * C;
+    int rc;
+    if ((rc = asr_reduce::colsum(partials, nblk, C, 2 * C, dgamma, tmp, st))) return rc;
+    if ((rc = asr_reduce::colsum(partials + C, nblk, C, 2 * C, dbeta, tmp, st))) return rc;
+    return ASR_OK;
+}
+
+extern "C" int asr_embed_fwd(const float* table, const int32_t* ids, const float* pos, int N, int T, int C,
+                             int zero_pad, float scale, float* out, void* stream) {
+    if ((!table && !pos) || (table && !ids) || !out || (C & 3) || N < 1 || T < 1) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(grid_for((long)N * T * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream, table, ids, pos, N, T, C, zero_pad, scale, out);
+    ASR_CHECK_LAUNCH("embed_fwd");
+    return ASR_OK;
+}
+
+extern "C" int asr_embed_bwd(const float* dout, const int32_t* perm, const int32_t* uniq, const int32_t* seg, int n_uniq,
+                             int C, int zero_pad, float scale, float* dtable, void* stream) {
+    if (!dout || !perm || !uniq || !seg || !dtable || n_uniq < 0) return ASR_ERR_BAD_ARG;
+    if (n_uniq == 0) return ASR_OK;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(n_uniq), dim3(256), 0, (hipStream_t)stream, dout, perm, uniq, seg, C, zero_pad, scale, dtable);
+    ASR_CHECK_LAUNCH("embed_bwd");
+    return ASR_OK;
+}
+
+extern "C" int asr_smoothed_ce(const float* logits, int ld, const int32_t* target, int rows, int V, float eps, int pad_id,
+                               float inv_count, float* loss_rows, int32_t* preds, float* stats, float* dlogits, void* stream) {
+    if (!logits || !target || !loss_rows || !preds || !stats || rows < 1 || V < 1 || ld < V) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(smoothed_ce_kernel, dim3(asr_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, rows, V, eps, pad_id, inv_count, loss_rows, preds, stats, dlogits);
+    ASR_CHECK_LAUNCH("smoothed_ce");
+    return ASR_OK;
+}

@@ -237,3 +237,45 @@ def fbank(signal, nsamples, frame_len, frame_step, nfft, preemph, nfilt, fb_star
     check(_lib.load().asr_fbank(_ptr(signal), _ptr(nsamples), B, max_samples, frame_len, frame_step, nfft, preemph,
                                 nfilt, _ptr(fb_start), _ptr(fb_count), _ptr(fb_weight), fb_width, _ptr(twiddle),
                                 _ptr(logfb), max_frames, _ptr(out), t_pad, _ptr(frames), _stream()), 'asr_fbank')
+
+
+# ------------------------------------------------------------------ Transformer path
+def attention_fwd(Q, K, V, N, Tq, Tk, Cc, H, causal, O, lse):
+    check(_lib.load().asr_attention_fwd(_ptr(Q), _ptr(K), _ptr(V), N, Tq, Tk, Cc, H, int(causal), _ptr(O), _ptr(lse),
+                                        _stream()), 'asr_attention_fwd')
+
+
+def attention_bwd(Q, K, V, O, dO, lse, N, Tq, Tk, Cc, H, causal, dQ, dK, dV, delta_ws):
+    check(_lib.load().asr_attention_bwd(_ptr(Q), _ptr(K), _ptr(V), _ptr(O), _ptr(dO), _ptr(lse), N, Tq, Tk, Cc, H,
+                                        int(causal), _ptr(dQ), _ptr(dK), _ptr(dV), _ptr(delta_ws), _stream()),
+          'asr_attention_bwd')
+
+
+def add_layernorm_fwd(a, b, gamma, beta, rows, Cc, eps, y, xhat, rstd):
+    check(_lib.load().asr_add_layernorm_fwd(_ptr(a), _ptr(b), _ptr(gamma), _ptr(beta), rows, Cc, eps, _ptr(y),
+                                            _ptr(xhat), _ptr(rstd), _stream()), 'asr_add_layernorm_fwd')
+
+
+def layernorm_bwd_workspace(rows, Cc):
+    return _lib.load().asr_layernorm_bwd_workspace(rows, Cc)
+
+
+def layernorm_bwd(dy, xhat, rstd, gamma, rows, Cc, dx, accumulate, dgamma, dbeta, partials):
+    check(_lib.load().asr_layernorm_bwd(_ptr(dy), _ptr(xhat), _ptr(rstd), _ptr(gamma), rows, Cc, _ptr(dx),
+                                        int(accumulate), _ptr(dgamma), _ptr(dbeta), _ptr(partials), _stream()),
+          'asr_layernorm_bwd')
+
+
+def embed_fwd(table, ids, pos, N, T, Cc, zero_pad, scale, out):
+    check(_lib.load().asr_embed_fwd(_ptr(table), _ptr(ids), _ptr(pos), N, T, Cc, int(zero_pad), scale, _ptr(out),
+                                    _stream()), 'asr_embed_fwd')
+
+
+def embed_bwd(dout, perm, uniq, seg, n_uniq, Cc, zero_pad, scale, dtable):
+    check(_lib.load().asr_embed_bwd(_ptr(dout), _ptr(perm), _ptr(uniq), _ptr(seg), n_uniq, Cc, int(zero_pad), scale,
+                                    _ptr(dtable), _stream()), 'asr_embed_bwd')
+
+
+def smoothed_ce(logits, ld, target, rows, V, eps, pad_id, inv_count, loss_rows, preds, stats, dlogits):
+    check(_lib.load().asr_smoothed_ce(_ptr(logits), ld, _ptr(target), rows, V, eps, pad_id, inv_count, _ptr(loss_rows),
+                                      _ptr(preds), _ptr(stats), _ptr(dlogits), _stream()), 'asr_smoothed_ce')

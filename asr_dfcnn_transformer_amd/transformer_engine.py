@@ -1,0 +1,498 @@
+"""Host-side engines of the Transformer path: ``LMEngine`` (the pinyin->hanzi
+``Language_Model`` of lm_and_am/model/language_model.py:22-78) and ``E2EEngine`` (the
+encoder-decoder of end2end/model.py:267-370).  They own flat parameter / gradient / Adam
+buffers and activation tensors and enqueue libasrhip kernels; no arithmetic happens here.
+
+Live graph as written in the reference: in every block loop the FFN result is
+stored in a different attribute than the one the next block reads, so N stacked MHA
+sub-layers and ONE live FFN (the last block's) remain; the decoder block is a single
+causal cross-attention.  Projections are Dense(relu, no bias).  ``tie`` (default on)
+re-uses encoder block i's dense kernels in decoder block i (variable-scope reuse, Q8).
+Dropout: identity (parity mode).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+
+LN_EPS = 1e-8
+SMOOTH_EPS = 0.1
+
+
+def sorted_segments(ids):
+    """Positions sorted by id (stable) + segment table, for the deterministic embedding scatter."""
+    flat = np.asarray(ids).reshape(-1)
+    perm = np.argsort(flat, kind='stable').astype(np.int32)
+    sv = flat[perm]
+    uniq, start = np.unique(sv, return_index=True)
+    seg = np.concatenate([start, [len(flat)]]).astype(np.int32)
+    return perm, uniq.astype(np.int32), seg
+
+
+def _r4(n):
+    return (n + 3) // 4 * 4
+
+
+class _Base:
+    """Flat parameter storage + block helpers shared by the two graphs."""
+
+    def __init__(self, C, heads, device, lr, beta2, decay_steps, min_lr):
+        self.C, self.H, self.device = C, heads, device
+        assert C == heads * 64, 'the attention kernels are built for 64-wide heads (512 / 8)'
+        self.entries = {}       # name -> (offset, shape)   shape = physical (padded) shape
+        self.logical = {}       # name -> logical shape
+        self._off = 0
+        self.lr0, self.beta1, self.beta2, self.adam_eps = lr, 0.9, beta2, 1e-8
+        self.decay_steps, self.min_lr = decay_steps, min_lr
+        self.global_step = 0
+
+    # ---- parameters
+    def _add(self, name, shape, phys=None):
+        phys = tuple(phys or shape)
+        self.entries[name] = (self._off, phys)
+        self.logical[name] = tuple(shape)
+        self._off += _r4(int(np.prod(phys)))
+
+    def _add_mha(self, name, share=None):
+        C = self.C
+        for k in ('wq', 'wk', 'wv', 'wo'):
+            if share is not None:
+                self.entries['%s/%s' % (name, k)] = self.entries['%s/%s' % (share, k)]
+                self.logical['%s/%s' % (name, k)] = (C, C)
+            else:
+                self._add('%s/%s' % (name, k), (C, C))
+        self._add(name + '/ln_g', (C,)); self._add(name + '/ln_b', (C,))
+
+    def _add_ffn(self, name, share=None):
+        C = self.C
+        for k, shp in (('w1', (C, 4 * C)), ('b1', (4 * C,)), ('w2', (4 * C, C)), ('b2', (C,))):
+            if share is not None:
+                self.entries['%s/%s' % (name, k)] = self.entries['%s/%s' % (share, k)]
+                self.logical['%s/%s' % (name, k)] = shp
+            else:
+                self._add('%s/%s' % (name, k), shp)
+        self._add(name + '/ln_g', (C,)); self._add(name + '/ln_b', (C,))
+
+    def _finish_params(self):
+        z = lambda: torch.zeros(self._off, dtype=torch.float32, device=self.device)
+        self.theta, self.grad, self.adam_m, self.adam_v = z(), z(), z(), z()
+        self.n_params = len({v[0] for v in self.entries.values()})
+
+    def p(self, name, buf=None):
+        off, shape = self.entries[name]
+        return (self.theta if buf is None else buf)[off:off + int(np.prod(shape))]
+
+    def g(self, name):
+        return self.p(name, self.grad)
+
+    def load_params(self, flat):
+        """flat: {name: ndarray} with logical shapes (vocabulary matrices are padded here)."""
+        host = self.theta.cpu().numpy()
+        for name, (off, phys) in self.entries.items():
+            v = np.asarray(flat[name], dtype=np.float32)
+            assert tuple(v.shape) == self.logical[name], (name, v.shape, self.logical[name])
+            buf = np.zeros(phys, dtype=np.float32)
+            buf[tuple(slice(0, s) for s in v.shape)] = v
+            host[off:off + buf.size] = buf.ravel()
+        self.theta.copy_(torch.from_numpy(host))
+
+    def grads_dict(self, buf=None):
+        host = (self.grad if buf is None else buf).cpu().numpy()
+        out = {}
+        for name, (off, phys) in self.entries.items():
+            a = host[off:off + int(np.prod(phys))].reshape(phys)
+            out[name] = a[tuple(slice(0, s) for s in self.logical[name])].copy()
+        return out
+
+    def params_dict(self):
+        return self.grads_dict(self.theta)
+
+    def init_params(self, seed=0):
+        """xavier/glorot-uniform matrices, zero biases, LayerNorm gamma 1 / beta 0."""
+        rng = np.random.default_rng(seed)
+        flat, seen = {}, {}
+        for name, (off, phys) in self.entries.items():
+            shp = self.logical[name]
+            if off in seen:
+                flat[name] = flat[seen[off]]
+                continue
+            seen[off] = name
+            if len(shp) == 2:
+                lim = math.sqrt(6.0 / (shp[0] + shp[1]))
+                flat[name] = rng.uniform(-lim, lim, shp)
+            elif name.endswith('ln_g'):
+                flat[name] = np.ones(shp)
+            else:
+                flat[name] = np.zeros(shp)
+        self.load_params(flat)
+
+    # ---- low-level helpers
+    def _t(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def _dense(self, x, rows, K, N, w, b, out, relu):
+        d = ops.gemm_desc(rows, K, N, K, N, 0, N, ntaps=1, relu=1 if relu else 0)
+        ops.tap_gemm(d, x, w, b, None, None, None, out)
+
+    def _dense_dgrad(self, dy, rows, K, N, w, dx, accumulate):
+        # dx[rows,K] (+)= dy[rows,N] . w[K,N]^T
+        d = ops.gemm_desc(rows, N, K, N, N, 0, K, ntaps=1, wmode=1, accumulate=1 if accumulate else 0)
+        ops.tap_gemm(d, dy, w, None, None, None, None, dx)
+
+    def _wgrad(self, x, dy, rows, K, N, name):
+        """grad[name] (+)= x^T dy; a tensor shared by two layers receives the sum."""
+        d = ops.gemm_desc(rows, K, N, K, N, ntaps=1)
+        if name_off(self, name) in self._written:
+            ops.tap_wgrad(d, x, dy, N, self._wtmp[:K * N], self.ws)
+            ops.axpy(self.g(name), self._wtmp[:K * N], 1.0, True)
+        else:
+            ops.tap_wgrad(d, x, dy, N, self.g(name), self.ws)
+            self._written.add(name_off(self, name))
+
+    def _bgrad(self, dy, rows, N, name):
+        if name_off(self, name) in self._written:
+            ops.colsum(dy, rows, N, N, self._wtmp[:N], self.ws)
+            ops.axpy(self.g(name), self._wtmp[:N], 1.0, True)
+        else:
+            ops.colsum(dy, rows, N, N, self.g(name), self.ws)
+            self._written.add(name_off(self, name))
+
+    # ---- blocks
+    def _mha_alloc(self, N, Tq, Tk):
+        C, H = self.C, self.H
+        return {'Q': self._t(N * Tq, C), 'K': self._t(N * Tk, C), 'V': self._t(N * Tk, C), 'A': self._t(N * Tq, C),
+                'Z': self._t(N * Tq, C), 'xhat': self._t(N * Tq, C), 'rstd': self._t(N * Tq), 'lse': self._t(N * H * Tq),
+                'out': self._t(N * Tq, C), 'N': N, 'Tq': Tq, 'Tk': Tk}
+
+    def _mha_fwd(self, name, st, q_in, k_in, causal):
+        C, N, Tq, Tk = self.C, st['N'], st['Tq'], st['Tk']
+        st['q_in'], st['k_in'], st['causal'] = q_in, k_in, causal
+        self._dense(q_in, N * Tq, C, C, self.p(name + '/wq'), None, st['Q'], True)
+        self._dense(k_in, N * Tk, C, C, self.p(name + '/wk'), None, st['K'], True)
+        self._dense(k_in, N * Tk, C, C, self.p(name + '/wv'), None, st['V'], True)
+        ops.attention_fwd(st['Q'], st['K'], st['V'], N, Tq, Tk, C, self.H, causal, st['A'], st['lse'])
+        self._dense(st['A'], N * Tq, C, C, self.p(name + '/wo'), None, st['Z'], True)
+        ops.add_layernorm_fwd(st['Z'], q_in, self.p(name + '/ln_g'), self.p(name + '/ln_b'), N * Tq, C, LN_EPS,
+                              st['out'], st['xhat'], st['rstd'])
+        return st['out']
+
+    def _mha_bwd(self, name, st, dout, dq_in, dq_acc, dk_in, dk_acc):
+        """dq_in (+)= dL/d(queries), dk_in (+)= dL/d(keys); dk_in may be dq_in (self-attention)."""
+        C, N, Tq, Tk = self.C, st['N'], st['Tq'], st['Tk']
+        rq, rk = N * Tq, N * Tk
+        dr, dZ, dA = self.sc['a'][:rq * C], self.sc['b'][:rq * C], self.sc['c'][:rq * C]
+        dQ, dK, dV = self.sc['d'][:rq * C], self.sc['e'][:rk * C], self.sc['f'][:rk * C]
+        ops.layernorm_bwd(dout, st['xhat'], st['rstd'], self.p(name + '/ln_g'), rq, C, dr, False,
+                          self.g(name + '/ln_g'), self.g(name + '/ln_b'), self.ws)
+        ops.axpy(dq_in, dr, 1.0, dq_acc)
+        ops.relu_bwd(dr, st['Z'], dZ)
+        self._wgrad(st['A'], dZ, rq, C, C, name + '/wo')
+        self._dense_dgrad(dZ, rq, C, C, self.p(name + '/wo'), dA, False)
+        ops.attention_bwd(st['Q'], st['K'], st['V'], st['A'], dA, st['lse'], N, Tq, Tk, C, self.H, st['causal'],
+                          dQ, dK, dV, self.ws)
+        ops.relu_bwd(dQ, st['Q'], dQ); ops.relu_bwd(dK, st['K'], dK); ops.relu_bwd(dV, st['V'], dV)
+        self._wgrad(st['q_in'], dQ, rq, C, C, name + '/wq')
+        self._wgrad(st['k_in'], dK, rk, C, C, name + '/wk')
+        self._wgrad(st['k_in'], dV, rk, C, C, name + '/wv')
+        self._dense_dgrad(dQ, rq, C, C, self.p(name + '/wq'), dq_in, True)
+        self._dense_dgrad(dK, rk, C, C, self.p(name + '/wk'), dk_in, dk_acc or (dk_in is dq_in))
+        self._dense_dgrad(dV, rk, C, C, self.p(name + '/wv'), dk_in, True)
+
+    def _ffn_alloc(self, rows):
+        C = self.C
+        return {'H': self._t(rows, 4 * C), 'Y': self._t(rows, C), 'xhat': self._t(rows, C), 'rstd': self._t(rows),
+                'out': self._t(rows, C), 'rows': rows}
+
+    def _ffn_fwd(self, name, st, x):
+        C, rows = self.C, st['rows']
+        st['x'] = x
+        self._dense(x, rows, C, 4 * C, self.p(name + '/w1'), self.p(name + '/b1'), st['H'], True)
+        self._dense(st['H'], rows, 4 * C, C, self.p(name + '/w2'), self.p(name + '/b2'), st['Y'], False)
+        ops.add_layernorm_fwd(st['Y'], x, self.p(name + '/ln_g'), self.p(name + '/ln_b'), rows, C, LN_EPS,
+                              st['out'], st['xhat'], st['rstd'])
+        return st['out']
+
+    def _ffn_bwd(self, name, st, dout, dx, dx_acc):
+        C, rows = self.C, st['rows']
+        dr = self.sc['a'][:rows * C]
+        dH = self.sc['h'][:rows * 4 * C]
+        ops.layernorm_bwd(dout, st['xhat'], st['rstd'], self.p(name + '/ln_g'), rows, C, dr, False,
+                          self.g(name + '/ln_g'), self.g(name + '/ln_b'), self.ws)
+        ops.axpy(dx, dr, 1.0, dx_acc)
+        self._bgrad(dr, rows, C, name + '/b2')
+        self._wgrad(st['H'], dr, rows, 4 * C, C, name + '/w2')
+        self._dense_dgrad(dr, rows, 4 * C, C, self.p(name + '/w2'), dH, False)
+        ops.relu_bwd(dH, st['H'], dH)
+        self._bgrad(dH, rows, 4 * C, name + '/b1')
+        self._wgrad(st['x'], dH, rows, C, 4 * C, name + '/w1')
+        self._dense_dgrad(dH, rows, C, 4 * C, self.p(name + '/w1'), dx, True)
+
+    def _alloc_scratch(self, max_rows, max_w, gemms):
+        """gemms: (rows, K, N) of every weight-gradient GEMM, to size the split-K slab workspace."""
+        C = self.C
+        self.sc = {k: self._t(max_rows * C) for k in 'abcdef'}
+        self.sc['h'] = self._t(max_rows * 4 * C)
+        self._wtmp = self._t(max_w)
+        ws = max(ops.layernorm_bwd_workspace(max_rows, C), ops.colsum_workspace(max_rows, 4 * C),
+                 ops.colsum_workspace(max_rows, self.Vp), 4 * (max_rows * self.H + 64), 1 << 20)
+        for rows, K, N in gemms:
+            ws = max(ws, ops.tap_wgrad_workspace(ops.gemm_desc(rows, K, N, K, N, ntaps=1)))
+        self.ws = self._t(ws // 4 + 64)
+
+    # ---- loss head
+    def _head_alloc(self, rows):
+        self.logits = self._t(rows, self.Vp)
+        self.dlogits = self._t(rows, self.Vp)
+        self.loss_rows = self._t(rows)
+        self.preds = self._t(rows, dtype=torch.int32)
+        self.stats = self._t(rows, 2)
+        self.stat_sum = self._t(4)
+        self.target = self._t(rows, dtype=torch.int32)
+
+    def _head_fwd(self, x, rows, target_host, train):
+        C = self.C
+        self._dense(x, rows, C, self.Vp, self.p('out_w'), self.p('out_b'), self.logits, False)
+        tg = np.ascontiguousarray(np.asarray(target_host, dtype=np.int32).reshape(-1))
+        self.target.copy_(torch.from_numpy(tg), non_blocking=True)
+        cnt = float((tg != 0).sum())
+        self._count = cnt
+        ops.smoothed_ce(self.logits, self.Vp, self.target, rows, self.V, SMOOTH_EPS, 0, 1.0 / max(cnt, 1.0),
+                        self.loss_rows, self.preds, self.stats, self.dlogits if train else None)
+        ops.colsum(self.stats, rows, 2, 2, self.stat_sum[:2], self.ws)
+
+    def _head_bwd(self, x, rows, dx):
+        C = self.C
+        self._wgrad(x, self.dlogits, rows, C, self.Vp, 'out_w')
+        self._bgrad(self.dlogits, rows, self.Vp, 'out_b')
+        self._dense_dgrad(self.dlogits, rows, C, self.Vp, self.p('out_w'), dx, False)
+
+    def fetch(self):
+        s = self.stat_sum.cpu().numpy()
+        c = max(self._count, 1.0)
+        return float(s[0]) / c, float(s[1]) / c            # mean_loss, acc
+
+    # ---- optimiser (tf.train.polynomial_decay(cycle, power 0.5) + AdamOptimizer)
+    def current_learning_rate(self, step=None):
+        step = float(self.global_step if step is None else step)
+        ds = float(self.decay_steps)
+        mult = 1.0 if step == 0 else math.ceil(step / ds)
+        return (self.lr0 - self.min_lr) * math.sqrt(max(0.0, 1.0 - step / (ds * mult))) + self.min_lr
+
+    def apply_adam(self, gscale=1.0):
+        lr = self.current_learning_rate()
+        t = self.global_step + 1
+        lr_t = lr * math.sqrt(1.0 - self.beta2 ** t) / (1.0 - self.beta1 ** t)
+        ops.adam_tf(self.theta, self.grad, self.adam_m, self.adam_v, lr_t, self.beta1, self.beta2, self.adam_eps, gscale)
+        self.global_step += 1
+        return lr
+
+
+def name_off(eng, name):
+    return eng.entries[name][0]
+
+
+class LMEngine(_Base):
+    """Language_Model (language_model.py:22-78): embedding*sqrt(d) (zero_pad) + learned positions ->
+    ``num_blocks`` causal self-attention MHA sub-layers -> one FFN -> dense(V_hanzi) ->
+    label-smoothed CE masked by y != 0; Adam(beta2 0.999) on the polynomial-decay lr_lm."""
+
+    def __init__(self, vin=1536, vout=6345, N=64, T=100, C=512, heads=8, blocks=12, pos_max=100, lr=5e-5,
+                 decay_steps=5000, min_lr=1e-6, seed=0, device='cuda'):
+        super().__init__(C, heads, device, lr, 0.999, decay_steps, min_lr)
+        assert T <= pos_max, 'positions >= position_max_length index past the table (language_model.py:29-30)'
+        self.vin, self.V, self.Vp, self.N, self.T, self.blocks, self.pos_max = vin, vout, _r4(vout), N, T, blocks, pos_max
+        self._add('emb', (vin, C)); self._add('pos', (pos_max, C))
+        for i in range(blocks):
+            self._add_mha('mha%d' % i)
+        self._add_ffn('ffn')
+        self._add('out_w', (C, vout), (C, self.Vp)); self._add('out_b', (vout,), (self.Vp,))
+        self._finish_params()
+        self.init_params(seed)
+        rows = N * T
+        self.ids = self._t(N, T, dtype=torch.int32)
+        self.x0 = self._t(rows, C)
+        self.mha = [self._mha_alloc(N, T, T) for _ in range(blocks)]
+        self.ffn = self._ffn_alloc(rows)
+        self._head_alloc(rows)
+        self.dstream = [self._t(rows * C), self._t(rows * C)]
+        self.seg = [self._t(rows, dtype=torch.int32), self._t(rows, dtype=torch.int32), self._t(rows + 1, dtype=torch.int32)]
+        self._alloc_scratch(rows, max(C * self.Vp, 4 * C * C),
+                            [(rows, C, C), (rows, C, 4 * C), (rows, 4 * C, C), (rows, C, self.Vp)])
+
+    def flat_from_oracle(self, P):
+        flat = {'emb': P['emb'], 'pos': P['pos'], 'out_w': P['out_w'], 'out_b': P['out_b']}
+        for i in range(self.blocks):
+            for k, v in P['mha%d' % i].items():
+                flat['mha%d/%s' % (i, k)] = v
+        for k, v in P['ffn'].items():
+            flat['ffn/%s' % k] = v
+        return flat
+
+    def forward(self, x_ids, y=None, train=True):
+        N, T, C = self.N, self.T, self.C
+        xi = np.ascontiguousarray(np.asarray(x_ids, dtype=np.int32))
+        assert xi.shape == (N, T)
+        self._x_host = xi
+        self.ids.copy_(torch.from_numpy(xi), non_blocking=True)
+        ops.embed_fwd(self.p('emb'), self.ids, self.p('pos'), N, T, C, True, float(C) ** 0.5, self.x0)
+        enc = self.x0
+        for i in range(self.blocks):
+            enc = self._mha_fwd('mha%d' % i, self.mha[i], enc, enc, True)
+        self.enc = enc
+        out = self._ffn_fwd('ffn', self.ffn, enc)
+        if y is not None:
+            self._head_fwd(out, N * T, y, train)
+        else:
+            self._dense(out, N * T, C, self.Vp, self.p('out_w'), self.p('out_b'), self.logits, False)
+        return self.logits
+
+    def backward(self):
+        N, T, C = self.N, self.T, self.C
+        rows = N * T
+        self.grad.zero_()
+        self._written = set()
+        d0, d1 = self.dstream
+        self._head_bwd(self.ffn['out'], rows, d0)
+        self._ffn_bwd('ffn', self.ffn, d0, d1, False)
+        cur, nxt = d1, d0
+        for i in reversed(range(self.blocks)):
+            self._mha_bwd('mha%d' % i, self.mha[i], cur, nxt, False, nxt, True)
+            cur, nxt = nxt, cur
+        perm, uniq, seg = sorted_segments(self._x_host)
+        self.seg[0].copy_(torch.from_numpy(perm), non_blocking=True)
+        self.seg[1][:len(uniq)].copy_(torch.from_numpy(uniq), non_blocking=True)
+        self.seg[2][:len(seg)].copy_(torch.from_numpy(seg), non_blocking=True)
+        ops.embed_bwd(cur, self.seg[0], self.seg[1], self.seg[2], len(uniq), C, True, float(C) ** 0.5, self.g('emb'))
+        ops.colsum(cur, N, T * C, T * C, self.g('pos')[:T * C], self.ws)
+
+
+class E2EEngine(_Base):
+    """Transformer_Model.{embedding_input, encoder, decoder, loss} (end2end/model.py:267-370).
+    Encoder input: features [N,T,Din] -> dense(relu)+LayerNorm+enc_pe; or, for the pinyin->hanzi
+    configuration of BASELINE.json configs[3], pinyin ids through an embedding (``vin``)."""
+
+    def __init__(self, din=5120, vout=6347, N=8, T=150, L=50, C=512, heads=8, blocks=6, pos_max=600, tie=True, vin=None,
+                 lr=5e-4, decay_steps=5000, min_lr=1e-6, seed=0, device='cuda'):
+        super().__init__(C, heads, device, lr, 0.98, decay_steps, min_lr)
+        assert T <= pos_max and L <= pos_max
+        self.din, self.V, self.Vp, self.N, self.T, self.L = din, vout, _r4(vout), N, T, L
+        self.blocks, self.tie, self.vin, self.pos_max = blocks, tie, vin, pos_max
+        if vin is None:
+            self._add('in_w', (din, C)); self._add('in_b', (C,)); self._add('in_ln_g', (C,)); self._add('in_ln_b', (C,))
+        else:
+            self._add('enc_emb', (vin, C))
+        self._add('enc_pe', (pos_max, C)); self._add('dec_pe', (pos_max, C)); self._add('dec_input', (vout, C))
+        for i in range(blocks):
+            self._add_mha('enc%d' % i)
+        for i in range(blocks):
+            self._add_mha('dec%d' % i, share=('enc%d' % i) if tie else None)
+        self._add_ffn('enc_ffn')
+        self._add_ffn('dec_ffn', share='enc_ffn' if tie else None)
+        self._add('out_w', (C, vout), (C, self.Vp)); self._add('out_b', (vout,), (self.Vp,))
+        self._finish_params()
+        self.init_params(seed)
+        re, rd = N * T, N * L
+        self.u = self._t(re, C); self.u_xhat = self._t(re, C); self.u_rstd = self._t(re)
+        self.enc0 = self._t(re, C); self.dec0 = self._t(rd, C); self.pe_tmp = self._t(re, C)
+        self.x_ids = self._t(N, T, dtype=torch.int32)
+        self.y_ids = self._t(N, L, dtype=torch.int32)
+        self.enc = [self._mha_alloc(N, T, T) for _ in range(blocks)]
+        self.dec = [self._mha_alloc(N, L, T) for _ in range(blocks)]
+        self.enc_ffn, self.dec_ffn = self._ffn_alloc(re), self._ffn_alloc(rd)
+        self._head_alloc(rd)
+        mr = max(re, rd)
+        self.dstream = [self._t(mr * C), self._t(mr * C)]
+        self.dmem = self._t(re * C)
+        self.seg = [self._t(mr, dtype=torch.int32), self._t(mr, dtype=torch.int32), self._t(mr + 1, dtype=torch.int32)]
+        self._alloc_scratch(mr, max(C * self.Vp, 4 * C * C, din * C),
+                            [(r, C, C) for r in (re, rd)] + [(r, C, 4 * C) for r in (re, rd)] +
+                            [(r, 4 * C, C) for r in (re, rd)] + [(rd, C, self.Vp), (re, din, C)])
+
+    def flat_from_oracle(self, P):
+        flat = {}
+        for k, v in P.items():
+            if isinstance(v, dict):
+                for kk, vv in v.items():
+                    flat['%s/%s' % (k, kk)] = vv
+            else:
+                flat[k] = v
+        return flat
+
+    def forward(self, x, y_in, y_tgt=None, train=True):
+        N, T, L, C = self.N, self.T, self.L, self.C
+        re, rd = N * T, N * L
+        if self.vin is None:
+            assert tuple(x.shape) == (N, T, self.din) and x.is_contiguous()
+            self.x_feat = x
+            self._dense(x, re, self.din, C, self.p('in_w'), self.p('in_b'), self.u, True)
+            ops.add_layernorm_fwd(self.u, None, self.p('in_ln_g'), self.p('in_ln_b'), re, C, LN_EPS, self.enc0,
+                                  self.u_xhat, self.u_rstd)
+            ops.embed_fwd(None, None, self.p('enc_pe'), N, T, C, False, 1.0, self.pe_tmp)
+            ops.axpy(self.enc0, self.pe_tmp, 1.0, True)
+        else:
+            xi = np.ascontiguousarray(np.asarray(x, dtype=np.int32))
+            self._x_host = xi
+            self.x_ids.copy_(torch.from_numpy(xi), non_blocking=True)
+            ops.embed_fwd(self.p('enc_emb'), self.x_ids, self.p('enc_pe'), N, T, C, True, float(C) ** 0.5, self.enc0)
+        yi = np.ascontiguousarray(np.asarray(y_in, dtype=np.int32))
+        self._y_host = yi
+        self.y_ids.copy_(torch.from_numpy(yi), non_blocking=True)
+        ops.embed_fwd(self.p('dec_input'), self.y_ids, self.p('dec_pe'), N, L, C, False, 1.0, self.dec0)
+        e = self.enc0
+        for i in range(self.blocks):
+            e = self._mha_fwd('enc%d' % i, self.enc[i], e, e, False)
+        memory = self._ffn_fwd('enc_ffn', self.enc_ffn, e)
+        self.memory = memory
+        d = self.dec0
+        for i in range(self.blocks):
+            d = self._mha_fwd('dec%d' % i, self.dec[i], d, memory, True)
+        out = self._ffn_fwd('dec_ffn', self.dec_ffn, d)
+        if y_tgt is not None:
+            self._head_fwd(out, rd, y_tgt, train)
+        else:
+            self._dense(out, rd, C, self.Vp, self.p('out_w'), self.p('out_b'), self.logits, False)
+        return self.logits
+
+    def backward(self):
+        N, T, L, C = self.N, self.T, self.L, self.C
+        re, rd = N * T, N * L
+        self.grad.zero_()
+        self._written = set()
+        d0, d1 = self.dstream[0][:rd * C], self.dstream[1][:rd * C]
+        self._head_bwd(self.dec_ffn['out'], rd, d0)
+        self._ffn_bwd('dec_ffn', self.dec_ffn, d0, d1, False)
+        cur, nxt = d1, d0
+        first = True
+        for i in reversed(range(self.blocks)):
+            self._mha_bwd('dec%d' % i, self.dec[i], cur, nxt, False, self.dmem, not first)
+            first = False
+            cur, nxt = nxt, cur
+        perm, uniq, seg = sorted_segments(self._y_host)
+        self._seg_upload(perm, uniq, seg)
+        ops.embed_bwd(cur, self.seg[0], self.seg[1], self.seg[2], len(uniq), C, False, 1.0, self.g('dec_input'))
+        ops.colsum(cur, N, L * C, L * C, self.g('dec_pe')[:L * C], self.ws)
+        e0, e1 = self.dstream[0][:re * C], self.dstream[1][:re * C]
+        self._ffn_bwd('enc_ffn', self.enc_ffn, self.dmem, e0, False)
+        cur, nxt = e0, e1
+        for i in reversed(range(self.blocks)):
+            self._mha_bwd('enc%d' % i, self.enc[i], cur, nxt, False, nxt, True)
+            cur, nxt = nxt, cur
+        ops.colsum(cur, N, T * C, T * C, self.g('enc_pe')[:T * C], self.ws)
+        if self.vin is None:
+            du = self.sc['b'][:re * C]
+            ops.layernorm_bwd(cur, self.u_xhat, self.u_rstd, self.p('in_ln_g'), re, C, du, False, self.g('in_ln_g'),
+                              self.g('in_ln_b'), self.ws)
+            ops.relu_bwd(du, self.u, du)
+            self._wgrad(self.x_feat, du, re, self.din, C, 'in_w')
+            self._bgrad(du, re, C, 'in_b')
+        else:
+            perm, uniq, seg = sorted_segments(self._x_host)
+            self._seg_upload(perm, uniq, seg)
+            ops.embed_bwd(cur, self.seg[0], self.seg[1], self.seg[2], len(uniq), C, True, float(C) ** 0.5, self.g('enc_emb'))
+
+    def _seg_upload(self, perm, uniq, seg):
+        self.seg[0][:len(perm)].copy_(torch.from_numpy(perm), non_blocking=True)
+        self.seg[1][:len(uniq)].copy_(torch.from_numpy(uniq), non_blocking=True)
+        self.seg[2][:len(seg)].copy_(torch.from_numpy(seg), non_blocking=True)

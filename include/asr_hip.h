@@ -212,6 +212,53 @@ int asr_edit_distance(const int32_t* hyp, int hyp_pitch, const int32_t* hyp_len,
 int asr_adam_tf(float* theta, const float* grad, float* m, float* v, size_t n,
                 float lr_t, float beta1, float beta2, float eps, float gscale, void* stream);
 
+/* ====================================================================== Transformer path
+ * end2end/transformer.py (used by lm_and_am/model/language_model.py and end2end/model.py).
+ * Projections / FFN / vocabulary GEMMs are asr_tap_gemm / asr_tap_wgrad with ntaps = 1.
+ */
+
+/* K13 scaled_dot_product_attention + head split/merge (transformer.py:89-115,144-151).
+ *   Q [N][Tq][C], K, V [N][Tk][C]: the relu'd projections; C = H*64; head h = columns h*64..h*64+63
+ *   scores = Q_h K_h^T / 8; key mask: keys whose per-head K row sums to 0 get -2^32+1;
+ *   causal: keys > query get -2^32+1; softmax; rows whose per-head |Q| sum is 0 are zeroed
+ *   (query mask, applied AFTER the softmax); O = P V_h merged back to [N][Tq][C].
+ *   lse [N][H][Tq] (log-sum-exp of the masked scores) is kept for the backward.
+ * Backward: dQ, dK, dV (=).  Masked scores receive no gradient (tf.where), V still does.
+ *   delta_ws: N*H*Tq floats.  Deterministic (no atomics: dK/dV and dQ are separate passes). */
+int asr_attention_fwd(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
+                      int causal, float* O, float* lse, void* stream);
+int asr_attention_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                      const float* lse, int N, int Tq, int Tk, int C, int H, int causal,
+                      float* dQ, float* dK, float* dV, float* delta_ws, void* stream);
+
+/* K15 layer_norm (transformer.py:4-27) fused with the residual add in front of it:
+ *   x = a (+ b);  y = gamma*(x-mean)/sqrt(var+eps) + beta  (biased variance, eps 1e-8)
+ *   xhat [rows][C] and rstd [rows] are saved for the backward.
+ * Backward: dx (= or +=) -- the same dx is the gradient of both a and b. */
+int asr_add_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, int rows, int C,
+                          float eps, float* y, float* xhat, float* rstd, void* stream);
+size_t asr_layernorm_bwd_workspace(int rows, int C);
+int asr_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int C,
+                      float* dx, int accumulate, float* dgamma, float* dbeta, float* partials, void* stream);
+
+/* K12 embedding (transformer.py:30-55): out[n][t] = scale * table[ids[n][t]] (row 0 reads as zeros
+ * when zero_pad) + pos[t] (either table or pos may be NULL).  Backward is a deterministic
+ * segmented sum: perm = positions sorted by id, uniq[u] = the u-th distinct id, seg[u]..seg[u+1]
+ * its slice of perm (built on the host from the fed ids); rows of ids that do not occur are
+ * not written (zero the gradient buffer first). */
+int asr_embed_fwd(const float* table, const int32_t* ids, const float* pos, int N, int T, int C,
+                  int zero_pad, float scale, float* out, void* stream);
+int asr_embed_bwd(const float* dout, const int32_t* perm, const int32_t* uniq, const int32_t* seg, int n_uniq,
+                  int C, int zero_pad, float scale, float* dtable, void* stream);
+
+/* K16 label_smoothing(one_hot(y)) + softmax_cross_entropy_with_logits_v2 + istarget masking
+ * (end2end/model.py:342-356, language_model.py:55-67).  logits [rows][ld] (ld >= V, pad columns ignored),
+ * target [rows] (may be -1: one_hot = 0 but the row still counts), pad_id = 0.
+ *   loss_rows [rows]; preds [rows] = argmax; stats [rows][2] = {loss*ist, (pred==target)*ist};
+ *   dlogits [rows][ld] = d(mean_loss)/dlogits with inv_count = 1/sum(ist) (NULL: forward only). */
+int asr_smoothed_ce(const float* logits, int ld, const int32_t* target, int rows, int V, float eps, int pad_id,
+                    float inv_count, float* loss_rows, int32_t* preds, float* stats, float* dlogits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

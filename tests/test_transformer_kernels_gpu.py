@@ -1,0 +1,129 @@
+"""GPU parity of the Transformer kernels (asr_attention_*, asr_add_layernorm_*, asr_embed_*,
+asr_smoothed_ce) against oracle/transformer.py.  fp32 tolerances are written per check."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import transformer as otr
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.ascontiguousarray(a), dtype=dtype, device='cuda')
+
+
+def report(name, got, want, tol):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    err = np.abs(got - want).max()
+    scale = max(1.0, np.abs(want).max())
+    print('%-36s max|err| %.3e (scale %.2e, tol %.0e)' % (name, err, scale, tol))
+    assert got.shape == want.shape
+    assert err <= tol * scale, name
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from asr_dfcnn_transformer_amd import ops as _ops
+    return _ops
+
+
+@pytest.mark.parametrize("N,Tq,Tk,H,causal", [(2, 7, 7, 2, True), (2, 100, 100, 8, True), (1, 130, 70, 2, False),
+                                              (2, 33, 200, 4, True), (1, 512, 512, 8, False)])
+def test_attention_fwd_bwd(ops, N, Tq, Tk, H, causal):
+    rng = np.random.default_rng(0)
+    C = H * 64
+    relu = lambda x: np.maximum(x, 0)
+    Q = relu(rng.standard_normal((N, Tq, C))).astype(np.float32)
+    K = relu(rng.standard_normal((N, Tk, C))).astype(np.float32)
+    V = relu(rng.standard_normal((N, Tk, C))).astype(np.float32)
+    K[0, Tk - 3:, :] = 0                      # padded keys: zero rows in every head -> key mask
+    K[N - 1, 1, :64] = 0                      # one key masked in head 0 only
+    Q[0, Tq - 1, :] = 0                       # a zero query row -> query mask zeroes its output
+    if Tk > 8:
+        K[N - 1, :, 64:128] = 0               # head 1 of the last sample: ALL keys masked -> uniform softmax
+    Oref, cache = otr.attention_core(Q.astype(np.float64), K.astype(np.float64), V.astype(np.float64), H, causal)
+    O = torch.zeros(N, Tq, C, device='cuda')
+    lse = torch.zeros(N, H, Tq, device='cuda')
+    dQ, dK, dV = dev(Q), dev(K), dev(V)
+    ops.attention_fwd(dQ, dK, dV, N, Tq, Tk, C, H, causal, O, lse)
+    report('attention fwd', O.cpu().numpy(), Oref, 2e-5)
+    dO = rng.standard_normal((N, Tq, C)).astype(np.float32)
+    gq_ref, gk_ref, gv_ref = otr.attention_core_bwd(cache, dO.astype(np.float64))
+    gq, gk, gv = torch.zeros_like(dQ), torch.zeros_like(dK), torch.zeros_like(dV)
+    ws = torch.zeros(N * H * Tq + 16, device='cuda')
+    ops.attention_bwd(dQ, dK, dV, O, dev(dO), lse, N, Tq, Tk, C, H, causal, gq, gk, gv, ws)
+    report('attention dQ', gq.cpu().numpy(), gq_ref, 3e-5)
+    report('attention dK', gk.cpu().numpy(), gk_ref, 3e-5)
+    report('attention dV', gv.cpu().numpy(), gv_ref, 3e-5)
+
+
+@pytest.mark.parametrize("rows,C,with_b", [(10, 512, True), (300, 64, False), (77, 2048, True)])
+def test_add_layernorm(ops, rows, C, with_b):
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal((rows, C)).astype(np.float32)
+    b = rng.standard_normal((rows, C)).astype(np.float32) if with_b else None
+    g = (1 + 0.1 * rng.standard_normal(C)).astype(np.float32)
+    be = (0.1 * rng.standard_normal(C)).astype(np.float32)
+    x = a.astype(np.float64) + (b.astype(np.float64) if with_b else 0)
+    yref, cache = otr.layer_norm(x, g.astype(np.float64), be.astype(np.float64))
+    y, xh, rs = torch.zeros(rows, C, device='cuda'), torch.zeros(rows, C, device='cuda'), torch.zeros(rows, device='cuda')
+    ops.add_layernorm_fwd(dev(a), dev(b) if with_b else None, dev(g), dev(be), rows, C, 1e-8, y, xh, rs)
+    report('add_ln fwd', y.cpu().numpy(), yref, 1e-5)
+    dy = rng.standard_normal((rows, C)).astype(np.float32)
+    dxr, dgr, dbr = otr.layer_norm_bwd(cache, g.astype(np.float64), dy.astype(np.float64))
+    dx = torch.zeros(rows, C, device='cuda')
+    dg, db = torch.zeros(C, device='cuda'), torch.zeros(C, device='cuda')
+    ws = torch.zeros(ops.layernorm_bwd_workspace(rows, C) // 4 + 4, device='cuda')
+    ops.layernorm_bwd(dev(dy), xh, rs, dev(g), rows, C, dx, False, dg, db, ws)
+    report('ln dx', dx.cpu().numpy(), dxr, 2e-5)
+    report('ln dgamma', dg.cpu().numpy(), dgr, 2e-5)
+    report('ln dbeta', db.cpu().numpy(), dbr, 2e-5)
+    ops.layernorm_bwd(dev(dy), xh, rs, dev(g), rows, C, dx, True, dg, db, ws)
+    report('ln dx accumulate', dx.cpu().numpy(), 2 * dxr, 2e-5)
+
+
+def test_embedding_fwd_bwd(ops):
+    from asr_dfcnn_transformer_amd.transformer_engine import sorted_segments
+    rng = np.random.default_rng(2)
+    N, T, C, V = 3, 9, 64, 17
+    table = rng.standard_normal((V, C)).astype(np.float32)
+    pos = rng.standard_normal((T + 3, C)).astype(np.float32)
+    ids = rng.integers(0, V, (N, T)).astype(np.int32)
+    ids[0, :3] = 0
+    ref = otr.embedding(table.astype(np.float64), ids, True, True) + pos[:T][None]
+    out = torch.zeros(N, T, C, device='cuda')
+    ops.embed_fwd(dev(table), dev(ids, torch.int32), dev(pos), N, T, C, True, C ** 0.5, out)
+    report('embed fwd', out.cpu().numpy(), ref, 1e-6)
+    dout = rng.standard_normal((N, T, C)).astype(np.float32)
+    gref = otr.embedding_bwd((V, C), ids, dout.astype(np.float64), True, True)
+    perm, uniq, seg = sorted_segments(ids)
+    g = torch.zeros(V, C, device='cuda')
+    ops.embed_bwd(dev(dout), dev(perm, torch.int32), dev(uniq, torch.int32), dev(seg, torch.int32), len(uniq), C, True,
+                  C ** 0.5, g)
+    report('embed bwd', g.cpu().numpy(), gref, 2e-6)
+
+
+@pytest.mark.parametrize("rows,V", [(12, 13), (64, 6345), (7, 6347)])
+def test_smoothed_ce(ops, rows, V):
+    rng = np.random.default_rng(3)
+    ld = (V + 3) // 4 * 4
+    logits = np.zeros((rows, ld), dtype=np.float32)
+    logits[:, :V] = (rng.standard_normal((rows, V)) * 2).astype(np.float32)
+    logits[:, V:] = 55.0                                   # pad columns must be ignored
+    tgt = rng.integers(1, V, rows).astype(np.int32)
+    tgt[0] = 0                                             # PAD: not counted
+    tgt[1] = -1                                            # IGNORE: counted with an all-zero one-hot (Q9)
+    tgt[2] = int(np.argmax(logits[2, :V]))                 # a correct prediction
+    ml, acc, preds, loss, dl = otr.smoothed_ce(logits[None, :, :V].astype(np.float64), tgt[None].astype(np.int64))
+    cnt = float((tgt != 0).sum())
+    lr, pr = torch.zeros(rows, device='cuda'), torch.zeros(rows, dtype=torch.int32, device='cuda')
+    st, dlg = torch.zeros(rows, 2, device='cuda'), torch.zeros(rows, ld, device='cuda')
+    ops.smoothed_ce(dev(logits), ld, dev(tgt, torch.int32), rows, V, 0.1, 0, 1.0 / cnt, lr, pr, st, dlg)
+    report('ce loss rows', lr.cpu().numpy(), loss[0], 1e-5)
+    assert np.array_equal(pr.cpu().numpy(), preds[0])
+    s = st.cpu().numpy().astype(np.float64).sum(axis=0)
+    assert abs(s[0] / cnt - ml) < 1e-4 and abs(s[1] / cnt - acc) < 1e-6
+    d = dlg.cpu().numpy()
+    report('ce dlogits', d[:, :V], dl[0], 1e-6)
+    assert np.all(d[:, V:] == 0)
