@@ -146,7 +146,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         }
     }
     __syncthreads();
-    if (q < Tq && lh == 0) lse[((long)n * H + head) * Tq + q] = m_run + logf(l_run);
+    if (q < Tq && lh == 0) {      // kept as (max, log-sum) pair: max may be the -2^32+1 fill, which would swallow log(l)
+        lse[((long)n * H + head) * Tq + q] = m_run;
+        lse[(long)gridDim.z * H * Tq + ((long)n * H + head) * Tq + q] = logf(l_run);
+    }
     store_tile_T(O, Ks + wave * (32 * 65), oacc, qmask / l_run, qbase, q0, Tq, C, hoff, lane);
 }
 
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
     __shared__ __attribute__((aligned(16))) float Qs[32 * KP];
     __shared__ __attribute__((aligned(16))) float Ds[32 * KP];
     __shared__ float qstat[32];
-    __shared__ float lse_s[32], del_s[32];
+    __shared__ float lse_s[32], lsl_s[32], del_s[32];
     __shared__ float scratch[4 * 32 * 65];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
     const int head = blockIdx.y, n = blockIdx.z, hoff = head * DH;
@@ -218,6 +221,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
         if (tid < 32) {
             const int q = q0 + tid;
             lse_s[tid] = (q < Tq) ? lse[((long)n * H + head) * Tq + q] : INFINITY;
+            lsl_s[tid] = (q < Tq) ? lse[(long)gridDim.z * H * Tq + ((long)n * H + head) * Tq + q] : 0.f;
             del_s[tid] = (q < Tq) ? delta[((long)n * H + head) * Tq + q] : 0.f;
         }
         __syncthreads();
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
             const int ql = rowidx(r, lh), q = q0 + ql;
             const bool keep = kkeep && (!CAUSAL || key <= q);
             const float sv = keep ? s[r] * 0.125f : MASK_FILL;
-            const float p = (key < Tk) ? expf(sv - lse_s[ql]) : 0.f;
+            const float p = (key < Tk) ? expf((sv - lse_s[ql]) - lsl_s[ql]) : 0.f;
             const float ds = keep ? p * (dp[r] - del_s[ql]) * 0.125f : 0.f;
             s[r] = p; dp[r] = ds;
         }
@@ -303,6 +307,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 32; ++i) doreg[i] *= qmask;
     const float my_lse = (q < Tq) ? lse[((long)n * H + head) * Tq + q] : INFINITY;
+    const float my_lsl = (q < Tq) ? lse[(long)gridDim.z * H * Tq + ((long)n * H + head) * Tq + q] : 0.f;
     const float my_del = (q < Tq) ? delta[((long)n * H + head) * Tq + q] : 0.f;
 
     floatx16 dq[2];
@@ -337,7 +342,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
                 const int kl = sub * 32 + rowidx(r, lh), key = k0 + kl;
                 const bool keep = (kstat[kl] != 0.f) && (!CAUSAL || key <= q);
                 const float sv = keep ? s[r] : MASK_FILL;
-                const float p = (key < Tk) ? expf(sv - my_lse) : 0.f;
+                const float p = (key < Tk) ? expf((sv - my_lse) - my_lsl) : 0.f;
                 dp[r] = keep ? p * (dp[r] - my_del) * 0.125f : 0.f;
             }
 #pragma unroll

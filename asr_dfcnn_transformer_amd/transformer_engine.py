@@ -163,7 +163,7 @@ class _Base:
     def _mha_alloc(self, N, Tq, Tk):
         C, H = self.C, self.H
         return {'Q': self._t(N * Tq, C), 'K': self._t(N * Tk, C), 'V': self._t(N * Tk, C), 'A': self._t(N * Tq, C),
-                'Z': self._t(N * Tq, C), 'xhat': self._t(N * Tq, C), 'rstd': self._t(N * Tq), 'lse': self._t(N * H * Tq),
+                'Z': self._t(N * Tq, C), 'xhat': self._t(N * Tq, C), 'rstd': self._t(N * Tq), 'lse': self._t(2 * N * H * Tq),
                 'out': self._t(N * Tq, C), 'N': N, 'Tq': Tq, 'Tk': Tk}
 
     def _mha_fwd(self, name, st, q_in, k_in, causal):

@@ -88,17 +88,88 @@ def cpu_baseline(variant, t_pad, vocab, seconds=10.0, budget_s=15.0):
                       'torch-CPU fp32 + numpy fbank) after 1 warm-up' % (n, Bc, t_pad)}
 
 
+def run_transformer(args):
+    """BASELINE.json configs[3]: pinyin->hanzi encoder-decoder (6+6 MHA sub-layers, d_model 512, 8 heads),
+    batch 64 x seq 512, as-written live graph, fwd + bwd + Adam.  Secondary workload."""
+    from asr_dfcnn_transformer_amd import ops
+    from asr_dfcnn_transformer_amd.parallel import init_from_env, BucketedAllReduce
+    from asr_dfcnn_transformer_amd.transformer_engine import E2EEngine
+    rank, world, local = init_from_env()
+    torch.cuda.set_device(local)
+    N, T, C, H, blocks, Vin, Vout = args.batch if args.batch != 32 else 64, 512, 512, 8, 6, 1536, 6347
+    eng = E2EEngine(vin=Vin, vout=Vout, N=N, T=T, L=T, C=C, heads=H, blocks=blocks, pos_max=600, tie=True)
+    red = BucketedAllReduce(eng.grad, [(0, eng.grad.numel())])
+    rng = np.random.default_rng(7 + rank)
+    x = rng.integers(1, Vin, (N, T)); y = rng.integers(3, Vout, (N, T))
+    y_in = np.concatenate([np.ones((N, 1), dtype=np.int64), y[:, :-1]], axis=1)
+
+    def step():
+        eng.forward(x, y_in, y)
+        eng.backward()
+        red.launch(0); red.wait()
+        eng.apply_adam(red.grad_scale)
+
+    ops.TIMER = ops.KernelTimer()
+    for i in range(max(1, args.warmup)):
+        step()
+        if i == 0:
+            torch.cuda.synchronize(); table = ops.TIMER.summary(); ops.TIMER = None
+    dom = max(table, key=lambda k: table[k]['total_ms'])
+    ops.TIMER = ops.KernelTimer(only={dom})
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timed = ops.TIMER.summary(); ops.TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda'); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    if rank == 0:
+        mha = 4 * 2 * T * C * C + 2 * 2 * T * T * C
+        fwd = 2 * blocks * mha + 2 * (2 * 2 * T * C * 4 * C) + 2 * T * C * Vout
+        fstep = 3.0 * fwd
+        r = timed[dom]
+        seq_s = world * N * args.steps / dt
+        out = {'metric': 'sequences/sec (B=64, T=512) end2end Transformer fwd+bwd', 'value': round(seq_s, 2),
+               'unit': 'sequences/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+               'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
+               'config': {'workload': 'end2end Transformer (end2end/model.py live graph: 6 enc + 6 dec MHA, 2 FFN, V 6347), '
+                                      'pinyin ids -> hanzi, fwd+bwd+Adam, tied enc/dec kernels', 'global_batch': world * N,
+                          'seq_len': T, 'parallelism': 'dp%d' % world, 'gflop_per_seq_fwd_bwd': round(fstep / 1e9, 2),
+                          'step_tflops': round(seq_s / world * fstep / 1e12, 2),
+                          'step_frac_of_fp32_peak': round(seq_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
+                          'mean_loss': round(eng.fetch()[0], 4)},
+               'roofline': {'bound': 'mfma', 'achieved': round(r['tflops'], 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                            'frac': round(r['tflops'] / FP32_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': kernel_name(dom),
+                            'launches_per_step': r['launches'] // args.steps, 'avg_launch_us': round(r['avg_us'], 2)}}
+        if args.kernel_table:
+            for key, rr in sorted(table.items(), key=lambda kv: -kv[1]['total_ms']):
+                print('%-28s launches %3d  total %8.3f ms  avg %9.1f us  %7.2f TFLOP/s' %
+                      (key, rr['launches'], rr['total_ms'], rr['avg_us'], rr['tflops']), file=sys.stderr)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='dfcnn', choices=['dfcnn', 'se_dfcnn'])
+    ap.add_argument('--workload', default='dfcnn', choices=['dfcnn', 'se_dfcnn', 'transformer'])
     ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
     ap.add_argument('--tpad', type=int, default=1600)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--kernel-table', action='store_true', help='also print per-kernel timings to stderr')
     args = ap.parse_args()
+    if args.workload == 'transformer':
+        return run_transformer(args)
 
     from asr_dfcnn_transformer_amd import ops
     from asr_dfcnn_transformer_amd.engine import DFCNNEngine, step_flops_per_utt, fwd_flops_per_utt

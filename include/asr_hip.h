@@ -222,7 +222,8 @@ int asr_adam_tf(float* theta, const float* grad, float* m, float* v, size_t n,
  *   scores = Q_h K_h^T / 8; key mask: keys whose per-head K row sums to 0 get -2^32+1;
  *   causal: keys > query get -2^32+1; softmax; rows whose per-head |Q| sum is 0 are zeroed
  *   (query mask, applied AFTER the softmax); O = P V_h merged back to [N][Tq][C].
- *   lse [N][H][Tq] (log-sum-exp of the masked scores) is kept for the backward.
+ *   lse [2][N][H][Tq] (row max and log of the row sum of the masked scores, kept apart because
+ *   the max can be the -2^32+1 fill value) is saved for the backward.
  * Backward: dQ, dK, dV (=).  Masked scores receive no gradient (tf.where), V still does.
  *   delta_ws: N*H*Tq floats.  Deterministic (no atomics: dK/dV and dQ are separate passes). */
 int asr_attention_fwd(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,

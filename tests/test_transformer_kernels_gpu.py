@@ -44,7 +44,7 @@ def test_attention_fwd_bwd(ops, N, Tq, Tk, H, causal):
         K[N - 1, :, 64:128] = 0               # head 1 of the last sample: ALL keys masked -> uniform softmax
     Oref, cache = otr.attention_core(Q.astype(np.float64), K.astype(np.float64), V.astype(np.float64), H, causal)
     O = torch.zeros(N, Tq, C, device='cuda')
-    lse = torch.zeros(N, H, Tq, device='cuda')
+    lse = torch.zeros(2, N, H, Tq, device='cuda')
     dQ, dK, dV = dev(Q), dev(K), dev(V)
     ops.attention_fwd(dQ, dK, dV, N, Tq, Tk, C, H, causal, O, lse)
     report('attention fwd', O.cpu().numpy(), Oref, 2e-5)
