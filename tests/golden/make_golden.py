@@ -22,7 +22,9 @@ def fbank_cases():
     sigs = {
         'zero': np.zeros(n, dtype=np.float32),
         'impulse': np.eye(1, n, 1000, dtype=np.float32)[0],
-        'sine1k': (0.5 * np.sin(2 * np.pi * 1000 * np.arange(n) / 16000)).astype(np.float32),
+        # a chirp, not a stationary sine: with a 10 ms hop a 1 kHz sine gives identical frames, every column is
+        # constant up to rounding and the standardised output is noise/noise (ill-conditioned, not a parity vector)
+        'chirp': (0.5 * np.sin(2 * np.pi * (300 * np.arange(n) / 16000 + 2000 * (np.arange(n) / 16000) ** 2))).astype(np.float32),
         'gauss': (0.1 * rng.standard_normal(n)).astype(np.float32),
         'short': (0.1 * rng.standard_normal(300)).astype(np.float32),
     }
