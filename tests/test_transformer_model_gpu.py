@@ -108,3 +108,37 @@ def test_e2e_with_pinyin_ids_runs_and_learns():
         eng.apply_adam()
         losses.append(eng.fetch()[0])
     assert losses[-1] < 0.8 * losses[0], losses
+
+
+def test_language_model_shim_session_api():
+    """Language_Model with the reference's feed/fetch names (lm_and_am/train.py:138-141); batches
+    of different max length share one engine because the causal mask hides trailing pads."""
+    from asr_dfcnn_transformer_amd.language_model import Language_Model
+    from asr_dfcnn_transformer_amd.hparams import AmLmHparams
+    hp = AmLmHparams().args
+    hp.hidden_units, hp.num_heads, hp.num_blocks, hp.position_max_length, hp.lm_batch_size, hp.lm_lr = 128, 2, 2, 16, 4, 2e-3
+    m = Language_Model(hp, 30, 25)
+    rng = np.random.default_rng(3)
+    x = rng.integers(1, 30, (4, 9)); y = rng.integers(1, 25, (4, 9))
+    x[0, 6:] = 0; y[0, 6:] = 0
+    losses = [m.run([m.mean_loss, m.current_learning, m.train_op], {m.x: x, m.y: y})[0] for _ in range(25)]
+    assert losses[-1] < 0.8 * losses[0]
+    p_short = m.run(m.preds, {m.x: x[:, :5]})
+    p_long = m.run(m.preds, {m.x: x})
+    assert p_short.shape == (4, 5) and np.array_equal(p_short, p_long[:, :5])     # causal: prefix-invariant
+    acc = m.run(m.acc, {m.x: x, m.y: y})
+    assert 0.0 <= acc <= 1.0
+
+
+def test_transformer_model_shim_rebuilds_per_shape():
+    from asr_dfcnn_transformer_amd.e2e_model import Transformer_Model, E2EHparams
+    hp = E2EHparams()
+    hp.batch_size, hp.num_blocks, hp.hidden_units, hp.num_heads, hp.position_max_length = 2, 2, 128, 2, 32
+    m = Transformer_Model(hp, label_vocab_size=19, input_dim=20).build_transformer()
+    rng = np.random.default_rng(4)
+    for T, L in ((10, 6), (12, 7)):
+        feed = {m.x_input: rng.standard_normal((2, T, 20)).astype(np.float32), m.y_input: rng.integers(1, 19, (2, L)),
+                m.y_target: rng.integers(1, 19, (2, L)), m.learning_rate: 5e-4}
+        ml, merged, lr, _ = m.run([m.mean_loss, m.merged, m.current_learning, m.train_op], feed)
+        assert np.isfinite(ml) and abs(merged['mean_loss'] - ml) < 1e-6
+    assert m.engine.global_step == 2 and (m.engine.T, m.engine.L) == (12, 7)
