@@ -46,7 +46,8 @@ SIGNATURES = {
     'asr_colsum': (_I, [_P, _I, _I, _I, _P, _P, _P]),
     'asr_ctc_workspace': (_Z, [_I, _I, _I]),
     'asr_ctc_loss': (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P]),
-    'asr_ctc_greedy': (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P]),
+    'asr_ctc_greedy_workspace': (_Z, [_I, _I]),
+    'asr_ctc_greedy': (_I, [_P, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P]),
     'asr_edit_distance': (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _P]),
     'asr_adam_tf': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _P]),
     'asr_attention_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),

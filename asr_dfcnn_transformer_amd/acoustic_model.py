@@ -130,7 +130,7 @@ class CNNCTCModel:
         e = self.engine
         sl = torch.as_tensor(np.asarray(feed_dict[self.logits_length], dtype=np.int32)).to(e.device)
         e.seq_len.copy_(sl)
-        ops.ctc_greedy(e.logits, e.T8, e.B, e.V, e.seq_len, e.V - 1, e.dec_ids, e.dec_len, e.neg_sum)
+        ops.ctc_greedy(e.logits, e.T8, e.B, e.V, e.seq_len, e.V - 1, e.dec_ids, e.dec_len, e.neg_sum, e.dec_ws)
 
 
 class CNNCTCModel1(CNNCTCModel):

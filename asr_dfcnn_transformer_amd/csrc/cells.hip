@@ -167,21 +167,22 @@ __device__ __forceinline__ float pick_max_grad(float y0, float y1, float y2, flo
     return arg == mine ? dp : 0.f;
 }
 
-constexpr int kPrePPB = 2048;   // padded pixels per block
+// padded pixels per block: sized so that even the 200x25 layers launch >= ~1300 blocks
+inline int pre_ppb(long NP) { return NP >= (4L << 20) ? 1024 : (NP >= (1L << 20) ? 512 : 128); }
 
 template <int POOL>
 __global__ __launch_bounds__(256) void cell_bwd_pre_kernel(const float* __restrict__ dy, int layout,
                                                            const float* __restrict__ a, int B, int H, int W, int C,
                                                            const float* __restrict__ sc, const float* __restrict__ sh,
-                                                           float* __restrict__ dz, float* __restrict__ partials) {
+                                                           float* __restrict__ dz, float* __restrict__ partials, int PPB) {
     __shared__ float red[256 * 12];
     const int C4 = C >> 2;
     const int tid = threadIdx.x;
     const int cg = tid % C4, slot = tid / C4, nslots = 256 / C4;
     const int WP = W + 2, HPWP = (H + 2) * WP;
     const long NP = (long)B * HPWP;
-    const long pbeg = (long)blockIdx.x * kPrePPB;
-    const long pend = (pbeg + kPrePPB < NP) ? pbeg + kPrePPB : NP;
+    const long pbeg = (long)blockIdx.x * PPB;
+    const long pend = (pbeg + PPB < NP) ? pbeg + PPB : NP;
     const float4 s = ld4(sc + cg * 4), h = ld4(sh + cg * 4);
     float4 s_shift = f4(0.f), s_scale = f4(0.f), s_bias = f4(0.f);
     const int H2 = H >> 1, W2 = W >> 1;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(256) void cell_bwd_pre_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ squeeze-excitation
-constexpr int kSePPB = 2048;
+constexpr int kSePPB = 512;
 
 // partial[b][split][C] = sum over a pixel range of image b of x (MODE 0) or dout*(sc*x+sh) (MODE 1)
 template <int MODE>
@@ -371,22 +372,22 @@ __global__ __launch_bounds__(256) void se_bwd_mlp_kernel(const float* __restrict
     }
 }
 
-constexpr int kSeApplyPPB = 2048;
+inline int se_apply_ppb(long NP) { return NP >= (4L << 20) ? 1024 : (NP >= (1L << 20) ? 512 : 128); }
 
 // dxt = dout*e + dsb; dx = dxt*sc (+ dout when add_dout); channel sums dshift = sum dxt, dscale = sum dxt*x
 __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ x,
                                                            int B, int H, int W, int C, const float* __restrict__ sc,
                                                            const float* __restrict__ e, const float* __restrict__ dsb,
                                                            int add_dout, float* __restrict__ dx,
-                                                           float* __restrict__ partials) {
+                                                           float* __restrict__ partials, int PPB) {
     __shared__ float red[256 * 8];
     const int C4 = C >> 2;
     const int tid = threadIdx.x;
     const int cg = tid % C4, slot = tid / C4, nslots = 256 / C4;
     const int WP = W + 2, HPWP = (H + 2) * WP;
     const long NP = (long)B * HPWP;
-    const long pbeg = (long)blockIdx.x * kSeApplyPPB;
-    const long pend = (pbeg + kSeApplyPPB < NP) ? pbeg + kSeApplyPPB : NP;
+    const long pbeg = (long)blockIdx.x * PPB;
+    const long pend = (pbeg + PPB < NP) ? pbeg + PPB : NP;
     const float4 s = ld4(sc + cg * 4);
     float4 s_shift = f4(0.f), s_scale = f4(0.f);
     for (long p = pbeg + slot; p < pend; p += nslots) {
@@ -502,7 +503,7 @@ extern "C" int asr_pool_fwd(const float* a, int B, int H, int W, int C, const fl
 
 extern "C" size_t asr_cell_bwd_pre_workspace(int B, int H, int W, int C) {
     const long NP = (long)B * (H + 2) * (W + 2);
-    const size_t nblk = (size_t)asr_cdiv(NP, kPrePPB);
+    const size_t nblk = (size_t)asr_cdiv(NP, pre_ppb(NP));
     return (nblk * 3 * C + asr_reduce::colsum_tmp_floats((int)nblk, 3 * C)) * sizeof(float);
 }
 
@@ -515,11 +516,12 @@ extern "C" int asr_cell_bwd_pre(const float* dy, int dy_layout, const float* a, 
     if ((pool != 0) != (dy_layout == 1)) return ASR_ERR_BAD_ARG;
     if (dy_layout < 0 || dy_layout > 2) return ASR_ERR_BAD_ARG;
     const long NP = (long)B * (H + 2) * (W + 2);
-    const int nblk = asr_cdiv(NP, kPrePPB);
+    const int ppb = pre_ppb(NP);
+    const int nblk = asr_cdiv(NP, ppb);
     hipStream_t st = (hipStream_t)stream;
-    if (pool == 0) hipLaunchKernelGGL(cell_bwd_pre_kernel<0>, dim3(nblk), dim3(256), 0, st, dy, dy_layout, a, B, H, W, C, bn_scale, bn_shift, dz, partials);
-    else if (pool == 1) hipLaunchKernelGGL(cell_bwd_pre_kernel<1>, dim3(nblk), dim3(256), 0, st, dy, dy_layout, a, B, H, W, C, bn_scale, bn_shift, dz, partials);
-    else hipLaunchKernelGGL(cell_bwd_pre_kernel<2>, dim3(nblk), dim3(256), 0, st, dy, dy_layout, a, B, H, W, C, bn_scale, bn_shift, dz, partials);
+    if (pool == 0) hipLaunchKernelGGL(cell_bwd_pre_kernel<0>, dim3(nblk), dim3(256), 0, st, dy, dy_layout, a, B, H, W, C, bn_scale, bn_shift, dz, partials, ppb);
+    else if (pool == 1) hipLaunchKernelGGL(cell_bwd_pre_kernel<1>, dim3(nblk), dim3(256), 0, st, dy, dy_layout, a, B, H, W, C, bn_scale, bn_shift, dz, partials, ppb);
+    else hipLaunchKernelGGL(cell_bwd_pre_kernel<2>, dim3(nblk), dim3(256), 0, st, dy, dy_layout, a, B, H, W, C, bn_scale, bn_shift, dz, partials, ppb);
     ASR_CHECK_LAUNCH("cell_bwd_pre");
     float* tmp = partials + (size_t)nblk * 3 * C;
     int rc;
@@ -540,7 +542,7 @@ extern "C" size_t asr_se_fwd_workspace(int B, int H, int W, int C) {
 extern "C" size_t asr_se_bwd_workspace(int B, int H, int W, int C, int hid) {
     const size_t per = (size_t)C * hid + hid + (size_t)hid * C + C;
     const long NP = (long)B * (H + 2) * (W + 2);
-    const size_t nblk = (size_t)asr_cdiv(NP, kSeApplyPPB);
+    const size_t nblk = (size_t)asr_cdiv(NP, se_apply_ppb(NP));
     const size_t fl = (size_t)B * se_nsplit(H, W) * C + (size_t)B * per + (size_t)B * C + nblk * 2 * C
                     + asr_reduce::colsum_tmp_floats((int)nblk, 2 * C) + 64;
     return fl * sizeof(float);
@@ -576,7 +578,8 @@ extern "C" int asr_se_bwd(const float* dout, const float* x, int B, int H, int W
     const int ns = se_nsplit(H, W);
     const size_t per = (size_t)C * hid + hid + (size_t)hid * C + C;
     const long NP = (long)B * (H + 2) * (W + 2);
-    const int nblk = asr_cdiv(NP, kSeApplyPPB);
+    const int appb = se_apply_ppb(NP);
+    const int nblk = asr_cdiv(NP, appb);
     float* part_red = partials;
     float* mlp_out = part_red + (size_t)B * ns * C;
     float* dsb = mlp_out + (size_t)B * per;
@@ -591,7 +594,7 @@ extern "C" int asr_se_bwd(const float* dout, const float* x, int B, int H, int W
     if ((rc = asr_reduce::colsum(mlp_out + (size_t)C * hid, B, hid, (long)per, db1, tmp, st))) return rc;
     if ((rc = asr_reduce::colsum(mlp_out + (size_t)C * hid + hid, B, hid * C, (long)per, dw2, tmp, st))) return rc;
     if ((rc = asr_reduce::colsum(mlp_out + (size_t)C * hid + hid + (size_t)hid * C, B, C, (long)per, db2, tmp, st))) return rc;
-    hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(nblk), dim3(256), 0, st, dout, x, B, H, W, C, bn_scale, st_e, (const float*)dsb, add_dout, dx, part_apply);
+    hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(nblk), dim3(256), 0, st, dout, x, B, H, W, C, bn_scale, st_e, (const float*)dsb, add_dout, dx, part_apply, appb);
     ASR_CHECK_LAUNCH("se_bwd_apply");
     if ((rc = asr_reduce::colsum(part_apply, nblk, C, 2 * C, dscale, tmp, st))) return rc;
     if ((rc = asr_reduce::colsum(part_apply + C, nblk, C, 2 * C, dshift, tmp, st))) return rc;

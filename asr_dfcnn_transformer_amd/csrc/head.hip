@@ -209,42 +209,44 @@ __global__ __launch_bounds__(256) void ctc_lattice_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------ greedy decode
-__global__ __launch_bounds__(256) void ctc_greedy_kernel(const float* __restrict__ logits, int T, int B, int V,
-                                                         const int32_t* __restrict__ seq_len, int blank,
+// pass 1: one wave per (t,b) row over the whole chip: argmax with the lowest index on ties
+__global__ __launch_bounds__(256) void ctc_argmax_kernel(const float* __restrict__ logits, int T, int B, int V,
+                                                         int32_t* __restrict__ best_k, float* __restrict__ best_v) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // row = t*B + b
+    if (row >= T * B) return;
+    const int lane = threadIdx.x & 63;
+    const float* x = logits + (long)row * V;
+    float bv = -INFINITY; int bk = 0x7fffffff;
+    for (int k = lane; k < V; k += 64) {
+        const float v = x[k];
+        if (v > bv || bk == 0x7fffffff) { bv = v; bk = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int ok = __shfl_xor(bk, o, 64);
+        if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
+    }
+    if (lane == 0) { best_k[row] = bk; best_v[row] = bv; }
+}
+
+// pass 2: per utterance, merge repeats / drop blanks in time order
+__global__ __launch_bounds__(64) void ctc_compact_kernel(const int32_t* __restrict__ best_k, const float* __restrict__ best_v,
+                                                         int T, int B, const int32_t* __restrict__ seq_len, int blank,
                                                          int32_t* __restrict__ out_ids, int32_t* __restrict__ out_len,
                                                          float* __restrict__ neg_sum) {
-    extern __shared__ int sm_i[];
-    int* best_k = sm_i;                     // [T]
-    float* best_v = (float*)(sm_i + T);     // [T]
     const int b = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int Tb = seq_len[b];
     if (Tb > T) Tb = T;
     if (Tb < 0) Tb = 0;
-    for (int t = wave; t < Tb; t += 4) {
-        const float* x = logits + ((long)t * B + b) * V;
-        float bv = -INFINITY; int bk = 0x7fffffff;
-        for (int k = lane; k < V; k += 64) {
-            const float v = x[k];
-            if (v > bv || (bk == 0x7fffffff)) { if (v > bv || bk == 0x7fffffff) { bv = v; bk = k; } }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(bv, o, 64);
-            const int ok = __shfl_xor(bk, o, 64);
-            if (ov > bv || (ov == bv && ok < bk)) { bv = ov; bk = ok; }
-        }
-        if (lane == 0) { best_k[t] = bk; best_v[t] = bv; }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < T; i += 256) out_ids[(long)b * T + i] = -1;
+    for (int i = threadIdx.x; i < T; i += 64) out_ids[(long)b * T + i] = -1;
     __syncthreads();
     if (threadIdx.x == 0) {
         int n = 0, prev = -1;
         float acc = 0.f;
         for (int t = 0; t < Tb; ++t) {
-            const int k = best_k[t];
-            acc += -best_v[t];
+            const int k = best_k[(long)t * B + b];
+            acc += -best_v[(long)t * B + b];
             if (k != blank && k != prev) out_ids[(long)b * T + n++] = k;
             prev = k;
         }
@@ -380,11 +382,17 @@ extern "C" int asr_ctc_loss(const float* logits_tm, int T, int B, int V, const i
     return ASR_OK;
 }
 
+extern "C" size_t asr_ctc_greedy_workspace(int T, int B) { return (size_t)T * B * 8 + 64; }
+
 extern "C" int asr_ctc_greedy(const float* logits_tm, int T, int B, int V, const int32_t* seq_len, int blank,
-                              int32_t* out_ids, int32_t* out_len, float* neg_sum_logits, void* stream) {
-    if (!logits_tm || !seq_len || !out_ids || !out_len || !neg_sum_logits) return ASR_ERR_BAD_ARG;
-    if (T < 1 || T > 8192 || B < 1 || V < 1) return ASR_ERR_BAD_ARG;
-    hipLaunchKernelGGL(ctc_greedy_kernel, dim3(B), dim3(256), (size_t)T * 8, (hipStream_t)stream, logits_tm, T, B, V, seq_len, blank, out_ids, out_len, neg_sum_logits);
+                              int32_t* out_ids, int32_t* out_len, float* neg_sum_logits, void* workspace, void* stream) {
+    if (!logits_tm || !seq_len || !out_ids || !out_len || !neg_sum_logits || !workspace) return ASR_ERR_BAD_ARG;
+    if (T < 1 || B < 1 || V < 1) return ASR_ERR_BAD_ARG;
+    int32_t* best_k = (int32_t*)workspace;
+    float* best_v = (float*)(best_k + (size_t)T * B);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ctc_argmax_kernel, dim3(asr_cdiv((long)T * B, 4)), dim3(256), 0, st, logits_tm, T, B, V, best_k, best_v);
+    hipLaunchKernelGGL(ctc_compact_kernel, dim3(B), dim3(64), 0, st, (const int32_t*)best_k, (const float*)best_v, T, B, seq_len, blank, out_ids, out_len, neg_sum_logits);
     ASR_CHECK_LAUNCH("ctc_greedy");
     return ASR_OK;
 }

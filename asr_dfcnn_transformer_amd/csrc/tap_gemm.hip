@@ -37,16 +37,19 @@ template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE>
 __global__ __launch_bounds__(256) void tap_gemm_kernel(TapGemmArgs g) {
     constexpr int TM = MT / WM / 32, TN = NT / WN / 32;
     constexpr int WREG = KC * NT / 4 / 256;            // float4 per thread per weight tile
-    constexpr int AREG = (NTAPS == 1) ? MT * 8 / 256 : 1;
-    constexpr int WPITCH = (WMODE == 0) ? NT : (KC + 1);
+    // float4 per thread of the A-tile register prefetch: the whole tile for the shapes of the
+    // DFCNN planes (W+2 <= 52 at MT = 128, <= 102 at MT = 256); wider planes stage the rest directly
+    constexpr int AREG = (NTAPS == 1) ? MT * 8 / 256 : (MT == 128 ? 8 : 15);
+    constexpr int WSZ = ((WMODE == 0) ? KC * NT : NT * (KC + 1) + 3) / 4 * 4;
     static_assert(WREG >= 1 && TM >= 1 && TN >= 1, "tile");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int halo = g.halo;
     const int arows = MT + 2 * halo;
-    float* As = smem;
-    float* Ws = As + arows * AP;
-    int* rowa = (int*)(Ws + ((WMODE == 0) ? KC * NT : NT * (KC + 1) + 3) / 4 * 4);
+    const int asz = arows * AP;
+    float* As = smem;                                   // NTAPS == 1: two buffers
+    float* Ws = As + ((NTAPS == 1) ? 2 * asz : asz);    // two buffers of WSZ floats
+    int* rowa = (int*)(Ws + 2 * WSZ);
     int* rowy = rowa + MT;
 
     const int tid = threadIdx.x;
@@ -88,6 +91,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(TapGemmArgs g) {
 
     const int nkc = (K + KC - 1) / KC;
     const int nsteps = nkc * NTAPS;
+    const int atotal = arows * 8;                       // float4 of one A chunk tile
     float4 wreg[WREG];
     float4 areg[AREG];
 
@@ -111,16 +115,16 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(TapGemmArgs g) {
             wreg[i] = v;
         }
     };
-    auto store_w = [&]() {
+    auto store_w = [&](float* dst) {
 #pragma unroll
         for (int i = 0; i < WREG; ++i) {
             const int f = tid + i * 256;
             if (WMODE == 0) {
                 const int k = f / (NT / 4), n4 = f - k * (NT / 4);
-                *(float4*)(Ws + k * NT + n4 * 4) = wreg[i];
+                *(float4*)(dst + k * NT + n4 * 4) = wreg[i];
             } else {
                 const int n = f >> 3, k4 = f & 7;
-                float* d = Ws + n * (KC + 1) + k4 * 4;
+                float* d = dst + n * (KC + 1) + k4 * 4;
                 d[0] = wreg[i].x; d[1] = wreg[i].y; d[2] = wreg[i].z; d[3] = wreg[i].w;
             }
         }
@@ -134,41 +138,44 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(TapGemmArgs g) {
             v = *(const float4*)(g.A + grow * g.lda + kk);
         return v;
     };
-
-    load_w(0);
-    if (NTAPS == 1) {
+    auto load_a = [&](int kc) {          // issue-early half of the A staging
 #pragma unroll
-        for (int i = 0; i < AREG; ++i) areg[i] = load_a_row(tid + i * 256, 0);
-    }
+        for (int i = 0; i < AREG; ++i) {
+            const int f = tid + i * 256;
+            areg[i] = (f < atotal) ? load_a_row(f, kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_a = [&](float* dst, int kc) {   // write-late half (+ direct staging of rows beyond the prefetch)
+#pragma unroll
+        for (int i = 0; i < AREG; ++i) {
+            const int f = tid + i * 256;
+            if (f < atotal) *(float4*)(dst + (f >> 3) * AP + (f & 7) * 4) = areg[i];
+        }
+        for (int f = tid + AREG * 256; f < atotal; f += 256)
+            *(float4*)(dst + (f >> 3) * AP + (f & 7) * 4) = load_a_row(f, kc);
+    };
 
+    // prologue: tile 0 of A and W
+    load_w(0);
+    load_a(0);
+    store_a(As, 0);
+    store_w(Ws);
+    __syncthreads();
+    if (nsteps > 1) load_w(1);
+    if (NTAPS == 1 && nkc > 1) load_a(1);
+
+    int cur = 0;
     for (int step = 0; step < nsteps; ++step) {
         const int kc = step / NTAPS, tap = step - kc * NTAPS;
-        __syncthreads();
-        if (tap == 0) {
-            if (NTAPS == 1) {
-#pragma unroll
-                for (int i = 0; i < AREG; ++i) {
-                    const int f = tid + i * 256;
-                    *(float4*)(As + (f >> 3) * AP + (f & 7) * 4) = areg[i];
-                }
-            } else {
-                for (int f = tid; f < arows * 8; f += 256)
-                    *(float4*)(As + (f >> 3) * AP + (f & 7) * 4) = load_a_row(f, kc);
-            }
-        }
-        store_w();
-        __syncthreads();
-        if (step + 1 < nsteps) {
-            load_w(step + 1);
-            if (NTAPS == 1) {
-#pragma unroll
-                for (int i = 0; i < AREG; ++i) areg[i] = load_a_row(tid + i * 256, kc + 1);
-            }
-        }
+        const bool more = step + 1 < nsteps;
+        if (NTAPS == 9 && tap == 3 && kc + 1 < nkc) load_a(kc + 1);
+
+        const float* Ac = (NTAPS == 1) ? As + cur * asz : As;
+        const float* Wc = Ws + cur * WSZ;
         const int toff = halo + ((NTAPS == 9) ? ((tap / 3) - 1) * g.WP + (tap % 3) - 1 : 0);
-        const float* abase = As + (wm * (TM * 32) + li + toff) * AP + 4 * lh;
-        const float* wbase = (WMODE == 0) ? (Ws + (4 * lh) * NT + wn * (TN * 32) + li)
-                                          : (Ws + (wn * (TN * 32) + li) * (KC + 1) + 4 * lh);
+        const float* abase = Ac + (wm * (TM * 32) + li + toff) * AP + 4 * lh;
+        const float* wbase = (WMODE == 0) ? (Wc + (4 * lh) * NT + wn * (TN * 32) + li)
+                                          : (Wc + (wn * (TN * 32) + li) * (KC + 1) + 4 * lh);
 #pragma unroll
         for (int gk = 0; gk < KC / 8; ++gk) {
             float4 av[TM];
@@ -192,6 +199,21 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(TapGemmArgs g) {
                 }
             }
         }
+
+        // write-late: the next step's tiles go into the other buffers (last read one barrier ago)
+        if (more) {
+            store_w(Ws + (cur ^ 1) * WSZ);
+            if (step + 2 < nsteps) load_w(step + 2);
+            if (NTAPS == 1) {
+                store_a(As + (cur ^ 1) * asz, kc + 1);
+                if (kc + 2 < nkc) load_a(kc + 2);
+            } else if (tap == NTAPS - 1) {
+                __syncthreads();                 // every wave is done with this chunk's A tile
+                store_a(As, kc + 1);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -228,7 +250,7 @@ int launch_cfg(const TapGemmArgs& a, hipStream_t st) {
     auto kern = tap_gemm_kernel<MT, NT, WM, WN, NTAPS, WMODE>;
     const int arows = MT + 2 * a.halo;
     const size_t wfl = ((WMODE == 0) ? KC * NT : NT * (KC + 1) + 3) / 4 * 4;
-    const size_t lds = ((size_t)arows * AP + wfl) * sizeof(float) + 2 * MT * sizeof(int);
+    const size_t lds = ((size_t)arows * AP * (NTAPS == 1 ? 2 : 1) + 2 * wfl) * sizeof(float) + 2 * MT * sizeof(int);
     if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {

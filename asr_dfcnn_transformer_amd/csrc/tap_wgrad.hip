@@ -23,7 +23,7 @@ struct WgradArgs {
 };
 
 template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS>
-__global__ __launch_bounds__(256, 2) void tap_wgrad_kernel(WgradArgs g) {
+__global__ __launch_bounds__(256) void tap_wgrad_kernel(WgradArgs g) {
     constexpr int WAVES_P = 4 / WAVES_N;
     constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32;
     constexpr int NACC = NTAPS * TKW * TNW;
@@ -31,8 +31,7 @@ __global__ __launch_bounds__(256, 2) void tap_wgrad_kernel(WgradArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int halo = g.halo;
     const int arows = PS + 2 * halo;
-    float* As = smem;                 // [arows][KT]
-    float* Zs = As + arows * KT;      // [PS][NT]
+    const int bufsz = arows * KT + PS * NT;   // one staging buffer: A run [arows][KT] then dZ run [PS][NT]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -52,27 +51,66 @@ __global__ __launch_bounds__(256, 2) void tap_wgrad_kernel(WgradArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
 
-    for (long ps0 = cbeg; ps0 < cend; ps0 += PS) {
-        __syncthreads();
-        for (int f = tid; f < arows * (KT / 4); f += 256) {
-            const int row = f / (KT / 4), c4 = f - row * (KT / 4);
-            const long grow = ps0 - halo + row;
-            const int kk = k0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (grow >= g.rmin && grow < g.rmax && kk < g.K)
-                v = *(const float4*)(g.A + grow * g.lda + kk);
-            *(float4*)(As + row * KT + c4 * 4) = v;
+    // issue-early / write-late staging: the next run of pixels is loaded into registers while the
+    // MFMAs of the current run execute, and written to LDS after the barrier that retires it.
+    constexpr int HALO_MAX = (NTAPS == 9) ? 103 : 0;                     // W + 3 of the widest DFCNN plane (100 + 3)
+    constexpr int AR = ((PS + 2 * HALO_MAX) * (KT / 4) + 255) / 256;     // float4 per thread, A run (+ halo)
+    constexpr int ZR = (PS * (NT / 4) + 255) / 256;                      // float4 per thread, dZ run
+    const int atotal = arows * (KT / 4);
+    float4 areg[AR], zreg[ZR];
+    auto load_a_one = [&](int f, long ps0) -> float4 {
+        const int row = f / (KT / 4), c4 = f - row * (KT / 4);
+        const long grow = ps0 - halo + row;
+        const int kk = k0 + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grow >= g.rmin && grow < g.rmax && kk < g.K) v = *(const float4*)(g.A + grow * g.lda + kk);
+        return v;
+    };
+    auto load_tiles = [&](long ps0) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int f = tid + i * 256;
+            areg[i] = (f < atotal) ? load_a_one(f, ps0) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        for (int f = tid; f < PS * (NT / 4); f += 256) {
+#pragma unroll
+        for (int i = 0; i < ZR; ++i) {
+            const int f = tid + i * 256;
             const int row = f / (NT / 4), n4 = f - row * (NT / 4);
             const long grow = ps0 + row;
             const int nn = n0 + n4 * 4;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (grow < cend && nn < g.N)
-                v = *(const float4*)(g.Z + grow * g.ldz + nn);
-            *(float4*)(Zs + row * NT + n4 * 4) = v;
+            if (f < PS * (NT / 4) && grow < cend && nn < g.N) v = *(const float4*)(g.Z + grow * g.ldz + nn);
+            zreg[i] = v;
         }
-        __syncthreads();
+    };
+    auto store_tiles = [&](long ps0, float* As) {
+        float* Zs = As + arows * KT;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int f = tid + i * 256;
+            if (f < atotal) { const int row = f / (KT / 4), c4 = f - row * (KT / 4); *(float4*)(As + row * KT + c4 * 4) = areg[i]; }
+        }
+        for (int f = tid + AR * 256; f < atotal; f += 256) {           // planes wider than HALO_MAX: direct
+            const int row = f / (KT / 4), c4 = f - row * (KT / 4);
+            *(float4*)(As + row * KT + c4 * 4) = load_a_one(f, ps0);
+        }
+#pragma unroll
+        for (int i = 0; i < ZR; ++i) {
+            const int f = tid + i * 256;
+            if (f < PS * (NT / 4)) { const int row = f / (NT / 4), n4 = f - row * (NT / 4); *(float4*)(Zs + row * NT + n4 * 4) = zreg[i]; }
+        }
+    };
+
+    // two LDS buffers, one barrier per run: run i+1 is written into the other buffer while
+    // slower waves may still read run i; the barrier at the end of the iteration retires both.
+    load_tiles(cbeg);
+    store_tiles(cbeg, smem);
+    __syncthreads();
+    if (cbeg + PS < cend) load_tiles(cbeg + PS);
+    int cur = 0;
+    for (long ps0 = cbeg; ps0 < cend; ps0 += PS) {
+        const float* As = smem + cur * bufsz;
+        const float* Zs = As + arows * KT;
         for (int r = 2 * wp; r < PS; r += 2 * WAVES_P) {
             float bz[TNW];
 #pragma unroll
@@ -90,6 +128,12 @@ __global__ __launch_bounds__(256, 2) void tap_wgrad_kernel(WgradArgs g) {
                 }
             }
         }
+        if (ps0 + PS < cend) {
+            store_tiles(ps0 + PS, smem + (cur ^ 1) * bufsz);
+            if (ps0 + 2 * PS < cend) load_tiles(ps0 + 2 * PS);
+        }
+        __syncthreads();
+        cur ^= 1;
     }
 
     // fold the pixel-split waves of this block through LDS, one tap at a time (keeps the
@@ -147,20 +191,25 @@ __global__ void sum_chunks_kernel(const float* __restrict__ part, float* __restr
                                   long n, int nchunks) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i >= n) return;
-    if (i + 4 <= n) {
-        float4 s = *(const float4*)(part + i);
-        for (int c = 1; c < nchunks; ++c) {
-            const float4 v = *(const float4*)(part + (long)c * n + i);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        *(float4*)(out + i) = s;
-    } else {
-        for (long j = i; j < n; ++j) {
-            float s = part[j];
-            for (int c = 1; c < nchunks; ++c) s += part[(long)c * n + j];
-            out[j] = s;
-        }
+    // four independent chains over the chunks (loads in flight together), folded in a fixed order
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    int c = 0;
+    for (; c + 4 <= nchunks; c += 4) {
+        const float4 v0 = *(const float4*)(part + (long)c * n + i);
+        const float4 v1 = *(const float4*)(part + (long)(c + 1) * n + i);
+        const float4 v2 = *(const float4*)(part + (long)(c + 2) * n + i);
+        const float4 v3 = *(const float4*)(part + (long)(c + 3) * n + i);
+        s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+        s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+        s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
+        s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
     }
+    for (; c < nchunks; ++c) {
+        const float4 v = *(const float4*)(part + (long)c * n + i);
+        s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+    }
+    *(float4*)(out + i) = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y),
+                                      (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
 }
 
 struct Plan { int ktile, ntile, ps, nchunks, pch; };
@@ -193,7 +242,7 @@ template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS>
 int launch_wgrad(const WgradArgs& a, const Plan& p, int K, int N, hipStream_t st) {
     auto kern = tap_wgrad_kernel<NTAPS, TKW, WAVES_N, TNW, PS>;
     constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32, NACC = NTAPS * TKW * TNW;
-    size_t lds = ((size_t)(PS + 2 * a.halo) * KT + (size_t)PS * NT) * sizeof(float);
+    size_t lds = 2 * ((size_t)(PS + 2 * a.halo) * KT + (size_t)PS * NT) * sizeof(float);
     const size_t red = (size_t)(4 / WAVES_N - 1) * WAVES_N * TKW * TNW * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
     if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
@@ -244,7 +293,7 @@ extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float
     if (rc != ASR_OK) return rc;
     if (p.nchunks > 1) {
         const long n = a.slab;
-        const int threads = 256;
+        const int threads = 64;
         const int blocks = asr_cdiv(asr_cdiv(n, 4), threads);
         hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks), dim3(threads), 0, st, partials, dW, n, p.nchunks);
         ASR_CHECK_LAUNCH("sum_chunks");

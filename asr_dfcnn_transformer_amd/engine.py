@@ -293,6 +293,7 @@ class DFCNNEngine:
         self.ctc_ws = torch.zeros(ops.ctc_workspace(T8, B, MAX_LABEL) // 8 + 8, dtype=torch.float64, device=dev)
         self.dec_ids = torch.zeros(B, T8, dtype=torch.int32, device=dev)
         self.dec_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.dec_ws = torch.zeros(ops.ctc_greedy_workspace(T8, B) // 4 + 4, dtype=torch.int32, device=dev)
         self.neg_sum = torch.zeros(B, dtype=torch.float32, device=dev)
         self.dist = torch.zeros(B, dtype=torch.float32, device=dev)
         self.scalars = torch.zeros(8, dtype=torch.float32, device=dev)     # [0] sum loss, [1] sum dist
@@ -396,7 +397,7 @@ class DFCNNEngine:
         B, T8, V = self.B, self.T8, self.V
         ops.ctc_loss(self.logits, T8, B, V, self.labels, MAX_LABEL, self.label_len, self.seq_len, V - 1,
                      self.loss, self.ctc_grad, self.ctc_status, self.ctc_ws)
-        ops.ctc_greedy(self.logits, T8, B, V, self.seq_len, V - 1, self.dec_ids, self.dec_len, self.neg_sum)
+        ops.ctc_greedy(self.logits, T8, B, V, self.seq_len, V - 1, self.dec_ids, self.dec_len, self.neg_sum, self.dec_ws)
         ops.edit_distance(self.dec_ids, T8, self.dec_len, self.labels, MAX_LABEL, self.label_len, B, self.dist)
         ops.colsum(self.loss, B, 1, 1, self.scalars[0:1], self.ws)
         ops.colsum(self.dist, B, 1, 1, self.scalars[1:2], self.ws)

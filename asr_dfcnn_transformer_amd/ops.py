@@ -216,9 +216,13 @@ def ctc_loss(logits_tm, T, B, V, labels, max_label, label_len, seq_len, blank, l
           'asr_ctc_loss')
 
 
-def ctc_greedy(logits_tm, T, B, V, seq_len, blank, out_ids, out_len, neg_sum):
+def ctc_greedy_workspace(T, B):
+    return _lib.load().asr_ctc_greedy_workspace(T, B)
+
+
+def ctc_greedy(logits_tm, T, B, V, seq_len, blank, out_ids, out_len, neg_sum, workspace):
     check(_lib.load().asr_ctc_greedy(_ptr(logits_tm), T, B, V, _ptr(seq_len), blank, _ptr(out_ids), _ptr(out_len),
-                                     _ptr(neg_sum), _stream()), 'asr_ctc_greedy')
+                                     _ptr(neg_sum), _ptr(workspace), _stream()), 'asr_ctc_greedy')
 
 
 def edit_distance(hyp, hyp_pitch, hyp_len, truth, truth_pitch, truth_len, B, dist):

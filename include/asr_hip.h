@@ -198,8 +198,9 @@ int asr_ctc_loss(const float* logits_tm, int T, int B, int V, const int32_t* lab
  * tf.edit_distance(decoded, sparse_labels, normalize=True) (acoustic_model2.py:72):
  *   dist [B] f32 = levenshtein / len(truth)  (inf if truth empty and hyp not).
  */
+size_t asr_ctc_greedy_workspace(int T, int B);
 int asr_ctc_greedy(const float* logits_tm, int T, int B, int V, const int32_t* seq_len, int blank,
-                   int32_t* out_ids, int32_t* out_len, float* neg_sum_logits, void* stream);
+                   int32_t* out_ids, int32_t* out_len, float* neg_sum_logits, void* workspace, void* stream);
 int asr_edit_distance(const int32_t* hyp, int hyp_pitch, const int32_t* hyp_len,
                       const int32_t* truth, int truth_pitch, const int32_t* truth_len,
                       int B, float* dist, void* stream);

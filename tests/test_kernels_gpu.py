@@ -360,7 +360,8 @@ def test_greedy_decode_bit_exact(ops):
     ids = torch.zeros(B, T, dtype=torch.int32, device='cuda')
     n = torch.zeros(B, dtype=torch.int32, device='cuda')
     neg = torch.zeros(B, device='cuda')
-    ops.ctc_greedy(dev(x), T, B, V, dev(np.array(seq), torch.int32), V - 1, ids, n, neg)
+    ops.ctc_greedy(dev(x), T, B, V, dev(np.array(seq), torch.int32), V - 1, ids, n, neg,
+                   torch.zeros(ops.ctc_greedy_workspace(T, B) // 4 + 4, dtype=torch.int32, device='cuda'))
     ids, n = ids.cpu().numpy(), n.cpu().numpy()
     for b in range(B):
         assert n[b] == len(dec_ref[b])
