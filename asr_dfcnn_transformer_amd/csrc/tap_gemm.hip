@@ -16,6 +16,7 @@
 //     tap run (issue-early / write-late staging); 2-3 blocks per CU cover the rest;
 //   * epilogue fuses bias + ReLU (+ the frozen-BN affine) and skips border pixels.
 #include "asr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(TapGemmArgs g) {
     constexpr int WREG = KC * NT / 4 / 256;            // float4 per thread per weight tile
     // float4 per thread of the A-tile register prefetch: the whole tile for the shapes of the
     // DFCNN planes (W+2 <= 52 at MT = 128, <= 102 at MT = 256); wider planes stage the rest directly
-    constexpr int AREG = (NTAPS == 1) ? MT * 8 / 256 : (MT == 128 ? 8 : 15);
+    constexpr int AREG = (NTAPS == 1) ? MT * 8 / 256 : (MT <= 128 ? 8 : 15);
     constexpr int WSZ = ((WMODE == 0) ? KC * NT : NT * (KC + 1) + 3) / 4 * 4;
     static_assert(WREG >= 1 && TM >= 1 && TN >= 1, "tile");
 
@@ -245,17 +246,224 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(TapGemmArgs g) {
     }
 }
 
+// ---- v1: single-buffered W, direct A staging, two barriers per tap, 3 blocks per CU
+template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE>
+__global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
+    constexpr int TM = MT / WM / 32, TN = NT / WN / 32;
+    constexpr int WREG = KC * NT / 4 / 256;            // float4 per thread per weight tile
+    constexpr int AREG = (NTAPS == 1) ? MT * 8 / 256 : 1;
+    constexpr int WPITCH = (WMODE == 0) ? NT : (KC + 1);
+    static_assert(WREG >= 1 && TM >= 1 && TN >= 1, "tile");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int halo = g.halo;
+    const int arows = MT + 2 * halo;
+    float* As = smem;
+    float* Ws = As + arows * AP;
+    int* rowa = (int*)(Ws + ((WMODE == 0) ? KC * NT : NT * (KC + 1) + 3) / 4 * 4);
+    int* rowy = rowa + MT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+
+    const int swz = asr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_m = swz / g.ntn, tile_n = swz - tile_m * g.ntn;
+    const long p0 = (long)tile_m * MT;
+    const int n0 = tile_n * NT;
+    const int K = g.K, N = g.N;
+
+    if (tid < MT) {
+        const long p = p0 + tid;
+        int ra = -1, ry = -1;
+        if (p < g.M) {
+            if (g.H == 0) {
+                ra = (int)p; ry = (int)p;
+            } else {
+                const int b = (int)(p / g.HPWP);
+                const int r = (int)(p - (long)b * g.HPWP);
+                const int hh = r / g.WP, ww = r - hh * g.WP;
+                if (hh >= 1 && hh <= g.H && ww >= 1 && ww <= g.Wd) {
+                    ra = (int)p;
+                    ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : (int)p;
+                }
+            }
+        }
+        rowa[tid] = ra; rowy[tid] = ry;
+    }
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nkc = (K + KC - 1) / KC;
+    const int nsteps = nkc * NTAPS;
+    float4 wreg[WREG];
+    float4 areg[AREG];
+
+    auto load_w = [&](int step) {
+        const int kc = step / NTAPS, tap = step - kc * NTAPS;
+#pragma unroll
+        for (int i = 0; i < WREG; ++i) {
+            const int f = tid + i * 256;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (WMODE == 0) {
+                const int k = f / (NT / 4), n4 = f - k * (NT / 4);
+                const int kk = kc * KC + k, nn = n0 + n4 * 4;
+                if (kk < K && nn < N)
+                    v = *(const float4*)(g.W + ((long)tap * K + kk) * g.ldw + nn);
+            } else {
+                const int n = f >> 3, k4 = f & 7;
+                const int kk = kc * KC + k4 * 4, nn = n0 + n;
+                if (kk < K && nn < N)
+                    v = *(const float4*)(g.W + ((long)(NTAPS - 1 - tap) * N + nn) * g.ldw + kk);
+            }
+            wreg[i] = v;
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < WREG; ++i) {
+            const int f = tid + i * 256;
+            if (WMODE == 0) {
+                const int k = f / (NT / 4), n4 = f - k * (NT / 4);
+                *(float4*)(Ws + k * NT + n4 * 4) = wreg[i];
+            } else {
+                const int n = f >> 3, k4 = f & 7;
+                float* d = Ws + n * (KC + 1) + k4 * 4;
+                d[0] = wreg[i].x; d[1] = wreg[i].y; d[2] = wreg[i].z; d[3] = wreg[i].w;
+            }
+        }
+    };
+    auto load_a_row = [&](int f, int kc) -> float4 {
+        const int row = f >> 3, c4 = f & 7;
+        const long grow = p0 - halo + row;
+        const int kk = kc * KC + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grow >= g.rmin && grow < g.rmax && kk < K)
+            v = *(const float4*)(g.A + grow * g.lda + kk);
+        return v;
+    };
+
+    load_w(0);
+    if (NTAPS == 1) {
+#pragma unroll
+        for (int i = 0; i < AREG; ++i) areg[i] = load_a_row(tid + i * 256, 0);
+    }
+
+    for (int step = 0; step < nsteps; ++step) {
+        const int kc = step / NTAPS, tap = step - kc * NTAPS;
+        __syncthreads();
+        if (tap == 0) {
+            if (NTAPS == 1) {
+#pragma unroll
+                for (int i = 0; i < AREG; ++i) {
+                    const int f = tid + i * 256;
+                    *(float4*)(As + (f >> 3) * AP + (f & 7) * 4) = areg[i];
+                }
+            } else {
+                for (int f = tid; f < arows * 8; f += 256)
+                    *(float4*)(As + (f >> 3) * AP + (f & 7) * 4) = load_a_row(f, kc);
+            }
+        }
+        store_w();
+        __syncthreads();
+        if (step + 1 < nsteps) {
+            load_w(step + 1);
+            if (NTAPS == 1) {
+#pragma unroll
+                for (int i = 0; i < AREG; ++i) areg[i] = load_a_row(tid + i * 256, kc + 1);
+            }
+        }
+        const int toff = halo + ((NTAPS == 9) ? ((tap / 3) - 1) * g.WP + (tap % 3) - 1 : 0);
+        const float* abase = As + (wm * (TM * 32) + li + toff) * AP + 4 * lh;
+        const float* wbase = (WMODE == 0) ? (Ws + (4 * lh) * NT + wn * (TN * 32) + li)
+                                          : (Ws + (wn * (TN * 32) + li) * (KC + 1) + 4 * lh);
+#pragma unroll
+        for (int gk = 0; gk < KC / 8; ++gk) {
+            float4 av[TM];
+            float bv[TN][4];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) av[a] = *(const float4*)(abase + a * 32 * AP + gk * 8);
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    bv[b][s] = (WMODE == 0) ? wbase[(gk * 8 + s) * NT + b * 32]
+                                            : wbase[b * 32 * (KC + 1) + gk * 8 + s];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const float as = (s == 0) ? av[a].x : (s == 1) ? av[a].y : (s == 2) ? av[a].z : av[a].w;
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bv[b][s], acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wn * (TN * 32) + b * 32 + li;
+        if (n >= N) continue;
+        const float bs = g.bias ? g.bias[n] : 0.f;
+        const float sc = g.scale ? g.scale[n] : 1.f;
+        const float sh = g.shift ? g.shift[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * (TM * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int ra = rowa[m];
+                if (ra < 0) continue;
+                float v = acc[a][b][r] + bs;
+                if (g.relu) v = fmaxf(v, 0.f);
+                if (g.out_a) g.out_a[(long)ra * g.ldo_a + n] = v;
+                if (g.out_y) {
+                    float y = sc * v + sh;
+                    float* o = g.out_y + (long)rowy[m] * g.ldo_y + n;
+                    if (g.accumulate) y += *o;
+                    *o = y;
+                }
+            }
+        }
+    }
+}
+
+// Two generations of the main loop are kept because neither wins everywhere (tools/bench_layers.py,
+// MI355X): v1 (single-buffered tiles, two barriers per tap, 3 workgroups per CU) is faster wherever
+// thread-level parallelism hides the staging; v2 (double-buffered W, register-prefetched A, one barrier
+// per tap, 2 workgroups per CU) wins the data-gradients into 32/64 output channels, whose A tiles
+// (wide planes, large halo) are the expensive part.  ASR_TAPGEMM_VARIANT=1|2 forces one for A/B runs.
+inline int tap_gemm_variant(int ntaps, int wmode, int K, int N) {
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("ASR_TAPGEMM_VARIANT"); forced = e ? atoi(e) : 0; }
+    if (forced == 1 || forced == 2) return forced;
+    if (ntaps == 9 && wmode == 1 && N <= 64 && (N > 32 || K >= 64)) return 2;
+    return 1;
+}
+
 template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE>
 int launch_cfg(const TapGemmArgs& a, hipStream_t st) {
-    auto kern = tap_gemm_kernel<MT, NT, WM, WN, NTAPS, WMODE>;
+    const int variant = tap_gemm_variant(NTAPS, WMODE, a.K, a.N);
+    auto kern = (variant == 1) ? tap_gemm_kernel_v1<MT, NT, WM, WN, NTAPS, WMODE> : tap_gemm_kernel<MT, NT, WM, WN, NTAPS, WMODE>;
     const int arows = MT + 2 * a.halo;
     const size_t wfl = ((WMODE == 0) ? KC * NT : NT * (KC + 1) + 3) / 4 * 4;
-    const size_t lds = ((size_t)arows * AP * (NTAPS == 1 ? 2 : 1) + 2 * wfl) * sizeof(float) + 2 * MT * sizeof(int);
+    const size_t lds = (variant == 1)
+        ? ((size_t)arows * AP + wfl) * sizeof(float) + 2 * MT * sizeof(int)
+        : ((size_t)arows * AP * (NTAPS == 1 ? 2 : 1) + 2 * wfl) * sizeof(float) + 2 * MT * sizeof(int);
     if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[variant == 1]) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set[variant == 1] = true;
     }
     TapGemmArgs g = a;
     g.ntm = asr_cdiv(a.M, MT);
@@ -267,6 +475,12 @@ int launch_cfg(const TapGemmArgs& a, hipStream_t st) {
 
 template <int NTAPS, int WMODE>
 int launch_n(const TapGemmArgs& a, hipStream_t st) {
+    if (NTAPS == 1 && a.N > 32) {
+        // a grid of 128x128 tiles that leaves most CUs idle (e.g. the 6400->128 hidden dense of
+        // acoustic_model.py: 50 tiles) runs on 64x64 tiles instead
+        const long tiles = (long)asr_cdiv(a.M, 128) * asr_cdiv(a.N, 128);
+        if (tiles < 160) return launch_cfg<64, 64, 2, 2, NTAPS, WMODE>(a, st);
+    }
     if (a.N > 64) return launch_cfg<128, 128, 2, 2, NTAPS, WMODE>(a, st);
     if (a.N > 32) return launch_cfg<256, 64, 4, 1, NTAPS, WMODE>(a, st);
     return launch_cfg<256, 32, 4, 1, NTAPS, WMODE>(a, st);

@@ -10,6 +10,7 @@
 // Chunk partials go to a slab and are summed by a second, fixed-order pass, so the
 // result is bitwise reproducible (no float atomics).
 #include "asr_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -187,6 +188,128 @@ __global__ __launch_bounds__(256) void tap_wgrad_kernel(WgradArgs g) {
             }
 }
 
+// ---- v1: direct staging, two barriers per run, two blocks per CU
+template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS>
+__global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_v1(WgradArgs g) {
+    constexpr int WAVES_P = 4 / WAVES_N;
+    constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32;
+    constexpr int NACC = NTAPS * TKW * TNW;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int halo = g.halo;
+    const int arows = PS + 2 * halo;
+    float* As = smem;                 // [arows][KT]
+    float* Zs = As + arows * KT;      // [PS][NT]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = tid >> 6, wn = wave % WAVES_N, wp = wave / WAVES_N;
+    const int chunk = blockIdx.x;
+    const int k0 = blockIdx.y * KT, n0 = blockIdx.z * NT;
+    const long cbeg = (long)chunk * g.pch;
+    const long cend = (cbeg + g.pch < g.M) ? cbeg + g.pch : g.M;
+
+    floatx16 acc[NTAPS][TKW][TNW];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int a = 0; a < TKW; ++a)
+#pragma unroll
+            for (int b = 0; b < TNW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
+
+    for (long ps0 = cbeg; ps0 < cend; ps0 += PS) {
+        __syncthreads();
+        for (int f = tid; f < arows * (KT / 4); f += 256) {
+            const int row = f / (KT / 4), c4 = f - row * (KT / 4);
+            const long grow = ps0 - halo + row;
+            const int kk = k0 + c4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grow >= g.rmin && grow < g.rmax && kk < g.K)
+                v = *(const float4*)(g.A + grow * g.lda + kk);
+            *(float4*)(As + row * KT + c4 * 4) = v;
+        }
+        for (int f = tid; f < PS * (NT / 4); f += 256) {
+            const int row = f / (NT / 4), n4 = f - row * (NT / 4);
+            const long grow = ps0 + row;
+            const int nn = n0 + n4 * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grow < cend && nn < g.N)
+                v = *(const float4*)(g.Z + grow * g.ldz + nn);
+            *(float4*)(Zs + row * NT + n4 * 4) = v;
+        }
+        __syncthreads();
+        for (int r = 2 * wp; r < PS; r += 2 * WAVES_P) {
+            float bz[TNW];
+#pragma unroll
+            for (int b = 0; b < TNW; ++b) bz[b] = Zs[(r + lh) * NT + (wn * TNW + b) * 32 + li];
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                const int off = (NTAPS == 9) ? ((t / 3) - 1) * g.WP + (t % 3) - 1 : 0;
+                const float* ar = As + (r + lh + halo + off) * KT + li;
+#pragma unroll
+                for (int a = 0; a < TKW; ++a) {
+                    const float av = ar[a * 32];
+#pragma unroll
+                    for (int b = 0; b < TNW; ++b)
+                        acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bz[b], acc[t][a][b], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // fold the pixel-split waves of this block through LDS, one tap at a time (keeps the
+    // transfer at 16 registers per lane) and in a fixed order wp = 1, 2, ...
+    if (WAVES_P > 1) {
+        float* red = smem;   // [WAVES_P-1][WAVES_N][TKW*TNW*16][64]
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            __syncthreads();
+            if (wp > 0) {
+                float* dst = red + (((wp - 1) * WAVES_N + wn) * (TKW * TNW * 16)) * 64 + lane;
+#pragma unroll
+                for (int a = 0; a < TKW; ++a)
+#pragma unroll
+                    for (int b = 0; b < TNW; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            dst[((a * TNW + b) * 16 + r) * 64] = acc[t][a][b][r];
+            }
+            __syncthreads();
+            if (wp == 0) {
+                for (int src = 1; src < WAVES_P; ++src) {
+                    const float* sp = red + (((src - 1) * WAVES_N + wn) * (TKW * TNW * 16)) * 64 + lane;
+#pragma unroll
+                    for (int a = 0; a < TKW; ++a)
+#pragma unroll
+                        for (int b = 0; b < TNW; ++b)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                acc[t][a][b][r] += sp[((a * TNW + b) * 16 + r) * 64];
+                }
+            }
+        }
+    }
+    if (wp != 0) return;
+
+    float* out = g.out + (long)chunk * g.slab;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int a = 0; a < TKW; ++a)
+#pragma unroll
+            for (int b = 0; b < TNW; ++b) {
+                const int n = n0 + (wn * TNW + b) * 32 + li;
+                if (n >= g.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = k0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (k < g.K) out[((long)t * g.K + k) * g.N + n] = acc[t][a][b][r];
+                }
+            }
+}
+
 __global__ void sum_chunks_kernel(const float* __restrict__ part, float* __restrict__ out,
                                   long n, int nchunks) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -240,16 +363,21 @@ Plan make_plan(const asr_gemm_desc* d) {
 
 template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS>
 int launch_wgrad(const WgradArgs& a, const Plan& p, int K, int N, hipStream_t st) {
-    auto kern = tap_wgrad_kernel<NTAPS, TKW, WAVES_N, TNW, PS>;
+    // v1 (direct staging, 2 workgroups per CU) is faster for the 128-wide 3x3 layers, v2 (register prefetch +
+    // LDS double buffer, 1 workgroup per CU) everywhere else (tools/bench_layers.py); ASR_WGRAD_VARIANT forces one.
+    static int forced = -1;
+    if (forced < 0) { const char* e = getenv("ASR_WGRAD_VARIANT"); forced = e ? atoi(e) : 0; }
+    const int variant = (forced == 1 || forced == 2) ? forced : ((NTAPS == 9 && WAVES_N == 4) ? 1 : 2);
+    auto kern = (variant == 1) ? tap_wgrad_kernel_v1<NTAPS, TKW, WAVES_N, TNW, PS> : tap_wgrad_kernel<NTAPS, TKW, WAVES_N, TNW, PS>;
     constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32, NACC = NTAPS * TKW * TNW;
-    size_t lds = 2 * ((size_t)(PS + 2 * a.halo) * KT + (size_t)PS * NT) * sizeof(float);
+    size_t lds = (variant == 1 ? 1 : 2) * ((size_t)(PS + 2 * a.halo) * KT + (size_t)PS * NT) * sizeof(float);
     const size_t red = (size_t)(4 / WAVES_N - 1) * WAVES_N * TKW * TNW * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
     if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[variant == 1]) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        attr_set[variant == 1] = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.nchunks, asr_cdiv(K, KT), asr_cdiv(N, NT)), dim3(256), lds, st, a);
     ASR_CHECK_LAUNCH("tap_wgrad");
