@@ -247,11 +247,12 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(TapGemmArgs g) {
 }
 
 // ---- v1: single-buffered W, direct A staging, two barriers per tap, 3 blocks per CU
-template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE>
+template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE, int KCV = 32>
 __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
+    constexpr int KC = KCV, AP = KCV + 4;   // shadow the file-level chunk size: this generation is instantiated at 16 and 32
     constexpr int TM = MT / WM / 32, TN = NT / WN / 32;
     constexpr int WREG = KC * NT / 4 / 256;            // float4 per thread per weight tile
-    constexpr int AREG = (NTAPS == 1) ? MT * 8 / 256 : 1;
+    constexpr int AREG = (NTAPS == 1) ? MT * (KC / 4) / 256 : 1;
     constexpr int WPITCH = (WMODE == 0) ? NT : (KC + 1);
     static_assert(WREG >= 1 && TM >= 1 && TN >= 1, "tile");
 
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
                 if (kk < K && nn < N)
                     v = *(const float4*)(g.W + ((long)tap * K + kk) * g.ldw + nn);
             } else {
-                const int n = f >> 3, k4 = f & 7;
+                const int n = f / (KC / 4), k4 = f - n * (KC / 4);
                 const int kk = kc * KC + k4 * 4, nn = n0 + n;
                 if (kk < K && nn < N)
                     v = *(const float4*)(g.W + ((long)(NTAPS - 1 - tap) * N + nn) * g.ldw + kk);
@@ -333,14 +334,14 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
                 const int k = f / (NT / 4), n4 = f - k * (NT / 4);
                 *(float4*)(Ws + k * NT + n4 * 4) = wreg[i];
             } else {
-                const int n = f >> 3, k4 = f & 7;
+                const int n = f / (KC / 4), k4 = f - n * (KC / 4);
                 float* d = Ws + n * (KC + 1) + k4 * 4;
                 d[0] = wreg[i].x; d[1] = wreg[i].y; d[2] = wreg[i].z; d[3] = wreg[i].w;
             }
         }
     };
     auto load_a_row = [&](int f, int kc) -> float4 {
-        const int row = f >> 3, c4 = f & 7;
+        const int row = f / (KC / 4), c4 = f - row * (KC / 4);
         const long grow = p0 - halo + row;
         const int kk = kc * KC + c4 * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -363,11 +364,11 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
 #pragma unroll
                 for (int i = 0; i < AREG; ++i) {
                     const int f = tid + i * 256;
-                    *(float4*)(As + (f >> 3) * AP + (f & 7) * 4) = areg[i];
+                    *(float4*)(As + (f / (KC / 4)) * AP + (f % (KC / 4)) * 4) = areg[i];
                 }
             } else {
-                for (int f = tid; f < arows * 8; f += 256)
-                    *(float4*)(As + (f >> 3) * AP + (f & 7) * 4) = load_a_row(f, kc);
+                for (int f = tid; f < arows * (KC / 4); f += 256)
+                    *(float4*)(As + (f / (KC / 4)) * AP + (f % (KC / 4)) * 4) = load_a_row(f, kc);
             }
         }
         store_w();
@@ -450,20 +451,17 @@ inline int tap_gemm_variant(int ntaps, int wmode, int K, int N) {
     return 1;
 }
 
-template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE>
-int launch_cfg(const TapGemmArgs& a, hipStream_t st) {
-    const int variant = tap_gemm_variant(NTAPS, WMODE, a.K, a.N);
-    auto kern = (variant == 1) ? tap_gemm_kernel_v1<MT, NT, WM, WN, NTAPS, WMODE> : tap_gemm_kernel<MT, NT, WM, WN, NTAPS, WMODE>;
+template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE, int KCV>
+int launch_v1(const TapGemmArgs& a, hipStream_t st) {
+    auto kern = tap_gemm_kernel_v1<MT, NT, WM, WN, NTAPS, WMODE, KCV>;
     const int arows = MT + 2 * a.halo;
-    const size_t wfl = ((WMODE == 0) ? KC * NT : NT * (KC + 1) + 3) / 4 * 4;
-    const size_t lds = (variant == 1)
-        ? ((size_t)arows * AP + wfl) * sizeof(float) + 2 * MT * sizeof(int)
-        : ((size_t)arows * AP * (NTAPS == 1 ? 2 : 1) + 2 * wfl) * sizeof(float) + 2 * MT * sizeof(int);
+    const size_t wfl = ((WMODE == 0) ? KCV * NT : NT * (KCV + 1) + 3) / 4 * 4;
+    const size_t lds = ((size_t)arows * (KCV + 4) + wfl) * sizeof(float) + 2 * MT * sizeof(int);
     if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[variant == 1]) {
+    static bool attr_set = false;
+    if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[variant == 1] = true;
+        attr_set = true;
     }
     TapGemmArgs g = a;
     g.ntm = asr_cdiv(a.M, MT);
@@ -473,6 +471,38 @@ int launch_cfg(const TapGemmArgs& a, hipStream_t st) {
     return ASR_OK;
 }
 
+template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE>
+int launch_v2(const TapGemmArgs& a, hipStream_t st) {
+    auto kern = tap_gemm_kernel<MT, NT, WM, WN, NTAPS, WMODE>;
+    const int arows = MT + 2 * a.halo;
+    const size_t wfl = ((WMODE == 0) ? KC * NT : NT * (KC + 1) + 3) / 4 * 4;
+    const size_t lds = ((size_t)arows * AP * (NTAPS == 1 ? 2 : 1) + 2 * wfl) * sizeof(float) + 2 * MT * sizeof(int);
+    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    TapGemmArgs g = a;
+    g.ntm = asr_cdiv(a.M, MT);
+    g.ntn = asr_cdiv(a.N, NT);
+    hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn), dim3(256), lds, st, g);
+    ASR_CHECK_LAUNCH("tap_gemm");
+    return ASR_OK;
+}
+
+template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE>
+int launch_cfg(const TapGemmArgs& a, hipStream_t st) {
+    if (tap_gemm_variant(NTAPS, WMODE, a.K, a.N) == 1) return launch_v1<MT, NT, WM, WN, NTAPS, WMODE, 32>(a, st);
+    return launch_v2<MT, NT, WM, WN, NTAPS, WMODE>(a, st);
+}
+
+inline int tap_gemm_experiment() {      // tuning experiments (tools/bench_layers.py): 0 none, 1 NT=64 tiles, 2 KC=16
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ASR_TG_EXP"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
 template <int NTAPS, int WMODE>
 int launch_n(const TapGemmArgs& a, hipStream_t st) {
     if (NTAPS == 1 && a.N > 32) {
@@ -480,6 +510,24 @@ int launch_n(const TapGemmArgs& a, hipStream_t st) {
         // acoustic_model.py: 50 tiles) runs on 64x64 tiles instead
         const long tiles = (long)asr_cdiv(a.M, 128) * asr_cdiv(a.N, 128);
         if (tiles < 160) return launch_cfg<64, 64, 2, 2, NTAPS, WMODE>(a, st);
+    }
+    if (NTAPS == 9) {
+        const int ex = tap_gemm_experiment();
+        if (ex == 1 && a.N > 64) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
+        if (ex == 2 && a.N > 64) return launch_v1<128, 128, 2, 2, NTAPS, WMODE, 16>(a, st);
+        if (ex == 2 && a.N > 32) return launch_v1<256, 64, 4, 1, NTAPS, WMODE, 16>(a, st);
+        if (ex == 3 && a.N > 32 && a.N <= 64) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
+        if (ex == 4 && a.N > 32) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 16>(a, st);
+        if (ex == 0) {
+            // measured on the DFCNN layer shapes (tools/bench_layers.py, profiles/r01b_layer_tiles.txt):
+            // 128x64 tiles (more, smaller workgroups per CU) win up to 128 output channels; a 16-deep
+            // K chunk wins while the A tile (plane width + halo) dominates LDS, 32-deep for K >= 128
+            if (a.N > 32 && a.N <= 64) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 16>(a, st);
+            if (a.N > 64 && a.N <= 128) {
+                if (a.K >= 128) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
+                return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 16>(a, st);
+            }
+        }
     }
     if (a.N > 64) return launch_cfg<128, 128, 2, 2, NTAPS, WMODE>(a, st);
     if (a.N > 32) return launch_cfg<256, 64, 4, 1, NTAPS, WMODE>(a, st);

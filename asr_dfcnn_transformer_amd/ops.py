@@ -74,9 +74,35 @@ class KernelTimer:
 TIMER = None
 
 
+def kernel_symbol(family, ntaps, wmode, M, K, N):
+    """The kernel instantiation libasrhip launches for a descriptor (mirrors launch_n / launch_wgrad in
+    csrc/tap_gemm.hip and csrc/tap_wgrad.hip), as rocprofv3 --stats prints it."""
+    if family == 'tap_wgrad':
+        if ntaps == 1:
+            return 'tap_wgrad_kernel<1, 4, 4, 1, 64>'
+        if N > 64:
+            return 'tap_wgrad_kernel_v1<9, 1, 4, 1, 64>'
+        return 'tap_wgrad_kernel<9, 1, 2, 1, 64>' if N > 32 else 'tap_wgrad_kernel<9, 1, 1, 1, 128>'
+    v2 = ntaps == 9 and wmode == 1 and N <= 64 and (N > 32 or K >= 64)
+    if ntaps == 1 and N > 32 and -(-M // 128) * -(-N // 128) < 160:
+        cfg, kc = '64, 64, 2, 2', 32
+    elif ntaps == 9 and 32 < N <= 64:
+        cfg, kc, v2 = '128, 64, 2, 2', 16, False
+    elif ntaps == 9 and 64 < N <= 128:
+        cfg, kc, v2 = '128, 64, 2, 2', (32 if K >= 128 else 16), False
+    elif N > 64:
+        cfg, kc = '128, 128, 2, 2', 32
+    elif N > 32:
+        cfg, kc = '256, 64, 4, 1', 32
+    else:
+        cfg, kc = '256, 32, 4, 1', 32
+    if v2:
+        return 'tap_gemm_kernel<%s, %d, %d>' % (cfg, ntaps, wmode)
+    return 'tap_gemm_kernel_v1<%s, %d, %d, %d>' % (cfg, ntaps, wmode, kc)
+
+
 def _key(family, d):
-    ncls = 128 if d.N > 64 else (64 if d.N > 32 else 32)
-    return (family, d.ntaps, d.wmode, ncls)
+    return kernel_symbol(family, d.ntaps, d.wmode, d.M, d.K, d.N)
 
 
 def _flops(d):

@@ -28,18 +28,8 @@ FP32_PEAK_TFLOPS = 157.3        # MI355X dense fp32 (vector = matrix), MI355X_MI
 
 
 def kernel_name(key):
-    """The kernel symbol (as rocprofv3 --stats prints it) behind a KernelTimer key."""
-    fam, ntaps, wmode, ncls = key
-    if fam == 'tap_gemm':
-        cfg = {128: '128, 128, 2, 2', 64: '256, 64, 4, 1', 32: '256, 32, 4, 1'}[ncls]
-        what = {(9, 0): 'conv3x3 forward', (9, 1): 'conv3x3 data-gradient', (1, 0): 'dense/conv1x1 forward',
-                (1, 1): 'dense/conv1x1 data-gradient'}[(ntaps, wmode)]
-        return 'tap_gemm_kernel<%s, %d, %d> (%s)' % (cfg, ntaps, wmode, what)
-    if ntaps == 9:
-        cfg = {128: '9, 1, 4, 1, 64', 64: '9, 1, 2, 1, 64', 32: '9, 1, 1, 1, 128'}[ncls]
-        return 'tap_wgrad_kernel<%s> (conv3x3 weight-gradient)' % cfg
-    return 'tap_wgrad_kernel<1, 4, 4, 1, 64> (dense/conv1x1 weight-gradient)'
-
+    """KernelTimer keys are the kernel symbols themselves (ops.kernel_symbol)."""
+    return key
 
 
 def cpu_baseline(variant, t_pad, vocab, seconds=10.0, budget_s=15.0):
@@ -150,7 +140,7 @@ def run_transformer(args):
                             'launches_per_step': r['launches'] // args.steps, 'avg_launch_us': round(r['avg_us'], 2)}}
         if args.kernel_table:
             for key, rr in sorted(table.items(), key=lambda kv: -kv[1]['total_ms']):
-                print('%-28s launches %3d  total %8.3f ms  avg %9.1f us  %7.2f TFLOP/s' %
+                print('%-48s launches %3d  total %8.3f ms  avg %9.1f us  %7.2f TFLOP/s' %
                       (key, rr['launches'], rr['total_ms'], rr['avg_us'], rr['tflops']), file=sys.stderr)
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -270,7 +260,7 @@ def main():
         }
         if args.kernel_table:
             for key, r in sorted(table.items(), key=lambda kv: -kv[1]['total_ms']):
-                print('%-28s launches %3d  total %8.3f ms  avg %9.1f us  %7.2f TFLOP/s' %
+                print('%-48s launches %3d  total %8.3f ms  avg %9.1f us  %7.2f TFLOP/s' %
                       (key, r['launches'], r['total_ms'], r['avg_us'], r['tflops']), file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(variant, T, V)
