@@ -112,21 +112,38 @@ __global__ __launch_bounds__(256) void tap_wgrad_kernel(WgradArgs g) {
     for (long ps0 = cbeg; ps0 < cend; ps0 += PS) {
         const float* As = smem + cur * bufsz;
         const float* Zs = As + arows * KT;
-        for (int r = 2 * wp; r < PS; r += 2 * WAVES_P) {
-            float bz[TNW];
+        // Software-pipelined operand fetch, unrolled by two with two named register sets: the LDS reads of
+        // the next pixel pair are issued BEFORE the MFMAs of the current pair and consumed after them, so
+        // their latency hides under 9 x 64 MFMA cycles.
+        {
+            float a0[NTAPS][TKW], b0[TNW], a1[NTAPS][TKW], b1[TNW];
+            auto fetch = [&](float (&an)[NTAPS][TKW], float (&bn)[TNW], int r) {
 #pragma unroll
-            for (int b = 0; b < TNW; ++b) bz[b] = Zs[(r + lh) * NT + (wn * TNW + b) * 32 + li];
+                for (int b = 0; b < TNW; ++b) bn[b] = Zs[(r + lh) * NT + (wn * TNW + b) * 32 + li];
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t) {
-                const int off = (NTAPS == 9) ? ((t / 3) - 1) * g.WP + (t % 3) - 1 : 0;
-                const float* ar = As + (r + lh + halo + off) * KT + li;
+                for (int t = 0; t < NTAPS; ++t) {
+                    const int off = (NTAPS == 9) ? ((t / 3) - 1) * g.WP + (t % 3) - 1 : 0;
 #pragma unroll
-                for (int a = 0; a < TKW; ++a) {
-                    const float av = ar[a * 32];
-#pragma unroll
-                    for (int b = 0; b < TNW; ++b)
-                        acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bz[b], acc[t][a][b], 0, 0, 0);
+                    for (int a = 0; a < TKW; ++a) an[t][a] = As[(r + lh + halo + off) * KT + li + a * 32];
                 }
+            };
+            auto fma_all = [&](const float (&ac)[NTAPS][TKW], const float (&bc)[TNW]) {
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                    for (int a = 0; a < TKW; ++a)
+#pragma unroll
+                        for (int b = 0; b < TNW; ++b)
+                            acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][a], bc[b], acc[t][a][b], 0, 0, 0);
+            };
+            constexpr int RS = 2 * WAVES_P;             // pixel-pair stride of this wave (PS / RS is even)
+            static_assert((PS / RS) % 2 == 0, "unroll by two");
+            fetch(a0, b0, 2 * wp);
+            for (int r = 2 * wp; r < PS; r += 2 * RS) {
+                fetch(a1, b1, r + RS);
+                fma_all(a0, b0);
+                if (r + 2 * RS < PS) fetch(a0, b0, r + 2 * RS);
+                fma_all(a1, b1);
             }
         }
         if (ps0 + PS < cend) {
@@ -221,40 +238,82 @@ __global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_v1(WgradArgs g) {
 
     for (long ps0 = cbeg; ps0 < cend; ps0 += PS) {
         __syncthreads();
-        for (int f = tid; f < arows * (KT / 4); f += 256) {
-            const int row = f / (KT / 4), c4 = f - row * (KT / 4);
-            const long grow = ps0 - halo + row;
-            const int kk = k0 + c4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (grow >= g.rmin && grow < g.rmax && kk < g.K)
-                v = *(const float4*)(g.A + grow * g.lda + kk);
-            *(float4*)(As + row * KT + c4 * 4) = v;
+        // batches of SB independent loads before the LDS writes: a plain "load; store" loop makes hipcc wait
+        // for every load before it issues the next (one exposed memory latency per float4)
+        constexpr int SB = 4;
+        for (int base = 0; base < arows * (KT / 4); base += SB * 256) {
+            float4 t[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                const int row = f / (KT / 4), c4 = f - row * (KT / 4);
+                const long grow = ps0 - halo + row;
+                const int kk = k0 + c4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < arows * (KT / 4) && grow >= g.rmin && grow < g.rmax && kk < g.K)
+                    v = *(const float4*)(g.A + grow * g.lda + kk);
+                t[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                const int row = f / (KT / 4), c4 = f - row * (KT / 4);
+                if (f < arows * (KT / 4)) *(float4*)(As + row * KT + c4 * 4) = t[i];
+            }
         }
-        for (int f = tid; f < PS * (NT / 4); f += 256) {
-            const int row = f / (NT / 4), n4 = f - row * (NT / 4);
-            const long grow = ps0 + row;
-            const int nn = n0 + n4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (grow < cend && nn < g.N)
-                v = *(const float4*)(g.Z + grow * g.ldz + nn);
-            *(float4*)(Zs + row * NT + n4 * 4) = v;
+        for (int base = 0; base < PS * (NT / 4); base += SB * 256) {
+            float4 t[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                const int row = f / (NT / 4), n4 = f - row * (NT / 4);
+                const long grow = ps0 + row;
+                const int nn = n0 + n4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < PS * (NT / 4) && grow < cend && nn < g.N)
+                    v = *(const float4*)(g.Z + grow * g.ldz + nn);
+                t[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                const int row = f / (NT / 4), n4 = f - row * (NT / 4);
+                if (f < PS * (NT / 4)) *(float4*)(Zs + row * NT + n4 * 4) = t[i];
+            }
         }
         __syncthreads();
-        for (int r = 2 * wp; r < PS; r += 2 * WAVES_P) {
-            float bz[TNW];
+        // Software-pipelined operand fetch, unrolled by two with two named register sets: the LDS reads of
+        // the next pixel pair are issued BEFORE the MFMAs of the current pair and consumed after them, so
+        // their latency hides under 9 x 64 MFMA cycles.
+        {
+            float a0[NTAPS][TKW], b0[TNW], a1[NTAPS][TKW], b1[TNW];
+            auto fetch = [&](float (&an)[NTAPS][TKW], float (&bn)[TNW], int r) {
 #pragma unroll
-            for (int b = 0; b < TNW; ++b) bz[b] = Zs[(r + lh) * NT + (wn * TNW + b) * 32 + li];
+                for (int b = 0; b < TNW; ++b) bn[b] = Zs[(r + lh) * NT + (wn * TNW + b) * 32 + li];
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t) {
-                const int off = (NTAPS == 9) ? ((t / 3) - 1) * g.WP + (t % 3) - 1 : 0;
-                const float* ar = As + (r + lh + halo + off) * KT + li;
+                for (int t = 0; t < NTAPS; ++t) {
+                    const int off = (NTAPS == 9) ? ((t / 3) - 1) * g.WP + (t % 3) - 1 : 0;
 #pragma unroll
-                for (int a = 0; a < TKW; ++a) {
-                    const float av = ar[a * 32];
-#pragma unroll
-                    for (int b = 0; b < TNW; ++b)
-                        acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bz[b], acc[t][a][b], 0, 0, 0);
+                    for (int a = 0; a < TKW; ++a) an[t][a] = As[(r + lh + halo + off) * KT + li + a * 32];
                 }
+            };
+            auto fma_all = [&](const float (&ac)[NTAPS][TKW], const float (&bc)[TNW]) {
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                    for (int a = 0; a < TKW; ++a)
+#pragma unroll
+                        for (int b = 0; b < TNW; ++b)
+                            acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][a], bc[b], acc[t][a][b], 0, 0, 0);
+            };
+            constexpr int RS = 2 * WAVES_P;             // pixel-pair stride of this wave (PS / RS is even)
+            static_assert((PS / RS) % 2 == 0, "unroll by two");
+            fetch(a0, b0, 2 * wp);
+            for (int r = 2 * wp; r < PS; r += 2 * RS) {
+                fetch(a1, b1, r + RS);
+                fma_all(a0, b0);
+                if (r + 2 * RS < PS) fetch(a0, b0, r + 2 * RS);
+                fma_all(a1, b1);
             }
         }
     }
@@ -363,11 +422,11 @@ Plan make_plan(const asr_gemm_desc* d) {
 
 template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS>
 int launch_wgrad(const WgradArgs& a, const Plan& p, int K, int N, hipStream_t st) {
-    // v1 (direct staging, 2 workgroups per CU) is faster for the 128-wide 3x3 layers, v2 (register prefetch +
-    // LDS double buffer, 1 workgroup per CU) everywhere else (tools/bench_layers.py); ASR_WGRAD_VARIANT forces one.
+    // v1 (batched direct staging, 2 workgroups per CU) wins almost everywhere; v2 (register prefetch + LDS double
+    // buffer, 1 workgroup per CU) only for the 64->64 class (tools/bench_layers.py).  ASR_WGRAD_VARIANT forces one.
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("ASR_WGRAD_VARIANT"); forced = e ? atoi(e) : 0; }
-    const int variant = (forced == 1 || forced == 2) ? forced : ((NTAPS == 9 && WAVES_N == 4) ? 1 : 2);
+    const int variant = (forced == 1 || forced == 2) ? forced : ((NTAPS == 9 && WAVES_N == 2 && K >= 64) ? 2 : 1);
     auto kern = (variant == 1) ? tap_wgrad_kernel_v1<NTAPS, TKW, WAVES_N, TNW, PS> : tap_wgrad_kernel<NTAPS, TKW, WAVES_N, TNW, PS>;
     constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32, NACC = NTAPS * TKW * TNW;
     size_t lds = (variant == 1 ? 1 : 2) * ((size_t)(PS + 2 * a.halo) * KT + (size_t)PS * NT) * sizeof(float);

@@ -79,10 +79,12 @@ def kernel_symbol(family, ntaps, wmode, M, K, N):
     csrc/tap_gemm.hip and csrc/tap_wgrad.hip), as rocprofv3 --stats prints it."""
     if family == 'tap_wgrad':
         if ntaps == 1:
-            return 'tap_wgrad_kernel<1, 4, 4, 1, 64>'
+            return 'tap_wgrad_kernel_v1<1, 4, 4, 1, 64>'
         if N > 64:
             return 'tap_wgrad_kernel_v1<9, 1, 4, 1, 64>'
-        return 'tap_wgrad_kernel<9, 1, 2, 1, 64>' if N > 32 else 'tap_wgrad_kernel<9, 1, 1, 1, 128>'
+        if N > 32:
+            return 'tap_wgrad_kernel<9, 1, 2, 1, 64>' if K >= 64 else 'tap_wgrad_kernel_v1<9, 1, 2, 1, 64>'
+        return 'tap_wgrad_kernel_v1<9, 1, 1, 1, 128>'
     v2 = ntaps == 9 and wmode == 1 and N <= 64 and (N > 32 or K >= 64)
     if ntaps == 1 and N > 32 and -(-M // 128) * -(-N // 128) < 160:
         cfg, kc = '64, 64, 2, 2', 32
