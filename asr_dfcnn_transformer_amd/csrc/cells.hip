@@ -482,12 +482,10 @@ extern "C" int asr_cell1_bwd(const float* x, int B, int T, int F, int C, const f
         hipLaunchKernelGGL((cell1_kernel<2, true>), grid, dim3(256), lds, st, x, B, T, F, C, w, bias, bn_scale, bn_shift, (float*)nullptr, dy, partials, kCell1RPB);
     ASR_CHECK_LAUNCH("cell1_bwd");
     float* tmp = partials + (size_t)nblk * 12 * C;
-    int rc;
-    if ((rc = asr_reduce::colsum(partials, nblk, 9 * C, 12 * C, dw, tmp, st))) return rc;
-    if ((rc = asr_reduce::colsum(partials + 9 * C, nblk, C, 12 * C, db, tmp, st))) return rc;
-    if ((rc = asr_reduce::colsum(partials + 10 * C, nblk, C, 12 * C, dscale, tmp, st))) return rc;
-    if ((rc = asr_reduce::colsum(partials + 11 * C, nblk, C, 12 * C, dshift, tmp, st))) return rc;
-    return ASR_OK;
+    asr_reduce::Multi m;
+    m.nseg = 4; m.width[0] = 9 * C; m.width[1] = C; m.width[2] = C; m.width[3] = C;
+    m.out[0] = dw; m.out[1] = db; m.out[2] = dscale; m.out[3] = dshift;
+    return asr_reduce::colsum_multi(partials, nblk, 12 * C, m, tmp, st);
 }
 
 extern "C" int asr_pool_fwd(const float* a, int B, int H, int W, int C, const float* bn_scale,
@@ -524,11 +522,10 @@ extern "C" int asr_cell_bwd_pre(const float* dy, int dy_layout, const float* a, 
     else hipLaunchKernelGGL(cell_bwd_pre_kernel<2>, dim3(nblk), dim3(256), 0, st, dy, dy_layout, a, B, H, W, C, bn_scale, bn_shift, dz, partials, ppb);
     ASR_CHECK_LAUNCH("cell_bwd_pre");
     float* tmp = partials + (size_t)nblk * 3 * C;
-    int rc;
-    if ((rc = asr_reduce::colsum(partials, nblk, C, 3 * C, dscale, tmp, st))) return rc;
-    if ((rc = asr_reduce::colsum(partials + C, nblk, C, 3 * C, dshift, tmp, st))) return rc;
-    if ((rc = asr_reduce::colsum(partials + 2 * C, nblk, C, 3 * C, dbias, tmp, st))) return rc;
-    return ASR_OK;
+    asr_reduce::Multi m;
+    m.nseg = 3; m.width[0] = C; m.width[1] = C; m.width[2] = C; m.width[3] = 0;
+    m.out[0] = dscale; m.out[1] = dshift; m.out[2] = dbias; m.out[3] = nullptr;
+    return asr_reduce::colsum_multi(partials, nblk, 3 * C, m, tmp, st);
 }
 
 extern "C" size_t asr_se_state_floats(int B, int C, int hid) { return (size_t)B * (2 * C + hid); }
@@ -590,14 +587,20 @@ extern "C" int asr_se_bwd(const float* dout, const float* x, int B, int H, int W
     hipLaunchKernelGGL(se_bwd_mlp_kernel, dim3(B), dim3(256), (size_t)(C + hid) * sizeof(float), st, (const float*)part_red, ns, H, W, C, hid, w1, w2, st_s, st_r, st_e, mlp_out, dsb);
     ASR_CHECK_LAUNCH("se_bwd_mlp");
     int rc;
-    if ((rc = asr_reduce::colsum(mlp_out, B, C * hid, (long)per, dw1, tmp, st))) return rc;
-    if ((rc = asr_reduce::colsum(mlp_out + (size_t)C * hid, B, hid, (long)per, db1, tmp, st))) return rc;
-    if ((rc = asr_reduce::colsum(mlp_out + (size_t)C * hid + hid, B, hid * C, (long)per, dw2, tmp, st))) return rc;
-    if ((rc = asr_reduce::colsum(mlp_out + (size_t)C * hid + hid + (size_t)hid * C, B, C, (long)per, db2, tmp, st))) return rc;
+    {
+        asr_reduce::Multi m;
+        m.nseg = 4; m.width[0] = C * hid; m.width[1] = hid; m.width[2] = hid * C; m.width[3] = C;
+        m.out[0] = dw1; m.out[1] = db1; m.out[2] = dw2; m.out[3] = db2;
+        if ((rc = asr_reduce::colsum_multi(mlp_out, B, (long)per, m, tmp, st))) return rc;
+    }
     hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(nblk), dim3(256), 0, st, dout, x, B, H, W, C, bn_scale, st_e, (const float*)dsb, add_dout, dx, part_apply, appb);
     ASR_CHECK_LAUNCH("se_bwd_apply");
-    if ((rc = asr_reduce::colsum(part_apply, nblk, C, 2 * C, dscale, tmp, st))) return rc;
-    if ((rc = asr_reduce::colsum(part_apply + C, nblk, C, 2 * C, dshift, tmp, st))) return rc;
+    {
+        asr_reduce::Multi m;
+        m.nseg = 2; m.width[0] = C; m.width[1] = C; m.width[2] = 0; m.width[3] = 0;
+        m.out[0] = dscale; m.out[1] = dshift; m.out[2] = nullptr; m.out[3] = nullptr;
+        if ((rc = asr_reduce::colsum_multi(part_apply, nblk, 2 * C, m, tmp, st))) return rc;
+    }
     return ASR_OK;
 }
 

@@ -574,10 +574,10 @@ extern "C" int asr_layernorm_bwd(const float* dy, const float* xhat, const float
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), (size_t)8 * C * sizeof(float), st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials);
     ASR_CHECK_LAUNCH("layernorm_bwd");
     float* tmp = partials + (size_t)nblk * 2 * C;
-    int rc;
-    if ((rc = asr_reduce::colsum(partials, nblk, C, 2 * C, dgamma, tmp, st))) return rc;
-    if ((rc = asr_reduce::colsum(partials + C, nblk, C, 2 * C, dbeta, tmp, st))) return rc;
-    return ASR_OK;
+    asr_reduce::Multi m;
+    m.nseg = 2; m.width[0] = C; m.width[1] = C; m.width[2] = 0; m.width[3] = 0;
+    m.out[0] = dgamma; m.out[1] = dbeta; m.out[2] = nullptr; m.out[3] = nullptr;
+    return asr_reduce::colsum_multi(partials, nblk, 2 * C, m, tmp, st);
 }
 
 extern "C" int asr_embed_fwd(const float* table, const int32_t* ids, const float* pos, int N, int T, int C,
