@@ -367,8 +367,22 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
                     *(float4*)(As + (f / (KC / 4)) * AP + (f % (KC / 4)) * 4) = areg[i];
                 }
             } else {
-                for (int f = tid; f < arows * (KC / 4); f += 256)
-                    *(float4*)(As + (f / (KC / 4)) * AP + (f % (KC / 4)) * 4) = load_a_row(f, kc);
+                // batches of SB independent loads, then SB LDS writes: a plain "load; store" loop makes hipcc
+                // wait for every load before issuing the next one (one exposed memory latency per float4)
+                constexpr int SB = (TM * TN >= 4) ? 1 : 4;   // the 128x128 tile has no registers to spare (3 waves per SIMD)
+                for (int base = 0; base < arows * (KC / 4); base += SB * 256) {
+                    float4 t[SB];
+#pragma unroll
+                    for (int i = 0; i < SB; ++i) {
+                        const int f = base + tid + i * 256;
+                        t[i] = (f < arows * (KC / 4)) ? load_a_row(f, kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int i = 0; i < SB; ++i) {
+                        const int f = base + tid + i * 256;
+                        if (f < arows * (KC / 4)) *(float4*)(As + (f / (KC / 4)) * AP + (f % (KC / 4)) * 4) = t[i];
+                    }
+                }
             }
         }
         store_w();

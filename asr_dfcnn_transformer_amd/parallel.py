@@ -23,10 +23,12 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            backend = os.environ.get('ASR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if torch.cuda.is_available() and torch.cuda.device_count() > 0:
+        local = local % torch.cuda.device_count()     # rehearsals with more ranks than GPUs (gloo) share devices
     return rank, world, local
 
 
