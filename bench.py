@@ -32,6 +32,22 @@ def kernel_name(key):
     return key
 
 
+def pmc_traffic(workload, symbol):
+    """HBM bytes per launch of `symbol` from the latest committed PMC pass (profiles/*_<workload>_traffic.json,
+    written from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs with the gfx950 x2 FETCH correction of
+    MI355X_MICROARCH.md).  Returns (bytes or None, source file or None)."""
+    import glob
+    tag = {'dfcnn': 'dfcnn_m1', 'se_dfcnn': 'se_dfcnn_m2', 'transformer': 'transformer'}[workload]
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_%s_traffic.json' % tag)))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return (d[symbol]['hbm_bytes_per_launch'] if symbol in d else None), os.path.relpath(files[-1], ROOT)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(variant, t_pad, vocab, seconds=10.0, budget_s=15.0):
     """CPU restatement ("port": oracle/torch_ref.py on torch-CPU ops + the numpy fbank oracle)
     of the identical step, timed on this host's cores on a bounded sample.  Stand-in for the
@@ -258,6 +274,10 @@ def main():
                          'flop_per_launch': round(fl / nl / 1e9, 3), 'flop_unit': 'GFLOP',
                          'share_of_step_time': round(ms / args.steps / (1e3 * dt / args.steps), 3)},
         }
+        tr, src = pmc_traffic(args.workload, dom)
+        out['roofline']['traffic'] = tr
+        if src:
+            out['roofline']['traffic_unit'] = 'bytes/launch (PMC pass: %s)' % src
         if args.kernel_table:
             for key, r in sorted(table.items(), key=lambda kv: -kv[1]['total_ms']):
                 print('%-48s launches %3d  total %8.3f ms  avg %9.1f us  %7.2f TFLOP/s' %
