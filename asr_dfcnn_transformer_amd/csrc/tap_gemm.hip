@@ -20,6 +20,7 @@
 
 namespace {
 
+constexpr size_t kEpilogueLds = 4 * 32 * 33 * sizeof(float);   // per-wave transpose scratch of the epilogue
 constexpr int KC = 32;       // contraction chunk staged per step
 constexpr int AP = KC + 4;   // LDS pitch of an A row (floats): conflict-free ds_read_b128
 
@@ -32,7 +33,52 @@ struct TapGemmArgs {
     long rmin, rmax;
     int relu, accumulate, y_unpadded;
     int ntm, ntn;
+    int ablate;          // timing experiments only (ASR_TG_ABLATE): 1 skip A restaging, 2 skip W restaging, 4 skip epilogue
 };
+
+// Epilogue shared by the three generations.  The 32x32 MFMA result has the output channel on the lane and
+// the pixel row in the register, which makes the natural store 4 bytes per lane (two 128-byte rows per wave
+// instruction, 32 instructions per tile and tensor).  Each wave instead transposes its tile through a private
+// 32x33 LDS scratch and stores float4 rows: 4x fewer, 16-byte store instructions (+8 % on the conv kernels).
+template <int TM, int TN>
+__device__ __forceinline__ void tap_epilogue(const TapGemmArgs& g, const floatx16 (&acc)[TM][TN], float* scratch,
+                                             const int* rowa, const int* rowy, int row0, int col0, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int c4 = lane & 7, rsub = lane >> 3;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = col0 + b * 32 + c4 * 4;
+        const bool ncol = n < g.N;
+        float4 bs = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bs;
+        if (ncol) {
+            if (g.bias) bs = *(const float4*)(g.bias + n);
+            if (g.scale) sc = *(const float4*)(g.scale + n);
+            if (g.shift) sh = *(const float4*)(g.shift + n);
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[a][b][r];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + rsub;
+                const int m = row0 + a * 32 + row;
+                const int ra = rowa[m];
+                const float* sp = scratch + row * 33 + c4 * 4;
+                float4 v = make_float4(sp[0] + bs.x, sp[1] + bs.y, sp[2] + bs.z, sp[3] + bs.w);
+                if (ra < 0 || !ncol) continue;
+                if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (g.out_a) *(float4*)(g.out_a + (long)ra * g.ldo_a + n) = v;
+                if (g.out_y) {
+                    float4 y = make_float4(sc.x * v.x + sh.x, sc.y * v.y + sh.y, sc.z * v.z + sh.z, sc.w * v.w + sh.w);
+                    float* o = g.out_y + (long)rowy[m] * g.ldo_y + n;
+                    if (g.accumulate) { const float4 p = *(const float4*)o; y.x += p.x; y.y += p.y; y.z += p.z; y.w += p.w; }
+                    *(float4*)o = y;
+                }
+            }
+        }
+    }
+}
 
 template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE>
 __global__ __launch_bounds__(256) void tap_gemm_kernel(TapGemmArgs g) {
@@ -48,10 +94,11 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(TapGemmArgs g) {
     const int halo = g.halo;
     const int arows = MT + 2 * halo;
     const int asz = arows * AP;
-    float* As = smem;                                   // NTAPS == 1: two buffers
-    float* Ws = As + ((NTAPS == 1) ? 2 * asz : asz);    // two buffers of WSZ floats
-    int* rowa = (int*)(Ws + 2 * WSZ);
+    int* rowa = (int*)smem;                             // [MT] output row of out_a (or -1), [MT] of out_y
     int* rowy = rowa + MT;
+    float* tile_lds = smem + 2 * MT;                    // staging tiles; reused as the epilogue's transpose scratch
+    float* As = tile_lds;                               // NTAPS == 1: two buffers
+    float* Ws = As + ((NTAPS == 1) ? 2 * asz : asz);    // two buffers of WSZ floats
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -217,33 +264,9 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(TapGemmArgs g) {
         cur ^= 1;
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int n = n0 + wn * (TN * 32) + b * 32 + li;
-        if (n >= N) continue;
-        const float bs = g.bias ? g.bias[n] : 0.f;
-        const float sc = g.scale ? g.scale[n] : 1.f;
-        const float sh = g.shift ? g.shift[n] : 0.f;
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = wm * (TM * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int ra = rowa[m];
-                if (ra < 0) continue;
-                float v = acc[a][b][r] + bs;
-                if (g.relu) v = fmaxf(v, 0.f);
-                if (g.out_a) g.out_a[(long)ra * g.ldo_a + n] = v;
-                if (g.out_y) {
-                    float y = sc * v + sh;
-                    float* o = g.out_y + (long)rowy[m] * g.ldo_y + n;
-                    if (g.accumulate) y += *o;
-                    *o = y;
-                }
-            }
-        }
-    }
+    // epilogue (tap_epilogue): transpose through LDS, float4 stores.  The staging tiles are dead by now.
+    __syncthreads();
+    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
 }
 
 // ---- v1: single-buffered W, direct A staging, two barriers per tap, 3 blocks per CU
@@ -259,10 +282,11 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int halo = g.halo;
     const int arows = MT + 2 * halo;
-    float* As = smem;
-    float* Ws = As + arows * AP;
-    int* rowa = (int*)(Ws + ((WMODE == 0) ? KC * NT : NT * (KC + 1) + 3) / 4 * 4);
+    int* rowa = (int*)smem;
     int* rowy = rowa + MT;
+    float* tile_lds = smem + 2 * MT;
+    float* As = tile_lds;
+    float* Ws = As + arows * AP;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -359,7 +383,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
     for (int step = 0; step < nsteps; ++step) {
         const int kc = step / NTAPS, tap = step - kc * NTAPS;
         __syncthreads();
-        if (tap == 0) {
+        if (tap == 0 && !((g.ablate & 1) && kc > 0)) {
             if (NTAPS == 1) {
 #pragma unroll
                 for (int i = 0; i < AREG; ++i) {
@@ -385,9 +409,9 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
                 }
             }
         }
-        store_w();
+        if (!((g.ablate & 2) && step > 0)) store_w();
         __syncthreads();
-        if (step + 1 < nsteps) {
+        if (step + 1 < nsteps && !(g.ablate & 2)) {
             load_w(step + 1);
             if (NTAPS == 1) {
 #pragma unroll
@@ -423,34 +447,164 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
         }
     }
 
-    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // epilogue (tap_epilogue): transpose through LDS, float4 stores.  The staging tiles are dead by now.
+    __syncthreads();
+    if ((g.ablate & 4) && acc[0][0][0] != 123.456f) return;
+    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
+}
+
+// ---- v3 (3x3 only): ALL NINE weight taps of a 16-channel chunk are staged together with the A tile, so a
+// workgroup synchronises twice per chunk (144 MFMAs per wave in between) instead of twice per tap.  Waves of one
+// workgroup sit on four different SIMDs, each shared with other workgroups, so they drift apart under contention;
+// every barrier re-aligns them, and with a barrier pair every 16-32 MFMAs the matrix pipe idled ~25 % of the time.
+template <int MT, int NT, int WM, int WN, int WMODE>
+__global__ __launch_bounds__(256) void tap_gemm_kernel_v3(TapGemmArgs g) {
+    constexpr int KC = 16, AP = KC + 4, NTAPS = 9;
+    constexpr int TM = MT / WM / 32, TN = NT / WN / 32;
+    constexpr int WTAP = (WMODE == 0) ? KC * NT : NT * (KC + 1);      // floats per tap in LDS
+    constexpr int WF4 = KC * NT / 4;                                   // float4 per tap in global memory
+    constexpr int SB = 4;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int halo = g.halo;
+    const int arows = MT + 2 * halo;
+    int* rowa = (int*)smem;
+    int* rowy = rowa + MT;
+    float* tile_lds = smem + 2 * MT;
+    float* As = tile_lds;
+    float* Ws = As + arows * AP;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+    const int swz = asr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_m = swz / g.ntn, tile_n = swz - tile_m * g.ntn;
+    const long p0 = (long)tile_m * MT;
+    const int n0 = tile_n * NT;
+    const int K = g.K, N = g.N;
+
+    if (tid < MT) {
+        const long p = p0 + tid;
+        int ra = -1, ry = -1;
+        if (p < g.M) {
+            const int b = (int)(p / g.HPWP);
+            const int r = (int)(p - (long)b * g.HPWP);
+            const int hh = r / g.WP, ww = r - hh * g.WP;
+            if (hh >= 1 && hh <= g.H && ww >= 1 && ww <= g.Wd) {
+                ra = (int)p;
+                ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : (int)p;
+            }
+        }
+        rowa[tid] = ra; rowy[tid] = ry;
+    }
+
+    floatx16 acc[TM][TN];
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int n = n0 + wn * (TN * 32) + b * 32 + li;
-        if (n >= N) continue;
-        const float bs = g.bias ? g.bias[n] : 0.f;
-        const float sc = g.scale ? g.scale[n] : 1.f;
-        const float sh = g.shift ? g.shift[n] : 0.f;
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = wm * (TM * 32) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int ra = rowa[m];
-                if (ra < 0) continue;
-                float v = acc[a][b][r] + bs;
-                if (g.relu) v = fmaxf(v, 0.f);
-                if (g.out_a) g.out_a[(long)ra * g.ldo_a + n] = v;
-                if (g.out_y) {
-                    float y = sc * v + sh;
-                    float* o = g.out_y + (long)rowy[m] * g.ldo_y + n;
-                    if (g.accumulate) y += *o;
-                    *o = y;
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nkc = (K + KC - 1) / KC;
+    const int atotal = arows * (KC / 4);
+    for (int kc = 0; kc < nkc; ++kc) {
+        __syncthreads();
+        // ---- stage the A tile chunk and the nine weight tiles (batches of SB independent loads)
+        for (int base = 0; base < atotal; base += SB * 256) {
+            float4 t[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                const int row = f / (KC / 4), c4 = f - row * (KC / 4);
+                const long grow = p0 - halo + row;
+                const int kk = kc * KC + c4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < atotal && grow >= g.rmin && grow < g.rmax && kk < K) v = *(const float4*)(g.A + grow * g.lda + kk);
+                t[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                const int row = f / (KC / 4), c4 = f - row * (KC / 4);
+                if (f < atotal) *(float4*)(As + row * AP + c4 * 4) = t[i];
+            }
+        }
+        for (int base = 0; base < NTAPS * WF4; base += SB * 256) {
+            float4 t[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                const int tap = f / WF4, q = f - tap * WF4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < NTAPS * WF4) {
+                    if (WMODE == 0) {
+                        const int k = q / (NT / 4), n4 = q - k * (NT / 4);
+                        const int kk = kc * KC + k, nn = n0 + n4 * 4;
+                        if (kk < K && nn < N) v = *(const float4*)(g.W + ((long)tap * K + kk) * g.ldw + nn);
+                    } else {
+                        const int n = q / (KC / 4), k4 = q - n * (KC / 4);
+                        const int kk = kc * KC + k4 * 4, nn = n0 + n;
+                        if (kk < K && nn < N) v = *(const float4*)(g.W + ((long)(NTAPS - 1 - tap) * N + nn) * g.ldw + kk);
+                    }
+                }
+                t[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                const int tap = f / WF4, q = f - tap * WF4;
+                if (f < NTAPS * WF4) {
+                    if (WMODE == 0) {
+                        const int k = q / (NT / 4), n4 = q - k * (NT / 4);
+                        *(float4*)(Ws + tap * WTAP + k * NT + n4 * 4) = t[i];
+                    } else {
+                        const int n = q / (KC / 4), k4 = q - n * (KC / 4);
+                        float* d = Ws + tap * WTAP + n * (KC + 1) + k4 * 4;
+                        d[0] = t[i].x; d[1] = t[i].y; d[2] = t[i].z; d[3] = t[i].w;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- 9 taps x 2 groups of 8 channels, no synchronisation in between
+        for (int tap = 0; tap < NTAPS; ++tap) {
+            const int toff = halo + ((tap / 3) - 1) * g.WP + (tap % 3) - 1;
+            const float* abase = As + (wm * (TM * 32) + li + toff) * AP + 4 * lh;
+            const float* wt = Ws + tap * WTAP;
+            const float* wbase = (WMODE == 0) ? (wt + (4 * lh) * NT + wn * (TN * 32) + li)
+                                              : (wt + (wn * (TN * 32) + li) * (KC + 1) + 4 * lh);
+#pragma unroll
+            for (int gk = 0; gk < KC / 8; ++gk) {
+                float4 av[TM];
+                float bv[TN][4];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) av[a] = *(const float4*)(abase + a * 32 * AP + gk * 8);
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2)
+                        bv[b][s2] = (WMODE == 0) ? wbase[(gk * 8 + s2) * NT + b * 32]
+                                                 : wbase[b * 32 * (KC + 1) + gk * 8 + s2];
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        const float as = (s2 == 0) ? av[a].x : (s2 == 1) ? av[a].y : (s2 == 2) ? av[a].z : av[a].w;
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bv[b][s2], acc[a][b], 0, 0, 0);
+                    }
                 }
             }
         }
     }
+
+    // epilogue (tap_epilogue): transpose through LDS, float4 stores.  The staging tiles are dead by now.
+    __syncthreads();
+    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
 }
+
 
 // Two generations of the main loop are kept because neither wins everywhere (tools/bench_layers.py,
 // MI355X): v1 (single-buffered tiles, two barriers per tap, 3 workgroups per CU) is faster wherever
@@ -470,7 +624,30 @@ int launch_v1(const TapGemmArgs& a, hipStream_t st) {
     auto kern = tap_gemm_kernel_v1<MT, NT, WM, WN, NTAPS, WMODE, KCV>;
     const int arows = MT + 2 * a.halo;
     const size_t wfl = ((WMODE == 0) ? KCV * NT : NT * (KCV + 1) + 3) / 4 * 4;
-    const size_t lds = ((size_t)arows * (KCV + 4) + wfl) * sizeof(float) + 2 * MT * sizeof(int);
+    size_t lds = ((size_t)arows * (KCV + 4) + wfl) * sizeof(float) + 2 * MT * sizeof(int);
+    if (lds < kEpilogueLds + 2 * MT * sizeof(int)) lds = kEpilogueLds + 2 * MT * sizeof(int);
+    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    TapGemmArgs g = a;
+    g.ntm = asr_cdiv(a.M, MT);
+    g.ntn = asr_cdiv(a.N, NT);
+    hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn), dim3(256), lds, st, g);
+    ASR_CHECK_LAUNCH("tap_gemm");
+    return ASR_OK;
+}
+
+template <int MT, int NT, int WM, int WN, int WMODE>
+int launch_v3(const TapGemmArgs& a, hipStream_t st) {
+    auto kern = tap_gemm_kernel_v3<MT, NT, WM, WN, WMODE>;
+    constexpr int KCV = 16;
+    const int arows = MT + 2 * a.halo;
+    const size_t wfl = (size_t)(9 * ((WMODE == 0) ? KCV * NT : NT * (KCV + 1)) + 3) / 4 * 4;
+    size_t lds = ((size_t)arows * (KCV + 4) + wfl) * sizeof(float) + 2 * MT * sizeof(int);
+    if (lds < kEpilogueLds + 2 * MT * sizeof(int)) lds = kEpilogueLds + 2 * MT * sizeof(int);
     if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
@@ -490,7 +667,8 @@ int launch_v2(const TapGemmArgs& a, hipStream_t st) {
     auto kern = tap_gemm_kernel<MT, NT, WM, WN, NTAPS, WMODE>;
     const int arows = MT + 2 * a.halo;
     const size_t wfl = ((WMODE == 0) ? KC * NT : NT * (KC + 1) + 3) / 4 * 4;
-    const size_t lds = ((size_t)arows * AP * (NTAPS == 1 ? 2 : 1) + 2 * wfl) * sizeof(float) + 2 * MT * sizeof(int);
+    size_t lds = ((size_t)arows * AP * (NTAPS == 1 ? 2 : 1) + 2 * wfl) * sizeof(float) + 2 * MT * sizeof(int);
+    if (lds < kEpilogueLds + 2 * MT * sizeof(int)) lds = kEpilogueLds + 2 * MT * sizeof(int);
     if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
@@ -532,6 +710,8 @@ int launch_n(const TapGemmArgs& a, hipStream_t st) {
         if (ex == 2 && a.N > 32) return launch_v1<256, 64, 4, 1, NTAPS, WMODE, 16>(a, st);
         if (ex == 3 && a.N > 32 && a.N <= 64) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
         if (ex == 4 && a.N > 32) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 16>(a, st);
+        if (ex == 5 && a.N > 32) return launch_v3<128, 64, 2, 2, WMODE>(a, st);
+        if (ex == 6) { if (a.N > 32) return launch_v3<128, 64, 2, 2, WMODE>(a, st); return launch_v3<256, 32, 4, 1, WMODE>(a, st); }
         if (ex == 0) {
             // measured on the DFCNN layer shapes (tools/bench_layers.py, profiles/r01b_layer_tiles.txt):
             // 128x64 tiles (more, smaller workgroups per CU) win up to 128 output channels; a 16-deep
@@ -570,6 +750,9 @@ extern "C" int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float*
     a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
     a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
     a.ntm = a.ntn = 0;
+    static int ablate = -1;
+    if (ablate < 0) { const char* e = getenv("ASR_TG_ABLATE"); ablate = e ? atoi(e) : 0; }
+    a.ablate = ablate;
     hipStream_t st = (hipStream_t)stream;
     if (d->ntaps == 9) return d->wmode ? launch_n<9, 1>(a, st) : launch_n<9, 0>(a, st);
     return d->wmode ? launch_n<1, 1>(a, st) : launch_n<1, 0>(a, st);
