@@ -369,6 +369,160 @@ __global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_v1(WgradArgs g) {
             }
 }
 
+// ---- v3: as v1, but dZ never touches LDS.  A wave only needs its own 32 output channels of dZ, and for a
+// pixel pair that is one coalesced 2 x 128-byte row segment per wave: it is loaded straight into registers
+// (all pairs of the run up front, before the A staging and its barriers, so the latency is covered) and used
+// as the MFMA B operand.  LDS traffic per run drops from 47 KB to 15 KB (N = 128), the barrier phase shrinks.
+template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS>
+__global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_v3(WgradArgs g) {
+    constexpr int WAVES_P = 4 / WAVES_N;
+    constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32;
+    constexpr int NACC = NTAPS * TKW * TNW;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int halo = g.halo;
+    const int arows = PS + 2 * halo;
+    float* As = smem;                 // [arows][KT]
+    constexpr int RS = 2 * WAVES_P;   // pixel-pair stride of this wave
+    constexpr int NPW = PS / RS;      // pixel pairs per wave and run
+    static_assert(NPW % 2 == 0, "unroll by two");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = tid >> 6, wn = wave % WAVES_N, wp = wave / WAVES_N;
+    const int chunk = blockIdx.x;
+    const int k0 = blockIdx.y * KT, n0 = blockIdx.z * NT;
+    const long cbeg = (long)chunk * g.pch;
+    const long cend = (cbeg + g.pch < g.M) ? cbeg + g.pch : g.M;
+
+    floatx16 acc[NTAPS][TKW][TNW];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int a = 0; a < TKW; ++a)
+#pragma unroll
+            for (int b = 0; b < TNW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
+
+    for (long ps0 = cbeg; ps0 < cend; ps0 += PS) {
+        float zr[NPW][TNW];
+#pragma unroll
+        for (int j = 0; j < NPW; ++j)
+#pragma unroll
+            for (int b = 0; b < TNW; ++b) {
+                const long grow = ps0 + 2 * wp + j * RS + lh;
+                const int nn = n0 + (wn * TNW + b) * 32 + li;
+                zr[j][b] = (grow < cend && nn < g.N) ? g.Z[grow * g.ldz + nn] : 0.f;
+            }
+        __syncthreads();
+        // batches of SB independent loads before the LDS writes: a plain "load; store" loop makes hipcc wait
+        // for every load before it issues the next (one exposed memory latency per float4)
+        constexpr int SB = 4;
+        for (int base = 0; base < arows * (KT / 4); base += SB * 256) {
+            float4 t[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                const int row = f / (KT / 4), c4 = f - row * (KT / 4);
+                const long grow = ps0 - halo + row;
+                const int kk = k0 + c4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < arows * (KT / 4) && grow >= g.rmin && grow < g.rmax && kk < g.K)
+                    v = *(const float4*)(g.A + grow * g.lda + kk);
+                t[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                const int row = f / (KT / 4), c4 = f - row * (KT / 4);
+                if (f < arows * (KT / 4)) *(float4*)(As + row * KT + c4 * 4) = t[i];
+            }
+        }
+        __syncthreads();
+        // A operands: LDS reads of the next pixel pair are issued before the MFMAs of the current pair (two named
+        // register sets, statically unrolled); B operands are the zr registers.
+        {
+            float a0[NTAPS][TKW], a1[NTAPS][TKW];
+            auto fetch = [&](float (&an)[NTAPS][TKW], int r) {
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) {
+                    const int off = (NTAPS == 9) ? ((t / 3) - 1) * g.WP + (t % 3) - 1 : 0;
+#pragma unroll
+                    for (int a = 0; a < TKW; ++a) an[t][a] = As[(r + lh + halo + off) * KT + li + a * 32];
+                }
+            };
+            auto fma_all = [&](const float (&ac)[NTAPS][TKW], const float (&bc)[TNW]) {
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                    for (int a = 0; a < TKW; ++a)
+#pragma unroll
+                        for (int b = 0; b < TNW; ++b)
+                            acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][a], bc[b], acc[t][a][b], 0, 0, 0);
+            };
+            fetch(a0, 2 * wp);
+#pragma unroll
+            for (int j = 0; j < NPW; j += 2) {
+                fetch(a1, 2 * wp + (j + 1) * RS);
+                fma_all(a0, zr[j]);
+                if (j + 2 < NPW) fetch(a0, 2 * wp + (j + 2) * RS);
+                fma_all(a1, zr[j + 1]);
+            }
+        }
+    }
+
+    // fold the pixel-split waves of this block through LDS, one tap at a time (keeps the
+    // transfer at 16 registers per lane) and in a fixed order wp = 1, 2, ...
+    if (WAVES_P > 1) {
+        float* red = smem;   // [WAVES_P-1][WAVES_N][TKW*TNW*16][64]
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            __syncthreads();
+            if (wp > 0) {
+                float* dst = red + (((wp - 1) * WAVES_N + wn) * (TKW * TNW * 16)) * 64 + lane;
+#pragma unroll
+                for (int a = 0; a < TKW; ++a)
+#pragma unroll
+                    for (int b = 0; b < TNW; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            dst[((a * TNW + b) * 16 + r) * 64] = acc[t][a][b][r];
+            }
+            __syncthreads();
+            if (wp == 0) {
+                for (int src = 1; src < WAVES_P; ++src) {
+                    const float* sp = red + (((src - 1) * WAVES_N + wn) * (TKW * TNW * 16)) * 64 + lane;
+#pragma unroll
+                    for (int a = 0; a < TKW; ++a)
+#pragma unroll
+                        for (int b = 0; b < TNW; ++b)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                acc[t][a][b][r] += sp[((a * TNW + b) * 16 + r) * 64];
+                }
+            }
+        }
+    }
+    if (wp != 0) return;
+
+    float* out = g.out + (long)chunk * g.slab;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int a = 0; a < TKW; ++a)
+#pragma unroll
+            for (int b = 0; b < TNW; ++b) {
+                const int n = n0 + (wn * TNW + b) * 32 + li;
+                if (n >= g.N) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = k0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (k < g.K) out[((long)t * g.K + k) * g.N + n] = acc[t][a][b][r];
+                }
+            }
+}
+
 __global__ void sum_chunks_kernel(const float* __restrict__ part, float* __restrict__ out,
                                   long n, int nchunks) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -422,21 +576,25 @@ Plan make_plan(const asr_gemm_desc* d) {
 
 template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS>
 int launch_wgrad(const WgradArgs& a, const Plan& p, int K, int N, hipStream_t st) {
-    // v1 (batched direct staging, 2 workgroups per CU) wins almost everywhere; v2 (register prefetch + LDS double
-    // buffer, 1 workgroup per CU) only for the 64->64 class (tools/bench_layers.py).  ASR_WGRAD_VARIANT forces one.
+    // 3x3: v1 (batched direct staging, 2 workgroups per CU) wins almost everywhere, v2 (register prefetch + LDS
+    // double buffer, 1 workgroup per CU) only for the 64->64 class; dense / 1x1 (no halo): v3 (dZ in registers,
+    // half-length runs) is 10-30 % faster (tools/bench_layers.py).  ASR_WGRAD_VARIANT forces one.
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("ASR_WGRAD_VARIANT"); forced = e ? atoi(e) : 0; }
-    const int variant = (forced == 1 || forced == 2) ? forced : ((NTAPS == 9 && WAVES_N == 2 && K >= 64) ? 2 : 1);
-    auto kern = (variant == 1) ? tap_wgrad_kernel_v1<NTAPS, TKW, WAVES_N, TNW, PS> : tap_wgrad_kernel<NTAPS, TKW, WAVES_N, TNW, PS>;
+    const int variant = (forced >= 1 && forced <= 3) ? forced : (NTAPS == 1 ? 3 : ((WAVES_N == 2 && K >= 64) ? 2 : 1));
+    constexpr int PS3 = PS / 2;          // v3 keeps the run's dZ in registers: half the run length
+    auto kern = (variant == 1) ? tap_wgrad_kernel_v1<NTAPS, TKW, WAVES_N, TNW, PS>
+              : (variant == 3) ? tap_wgrad_kernel_v3<NTAPS, TKW, WAVES_N, TNW, PS3> : tap_wgrad_kernel<NTAPS, TKW, WAVES_N, TNW, PS>;
     constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32, NACC = NTAPS * TKW * TNW;
-    size_t lds = (variant == 1 ? 1 : 2) * ((size_t)(PS + 2 * a.halo) * KT + (size_t)PS * NT) * sizeof(float);
+    size_t lds = (variant == 3) ? (size_t)(PS3 + 2 * a.halo) * KT * sizeof(float)
+               : (variant == 1 ? 1 : 2) * ((size_t)(PS + 2 * a.halo) * KT + (size_t)PS * NT) * sizeof(float);
     const size_t red = (size_t)(4 / WAVES_N - 1) * WAVES_N * TKW * TNW * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
     if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[variant == 1]) {
+    static bool attr_set[4] = {false, false, false, false};
+    if (!attr_set[variant]) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[variant == 1] = true;
+        attr_set[variant] = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.nchunks, asr_cdiv(K, KT), asr_cdiv(N, NT)), dim3(256), lds, st, a);
     ASR_CHECK_LAUNCH("tap_wgrad");

@@ -79,7 +79,7 @@ def kernel_symbol(family, ntaps, wmode, M, K, N):
     csrc/tap_gemm.hip and csrc/tap_wgrad.hip), as rocprofv3 --stats prints it."""
     if family == 'tap_wgrad':
         if ntaps == 1:
-            return 'tap_wgrad_kernel_v1<1, 4, 4, 1, 64>'
+            return 'tap_wgrad_kernel_v3<1, 4, 4, 1, 32>'
         if N > 64:
             return 'tap_wgrad_kernel_v1<9, 1, 4, 1, 64>'
         if N > 32:
