@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void cell1_kernel(const float* __restrict__ x,
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int FP = F + 2;
     float* xs = smem;                    // [4][F+2]
-    const int H2 = T / 2, W2 = F / 2, WP2 = W2 + 2, HP2 = H2 + 2;
+    const int H2 = T / 2, W2 = F / 2, WP2 = W2 + 1, HP2 = H2 + 1;
     const int tid = threadIdx.x;
     const int c = tid % C, slot = tid / C, nslots = 256 / C;
     const int b = blockIdx.y;
@@ -133,7 +133,7 @@ __global__ void pool_fwd_kernel(const float* __restrict__ a, int B, int H, int W
                                 float* __restrict__ y) {
     const int C4 = C >> 2, H2 = H >> 1, W2 = W >> 1;
     const long total = (long)B * H2 * W2 * C4;
-    const int WP = W + 2, HP = H + 2, WP2 = W2 + 2, HP2 = H2 + 2;
+    const int WP = W + 1, HP = H + 1, WP2 = W2 + 1, HP2 = H2 + 1;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int cg = (int)(idx % C4);
         long pix = idx / C4;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void cell_bwd_pre_kernel(const float* __restri
     const int C4 = C >> 2;
     const int tid = threadIdx.x;
     const int cg = tid % C4, slot = tid / C4, nslots = 256 / C4;
-    const int WP = W + 2, HPWP = (H + 2) * WP;
+    const int WP = W + 1, HPWP = (H + 1) * WP;
     const long NP = (long)B * HPWP;
     const long pbeg = (long)blockIdx.x * PPB;
     const long pend = (pbeg + PPB < NP) ? pbeg + PPB : NP;
@@ -197,11 +197,11 @@ __global__ __launch_bounds__(256) void cell_bwd_pre_kernel(const float* __restri
         } else {
             const int hi = hh - 1, wi = ww - 1, h2 = hi >> 1, w2 = wi >> 1;
             if (h2 < H2 && w2 < W2) {
-                const float4 dp = ld4(dy + (((long)b * (H2 + 2) + h2 + 1) * (W2 + 2) + w2 + 1) * C + cg * 4);
+                const float4 dp = ld4(dy + (((long)b * (H2 + 1) + h2 + 1) * (W2 + 1) + w2 + 1) * C + cg * 4);
                 if (POOL == 1) {
                     g = make_float4(0.25f * dp.x, 0.25f * dp.y, 0.25f * dp.z, 0.25f * dp.w);
                 } else {
-                    const long q = ((long)b * (H + 2) + 2 * h2 + 1) * WP + 2 * w2 + 1;
+                    const long q = ((long)b * (H + 1) + 2 * h2 + 1) * WP + 2 * w2 + 1;
                     const float4 y0 = fma4(s, ld4(a + q * C + cg * 4), h);
                     const float4 y1 = fma4(s, ld4(a + (q + 1) * C + cg * 4), h);
                     const float4 y2 = fma4(s, ld4(a + (q + WP) * C + cg * 4), h);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void se_reduce_kernel(const float* __restrict_
     const int C4 = C >> 2;
     const int tid = threadIdx.x;
     const int cg = tid % C4, slot = tid / C4, nslots = 256 / C4;
-    const int WP = W + 2, HPWP = (H + 2) * WP;
+    const int WP = W + 1, HPWP = (H + 1) * WP;
     const int b = blockIdx.y;
     const long base = (long)b * HPWP;
     const int pbeg = blockIdx.x * kSePPB;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void se_excite_kernel(const float* __restrict_
 __global__ void se_apply_kernel(const float* __restrict__ main_in, const float* __restrict__ x, int B, int H, int W,
                                 int C, const float* __restrict__ sc, const float* __restrict__ sh,
                                 const float* __restrict__ e, float* __restrict__ out) {
-    const int C4 = C >> 2, WP = W + 2, HPWP = (H + 2) * WP;
+    const int C4 = C >> 2, WP = W + 1, HPWP = (H + 1) * WP;
     const long total = (long)B * HPWP * C4;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int cg = (int)(idx % C4);
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const float* __restri
     const int C4 = C >> 2;
     const int tid = threadIdx.x;
     const int cg = tid % C4, slot = tid / C4, nslots = 256 / C4;
-    const int WP = W + 2, HPWP = (H + 2) * WP;
+    const int WP = W + 1, HPWP = (H + 1) * WP;
     const long NP = (long)B * HPWP;
     const long pbeg = (long)blockIdx.x * PPB;
     const long pend = (pbeg + PPB < NP) ? pbeg + PPB : NP;
@@ -500,7 +500,7 @@ extern "C" int asr_pool_fwd(const float* a, int B, int H, int W, int C, const fl
 }
 
 extern "C" size_t asr_cell_bwd_pre_workspace(int B, int H, int W, int C) {
-    const long NP = (long)B * (H + 2) * (W + 2);
+    const long NP = (long)B * (H + 1) * (W + 1);
     const size_t nblk = (size_t)asr_cdiv(NP, pre_ppb(NP));
     return (nblk * 3 * C + asr_reduce::colsum_tmp_floats((int)nblk, 3 * C)) * sizeof(float);
 }
@@ -513,7 +513,7 @@ extern "C" int asr_cell_bwd_pre(const float* dy, int dy_layout, const float* a, 
     if (!chan_ok(C) || pool < 0 || pool > 2) return ASR_ERR_BAD_ARG;
     if ((pool != 0) != (dy_layout == 1)) return ASR_ERR_BAD_ARG;
     if (dy_layout < 0 || dy_layout > 2) return ASR_ERR_BAD_ARG;
-    const long NP = (long)B * (H + 2) * (W + 2);
+    const long NP = (long)B * (H + 1) * (W + 1);
     const int ppb = pre_ppb(NP);
     const int nblk = asr_cdiv(NP, ppb);
     hipStream_t st = (hipStream_t)stream;
@@ -530,7 +530,7 @@ extern "C" int asr_cell_bwd_pre(const float* dy, int dy_layout, const float* a, 
 
 extern "C" size_t asr_se_state_floats(int B, int C, int hid) { return (size_t)B * (2 * C + hid); }
 
-static inline int se_nsplit(int H, int W) { return asr_cdiv((long)(H + 2) * (W + 2), kSePPB); }
+static inline int se_nsplit(int H, int W) { return asr_cdiv((long)(H + 1) * (W + 1), kSePPB); }
 
 extern "C" size_t asr_se_fwd_workspace(int B, int H, int W, int C) {
     return ((size_t)B * se_nsplit(H, W) * C + 64) * sizeof(float);
@@ -538,7 +538,7 @@ extern "C" size_t asr_se_fwd_workspace(int B, int H, int W, int C) {
 
 extern "C" size_t asr_se_bwd_workspace(int B, int H, int W, int C, int hid) {
     const size_t per = (size_t)C * hid + hid + (size_t)hid * C + C;
-    const long NP = (long)B * (H + 2) * (W + 2);
+    const long NP = (long)B * (H + 1) * (W + 1);
     const size_t nblk = (size_t)asr_cdiv(NP, se_apply_ppb(NP));
     const size_t fl = (size_t)B * se_nsplit(H, W) * C + (size_t)B * per + (size_t)B * C + nblk * 2 * C
                     + asr_reduce::colsum_tmp_floats((int)nblk, 2 * C) + 64;
@@ -557,7 +557,7 @@ extern "C" int asr_se_fwd(const float* main_in, const float* x, int B, int H, in
     float* st_s = state; float* st_r = st_s + (size_t)B * C; float* st_e = st_r + (size_t)B * hid;
     hipLaunchKernelGGL(se_reduce_kernel<0>, dim3(ns, B), dim3(256), 0, st, x, (const float*)nullptr, H, W, C, bn_scale, bn_shift, partials);
     hipLaunchKernelGGL(se_excite_kernel, dim3(B), dim3(256), (size_t)(C + hid) * sizeof(float), st, (const float*)partials, ns, H, W, C, hid, bn_scale, bn_shift, w1, b1, w2, b2, st_s, st_r, st_e);
-    const long total = (long)B * (H + 2) * (W + 2) * (C / 4);
+    const long total = (long)B * (H + 1) * (W + 1) * (C / 4);
     hipLaunchKernelGGL(se_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, main_in, x, B, H, W, C, bn_scale, bn_shift, (const float*)st_e, out);
     ASR_CHECK_LAUNCH("se_fwd");
     return ASR_OK;
@@ -574,7 +574,7 @@ extern "C" int asr_se_bwd(const float* dout, const float* x, int B, int H, int W
     hipStream_t st = (hipStream_t)stream;
     const int ns = se_nsplit(H, W);
     const size_t per = (size_t)C * hid + hid + (size_t)hid * C + C;
-    const long NP = (long)B * (H + 2) * (W + 2);
+    const long NP = (long)B * (H + 1) * (W + 1);
     const int appb = se_apply_ppb(NP);
     const int nblk = asr_cdiv(NP, appb);
     float* part_red = partials;

@@ -744,7 +744,7 @@ extern "C" int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float*
     a.out_a = out_a; a.out_y = out_y;
     a.M = d->M; a.K = d->K; a.N = d->N; a.lda = d->lda; a.ldw = d->ldw;
     a.ldo_a = d->ldo_a; a.ldo_y = d->ldo_y;
-    a.H = d->H; a.Wd = d->W; a.WP = d->W + 2; a.HPWP = (d->H + 2) * (d->W + 2);
+    a.H = d->H; a.Wd = d->W; a.WP = d->W + 1; a.HPWP = (d->H + 1) * (d->W + 1);
     if (d->H > 0 && d->M != d->B * a.HPWP) return ASR_ERR_BAD_ARG;
     a.halo = (d->ntaps == 9) ? a.WP + 1 : 0;
     a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;

@@ -621,7 +621,7 @@ extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float
     WgradArgs a;
     a.A = A; a.Z = dZ; a.out = (p.nchunks > 1) ? partials : dW;
     a.M = d->M; a.K = d->K; a.N = d->N; a.lda = d->lda; a.ldz = ldz;
-    a.WP = d->W + 2;
+    a.WP = d->W + 1;
     a.halo = (d->ntaps == 9) ? a.WP + 1 : 0;
     a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
     a.pch = p.pch;

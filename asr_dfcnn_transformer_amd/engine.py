@@ -246,7 +246,7 @@ class DFCNNEngine:
                     ws_bytes = max(ws_bytes, ops.cell1_bwd_workspace(B, H, W, cout))
                     continue
                 self.a[dst] = Plane(B, H, W, cout, dev)
-                NP = B * (H + 2) * (W + 2)
+                NP = B * (H + 1) * (W + 1)
                 if feeds_dense:
                     assert not pool
                     self.flat[dst] = torch.zeros(B * H * W, cout, dtype=torch.float32, device=dev)

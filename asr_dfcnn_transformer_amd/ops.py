@@ -17,12 +17,14 @@ def _stream():
 
 
 class Plane:
-    """A padded NHWC plane [B][H+2][W+2][C] with zero border and (W+3)-pixel zero guards
-    on both ends (include/asr_hip.h).  Kernels only write the interior."""
+    """A padded NHWC plane [B][H+1][W+1][C] (include/asr_hip.h): one zero row above every image and
+    one zero column left of every row -- the right/bottom borders are the next row's / next image's
+    left/top border -- plus (W+3)-pixel zero guards on both ends (the last image's bottom border lives
+    in the tail guard).  Kernels only write the interior."""
 
     def __init__(self, B, H, W, C, device='cuda'):
         self.B, self.H, self.W, self.C = B, H, W, C
-        self.HP, self.WP = H + 2, W + 2
+        self.HP, self.WP = H + 1, W + 1
         self.NP = B * self.HP * self.WP
         self.G = W + 3
         self.buf = torch.zeros((self.NP + 2 * self.G) * C, dtype=torch.float32, device=device)
@@ -36,7 +38,7 @@ class Plane:
         return self.body.view(self.B, self.HP, self.WP, self.C)
 
     def interior(self):
-        return self.view()[:, 1:-1, 1:-1, :]
+        return self.view()[:, 1:, 1:, :]
 
     def set_interior(self, x):
         self.interior().copy_(x)

@@ -15,10 +15,13 @@
  *   - return value: 0 = enqueued, negative asr_status on a bad descriptor;
  *   - reductions run in a fixed order: repeated calls give bit-identical results;
  *   - activations are fp32, NHWC.  A "padded plane" is the layout
- *         float [B][H+2][W+2][C]   (zero border, interior at [h+1][w+1])
- *     preceded and followed by at least (W+3) zero guard pixels; kernels only ever
- *     write the interior, so borders/guards stay zero once the buffer was zeroed.
- *     `x` arguments of padded planes point at pixel 0 (after the leading guard).
+ *         float [B][H+1][W+1][C]   (interior at [h+1][w+1]; row 0 and column 0 are zero)
+ *     i.e. ONE shared zero border: the right border of a row is the left border of the next
+ *     row, the bottom border of an image is the top border of the next image.  It is preceded
+ *     and followed by at least (W+3) zero guard pixels (the last image's bottom border lives
+ *     in the tail guard); kernels only ever write the interior, so borders/guards stay zero
+ *     once the buffer was zeroed.  `x` arguments of padded planes point at pixel 0 (after
+ *     the leading guard).
  */
 #ifndef ASR_HIP_H
 #define ASR_HIP_H
@@ -68,8 +71,8 @@ int asr_fbank(const float* signal, const int32_t* nsamples, int B, int max_sampl
  *   v = acc + bias[n];  if relu: v = max(v,0);          out_a[row_a(m)][n] = v
  *   y = scale[n]*v + shift[n];  out_y[row_y(m)][n] (+)= y
  *
- * ntaps = 9: A is a padded plane [B][H+2][W+2][K] (m = padded pixel index,
- *            off = dh*(W+2)+dw), rows at border positions are not written;
+ * ntaps = 9: A is a padded plane [B][H+1][W+1][K] (m = padded pixel index,
+ *            off = dh*(W+1)+dw), rows at border positions are not written;
  * ntaps = 1: A is a plain [M][K] matrix when H == 0 (dense), or a padded plane
  *            (1x1 conv) when H > 0.
  * wmode 0: Wt(tap,k,n) = W[(tap*K + k)*ldw + n]          (HWIO as stored by the model)
@@ -80,7 +83,7 @@ int asr_fbank(const float* signal, const int32_t* nsamples, int B, int max_sampl
  * Arithmetic: fp32 MFMA (v_mfma_f32_32x32x2_f32), i.e. exact fp32 FMA chains.
  */
 typedef struct {
-    int M;            /* rows: padded pixel count B*(H+2)*(W+2), or matrix rows     */
+    int M;            /* rows: padded pixel count B*(H+1)*(W+1), or matrix rows     */
     int K, N;
     int lda, ldw;     /* row pitches of A and W in floats                          */
     int ldo_a, ldo_y; /* row pitches of out_a / out_y                              */
