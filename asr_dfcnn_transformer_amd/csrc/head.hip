@@ -98,113 +98,128 @@ __device__ __forceinline__ double lse3(double a, double b, double c) {
     return m + log(exp(a - m) + exp(b - m) + exp(c - m));
 }
 
-// One workgroup per utterance; thread s owns lattice state s of the blank-extended label.
-__global__ __launch_bounds__(256) void ctc_lattice_kernel(const float* __restrict__ logits, int T, int B, int V,
+// One workgroup of 512 threads per utterance.  Phase 1: threads 0-255 run the alpha recursion while threads
+// 256-511 run the beta recursion (thread s / s-256 owns lattice state s), one barrier per time step, both
+// lattices go to the float64 workspace.  Phase 2 has no sequential dependency: the eight waves walk the time
+// steps in parallel, form the state occupancies exp(alpha+beta-lp-ll) and subtract their per-label sums from
+// the dense softmax term that ctc_rows_kernel already wrote.
+__global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restrict__ logits, int T, int B, int V,
                                                           const int32_t* __restrict__ labels, int max_label,
                                                           const int32_t* __restrict__ label_len,
                                                           const int32_t* __restrict__ seq_len, int blank,
                                                           const int32_t* __restrict__ status, const double* __restrict__ lse,
-                                                          double* __restrict__ alpha_ws, float* __restrict__ loss,
-                                                          float* __restrict__ grad) {
+                                                          double* __restrict__ alpha_ws, double* __restrict__ beta_ws,
+                                                          float* __restrict__ loss, float* __restrict__ grad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
-    const int b = blockIdx.x, s = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x;
     if (status[b] != 0) {
-        if (s == 0) loss[b] = INFINITY;
+        if (tid == 0) loss[b] = INFINITY;
         return;
     }
     const int L = label_len[b], Tb = seq_len[b], S = 2 * L + 1;
     const int SMAX = 2 * max_label + 1;
-    double* buf0 = (double*)smraw;              // [SMAX + 2]  (two leading -inf sentinels)
-    double* buf1 = buf0 + SMAX + 4;
-    double* occ = buf1 + SMAX + 4;              // [SMAX + 1]
-    double* lse_t = occ + SMAX + 3;             // [T]
-    int* ext = (int*)(lse_t + T);               // [SMAX]
-    int* nxt = ext + SMAX + 1;                  // [SMAX]
-    float* lg = (float*)(nxt + SMAX + 1);       // [Tb][S]
+    const int half = tid >> 8, s = tid & 255;           // half 0: alpha, half 1: beta
+    double* abuf0 = (double*)smraw;                     // alpha ping/pong with two leading -inf sentinels
+    double* abuf1 = abuf0 + SMAX + 4;
+    double* bbuf0 = abuf1 + SMAX + 4;                   // beta ping/pong with two trailing -inf sentinels
+    double* bbuf1 = bbuf0 + SMAX + 4;
+    double* occ = bbuf1 + SMAX + 4;                     // [8 waves][SMAX + 1]
+    double* lse_t = occ + 8 * (SMAX + 1);               // [T]
+    double* llp = lse_t + T;                            // [1] log-likelihood
+    int* ext = (int*)(llp + 2);                         // [SMAX + 1]
+    int* nxt = ext + SMAX + 1;                          // [SMAX + 1] next state with the same label (or -1)
+    int* lead = nxt + SMAX + 1;                         // [SMAX + 1] 1 = first odd state of its label
+    float* lg = (float*)(lead + SMAX + 1);              // [Tb][S] gathered lattice inputs
 
-    if (s < S) ext[s] = (s & 1) ? labels[(long)b * max_label + (s >> 1)] : blank;
-    for (int t = s; t < Tb; t += 256) lse_t[t] = lse[(long)t * B + b];
+    if (tid < S) ext[tid] = (tid & 1) ? labels[(long)b * max_label + (tid >> 1)] : blank;
+    for (int t = tid; t < Tb; t += 512) lse_t[t] = lse[(long)t * B + b];
     __syncthreads();
-    int my = blank; bool skip_f = false, skip_b = false; int leader = 0;
+    int my = blank; bool skip_f = false, skip_b = false;
     if (s < S) {
         my = ext[s];
         skip_f = (s >= 2) && (my != blank) && (my != ext[s - 2]);
         skip_b = (s + 2 < S) && (my != blank) && (my != ext[s + 2]);
-        int n = -1;
-        if (s & 1) {
-            leader = 1;
-            for (int j = 1; j < s; j += 2) if (ext[j] == my) { leader = 0; break; }
-            for (int j = s + 2; j < S; j += 2) if (ext[j] == my) { n = j; break; }
+        if (half == 0) {
+            int n = -1, ld = 0;
+            if (s & 1) {
+                ld = 1;
+                for (int j = 1; j < s; j += 2) if (ext[j] == my) { ld = 0; break; }
+                for (int j = s + 2; j < S; j += 2) if (ext[j] == my) { n = j; break; }
+            }
+            nxt[s] = n; lead[s] = ld;
         }
-        nxt[s] = n;
     }
-    // gather the lattice inputs: lg[t][s] = logits[t][b][ext[s]]
-    for (int i = s; i < Tb * S; i += 256) {
+    for (int i = tid; i < Tb * S; i += 512) {
         const int t = i / S, q = i - t * S;
         lg[i] = logits[((long)t * B + b) * V + ext[q]];
     }
+    if (tid < 2) { abuf0[tid] = -INFINITY; abuf1[tid] = -INFINITY; }
+    if (tid >= 2 && tid < 4) { bbuf0[2 + S + tid - 2] = -INFINITY; bbuf1[2 + S + tid - 2] = -INFINITY; }
     __syncthreads();
 
-    double* prev = buf0 + 2; double* cur = buf1 + 2;
-    if (s < 2) { buf0[s] = -INFINITY; buf1[s] = -INFINITY; }
     double* aw = alpha_ws + (long)b * T * SMAX;
-    // ---- alpha
+    double* bw = beta_ws + (long)b * T * SMAX;
+    double* prev = (half == 0 ? abuf0 : bbuf0) + 2;
+    double* cur = (half == 0 ? abuf1 : bbuf1) + 2;
+    // ---- phase 1: alpha forward in time, beta backward in time, concurrently
     if (s < S) {
-        const double v = (s < 2) ? (double)lg[s] - lse_t[0] : -INFINITY;
-        prev[s] = v; aw[s] = v;
+        if (half == 0) {
+            const double v = (s < 2) ? (double)lg[s] - lse_t[0] : -INFINITY;
+            prev[s] = v; aw[s] = v;
+        } else {
+            const int t = Tb - 1;
+            const double v = (s >= S - 2) ? (double)lg[t * S + s] - lse_t[t] : -INFINITY;
+            prev[s] = v; bw[(long)t * SMAX + s] = v;
+        }
     }
-    for (int t = 1; t < Tb; ++t) {
+    for (int k = 1; k < Tb; ++k) {
         __syncthreads();
         if (s < S) {
-            const double a0 = prev[s], a1 = prev[s - 1], a2 = skip_f ? prev[s - 2] : -INFINITY;
-            const double v = lse3(a0, a1, a2) + ((double)lg[t * S + s] - lse_t[t]);
-            cur[s] = v; aw[(long)t * SMAX + s] = v;
+            if (half == 0) {
+                const int t = k;
+                const double a0 = prev[s], a1 = prev[s - 1], a2 = skip_f ? prev[s - 2] : -INFINITY;
+                const double v = lse3(a0, a1, a2) + ((double)lg[t * S + s] - lse_t[t]);
+                cur[s] = v; aw[(long)t * SMAX + s] = v;
+            } else {
+                const int t = Tb - 1 - k;
+                const double b0 = prev[s], b1 = prev[s + 1], b2 = skip_b ? prev[s + 2] : -INFINITY;
+                const double v = lse3(b0, b1, b2) + ((double)lg[t * S + s] - lse_t[t]);
+                cur[s] = v; bw[(long)t * SMAX + s] = v;
+            }
         }
         double* tmp = prev; prev = cur; cur = tmp;
     }
     __syncthreads();
-    const double ll = (S > 1) ? lse3(prev[S - 1], prev[S - 2], -INFINITY) : prev[0];
-    if (s == 0) loss[b] = (float)(-ll);
-    __syncthreads();
-    // ---- beta + gradient (beta buffers get trailing -inf sentinels)
-    double* bp = buf0 + 2; double* bc = buf1 + 2;
-    if (s < 2) { bp[S + s] = -INFINITY; bc[S + s] = -INFINITY; }
-    double a_next = 0.0;
-    if (s < S) {
-        const int t = Tb - 1;
-        bp[s] = (s >= S - 2) ? (double)lg[t * S + s] - lse_t[t] : -INFINITY;
-        a_next = aw[(long)t * SMAX + s];
+    if (tid == 0) {       // half 0's `prev` holds alpha at the last frame
+        const double ll = (S > 1) ? lse3(prev[S - 1], prev[S - 2], -INFINITY) : prev[0];
+        llp[0] = ll;
+        loss[b] = (float)(-ll);
     }
-    for (int t = Tb - 1; t >= 0; --t) {
-        __syncthreads();
-        double bcur = -INFINITY, a_t = a_next;
-        if (s < S) {
-            const double lp = (double)lg[t * S + s] - lse_t[t];
-            if (t == Tb - 1) {
-                bcur = bp[s];
-            } else {
-                const double b0 = bp[s], b1 = bp[s + 1], b2 = skip_b ? bp[s + 2] : -INFINITY;
-                bcur = lse3(b0, b1, b2) + lp;
-                bc[s] = bcur;
-            }
-            if (t > 0) a_next = aw[(long)(t - 1) * SMAX + s];
-            const double ab = a_t + bcur;
-            occ[s] = (ab == -INFINITY) ? 0.0 : exp(ab - lp - ll);
+    __threadfence_block();
+    __syncthreads();
+    const double ll = llp[0];
+    // ---- phase 2: occupancies and the sparse part of the gradient, time steps in parallel over the waves
+    const int wave = tid >> 6, lane = tid & 63;
+    double* oc = occ + wave * (SMAX + 1);
+    for (int t = wave; t < Tb; t += 8) {
+        for (int q = lane; q < S; q += 64) {
+            const double lp = (double)lg[t * S + q] - lse_t[t];
+            const double ab = aw[(long)t * SMAX + q] + bw[(long)t * SMAX + q];
+            oc[q] = (ab == -INFINITY) ? 0.0 : exp(ab - lp - ll);
         }
-        __syncthreads();
+        // (the wave's LDS writes are ordered before its own later reads)
         float* gr = grad + ((long)t * B + b) * V;
-        if (s < 64) {                       // wave 0: all blank states (even s)
-            double sum = 0.0;
-            for (int q = 2 * s; q < S; q += 128) sum += occ[q];
-            sum = asr_wave_sum_d(sum);
-            if (s == 0) gr[blank] -= (float)sum;
+        double bsum = 0.0;
+        for (int q = 2 * lane; q < S; q += 128) bsum += oc[q];
+        bsum = asr_wave_sum_d(bsum);
+        if (lane == 0) gr[blank] -= (float)bsum;
+        for (int q = 2 * lane + 1; q < S; q += 128) {
+            if (lead[q]) {
+                double sum = oc[q];
+                for (int j = nxt[q]; j >= 0; j = nxt[j]) sum += oc[j];
+                gr[ext[q]] -= (float)sum;
+            }
         }
-        if (s < S && leader) {
-            double sum = occ[s];
-            for (int q = nxt[s]; q >= 0; q = nxt[q]) sum += occ[q];
-            gr[my] -= (float)sum;
-        }
-        if (t != Tb - 1) { double* tmp = bp; bp = bc; bc = tmp; }
     }
 }
 
@@ -333,7 +348,7 @@ __global__ void adam_tf_kernel(float* __restrict__ theta, const float* __restric
 
 inline size_t ctc_lds_bytes(int T, int max_label) {
     const size_t SMAX = 2 * (size_t)max_label + 1;
-    return (2 * (SMAX + 4) + (SMAX + 3) + (size_t)T) * sizeof(double) + 2 * (SMAX + 1) * sizeof(int) +
+    return (4 * (SMAX + 4) + 8 * (SMAX + 1) + (size_t)T + 2) * sizeof(double) + 3 * (SMAX + 1) * sizeof(int) +
            (size_t)T * SMAX * sizeof(float) + 16;
 }
 
@@ -356,7 +371,7 @@ extern "C" int asr_softmax_log_bwd(const float* logits_tm, const float* g_tm, in
 
 extern "C" size_t asr_ctc_workspace(int T, int B, int max_label) {
     const size_t SMAX = 2 * (size_t)max_label + 1;
-    return ((size_t)T * B + (size_t)B * T * SMAX) * sizeof(double) + 64;
+    return ((size_t)T * B + 2 * (size_t)B * T * SMAX) * sizeof(double) + 64;
 }
 
 extern "C" int asr_ctc_loss(const float* logits_tm, int T, int B, int V, const int32_t* labels, int max_label,
@@ -370,6 +385,7 @@ extern "C" int asr_ctc_loss(const float* logits_tm, int T, int B, int V, const i
     hipStream_t st = (hipStream_t)stream;
     double* lse = (double*)workspace;
     double* alpha_ws = lse + (size_t)T * B;
+    double* beta_ws = alpha_ws + (size_t)B * T * (2 * (size_t)max_label + 1);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)ctc_lattice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -377,7 +393,7 @@ extern "C" int asr_ctc_loss(const float* logits_tm, int T, int B, int V, const i
     }
     hipLaunchKernelGGL(ctc_check_kernel, dim3(asr_cdiv(B, 64)), dim3(64), 0, st, labels, max_label, label_len, seq_len, T, B, status);
     hipLaunchKernelGGL(ctc_rows_kernel, dim3(asr_cdiv((long)T * B, 4)), dim3(256), 0, st, logits_tm, T, B, V, seq_len, (const int32_t*)status, lse, grad);
-    hipLaunchKernelGGL(ctc_lattice_kernel, dim3(B), dim3(256), lds, st, logits_tm, T, B, V, labels, max_label, label_len, seq_len, blank, (const int32_t*)status, (const double*)lse, alpha_ws, loss, grad);
+    hipLaunchKernelGGL(ctc_lattice_kernel, dim3(B), dim3(512), lds, st, logits_tm, T, B, V, labels, max_label, label_len, seq_len, blank, (const int32_t*)status, (const double*)lse, alpha_ws, beta_ws, loss, grad);
     ASR_CHECK_LAUNCH("ctc_loss");
     return ASR_OK;
 }
