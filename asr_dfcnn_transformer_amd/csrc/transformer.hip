@@ -64,6 +64,20 @@ __device__ __forceinline__ void store_tile_T(float* __restrict__ X, float* scrat
     }
 }
 
+// Workgroup -> (tile, head, sample).  Plain launches use grid (tiles, H, N): the tiles of one (sample, head) run
+// together and share its K/V in L2.  Causal launches use grid (N*H, tiles): their tiles do unequal work (the key
+// range ends at the diagonal), so the longest tiles are dispatched first across all (sample, head) pairs --
+// longest-first keeps the last round full; with the plain order the skipped tiles bought no time at all.
+template <bool CAUSAL>
+__device__ __forceinline__ void attn_block_coords(int H, bool longest_is_last, int& tile, int& head, int& n, int& N) {
+    if (CAUSAL) {
+        head = blockIdx.x % H; n = blockIdx.x / H; N = gridDim.x / H;
+        tile = longest_is_last ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
+    } else {
+        tile = blockIdx.x; head = blockIdx.y; n = blockIdx.z; N = gridDim.z;
+    }
+}
+
 // ------------------------------------------------------------------ attention forward
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
@@ -75,8 +89,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     __shared__ float kstat[64];
     static_assert(4 * 32 * 65 <= 2 * 64 * KP, "transpose scratch must fit in the K/V tiles");
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
-    const int head = blockIdx.y, n = blockIdx.z, hoff = head * DH;
-    const int q0 = blockIdx.x * 128 + wave * 32, q = q0 + li;
+    int qtile, head, n, Nn;
+    attn_block_coords<CAUSAL>(H, true, qtile, head, n, Nn);
+    const int hoff = head * DH;
+    const int q0 = qtile * 128 + wave * 32, q = q0 + li;
     const long qbase = (long)n * Tq, kbase = (long)n * Tk;
 
     float qreg[32];
@@ -97,7 +113,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
 
+    const int qlast_blk = qtile * 128 + 127;
     for (int k0 = 0; k0 < Tk; k0 += 64) {
+        // A tile that lies entirely in the future of every query of this workgroup holds only the fill value:
+        // it contributes exp(fill - max) = 0 to a row that has already met a real score.  It may be skipped only
+        // when that holds for EVERY row (a row whose keys so far were all key-masked must still see it: TF's
+        // softmax is uniform over all fill entries, future ones included).
+        if (CAUSAL && k0 > qlast_blk) {
+            if (__syncthreads_and((q >= Tq) || (m_run > -1.0e9f))) break;
+        }
         __syncthreads();
         stage_tile(Ks, K, kbase, k0, 64, Tk, C, hoff, tid, 1.f, kstat, 0);
         stage_tile(Vs, V, kbase, k0, 64, Tk, C, hoff, tid, 1.f, nullptr, 0);
@@ -148,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     __syncthreads();
     if (q < Tq && lh == 0) {      // kept as (max, log-sum) pair: max may be the -2^32+1 fill, which would swallow log(l)
         lse[((long)n * H + head) * Tq + q] = m_run;
-        lse[(long)gridDim.z * H * Tq + ((long)n * H + head) * Tq + q] = logf(l_run);
+        lse[(long)Nn * H * Tq + ((long)n * H + head) * Tq + q] = logf(l_run);
     }
     store_tile_T(O, Ks + wave * (32 * 65), oacc, qmask / l_run, qbase, q0, Tq, C, hoff, lane);
 }
@@ -191,8 +215,10 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
     __shared__ float lse_s[32], lsl_s[32], del_s[32];
     __shared__ float scratch[4 * 32 * 65];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
-    const int head = blockIdx.y, n = blockIdx.z, hoff = head * DH;
-    const int k0 = blockIdx.x * 128 + wave * 32, key = k0 + li;
+    int ktile, head, n, Nn;
+    attn_block_coords<CAUSAL>(H, false, ktile, head, n, Nn);      // causal: the first key tile sees every query
+    const int hoff = head * DH;
+    const int k0 = ktile * 128 + wave * 32, key = k0 + li;
     const long qbase = (long)n * Tq, kbase = (long)n * Tk;
 
     float kreg[32], vreg[32];
@@ -215,13 +241,21 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
 
+    const int kfirst_blk = ktile * 128;
     for (int q0 = 0; q0 < Tq; q0 += 32) {
+        if (CAUSAL && q0 + 31 < kfirst_blk) {
+            // every score of this query tile against this key block is future-masked: dS = 0 (no dK), and P is
+            // exp(fill - max) = 0 unless a row's max IS the fill value (all of its keys masked) -- only then dV sees it
+            const int q = q0 + (tid & 31);
+            const bool degenerate = (q < Tq) && (lse[((long)n * H + head) * Tq + q] < -1.0e9f);
+            if (!__syncthreads_or(degenerate)) continue;
+        }
         __syncthreads();
         stage_tile(Qs, Q, qbase, q0, 32, Tq, C, hoff, tid, 1.f, qstat, 1);
         if (tid < 32) {
             const int q = q0 + tid;
             lse_s[tid] = (q < Tq) ? lse[((long)n * H + head) * Tq + q] : INFINITY;
-            lsl_s[tid] = (q < Tq) ? lse[(long)gridDim.z * H * Tq + ((long)n * H + head) * Tq + q] : 0.f;
+            lsl_s[tid] = (q < Tq) ? lse[(long)Nn * H * Tq + ((long)n * H + head) * Tq + q] : 0.f;
             del_s[tid] = (q < Tq) ? delta[((long)n * H + head) * Tq + q] : 0.f;
         }
         __syncthreads();
@@ -285,8 +319,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
     __shared__ float kstat[64];
     static_assert(4 * 32 * 65 <= 2 * 64 * KP, "transpose scratch must fit in the K/V tiles");
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
-    const int head = blockIdx.y, n = blockIdx.z, hoff = head * DH;
-    const int q0 = blockIdx.x * 128 + wave * 32, q = q0 + li;
+    int qtile, head, n, Nn;
+    attn_block_coords<CAUSAL>(H, true, qtile, head, n, Nn);
+    const int hoff = head * DH;
+    const int q0 = qtile * 128 + wave * 32, q = q0 + li;
     const long qbase = (long)n * Tq, kbase = (long)n * Tk;
 
     float qreg[32], doreg[32];
@@ -307,7 +343,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
 #pragma unroll
     for (int i = 0; i < 32; ++i) doreg[i] *= qmask;
     const float my_lse = (q < Tq) ? lse[((long)n * H + head) * Tq + q] : INFINITY;
-    const float my_lsl = (q < Tq) ? lse[(long)gridDim.z * H * Tq + ((long)n * H + head) * Tq + q] : 0.f;
+    const float my_lsl = (q < Tq) ? lse[(long)Nn * H * Tq + ((long)n * H + head) * Tq + q] : 0.f;
     const float my_del = (q < Tq) ? delta[((long)n * H + head) * Tq + q] : 0.f;
 
     floatx16 dq[2];
@@ -315,6 +351,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
     for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
 
     for (int k0 = 0; k0 < Tk; k0 += 64) {
+        if (CAUSAL && k0 > qtile * 128 + 127) break;     // masked scores get no gradient: nothing for dQ there
         __syncthreads();
         stage_tile(Ks, K, kbase, k0, 64, Tk, C, hoff, tid, 1.f, kstat, 0);
         stage_tile(Vs, V, kbase, k0, 64, Tk, C, hoff, tid, 1.f, nullptr, 0);
@@ -524,9 +561,9 @@ inline int grid_for(long total, int threads) {
 extern "C" int asr_attention_fwd(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
                                  int causal, float* O, float* lse, void* stream) {
     if (!Q || !K || !V || !O || !lse || N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
-    dim3 grid(asr_cdiv(Tq, 128), H, N);
+    dim3 grid(asr_cdiv(Tq, 128), H, N), grid_causal(N * H, asr_cdiv(Tq, 128), 1);      // see attn_block_coords
     hipStream_t st = (hipStream_t)stream;
-    if (causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H);
+    if (causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid_causal, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H);
     else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H);
     ASR_CHECK_LAUNCH("attention_fwd");
     return ASR_OK;
@@ -542,8 +579,9 @@ extern "C" int asr_attention_bwd(const float* Q, const float* K, const float* V,
     hipLaunchKernelGGL(attn_delta_kernel, dim3(asr_cdiv(groups * 16, 256)), dim3(256), 0, st, O, dO, delta_ws, N, Tq, C, H);
     dim3 gkv(asr_cdiv(Tk, 128), H, N), gq(asr_cdiv(Tq, 128), H, N);
     if (causal) {
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<true>, gkv, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dK, dV, Tq, Tk, C, H);
-        hipLaunchKernelGGL(attn_bwd_q_kernel<true>, gq, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dQ, Tq, Tk, C, H);
+        dim3 ckv(N * H, asr_cdiv(Tk, 128), 1), cq(N * H, asr_cdiv(Tq, 128), 1);
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<true>, ckv, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dK, dV, Tq, Tk, C, H);
+        hipLaunchKernelGGL(attn_bwd_q_kernel<true>, cq, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dQ, Tq, Tk, C, H);
     } else {
         hipLaunchKernelGGL(attn_bwd_kv_kernel<false>, gkv, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dK, dV, Tq, Tk, C, H);
         hipLaunchKernelGGL(attn_bwd_q_kernel<false>, gq, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dQ, Tq, Tk, C, H);

@@ -29,7 +29,8 @@ def ops():
 
 
 @pytest.mark.parametrize("N,Tq,Tk,H,causal", [(2, 7, 7, 2, True), (2, 100, 100, 8, True), (1, 130, 70, 2, False),
-                                              (2, 33, 200, 4, True), (1, 512, 512, 8, False)])
+                                              (2, 33, 200, 4, True), (1, 512, 512, 8, False),
+                                              (2, 300, 300, 2, True), (2, 520, 520, 2, True)])
 def test_attention_fwd_bwd(ops, N, Tq, Tk, H, causal):
     rng = np.random.default_rng(0)
     C = H * 64
@@ -42,6 +43,8 @@ def test_attention_fwd_bwd(ops, N, Tq, Tk, H, causal):
     Q[0, Tq - 1, :] = 0                       # a zero query row -> query mask zeroes its output
     if Tk > 8:
         K[N - 1, :, 64:128] = 0               # head 1 of the last sample: ALL keys masked -> uniform softmax
+        K[0, :2, :] = 0                       # causal: queries 0 and 1 of sample 0 see only masked keys, so their
+        #                                       softmax is uniform over ALL Tk fill entries (no future tile may be skipped)
     Oref, cache = otr.attention_core(Q.astype(np.float64), K.astype(np.float64), V.astype(np.float64), H, causal)
     O = torch.zeros(N, Tq, C, device='cuda')
     lse = torch.zeros(2, N, H, Tq, device='cuda')
