@@ -80,7 +80,7 @@ __device__ __forceinline__ void attn_block_coords(int H, bool longest_is_last, i
 
 // ------------------------------------------------------------------ attention forward
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+__global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                        const float* __restrict__ V, float* __restrict__ O,
                                                        float* __restrict__ lse, int Tq, int Tk, int C, int H) {
     __shared__ __attribute__((aligned(16))) float kv_lds[2 * 64 * KP];   // also the epilogue's transpose scratch
@@ -128,6 +128,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
         __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
+            // same rule per wave: 32 keys that are future to all 32 queries of this wave (no barrier in this loop)
+            if (CAUSAL && k0 + sub * 32 > q0 + 31 && __all((q >= Tq) || (m_run > -1.0e9f))) continue;
             floatx16 s;
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -202,17 +204,18 @@ __global__ void attn_delta_kernel(const float* __restrict__ O, const float* __re
 }
 
 // ------------------------------------------------------------------ attention backward: dK, dV
-// One wave owns 32 keys (K, V in registers); the block walks the queries in tiles of 32.
+// One wave owns 32 keys (K, V in registers); the block walks the queries in tiles of 64.
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+__global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                           const float* __restrict__ V, const float* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           float* __restrict__ dK, float* __restrict__ dV,
                                                           int Tq, int Tk, int C, int H) {
-    __shared__ __attribute__((aligned(16))) float Qs[32 * KP];
-    __shared__ __attribute__((aligned(16))) float Ds[32 * KP];
-    __shared__ float qstat[32];
-    __shared__ float lse_s[32], lsl_s[32], del_s[32];
+    constexpr int QT = 64;                       // queries staged per barrier round (two 32-row MFMA sub-tiles)
+    __shared__ __attribute__((aligned(16))) float Qs[QT * KP];
+    __shared__ __attribute__((aligned(16))) float Ds[QT * KP];
+    __shared__ float qstat[QT];
+    __shared__ float lse_s[QT], lsl_s[QT], del_s[QT];
     __shared__ float scratch[4 * 32 * 65];
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
     int ktile, head, n, Nn;
@@ -242,65 +245,74 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
     for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
 
     const int kfirst_blk = ktile * 128;
-    for (int q0 = 0; q0 < Tq; q0 += 32) {
-        if (CAUSAL && q0 + 31 < kfirst_blk) {
+    const long lrow = ((long)n * H + head) * Tq;
+    for (int q0 = 0; q0 < Tq; q0 += QT) {
+        if (CAUSAL && q0 + QT - 1 < kfirst_blk) {
             // every score of this query tile against this key block is future-masked: dS = 0 (no dK), and P is
             // exp(fill - max) = 0 unless a row's max IS the fill value (all of its keys masked) -- only then dV sees it
-            const int q = q0 + (tid & 31);
-            const bool degenerate = (q < Tq) && (lse[((long)n * H + head) * Tq + q] < -1.0e9f);
+            const int q = q0 + (tid & (QT - 1));
+            const bool degenerate = (q < Tq) && (lse[lrow + q] < -1.0e9f);
             if (!__syncthreads_or(degenerate)) continue;
         }
         __syncthreads();
-        stage_tile(Qs, Q, qbase, q0, 32, Tq, C, hoff, tid, 1.f, qstat, 1);
-        if (tid < 32) {
+        stage_tile(Qs, Q, qbase, q0, QT, Tq, C, hoff, tid, 1.f, qstat, 1);
+        if (tid < QT) {
             const int q = q0 + tid;
-            lse_s[tid] = (q < Tq) ? lse[((long)n * H + head) * Tq + q] : INFINITY;
-            lsl_s[tid] = (q < Tq) ? lse[(long)Nn * H * Tq + ((long)n * H + head) * Tq + q] : 0.f;
-            del_s[tid] = (q < Tq) ? delta[((long)n * H + head) * Tq + q] : 0.f;
+            lse_s[tid] = (q < Tq) ? lse[lrow + q] : INFINITY;
+            lsl_s[tid] = (q < Tq) ? lse[(long)Nn * H * Tq + lrow + q] : 0.f;
+            del_s[tid] = (q < Tq) ? delta[lrow + q] : 0.f;
         }
         __syncthreads();
         // dO' = qmask * dO  (the query mask multiplies the post-softmax matrix)
-        for (int f = tid; f < 32 * 16; f += 256) {
+        for (int f = tid; f < QT * 16; f += 256) {
             const int row = f >> 4, c4 = f & 15;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q0 + row < Tq && qstat[row] != 0.f) v = *(const float4*)(dO + (qbase + q0 + row) * C + hoff + c4 * 4);
             *(float4*)(Ds + row * KP + c4 * 4) = v;
         }
         __syncthreads();
-        floatx16 s, dp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        for (int sub = 0; sub < QT / 32; ++sub) {
+            const float* Qt = Qs + sub * 32 * KP;
+            const float* Dt = Ds + sub * 32 * KP;
+            const float* lse_t = lse_s + sub * 32; const float* lsl_t = lsl_s + sub * 32; const float* del_t = del_s + sub * 32;
+            // the same rule per wave: these 32 queries all precede this wave's 32 keys (no barrier inside this loop)
+            if (CAUSAL && q0 + sub * 32 + 31 < k0 && !__any(lse_t[li] < -1.0e9f)) continue;
+            floatx16 s, dp;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const float4 qv = *(const float4*)(Qs + li * KP + 8 * g + 4 * lh);
-            const float4 dv4 = *(const float4*)(Ds + li * KP + 8 * g + 4 * lh);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.x, kreg[g * 4 + 0], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.y, kreg[g * 4 + 1], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.z, kreg[g * 4 + 2], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.w, kreg[g * 4 + 3], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.x, vreg[g * 4 + 0], dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.y, vreg[g * 4 + 1], dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.z, vreg[g * 4 + 2], dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.w, vreg[g * 4 + 3], dp, 0, 0, 0);
-        }
-        // rows of s/dp = queries rowidx(r, lh), column = this lane's key
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ql = rowidx(r, lh), q = q0 + ql;
-            const bool keep = kkeep && (!CAUSAL || key <= q);
-            const float sv = keep ? s[r] * 0.125f : MASK_FILL;
-            const float p = (key < Tk) ? expf((sv - lse_s[ql]) - lsl_s[ql]) : 0.f;
-            const float ds = keep ? p * (dp[r] - del_s[ql]) * 0.125f : 0.f;
-            s[r] = p; dp[r] = ds;
-        }
+            for (int g = 0; g < 8; ++g) {
+                const float4 qv = *(const float4*)(Qt + li * KP + 8 * g + 4 * lh);
+                const float4 dv4 = *(const float4*)(Dt + li * KP + 8 * g + 4 * lh);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.x, kreg[g * 4 + 0], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.y, kreg[g * 4 + 1], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.z, kreg[g * 4 + 2], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.w, kreg[g * 4 + 3], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.x, vreg[g * 4 + 0], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.y, vreg[g * 4 + 1], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.z, vreg[g * 4 + 2], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.w, vreg[g * 4 + 3], dp, 0, 0, 0);
+            }
+            // rows of s/dp = queries rowidx(r, lh), column = this lane's key
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float* drow = Ds + rowidx(r, lh) * KP + li;
-            const float* qrow = Qs + rowidx(r, lh) * KP + li;
-            dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[0], s[r], dv[0], 0, 0, 0);
-            dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[32], s[r], dv[1], 0, 0, 0);
-            dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[0], dp[r], dk[0], 0, 0, 0);
-            dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[32], dp[r], dk[1], 0, 0, 0);
+            for (int r = 0; r < 16; ++r) {
+                const int ql = rowidx(r, lh), q = q0 + sub * 32 + ql;
+                const bool keep = kkeep && (!CAUSAL || key <= q);
+                const float sv = keep ? s[r] * 0.125f : MASK_FILL;
+                const float p = (key < Tk) ? expf((sv - lse_t[ql]) - lsl_t[ql]) : 0.f;
+                const float ds = keep ? p * (dp[r] - del_t[ql]) * 0.125f : 0.f;
+                s[r] = p; dp[r] = ds;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* drow = Dt + rowidx(r, lh) * KP + li;
+                const float* qrow = Qt + rowidx(r, lh) * KP + li;
+                dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[0], s[r], dv[0], 0, 0, 0);
+                dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[32], s[r], dv[1], 0, 0, 0);
+                dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[0], dp[r], dk[0], 0, 0, 0);
+                dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[32], dp[r], dk[1], 0, 0, 0);
+            }
         }
     }
     store_tile_T(dK, scratch + wave * (32 * 65), dk, 1.f, kbase, k0, Tk, C, hoff, lane);
@@ -309,7 +321,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kv_kernel(const float* __restric
 
 // ------------------------------------------------------------------ attention backward: dQ
 template <bool CAUSAL>
-__global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict__ Q, const float* __restrict__ K,
+__global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                          const float* __restrict__ V, const float* __restrict__ dO,
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
                                                          float* __restrict__ dQ, int Tq, int Tk, int C, int H) {
@@ -358,6 +370,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_kernel(const float* __restrict
         __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
+            if (CAUSAL && k0 + sub * 32 > q0 + 31) continue;       // future to this whole wave: dS = 0
             floatx16 s, dp;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }

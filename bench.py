@@ -136,8 +136,9 @@ def run_transformer(args):
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device='cuda'); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
     if rank == 0:
-        mha = 4 * 2 * T * C * C + 2 * 2 * T * T * C
-        fwd = 2 * blocks * mha + 2 * (2 * 2 * T * C * 4 * C) + 2 * T * C * Vout
+        # algorithmic flops: a causal score matrix has T(T+1)/2 live entries (the masked ones are not computed)
+        mha = lambda pairs: 4 * 2 * T * C * C + 2 * 2 * pairs * C
+        fwd = blocks * (mha(T * T) + mha(T * (T + 1) // 2)) + 2 * (2 * 2 * T * C * 4 * C) + 2 * T * C * Vout
         fstep = 3.0 * fwd
         r = timed[dom]
         seq_s = world * N * args.steps / dt
