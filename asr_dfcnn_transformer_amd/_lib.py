@@ -51,7 +51,7 @@ SIGNATURES = {
     'asr_edit_distance': (_I, [_P, _I, _P, _P, _I, _P, _I, _P, _P]),
     'asr_adam_tf': (_I, [_P, _P, _P, _P, _Z, _F, _F, _F, _F, _F, _P]),
     'asr_attention_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
-    'asr_attention_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    'asr_attention_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     'asr_add_layernorm_fwd': (_I, [_P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
     'asr_layernorm_bwd_workspace': (_Z, [_I, _I]),
     'asr_layernorm_bwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P]),

@@ -46,8 +46,10 @@ __device__ __forceinline__ void stage_tile(float* dst, const float* __restrict__
 
 // write a wave's transposed accumulator tile (rows = d in registers, column = token on the lane)
 // to X[n][tok][hoff + d] through an LDS transpose so the global stores are whole rows.
+// relu_src (optional): the post-ReLU tensor this gradient belongs to; the stored value is masked by (relu_src > 0).
 __device__ __forceinline__ void store_tile_T(float* __restrict__ X, float* scratch, const floatx16 (&acc)[2], float mul_lane,
-                                             long base_row, int tok0, int T, int C, int hoff, int lane) {
+                                             long base_row, int tok0, int T, int C, int hoff, int lane,
+                                             const float* __restrict__ relu_src = nullptr) {
     const int li = lane & 31, lh = lane >> 5;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -59,7 +61,12 @@ __device__ __forceinline__ void store_tile_T(float* __restrict__ X, float* scrat
         const int row = it * 4 + (lane >> 4), c4 = lane & 15;
         if (tok0 + row < T) {
             const float* s = scratch + row * 65 + c4 * 4;
-            *(float4*)(X + (base_row + tok0 + row) * C + hoff + c4 * 4) = make_float4(s[0], s[1], s[2], s[3]);
+            float4 o = make_float4(s[0], s[1], s[2], s[3]);
+            if (relu_src) {
+                const float4 h = *(const float4*)(relu_src + (base_row + tok0 + row) * C + hoff + c4 * 4);
+                o.x = h.x > 0.f ? o.x : 0.f; o.y = h.y > 0.f ? o.y : 0.f; o.z = h.z > 0.f ? o.z : 0.f; o.w = h.w > 0.f ? o.w : 0.f;
+            }
+            *(float4*)(X + (base_row + tok0 + row) * C + hoff + c4 * 4) = o;
         }
     }
 }
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
                                                           const float* __restrict__ V, const float* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           float* __restrict__ dK, float* __restrict__ dV,
-                                                          int Tq, int Tk, int C, int H) {
+                                                          int Tq, int Tk, int C, int H, int relu_grad) {
     constexpr int QT = 64;                       // queries staged per barrier round (two 32-row MFMA sub-tiles)
     __shared__ __attribute__((aligned(16))) float Qs[QT * KP];
     __shared__ __attribute__((aligned(16))) float Ds[QT * KP];
@@ -315,8 +322,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
             }
         }
     }
-    store_tile_T(dK, scratch + wave * (32 * 65), dk, 1.f, kbase, k0, Tk, C, hoff, lane);
-    store_tile_T(dV, scratch + wave * (32 * 65), dv, 1.f, kbase, k0, Tk, C, hoff, lane);
+    store_tile_T(dK, scratch + wave * (32 * 65), dk, 1.f, kbase, k0, Tk, C, hoff, lane, relu_grad ? K : nullptr);
+    store_tile_T(dV, scratch + wave * (32 * 65), dv, 1.f, kbase, k0, Tk, C, hoff, lane, relu_grad ? V : nullptr);
 }
 
 // ------------------------------------------------------------------ attention backward: dQ
@@ -324,7 +331,7 @@ template <bool CAUSAL>
 __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                          const float* __restrict__ V, const float* __restrict__ dO,
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                         float* __restrict__ dQ, int Tq, int Tk, int C, int H) {
+                                                         float* __restrict__ dQ, int Tq, int Tk, int C, int H, int relu_grad) {
     __shared__ __attribute__((aligned(16))) float kv_lds[2 * 64 * KP];   // also the epilogue's transpose scratch
     float* Ks = kv_lds;
     float* Vs = kv_lds + 64 * KP;
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
         }
     }
     __syncthreads();
-    store_tile_T(dQ, Ks + wave * (32 * 65), dq, 1.f, qbase, q0, Tq, C, hoff, lane);
+    store_tile_T(dQ, Ks + wave * (32 * 65), dq, 1.f, qbase, q0, Tq, C, hoff, lane, relu_grad ? Q : nullptr);
 }
 
 // ------------------------------------------------------------------ (add +) LayerNorm
@@ -583,7 +590,7 @@ extern "C" int asr_attention_fwd(const float* Q, const float* K, const float* V,
 }
 
 extern "C" int asr_attention_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO,
-                                 const float* lse, int N, int Tq, int Tk, int C, int H, int causal,
+                                 const float* lse, int N, int Tq, int Tk, int C, int H, int causal, int relu_grad,
                                  float* dQ, float* dK, float* dV, float* delta_ws, void* stream) {
     if (!Q || !K || !V || !O || !dO || !lse || !dQ || !dK || !dV || !delta_ws) return ASR_ERR_BAD_ARG;
     if (N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
@@ -593,11 +600,11 @@ extern "C" int asr_attention_bwd(const float* Q, const float* K, const float* V,
     dim3 gkv(asr_cdiv(Tk, 128), H, N), gq(asr_cdiv(Tq, 128), H, N);
     if (causal) {
         dim3 ckv(N * H, asr_cdiv(Tk, 128), 1), cq(N * H, asr_cdiv(Tq, 128), 1);
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<true>, ckv, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dK, dV, Tq, Tk, C, H);
-        hipLaunchKernelGGL(attn_bwd_q_kernel<true>, cq, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dQ, Tq, Tk, C, H);
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<true>, ckv, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dK, dV, Tq, Tk, C, H, relu_grad);
+        hipLaunchKernelGGL(attn_bwd_q_kernel<true>, cq, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dQ, Tq, Tk, C, H, relu_grad);
     } else {
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<false>, gkv, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dK, dV, Tq, Tk, C, H);
-        hipLaunchKernelGGL(attn_bwd_q_kernel<false>, gq, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dQ, Tq, Tk, C, H);
+        hipLaunchKernelGGL(attn_bwd_kv_kernel<false>, gkv, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dK, dV, Tq, Tk, C, H, relu_grad);
+        hipLaunchKernelGGL(attn_bwd_q_kernel<false>, gq, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dQ, Tq, Tk, C, H, relu_grad);
     }
     ASR_CHECK_LAUNCH("attention_bwd");
     return ASR_OK;

@@ -279,9 +279,9 @@ def attention_fwd(Q, K, V, N, Tq, Tk, Cc, H, causal, O, lse):
                                         _stream()), 'asr_attention_fwd')
 
 
-def attention_bwd(Q, K, V, O, dO, lse, N, Tq, Tk, Cc, H, causal, dQ, dK, dV, delta_ws):
+def attention_bwd(Q, K, V, O, dO, lse, N, Tq, Tk, Cc, H, causal, dQ, dK, dV, delta_ws, relu_grad=False):
     check(_lib.load().asr_attention_bwd(_ptr(Q), _ptr(K), _ptr(V), _ptr(O), _ptr(dO), _ptr(lse), N, Tq, Tk, Cc, H,
-                                        int(causal), _ptr(dQ), _ptr(dK), _ptr(dV), _ptr(delta_ws), _stream()),
+                                        int(causal), int(relu_grad), _ptr(dQ), _ptr(dK), _ptr(dV), _ptr(delta_ws), _stream()),
           'asr_attention_bwd')
 
 

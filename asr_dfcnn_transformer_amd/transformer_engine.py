@@ -191,8 +191,7 @@ class _Base:
         self._wgrad(st['A'], dZ, rq, C, C, name + '/wo')
         self._dense_dgrad(dZ, rq, C, C, self.p(name + '/wo'), dA, False)
         ops.attention_bwd(st['Q'], st['K'], st['V'], st['A'], dA, st['lse'], N, Tq, Tk, C, self.H, st['causal'],
-                          dQ, dK, dV, self.ws)
-        ops.relu_bwd(dQ, st['Q'], dQ); ops.relu_bwd(dK, st['K'], dK); ops.relu_bwd(dV, st['V'], dV)
+                          dQ, dK, dV, self.ws, relu_grad=True)      # gradients of the pre-ReLU projections
         self._wgrad(st['q_in'], dQ, rq, C, C, name + '/wq')
         self._wgrad(st['k_in'], dK, rk, C, C, name + '/wk')
         self._wgrad(st['k_in'], dV, rk, C, C, name + '/wv')

@@ -229,11 +229,13 @@ int asr_adam_tf(float* theta, const float* grad, float* m, float* v, size_t n,
  *   lse [2][N][H][Tq] (row max and log of the row sum of the masked scores, kept apart because
  *   the max can be the -2^32+1 fill value) is saved for the backward.
  * Backward: dQ, dK, dV (=).  Masked scores receive no gradient (tf.where), V still does.
+ *   relu_grad != 0: Q, K, V are outputs of Dense(activation=relu) (transformer.py:139-141) and the
+ *   returned gradients are those of the pre-activations, i.e. dQ *= (Q > 0) etc., fused in the store.
  *   delta_ws: N*H*Tq floats.  Deterministic (no atomics: dK/dV and dQ are separate passes). */
 int asr_attention_fwd(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
                       int causal, float* O, float* lse, void* stream);
 int asr_attention_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO,
-                      const float* lse, int N, int Tq, int Tk, int C, int H, int causal,
+                      const float* lse, int N, int Tq, int Tk, int C, int H, int causal, int relu_grad,
                       float* dQ, float* dK, float* dV, float* delta_ws, void* stream);
 
 /* K15 layer_norm (transformer.py:4-27) fused with the residual add in front of it:

@@ -59,6 +59,11 @@ def test_attention_fwd_bwd(ops, N, Tq, Tk, H, causal):
     report('attention dQ', gq.cpu().numpy(), gq_ref, 3e-5)
     report('attention dK', gk.cpu().numpy(), gk_ref, 3e-5)
     report('attention dV', gv.cpu().numpy(), gv_ref, 3e-5)
+    # relu_grad: the same gradients masked by (projection > 0), fused into the stores
+    ops.attention_bwd(dQ, dK, dV, O, dev(dO), lse, N, Tq, Tk, C, H, causal, gq, gk, gv, ws, relu_grad=True)
+    report('attention dQ (pre-relu)', gq.cpu().numpy(), gq_ref * (Q > 0), 3e-5)
+    report('attention dK (pre-relu)', gk.cpu().numpy(), gk_ref * (K > 0), 3e-5)
+    report('attention dV (pre-relu)', gv.cpu().numpy(), gv_ref * (V > 0), 3e-5)
 
 
 @pytest.mark.parametrize("rows,C,with_b", [(10, 512, True), (300, 64, False), (77, 2048, True)])
