@@ -606,6 +606,163 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v3(TapGemmArgs g) {
 }
 
 
+// ---- v4: the weight operand never touches LDS.  A lane's B operand of v_mfma_f32_32x32x2 is W[k][n = lane & 31]:
+// rows of the HWIO tensor are contiguous in n, so one global dword load per (k, half-wave) is two coalesced 128-byte
+// rows (forward), and the data-gradient's transposed view is contiguous in k, i.e. one float4 per lane feeds four
+// MFMAs.  The loads run D pipeline units (one unit = 8 contraction indices of one tap) ahead in a register ring,
+// they survive the barriers, and the only LDS traffic left is the A tile: two barriers per CHUNK instead of two
+// per tap, no weight staging writes, and LDS small enough that registers alone set the occupancy.
+template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE, int KCV, int D>
+__global__ __launch_bounds__(256) void tap_gemm_kernel_v4(TapGemmArgs g) {
+    constexpr int KC = KCV, AP = KCV + 4;
+    constexpr int TM = MT / WM / 32, TN = NT / WN / 32;
+    constexpr int GK = KC / 8;               // 8-wide contraction groups per chunk
+    constexpr int U = NTAPS * GK;            // pipeline units per chunk
+    constexpr int SB = 4;
+    static_assert(U % D == 0 && TM >= 1 && TN >= 1, "ring depth must divide the units of a chunk");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int halo = g.halo;
+    const int arows = MT + 2 * halo;
+    int* rowa = (int*)smem;
+    int* rowy = rowa + MT;
+    float* tile_lds = smem + 2 * MT;
+    float* As = tile_lds;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+    const int swz = asr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_m = swz / g.ntn, tile_n = swz - tile_m * g.ntn;
+    const long p0 = (long)tile_m * MT;
+    const int n0 = tile_n * NT;
+    const int K = g.K, N = g.N;
+
+    if (tid < MT) {
+        const long p = p0 + tid;
+        int ra = -1, ry = -1;
+        if (p < g.M) {
+            if (g.H == 0) {
+                ra = (int)p; ry = (int)p;
+            } else {
+                const int b = (int)(p / g.HPWP);
+                const int r = (int)(p - (long)b * g.HPWP);
+                const int hh = r / g.WP, ww = r - hh * g.WP;
+                if (hh >= 1 && hh <= g.H && ww >= 1 && ww <= g.Wd) {
+                    ra = (int)p;
+                    ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : (int)p;
+                }
+            }
+        }
+        rowa[tid] = ra; rowy[tid] = ry;
+    }
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nkc = (K + KC - 1) / KC;
+    float breg[D][TN][4];
+    const int ncol = n0 + wn * (TN * 32) + li;           // this lane's output column of sub-tile b = 0
+
+    // B operands of unit u (tap = u / GK, group = u % GK) of chunk kc into ring slot `slot`
+    auto load_b = [&](float (&dst)[TN][4], int kc, int u) {
+        const int tap = u / GK, gk = u - tap * GK;
+        const int kk = kc * KC + gk * 8 + 4 * lh;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int n = ncol + b * 32;
+            if (WMODE == 0) {
+                const float* src = g.W + ((long)tap * K + kk) * g.ldw + n;
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) dst[b][s2] = (kk + s2 < K && n < N) ? src[(long)s2 * g.ldw] : 0.f;
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (kk < K && n < N) v = *(const float4*)(g.W + ((long)(NTAPS - 1 - tap) * N + n) * g.ldw + kk);
+                dst[b][0] = v.x; dst[b][1] = v.y; dst[b][2] = v.z; dst[b][3] = v.w;
+            }
+        }
+    };
+    auto load_a_row = [&](int f, int kc) -> float4 {
+        const int row = f / (KC / 4), c4 = f - row * (KC / 4);
+        const long grow = p0 - halo + row;
+        const int kk = kc * KC + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grow >= g.rmin && grow < g.rmax && kk < K) v = *(const float4*)(g.A + grow * g.lda + kk);
+        return v;
+    };
+
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_b(breg[d], 0, d);
+
+    for (int kc = 0; kc < nkc; ++kc) {
+        __syncthreads();
+        for (int base = 0; base < arows * (KC / 4); base += SB * 256) {
+            float4 t[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                t[i] = (f < arows * (KC / 4)) ? load_a_row(f, kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                if (f < arows * (KC / 4)) *(float4*)(As + (f / (KC / 4)) * AP + (f % (KC / 4)) * 4) = t[i];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int tap = u / GK, gk = u - tap * GK;
+            const int toff = halo + ((NTAPS == 9) ? ((tap / 3) - 1) * g.WP + (tap % 3) - 1 : 0);
+            const float* abase = As + (wm * (TM * 32) + li + toff) * AP + 4 * lh + gk * 8;
+            float4 av[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) av[a] = *(const float4*)(abase + a * 32 * AP);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const float as = (s2 == 0) ? av[a].x : (s2 == 1) ? av[a].y : (s2 == 2) ? av[a].z : av[a].w;
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, breg[u % D][b][s2], acc[a][b], 0, 0, 0);
+                }
+            }
+            // refill this ring slot with the unit D ahead (it may belong to the next chunk)
+            const int nu = (u + D) % U, nk = kc + ((u + D) >= U ? 1 : 0);
+            if (nk < nkc) load_b(breg[u % D], nk, nu);
+        }
+    }
+
+    __syncthreads();
+    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
+}
+
+template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE, int KCV, int D>
+int launch_v4(const TapGemmArgs& a, hipStream_t st) {
+    auto kern = tap_gemm_kernel_v4<MT, NT, WM, WN, NTAPS, WMODE, KCV, D>;
+    const int arows = MT + 2 * a.halo;
+    size_t lds = (size_t)arows * (KCV + 4) * sizeof(float) + 2 * MT * sizeof(int);
+    if (lds < kEpilogueLds + 2 * MT * sizeof(int)) lds = kEpilogueLds + 2 * MT * sizeof(int);
+    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    TapGemmArgs g = a;
+    g.ntm = asr_cdiv(a.M, MT);
+    g.ntn = asr_cdiv(a.N, NT);
+    hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn), dim3(256), lds, st, g);
+    ASR_CHECK_LAUNCH("tap_gemm");
+    return ASR_OK;
+}
+
 // Two generations of the main loop are kept because neither wins everywhere (tools/bench_layers.py,
 // MI355X): v1 (single-buffered tiles, two barriers per tap, 3 workgroups per CU) is faster wherever
 // thread-level parallelism hides the staging; v2 (double-buffered W, register-prefetched A, one barrier
@@ -702,6 +859,26 @@ int launch_n(const TapGemmArgs& a, hipStream_t st) {
         // acoustic_model.py: 50 tiles) runs on 64x64 tiles instead
         const long tiles = (long)asr_cdiv(a.M, 128) * asr_cdiv(a.N, 128);
         if (tiles < 160) return launch_cfg<64, 64, 2, 2, NTAPS, WMODE>(a, st);
+    }
+    {
+        const int ex = tap_gemm_experiment();
+        if (ex == 7 || ex == 8) {       // v4 (weights straight from global memory)
+            if constexpr (NTAPS == 9) {
+                if (a.N > 128) return launch_v4<128, 128, 2, 2, NTAPS, WMODE, 16, 3>(a, st);
+                if (a.N > 32) {
+                    if (ex == 8) return launch_v4<128, 64, 2, 2, NTAPS, WMODE, 32, 3>(a, st);
+                    return launch_v4<128, 64, 2, 2, NTAPS, WMODE, 16, 3>(a, st);
+                }
+                return launch_v4<256, 32, 4, 1, NTAPS, WMODE, 16, 3>(a, st);
+            } else {
+                if (a.N > 64) {
+                    if (ex == 8) return launch_v4<128, 64, 2, 2, NTAPS, WMODE, 32, 2>(a, st);
+                    return launch_v4<128, 128, 2, 2, NTAPS, WMODE, 32, 2>(a, st);
+                }
+                if (a.N > 32) return launch_v4<128, 64, 2, 2, NTAPS, WMODE, 32, 2>(a, st);
+                return launch_v4<256, 32, 4, 1, NTAPS, WMODE, 32, 2>(a, st);
+            }
+        }
     }
     if (NTAPS == 9) {
         const int ex = tap_gemm_experiment();
