@@ -14,6 +14,10 @@ class GemmDesc(C.Structure):
                 ('accumulate', C.c_int), ('y_unpadded', C.c_int)]
 
 
+class PixMap(C.Structure):
+    _fields_ = [('kind', C.c_int), ('B', C.c_int), ('H', C.c_int), ('W', C.c_int), ('C', C.c_int), ('ld', C.c_int)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
@@ -58,6 +62,25 @@ SIGNATURES = {
     'asr_embed_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P]),
     'asr_embed_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P]),
     'asr_smoothed_ce': (_I, [_P, _I, _P, _I, _I, _F, _I, _F, _P, _P, _P, _P, _P]),
+    'asr_prenet_conv1_fwd': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
+    'asr_prenet_conv1_bwd_workspace': (_Z, [_I, _I, _I]),
+    'asr_prenet_conv1_bwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
+    'asr_bn_workspace': (_Z, [C.POINTER(PixMap)]),
+    'asr_bn_stats': (_I, [_P, C.POINTER(PixMap), _F, _P, _P, _P, _P]),
+    'asr_bn_apply': (_I, [_P, C.POINTER(PixMap), _P, _P, _P, _P, _P, C.POINTER(PixMap), _I, _P, C.POINTER(PixMap), _P]),
+    'asr_bn_bwd': (_I, [_P, C.POINTER(PixMap), _P, C.POINTER(PixMap), _P, _P, _P, _I, _P, C.POINTER(PixMap), _P, _P, _P, _P]),
+    'asr_relu_mask': (_I, [_P, C.POINTER(PixMap), _P, C.POINTER(PixMap), _P, C.POINTER(PixMap), _P]),
+    'asr_conv_s2_expand': (_I, [_P, _I, _I, _P, _P]),
+    'asr_conv_s2_gather': (_I, [_P, _I, _I, _P, _P]),
+    'asr_plane_to_T': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
+    'asr_T_to_plane': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    'asr_attention_nomask_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    'asr_attention_nomask_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    'asr_freq_attention_fwd': (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    'asr_freq_attention_bwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
+    'asr_pix_add_ln_fwd': (_I, [_P, _P, C.POINTER(PixMap), _P, _P, _F, _P, _P, _P, _P]),
+    'asr_pix_ln_bwd_workspace': (_Z, [C.POINTER(PixMap)]),
+    'asr_pix_ln_bwd': (_I, [_P, _P, _P, C.POINTER(PixMap), _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -36,6 +36,20 @@ struct TapGemmArgs {
     int ablate;          // timing experiments only (ASR_TG_ABLATE): 1 skip A restaging, 2 skip W restaging, 4 skip epilogue
 };
 
+// Row offset of tap `tap` in the flattened padded plane, and the tap of the weight tensor it multiplies.
+//   9 taps: 3x3 SAME window, offsets (dh-1)*WP + (dw-1); the data-gradient walks the same offsets with the
+//           mirrored weight tap (offset(8-t) = -offset(t)).
+//   4 taps: forward-looking 2x2 window {0,1}x{0,1} -- the stride-2 3x3 conv of the end2end pre-net on a
+//           phase-split plane (prenet.hip); its data-gradient looks backwards with the same weight tap.
+template <int NTAPS, int WMODE>
+__device__ __forceinline__ int tap_row_offset(int tap, int WP) {
+    if (NTAPS == 9) return ((tap / 3) - 1) * WP + (tap % 3) - 1;
+    if (NTAPS == 4) { const int o = (tap >> 1) * WP + (tap & 1); return WMODE == 0 ? o : -o; }
+    return 0;
+}
+template <int NTAPS, int WMODE>
+__device__ __forceinline__ int tap_weight_index(int tap) { return (NTAPS == 9 && WMODE == 1) ? NTAPS - 1 - tap : tap; }
+
 // Epilogue shared by the three generations.  The 32x32 MFMA result has the output channel on the lane and
 // the pixel row in the register, which makes the natural store 4 bytes per lane (two 128-byte rows per wave
 // instruction, 32 instructions per tile and tensor).  Each wave instead transposes its tile through a private
@@ -67,7 +81,8 @@ __device__ __forceinline__ void tap_epilogue(const TapGemmArgs& g, const floatx1
                 const float* sp = scratch + row * 33 + c4 * 4;
                 float4 v = make_float4(sp[0] + bs.x, sp[1] + bs.y, sp[2] + bs.z, sp[3] + bs.w);
                 if (ra < 0 || !ncol) continue;
-                if (g.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (g.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (g.relu == 2) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
                 if (g.out_a) *(float4*)(g.out_a + (long)ra * g.ldo_a + n) = v;
                 if (g.out_y) {
                     float4 y = make_float4(sc.x * v.x + sh.x, sc.y * v.y + sh.y, sc.z * v.z + sh.z, sc.w * v.w + sh.w);
@@ -345,7 +360,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
                 const int n = f / (KC / 4), k4 = f - n * (KC / 4);
                 const int kk = kc * KC + k4 * 4, nn = n0 + n;
                 if (kk < K && nn < N)
-                    v = *(const float4*)(g.W + ((long)(NTAPS - 1 - tap) * N + nn) * g.ldw + kk);
+                    v = *(const float4*)(g.W + ((long)tap_weight_index<NTAPS, WMODE>(tap) * N + nn) * g.ldw + kk);
             }
             wreg[i] = v;
         }
@@ -418,7 +433,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
                 for (int i = 0; i < AREG; ++i) areg[i] = load_a_row(tid + i * 256, kc + 1);
             }
         }
-        const int toff = halo + ((NTAPS == 9) ? ((tap / 3) - 1) * g.WP + (tap % 3) - 1 : 0);
+        const int toff = halo + tap_row_offset<NTAPS, WMODE>(tap, g.WP);
         const float* abase = As + (wm * (TM * 32) + li + toff) * AP + 4 * lh;
         const float* wbase = (WMODE == 0) ? (Ws + (4 * lh) * NT + wn * (TN * 32) + li)
                                           : (Ws + (wn * (TN * 32) + li) * (KC + 1) + 4 * lh);
@@ -854,6 +869,11 @@ inline int tap_gemm_experiment() {      // tuning experiments (tools/bench_layer
 
 template <int NTAPS, int WMODE>
 int launch_n(const TapGemmArgs& a, hipStream_t st) {
+    if constexpr (NTAPS == 4) {         // pre-net stride-2 conv on the phase-split plane: 256 -> 64 and its data-gradient
+        if (a.N > 64) return launch_v1<128, 128, 2, 2, NTAPS, WMODE, 32>(a, st);
+        if (a.N > 32) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
+        return launch_v1<256, 32, 4, 1, NTAPS, WMODE, 32>(a, st);
+    } else {
     if (NTAPS == 1 && a.N > 32) {
         // a grid of 128x128 tiles that leaves most CUs idle (e.g. the 6400->128 hidden dense of
         // acoustic_model.py: 50 tiles) runs on 64x64 tiles instead
@@ -903,6 +923,7 @@ int launch_n(const TapGemmArgs& a, hipStream_t st) {
     if (a.N > 64) return launch_cfg<128, 128, 2, 2, NTAPS, WMODE>(a, st);
     if (a.N > 32) return launch_cfg<256, 64, 4, 1, NTAPS, WMODE>(a, st);
     return launch_cfg<256, 32, 4, 1, NTAPS, WMODE>(a, st);
+    }
 }
 
 }  // namespace
@@ -911,9 +932,9 @@ extern "C" int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float*
                             const float* bias, const float* scale, const float* shift,
                             float* out_a, float* out_y, void* stream) {
     if (!d || !A || !W || (!out_a && !out_y)) return ASR_ERR_BAD_ARG;
-    if (d->ntaps != 1 && d->ntaps != 9) return ASR_ERR_BAD_ARG;
+    if (d->ntaps != 1 && d->ntaps != 9 && d->ntaps != 4) return ASR_ERR_BAD_ARG;
     if ((d->K & 3) || (d->N & 3) || (d->lda & 3) || (d->ldw & 3)) return ASR_ERR_BAD_ARG;
-    if (d->ntaps == 9 && d->H <= 0) return ASR_ERR_BAD_ARG;
+    if (d->ntaps != 1 && d->H <= 0) return ASR_ERR_BAD_ARG;
     if (d->M <= 0 || d->K <= 0 || d->N <= 0) return ASR_ERR_BAD_ARG;
     if (((uintptr_t)A | (uintptr_t)W) & 15) return ASR_ERR_BAD_ARG;
     TapGemmArgs a;
@@ -923,7 +944,7 @@ extern "C" int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float*
     a.ldo_a = d->ldo_a; a.ldo_y = d->ldo_y;
     a.H = d->H; a.Wd = d->W; a.WP = d->W + 1; a.HPWP = (d->H + 1) * (d->W + 1);
     if (d->H > 0 && d->M != d->B * a.HPWP) return ASR_ERR_BAD_ARG;
-    a.halo = (d->ntaps == 9) ? a.WP + 1 : 0;
+    a.halo = (d->ntaps != 1) ? a.WP + 1 : 0;
     a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
     a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
     a.ntm = a.ntn = 0;
@@ -932,5 +953,6 @@ extern "C" int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float*
     a.ablate = ablate;
     hipStream_t st = (hipStream_t)stream;
     if (d->ntaps == 9) return d->wmode ? launch_n<9, 1>(a, st) : launch_n<9, 0>(a, st);
+    if (d->ntaps == 4) return d->wmode ? launch_n<4, 1>(a, st) : launch_n<4, 0>(a, st);
     return d->wmode ? launch_n<1, 1>(a, st) : launch_n<1, 0>(a, st);
 }

@@ -292,7 +292,9 @@ __global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_v1(WgradArgs g) {
                 for (int b = 0; b < TNW; ++b) bn[b] = Zs[(r + lh) * NT + (wn * TNW + b) * 32 + li];
 #pragma unroll
                 for (int t = 0; t < NTAPS; ++t) {
-                    const int off = (NTAPS == 9) ? ((t / 3) - 1) * g.WP + (t % 3) - 1 : 0;
+                    // 9: 3x3 SAME window; 4: forward-looking 2x2 window of the phase-split stride-2 conv (see tap_gemm.hip)
+                    const int off = (NTAPS == 9) ? ((t / 3) - 1) * g.WP + (t % 3) - 1
+                                  : (NTAPS == 4) ? (t >> 1) * g.WP + (t & 1) : 0;
 #pragma unroll
                     for (int a = 0; a < TKW; ++a) an[t][a] = As[(r + lh + halo + off) * KT + li + a * 32];
                 }
@@ -552,7 +554,7 @@ struct Plan { int ktile, ntile, ps, nchunks, pch; };
 
 Plan make_plan(const asr_gemm_desc* d) {
     Plan p;
-    if (d->ntaps == 9) {
+    if (d->ntaps != 1) {
         p.ktile = 32;
         p.ntile = d->N > 64 ? 128 : (d->N > 32 ? 64 : 32);
         p.ps = d->N > 32 ? 64 : 128;
@@ -581,7 +583,7 @@ int launch_wgrad(const WgradArgs& a, const Plan& p, int K, int N, hipStream_t st
     // half-length runs) is 10-30 % faster (tools/bench_layers.py).  ASR_WGRAD_VARIANT forces one.
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("ASR_WGRAD_VARIANT"); forced = e ? atoi(e) : 0; }
-    const int variant = (forced >= 1 && forced <= 3) ? forced : (NTAPS == 1 ? 3 : ((WAVES_N == 2 && K >= 64) ? 2 : 1));
+    const int variant = (NTAPS == 4) ? 1 : (forced >= 1 && forced <= 3) ? forced : (NTAPS == 1 ? 3 : ((WAVES_N == 2 && K >= 64) ? 2 : 1));
     constexpr int PS3 = PS / 2;          // v3 keeps the run's dZ in registers: half the run length
     auto kern = (variant == 1) ? tap_wgrad_kernel_v1<NTAPS, TKW, WAVES_N, TNW, PS>
               : (variant == 3) ? tap_wgrad_kernel_v3<NTAPS, TKW, WAVES_N, TNW, PS3> : tap_wgrad_kernel<NTAPS, TKW, WAVES_N, TNW, PS>;
@@ -613,16 +615,16 @@ extern "C" size_t asr_tap_wgrad_workspace(const asr_gemm_desc* d) {
 extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz,
                              float* dW, float* partials, void* stream) {
     if (!d || !A || !dZ || !dW) return ASR_ERR_BAD_ARG;
-    if (d->ntaps != 1 && d->ntaps != 9) return ASR_ERR_BAD_ARG;
+    if (d->ntaps != 1 && d->ntaps != 9 && d->ntaps != 4) return ASR_ERR_BAD_ARG;
     if ((d->K & 3) || (d->N & 3) || (d->lda & 3) || (ldz & 3)) return ASR_ERR_BAD_ARG;
-    if (d->ntaps == 9 && d->H <= 0) return ASR_ERR_BAD_ARG;
+    if (d->ntaps != 1 && d->H <= 0) return ASR_ERR_BAD_ARG;
     const Plan p = make_plan(d);
     if (p.nchunks > 1 && !partials) return ASR_ERR_BAD_ARG;
     WgradArgs a;
     a.A = A; a.Z = dZ; a.out = (p.nchunks > 1) ? partials : dW;
     a.M = d->M; a.K = d->K; a.N = d->N; a.lda = d->lda; a.ldz = ldz;
     a.WP = d->W + 1;
-    a.halo = (d->ntaps == 9) ? a.WP + 1 : 0;
+    a.halo = (d->ntaps != 1) ? a.WP + 1 : 0;
     a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
     a.pch = p.pch;
     a.slab = (long)d->ntaps * d->K * d->N;
@@ -632,6 +634,10 @@ extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float
         if (d->N > 64) rc = launch_wgrad<9, 1, 4, 1, 64>(a, p, d->K, d->N, st);
         else if (d->N > 32) rc = launch_wgrad<9, 1, 2, 1, 64>(a, p, d->K, d->N, st);
         else rc = launch_wgrad<9, 1, 1, 1, 128>(a, p, d->K, d->N, st);
+    } else if (d->ntaps == 4) {
+        if (d->N > 64) rc = launch_wgrad<4, 1, 4, 1, 64>(a, p, d->K, d->N, st);
+        else if (d->N > 32) rc = launch_wgrad<4, 1, 2, 1, 64>(a, p, d->K, d->N, st);
+        else rc = launch_wgrad<4, 1, 1, 1, 128>(a, p, d->K, d->N, st);
     } else {
         rc = launch_wgrad<1, 4, 4, 1, 64>(a, p, d->K, d->N, st);
     }

@@ -82,11 +82,16 @@ def kernel_symbol(family, ntaps, wmode, M, K, N):
     if family == 'tap_wgrad':
         if ntaps == 1:
             return 'tap_wgrad_kernel_v3<1, 4, 4, 1, 32>'
+        if ntaps == 4:
+            return 'tap_wgrad_kernel_v1<4, 1, %d, 1, %d>' % ((4, 64) if N > 64 else (2, 64) if N > 32 else (1, 128))
         if N > 64:
             return 'tap_wgrad_kernel_v1<9, 1, 4, 1, 64>'
         if N > 32:
             return 'tap_wgrad_kernel<9, 1, 2, 1, 64>' if K >= 64 else 'tap_wgrad_kernel_v1<9, 1, 2, 1, 64>'
         return 'tap_wgrad_kernel_v1<9, 1, 1, 1, 128>'
+    if ntaps == 4:
+        cfg = '128, 128, 2, 2' if N > 64 else '128, 64, 2, 2' if N > 32 else '256, 32, 4, 1'
+        return 'tap_gemm_kernel_v1<%s, 4, %d, 32>' % (cfg, wmode)
     v2 = ntaps == 9 and wmode == 1 and N <= 64 and (N > 32 or K >= 64)
     if ntaps == 1 and N > 32 and -(-M // 128) * -(-N // 128) < 160:
         cfg, kc = '64, 64, 2, 2', 32
@@ -313,3 +318,120 @@ def embed_bwd(dout, perm, uniq, seg, n_uniq, Cc, zero_pad, scale, dtable):
 def smoothed_ce(logits, ld, target, rows, V, eps, pad_id, inv_count, loss_rows, preds, stats, dlogits):
     check(_lib.load().asr_smoothed_ce(_ptr(logits), ld, _ptr(target), rows, V, eps, pad_id, inv_count, _ptr(loss_rows),
                                       _ptr(preds), _ptr(stats), _ptr(dlogits), _stream()), 'asr_smoothed_ce')
+
+
+# ---------------------------------------------------------------------------- end2end pre-net (include/asr_hip.h)
+from ._lib import PixMap  # noqa: E402
+
+
+def pixmap(t, C_=None, phase_split=False):
+    """(pointer, asr_pixmap) of a Plane (kind 0, or kind 2 when it holds a phase-split tensor of 2H x 2W pixels and
+    C/4 channels) or of a plain [B][H][W][C] tensor (kind 1)."""
+    if isinstance(t, Plane):
+        if phase_split:
+            return t.ptr, PixMap(2, t.B, 2 * t.H, 2 * t.W, t.C // 4, t.C)
+        return t.ptr, PixMap(0, t.B, t.H, t.W, C_ or t.C, t.C)
+    B, H, W, Cc = t.shape
+    return _ptr(t), PixMap(1, B, H, W, Cc, Cc)
+
+
+def prenet_conv1_fwd(x, w, b, a1):
+    B, T, F = x.shape
+    check(_lib.load().asr_prenet_conv1_fwd(_ptr(x), _ptr(w), _ptr(b), B, T, F, _ptr(a1), _stream()), 'asr_prenet_conv1_fwd')
+
+
+def prenet_conv1_bwd_workspace(B, T, F):
+    return _lib.load().asr_prenet_conv1_bwd_workspace(B, T, F)
+
+
+def prenet_conv1_bwd(x, dz, dw, db, ws):
+    B, T, F = x.shape
+    check(_lib.load().asr_prenet_conv1_bwd(_ptr(x), _ptr(dz), B, T, F, _ptr(dw), _ptr(db), _ptr(ws), _stream()),
+          'asr_prenet_conv1_bwd')
+
+
+def bn_workspace(t, **kw):
+    _, m = pixmap(t, **kw)
+    return _lib.load().asr_bn_workspace(C.byref(m))
+
+
+def bn_stats(src, eps, mean, rstd, ws, **kw):
+    p, m = pixmap(src, **kw)
+    check(_lib.load().asr_bn_stats(p, C.byref(m), eps, _ptr(mean), _ptr(rstd), _ptr(ws), _stream()), 'asr_bn_stats')
+
+
+def bn_apply(src, mean, rstd, gamma, beta, dst, res=None, relu=False, dst_phase_split=False):
+    ps, sm = pixmap(src)
+    pd, dm = pixmap(dst, phase_split=dst_phase_split)
+    pr, rm = pixmap(res) if res is not None else (C.c_void_p(0), sm)
+    check(_lib.load().asr_bn_apply(ps, C.byref(sm), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), pr, C.byref(rm),
+                                   int(relu), pd, C.byref(dm), _stream()), 'asr_bn_apply')
+
+
+def bn_bwd(dy, a, mean, rstd, gamma, act, dz, dgamma, dbeta, ws, dy_phase_split=False):
+    py, ym = pixmap(dy, phase_split=dy_phase_split)
+    pa, am = pixmap(a)
+    pz, zm = pixmap(dz)
+    check(_lib.load().asr_bn_bwd(py, C.byref(ym), pa, C.byref(am), _ptr(mean), _ptr(rstd), _ptr(gamma), act, pz, C.byref(zm),
+                                 _ptr(dgamma), _ptr(dbeta), _ptr(ws), _stream()), 'asr_bn_bwd')
+
+
+def relu_mask(dy, y, dst):
+    py, ym = pixmap(dy)
+    po, om = pixmap(y)
+    pd, dm = pixmap(dst)
+    check(_lib.load().asr_relu_mask(py, C.byref(ym), po, C.byref(om), pd, C.byref(dm), _stream()), 'asr_relu_mask')
+
+
+def conv_s2_expand(w, Cin, Cout, W4):
+    check(_lib.load().asr_conv_s2_expand(_ptr(w), Cin, Cout, _ptr(W4), _stream()), 'asr_conv_s2_expand')
+
+
+def conv_s2_gather(dW4, Cin, Cout, dw):
+    check(_lib.load().asr_conv_s2_gather(_ptr(dW4), Cin, Cout, _ptr(dw), _stream()), 'asr_conv_s2_gather')
+
+
+def plane_to_T(plane, choff, dst):
+    check(_lib.load().asr_plane_to_T(plane.ptr, plane.B, plane.H, plane.W, plane.C, choff, _ptr(dst), _stream()), 'asr_plane_to_T')
+
+
+def T_to_plane(srcA, srcB, plane, choff):
+    check(_lib.load().asr_T_to_plane(_ptr(srcA), _ptr(srcB), plane.B, plane.H, plane.W, plane.C, choff, plane.ptr, _stream()),
+          'asr_T_to_plane')
+
+
+def attention_nomask_fwd(Q, K, V, N, Tq, Tk, Cc, H, O, lse):
+    check(_lib.load().asr_attention_nomask_fwd(_ptr(Q), _ptr(K), _ptr(V), N, Tq, Tk, Cc, H, _ptr(O), _ptr(lse), _stream()),
+          'asr_attention_nomask_fwd')
+
+
+def attention_nomask_bwd(Q, K, V, O, dO, lse, N, Tq, Tk, Cc, H, dQ, dK, dV, delta_ws):
+    check(_lib.load().asr_attention_nomask_bwd(_ptr(Q), _ptr(K), _ptr(V), _ptr(O), _ptr(dO), _ptr(lse), N, Tq, Tk, Cc, H,
+                                               _ptr(dQ), _ptr(dK), _ptr(dV), _ptr(delta_ws), _stream()),
+          'asr_attention_nomask_bwd')
+
+
+def freq_attention_fwd(Q, K, V, B, T, P, O):
+    check(_lib.load().asr_freq_attention_fwd(_ptr(Q), _ptr(K), _ptr(V), B, T, _ptr(P), _ptr(O), _stream()), 'asr_freq_attention_fwd')
+
+
+def freq_attention_bwd(Q, K, V, P, dO, B, T, dQ, dK, dV, dS_ws):
+    check(_lib.load().asr_freq_attention_bwd(_ptr(Q), _ptr(K), _ptr(V), _ptr(P), _ptr(dO), B, T, _ptr(dQ), _ptr(dK), _ptr(dV),
+                                             _ptr(dS_ws), _stream()), 'asr_freq_attention_bwd')
+
+
+def pix_add_ln_fwd(a, r, gamma, beta, eps, y, xhat, rstd):
+    pa, m = pixmap(a)
+    check(_lib.load().asr_pix_add_ln_fwd(pa, pixmap(r)[0], C.byref(m), _ptr(gamma), _ptr(beta), eps, pixmap(y)[0],
+                                         pixmap(xhat)[0], _ptr(rstd), _stream()), 'asr_pix_add_ln_fwd')
+
+
+def pix_ln_bwd_workspace(t):
+    _, m = pixmap(t)
+    return _lib.load().asr_pix_ln_bwd_workspace(C.byref(m))
+
+
+def pix_ln_bwd(dy, xhat, rstd, gamma, dx, dgamma, dbeta, ws):
+    pd, m = pixmap(dy)
+    check(_lib.load().asr_pix_ln_bwd(pd, pixmap(xhat)[0], _ptr(rstd), C.byref(m), _ptr(gamma), pixmap(dx)[0], _ptr(dgamma),
+                                     _ptr(dbeta), _ptr(ws), _stream()), 'asr_pix_ln_bwd')

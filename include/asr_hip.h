@@ -87,10 +87,10 @@ typedef struct {
     int K, N;
     int lda, ldw;     /* row pitches of A and W in floats                          */
     int ldo_a, ldo_y; /* row pitches of out_a / out_y                              */
-    int ntaps;        /* 1 or 9                                                    */
+    int ntaps;        /* 1, 9, or 4 (2x2 forward window: phase-split stride-2 conv)  */
     int B, H, W;      /* geometry of the padded plane (H == 0: plain matrix)       */
     int wmode;        /* 0 | 1                                                     */
-    int relu;         /* apply max(.,0) after the bias                             */
+    int relu;         /* activation after the bias: 0 none, 1 max(.,0), 2 tanh      */
     int accumulate;   /* out_y += instead of =                                     */
     int y_unpadded;   /* out_y is [B*H*W][ldo_y]                                   */
 } asr_gemm_desc;
@@ -265,6 +265,76 @@ int asr_embed_bwd(const float* dout, const int32_t* perm, const int32_t* uniq, c
  *   dlogits [rows][ld] = d(mean_loss)/dlogits with inv_count = 1/sum(ist) (NULL: forward only). */
 int asr_smoothed_ce(const float* logits, int ld, const int32_t* target, int rows, int V, float eps, int pad_id,
                     float inv_count, float* loss_rows, int32_t* preds, float* stats, float* dlogits, void* stream);
+
+/* ====================================================================== end2end pre-net
+ * end2end/model.py:214-264 (Transformer_Model.pre_net) + dot_product_attention :134-172.
+ * 3x3 stride-1 convs are asr_tap_gemm / asr_tap_wgrad (ntaps = 9; desc.relu = 2 selects tanh).  The 64 -> 64
+ * stride-2 conv runs as a 2x2-tap conv (ntaps = 4) over the "phase split" plane of its input: a padded plane of
+ * (H/2, W/2) pixels x 4*C channels whose channel block (h&1)*2+(w&1) holds input pixel (h, w); its weights are
+ * expanded with asr_conv_s2_expand and its weight gradient folded back with asr_conv_s2_gather.
+ */
+
+/* Pixel addressing of a logical [B][H][W][C] tensor (base pointer = pixel (0,0,0) of the buffer / plane row 0):
+ *   kind 0  padded plane   [B][H+1][W+1][ld]   (interior pixel (h,w) at row h+1, column w+1)
+ *   kind 1  plain NHWC     [B][H][W][ld]
+ *   kind 2  phase-split padded plane [B][H/2+1][W/2+1][ld], ld >= 4*C, channel block ((h&1)*2+(w&1))*C
+ * C must be a multiple of 4 with C/4 a divisor of 256; ld a multiple of 4. */
+typedef struct { int kind, B, H, W, C, ld; } asr_pixmap;
+
+/* conv2d(1 -> 64, 3x3, stride 2, 'same', tanh) on x [B][T][F] (T, F even): a1 [B][T/2][F/2][64]  (model.py:219).
+ * Backward: dz = dL/d(pre-activation) [B][T/2][F/2][64] -> dw [3][3][1][64], db [64]. */
+int asr_prenet_conv1_fwd(const float* x, const float* w, const float* bias, int B, int T, int F, float* a1, void* stream);
+size_t asr_prenet_conv1_bwd_workspace(int B, int T, int F);
+int asr_prenet_conv1_bwd(const float* x, const float* dz, int B, int T, int F, float* dw, float* db,
+                         float* workspace, void* stream);
+
+/* tf.layers.batch_normalization(training=True) (model.py:220,222,228-232,264,266): batch moments over B*H*W
+ * (biased variance, accumulated in float64), y = gamma*(a-mean)*rstd + beta, optionally y = relu(y + res) (:267).
+ * Backward: dz = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat)) * act'(.) where the normalised tensor a is the
+ * OUTPUT of the activation of the conv in front (act 0 none, 1 relu: a > 0, 2 tanh: 1 - a^2); dgamma, dbeta (=). */
+size_t asr_bn_workspace(const asr_pixmap* m);
+int asr_bn_stats(const float* src, const asr_pixmap* m, float eps, float* mean, float* rstd, void* workspace, void* stream);
+int asr_bn_apply(const float* src, const asr_pixmap* sm, const float* mean, const float* rstd, const float* gamma,
+                 const float* beta, const float* res, const asr_pixmap* rm, int relu, float* dst, const asr_pixmap* dm,
+                 void* stream);
+int asr_bn_bwd(const float* dy, const asr_pixmap* ym, const float* a, const asr_pixmap* am, const float* mean,
+               const float* rstd, const float* gamma, int act, float* dz, const asr_pixmap* zm, float* dgamma,
+               float* dbeta, void* workspace, void* stream);
+/* dst = dy * (y > 0): gradient of the closing relu(f2 + out) (model.py:267) */
+int asr_relu_mask(const float* dy, const asr_pixmap* ym, const float* y, const asr_pixmap* om, float* dst,
+                  const asr_pixmap* dm, void* stream);
+
+/* HWIO [3][3][Cin][Cout] <-> the 2x2-tap weights [4][4*Cin][Cout] of the phase-split stride-2 conv */
+int asr_conv_s2_expand(const float* w, int Cin, int Cout, float* W4, void* stream);
+int asr_conv_s2_gather(const float* dW4, int Cin, int Cout, float* dw, void* stream);
+
+/* tf.transpose(q, [0,3,1,2]) and back (model.py:234-256): 64 channels [choff, choff+64) of a padded plane
+ * [B][H+1][W+1][ld] (W = 80) <-> T-layout [B][H][64][W]; the reverse direction can add two sources. */
+int asr_plane_to_T(const float* plane, int B, int H, int W, int ld, int choff, float* dst, void* stream);
+int asr_T_to_plane(const float* srcA, const float* srcB, int B, int H, int W, int ld, int choff, float* plane, void* stream);
+
+/* dot_product_attention(q_time, k_time, v_time, mask=False) (model.py:252): per (batch, channel) attention over
+ * the time axis, head width 80, no masks; tensors in T-layout = [N][T][H*80] with H = 64 "heads".
+ * lse [N][H][Tq]; delta_ws N*H*Tq floats. */
+int asr_attention_nomask_fwd(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
+                             float* O, float* lse, void* stream);
+int asr_attention_nomask_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                             const float* lse, int N, int Tq, int Tk, int C, int H,
+                             float* dQ, float* dK, float* dV, float* delta_ws, void* stream);
+/* dot_product_attention(q_fre, k_fre, v_fre, mask=False) (model.py:253): per (batch, channel) attention over the
+ * 80 frequency bins with the time axis as depth (scale 1/sqrt(T)); T-layout tensors [B][T][64][80].
+ * P [B][64][80][80] (attention weights) is saved for the backward; dS_ws: same size. */
+int asr_freq_attention_fwd(const float* Q, const float* K, const float* V, int B, int T, float* P, float* O, void* stream);
+int asr_freq_attention_bwd(const float* Q, const float* K, const float* V, const float* P, const float* dO, int B, int T,
+                           float* dQ, float* dK, float* dV, float* dS_ws, void* stream);
+
+/* layer_norm(a + r) over the 64 channels of a pixel map (model.py:261; eps 1e-8, biased variance).
+ * xhat (same map) and rstd [B*H*W] are saved; backward: dx (=), dgamma, dbeta (=). */
+int asr_pix_add_ln_fwd(const float* a, const float* r, const asr_pixmap* m, const float* gamma, const float* beta,
+                       float eps, float* y, float* xhat, float* rstd, void* stream);
+size_t asr_pix_ln_bwd_workspace(const asr_pixmap* m);
+int asr_pix_ln_bwd(const float* dy, const float* xhat, const float* rstd, const asr_pixmap* m, const float* gamma,
+                   float* dx, float* dgamma, float* dbeta, float* workspace, void* stream);
 
 #ifdef __cplusplus
 }
