@@ -373,8 +373,9 @@ class E2EEngine(_Base):
     configuration of BASELINE.json configs[3], pinyin ids through an embedding (``vin``)."""
 
     def __init__(self, din=5120, vout=6347, N=8, T=150, L=50, C=512, heads=8, blocks=6, pos_max=600, tie=True, vin=None,
-                 lr=5e-4, decay_steps=5000, min_lr=1e-6, seed=0, device='cuda'):
+                 lr=5e-4, decay_steps=5000, min_lr=1e-6, seed=0, device='cuda', need_dx=False):
         super().__init__(C, heads, device, lr, 0.98, decay_steps, min_lr)
+        self.need_dx = need_dx and vin is None       # dL/d(features) for the pre-net in front (prenet_engine.py)
         assert T <= pos_max and L <= pos_max
         self.din, self.V, self.Vp, self.N, self.T, self.L = din, vout, _r4(vout), N, T, L
         self.blocks, self.tie, self.vin, self.pos_max = blocks, tie, vin, pos_max
@@ -405,6 +406,7 @@ class E2EEngine(_Base):
         self.dstream = [self._t(mr * C), self._t(mr * C)]
         self.dmem = self._t(re * C)
         self.seg = [self._t(mr, dtype=torch.int32), self._t(mr, dtype=torch.int32), self._t(mr + 1, dtype=torch.int32)]
+        self.dx_feat = self._t(re, din) if self.need_dx else None
         self._alloc_scratch(mr, max(C * self.Vp, 4 * C * C, din * C),
                             [(r, C, C) for r in (re, rd)] + [(r, C, 4 * C) for r in (re, rd)] +
                             [(r, 4 * C, C) for r in (re, rd)] + [(rd, C, self.Vp), (re, din, C)])
@@ -486,6 +488,8 @@ class E2EEngine(_Base):
             ops.relu_bwd(du, self.u, du)
             self._wgrad(self.x_feat, du, re, self.din, C, 'in_w')
             self._bgrad(du, re, C, 'in_b')
+            if self.need_dx:
+                self._dense_dgrad(du, re, self.din, C, self.p('in_w'), self.dx_feat, False)
         else:
             perm, uniq, seg = sorted_segments(self._x_host)
             self._seg_upload(perm, uniq, seg)

@@ -304,6 +304,7 @@ def e2e_step(P, x_feat, y_in, y_tgt, heads, blocks, tie=True, want_grads=True):
     du = du * (u > 0)
     G['in_w'] = x_feat.reshape(-1, Din).T @ du.reshape(-1, C)
     G['in_b'] = du.reshape(-1, C).sum(axis=0)
+    out['dx_feat'] = du @ P['in_w'].T            # dL/d(x_feat): what the pre-net (oracle/prenet.py) backpropagates
     if tie:          # shared tensors receive the sum of both uses
         for i in range(blocks):
             for k in ('wq', 'wk', 'wv', 'wo'):
