@@ -128,17 +128,20 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
-__global__ void bn_stats_final_kernel(const double* __restrict__ partials, int nblocks, int C, double count, float eps,
-                                      float* __restrict__ mean, float* __restrict__ rstd) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// one wave per channel: lane l folds partial blocks l, l+64, ... in float64, then a fixed shuffle tree
+__global__ __launch_bounds__(64) void bn_stats_final_kernel(const double* __restrict__ partials, int nblocks, int C, double count,
+                                                            float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+    const int c = blockIdx.x, l = threadIdx.x;
     double s = 0, q = 0;
-    for (int k = 0; k < nblocks; ++k) { s += partials[(long)k * 2 * C + c]; q += partials[(long)k * 2 * C + C + c]; }
-    const double mu = s / count;
-    double var = q / count - mu * mu;
-    if (var < 0) var = 0;
-    mean[c] = (float)mu;
-    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    for (int k = l; k < nblocks; k += 64) { s += partials[(long)k * 2 * C + c]; q += partials[(long)k * 2 * C + C + c]; }
+    s = asr_wave_sum_d(s); q = asr_wave_sum_d(q);
+    if (l == 0) {
+        const double mu = s / count;
+        double var = q / count - mu * mu;
+        if (var < 0) var = 0;
+        mean[c] = (float)mu;
+        rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 // y = gamma * (a - mean) * rstd + beta; optionally y = relu(y + res)
@@ -200,17 +203,21 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
-// dgamma = sum(dy*xhat), dbeta = sum(dy); also the two means the apply pass needs (as floats in `sums`)
-__global__ void bn_bwd_final_kernel(const double* __restrict__ partials, int nblocks, int C, double count,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ sums) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// dgamma = sum(dy*xhat), dbeta = sum(dy); also the two means the apply pass needs (as floats in `sums`);
+// one wave per channel as above
+__global__ __launch_bounds__(64) void bn_bwd_final_kernel(const double* __restrict__ partials, int nblocks, int C, double count,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          float* __restrict__ sums) {
+    const int c = blockIdx.x, l = threadIdx.x;
     double s = 0, q = 0;
-    for (int k = 0; k < nblocks; ++k) { s += partials[(long)k * 2 * C + c]; q += partials[(long)k * 2 * C + C + c]; }
-    dbeta[c] = (float)s;
-    dgamma[c] = (float)q;
-    sums[c] = (float)(s / count);
-    sums[C + c] = (float)(q / count);
+    for (int k = l; k < nblocks; k += 64) { s += partials[(long)k * 2 * C + c]; q += partials[(long)k * 2 * C + C + c]; }
+    s = asr_wave_sum_d(s); q = asr_wave_sum_d(q);
+    if (l == 0) {
+        dbeta[c] = (float)s;
+        dgamma[c] = (float)q;
+        sums[c] = (float)(s / count);
+        sums[C + c] = (float)(q / count);
+    }
 }
 
 // d(a) = gamma*rstd*(dy - mean(dy) - xhat*mean(dy*xhat));  dz = d(a) * act'(z) written through a:
@@ -610,7 +617,7 @@ extern "C" int asr_bn_stats(const float* src, const asr_pixmap* m, float eps, fl
     hipStream_t st = (hipStream_t)stream;
     double* part = (double*)workspace;
     hipLaunchKernelGGL(bn_stats_kernel, dim3(nb), dim3(256), (size_t)ppb * 2 * m->C * sizeof(double), st, src, *m, part);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(asr_cdiv(m->C, 64)), dim3(64), 0, st, (const double*)part, nb, m->C,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(m->C), dim3(64), 0, st, (const double*)part, nb, m->C,
                        (double)npix, eps, mean, rstd);
     ASR_CHECK_LAUNCH("bn_stats");
     return ASR_OK;
@@ -644,7 +651,7 @@ extern "C" int asr_bn_bwd(const float* dy, const asr_pixmap* ym, const float* a,
     float* sums = (float*)(part + (size_t)nb * 2 * C);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(nb), dim3(256), (size_t)ppb * 2 * C * sizeof(double), st, dy, *ym, a, *am,
                        mean, rstd, part);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(asr_cdiv(C, 64)), dim3(64), 0, st, (const double*)part, nb, C, (double)npix,
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(C), dim3(64), 0, st, (const double*)part, nb, C, (double)npix,
                        dgamma, dbeta, sums);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(pix_blocks(npix, ppb * 4)), dim3(256), 0, st, dy, *ym, a, *am, mean, rstd,
                        gamma, (const float*)sums, act, dz, *zm);

@@ -25,7 +25,51 @@ static __global__ void colsum_pass_kernel(const float* __restrict__ x, int rows,
     out[(long)blockIdx.y * ldo + c] = (s0 + s1) + (s2 + s3);
 }
 
+// Tall, narrow matrices (bias gradients over millions of pixels x 64 channels): the column-per-thread pass above
+// would run on cols/256 x 64 workgroups.  Here cols/4 threads own one row (float4 each), 256/(cols/4) rows per
+// workgroup iteration, up to kTallBlocks workgroups; block partials are folded by the two-level pass.
+constexpr int kTallBlocks = 1024;
+constexpr int kTallMinRows = 16384;
+
+inline bool colsum_is_tall(int rows, int cols) {
+    const int cpp = cols / 4;
+    return rows >= kTallMinRows && (cols & 3) == 0 && cpp >= 1 && cpp <= 256 && (256 % cpp) == 0;
+}
+inline int colsum_tall_blocks(int rows, int cols) {
+    const int rpb = 256 / (cols / 4);
+    const int nb = asr_cdiv(rows, (long)rpb * 8);
+    return nb > kTallBlocks ? kTallBlocks : nb;
+}
+
+static __global__ __launch_bounds__(256) void colsum_tall_kernel(const float* __restrict__ x, int rows, int cols, long ldx,
+                                                                 float* __restrict__ partial) {
+    __shared__ float red[1024];                       // [rows per block][cols] = 256 * 4 floats
+    const int cpp = cols / 4, rpb = 256 / cpp;
+    const int c4 = threadIdx.x % cpp, rl = threadIdx.x / cpp;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    long r = (long)blockIdx.x * rpb + rl;
+    const long stride = (long)gridDim.x * rpb;
+    for (; r + stride < rows; r += 2 * stride) {      // two independent chains, folded in a fixed order
+        const float4 a = *(const float4*)(x + r * ldx + c4 * 4);
+        const float4 b = *(const float4*)(x + (r + stride) * ldx + c4 * 4);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+    }
+    if (r < rows) {
+        const float4 a = *(const float4*)(x + r * ldx + c4 * 4);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+    *(float4*)(red + rl * cols + c4 * 4) = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float t = 0.f;
+        for (int k = 0; k < rpb; ++k) t += red[k * cols + c];
+        partial[(long)blockIdx.x * cols + c] = t;
+    }
+}
+
 inline size_t colsum_tmp_floats(int rows, int cols) {
+    if (colsum_is_tall(rows, cols)) return (size_t)(colsum_tall_blocks(rows, cols) + kSplits) * cols;
     return rows > kSplits ? (size_t)kSplits * cols : 4;
 }
 
@@ -33,6 +77,12 @@ inline size_t colsum_tmp_floats(int rows, int cols) {
 inline int colsum(const float* x, int rows, int cols, long ldx, float* out, float* tmp, hipStream_t st) {
     const int threads = 256;
     const int gx = asr_cdiv(cols, threads);
+    if (colsum_is_tall(rows, cols) && (ldx & 3) == 0 && (((uintptr_t)x) & 15) == 0 && tmp) {
+        const int nb = colsum_tall_blocks(rows, cols);
+        float* part = tmp + (size_t)kSplits * cols;
+        hipLaunchKernelGGL(colsum_tall_kernel, dim3(nb), dim3(256), 0, st, x, rows, cols, ldx, part);
+        x = part; rows = nb; ldx = cols;
+    }
     if (rows <= kSplits) {
         hipLaunchKernelGGL(colsum_pass_kernel, dim3(gx, 1), dim3(threads), 0, st, x, rows, cols, ldx, rows, out, (long)cols);
     } else {

@@ -2,13 +2,15 @@
 placeholder / fetch names (x_input, y_input, y_target, learning_rate; mean_loss, merged,
 current_learning, train_op), driven session-style (end2end/model.py:104-109).
 
-``x_input`` here is the flattened pre-net output fed to ``embedding_input`` (model.py:267-279);
-the stride-2 conv + 2-D attention pre-net (model.py:214-264) is the next widening step
-(SURVEY 8f.1).  The encoder is not causal, so padding would change results: an engine is
-(re)built per (T, L) shape and the parameter / Adam state carried over."""
+``x_input`` is the reference's placeholder ``[batch, T, 4 * dimension]`` (model.py:203): stacked frames that go
+through ``pre_net`` (model.py:214-264; prenet_engine.PreNetEngine) and ``embedding_input``.  A feed whose last
+dimension equals ``input_dim`` instead is taken as an already-computed, flattened pre-net output (the entry point
+of ``embedding_input``, model.py:267-279).  The encoder is not causal, so padding would change results: engines
+are (re)built per (T, L) shape and the parameter / Adam state carried over."""
 import numpy as np
 import torch
 
+from .prenet_engine import PreNetEngine
 from .transformer_engine import E2EEngine
 
 
@@ -24,20 +26,34 @@ class Transformer_Model:
         self.dacay_step, self.min_learning_rate = arg.dacay_step, arg.min_learning_rate
         self.label_vocab_size = label_vocab_size
         self.input_dim = input_dim or (arg.feature_dim * 4 // 4) * 64          # [T/4, F/4, 64] flattened (model.py:270)
+        self.raw_dim = 4 * getattr(arg, 'dimension', arg.feature_dim)           # x_input's last dimension (model.py:203)
         self.tie, self.seed, self.device = tie, seed, device
         self.engine = None
+        self.prenet = None
 
     def build_transformer(self):
         return self
 
-    def _engine_for(self, T, L, lr):
+    def _prenet_for(self, T):
+        p = self.prenet
+        if p is not None and p.T == T:
+            return p
+        new = PreNetEngine(self.batch_size, T, self.raw_dim, seed=self.seed + 1, device=self.device)
+        if p is not None:
+            new.theta.copy_(p.theta); new.adam_m.copy_(p.adam_m); new.adam_v.copy_(p.adam_v)
+            new.global_step = p.global_step
+        self.prenet = new
+        return new
+
+    def _engine_for(self, T, L, lr, need_dx=False):
         e = self.engine
-        if e is not None and (e.T, e.L) == (T, L):
+        if e is not None and (e.T, e.L) == (T, L) and (e.need_dx or not need_dx):
             e.lr0 = lr
             return e
         new = E2EEngine(din=self.input_dim, vout=self.label_vocab_size, N=self.batch_size, T=T, L=L, C=self.hidden_units,
                         heads=self.num_heads, blocks=self.num_blocks, pos_max=self.position_max_length, tie=self.tie,
-                        lr=lr, decay_steps=self.dacay_step, min_lr=self.min_learning_rate, seed=self.seed, device=self.device)
+                        lr=lr, decay_steps=self.dacay_step, min_lr=self.min_learning_rate, seed=self.seed, device=self.device,
+                        need_dx=need_dx)
         if e is not None:
             new.theta.copy_(e.theta); new.adam_m.copy_(e.adam_m); new.adam_v.copy_(e.adam_v)
             new.global_step = e.global_step
@@ -52,13 +68,26 @@ class Transformer_Model:
             x = torch.as_tensor(np.asarray(x, dtype=np.float32))
         x = x.to(self.device, dtype=torch.float32).contiguous()
         y_in, y_tgt = np.asarray(feed_dict[self.y_input]), feed_dict.get(self.y_target)
-        e = self._engine_for(x.shape[1], y_in.shape[1], float(feed_dict.get(self.learning_rate, self.arg.learning_rate)))
+        raw = x.shape[2] == self.raw_dim and x.shape[2] != self.input_dim
+        pre = None
+        if raw:
+            pre = self._prenet_for(x.shape[1])
+            x = pre.forward(x)                          # [B, T/4, 80*64]
+        elif x.shape[2] != self.input_dim:
+            raise ValueError('x_input has %d features: expected %d (stacked frames) or %d (flattened pre-net output)' %
+                             (x.shape[2], self.raw_dim, self.input_dim))
+        e = self._engine_for(x.shape[1], y_in.shape[1], float(feed_dict.get(self.learning_rate, self.arg.learning_rate)),
+                             need_dx=raw)
         train = self.train_op in flist
         e.forward(x, y_in, np.zeros_like(y_in) if y_tgt is None else np.asarray(y_tgt), train=train)
         lr = None
         if train:
             e.backward()
+            if pre is not None:
+                pre.backward(e.dx_feat)
             lr = e.apply_adam()
+            if pre is not None:
+                pre.apply_adam(lr)                      # one AdamOptimizer over all variables (model.py:366-370)
         out, sc = [], None
         for f in flist:
             if f in (self.mean_loss, self.acc):
@@ -83,6 +112,6 @@ class Transformer_Model:
 class E2EHparams:
     """The module-level argparse defaults of end2end/model.py:15-55."""
     batch_size, num_blocks, hidden_units, num_heads = 8, 6, 512, 8
-    position_max_length, dropout_rate, feature_dim = 600, 0.2, 80
+    position_max_length, dropout_rate, feature_dim, dimension = 600, 0.2, 80, 80
     learning_rate, dacay_step, min_learning_rate = 5e-4, 5000, 1e-6
     is_training = True

@@ -37,7 +37,7 @@ def pmc_traffic(workload, symbol):
     written from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs with the gfx950 x2 FETCH correction of
     MI355X_MICROARCH.md).  Returns (bytes or None, source file or None)."""
     import glob
-    tag = {'dfcnn': 'dfcnn_m1', 'se_dfcnn': 'se_dfcnn_m2', 'transformer': 'transformer'}[workload]
+    tag = {'dfcnn': 'dfcnn_m1', 'se_dfcnn': 'se_dfcnn_m2', 'transformer': 'transformer', 'e2e_prenet': 'e2e_prenet'}[workload]
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_%s_traffic.json' % tag)))
     if not files:
         return None, None
@@ -96,24 +96,44 @@ def cpu_baseline(variant, t_pad, vocab, seconds=10.0, budget_s=15.0):
 
 def run_transformer(args):
     """BASELINE.json configs[3]: pinyin->hanzi encoder-decoder (6+6 MHA sub-layers, d_model 512, 8 heads),
-    batch 64 x seq 512, as-written live graph, fwd + bwd + Adam.  Secondary workload."""
+    batch 64 x seq 512, as-written live graph, fwd + bwd + Adam.  Secondary workload.
+    --workload e2e_prenet: the same encoder-decoder fed by the speech pre-net (end2end/model.py:214-264) from
+    stacked frames [64, 2048, 320]."""
     from asr_dfcnn_transformer_amd import ops
     from asr_dfcnn_transformer_amd.parallel import init_from_env, BucketedAllReduce
     from asr_dfcnn_transformer_amd.transformer_engine import E2EEngine
+    from asr_dfcnn_transformer_amd.prenet_engine import PreNetEngine, fwd_flops_per_seq
     rank, world, local = init_from_env()
     torch.cuda.set_device(local)
+    prenet = args.workload == 'e2e_prenet'
     N, T, C, H, blocks, Vin, Vout = args.batch if args.batch != 32 else 64, 512, 512, 8, 6, 1536, 6347
-    eng = E2EEngine(vin=Vin, vout=Vout, N=N, T=T, L=T, C=C, heads=H, blocks=blocks, pos_max=600, tie=True)
-    red = BucketedAllReduce(eng.grad, [(0, eng.grad.numel())])
     rng = np.random.default_rng(7 + rank)
-    x = rng.integers(1, Vin, (N, T)); y = rng.integers(3, Vout, (N, T))
+    if prenet:
+        pre = PreNetEngine(N, 4 * T, 320)
+        eng = E2EEngine(din=5120, vout=Vout, N=N, T=T, L=T, C=C, heads=H, blocks=blocks, pos_max=600, tie=True, need_dx=True)
+        gen = torch.Generator(device='cuda').manual_seed(7 + rank)
+        xraw = torch.randn(N, 4 * T, 320, device='cuda', generator=gen)
+        red_pre = BucketedAllReduce(pre.grad, [(0, pre.grad.numel())])
+    else:
+        eng = E2EEngine(vin=Vin, vout=Vout, N=N, T=T, L=T, C=C, heads=H, blocks=blocks, pos_max=600, tie=True)
+        x = rng.integers(1, Vin, (N, T))
+    red = BucketedAllReduce(eng.grad, [(0, eng.grad.numel())])
+    y = rng.integers(3, Vout, (N, T))
     y_in = np.concatenate([np.ones((N, 1), dtype=np.int64), y[:, :-1]], axis=1)
 
     def step():
-        eng.forward(x, y_in, y)
-        eng.backward()
-        red.launch(0); red.wait()
-        eng.apply_adam(red.grad_scale)
+        if prenet:
+            eng.forward(pre.forward(xraw), y_in, y)
+            eng.backward()
+            red.launch(0)
+            pre.backward(eng.dx_feat)
+            red_pre.launch(0); red.wait(); red_pre.wait()
+            pre.apply_adam(eng.apply_adam(red.grad_scale), red_pre.grad_scale)
+        else:
+            eng.forward(x, y_in, y)
+            eng.backward()
+            red.launch(0); red.wait()
+            eng.apply_adam(red.grad_scale)
 
     ops.TIMER = ops.KernelTimer()
     for i in range(max(1, args.warmup)):
@@ -139,15 +159,21 @@ def run_transformer(args):
         # algorithmic flops: a causal score matrix has T(T+1)/2 live entries (the masked ones are not computed)
         mha = lambda pairs: 4 * 2 * T * C * C + 2 * 2 * pairs * C
         fwd = blocks * (mha(T * T) + mha(T * (T + 1) // 2)) + 2 * (2 * 2 * T * C * 4 * C) + 2 * T * C * Vout
+        if prenet:
+            fwd += fwd_flops_per_seq(4 * T) + 2 * T * 5120 * C
         fstep = 3.0 * fwd
         r = timed[dom]
         seq_s = world * N * args.steps / dt
+        wl = ('end2end Transformer (end2end/model.py live graph: 6 enc + 6 dec MHA, 2 FFN, V 6347), pinyin ids -> hanzi, '
+              'fwd+bwd+Adam, tied enc/dec kernels')
+        if prenet:
+            wl = ('end2end speech Transformer: stacked frames [2048 x 320] -> pre_net (stride-2 convs, batch-stat BN, time/freq '
+                  'attention; model.py:214-264) -> 6 enc + 6 dec MHA, 2 FFN, V 6347 -> hanzi, fwd+bwd+Adam')
         out = {'metric': 'sequences/sec (B=64, T=512) end2end Transformer fwd+bwd', 'value': round(seq_s, 2),
                'unit': 'sequences/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
                'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
-               'config': {'workload': 'end2end Transformer (end2end/model.py live graph: 6 enc + 6 dec MHA, 2 FFN, V 6347), '
-                                      'pinyin ids -> hanzi, fwd+bwd+Adam, tied enc/dec kernels', 'global_batch': world * N,
+               'config': {'workload': wl, 'global_batch': world * N,
                           'seq_len': T, 'parallelism': 'dp%d' % world, 'gflop_per_seq_fwd_bwd': round(fstep / 1e9, 2),
                           'step_tflops': round(seq_s / world * fstep / 1e12, 2),
                           'step_frac_of_fp32_peak': round(seq_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
@@ -169,13 +195,13 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='dfcnn', choices=['dfcnn', 'se_dfcnn', 'transformer'])
+    ap.add_argument('--workload', default='dfcnn', choices=['dfcnn', 'se_dfcnn', 'transformer', 'e2e_prenet'])
     ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
     ap.add_argument('--tpad', type=int, default=1600)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--kernel-table', action='store_true', help='also print per-kernel timings to stderr')
     args = ap.parse_args()
-    if args.workload == 'transformer':
+    if args.workload in ('transformer', 'e2e_prenet'):
         return run_transformer(args)
 
     from asr_dfcnn_transformer_amd import ops

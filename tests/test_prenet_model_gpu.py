@@ -111,3 +111,21 @@ def test_prenet_plus_encoder_decoder_matches_oracle():
     print('dL/d(features) rel err %.3e' % e)
     assert e < 1e-3
     print('prenet worst grad rel err (through the whole model) %.3e' % check_grads(pre.grads_dict(), Rp))
+
+
+def test_transformer_model_shim_from_stacked_frames():
+    """Transformer_Model.run with the reference's x_input [batch, T, 4*dimension] (model.py:203): pre-net + encoder +
+    decoder + one Adam over all variables; the loss of a repeated batch goes down."""
+    from asr_dfcnn_transformer_amd.e2e_model import Transformer_Model, E2EHparams
+    hp = E2EHparams()
+    hp.batch_size, hp.num_blocks, hp.hidden_units, hp.num_heads, hp.position_max_length = 2, 2, 128, 2, 32
+    m = Transformer_Model(hp, label_vocab_size=23).build_transformer()
+    rng = np.random.default_rng(6)
+    feed = {m.x_input: rng.standard_normal((2, 32, 320)).astype(np.float32), m.y_input: rng.integers(1, 23, (2, 6)),
+            m.y_target: rng.integers(1, 23, (2, 6)), m.learning_rate: 1e-3}
+    losses = [m.run([m.mean_loss, m.train_op], feed)[0] for _ in range(8)]
+    print('losses', ['%.3f' % v for v in losses])
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert m.prenet.global_step == 8 and m.engine.global_step == 8 and m.engine.T == 8
+    with pytest.raises(ValueError):
+        m.run(m.mean_loss, {m.x_input: np.zeros((2, 8, 77), np.float32), m.y_input: feed[m.y_input]})
