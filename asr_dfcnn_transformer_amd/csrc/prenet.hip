@@ -22,11 +22,13 @@ __device__ __forceinline__ long pix_off(const asr_pixmap& m, int b, int h, int w
     return ((long)(b * (m.H / 2 + 1) + (h >> 1) + 1) * (m.W / 2 + 1) + (w >> 1) + 1) * m.ld + ((h & 1) * 2 + (w & 1)) * m.C;
 }
 
-__device__ __forceinline__ void pix_decode(const asr_pixmap& m, long p, int& b, int& h, int& w) {
-    const int hw = m.H * m.W;
-    b = (int)(p / hw);
-    const int r = (int)(p - (long)b * hw);
-    h = r / m.W; w = r - h * m.W;
+// pixel counts are checked on the host to fit 31 bits: 32-bit division only (a 64-bit one per pixel costs more
+// than the memory access it addresses)
+__device__ __forceinline__ void pix_decode(const asr_pixmap& m, int p, int& b, int& h, int& w) {
+    const unsigned hw = (unsigned)(m.H * m.W), up = (unsigned)p;
+    const unsigned ub = up / hw, r = up - ub * hw;
+    const unsigned uh = r / (unsigned)m.W;
+    b = (int)ub; h = (int)uh; w = (int)(r - uh * (unsigned)m.W);
 }
 
 // ------------------------------------------------------------------ first conv: 1 -> CO channels, 3x3, stride 2, tanh
@@ -41,11 +43,11 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     for (int i = threadIdx.x; i < CO; i += 256) ws[9 * CO + i] = bias[i];
     __syncthreads();
     const int H1 = T / 2, W1 = F / 2;
-    const long npix = (long)B * H1 * W1;
+    const int npix = B * H1 * W1;
     const int c4 = threadIdx.x & 15;
-    for (long p = (long)blockIdx.x * 16 + (threadIdx.x >> 4); p < npix; p += (long)gridDim.x * 16) {
-        const int b = (int)(p / ((long)H1 * W1));
-        const int r = (int)(p - (long)b * H1 * W1);
+    for (int p = blockIdx.x * 16 + (threadIdx.x >> 4); p < npix; p += gridDim.x * 16) {
+        const int b = p / (H1 * W1);
+        const int r = p - b * H1 * W1;
         const int i = r / W1, j = r - i * W1;
         float4 acc = *(const float4*)(ws + 9 * CO + c4 * 4);
 #pragma unroll
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
                 const float4 wv = *(const float4*)(ws + (dh * 3 + dw) * CO + c4 * 4);
                 acc.x += xv * wv.x; acc.y += xv * wv.y; acc.z += xv * wv.z; acc.w += xv * wv.w;
             }
-        *(float4*)(a1 + p * CO + c4 * 4) = make_float4(tanhf(acc.x), tanhf(acc.y), tanhf(acc.z), tanhf(acc.w));
+        *(float4*)(a1 + (long)p * CO + c4 * 4) = make_float4(tanhf(acc.x), tanhf(acc.y), tanhf(acc.z), tanhf(acc.w));
     }
 }
 
@@ -66,16 +68,16 @@ __global__ __launch_bounds__(256) void conv1_bwd_kernel(const float* __restrict_
                                                         int B, int T, int F, float* __restrict__ partials) {
     __shared__ float red[16][10 * CO + 4];
     const int H1 = T / 2, W1 = F / 2;
-    const long npix = (long)B * H1 * W1;
+    const int npix = B * H1 * W1;
     const int c4 = threadIdx.x & 15, pl = threadIdx.x >> 4;
     float4 acc[10];
 #pragma unroll
     for (int t = 0; t < 10; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (long p = (long)blockIdx.x * 16 + pl; p < npix; p += (long)gridDim.x * 16) {
-        const int b = (int)(p / ((long)H1 * W1));
-        const int r = (int)(p - (long)b * H1 * W1);
+    for (int p = blockIdx.x * 16 + pl; p < npix; p += gridDim.x * 16) {
+        const int b = p / (H1 * W1);
+        const int r = p - b * H1 * W1;
         const int i = r / W1, j = r - i * W1;
-        const float4 g = *(const float4*)(dz + p * CO + c4 * 4);
+        const float4 g = *(const float4*)(dz + (long)p * CO + c4 * 4);
 #pragma unroll
         for (int dh = 0; dh < 3; ++dh)
 #pragma unroll
@@ -106,9 +108,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     extern __shared__ double sh[];                     // [ppb][2*C]
     const int cpp = m.C / 4, ppb = 256 / cpp;
     const int c4 = threadIdx.x % cpp, pl = threadIdx.x / cpp;
-    const long npix = (long)m.B * m.H * m.W;
+    const int npix = m.B * m.H * m.W;
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    for (long p = (long)blockIdx.x * ppb + pl; p < npix; p += (long)gridDim.x * ppb) {
+    for (int p = blockIdx.x * ppb + pl; p < npix; p += gridDim.x * ppb) {
         int b, h, w;
         pix_decode(m, p, b, h, w);
         const float4 v = *(const float4*)(src + pix_off(m, b, h, w) + c4 * 4);
@@ -152,10 +154,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        float* __restrict__ dst, asr_pixmap dm) {
     const int cpp = sm.C / 4, ppb = 256 / cpp;
     const int c4 = threadIdx.x % cpp, pl = threadIdx.x / cpp;
-    const long npix = (long)sm.B * sm.H * sm.W;
+    const int npix = sm.B * sm.H * sm.W;
     const float4 mu = *(const float4*)(mean + c4 * 4), rs = *(const float4*)(rstd + c4 * 4);
     const float4 g = *(const float4*)(gamma + c4 * 4), be = *(const float4*)(beta + c4 * 4);
-    for (long p = (long)blockIdx.x * ppb + pl; p < npix; p += (long)gridDim.x * ppb) {
+    for (int p = blockIdx.x * ppb + pl; p < npix; p += gridDim.x * ppb) {
         int b, h, w;
         pix_decode(sm, p, b, h, w);
         const float4 v = *(const float4*)(src + pix_off(sm, b, h, w) + c4 * 4);
@@ -178,10 +180,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     extern __shared__ double sh[];
     const int C = am.C, cpp = C / 4, ppb = 256 / cpp;
     const int c4 = threadIdx.x % cpp, pl = threadIdx.x / cpp;
-    const long npix = (long)am.B * am.H * am.W;
+    const int npix = am.B * am.H * am.W;
     const float4 mu = *(const float4*)(mean + c4 * 4), rs = *(const float4*)(rstd + c4 * 4);
     double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    for (long p = (long)blockIdx.x * ppb + pl; p < npix; p += (long)gridDim.x * ppb) {
+    for (int p = blockIdx.x * ppb + pl; p < npix; p += gridDim.x * ppb) {
         int b, h, w;
         pix_decode(am, p, b, h, w);
         const float4 g = *(const float4*)(dy + pix_off(ym, b, h, w) + c4 * 4);
@@ -229,11 +231,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int act, float* __restrict__ dz, asr_pixmap zm) {
     const int C = am.C, cpp = C / 4, ppb = 256 / cpp;
     const int c4 = threadIdx.x % cpp, pl = threadIdx.x / cpp;
-    const long npix = (long)am.B * am.H * am.W;
+    const int npix = am.B * am.H * am.W;
     const float4 mu = *(const float4*)(mean + c4 * 4), rs = *(const float4*)(rstd + c4 * 4);
     const float4 g = *(const float4*)(gamma + c4 * 4);
     const float4 m1 = *(const float4*)(sums + c4 * 4), m2 = *(const float4*)(sums + C + c4 * 4);
-    for (long p = (long)blockIdx.x * ppb + pl; p < npix; p += (long)gridDim.x * ppb) {
+    for (int p = blockIdx.x * ppb + pl; p < npix; p += gridDim.x * ppb) {
         int b, h, w;
         pix_decode(am, p, b, h, w);
         const float4 d = *(const float4*)(dy + pix_off(ym, b, h, w) + c4 * 4);
@@ -255,8 +257,8 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict_
                                                         float* __restrict__ dst, asr_pixmap dm) {
     const int cpp = ym.C / 4, ppb = 256 / cpp;
     const int c4 = threadIdx.x % cpp, pl = threadIdx.x / cpp;
-    const long npix = (long)ym.B * ym.H * ym.W;
-    for (long p = (long)blockIdx.x * ppb + pl; p < npix; p += (long)gridDim.x * ppb) {
+    const int npix = ym.B * ym.H * ym.W;
+    for (int p = blockIdx.x * ppb + pl; p < npix; p += gridDim.x * ppb) {
         int b, h, w;
         pix_decode(ym, p, b, h, w);
         const float4 d = *(const float4*)(dy + pix_off(ym, b, h, w) + c4 * 4);
@@ -481,10 +483,10 @@ __global__ __launch_bounds__(256) void pix_add_ln_fwd_kernel(const float* __rest
                                                              float* __restrict__ y, float* __restrict__ xhat,
                                                              float* __restrict__ rstd_out) {
     const int c4 = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const long npix = (long)m.B * m.H * m.W;
+    const int npix = m.B * m.H * m.W;
     const float4 g = *(const float4*)(gamma + c4 * 4), be = *(const float4*)(beta + c4 * 4);
-    for (long p0 = (long)blockIdx.x * 16; p0 < npix; p0 += (long)gridDim.x * 16) {
-        const long p = p0 + pl;
+    for (int p0 = blockIdx.x * 16; p0 < npix; p0 += gridDim.x * 16) {
+        const int p = p0 + pl;
         const bool ok = p < npix;
         int b = 0, h = 0, w = 0;
         if (ok) pix_decode(m, p, b, h, w);
@@ -515,11 +517,11 @@ __global__ __launch_bounds__(256) void pix_ln_bwd_kernel(const float* __restrict
                                                          float* __restrict__ partials) {
     __shared__ float red[16][128 + 4];
     const int c4 = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const long npix = (long)m.B * m.H * m.W;
+    const int npix = m.B * m.H * m.W;
     const float4 g = *(const float4*)(gamma + c4 * 4);
     float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
-    for (long p0 = (long)blockIdx.x * 16; p0 < npix; p0 += (long)gridDim.x * 16) {
-        const long p = p0 + pl;
+    for (int p0 = blockIdx.x * 16; p0 < npix; p0 += gridDim.x * 16) {
+        const int p = p0 + pl;
         const bool ok = p < npix;
         int b = 0, h = 0, w = 0;
         if (ok) pix_decode(m, p, b, h, w);
@@ -555,6 +557,7 @@ inline int pix_blocks(long npix, int ppb) {
 
 inline bool map_ok(const asr_pixmap* m) {
     if (!m || m->B < 1 || m->H < 1 || m->W < 1 || m->C < 4 || (m->C & 3) || (m->ld & 3)) return false;
+    if ((long)m->B * m->H * m->W >= (1L << 30)) return false;         // 32-bit pixel arithmetic in the kernels
     const int cpp = m->C / 4;
     if (cpp > 256 || (256 % cpp) != 0) return false;
     if (m->kind == 2) return (m->H % 2 == 0) && (m->W % 2 == 0) && m->ld >= 4 * m->C;
@@ -571,6 +574,7 @@ inline bool same_shape(const asr_pixmap* a, const asr_pixmap* b) {
 extern "C" int asr_prenet_conv1_fwd(const float* x, const float* w, const float* bias, int B, int T, int F,
                                     float* a1, void* stream) {
     if (!x || !w || !bias || !a1 || B < 1 || T < 2 || F < 2 || (T & 1) || (F & 1)) return ASR_ERR_BAD_ARG;
+    if ((long)B * T * F >= (1L << 31)) return ASR_ERR_UNSUPPORTED;
     const long npix = (long)B * (T / 2) * (F / 2);
     hipLaunchKernelGGL(conv1_fwd_kernel, dim3(pix_blocks(npix, 16)), dim3(256), 0, (hipStream_t)stream, x, w, bias, B, T, F, a1);
     ASR_CHECK_LAUNCH("prenet_conv1_fwd");
@@ -591,6 +595,7 @@ extern "C" size_t asr_prenet_conv1_bwd_workspace(int B, int T, int F) {
 extern "C" int asr_prenet_conv1_bwd(const float* x, const float* dz, int B, int T, int F, float* dw, float* db,
                                     float* workspace, void* stream) {
     if (!x || !dz || !dw || !db || !workspace || B < 1 || T < 2 || F < 2 || (T & 1) || (F & 1)) return ASR_ERR_BAD_ARG;
+    if ((long)B * T * F >= (1L << 31)) return ASR_ERR_UNSUPPORTED;
     const int nb = conv1_bwd_blocks(B, T, F);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(conv1_bwd_kernel, dim3(nb), dim3(256), 0, st, x, dz, B, T, F, workspace);

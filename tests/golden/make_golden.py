@@ -11,7 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle import fbank as ofb, ctc as octc, dfcnn, optim as oopt  # noqa: E402
+from oracle import fbank as ofb, ctc as octc, dfcnn, optim as oopt, prenet as opn  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
@@ -87,8 +87,23 @@ def misc():
                         lr_steps=np.array([0, 1, 4999, 5000, 5001]), lr=lr, vocab_sizes=np.array([1536, 1424, 6345]))
 
 
+def prenet_case():
+    """end2end pre-net (oracle/prenet.py): B=2, T=16 stacked frames of 320 -> pre_out [2, 4, 80, 64] and all gradients."""
+    rng = np.random.default_rng(21)
+    B, T, F = 2, 16, 320
+    P = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in opn.init_params(seed=9).items()}
+    x = rng.standard_normal((B, T, F)).astype(np.float32)
+    dout = rng.standard_normal((B, T // 4, F // 4, 64)).astype(np.float32)
+    out, grads, inter = opn.forward_backward(P, x.astype(np.float64), dout.astype(np.float64))
+    z = {'x': x, 'dout': dout, 'pre_out': out.astype(np.float32), 'x2': inter['x2'].astype(np.float32)}
+    for k in P:
+        z['p/' + k] = P[k].astype(np.float32)
+        z['g/' + k] = grads[k].astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, 'prenet.npz'), **z)
+
+
 if __name__ == '__main__':
-    fbank_cases(); ctc_cases(); misc()
+    fbank_cases(); ctc_cases(); misc(); prenet_case()
     model_case('m2', (8, 16, 32, 64), 'm2')
     model_case('m1', (8, 16, 32, 64, 8, 32), 'm1')
     print('golden vectors written to', OUT)
