@@ -389,13 +389,28 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
         return v;
     };
 
+    // 4-tap (phase-split stride-2 conv): 7 of the 16 (tap, phase) weight blocks are structurally zero -- input pixel
+    // (2i+dh, 2j+dw) exists only for dh, dw <= 2, i.e. not (tap row 1 & odd row phase) nor (tap col 1 & odd col
+    // phase).  The phase is the 64-channel block of the contraction chunk (forward) or of this tile's output
+    // columns (data-gradient, NT <= N/4); those steps are skipped altogether.
+    auto step_valid = [&](int step) -> bool {
+        if (NTAPS != 4) return true;
+        const int kc = step / NTAPS, tap = step - kc * NTAPS;
+        const int phase = (WMODE == 0) ? (kc * KC) / (K >> 2) : n0 / (N >> 2);
+        return !(((tap >> 1) & (phase >> 1)) | ((tap & 1) & (phase & 1)));
+    };
+    auto next_step = [&](int step) -> int {
+        do { ++step; } while (step < nsteps && !step_valid(step));
+        return step;
+    };
+
     load_w(0);
     if (NTAPS == 1) {
 #pragma unroll
         for (int i = 0; i < AREG; ++i) areg[i] = load_a_row(tid + i * 256, 0);
     }
 
-    for (int step = 0; step < nsteps; ++step) {
+    for (int step = 0; step < nsteps; step = next_step(step)) {
         const int kc = step / NTAPS, tap = step - kc * NTAPS;
         __syncthreads();
         if (tap == 0 && !((g.ablate & 1) && kc > 0)) {
@@ -426,8 +441,8 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
         }
         if (!((g.ablate & 2) && step > 0)) store_w();
         __syncthreads();
-        if (step + 1 < nsteps && !(g.ablate & 2)) {
-            load_w(step + 1);
+        if (next_step(step) < nsteps && !(g.ablate & 2)) {
+            load_w(next_step(step));
             if (NTAPS == 1) {
 #pragma unroll
                 for (int i = 0; i < AREG; ++i) areg[i] = load_a_row(tid + i * 256, kc + 1);
@@ -869,8 +884,9 @@ inline int tap_gemm_experiment() {      // tuning experiments (tools/bench_layer
 
 template <int NTAPS, int WMODE>
 int launch_n(const TapGemmArgs& a, hipStream_t st) {
-    if constexpr (NTAPS == 4) {         // pre-net stride-2 conv on the phase-split plane: 256 -> 64 and its data-gradient
-        if (a.N > 64) return launch_v1<128, 128, 2, 2, NTAPS, WMODE, 32>(a, st);
+    if constexpr (NTAPS == 4) {         // pre-net stride-2 conv on the phase-split plane: 4C -> C and its data-gradient
+        // 64-wide column tiles: a data-gradient tile then lies inside one phase block (see step_valid)
+        if (WMODE == 0 ? (a.K & 255) : (a.N & 255)) return ASR_ERR_UNSUPPORTED;        // C must be a multiple of 64
         if (a.N > 32) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
         return launch_v1<256, 32, 4, 1, NTAPS, WMODE, 32>(a, st);
     } else {

@@ -236,6 +236,15 @@ __global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_v1(WgradArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
 
+    // 4-tap (phase-split stride-2 conv): taps whose weight block is structurally zero for this tile's input-channel
+    // phase are skipped (see tap_gemm.hip step_valid); their accumulators stay zero.
+    bool tv[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+        const int phase = (NTAPS == 4) ? k0 / (g.K >> 2) : 0;
+        tv[t] = (NTAPS != 4) || !(((t >> 1) & (phase >> 1)) | ((t & 1) & (phase & 1)));
+    }
+
     for (long ps0 = cbeg; ps0 < cend; ps0 += PS) {
         __syncthreads();
         // batches of SB independent loads before the LDS writes: a plain "load; store" loop makes hipcc wait
@@ -292,6 +301,7 @@ __global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_v1(WgradArgs g) {
                 for (int b = 0; b < TNW; ++b) bn[b] = Zs[(r + lh) * NT + (wn * TNW + b) * 32 + li];
 #pragma unroll
                 for (int t = 0; t < NTAPS; ++t) {
+                    if (!tv[t]) continue;
                     // 9: 3x3 SAME window; 4: forward-looking 2x2 window of the phase-split stride-2 conv (see tap_gemm.hip)
                     const int off = (NTAPS == 9) ? ((t / 3) - 1) * g.WP + (t % 3) - 1
                                   : (NTAPS == 4) ? (t >> 1) * g.WP + (t & 1) : 0;
@@ -301,12 +311,14 @@ __global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_v1(WgradArgs g) {
             };
             auto fma_all = [&](const float (&ac)[NTAPS][TKW], const float (&bc)[TNW]) {
 #pragma unroll
-                for (int t = 0; t < NTAPS; ++t)
+                for (int t = 0; t < NTAPS; ++t) {
+                    if (!tv[t]) continue;
 #pragma unroll
                     for (int a = 0; a < TKW; ++a)
 #pragma unroll
                         for (int b = 0; b < TNW; ++b)
                             acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][a], bc[b], acc[t][a][b], 0, 0, 0);
+                }
             };
             constexpr int RS = 2 * WAVES_P;             // pixel-pair stride of this wave (PS / RS is even)
             static_assert((PS / RS) % 2 == 0, "unroll by two");
@@ -618,6 +630,7 @@ extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float
     if (d->ntaps != 1 && d->ntaps != 9 && d->ntaps != 4) return ASR_ERR_BAD_ARG;
     if ((d->K & 3) || (d->N & 3) || (d->lda & 3) || (ldz & 3)) return ASR_ERR_BAD_ARG;
     if (d->ntaps != 1 && d->H <= 0) return ASR_ERR_BAD_ARG;
+    if (d->ntaps == 4 && (d->K & 255)) return ASR_ERR_UNSUPPORTED;      // phase blocks of K/4 channels, whole 32-wide k-tiles
     const Plan p = make_plan(d);
     if (p.nchunks > 1 && !partials) return ASR_ERR_BAD_ARG;
     WgradArgs a;

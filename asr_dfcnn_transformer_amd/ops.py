@@ -90,7 +90,7 @@ def kernel_symbol(family, ntaps, wmode, M, K, N):
             return 'tap_wgrad_kernel<9, 1, 2, 1, 64>' if K >= 64 else 'tap_wgrad_kernel_v1<9, 1, 2, 1, 64>'
         return 'tap_wgrad_kernel_v1<9, 1, 1, 1, 128>'
     if ntaps == 4:
-        cfg = '128, 128, 2, 2' if N > 64 else '128, 64, 2, 2' if N > 32 else '256, 32, 4, 1'
+        cfg = '128, 64, 2, 2' if N > 32 else '256, 32, 4, 1'
         return 'tap_gemm_kernel_v1<%s, 4, %d, 32>' % (cfg, wmode)
     v2 = ntaps == 9 and wmode == 1 and N <= 64 and (N > 32 or K >= 64)
     if ntaps == 1 and N > 32 and -(-M // 128) * -(-N // 128) < 160:
