@@ -9,6 +9,7 @@ Graphs follow the reference model files:
 Every cell is conv -> +bias -> ReLU -> frozen-affine BN -> [pool].
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -298,6 +299,16 @@ class DFCNNEngine:
         self.dist = torch.zeros(B, dtype=torch.float32, device=dev)
         self.scalars = torch.zeros(8, dtype=torch.float32, device=dev)     # [0] sum loss, [1] sum dist
         self.ws = torch.zeros(ws_bytes // 4 + 64, dtype=torch.float32, device=dev)
+        # Second stream for the backward pass (ASR_DUAL_STREAM=0 turns it off): the weight-gradient of a cell (MFMA-bound)
+        # runs beside its data-gradient and the NEXT cell's HBM-bound backward prologue -- they only share the
+        # read-only dZ plane -- so one kernel's last partial round of workgroups is filled by the others and the
+        # HBM-bound prologues hide under MFMA work (+6 % M1, +8 % M2 at B = 32).  Per-kernel durations of the
+        # overlapped kernels then overlap in any profile.  Results are bitwise the same as with one stream.
+        self.side = torch.cuda.Stream(device=dev) if os.environ.get('ASR_DUAL_STREAM', '1') == '1' else None
+        self.ws_side = torch.zeros_like(self.ws) if self.side is not None else None
+        # with the side stream every geometry gets a second dZ plane, used alternately, so the next cell's (HBM-bound)
+        # backward prologue can run while the previous weight-gradient (MFMA-bound) still reads the other one
+        self.dz_alt = {geo: Plane(p.B, p.H, p.W, p.C, dev) for geo, p in self.dz_pool.items()} if self.side is not None else {}
         self.labels = torch.zeros(B, MAX_LABEL, dtype=torch.int32, device=dev)
         self.label_len = torch.zeros(B, dtype=torch.int32, device=dev)
         self.seq_len = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -416,6 +427,7 @@ class DFCNNEngine:
             return self.dy[name], acc
 
         dense_pending = sum(1 for op in self.g if op[0] == 'dense')
+        side_busy, dz_reader, flip = None, {}, {}
         for op in reversed(self.g):
             if op[0] == 'dense':
                 _, src, dst, cin, cout, act = op
@@ -456,17 +468,35 @@ class DFCNNEngine:
                     continue
                 H, W, _ = self.res[src]
                 dz = self.dz_pool[(H, W, cout)]
+                if self.side is not None:
+                    flip[(H, W, cout)] = not flip.get((H, W, cout), False)
+                    if flip[(H, W, cout)]:
+                        dz = self.dz_alt[(H, W, cout)]
                 if dst in self.dflat:
                     dyv, layout = self.dflat[dst], 2
                 else:
                     dyv, layout = self._dplane(dst), (1 if pool else 0)
+                if id(dz) in dz_reader:              # an earlier weight-gradient may still read this dZ plane
+                    torch.cuda.current_stream().wait_event(dz_reader.pop(id(dz)))
                 ops.cell_bwd_pre(dyv, layout, self.a[dst], sc, sh, pm, dz, self.dscale_of(dst),
                                  self.gview(dst, 'beta'), self.gview(dst, 'b'), self.ws)
-                ops.tap_wgrad(self.wdesc[dst], self.y[src], dz, cout, self.gview(dst, 'w'), self.ws)
+                if self.side is None:
+                    ops.tap_wgrad(self.wdesc[dst], self.y[src], dz, cout, self.gview(dst, 'w'), self.ws)
+                else:
+                    dz_ready = torch.cuda.Event()
+                    dz_ready.record()
+                    self.side.wait_event(dz_ready)
+                    with torch.cuda.stream(self.side):
+                        ops.tap_wgrad(self.wdesc[dst], self.y[src], dz, cout, self.gview(dst, 'w'), self.ws_side)
+                        side_busy = torch.cuda.Event()
+                        side_busy.record()
+                        dz_reader[id(dz)] = side_busy
                 dx, acc = grad_target(src)
                 d = self.bdesc[dst]
                 d.accumulate = 1 if acc else 0
                 ops.tap_gemm(d, dz, self.p(dst, 'w'), None, None, None, None, dx)
+        if side_busy is not None:
+            torch.cuda.current_stream().wait_event(side_busy)
         if self.n_gamma:
             ops.axpy(self.grad[:self.n_gamma], self.dscale[:self.n_gamma], RS, False)
 
