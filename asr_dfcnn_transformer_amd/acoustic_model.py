@@ -86,7 +86,7 @@ class CNNCTCModel:
                 self._decode_only(feed_dict)
             else:
                 e.set_targets(np.asarray(feed_dict[self.logits_length]), np.asarray(tp))
-                e.loss_and_decode()
+                e.loss_and_decode(defer_decode_join=self.train_op in flist)
         if self.train_op in flist:
             if not self.is_training:
                 raise RuntimeError('train_op needs is_training=True')

@@ -309,6 +309,7 @@ class DFCNNEngine:
         # with the side stream every geometry gets a second dZ plane, used alternately, so the next cell's (HBM-bound)
         # backward prologue can run while the previous weight-gradient (MFMA-bound) still reads the other one
         self.dz_alt = {geo: Plane(p.B, p.H, p.W, p.C, dev) for geo, p in self.dz_pool.items()} if self.side is not None else {}
+        self._decode_done = None
         self.labels = torch.zeros(B, MAX_LABEL, dtype=torch.int32, device=dev)
         self.label_len = torch.zeros(B, dtype=torch.int32, device=dev)
         self.seq_len = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -404,14 +405,35 @@ class DFCNNEngine:
         self.seq_len.copy_(torch.from_numpy(sl), non_blocking=True)
         self._host_labels = [lab[b, :ll[b]].tolist() for b in range(self.B)]
 
-    def loss_and_decode(self):
+    def loss_and_decode(self, defer_decode_join=False):
+        """CTC loss + gradient, greedy decode, edit distance.  With the side stream the decode runs beside the CTC
+        lattice; ``defer_decode_join=True`` (training loops) leaves it running until the end of backward(), otherwise
+        the main stream waits for it before this returns (so dec_ids / dist / neg_sum can be read right away)."""
         B, T8, V = self.B, self.T8, self.V
+        side = self.side
+        if side is not None:
+            # greedy decode + edit distance only need the logits: they run beside the CTC lattice (both are latency-bound,
+            # a few dozen workgroups) and the head's backward; the main stream joins them again in backward()
+            logits_ready = torch.cuda.Event()
+            logits_ready.record()
+            if self._decode_done is not None:           # (the previous step's decode is long finished; formal ordering only)
+                side.wait_event(self._decode_done)
+            side.wait_event(logits_ready)
+            with torch.cuda.stream(side):
+                ops.ctc_greedy(self.logits, T8, B, V, self.seq_len, V - 1, self.dec_ids, self.dec_len, self.neg_sum, self.dec_ws)
+                ops.edit_distance(self.dec_ids, T8, self.dec_len, self.labels, MAX_LABEL, self.label_len, B, self.dist)
+                ops.colsum(self.dist, B, 1, 1, self.scalars[1:2], self.ws_side)
+                self._decode_done = torch.cuda.Event()
+                self._decode_done.record()
         ops.ctc_loss(self.logits, T8, B, V, self.labels, MAX_LABEL, self.label_len, self.seq_len, V - 1,
                      self.loss, self.ctc_grad, self.ctc_status, self.ctc_ws)
-        ops.ctc_greedy(self.logits, T8, B, V, self.seq_len, V - 1, self.dec_ids, self.dec_len, self.neg_sum, self.dec_ws)
-        ops.edit_distance(self.dec_ids, T8, self.dec_len, self.labels, MAX_LABEL, self.label_len, B, self.dist)
+        if side is None:
+            ops.ctc_greedy(self.logits, T8, B, V, self.seq_len, V - 1, self.dec_ids, self.dec_len, self.neg_sum, self.dec_ws)
+            ops.edit_distance(self.dec_ids, T8, self.dec_len, self.labels, MAX_LABEL, self.label_len, B, self.dist)
+            ops.colsum(self.dist, B, 1, 1, self.scalars[1:2], self.ws)
         ops.colsum(self.loss, B, 1, 1, self.scalars[0:1], self.ws)
-        ops.colsum(self.dist, B, 1, 1, self.scalars[1:2], self.ws)
+        if side is not None and not defer_decode_join:
+            torch.cuda.current_stream().wait_event(self._decode_done)
 
     # ------------------------------------------------------------------ backward
     def backward(self, on_dense_grads_ready=None):
@@ -497,6 +519,8 @@ class DFCNNEngine:
                 ops.tap_gemm(d, dz, self.p(dst, 'w'), None, None, None, None, dx)
         if side_busy is not None:
             torch.cuda.current_stream().wait_event(side_busy)
+        if self._decode_done is not None:
+            torch.cuda.current_stream().wait_event(self._decode_done)
         if self.n_gamma:
             ops.axpy(self.grad[:self.n_gamma], self.dscale[:self.n_gamma], RS, False)
 

@@ -208,6 +208,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
     ap.add_argument('--tpad', type=int, default=1600)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prefetch', action='store_true', help='compute the fbank features in line instead of one step ahead')
     ap.add_argument('--kernel-table', action='store_true', help='also print per-kernel timings to stderr')
     args = ap.parse_args()
     if args.workload in ('transformer', 'e2e_prenet'):
@@ -238,13 +239,38 @@ def main():
     target = np.zeros((B, 64), dtype=np.int32)
     target[:, :32] = lab_rng.integers(1, V - 1, (B, 32))
     seq = np.full(B, min(200, 999 // 8 + 1), dtype=np.int32)
-    feat = torch.empty(B, T, F, dtype=torch.float32, device=dev)
+    # Feature prefetch, as a data loader would do it: the fbank of the NEXT batch is computed on a second stream while
+    # the model works on the current one (two feature buffers).  Every step still computes exactly one batch of
+    # features inside the timed region; --no-prefetch puts it back in line on the main stream.
+    prefetch = not args.no_prefetch
+    feats = [torch.empty(B, T, F, dtype=torch.float32, device=dev) for _ in range(2 if prefetch else 1)]
+    pf_stream = torch.cuda.Stream(device=dev) if prefetch else None
+    feat_ready = [None, None]
+    consumed = [None, None]
+    state = {'i': 0}
+
+    def produce(slot):
+        with torch.cuda.stream(pf_stream):
+            if consumed[slot] is not None:
+                pf_stream.wait_event(consumed[slot])          # the step that read this buffer (incl. its backward) is done
+            fb.batch(signal, nsamp, T, out=feats[slot])
+            ev = torch.cuda.Event(); ev.record()
+            feat_ready[slot] = ev
 
     def step():
-        fb.batch(signal, nsamp, T, out=feat)
+        if prefetch:
+            cur = state['i'] & 1
+            if feat_ready[cur] is None:
+                produce(cur)                                  # very first step: nothing was prefetched yet
+            produce(cur ^ 1)
+            torch.cuda.current_stream().wait_event(feat_ready[cur])
+            feat = feats[cur]
+        else:
+            feat = feats[0]
+            fb.batch(signal, nsamp, T, out=feat)
         eng.forward(feat)
         eng.set_targets(seq, target)
-        eng.loss_and_decode()
+        eng.loss_and_decode(defer_decode_join=True)
         if world > 1:
             eng.backward(on_dense_grads_ready=lambda: red.launch(0))
             red.launch(1); red.launch(2)
@@ -252,6 +278,11 @@ def main():
         else:
             eng.backward()
         eng.apply_adam(red.grad_scale)
+        if prefetch:
+            ev = torch.cuda.Event(); ev.record()
+            consumed[cur] = ev
+            feat_ready[cur] = None
+            state['i'] += 1
 
     def barrier():
         if world > 1:
@@ -310,7 +341,7 @@ def main():
                        'gflop_per_utt_fwd_bwd': round(fstep / 1e9, 3),
                        'step_tflops': round(utt_s / world * fstep / 1e12, 2),
                        'step_frac_of_fp32_peak': round(utt_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
-                       'backward_streams': 2 if overlapped else 1,
+                       'backward_streams': 2 if overlapped else 1, 'feature_prefetch': prefetch,
                        'mean_loss': round(mean_loss, 4)},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / FP32_PEAK_TFLOPS, 4), 'traffic': None,
