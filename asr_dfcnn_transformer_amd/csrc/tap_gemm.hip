@@ -890,11 +890,25 @@ int launch_n(const TapGemmArgs& a, hipStream_t st) {
         if (a.N > 32) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
         return launch_v1<256, 32, 4, 1, NTAPS, WMODE, 32>(a, st);
     } else {
+    if constexpr (NTAPS == 1) {
+        const int ex1 = tap_gemm_experiment();
+        if (ex1 == 9 && a.N > 64) return launch_v1<128, 128, 2, 2, NTAPS, WMODE, 16>(a, st);
+        if (ex1 == 10 && a.N > 64) return launch_v1<256, 128, 4, 1, NTAPS, WMODE, 16>(a, st);
+        if (ex1 == 11 && a.N > 64) return launch_v1<256, 128, 4, 1, NTAPS, WMODE, 32>(a, st);
+        if (ex1 == 12 && a.N > 64) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
+    }
     if (NTAPS == 1 && a.N > 32) {
         // a grid of 128x128 tiles that leaves most CUs idle (e.g. the 6400->128 hidden dense of
         // acoustic_model.py: 50 tiles) runs on 64x64 tiles instead
         const long tiles = (long)asr_cdiv(a.M, 128) * asr_cdiv(a.N, 128);
         if (tiles < 160) return launch_cfg<64, 64, 2, 2, NTAPS, WMODE>(a, st);
+        if constexpr (WMODE == 0) {
+            // forward GEMMs whose 128x128 grid is about one round of the chip (tools/bench_layers.py): up to 768 tiles
+            // (3 workgroups/CU at KC 32) leave CUs idle -> 128x64 tiles (+7 % on 6400x6400x1536); 769..1024 tiles fit
+            // one round only at 4 workgroups/CU, which the 16-deep chunk allows (+14 % on 32768x512x512)
+            if (a.N > 64 && tiles <= 768) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
+            if (a.N > 64 && tiles <= 1024) return launch_v1<128, 128, 2, 2, NTAPS, WMODE, 16>(a, st);
+        }
     }
     {
         const int ex = tap_gemm_experiment();

@@ -93,8 +93,13 @@ def kernel_symbol(family, ntaps, wmode, M, K, N):
         cfg = '128, 64, 2, 2' if N > 32 else '256, 32, 4, 1'
         return 'tap_gemm_kernel_v1<%s, 4, %d, 32>' % (cfg, wmode)
     v2 = ntaps == 9 and wmode == 1 and N <= 64 and (N > 32 or K >= 64)
-    if ntaps == 1 and N > 32 and -(-M // 128) * -(-N // 128) < 160:
+    t128 = -(-M // 128) * -(-N // 128)
+    if ntaps == 1 and N > 32 and t128 < 160:
         cfg, kc = '64, 64, 2, 2', 32
+    elif ntaps == 1 and wmode == 0 and N > 64 and t128 <= 768:
+        cfg, kc = '128, 64, 2, 2', 32
+    elif ntaps == 1 and wmode == 0 and N > 64 and t128 <= 1024:
+        cfg, kc = '128, 128, 2, 2', 16
     elif ntaps == 9 and 32 < N <= 64:
         cfg, kc, v2 = '128, 64, 2, 2', 16, False
     elif ntaps == 9 and 64 < N <= 128:
