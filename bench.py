@@ -262,7 +262,6 @@ def main():
             cur = state['i'] & 1
             if feat_ready[cur] is None:
                 produce(cur)                                  # very first step: nothing was prefetched yet
-            produce(cur ^ 1)
             torch.cuda.current_stream().wait_event(feat_ready[cur])
             feat = feats[cur]
         else:
@@ -271,6 +270,8 @@ def main():
         eng.forward(feat)
         eng.set_targets(seq, target)
         eng.loss_and_decode(defer_decode_join=True)
+        if prefetch:
+            produce(cur ^ 1)          # beside the backward pass: the forward contractions keep the chip to themselves
         if world > 1:
             eng.backward(on_dense_grads_ready=lambda: red.launch(0))
             red.launch(1); red.launch(2)
