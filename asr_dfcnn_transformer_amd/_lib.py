@@ -70,6 +70,7 @@ SIGNATURES = {
     'asr_bn_apply': (_I, [_P, C.POINTER(PixMap), _P, _P, _P, _P, _P, C.POINTER(PixMap), _I, _P, C.POINTER(PixMap), _P]),
     'asr_bn_bwd': (_I, [_P, C.POINTER(PixMap), _P, C.POINTER(PixMap), _P, _P, _P, _I, _P, C.POINTER(PixMap), _P, _P, _P, _P]),
     'asr_relu_mask': (_I, [_P, C.POINTER(PixMap), _P, C.POINTER(PixMap), _P, C.POINTER(PixMap), _P]),
+    'asr_maxpool_bwd': (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     'asr_conv_s2_expand': (_I, [_P, _I, _I, _P, _P]),
     'asr_conv_s2_gather': (_I, [_P, _I, _I, _P, _P]),
     'asr_plane_to_T': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),

@@ -268,6 +268,43 @@ __global__ __launch_bounds__(256) void relu_mask_kernel(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------ 2x2 max-pool backward on padded planes
+// (Keras MaxPooling2D behind a batch-stat BN, lm_and_am/model/cnn_ctc.py:108-131: unlike the frozen-BN cells of
+// cells.hip there is no ReLU / affine to fuse here).  The first maximum in the order (0,0),(0,1),(1,0),(1,1) takes
+// the gradient, as in cells.hip and oracle/nn.py.
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          int B, int H, int W, int C, float* __restrict__ dx) {
+    const int C4 = C >> 2, H2 = H >> 1, W2 = W >> 1;
+    const int total = B * H2 * W2 * C4;
+    const int WP = W + 1, HP = H + 1, WP2 = W2 + 1, HP2 = H2 + 1;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int cg = idx % C4;
+        int pix = idx / C4;
+        const int w2 = pix % W2; pix /= W2;
+        const int h2 = pix % H2;
+        const int b = pix / H2;
+        const long pin = ((long)b * HP + 2 * h2 + 1) * WP + 2 * w2 + 1;
+        const float4 g = *(const float4*)(dy + (((long)b * HP2 + h2 + 1) * WP2 + w2 + 1) * C + cg * 4);
+        const long offs[4] = {pin, pin + 1, pin + WP, pin + WP + 1};
+        float4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = *(const float4*)(y + offs[k] * C + cg * 4);
+        int ax = 0, ay = 0, az = 0, aw = 0;
+        float mx = v[0].x, my = v[0].y, mz = v[0].z, mw = v[0].w;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            if (v[k].x > mx) { mx = v[k].x; ax = k; }
+            if (v[k].y > my) { my = v[k].y; ay = k; }
+            if (v[k].z > mz) { mz = v[k].z; az = k; }
+            if (v[k].w > mw) { mw = v[k].w; aw = k; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            *(float4*)(dx + offs[k] * C + cg * 4) =
+                make_float4(ax == k ? g.x : 0.f, ay == k ? g.y : 0.f, az == k ? g.z : 0.f, aw == k ? g.w : 0.f);
+    }
+}
+
 // ------------------------------------------------------------------ stride-2 conv as a 2x2-tap conv on the phase-split plane
 // W4[t = th*2+tw][(ph*2+pw)*Cin + c][n] = w[2*th+ph][2*tw+pw][c][n]  (zero where 2*th+ph or 2*tw+pw exceeds 2)
 __global__ void s2_expand_kernel(const float* __restrict__ w, int Cin, int Cout, float* __restrict__ W4) {
@@ -672,6 +709,17 @@ extern "C" int asr_relu_mask(const float* dy, const asr_pixmap* ym, const float*
     const long npix = (long)ym->B * ym->H * ym->W;
     hipLaunchKernelGGL(relu_mask_kernel, dim3(pix_blocks(npix, ppb * 4)), dim3(256), 0, (hipStream_t)stream, dy, *ym, y, *om, dst, *dm);
     ASR_CHECK_LAUNCH("relu_mask");
+    return ASR_OK;
+}
+
+extern "C" int asr_maxpool_bwd(const float* dy, const float* y, int B, int H, int W, int C, float* dx, void* stream) {
+    if (!dy || !y || !dx || B < 1 || H < 2 || W < 2 || (H & 1) || (W & 1) || C < 4 || (C & 3)) return ASR_ERR_BAD_ARG;
+    const long total = (long)B * (H / 2) * (W / 2) * (C / 4);
+    if (total >= (1L << 31)) return ASR_ERR_UNSUPPORTED;
+    long nb = (total + 255) / 256;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, dy, y, B, H, W, C, dx);
+    ASR_CHECK_LAUNCH("maxpool_bwd");
     return ASR_OK;
 }
 

@@ -440,3 +440,8 @@ def pix_ln_bwd(dy, xhat, rstd, gamma, dx, dgamma, dbeta, ws):
     pd, m = pixmap(dy)
     check(_lib.load().asr_pix_ln_bwd(pd, pixmap(xhat)[0], _ptr(rstd), C.byref(m), _ptr(gamma), pixmap(dx)[0], _ptr(dgamma),
                                      _ptr(dbeta), _ptr(ws), _stream()), 'asr_pix_ln_bwd')
+
+
+def maxpool_bwd(dy, y, dx):
+    """dy: pooled-gradient Plane, y: the pooled tensor's input Plane, dx: Plane like y."""
+    check(_lib.load().asr_maxpool_bwd(dy.ptr, y.ptr, y.B, y.H, y.W, y.C, dx.ptr, _stream()), 'asr_maxpool_bwd')

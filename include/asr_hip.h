@@ -304,6 +304,11 @@ int asr_bn_bwd(const float* dy, const asr_pixmap* ym, const float* a, const asr_
 int asr_relu_mask(const float* dy, const asr_pixmap* ym, const float* y, const asr_pixmap* om, float* dst,
                   const asr_pixmap* dm, void* stream);
 
+/* Gradient of MaxPooling2D(2,2) on padded planes (Keras variant, lm_and_am/model/cnn_ctc.py:108-109,124-131):
+ * dy [B][H/2+1][W/2+1][C], y = the pooled tensor's input [B][H+1][W+1][C] -> dx (=, every interior pixel written);
+ * the first maximum of a window in row-major order takes the gradient. */
+int asr_maxpool_bwd(const float* dy, const float* y, int B, int H, int W, int C, float* dx, void* stream);
+
 /* HWIO [3][3][Cin][Cout] <-> the 2x2-tap weights [4][4*Cin][Cout] of the phase-split stride-2 conv */
 int asr_conv_s2_expand(const float* w, int Cin, int Cout, float* W4, void* stream);
 int asr_conv_s2_gather(const float* dW4, int Cin, int Cout, float* dw, void* stream);

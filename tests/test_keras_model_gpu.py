@@ -1,0 +1,75 @@
+"""Parity of the Keras-variant DFCNN engine (lm_and_am/model/cnn_ctc.py: two convs per cell, batch-statistics
+BatchNormalization, max-pooling, K.ctc_batch_cost) against oracle/keras_dfcnn.py: logits / loss within 1e-3,
+greedy ids exact, gradients within 1e-3 of their scale, plus the max-pool backward kernel on its own."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import keras_dfcnn as ok
+
+pytestmark = pytest.mark.gpu
+
+
+def test_maxpool_bwd_routes_to_first_maximum():
+    from asr_dfcnn_transformer_amd import ops
+    rng = np.random.default_rng(0)
+    B, H, W, C = 2, 6, 8, 8
+    y = rng.standard_normal((B, H, W, C)).astype(np.float32)
+    y[0, 0:2, 0:2, :] = 0.5                               # a window of ties: the first element takes the gradient
+    dy = rng.standard_normal((B, H // 2, W // 2, C)).astype(np.float32)
+    yp, dyp, dxp = ops.Plane(B, H, W, C), ops.Plane(B, H // 2, W // 2, C), ops.Plane(B, H, W, C)
+    yp.set_interior(torch.tensor(y, device='cuda')); dyp.set_interior(torch.tensor(dy, device='cuda'))
+    ops.maxpool_bwd(dyp, yp, dxp)
+    win = y.reshape(B, H // 2, 2, W // 2, 2, C).transpose(0, 1, 3, 5, 2, 4).reshape(B, H // 2, W // 2, C, 4)
+    arg = win.argmax(axis=-1)                             # first occurrence, row-major (0,0),(0,1),(1,0),(1,1)
+    ref = np.zeros((B, H // 2, W // 2, C, 4), np.float32)
+    np.put_along_axis(ref, arg[..., None], dy[..., None], axis=-1)
+    ref = ref.reshape(B, H // 2, W // 2, C, 2, 2).transpose(0, 1, 4, 2, 5, 3).reshape(B, H, W, C)
+    assert np.array_equal(dxp.interior().cpu().numpy(), ref)
+    assert ref[0, 0, 0, 0] == dy[0, 0, 0, 0] and ref[0, 0, 1, 0] == 0
+
+
+@pytest.mark.parametrize("B,T", [(2, 32), (3, 64)])
+def test_keras_dfcnn_step_matches_oracle(B, T):
+    from asr_dfcnn_transformer_amd.keras_engine import KerasDFCNNEngine
+    rng = np.random.default_rng(1)
+    F, V, hidden = 16, 12, 16
+    cells = [(8, True), (16, True), (32, True), (32, False), (32, False)]
+    P = {k: np.asarray(v, np.float32).astype(np.float64) for k, v in ok.init_params(V, F, cells, hidden, seed=2).items()}
+    x = rng.standard_normal((B, T, F)).astype(np.float32)
+    T8 = T // 8
+    labels = np.zeros((B, 8), dtype=np.int64)
+    ll, il = [], []
+    for b in range(B):
+        n = 1 + b % 2
+        labels[b, :n] = rng.integers(1, V - 1, n)
+        ll.append(n); il.append(T8 if b % 2 == 0 else T8 - 1)
+    ref = ok.train_step(P, x.astype(np.float64), labels, ll, il, cells)
+    eng = KerasDFCNNEngine(vocab=V, B=B, T=T, F=F, cells=cells, hidden=hidden)
+    eng.load_params(P)
+    logits = eng.forward(torch.tensor(x, device='cuda'))
+    eng.set_targets(il, labels, ll)
+    eng.loss_and_decode()
+    eng.backward()
+    torch.cuda.synchronize()
+    err = np.abs(logits.cpu().numpy() - ref['logits']).max()
+    print('logits err %.3e' % err)
+    assert err < 1e-3
+    assert np.abs(eng.loss.cpu().numpy() - ref['loss']).max() < 1e-3
+    assert abs(eng.fetch_loss() - ref['mean_loss']) < 1e-3
+    assert eng.decoded_lists() == [list(d) for d in ref['decoded']]
+    G, worst = eng.grads_dict(), 0.0
+    for k, want in ref['grads'].items():
+        scale = np.abs(want).max()
+        e = np.abs(G[k] - want).max()
+        if scale < 1e-9:
+            assert e < 5e-4, (k, e)
+            continue
+        worst = max(worst, e / scale)
+        assert e <= 1e-3 * scale, (k, e / scale)
+    print('worst grad rel err %.3e' % worst)
+    g1 = eng.grad.clone()
+    eng.forward(torch.tensor(x, device='cuda')); eng.loss_and_decode(); eng.backward()
+    assert torch.equal(g1, eng.grad)                      # bitwise reproducible
+    eng.apply_adam()
+    assert eng.global_step == 1
