@@ -11,6 +11,7 @@ Buffers follow DESIGN.md 2: padded planes [B][H+1][W+1][C] for everything a 3x3 
 "phase split" plane for the input of the 64->64 stride-2 conv, [B][T'][64][80] for the attention operands.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -96,6 +97,14 @@ class PreNetEngine:
                  ops.bn_workspace(self.a1), ops.bn_workspace(self.x2), ops.pix_ln_bwd_workspace(self.x2),
                  ops.prenet_conv1_bwd_workspace(B, T, F), ops.colsum_workspace(NP, CH), 4 * (B * CH * H2 + 64), 1 << 20])
         self.ws = z(ws // 4 + 64)
+        # Second stream for the backward pass (ASR_DUAL_STREAM=0 turns it off; see engine.py): the weight- and bias-gradient
+        # of a conv run on it while the main stream goes on with the data-gradient and the next (HBM-bound) BatchNorm /
+        # transpose / LayerNorm backward.  The pre-activation gradient planes alternate between two buffers.
+        self.side = torch.cuda.Stream(device=device) if os.environ.get('ASR_DUAL_STREAM', '1') == '1' else None
+        self.ws_side = z(ws // 4 + 64) if self.side is not None else None
+        self.dz_alt = pl() if self.side is not None else None
+        self._busy = {}            # id(plane) -> event of the last side-stream reader
+        self._flip = False
 
     # ---- parameters
     def p(self, name, buf=None):
@@ -137,18 +146,52 @@ class PreNetEngine:
         ops.bn_stats(src, BN_EPS, mean, rstd, self.ws)
         ops.bn_apply(src, mean, rstd, self.p(name + '/g'), self.p(name + '/b'), dst, **kw)
 
+    def _next_dz(self):
+        """The pre-activation gradient plane for the next conv: alternates when the side stream is on."""
+        if self.side is None:
+            return self.dz
+        self._flip = not self._flip
+        return self.dz_alt if self._flip else self.dz
+
+    def _wait_readers(self, plane):
+        ev = self._busy.pop(id(plane), None)
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+
     def _bn_bwd(self, name, dy, a, act, dz, **kw):
         mean, rstd = self.stats[name]
+        if isinstance(dz, Plane):
+            self._wait_readers(dz)                  # an earlier weight-gradient may still read this plane
         ops.bn_bwd(dy, a, mean, rstd, self.p(name + '/g'), act, dz, self.g(name + '/g'), self.g(name + '/b'), self.ws, **kw)
+
+    def _on_side(self, reads, fn):
+        """Run fn(workspace) on the side stream once the main stream's work so far is done; `reads` = planes it reads that
+        the main stream will overwrite later."""
+        if self.side is None:
+            fn(self.ws)
+            return
+        ready = torch.cuda.Event()
+        ready.record()
+        self.side.wait_event(ready)
+        with torch.cuda.stream(self.side):
+            fn(self.ws_side)
+            done = torch.cuda.Event()
+            done.record()
+        for p in reads:
+            self._busy[id(p)] = done
+        self._last_side = done
 
     def _conv(self, name, src, dst):
         ops.tap_gemm(self.d_conv[name], src, self.p(name + '/w'), self.p(name + '/b'), None, None, dst, None)
 
     def _conv_bwd(self, name, src, dz, dx, accumulate):
         """parameter gradients of conv `name` (input plane src, pre-activation gradient dz) and dx (+)= its data gradient"""
-        ops.tap_wgrad(self.d_dw[name], src, dz, CH, self.g(name + '/w'), self.ws)
-        ops.colsum(dz.body, dz.NP, CH, CH, self.g(name + '/b'), self.ws)
+        def grads(ws):
+            ops.tap_wgrad(self.d_dw[name], src, dz, CH, self.g(name + '/w'), ws)
+            ops.colsum(dz.body, dz.NP, CH, CH, self.g(name + '/b'), ws)
+        self._on_side([dz], grads)
         if dx is not None:
+            self._wait_readers(dx)                  # dx may be a plane an earlier weight-gradient still reads (ds)
             d = self.d_dx[name]
             d.accumulate = 1 if accumulate else 0
             ops.tap_gemm(d, dz, self.p(name + '/w'), None, None, None, None, dx)
@@ -185,10 +228,13 @@ class PreNetEngine:
         B, H2, W2 = self.B, self.H2, self.W2
         d_pre = d_pre.view(B, H2, W2, CH)
         ops.relu_mask(d_pre, self.pre_out, self.dsum)                       # d(f2n) = d(out) so far
-        self._bn_bwd('bnf2', self.dsum, self.zf2, 0, self.dz)
-        self._conv_bwd('f2', self.f1n, self.dz, self.dA, False)             # dA = d(f1n)
-        self._bn_bwd('bnf1', self.dA, self.af1, 1, self.dz)
-        self._conv_bwd('f1', self.out, self.dz, self.dsum, True)            # dsum = d(out)
+        dz = self._next_dz()
+        self._bn_bwd('bnf2', self.dsum, self.zf2, 0, dz)
+        self._conv_bwd('f2', self.f1n, dz, self.dA, False)                  # dA = d(f1n)
+        dz = self._next_dz()
+        self._bn_bwd('bnf1', self.dA, self.af1, 1, dz)
+        self._conv_bwd('f1', self.out, dz, self.dsum, True)                 # dsum = d(out)
+        self._wait_readers(self.ds)
         ops.pix_ln_bwd(self.dsum, self.xhat, self.ln_rstd, self.p('ln/g'), self.ds, self.g('ln/g'), self.g('ln/b'), self.ws)
         # ds = d(merge conv output) = the residual's share of d(x2); later contributions accumulate into it
         self._conv_bwd('merge', self.cat, self.ds, self.dcat, False)
@@ -200,15 +246,23 @@ class PreNetEngine:
         ops.freq_attention_bwd(self.QT, self.KT, self.VT, self.P, self.dOF, B, H2, dq2, dk2, dv2, self.dS)
         for k, g1, g2 in (('q', dq1, dq2), ('k', dk1, dk2), ('v', dv1, dv2)):
             ops.T_to_plane(g1, g2, self.dA, 0)                              # d(normalised q/k/v)
-            self._bn_bwd('bn' + k, self.dA, self.z[k], 0, self.dz)
-            self._conv_bwd(k, self.x2, self.dz, self.ds, True)              # ds = d(x2)
-        self._bn_bwd('bn2', self.ds, self.a2, 2, self.dz)
-        ops.tap_wgrad(self.d_c2_dw, self.x1s, self.dz, CH, self.dW4, self.ws)
-        ops.conv_s2_gather(self.dW4, CH, CH, self.g('conv2/w'))
-        ops.colsum(self.dz.body, self.dz.NP, CH, CH, self.g('conv2/b'), self.ws)
-        ops.tap_gemm(self.d_c2_dx, self.dz, self.W4, None, None, None, None, self.dx1s)
+            dz = self._next_dz()
+            self._bn_bwd('bn' + k, self.dA, self.z[k], 0, dz)
+            self._conv_bwd(k, self.x2, dz, self.ds, True)                   # ds = d(x2)
+        dz = self._next_dz()
+        self._bn_bwd('bn2', self.ds, self.a2, 2, dz)
+
+        def grads2(ws):
+            ops.tap_wgrad(self.d_c2_dw, self.x1s, dz, CH, self.dW4, ws)
+            ops.conv_s2_gather(self.dW4, CH, CH, self.g('conv2/w'))
+            ops.colsum(dz.body, dz.NP, CH, CH, self.g('conv2/b'), ws)
+        self._on_side([dz], grads2)
+        ops.tap_gemm(self.d_c2_dx, dz, self.W4, None, None, None, None, self.dx1s)
         self._bn_bwd('bn1', self.dx1s, self.a1, 2, self.dz1, dy_phase_split=True)
         ops.prenet_conv1_bwd(self.x, self.dz1, self.g('conv1/w'), self.g('conv1/b'), self.ws)
+        if self.side is not None and getattr(self, '_last_side', None) is not None:
+            torch.cuda.current_stream().wait_event(self._last_side)        # all gradients are in self.grad for Adam / all-reduce
+            self._busy.clear()
 
     def apply_adam(self, lr, gscale=1.0):
         t = self.global_step + 1
