@@ -149,7 +149,8 @@ def run_transformer(args):
             torch.cuda.synchronize(); ops.TIMER = ops.KernelTimer()
         step()
     torch.cuda.synchronize(); table = ops.TIMER.summary(); ops.TIMER = None
-    overlapped = eng.side is not None         # weight-gradients on a second stream: price a kernel that runs alone (forward)
+    # weight-gradients on a second stream: price a kernel that runs alone (forward)
+    overlapped = eng.side is not None or (prenet and pre.side is not None)
     dom = max([k for k in table if not overlapped or is_forward_symbol(k)], key=lambda k: table[k]['total_ms'])
     ops.TIMER = ops.KernelTimer(only={dom})
     if world > 1:
