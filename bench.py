@@ -270,10 +270,12 @@ def main():
             feat = feats[0]
             fb.batch(signal, nsamp, T, out=feat)
         eng.forward(feat)
+        if prefetch:
+            # after the conv stack: the latency-bound fbank fills the chip while the (equally latency-bound) CTC lattice /
+            # decode / small head GEMMs run, and the forward contractions keep the chip to themselves
+            produce(cur ^ 1)
         eng.set_targets(seq, target)
         eng.loss_and_decode(defer_decode_join=True)
-        if prefetch:
-            produce(cur ^ 1)          # beside the backward pass: the forward contractions keep the chip to themselves
         if world > 1:
             eng.backward(on_dense_grads_ready=lambda: red.launch(0))
             red.launch(1); red.launch(2)
