@@ -570,6 +570,100 @@ __global__ __launch_bounds__(256) void smoothed_ce_kernel(const float* __restric
     }
 }
 
+// Same arithmetic with the whole row held in registers (TWO waves per row, NV float4 per lane): one HBM read of the
+// logits and one write of the gradient instead of three passes of 4-byte loads.  One wave per row needs 26 float4 per
+// lane at V = 6348, which leaves one wave per SIMD (256 VGPRs) and is slower than the loop version.
+// Rows up to 128 * 4 * NV columns; the loop version above serves wider vocabularies.
+template <int NV>
+__global__ __launch_bounds__(256) void smoothed_ce_reg_kernel(const float* __restrict__ logits, int ld, const int32_t* __restrict__ target,
+                                                              int rows, int V, float eps, int pad_id, float inv_count,
+                                                              float* __restrict__ loss_rows, int32_t* __restrict__ preds,
+                                                              float* __restrict__ stats, float* __restrict__ dlogits) {
+    __shared__ float sh_m[4], sh_sx[4], sh_se[4];
+    __shared__ int sh_am[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = wave & 1;
+    const int row = blockIdx.x * 2 + (wave >> 1);
+    const bool active = row < rows;
+    const float* x = logits + (long)(active ? row : 0) * ld;
+    const int tg = active ? target[row] : 0;
+    const int n4 = ld >> 2;
+    float4 v[NV];
+    float m = -INFINITY; int am = 0x7fffffff;
+    float sumx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int q = half * 64 + lane + i * 128;
+        v[i] = (active && q < n4) ? *(const float4*)(x + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = q * 4 + j;
+            if (k < V) {
+                sumx += e[j];
+                if (e[j] > m || am == 0x7fffffff) { m = e[j]; am = k; }      // k ascends within a lane: first maximum kept
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(m, o, 64);
+        const int ok = __shfl_xor(am, o, 64);
+        if (ov > m || (ov == m && ok < am)) { m = ov; am = ok; }
+    }
+    sumx = asr_wave_sum(sumx);
+    if (lane == 0) { sh_m[wave] = m; sh_am[wave] = am; sh_sx[wave] = sumx; }
+    __syncthreads();
+    {
+        const float om = sh_m[wave ^ 1]; const int oa = sh_am[wave ^ 1];
+        if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+        sumx = sh_sx[wave & ~1] + sh_sx[wave | 1];
+    }
+    float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k0 = (half * 64 + lane + i * 128) * 4;
+        // keep exp(x - max) in place of x: the gradient needs it again
+        v[i].x = (k0 + 0 < V) ? expf(v[i].x - m) : 0.f; v[i].y = (k0 + 1 < V) ? expf(v[i].y - m) : 0.f;
+        v[i].z = (k0 + 2 < V) ? expf(v[i].z - m) : 0.f; v[i].w = (k0 + 3 < V) ? expf(v[i].w - m) : 0.f;
+        se += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    se = asr_wave_sum(se);
+    if (lane == 0) sh_se[wave] = se;
+    __syncthreads();
+    se = sh_se[wave & ~1] + sh_se[wave | 1];
+    if (!active) return;
+    const float lse = m + logf(se);
+    const bool valid = tg >= 0 && tg < V;
+    const float ysum = (valid ? (1.f - eps) : 0.f) + eps;
+    const float xt = valid ? x[tg] : 0.f;
+    const float loss = ysum * lse - (valid ? (1.f - eps) * xt : 0.f) - (eps / (float)V) * sumx;
+    const float ist = (tg != pad_id) ? 1.f : 0.f;
+    if (lane == 0 && half == 0) {
+        loss_rows[row] = loss;
+        preds[row] = am;
+        stats[(long)row * 2] = loss * ist;
+        stats[(long)row * 2 + 1] = (am == tg) ? ist : 0.f;
+    }
+    if (dlogits) {
+        const float w = ist * inv_count;
+        const float pscale = ysum / se;                 // ysum * exp(x - lse) = ysum * exp(x - m) / se
+        const float ys0 = eps / (float)V;
+        float* d = dlogits + (long)row * ld;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int q = half * 64 + lane + i * 128;
+            if (q >= n4) continue;
+            const int k0 = q * 4;
+            float4 g;
+            g.x = (k0 + 0 < V) ? (pscale * v[i].x - ys0 - ((valid && k0 + 0 == tg) ? (1.f - eps) : 0.f)) * w : 0.f;
+            g.y = (k0 + 1 < V) ? (pscale * v[i].y - ys0 - ((valid && k0 + 1 == tg) ? (1.f - eps) : 0.f)) * w : 0.f;
+            g.z = (k0 + 2 < V) ? (pscale * v[i].z - ys0 - ((valid && k0 + 2 == tg) ? (1.f - eps) : 0.f)) * w : 0.f;
+            g.w = (k0 + 3 < V) ? (pscale * v[i].w - ys0 - ((valid && k0 + 3 == tg) ? (1.f - eps) : 0.f)) * w : 0.f;
+            *(float4*)(d + k0) = g;
+        }
+    }
+}
+
 inline int grid_for(long total, int threads) {
     long b = (total + threads - 1) / threads;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -658,7 +752,13 @@ extern "C" int asr_embed_bwd(const float* dout, const int32_t* perm, const int32
 extern "C" int asr_smoothed_ce(const float* logits, int ld, const int32_t* target, int rows, int V, float eps, int pad_id,
                                float inv_count, float* loss_rows, int32_t* preds, float* stats, float* dlogits, void* stream) {
     if (!logits || !target || !loss_rows || !preds || !stats || rows < 1 || V < 1 || ld < V) return ASR_ERR_BAD_ARG;
-    hipLaunchKernelGGL(smoothed_ce_kernel, dim3(asr_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, rows, V, eps, pad_id, inv_count, loss_rows, preds, stats, dlogits);
+    const bool aligned = (ld & 3) == 0 && (((uintptr_t)logits | (uintptr_t)dlogits) & 15) == 0;
+    if (aligned && ld <= 128 * 4 * 4)
+        hipLaunchKernelGGL(smoothed_ce_reg_kernel<4>, dim3(asr_cdiv(rows, 2)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, rows, V, eps, pad_id, inv_count, loss_rows, preds, stats, dlogits);
+    else if (aligned && ld <= 128 * 4 * 13)
+        hipLaunchKernelGGL(smoothed_ce_reg_kernel<13>, dim3(asr_cdiv(rows, 2)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, rows, V, eps, pad_id, inv_count, loss_rows, preds, stats, dlogits);
+    else
+        hipLaunchKernelGGL(smoothed_ce_kernel, dim3(asr_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, logits, ld, target, rows, V, eps, pad_id, inv_count, loss_rows, preds, stats, dlogits);
     ASR_CHECK_LAUNCH("smoothed_ce");
     return ASR_OK;
 }

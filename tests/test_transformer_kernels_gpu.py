@@ -112,7 +112,7 @@ def test_embedding_fwd_bwd(ops):
     report('embed bwd', g.cpu().numpy(), gref, 2e-6)
 
 
-@pytest.mark.parametrize("rows,V", [(12, 13), (64, 6345), (7, 6347)])
+@pytest.mark.parametrize("rows,V", [(12, 13), (64, 6345), (7, 6347), (5, 7001)])     # 7001: wider than the register kernel
 def test_smoothed_ce(ops, rows, V):
     rng = np.random.default_rng(3)
     ld = (V + 3) // 4 * 4
