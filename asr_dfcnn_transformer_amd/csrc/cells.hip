@@ -433,6 +433,14 @@ __global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __res
         dz[i] = h[i] > 0.f ? dy[i] : 0.f;
 }
 
+// 16-byte version (n4 = n / 4 float4 elements, 16-byte aligned pointers)
+__global__ void relu_bwd4_kernel(const float* __restrict__ dy, const float* __restrict__ h, size_t n4, float* __restrict__ dz) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 d = ld4(dy + i * 4), a = ld4(h + i * 4);
+        st4(dz + i * 4, make_float4(a.x > 0.f ? d.x : 0.f, a.y > 0.f ? d.y : 0.f, a.z > 0.f ? d.z : 0.f, a.w > 0.f ? d.w : 0.f));
+    }
+}
+
 inline bool chan_ok(int C) { return C >= 4 && (C & 3) == 0 && (256 % (C / 4)) == 0 && C <= 1024; }
 inline int grid_for(long total, int threads) {
     long b = (total + threads - 1) / threads;
@@ -615,7 +623,13 @@ extern "C" int asr_axpy(float* dst, const float* src, size_t n, float alpha, int
 extern "C" int asr_relu_bwd(const float* dy, const float* h, size_t n, float* dz, void* stream) {
     if (!dy || !h || !dz) return ASR_ERR_BAD_ARG;
     if (n == 0) return ASR_OK;
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for((long)n, 256)), dim3(256), 0, (hipStream_t)stream, dy, h, n, dz);
+    if ((n & 3) == 0 && ((((uintptr_t)dy | (uintptr_t)h | (uintptr_t)dz)) & 15) == 0) {
+        long b = (long)((n / 4 + 255) / 256);
+        if (b > 16384) b = 16384;
+        hipLaunchKernelGGL(relu_bwd4_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, dy, h, n / 4, dz);
+    } else {
+        hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for((long)n, 256)), dim3(256), 0, (hipStream_t)stream, dy, h, n, dz);
+    }
     ASR_CHECK_LAUNCH("relu_bwd");
     return ASR_OK;
 }

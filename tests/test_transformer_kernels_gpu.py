@@ -66,7 +66,7 @@ def test_attention_fwd_bwd(ops, N, Tq, Tk, H, causal):
     report('attention dV (pre-relu)', gv.cpu().numpy(), gv_ref * (V > 0), 3e-5)
 
 
-@pytest.mark.parametrize("rows,C,with_b", [(10, 512, True), (300, 64, False), (77, 2048, True)])
+@pytest.mark.parametrize("rows,C,with_b", [(10, 512, True), (300, 64, False), (77, 2048, True), (5, 1030, True)])   # 1030: scalar kernels
 def test_add_layernorm(ops, rows, C, with_b):
     rng = np.random.default_rng(1)
     a = rng.standard_normal((rows, C)).astype(np.float32)
