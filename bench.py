@@ -359,7 +359,8 @@ def main():
             out['roofline']['note'] = ('backward runs on two streams (weight-gradient beside data-gradient + next prologue), so '
                                        'backward kernel durations overlap; this is the dominant contraction that runs alone '
                                        '(forward).  ASR_DUAL_STREAM=0 gives the single-stream step and per-kernel numbers.')
-        tr, src = pmc_traffic(args.workload, dom)
+        # the committed PMC pass was taken on the default configuration only
+        tr, src = pmc_traffic(args.workload, dom) if (args.tpad == 1600 and args.batch == 32) else (None, None)
         out['roofline']['traffic'] = tr
         if src:
             out['roofline']['traffic_unit'] = 'bytes/launch (PMC pass: %s)' % src
