@@ -25,6 +25,16 @@ constexpr int KP = DH + 4;                      // LDS pitch of tiles read with 
 
 __device__ __forceinline__ int rowidx(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
+// Counter-based dropout mask (tf.layers.dropout, transformer.py:111,154,226; model.py:290): element `idx` of the tensor
+// drawn for `seed` is kept when the top 24 bits of a murmur3-finalised hash reach the threshold rate * 2^24; kept values
+// are scaled by 1 / (1 - rate).  The same function regenerates the mask in the backward pass (nothing is stored) and
+// in oracle/transformer.py.  TensorFlow's own random stream cannot be reproduced; parity is against this generator.
+__device__ __forceinline__ bool drop_keep(uint32_t idx, uint32_t seed, uint32_t thr) {
+    uint32_t h = idx * 0x9E3779B1u + seed;
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return (h >> 8) >= thr;
+}
+
 // stage a [rows x 64] head slice of X[n][t][C] into LDS with pitch KP; rows beyond T are zero.
 // 16 consecutive lanes own one row, so a 16-lane xor-reduction gives per-row statistics.
 __device__ __forceinline__ void stage_tile(float* dst, const float* __restrict__ X, long base_row, int row0, int nrows,
@@ -86,10 +96,11 @@ __device__ __forceinline__ void attn_block_coords(int H, bool longest_is_last, i
 }
 
 // ------------------------------------------------------------------ attention forward
-template <bool CAUSAL>
+template <bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                        const float* __restrict__ V, float* __restrict__ O,
-                                                       float* __restrict__ lse, int Tq, int Tk, int C, int H) {
+                                                       float* __restrict__ lse, int Tq, int Tk, int C, int H,
+                                                       uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
     __shared__ __attribute__((aligned(16))) float kv_lds[2 * 64 * KP];   // also the epilogue's transpose scratch
     float* Ks = kv_lds;
     float* Vs = kv_lds + 64 * KP;
@@ -170,6 +181,11 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const flo
             m_run = m_new;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+            if (DROP) {            // dropout of the attention weights (transformer.py:111): after the row sum, before P.V
+                const uint32_t base = (uint32_t)(((n * H + head) * Tq + q) * Tk + k0 + sub * 32);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = drop_keep(base + rowidx(r, lh), drop_seed, drop_thr) ? s[r] * drop_scale : 0.f;
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float* vrow = Vs + (sub * 32 + rowidx(r, lh)) * KP + li;
@@ -212,12 +228,13 @@ __global__ void attn_delta_kernel(const float* __restrict__ O, const float* __re
 
 // ------------------------------------------------------------------ attention backward: dK, dV
 // One wave owns 32 keys (K, V in registers); the block walks the queries in tiles of 64.
-template <bool CAUSAL>
+template <bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                           const float* __restrict__ V, const float* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           float* __restrict__ dK, float* __restrict__ dV,
-                                                          int Tq, int Tk, int C, int H, int relu_grad) {
+                                                          int Tq, int Tk, int C, int H, int relu_grad,
+                                                          uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
     constexpr int QT = 64;                       // queries staged per barrier round (two 32-row MFMA sub-tiles)
     __shared__ __attribute__((aligned(16))) float Qs[QT * KP];
     __shared__ __attribute__((aligned(16))) float Ds[QT * KP];
@@ -308,8 +325,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
                 const bool keep = kkeep && (!CAUSAL || key <= q);
                 const float sv = keep ? s[r] * 0.125f : MASK_FILL;
                 const float p = (key < Tk) ? expf((sv - lse_t[ql]) - lsl_t[ql]) : 0.f;
-                const float ds = keep ? p * (dp[r] - del_t[ql]) * 0.125f : 0.f;
-                s[r] = p; dp[r] = ds;
+                float pd = p, dpe = dp[r];
+                if (DROP) {        // O = (P o M / (1-rate)) V: dV sees the dropped weights, dP arrives through the same mask
+                    const bool dm = drop_keep((uint32_t)(((n * H + head) * Tq + q) * Tk + key), drop_seed, drop_thr);
+                    pd = dm ? p * drop_scale : 0.f;
+                    dpe = dm ? dpe * drop_scale : 0.f;
+                }
+                const float ds = keep ? p * (dpe - del_t[ql]) * 0.125f : 0.f;
+                s[r] = pd; dp[r] = ds;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -327,11 +350,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------ attention backward: dQ
-template <bool CAUSAL>
+template <bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                          const float* __restrict__ V, const float* __restrict__ dO,
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                         float* __restrict__ dQ, int Tq, int Tk, int C, int H, int relu_grad) {
+                                                         float* __restrict__ dQ, int Tq, int Tk, int C, int H, int relu_grad,
+                                                         uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
     __shared__ __attribute__((aligned(16))) float kv_lds[2 * 64 * KP];   // also the epilogue's transpose scratch
     float* Ks = kv_lds;
     float* Vs = kv_lds + 64 * KP;
@@ -400,7 +424,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
                 const bool keep = (kstat[kl] != 0.f) && (!CAUSAL || key <= q);
                 const float sv = keep ? s[r] : MASK_FILL;
                 const float p = (key < Tk) ? expf((sv - my_lse) - my_lsl) : 0.f;
-                dp[r] = keep ? p * (dp[r] - my_del) * 0.125f : 0.f;
+                float dpe = dp[r];
+                if (DROP) dpe = drop_keep((uint32_t)(((n * H + head) * Tq + q) * Tk + key), drop_seed, drop_thr) ? dpe * drop_scale : 0.f;
+                dp[r] = keep ? p * (dpe - my_del) * 0.125f : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -772,6 +798,12 @@ __global__ __launch_bounds__(256) void smoothed_ce_reg_kernel(const float* __res
     }
 }
 
+// y[i] = keep(i) ? x[i] / (1 - rate) : 0   (in place allowed; applied to a gradient with the same seed it is the backward)
+__global__ void dropout_kernel(const float* __restrict__ x, size_t n, uint32_t thr, uint32_t seed, float scale, float* __restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = drop_keep((uint32_t)i, seed, thr) ? x[i] * scale : 0.f;
+}
+
 inline int grid_for(long total, int threads) {
     long b = (total + threads - 1) / threads;
     return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -780,35 +812,71 @@ inline int grid_for(long total, int threads) {
 }  // namespace
 
 // ===================================================================== C ABI
+static inline uint32_t drop_threshold(float rate) {
+    double t = (double)rate * 16777216.0;
+    if (t < 0) t = 0;
+    if (t > 16777215.0) t = 16777215.0;
+    return (uint32_t)(t + 0.5);
+}
+
 extern "C" int asr_attention_fwd(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
-                                 int causal, float* O, float* lse, void* stream) {
+                                 int causal, float dropout_rate, unsigned int seed, float* O, float* lse, void* stream) {
     if (!Q || !K || !V || !O || !lse || N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
+    if (dropout_rate < 0.f || dropout_rate >= 1.f || (double)N * H * Tq * Tk >= 4294967296.0) return ASR_ERR_BAD_ARG;
     dim3 grid(asr_cdiv(Tq, 128), H, N), grid_causal(N * H, asr_cdiv(Tq, 128), 1);      // see attn_block_coords
     hipStream_t st = (hipStream_t)stream;
-    if (causal) hipLaunchKernelGGL(attn_fwd_kernel<true>, grid_causal, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H);
-    else hipLaunchKernelGGL(attn_fwd_kernel<false>, grid, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H);
+    const uint32_t thr = drop_threshold(dropout_rate);
+    const float sc = 1.0f / (1.0f - dropout_rate);
+    if (dropout_rate > 0.f) {
+        if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid_causal, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, thr, seed, sc);
+        else hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, thr, seed, sc);
+    } else {
+        if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid_causal, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, thr, seed, sc);
+        else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, thr, seed, sc);
+    }
     ASR_CHECK_LAUNCH("attention_fwd");
     return ASR_OK;
 }
 
 extern "C" int asr_attention_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO,
                                  const float* lse, int N, int Tq, int Tk, int C, int H, int causal, int relu_grad,
+                                 float dropout_rate, unsigned int seed,
                                  float* dQ, float* dK, float* dV, float* delta_ws, void* stream) {
     if (!Q || !K || !V || !O || !dO || !lse || !dQ || !dK || !dV || !delta_ws) return ASR_ERR_BAD_ARG;
     if (N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
+    if (dropout_rate < 0.f || dropout_rate >= 1.f || (double)N * H * Tq * Tk >= 4294967296.0) return ASR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const long groups = (long)N * Tq * H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(asr_cdiv(groups * 16, 256)), dim3(256), 0, st, O, dO, delta_ws, N, Tq, C, H);
     dim3 gkv(asr_cdiv(Tk, 128), H, N), gq(asr_cdiv(Tq, 128), H, N);
-    if (causal) {
-        dim3 ckv(N * H, asr_cdiv(Tk, 128), 1), cq(N * H, asr_cdiv(Tq, 128), 1);
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<true>, ckv, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dK, dV, Tq, Tk, C, H, relu_grad);
-        hipLaunchKernelGGL(attn_bwd_q_kernel<true>, cq, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dQ, Tq, Tk, C, H, relu_grad);
+    dim3 ckv(N * H, asr_cdiv(Tk, 128), 1), cq(N * H, asr_cdiv(Tq, 128), 1);
+    const float* dl = (const float*)delta_ws;
+    const uint32_t thr = drop_threshold(dropout_rate);
+    const float sc = 1.0f / (1.0f - dropout_rate);
+#define ASR_ATTN_BWD(CA, DR, GKV, GQ)                                                                                          \
+    do {                                                                                                                       \
+        hipLaunchKernelGGL((attn_bwd_kv_kernel<CA, DR>), GKV, dim3(256), 0, st, Q, K, V, dO, lse, dl, dK, dV, Tq, Tk, C, H,    \
+                           relu_grad, thr, seed, sc);                                                                          \
+        hipLaunchKernelGGL((attn_bwd_q_kernel<CA, DR>), GQ, dim3(256), 0, st, Q, K, V, dO, lse, dl, dQ, Tq, Tk, C, H,           \
+                           relu_grad, thr, seed, sc);                                                                          \
+    } while (0)
+    if (dropout_rate > 0.f) {
+        if (causal) ASR_ATTN_BWD(true, true, ckv, cq); else ASR_ATTN_BWD(false, true, gkv, gq);
     } else {
-        hipLaunchKernelGGL(attn_bwd_kv_kernel<false>, gkv, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dK, dV, Tq, Tk, C, H, relu_grad);
-        hipLaunchKernelGGL(attn_bwd_q_kernel<false>, gq, dim3(256), 0, st, Q, K, V, dO, lse, (const float*)delta_ws, dQ, Tq, Tk, C, H, relu_grad);
+        if (causal) ASR_ATTN_BWD(true, false, ckv, cq); else ASR_ATTN_BWD(false, false, gkv, gq);
     }
+#undef ASR_ATTN_BWD
     ASR_CHECK_LAUNCH("attention_bwd");
+    return ASR_OK;
+}
+
+extern "C" int asr_dropout(const float* x, size_t n, float rate, unsigned int seed, float* y, void* stream) {
+    if (!x || !y || n == 0 || rate < 0.f || rate >= 1.f || n >= 4294967296ull) return ASR_ERR_BAD_ARG;
+    long b = (long)((n + 255) / 256);
+    if (b > 16384) b = 16384;
+    hipLaunchKernelGGL(dropout_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, x, n, drop_threshold(rate), (uint32_t)seed,
+                       1.0f / (1.0f - rate), y);
+    ASR_CHECK_LAUNCH("dropout");
     return ASR_OK;
 }
 

@@ -53,7 +53,8 @@ class Transformer_Model:
         new = E2EEngine(din=self.input_dim, vout=self.label_vocab_size, N=self.batch_size, T=T, L=L, C=self.hidden_units,
                         heads=self.num_heads, blocks=self.num_blocks, pos_max=self.position_max_length, tie=self.tie,
                         lr=lr, decay_steps=self.dacay_step, min_lr=self.min_learning_rate, seed=self.seed, device=self.device,
-                        need_dx=need_dx)
+                        need_dx=need_dx,
+                        dropout_rate=self.arg.dropout_rate if getattr(self.arg, 'is_training', True) else 0.0, drop_seed=self.seed)
         if e is not None:
             new.theta.copy_(e.theta); new.adam_m.copy_(e.adam_m); new.adam_v.copy_(e.adam_v)
             new.global_step = e.global_step

@@ -8,7 +8,8 @@ dense(vocab, softmax), K.ctc_batch_cost, Keras Adam(beta_2 0.999, epsilon 1e-7).
 Kernels: 9-tap tap_gemm / tap_wgrad for every conv (the first one reads a 4-channel plane whose channels 1..3 are
 zero: K must be a multiple of 4), bn_stats / bn_apply / bn_bwd of the pre-net (batch moments, ReLU derivative fused
 into the backward), pool_fwd + maxpool_bwd, the M1 head kernels for dense / log-softmax / CTC / greedy / edit
-distance.  Dropout(0.3) of the reference is stochastic under fit(); this engine has none (rate 0).
+distance.  Dropout(0.3) in front of both dense layers (cnn_ctc.py:38,40): `dropout_rate` > 0 applies the counter-based
+mask of asr_dropout (Keras' own random stream cannot be reproduced); 0 = identity, which the parity runs use.
 """
 import math
 
@@ -25,11 +26,13 @@ CELLS = [(32, True), (64, True), (128, True), (128, False), (128, False)]
 
 
 class KerasDFCNNEngine:
-    def __init__(self, vocab=1424, B=4, T=1600, F=200, cells=CELLS, hidden=128, lr=8e-4, seed=0, device='cuda'):
+    def __init__(self, vocab=1424, B=4, T=1600, F=200, cells=CELLS, hidden=128, lr=8e-4, seed=0, device='cuda',
+                 dropout_rate=0.0, drop_seed=0):
         npool = sum(1 for _, p in cells if p)
         assert T % (1 << npool) == 0 and F % (1 << npool) == 0
         self.V, self.B, self.T, self.F, self.cells, self.hidden, self.device = vocab, B, T, F, list(cells), hidden, device
         self.lr, self.beta1, self.beta2, self.adam_eps, self.global_step = lr, 0.9, 0.999, 1e-7, 0
+        self.dropout_rate, self.drop_seed = float(dropout_rate), int(drop_seed)
         # ---- parameters: name -> (offset, physical shape); conv 1 is stored with 4 input channels (3 dead)
         self.entries, self.logical, off = {}, {}, 0
 
@@ -151,9 +154,13 @@ class KerasDFCNNEngine:
         return self.grads_dict(self.theta)
 
     # ---- step
-    def forward(self, x):
+    def _seed(self, site):
+        return (self.drop_seed + 1009 * self.global_step + 7919 * site) & 0xFFFFFFFF
+
+    def forward(self, x, train=True):
         """x: [B, T, F] float32 on the device -> time-major log(softmax + 1e-7) logits [T/8, B, vocab]."""
         assert tuple(x.shape) == (self.B, self.T, self.F)
+        self._rate = self.dropout_rate if train else 0.0
         self.x4.interior()[..., 0].copy_(x)
         src = self.x4
         for n, cp, cout, H, W, pool_after in self.convs:
@@ -166,7 +173,12 @@ class KerasDFCNNEngine:
                 ops.pool_fwd(self.y[n], self.ones[:cout], self.zeros[:cout], 2, self.yp[n])
                 src = self.yp[n]
         self.h6 = src.view(self.B * self.T8, self.din)
+        self._s6, self._s7 = self._seed(0), self._seed(1)
+        if self._rate > 0:
+            ops.dropout(self.h6, self._rate, self._s6)          # in place: the last BN output is only read again as dense input
         ops.tap_gemm(self.f1, self.h6, self.p('d1/w'), self.p('d1/b'), None, None, None, self.h7)
+        if self._rate > 0:
+            ops.dropout(self.h7, self._rate, self._s7)
         ops.tap_gemm(self.f2, self.h7, self.p('d2/w'), self.p('d2/b'), None, None, None, self.d)
         ops.softmax_log_fwd(self.d, self.B, self.T8, self.V, K_EPSILON, self.logits)
         return self.logits
@@ -200,9 +212,13 @@ class KerasDFCNNEngine:
         ops.colsum(self.dd, rows, V, V, self.g('d2/b'), self.ws)
         ops.tap_gemm(self.b2, self.dd, self.p('d2/w'), None, None, None, None, self.dh7)
         ops.relu_bwd(self.dh7, self.h7, self.dh7)
+        if self._rate > 0:
+            ops.dropout(self.dh7, self._rate, self._s7)
         ops.tap_wgrad(self.w1, self.h6, self.dh7, self.hidden, self.g('d1/w'), self.ws)
         ops.colsum(self.dh7, rows, self.hidden, self.hidden, self.g('d1/b'), self.ws)
         ops.tap_gemm(self.b1, self.dh7, self.p('d1/w'), None, None, None, None, self.dh6)
+        if self._rate > 0:
+            ops.dropout(self.dh6, self._rate, self._s6)
         dy = self.dh6.view(B, T8, self.W8, self.Clast)                    # d(last BN output), plain NHWC
         for idx in reversed(range(len(self.convs))):
             n, cp, cout, H, W, pool_after = self.convs[idx]

@@ -27,11 +27,12 @@ class Language_Model:
         self.num_heads, self.num_blocks = arg.num_heads, arg.num_blocks
         self.position_max_length = arg.position_max_length
         self.lm_lr, self.dacay_step, self.min_learning_rate = arg.lm_lr, arg.dacay_step, arg.min_learning_rate
-        self.dropout_rate = arg.dropout_rate            # parity mode: dropout is the identity here
+        self.dropout_rate = arg.dropout_rate            # language_model.py:19,34,46: active while is_training
         self.engine = LMEngine(vin=acoustic_vocab_size, vout=language_vocab_size, N=batch_size or arg.lm_batch_size,
                                T=self.position_max_length, C=self.hidden_units, heads=self.num_heads,
                                blocks=self.num_blocks, pos_max=self.position_max_length, lr=self.lm_lr,
-                               decay_steps=self.dacay_step, min_lr=self.min_learning_rate, seed=seed, device=device)
+                               decay_steps=self.dacay_step, min_lr=self.min_learning_rate, seed=seed, device=device,
+                               dropout_rate=self.dropout_rate if self.is_training else 0.0, drop_seed=seed)
 
     @property
     def global_step(self):

@@ -284,15 +284,22 @@ def fbank(signal, nsamples, frame_len, frame_step, nfft, preemph, nfilt, fb_star
 
 
 # ------------------------------------------------------------------ Transformer path
-def attention_fwd(Q, K, V, N, Tq, Tk, Cc, H, causal, O, lse):
-    check(_lib.load().asr_attention_fwd(_ptr(Q), _ptr(K), _ptr(V), N, Tq, Tk, Cc, H, int(causal), _ptr(O), _ptr(lse),
-                                        _stream()), 'asr_attention_fwd')
+def attention_fwd(Q, K, V, N, Tq, Tk, Cc, H, causal, O, lse, dropout_rate=0.0, seed=0):
+    check(_lib.load().asr_attention_fwd(_ptr(Q), _ptr(K), _ptr(V), N, Tq, Tk, Cc, H, int(causal), float(dropout_rate),
+                                        int(seed) & 0xffffffff, _ptr(O), _ptr(lse), _stream()), 'asr_attention_fwd')
 
 
-def attention_bwd(Q, K, V, O, dO, lse, N, Tq, Tk, Cc, H, causal, dQ, dK, dV, delta_ws, relu_grad=False):
+def attention_bwd(Q, K, V, O, dO, lse, N, Tq, Tk, Cc, H, causal, dQ, dK, dV, delta_ws, relu_grad=False, dropout_rate=0.0, seed=0):
     check(_lib.load().asr_attention_bwd(_ptr(Q), _ptr(K), _ptr(V), _ptr(O), _ptr(dO), _ptr(lse), N, Tq, Tk, Cc, H,
-                                        int(causal), int(relu_grad), _ptr(dQ), _ptr(dK), _ptr(dV), _ptr(delta_ws), _stream()),
+                                        int(causal), int(relu_grad), float(dropout_rate), int(seed) & 0xffffffff,
+                                        _ptr(dQ), _ptr(dK), _ptr(dV), _ptr(delta_ws), _stream()),
           'asr_attention_bwd')
+
+
+def dropout(x, rate, seed, y=None):
+    """y = keep(i, seed) ? x / (1 - rate) : 0 (in place when y is None); the same call on a gradient is the backward."""
+    y = x if y is None else y
+    check(_lib.load().asr_dropout(_ptr(x), x.numel(), float(rate), int(seed) & 0xffffffff, _ptr(y), _stream()), 'asr_dropout')
 
 
 def add_layernorm_fwd(a, b, gamma, beta, rows, Cc, eps, y, xhat, rstd):

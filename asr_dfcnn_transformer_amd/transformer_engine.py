@@ -39,8 +39,12 @@ def _r4(n):
 class _Base:
     """Flat parameter storage + block helpers shared by the two graphs."""
 
-    def __init__(self, C, heads, device, lr, beta2, decay_steps, min_lr):
+    def __init__(self, C, heads, device, lr, beta2, decay_steps, min_lr, dropout_rate=0.0, drop_seed=0):
         self.C, self.H, self.device = C, heads, device
+        # tf.layers.dropout(training=True) at the reference's sites (transformer.py:111,154,226; model.py:290;
+        # language_model.py:34) with the counter-based mask of asr_dropout; 0 = off (all parity runs against TF-free
+        # arithmetic use 0, the dropout parity runs compare with the oracle's restatement of the same generator)
+        self.dropout_rate, self.drop_seed = float(dropout_rate), int(drop_seed)
         assert C == heads * 64, 'the attention kernels are built for 64-wide heads (512 / 8)'
         self.entries = {}       # name -> (offset, shape)   shape = physical (padded) shape
         self.logical = {}       # name -> logical shape
@@ -129,6 +133,20 @@ class _Base:
                 flat[name] = np.zeros(shp)
         self.load_params(flat)
 
+    # ---- dropout sites (ids shared with oracle/transformer.py DROP_SITES / drop_site_seed)
+    def _drop_seed(self, site):
+        if isinstance(site, tuple):
+            kind, i, which = site
+            sid = {'enc': 10, 'mha': 10, 'dec': 40}[kind] + 2 * i + (0 if which == 'att' else 1)
+        else:
+            sid = {'emb_enc': 0, 'emb': 0, 'emb_dec': 1, 'enc_ffn': 70, 'ffn': 70, 'dec_ffn': 71}[site]
+        return (self.drop_seed + 1009 * self.global_step + 7919 * sid) & 0xFFFFFFFF
+
+    @staticmethod
+    def _block_site(name):
+        kind = name.rstrip('0123456789')
+        return kind, int(name[len(kind):])
+
     # ---- low-level helpers
     def _t(self, *shape, dtype=torch.float32):
         return torch.zeros(*shape, dtype=dtype, device=self.device)
@@ -214,8 +232,13 @@ class _Base:
         self._dense(q_in, N * Tq, C, C, self.p(name + '/wq'), None, st['Q'], True)
         self._dense(k_in, N * Tk, C, C, self.p(name + '/wk'), None, st['K'], True)
         self._dense(k_in, N * Tk, C, C, self.p(name + '/wv'), None, st['V'], True)
-        ops.attention_fwd(st['Q'], st['K'], st['V'], N, Tq, Tk, C, self.H, causal, st['A'], st['lse'])
+        rate = self._rate
+        kind, blk = self._block_site(name)
+        st['seed_att'], st['seed_out'] = self._drop_seed((kind, blk, 'att')), self._drop_seed((kind, blk, 'out'))
+        ops.attention_fwd(st['Q'], st['K'], st['V'], N, Tq, Tk, C, self.H, causal, st['A'], st['lse'], rate, st['seed_att'])
         self._dense(st['A'], N * Tq, C, C, self.p(name + '/wo'), None, st['Z'], True)
+        if rate > 0:
+            ops.dropout(st['Z'], rate, st['seed_out'])          # in place: Z > 0 now also means "kept"
         ops.add_layernorm_fwd(st['Z'], q_in, self.p(name + '/ln_g'), self.p(name + '/ln_b'), N * Tq, C, LN_EPS,
                               st['out'], st['xhat'], st['rstd'])
         return st['out']
@@ -231,10 +254,13 @@ class _Base:
                           self.g(name + '/ln_g'), self.g(name + '/ln_b'), self.ws)
         ops.axpy(dq_in, dr, 1.0, dq_acc)
         ops.relu_bwd(dr, st['Z'], dZ)
+        if self._rate > 0:
+            ops.dropout(dZ, self._rate, st['seed_out'])  # the 1/(1-rate) factor (the mask itself is already in Z > 0)
         self._wgrad(st['A'], dZ, rq, C, C, name + '/wo')
         self._dense_dgrad(dZ, rq, C, C, self.p(name + '/wo'), dA, False)
         ops.attention_bwd(st['Q'], st['K'], st['V'], st['A'], dA, st['lse'], N, Tq, Tk, C, self.H, st['causal'],
-                          dQ, dK, dV, self.ws, relu_grad=True)      # gradients of the pre-ReLU projections
+                          dQ, dK, dV, self.ws, relu_grad=True,      # gradients of the pre-ReLU projections
+                          dropout_rate=self._rate, seed=st['seed_att'])
         self._wgrad(st['q_in'], dQ, rq, C, C, name + '/wq')
         self._wgrad(st['k_in'], dK, rk, C, C, name + '/wk')
         self._wgrad(st['k_in'], dV, rk, C, C, name + '/wv')
@@ -253,6 +279,9 @@ class _Base:
         st['x'] = x
         self._dense(x, rows, C, 4 * C, self.p(name + '/w1'), self.p(name + '/b1'), st['H'], True)
         self._dense(st['H'], rows, 4 * C, C, self.p(name + '/w2'), self.p(name + '/b2'), st['Y'], False)
+        st['seed'] = self._drop_seed(name)
+        if self._rate > 0:
+            ops.dropout(st['Y'], self._rate, st['seed'])
         ops.add_layernorm_fwd(st['Y'], x, self.p(name + '/ln_g'), self.p(name + '/ln_b'), rows, C, LN_EPS,
                               st['out'], st['xhat'], st['rstd'])
         return st['out']
@@ -265,9 +294,14 @@ class _Base:
         ops.layernorm_bwd(dout, st['xhat'], st['rstd'], self.p(name + '/ln_g'), rows, C, dr, False,
                           self.g(name + '/ln_g'), self.g(name + '/ln_b'), self.ws)
         ops.axpy(dx, dr, 1.0, dx_acc)
-        self._bgrad(dr, rows, C, name + '/b2')
-        self._wgrad(st['H'], dr, rows, 4 * C, C, name + '/w2')
-        self._dense_dgrad(dr, rows, 4 * C, C, self.p(name + '/w2'), dH, False)
+        if self._rate > 0:                        # gradient of the dropped branch; the residual keeps dr itself
+            dY = self.sc['b'][:rows * C]
+            ops.dropout(dr, self._rate, st['seed'], dY)
+        else:
+            dY = dr
+        self._bgrad(dY, rows, C, name + '/b2')
+        self._wgrad(st['H'], dY, rows, 4 * C, C, name + '/w2')
+        self._dense_dgrad(dY, rows, 4 * C, C, self.p(name + '/w2'), dH, False)
         ops.relu_bwd(dH, st['H'], dH)
         self._bgrad(dH, rows, 4 * C, name + '/b1')
         self._wgrad(st['x'], dH, rows, C, 4 * C, name + '/w1')
@@ -357,8 +391,8 @@ class LMEngine(_Base):
     label-smoothed CE masked by y != 0; Adam(beta2 0.999) on the polynomial-decay lr_lm."""
 
     def __init__(self, vin=1536, vout=6345, N=64, T=100, C=512, heads=8, blocks=12, pos_max=100, lr=5e-5,
-                 decay_steps=5000, min_lr=1e-6, seed=0, device='cuda'):
-        super().__init__(C, heads, device, lr, 0.999, decay_steps, min_lr)
+                 decay_steps=5000, min_lr=1e-6, seed=0, device='cuda', dropout_rate=0.0, drop_seed=0):
+        super().__init__(C, heads, device, lr, 0.999, decay_steps, min_lr, dropout_rate, drop_seed)
         assert T <= pos_max, 'positions >= position_max_length index past the table (language_model.py:29-30)'
         self.vin, self.V, self.Vp, self.N, self.T, self.blocks, self.pos_max = vin, vout, _r4(vout), N, T, blocks, pos_max
         self._add('emb', (vin, C)); self._add('pos', (pos_max, C))
@@ -395,6 +429,10 @@ class LMEngine(_Base):
         self._x_host = xi
         self.ids.copy_(torch.from_numpy(xi), non_blocking=True)
         ops.embed_fwd(self.p('emb'), self.ids, self.p('pos'), N, T, C, True, float(C) ** 0.5, self.x0)
+        self._rate = self.dropout_rate if train else 0.0
+        self._seed_emb = self._drop_seed('emb')
+        if self._rate > 0:
+            ops.dropout(self.x0, self._rate, self._seed_emb)          # language_model.py:34
         enc = self.x0
         for i in range(self.blocks):
             enc = self._mha_fwd('mha%d' % i, self.mha[i], enc, enc, True)
@@ -418,6 +456,8 @@ class LMEngine(_Base):
         for i in reversed(range(self.blocks)):
             self._mha_bwd('mha%d' % i, self.mha[i], cur, nxt, False, nxt, True)
             cur, nxt = nxt, cur
+        if self._rate > 0:
+            ops.dropout(cur, self._rate, self._seed_emb)
         perm, uniq, seg = sorted_segments(self._x_host)
         self.seg[0].copy_(torch.from_numpy(perm), non_blocking=True)
         self.seg[1][:len(uniq)].copy_(torch.from_numpy(uniq), non_blocking=True)
@@ -433,8 +473,8 @@ class E2EEngine(_Base):
     configuration of BASELINE.json configs[3], pinyin ids through an embedding (``vin``)."""
 
     def __init__(self, din=5120, vout=6347, N=8, T=150, L=50, C=512, heads=8, blocks=6, pos_max=600, tie=True, vin=None,
-                 lr=5e-4, decay_steps=5000, min_lr=1e-6, seed=0, device='cuda', need_dx=False):
-        super().__init__(C, heads, device, lr, 0.98, decay_steps, min_lr)
+                 lr=5e-4, decay_steps=5000, min_lr=1e-6, seed=0, device='cuda', need_dx=False, dropout_rate=0.0, drop_seed=0):
+        super().__init__(C, heads, device, lr, 0.98, decay_steps, min_lr, dropout_rate, drop_seed)
         self.need_dx = need_dx and vin is None       # dL/d(features) for the pre-net in front (prenet_engine.py)
         assert T <= pos_max and L <= pos_max
         self.din, self.V, self.Vp, self.N, self.T, self.L = din, vout, _r4(vout), N, T, L
@@ -484,6 +524,7 @@ class E2EEngine(_Base):
     def forward(self, x, y_in, y_tgt=None, train=True):
         N, T, L, C = self.N, self.T, self.L, self.C
         re, rd = N * T, N * L
+        self._rate = self.dropout_rate if train else 0.0
         if self.vin is None:
             assert tuple(x.shape) == (N, T, self.din) and x.is_contiguous()
             self.x_feat = x
@@ -497,6 +538,9 @@ class E2EEngine(_Base):
             self._x_host = xi
             self.x_ids.copy_(torch.from_numpy(xi), non_blocking=True)
             ops.embed_fwd(self.p('enc_emb'), self.x_ids, self.p('enc_pe'), N, T, C, True, float(C) ** 0.5, self.enc0)
+        self._seed_emb = self._drop_seed('emb_enc')
+        if self._rate > 0:
+            ops.dropout(self.enc0, self._rate, self._seed_emb)        # model.py:290 (the decoder input is not dropped)
         yi = np.ascontiguousarray(np.asarray(y_in, dtype=np.int32))
         self._y_host = yi
         self.y_ids.copy_(torch.from_numpy(yi), non_blocking=True)
@@ -540,6 +584,8 @@ class E2EEngine(_Base):
         for i in reversed(range(self.blocks)):
             self._mha_bwd('enc%d' % i, self.enc[i], cur, nxt, False, nxt, True)
             cur, nxt = nxt, cur
+        if self._rate > 0:
+            ops.dropout(cur, self._rate, self._seed_emb)
         ops.colsum(cur, N, T * C, T * C, self.g('enc_pe')[:T * C], self.ws)
         if self.vin is None:
             self._begin_block()

@@ -118,12 +118,14 @@ def run_transformer(args):
     rng = np.random.default_rng(7 + rank)
     if prenet:
         pre = PreNetEngine(N, 4 * T, 320)
-        eng = E2EEngine(din=5120, vout=Vout, N=N, T=T, L=T, C=C, heads=H, blocks=blocks, pos_max=600, tie=True, need_dx=True)
+        eng = E2EEngine(din=5120, vout=Vout, N=N, T=T, L=T, C=C, heads=H, blocks=blocks, pos_max=600, tie=True, need_dx=True,
+                        dropout_rate=args.dropout, drop_seed=rank)
         gen = torch.Generator(device='cuda').manual_seed(7 + rank)
         xraw = torch.randn(N, 4 * T, 320, device='cuda', generator=gen)
         red_pre = BucketedAllReduce(pre.grad, [(0, pre.grad.numel())])
     else:
-        eng = E2EEngine(vin=Vin, vout=Vout, N=N, T=T, L=T, C=C, heads=H, blocks=blocks, pos_max=600, tie=True)
+        eng = E2EEngine(vin=Vin, vout=Vout, N=N, T=T, L=T, C=C, heads=H, blocks=blocks, pos_max=600, tie=True,
+                        dropout_rate=args.dropout, drop_seed=rank)
         x = rng.integers(1, Vin, (N, T))
     red = BucketedAllReduce(eng.grad, [(0, eng.grad.numel())])
     y = rng.integers(3, Vout, (N, T))
@@ -188,7 +190,8 @@ def run_transformer(args):
                           'seq_len': T, 'parallelism': 'dp%d' % world, 'gflop_per_seq_fwd_bwd': round(fstep / 1e9, 2),
                           'step_tflops': round(seq_s / world * fstep / 1e12, 2),
                           'step_frac_of_fp32_peak': round(seq_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
-                          'backward_streams': 2 if overlapped else 1, 'mean_loss': round(eng.fetch()[0], 4)},
+                          'backward_streams': 2 if overlapped else 1, 'dropout_rate': args.dropout,
+                          'mean_loss': round(eng.fetch()[0], 4)},
                'roofline': {'bound': 'mfma', 'achieved': round(r['tflops'], 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                             'frac': round(r['tflops'] / FP32_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': kernel_name(dom),
                             'launches_per_step': r['launches'] // args.steps, 'avg_launch_us': round(r['avg_us'], 2)}}
@@ -210,6 +213,7 @@ def main():
     ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
     ap.add_argument('--tpad', type=int, default=1600)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dropout', type=float, default=0.2, help='Transformer workloads: dropout_rate (reference default 0.2, model.py:36)')
     ap.add_argument('--no-prefetch', action='store_true', help='compute the fbank features in line instead of one step ahead')
     ap.add_argument('--kernel-table', action='store_true', help='also print per-kernel timings to stderr')
     args = ap.parse_args()

@@ -232,11 +232,19 @@ int asr_adam_tf(float* theta, const float* grad, float* m, float* v, size_t n,
  *   relu_grad != 0: Q, K, V are outputs of Dense(activation=relu) (transformer.py:139-141) and the
  *   returned gradients are those of the pre-activations, i.e. dQ *= (Q > 0) etc., fused in the store.
  *   delta_ws: N*H*Tq floats.  Deterministic (no atomics: dK/dV and dQ are separate passes). */
+/*   dropout_rate > 0: tf.layers.dropout on the attention weights (transformer.py:111) with the counter-based mask
+ *   keep(element index ((n*H + h)*Tq + q)*Tk + k, seed); kept weights are scaled by 1/(1-rate).  The backward must be
+ *   given the same rate and seed (the mask is regenerated, not stored).  N*H*Tq*Tk must stay below 2^32. */
 int asr_attention_fwd(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
-                      int causal, float* O, float* lse, void* stream);
+                      int causal, float dropout_rate, unsigned int seed, float* O, float* lse, void* stream);
 int asr_attention_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO,
                       const float* lse, int N, int Tq, int Tk, int C, int H, int causal, int relu_grad,
+                      float dropout_rate, unsigned int seed,
                       float* dQ, float* dK, float* dV, float* delta_ws, void* stream);
+/* tf.layers.dropout(x, rate, training=True) (transformer.py:154,226; model.py:290; language_model.py:34):
+ *   y[i] = keep(i, seed) ? x[i] / (1 - rate) : 0 with keep(i, seed) = (murmur3_fmix(i * 0x9E3779B1 + seed) >> 8) >= rate * 2^24.
+ *   In place is allowed; the same call on the gradient is the backward.  TensorFlow's random stream is not reproduced. */
+int asr_dropout(const float* x, size_t n, float rate, unsigned int seed, float* y, void* stream);
 
 /* K15 layer_norm (transformer.py:4-27) fused with the residual add in front of it:
  *   x = a (+ b);  y = gamma*(x-mean)/sqrt(var+eps) + beta  (biased variance, eps 1e-8)

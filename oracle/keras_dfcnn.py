@@ -11,7 +11,9 @@ Graph (cnn_ctc.py:27-49, 96-131):
   (zeros are NOT dropped here, unlike tf.contrib.layers.dense_to_sparse in acoustic_model*.py), mean over the batch
   by Keras' loss reduction.
 norm = BatchNormalization(axis=-1): batch moments while fitting (biased variance, epsilon 1e-3), gamma/beta trainable.
-Dropout is stochastic in Keras' fit(); parity runs use rate 0 (identity) -- the engine has no dropout either.
+Dropout(0.3) in front of both dense layers (:38,40) is stochastic under fit(); Keras' random stream cannot be reproduced,
+the build's counter-based mask (asr_dropout, restated in oracle/transformer.py) stands in: sites 0 (h6) and 1 (h7),
+seed = base + 1009 * step + 7919 * site.  rate 0 = identity.
 """
 import math
 
@@ -20,6 +22,7 @@ import torch
 import torch.nn.functional as F
 
 from . import ctc as octc
+from .transformer import drop_scale_mask
 
 BN_EPS = 1e-3
 K_EPSILON = 1e-7
@@ -63,8 +66,12 @@ def conv_relu(x, w, b):
     return torch.relu(y).permute(0, 2, 3, 1)
 
 
-def forward(P, x, cells=CELLS):
-    """x [B, T, F] -> softmax outputs y_pred [B, T/8, vocab] (torch, differentiable)."""
+def drop_seed(base, step, site):
+    return (int(base) + 1009 * int(step) + 7919 * int(site)) & 0xFFFFFFFF
+
+
+def forward(P, x, cells=CELLS, drop=None):
+    """x [B, T, F] -> softmax outputs y_pred [B, T/8, vocab] (torch, differentiable).  drop = (rate, base_seed, step)."""
     h = x.unsqueeze(-1)
     for i, (size, pool) in enumerate(cells):
         for j in 'ab':
@@ -74,14 +81,18 @@ def forward(P, x, cells=CELLS):
             h = F.max_pool2d(h.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
     B, H, W, C = h.shape
     h = h.reshape(B, H, W * C)
+    if drop is not None:
+        h = h * torch.tensor(drop_scale_mask(tuple(h.shape), drop[0], drop_seed(drop[1], drop[2], 0)))
     h = torch.relu(h @ P['d1/w'] + P['d1/b'])
+    if drop is not None:
+        h = h * torch.tensor(drop_scale_mask(tuple(h.shape), drop[0], drop_seed(drop[1], drop[2], 1)))
     return torch.softmax(h @ P['d2/w'] + P['d2/b'], dim=-1)
 
 
-def train_step(P_np, x_np, labels, label_len, input_len, cells=CELLS):
+def train_step(P_np, x_np, labels, label_len, input_len, cells=CELLS, drop=None):
     """Returns dict(y_pred, logits (time-major log(y_pred+eps)), loss [B], mean_loss, grads)."""
     P = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in P_np.items()}
-    y = forward(P, torch.tensor(x_np, dtype=torch.float64), cells)
+    y = forward(P, torch.tensor(x_np, dtype=torch.float64), cells, drop)
     logits = torch.log(y.permute(1, 0, 2) + K_EPSILON)
     B, V = y.shape[0], y.shape[2]
     labs = [list(np.asarray(labels[b])[:label_len[b]]) for b in range(B)]

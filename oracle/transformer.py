@@ -56,6 +56,45 @@ def embedding_bwd(table_shape, ids, dout, zero_pad, scale):
     return g
 
 
+# ----------------------------------------------------------------- dropout (tf.layers.dropout with training=True)
+# TensorFlow's random stream cannot be reproduced; the build defines its own counter-based mask (include/asr_hip.h,
+# asr_dropout) and the oracle restates that generator: element i of the tensor drawn for `seed` is kept when the top
+# 24 bits of murmur3_fmix32(i * 0x9E3779B1 + seed) reach rate * 2^24; kept values are scaled by 1 / (1 - rate).
+DROP_SITES = {'emb_enc': 0, 'emb_dec': 1, 'enc_ffn': 70, 'dec_ffn': 71, 'ffn': 70, 'emb': 0}
+
+
+def drop_site_seed(base_seed, step, site):
+    """site: a DROP_SITES name, or ('enc'|'dec'|'mha', block, 'att'|'out')."""
+    if isinstance(site, tuple):
+        kind, i, which = site
+        sid = {'enc': 10, 'mha': 10, 'dec': 40}[kind] + 2 * i + (0 if which == 'att' else 1)
+    else:
+        sid = DROP_SITES[site]
+    return (int(base_seed) + 1009 * int(step) + 7919 * sid) & 0xFFFFFFFF
+
+
+def drop_scale_mask(shape, rate, seed):
+    """float64 array of `shape`: 1/(1-rate) where kept, 0 where dropped (flat C-order element index)."""
+    n = int(np.prod(shape))
+    h = (np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B1) + np.uint64(seed)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16); h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13); h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    thr = np.uint64(int(min(max(float(rate) * 16777216.0, 0.0), 16777215.0) + 0.5))
+    keep = (h >> np.uint64(8)) >= thr
+    return (keep.astype(np.float64) / (1.0 - float(rate))).reshape(shape)
+
+
+class Drop:
+    """Dropout context of one training step: rate, base seed, step (all sites derive their seed from these)."""
+
+    def __init__(self, rate, seed=0, step=0):
+        self.rate, self.seed, self.step = float(rate), int(seed), int(step)
+
+    def mask(self, shape, site):
+        return drop_scale_mask(shape, self.rate, drop_site_seed(self.seed, self.step, site))
+
+
 def _split(x, h):       # [N,T,C] -> [N,h,T,C/h]
     N, T, C = x.shape
     return x.reshape(N, T, h, C // h).transpose(0, 2, 1, 3)
@@ -66,8 +105,9 @@ def _merge(x):          # [N,h,T,d] -> [N,T,h*d]
     return x.transpose(0, 2, 1, 3).reshape(N, T, h * d)
 
 
-def attention_core(Q, K, V, h, causal):
-    """scaled_dot_product_attention on head-split relu'd projections Q,K,V [N,T,C]."""
+def attention_core(Q, K, V, h, causal, drop_mask=None):
+    """scaled_dot_product_attention on head-split relu'd projections Q,K,V [N,T,C].
+    drop_mask [N,h,Tq,Tk] (0 or 1/(1-rate)): dropout of the attention weights, transformer.py:111."""
     Qh, Kh, Vh = _split(Q, h), _split(K, h), _split(V, h)
     d = Qh.shape[-1]
     S = np.einsum('nhqd,nhkd->nhqk', Qh, Kh) / (d ** 0.5)
@@ -82,18 +122,24 @@ def attention_core(Q, K, V, h, causal):
     P = e / e.sum(axis=-1, keepdims=True)
     qmask = np.sign(np.abs(Qh).sum(axis=-1))                       # [N,h,Tq]
     Pq = P * qmask[..., None]
+    if drop_mask is not None:
+        Pq = Pq * drop_mask
     O = np.einsum('nhqk,nhkd->nhqd', Pq, Vh)
-    return _merge(O), (Qh, Kh, Vh, P, keep, qmask)
+    return _merge(O), (Qh, Kh, Vh, P, keep, qmask, drop_mask)
 
 
 def attention_core_bwd(cache, dO):
-    Qh, Kh, Vh, P, keep, qmask = cache
+    Qh, Kh, Vh, P, keep, qmask, drop_mask = cache
     h = Qh.shape[1]
     d = Qh.shape[-1]
     dOh = _split(dO, h)
     Pq = P * qmask[..., None]
+    if drop_mask is not None:
+        Pq = Pq * drop_mask
     dV = np.einsum('nhqk,nhqd->nhkd', Pq, dOh)
     dPq = np.einsum('nhqd,nhkd->nhqk', dOh, Vh)
+    if drop_mask is not None:
+        dPq = dPq * drop_mask
     dP = dPq * qmask[..., None]
     dSm = P * (dP - (dP * P).sum(axis=-1, keepdims=True))
     dS = np.where(keep, dSm, 0.0) / (d ** 0.5)                     # tf.where: no gradient into masked scores
@@ -102,23 +148,30 @@ def attention_core_bwd(cache, dO):
     return _merge(dQ), _merge(dK), _merge(dV)
 
 
-def mha_fwd(q_in, k_in, p, h, causal):
-    """multihead_attention (transformer.py:118-158).  p: wq, wk, wv, wo [C,C], ln_g, ln_b."""
+def mha_fwd(q_in, k_in, p, h, causal, drop=None, site=None):
+    """multihead_attention (transformer.py:118-158).  p: wq, wk, wv, wo [C,C], ln_g, ln_b.
+    drop (Drop) + site ('enc'|'dec'|'mha', block): dropout of the attention weights (:111) and of the output (:154)."""
     Q = np.maximum(q_in @ p['wq'], 0)
     K = np.maximum(k_in @ p['wk'], 0)
     V = np.maximum(k_in @ p['wv'], 0)
-    A, c_att = attention_core(Q, K, V, h, causal)
+    N, Tq, C = Q.shape
+    m_att = drop.mask((N, h, Tq, K.shape[1]), site + ('att',)) if drop is not None else None
+    A, c_att = attention_core(Q, K, V, h, causal, m_att)
     Z = np.maximum(A @ p['wo'], 0)
-    out, c_ln = layer_norm(Z + q_in, p['ln_g'], p['ln_b'])
-    return out, (q_in, k_in, Q, K, V, A, Z, c_att, c_ln)
+    m_out = drop.mask(Z.shape, site + ('out',)) if drop is not None else None
+    Zd = Z * m_out if m_out is not None else Z
+    out, c_ln = layer_norm(Zd + q_in, p['ln_g'], p['ln_b'])
+    return out, (q_in, k_in, Q, K, V, A, Z, c_att, c_ln, m_out)
 
 
 def mha_bwd(cache, p, dout, self_attn):
-    q_in, k_in, Q, K, V, A, Z, c_att, c_ln = cache
+    q_in, k_in, Q, K, V, A, Z, c_att, c_ln, m_out = cache
     C = q_in.shape[-1]
     dr, dg, db = layer_norm_bwd(c_ln, p['ln_g'], dout)
     dq_in = dr.copy()
     dZ = dr * (Z > 0)
+    if m_out is not None:
+        dZ = dZ * m_out
     g = {'ln_g': dg, 'ln_b': db, 'wo': A.reshape(-1, C).T @ dZ.reshape(-1, C)}
     dA = dZ @ p['wo'].T
     dQ, dK, dV = attention_core_bwd(c_att, dA)
@@ -133,20 +186,23 @@ def mha_bwd(cache, p, dout, self_attn):
     return dq_in, dk_in, g
 
 
-def ffn_fwd(x, p):
-    """feedforward (transformer.py:204-231): conv1d(k=1) = dense with bias."""
+def ffn_fwd(x, p, drop=None, site=None):
+    """feedforward (transformer.py:204-231): conv1d(k=1) = dense with bias; dropout of the output (:226)."""
     H = np.maximum(x @ p['w1'] + p['b1'], 0)
     Y = H @ p['w2'] + p['b2']
-    out, c_ln = layer_norm(Y + x, p['ln_g'], p['ln_b'])
-    return out, (x, H, c_ln)
+    m = drop.mask(Y.shape, site) if drop is not None else None
+    Yd = Y * m if m is not None else Y
+    out, c_ln = layer_norm(Yd + x, p['ln_g'], p['ln_b'])
+    return out, (x, H, c_ln, m)
 
 
 def ffn_bwd(cache, p, dout):
-    x, H, c_ln = cache
+    x, H, c_ln, m = cache
     dr, dg, db = layer_norm_bwd(c_ln, p['ln_g'], dout)
     C, Fh = p['w1'].shape
-    g = {'ln_g': dg, 'ln_b': db, 'w2': H.reshape(-1, Fh).T @ dr.reshape(-1, C), 'b2': dr.reshape(-1, C).sum(axis=0)}
-    dH = (dr @ p['w2'].T) * (H > 0)
+    dY = dr * m if m is not None else dr
+    g = {'ln_g': dg, 'ln_b': db, 'w2': H.reshape(-1, Fh).T @ dY.reshape(-1, C), 'b2': dY.reshape(-1, C).sum(axis=0)}
+    dH = (dY @ p['w2'].T) * (H > 0)
     g['w1'] = x.reshape(-1, C).T @ dH.reshape(-1, Fh)
     g['b1'] = dH.reshape(-1, Fh).sum(axis=0)
     return dr + dH @ p['w1'].T, g
@@ -210,17 +266,20 @@ def init_lm(vin, vout, C, heads, blocks, pos_max, seed=0, perturb=False):
 
 
 # ----------------------------------------------------------------- Language_Model (language_model.py:22-78)
-def lm_step(P, x, y, heads, blocks, want_grads=True):
+def lm_step(P, x, y, heads, blocks, want_grads=True, drop=None):
     C = P['emb'].shape[1]
     N, T = x.shape
     e = embedding(P['emb'], x, zero_pad=True, scale=True)
     pos = np.broadcast_to(np.arange(T)[None, :], (N, T))
     enc = e + embedding(P['pos'], pos, zero_pad=False, scale=False)
+    m_emb = drop.mask(enc.shape, 'emb') if drop is not None else None          # language_model.py:34
+    if m_emb is not None:
+        enc = enc * m_emb
     caches = []
     for i in range(blocks):
-        enc, c = mha_fwd(enc, enc, P['mha%d' % i], heads, causal=True)
+        enc, c = mha_fwd(enc, enc, P['mha%d' % i], heads, causal=True, drop=drop, site=('mha', i))
         caches.append(c)
-    outputs, c_ffn = ffn_fwd(enc, P['ffn'])
+    outputs, c_ffn = ffn_fwd(enc, P['ffn'], drop, 'ffn')
     logits = outputs @ P['out_w'] + P['out_b']
     mean_loss, acc, preds, loss, dlogits = smoothed_ce(logits, y)
     out = {'logits': logits, 'mean_loss': mean_loss, 'acc': acc, 'preds': preds, 'enc': enc}
@@ -231,6 +290,8 @@ def lm_step(P, x, y, heads, blocks, want_grads=True):
     d, G['ffn'] = ffn_bwd(c_ffn, P['ffn'], d)
     for i in reversed(range(blocks)):
         d, _, G['mha%d' % i] = mha_bwd(caches[i], P['mha%d' % i], d, self_attn=True)
+    if m_emb is not None:
+        d = d * m_emb
     G['emb'] = embedding_bwd(P['emb'].shape, x, d, zero_pad=True, scale=True)
     G['pos'] = embedding_bwd(P['pos'].shape, pos, d, zero_pad=False, scale=False)
     out['grads'] = G
@@ -261,7 +322,7 @@ def init_e2e(din, vout, C, heads, blocks, pos_max, seed=0, perturb=False, tie=Tr
     return P
 
 
-def e2e_step(P, x_feat, y_in, y_tgt, heads, blocks, tie=True, want_grads=True):
+def e2e_step(P, x_feat, y_in, y_tgt, heads, blocks, tie=True, want_grads=True, drop=None):
     """x_feat [N,T,Din] (the flattened pre_net output fed to embedding_input), y_in/y_tgt [N,L]."""
     N, T, Din = x_feat.shape
     C = P['in_w'].shape[1]
@@ -272,16 +333,20 @@ def e2e_step(P, x_feat, y_in, y_tgt, heads, blocks, tie=True, want_grads=True):
     enc = iv + embedding(P['enc_pe'], posx, False, False)
     posy = np.broadcast_to(np.arange(L)[None, :], (N, L))
     dec = embedding(P['dec_input'], y_in, False, False) + embedding(P['dec_pe'], posy, False, False)
+    # model.py:290 drops the encoder input only (the decoder input goes into its blocks as it is, :312-329)
+    m_enc = drop.mask(enc.shape, 'emb_enc') if drop is not None else None
+    if m_enc is not None:
+        enc = enc * m_enc
     ce = []
     for i in range(blocks):
-        enc, c = mha_fwd(enc, enc, P['enc%d' % i], heads, causal=False)
+        enc, c = mha_fwd(enc, enc, P['enc%d' % i], heads, causal=False, drop=drop, site=('enc', i))
         ce.append(c)
-    memory, c_effn = ffn_fwd(enc, P['enc_ffn'])
+    memory, c_effn = ffn_fwd(enc, P['enc_ffn'], drop, 'enc_ffn')
     cd = []
     for i in range(blocks):
-        dec, c = mha_fwd(dec, memory, P['dec%d' % i], heads, causal=True)
+        dec, c = mha_fwd(dec, memory, P['dec%d' % i], heads, causal=True, drop=drop, site=('dec', i))
         cd.append(c)
-    outputs, c_dffn = ffn_fwd(dec, P['dec_ffn'])
+    outputs, c_dffn = ffn_fwd(dec, P['dec_ffn'], drop, 'dec_ffn')
     logits = outputs @ P['out_w'] + P['out_b']
     mean_loss, acc, preds, loss, dlogits = smoothed_ce(logits, y_tgt)
     out = {'logits': logits, 'mean_loss': mean_loss, 'acc': acc, 'preds': preds, 'memory': memory}
@@ -299,6 +364,8 @@ def e2e_step(P, x_feat, y_in, y_tgt, heads, blocks, tie=True, want_grads=True):
     de, G['enc_ffn'] = ffn_bwd(c_effn, P['enc_ffn'], dmem)
     for i in reversed(range(blocks)):
         de, _, G['enc%d' % i] = mha_bwd(ce[i], P['enc%d' % i], de, self_attn=True)
+    if m_enc is not None:
+        de = de * m_enc
     G['enc_pe'] = embedding_bwd(P['enc_pe'].shape, posx, de, False, False)
     du, G['in_ln_g'], G['in_ln_b'] = layer_norm_bwd(c_inln, P['in_ln_g'], de)
     du = du * (u > 0)

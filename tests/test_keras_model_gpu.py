@@ -29,8 +29,8 @@ def test_maxpool_bwd_routes_to_first_maximum():
     assert ref[0, 0, 0, 0] == dy[0, 0, 0, 0] and ref[0, 0, 1, 0] == 0
 
 
-@pytest.mark.parametrize("B,T", [(2, 32), (3, 64)])
-def test_keras_dfcnn_step_matches_oracle(B, T):
+@pytest.mark.parametrize("B,T,rate", [(2, 32, 0.0), (3, 64, 0.0), (2, 32, 0.3)])
+def test_keras_dfcnn_step_matches_oracle(B, T, rate):
     from asr_dfcnn_transformer_amd.keras_engine import KerasDFCNNEngine
     rng = np.random.default_rng(1)
     F, V, hidden = 16, 12, 16
@@ -44,8 +44,8 @@ def test_keras_dfcnn_step_matches_oracle(B, T):
         n = 1 + b % 2
         labels[b, :n] = rng.integers(1, V - 1, n)
         ll.append(n); il.append(T8 if b % 2 == 0 else T8 - 1)
-    ref = ok.train_step(P, x.astype(np.float64), labels, ll, il, cells)
-    eng = KerasDFCNNEngine(vocab=V, B=B, T=T, F=F, cells=cells, hidden=hidden)
+    ref = ok.train_step(P, x.astype(np.float64), labels, ll, il, cells, drop=(rate, 5, 0) if rate else None)
+    eng = KerasDFCNNEngine(vocab=V, B=B, T=T, F=F, cells=cells, hidden=hidden, dropout_rate=rate, drop_seed=5)
     eng.load_params(P)
     logits = eng.forward(torch.tensor(x, device='cuda'))
     eng.set_targets(il, labels, ll)

@@ -154,3 +154,34 @@ def test_smoothed_ce_ignore_target():
     ml, acc, preds, loss, dl = otr.smoothed_ce(logits, np.array([[2, -1]]))
     # valid target: ys sums to 1 -> loss = log 4 ; IGNORE target: ys = 0.1/4 each -> loss = 0.1*log 4
     assert np.allclose(loss, [[np.log(4), 0.1 * np.log(4)]]) and np.isclose(ml, 1.1 * np.log(4) / 2)
+
+
+def test_dropout_mask_generator_properties():
+    """The counter-based mask of asr_dropout as the oracle restates it: deterministic, seed-sensitive, keep rate 1 - rate,
+    inverted scaling, and rate 0 keeps everything."""
+    m = otr.drop_scale_mask((1000, 50), 0.2, 77)
+    assert np.array_equal(m, otr.drop_scale_mask((1000, 50), 0.2, 77))
+    assert not np.array_equal(m != 0, otr.drop_scale_mask((1000, 50), 0.2, 78) != 0)
+    assert abs((m != 0).mean() - 0.8) < 5e-3 and np.allclose(m[m != 0], 1.25)
+    assert np.all(otr.drop_scale_mask((64,), 0.0, 5) == 1.0)
+    # site seeds are distinct per site and step
+    seeds = {otr.drop_site_seed(1, st, s) for st in (0, 1) for s in ('emb', 'ffn', ('mha', 0, 'att'), ('mha', 0, 'out'), ('dec', 5, 'out'))}
+    assert len(seeds) == 10
+
+
+def test_dropout_backward_is_the_masked_gradient():
+    rng = np.random.default_rng(9)
+    N, T, C, H = 2, 5, 128, 2
+    p = otr.init_mha(rng, C, perturb=True)
+    x = rng.standard_normal((N, T, C))
+    drop = otr.Drop(0.3, seed=11, step=2)
+    out, cache = otr.mha_fwd(x, x, p, H, causal=True, drop=drop, site=('mha', 1))
+    dout = rng.standard_normal(out.shape)
+    dx, _, g = otr.mha_bwd(cache, p, dout, self_attn=True)
+    f = lambda xx, pp: float((otr.mha_fwd(xx, xx, pp, H, causal=True, drop=drop, site=('mha', 1))[0] * dout).sum())
+    h = 1e-6
+    xp, xm = x.copy(), x.copy(); xp[1, 2, 7] += h; xm[1, 2, 7] -= h
+    assert abs((f(xp, p) - f(xm, p)) / (2 * h) - dx[1, 2, 7]) < 1e-5
+    pp = {k: v.copy() for k, v in p.items()}; pm = {k: v.copy() for k, v in p.items()}
+    pp['wo'][3, 4] += h; pm['wo'][3, 4] -= h
+    assert abs((f(x, pp) - f(x, pm)) / (2 * h) - g['wo'][3, 4]) < 1e-5

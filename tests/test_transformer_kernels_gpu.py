@@ -135,3 +135,50 @@ def test_smoothed_ce(ops, rows, V):
     d = dlg.cpu().numpy()
     report('ce dlogits', d[:, :V], dl[0], 1e-6)
     assert np.all(d[:, V:] == 0)
+
+
+def test_dropout_matches_the_oracle_generator(ops):
+    """asr_dropout: the counter-based mask is restated in oracle/transformer.py; keep rate ~ 1 - rate; in place; the same
+    call on a gradient is the backward."""
+    rng = np.random.default_rng(5)
+    n, rate, seed = 100003, 0.2, 123456789
+    x = rng.standard_normal(n).astype(np.float32)
+    m = otr.drop_scale_mask((n,), rate, seed)
+    y = dev(x)
+    ops.dropout(y, rate, seed)
+    got = y.cpu().numpy()
+    assert np.array_equal(got != 0, (m != 0) & (x != 0))
+    report('dropout values', got, x * m, 1e-6)
+    assert abs((m != 0).mean() - (1 - rate)) < 5e-3
+    out = torch.zeros(n, device='cuda')
+    ops.dropout(dev(x), rate, seed + 1, out)                       # another seed: another mask
+    assert not np.array_equal(out.cpu().numpy() != 0, got != 0)
+
+
+@pytest.mark.parametrize("N,Tq,Tk,H,causal", [(2, 70, 70, 2, True), (1, 130, 200, 2, False), (2, 300, 300, 2, True)])
+def test_attention_with_weight_dropout(ops, N, Tq, Tk, H, causal):
+    """Dropout of the attention weights (transformer.py:111) inside the fused kernels, forward and backward."""
+    rng = np.random.default_rng(6)
+    C, rate, seed = H * 64, 0.2, 987654321
+    relu = lambda x: np.maximum(x, 0)
+    Q = relu(rng.standard_normal((N, Tq, C))).astype(np.float32)
+    K = relu(rng.standard_normal((N, Tk, C))).astype(np.float32)
+    V = relu(rng.standard_normal((N, Tk, C))).astype(np.float32)
+    K[0, Tk - 3:, :] = 0
+    Q[0, Tq - 1, :] = 0
+    K[N - 1, :, 64:128] = 0                                        # all keys of one head masked: uniform weights, then dropped
+    M = otr.drop_scale_mask((N, H, Tq, Tk), rate, seed)
+    Oref, cache = otr.attention_core(Q.astype(np.float64), K.astype(np.float64), V.astype(np.float64), H, causal, M)
+    O = torch.zeros(N, Tq, C, device='cuda')
+    lse = torch.zeros(2, N, H, Tq, device='cuda')
+    dQ, dK, dV = dev(Q), dev(K), dev(V)
+    ops.attention_fwd(dQ, dK, dV, N, Tq, Tk, C, H, causal, O, lse, rate, seed)
+    report('attention fwd (dropout)', O.cpu().numpy(), Oref, 3e-5)
+    dO = rng.standard_normal((N, Tq, C)).astype(np.float32)
+    gq_ref, gk_ref, gv_ref = otr.attention_core_bwd(cache, dO.astype(np.float64))
+    gq, gk, gv = torch.zeros_like(dQ), torch.zeros_like(dK), torch.zeros_like(dV)
+    ws = torch.zeros(N * H * Tq + 16, device='cuda')
+    ops.attention_bwd(dQ, dK, dV, O, dev(dO), lse, N, Tq, Tk, C, H, causal, gq, gk, gv, ws, dropout_rate=rate, seed=seed)
+    report('attention dQ (dropout)', gq.cpu().numpy(), gq_ref, 5e-5)
+    report('attention dK (dropout)', gk.cpu().numpy(), gk_ref, 5e-5)
+    report('attention dV (dropout)', gv.cpu().numpy(), gv_ref, 5e-5)

@@ -170,3 +170,59 @@ def test_am_to_lm_inference_pipeline():
     m.update([1, 2, 3, 4], [1, 2, 4])
     m.update([1, 2], [5, 6, 7, 8, 9])          # more errors than words -> capped at the sentence length
     assert m.words == 6 and m.errors == 1 + 2 and abs(m.accuracy - 0.5) < 1e-12
+
+
+@pytest.mark.parametrize("which", ["lm", "e2e"])
+def test_steps_with_dropout_match_oracle(which):
+    """dropout_rate 0.2 at every site of the reference (embedding input, attention weights, MHA output, FFN output) with
+    the build's counter-based mask: engines vs the oracle's restatement of the same generator, step 0 and step 1."""
+    from asr_dfcnn_transformer_amd.transformer_engine import LMEngine, E2EEngine
+    rng = np.random.default_rng(7)
+    rate, seed = 0.2, 4242
+    if which == "lm":
+        N, T, C, H, blocks, Vin, Vout, pos_max = 3, 9, 128, 2, 3, 21, 13, 12
+        P = f32(otr.init_lm(Vin, Vout, C, H, blocks, pos_max, seed=1, perturb=True))
+        x = rng.integers(1, Vin, (N, T)); x[0, T - 3:] = 0
+        y = rng.integers(1, Vout, (N, T)); y[0, T - 3:] = 0
+        eng = LMEngine(vin=Vin, vout=Vout, N=N, T=T, C=C, heads=H, blocks=blocks, pos_max=pos_max, dropout_rate=rate, drop_seed=seed)
+        eng.load_params(eng.flat_from_oracle(P))
+        run_ref = lambda step: otr.lm_step(P, x, y, H, blocks, drop=otr.Drop(rate, seed, step))
+        run_dev = lambda: eng.forward(x, y)
+        shape = (N, T)
+    else:
+        N, T, L, Din, C, H, blocks, Vout, pos_max = 2, 11, 6, 24, 128, 2, 2, 15, 16
+        P = f32(otr.init_e2e(Din, Vout, C, H, blocks, pos_max, seed=2, perturb=True, tie=True))
+        for i in range(blocks):
+            for k in ('wq', 'wk', 'wv', 'wo'):
+                P['dec%d' % i][k] = P['enc%d' % i][k]
+        for k in ('w1', 'b1', 'w2', 'b2'):
+            P['dec_ffn'][k] = P['enc_ffn'][k]
+        xf = rng.standard_normal((N, T, Din)).astype(np.float32)
+        y_in = rng.integers(1, Vout, (N, L)); y_tgt = rng.integers(1, Vout, (N, L))
+        eng = E2EEngine(din=Din, vout=Vout, N=N, T=T, L=L, C=C, heads=H, blocks=blocks, pos_max=pos_max, tie=True,
+                        dropout_rate=rate, drop_seed=seed)
+        eng.load_params(eng.flat_from_oracle(P))
+        xd = torch.tensor(xf, device='cuda')
+        run_ref = lambda step: otr.e2e_step(P, xf.astype(np.float64), y_in, y_tgt, H, blocks, tie=True, drop=otr.Drop(rate, seed, step))
+        run_dev = lambda: eng.forward(xd, y_in, y_tgt)
+        shape = (N, L)
+    ref0 = run_ref(0)
+    nodrop = (otr.lm_step(P, x, y, H, blocks) if which == "lm" else otr.e2e_step(P, xf.astype(np.float64), y_in, y_tgt, H, blocks, tie=True))
+    assert np.abs(ref0['logits'] - nodrop['logits']).max() > 1e-2          # the masks do something
+    logits = run_dev()
+    eng.backward()
+    torch.cuda.synchronize()
+    got = logits.cpu().numpy().reshape(shape + (-1,))[:, :, :ref0['logits'].shape[-1]]
+    print(which, 'logits err (dropout)', np.abs(got - ref0['logits']).max())
+    assert np.abs(got - ref0['logits']).max() < 1e-3
+    G, R = eng.grads_dict(), flat_grads(ref0['grads'])
+    worst = max(rel(G[k], R[k]) for k in R)
+    print(which, 'worst grad rel err (dropout)', worst)
+    assert worst < 1e-3
+    # the masks change with the step counter; evaluation (train=False) has no dropout
+    eng.global_step = 1
+    got1 = run_dev().cpu().numpy().reshape(shape + (-1,))[:, :, :ref0['logits'].shape[-1]]
+    assert np.abs(got1 - run_ref(1)['logits']).max() < 1e-3 and np.abs(got1 - got).max() > 1e-2
+    if which == "lm":
+        ev = eng.forward(x, y, train=False).cpu().numpy().reshape(shape + (-1,))[:, :, :ref0['logits'].shape[-1]]
+        assert np.abs(ev - nodrop['logits']).max() < 1e-3
