@@ -19,16 +19,25 @@ from .hparams import AmLmHparams, AmDataHparams
 from .parallel import init_from_env
 
 
+def _engine_of(obj):
+    return getattr(obj, 'engine', obj)
+
+
 def save_checkpoint(model, path):
-    e = model.engine
+    """Everything tf.train.Saver keeps for the reference (train.py:38,91-96; model.py:81-88): the variables, the Adam
+    slots and global_step -- of any engine here (DFCNN variants, Keras DFCNN, LM, encoder-decoder, pre-net) or of a
+    shim that owns one.  Own format (torch.save); TF checkpoint compatibility is out of scope."""
+    e = _engine_of(model)
     torch.save({'theta': e.theta.cpu(), 'adam_m': e.adam_m.cpu(), 'adam_v': e.adam_v.cpu(),
-                'global_step': e.global_step, 'variant': e.model, 'entries': e.entries}, path)
+                'global_step': e.global_step, 'variant': getattr(e, 'model', type(e).__name__),
+                'entries': {str(k): v for k, v in e.entries.items()}}, path)
 
 
 def load_checkpoint(model, path):
-    e = model.engine
+    e = _engine_of(model)
     ck = torch.load(path, map_location='cpu', weights_only=False)
-    assert ck['variant'] == e.model and ck['entries'] == e.entries
+    if ck['variant'] != getattr(e, 'model', type(e).__name__) or ck['entries'] != {str(k): v for k, v in e.entries.items()}:
+        raise ValueError('checkpoint %s was written by a different model (%s)' % (path, ck['variant']))
     e.theta.copy_(ck['theta']); e.adam_m.copy_(ck['adam_m']); e.adam_v.copy_(ck['adam_v'])
     e.global_step = int(ck['global_step'])
 

@@ -226,3 +226,25 @@ def test_steps_with_dropout_match_oracle(which):
     if which == "lm":
         ev = eng.forward(x, y, train=False).cpu().numpy().reshape(shape + (-1,))[:, :, :ref0['logits'].shape[-1]]
         assert np.abs(ev - nodrop['logits']).max() < 1e-3
+
+
+def test_checkpoint_roundtrip_for_any_engine(tmp_path):
+    """save_checkpoint / load_checkpoint: variables + Adam slots + global_step; a resumed engine continues bit-identically;
+    a checkpoint of another model is refused."""
+    from asr_dfcnn_transformer_amd.train import save_checkpoint, load_checkpoint
+    from asr_dfcnn_transformer_amd.transformer_engine import LMEngine
+    rng = np.random.default_rng(8)
+    mk = lambda blocks=2: LMEngine(vin=17, vout=13, N=2, T=8, C=128, heads=2, blocks=blocks, pos_max=8, dropout_rate=0.1, drop_seed=3)
+    x, y = rng.integers(1, 17, (2, 8)), rng.integers(1, 13, (2, 8))
+    a = mk()
+    for _ in range(2):
+        a.forward(x, y); a.backward(); a.apply_adam()
+    save_checkpoint(a, str(tmp_path / 'lm.pt'))
+    b = mk()
+    load_checkpoint(b, str(tmp_path / 'lm.pt'))
+    assert b.global_step == 2 and torch.equal(a.theta, b.theta) and torch.equal(a.adam_v, b.adam_v)
+    for e in (a, b):
+        e.forward(x, y); e.backward(); e.apply_adam()
+    assert torch.equal(a.theta, b.theta)
+    with pytest.raises(ValueError):
+        load_checkpoint(mk(blocks=3), str(tmp_path / 'lm.pt'))
