@@ -793,6 +793,436 @@ int launch_v4(const TapGemmArgs& a, hipStream_t st) {
     return ASR_OK;
 }
 
+// ---- bx6: EXPERIMENTAL split-bf16 contraction (tools/mfma_bf16x.hip).  Every fp32 operand is
+// written as hi + mid + lo bf16 pieces (3 x 8 mantissa bits = the 24 bits of fp32) and a product as SIX
+// v_mfma_f32_32x32x16_bf16 products accumulated in fp32 (hh, hm, mh, mm, hl, lh; the dropped terms are < 2^-32 relative):
+// fp32-chain accuracy at 2.6x the matrix-pipe rate.  Structure = v4: the A tile is split once when it is staged
+// (3 x KC bf16 per pixel row), the weights arrive pre-split and transposed ([tap][piece][n][Kp], asr_split_weights) so a
+// lane's B fragment is one 16-byte global load per piece, kept D units ahead in a register ring; two barriers per chunk.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+struct BxArgs { TapGemmArgs g; const __bf16* Ws; int Kp; };
+
+template <int MT, int NT, int WM, int WN, int NTAPS, int D, int KCV, int MINB>
+__global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_bx6(BxArgs args) {
+    const TapGemmArgs& g = args.g;
+    constexpr int KC = KCV;
+    constexpr int APB = 3 * KC * 2 + 16;              // LDS bytes per pixel row: 3 pieces x KC bf16 + pad (13 x 16 B)
+    constexpr int TM = MT / WM / 32, TN = NT / WN / 32;
+    constexpr int KS = KC / 16;                       // MFMA K-steps per chunk
+    constexpr int SB = 4;
+    static_assert(NTAPS == 1 || NTAPS % D == 0, "ring depth must divide the taps");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int halo = g.halo;
+    const int arows = MT + 2 * halo;
+    int* rowa = (int*)smem;
+    int* rowy = rowa + MT;
+    float* tile_lds = smem + 2 * MT;
+    char* As = (char*)tile_lds;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+    const int swz = asr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_m = swz / g.ntn, tile_n = swz - tile_m * g.ntn;
+    const long p0 = (long)tile_m * MT;
+    const int n0 = tile_n * NT;
+    const int K = g.K, N = g.N, Kp = args.Kp;
+
+    if (tid < MT) {
+        const long p = p0 + tid;
+        int ra = -1, ry = -1;
+        if (p < g.M) {
+            if (g.H == 0) {
+                ra = (int)p; ry = (int)p;
+            } else {
+                const int b = (int)(p / g.HPWP);
+                const int r = (int)(p - (long)b * g.HPWP);
+                const int hh = r / g.WP, ww = r - hh * g.WP;
+                if (hh >= 1 && hh <= g.H && ww >= 1 && ww <= g.Wd) {
+                    ra = (int)p;
+                    ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : (int)p;
+                }
+            }
+        }
+        rowa[tid] = ra; rowy[tid] = ry;
+    }
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nkc = (K + KC - 1) / KC;
+    // ring of D slots, one slot = the B fragments of ONE tap for the KS K-steps of a chunk
+    bf16x8 breg[D][KS][TN][3];
+    const int ncol = n0 + wn * (TN * 32) + li;
+
+    auto load_b = [&](bf16x8 (&dst)[KS][TN][3], int kc, int tap) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kk = kc * KC + ks * 16 + 8 * lh;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int n = ncol + b * 32;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+                    if (kk < Kp && n < N) v = *(const bf16x8*)(args.Ws + (((long)tap * 3 + pc) * N + n) * Kp + kk);
+                    dst[ks][b][pc] = v;
+                }
+            }
+        }
+    };
+    auto load_a_row = [&](int f, int kc) -> float4 {
+        const int row = f / (KC / 4), c4 = f - row * (KC / 4);
+        const long grow = p0 - halo + row;
+        const int kk = kc * KC + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grow >= g.rmin && grow < g.rmax && kk < K) v = *(const float4*)(g.A + grow * g.lda + kk);
+        return v;
+    };
+    auto compute_tap = [&](const bf16x8 (&bb)[KS][TN][3], int tap) {
+        const int toff = halo + tap_row_offset<NTAPS, 0>(tap, g.WP);
+        const char* abase = As + (wm * (TM * 32) + li + toff) * APB + lh * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const bf16x8 ah = *(const bf16x8*)(abase + a * 32 * APB + ks * 32);
+                const bf16x8 am = *(const bf16x8*)(abase + a * 32 * APB + ks * 32 + KC * 2);
+                const bf16x8 al = *(const bf16x8*)(abase + a * 32 * APB + ks * 32 + 2 * KC * 2);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    floatx16 c = acc[a][b];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bb[ks][b][0], c, 0, 0, 0);      // small terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bb[ks][b][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bb[ks][b][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bb[ks][b][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bb[ks][b][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bb[ks][b][0], c, 0, 0, 0);
+                    acc[a][b] = c;
+                }
+            }
+        }
+    };
+
+    auto stage_a = [&](int kc) {
+        __syncthreads();
+        for (int base = 0; base < arows * (KC / 4); base += SB * 256) {
+            float4 t[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                t[i] = (f < arows * (KC / 4)) ? load_a_row(f, kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                if (f >= arows * (KC / 4)) continue;
+                const int row = f / (KC / 4), c4 = f - row * (KC / 4);
+                bf16x4 ph, pm, pl;
+                const float e[4] = {t[i].x, t[i].y, t[i].z, t[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    __bf16 h, m, l;
+                    split3(e[j], h, m, l);
+                    ph[j] = h; pm[j] = m; pl[j] = l;
+                }
+                char* d = As + row * APB + c4 * 8;
+                *(bf16x4*)(d) = ph; *(bf16x4*)(d + KC * 2) = pm; *(bf16x4*)(d + 2 * KC * 2) = pl;
+            }
+        }
+        __syncthreads();
+    };
+
+    if (NTAPS > 1) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) load_b(breg[d], 0, d);
+        for (int kc = 0; kc < nkc; ++kc) {
+            stage_a(kc);
+            // groups of D taps: the slot index is static inside a group, the group loop is not unrolled (registers)
+#pragma unroll 1
+            for (int t0 = 0; t0 < NTAPS; t0 += D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int tap = t0 + d;
+                    compute_tap(breg[d], tap);
+                    int ntap = tap + D, nk = kc;
+                    if (ntap >= NTAPS) { ntap -= NTAPS; ++nk; }
+                    if (nk < nkc) load_b(breg[d], nk, ntap);
+                }
+            }
+        }
+    } else {
+        // one tap: slot d holds chunk kc0 + d, refilled D chunks ahead
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+            if (d < nkc) load_b(breg[d], d, 0);
+        for (int kc0 = 0; kc0 < nkc; kc0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int kc = kc0 + d;
+                if (kc < nkc) {                       // uniform over the workgroup
+                    stage_a(kc);
+                    compute_tap(breg[d], 0);
+                    if (kc + D < nkc) load_b(breg[d], kc + D, 0);
+                }
+            }
+        }
+    }
+
+    __syncthreads();
+    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
+}
+
+template <int MT, int NT, int WM, int WN, int NTAPS, int D, int KCV, int MINB>
+__global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_bx6p(BxArgs args) {
+    const TapGemmArgs& g = args.g;
+    constexpr int KC = KCV;
+    constexpr int APB = 3 * KC * 2 + 16;              // LDS bytes per pixel row: 3 pieces x KC bf16 + pad (13 x 16 B)
+    constexpr int TM = MT / WM / 32, TN = NT / WN / 32;
+    constexpr int KS = KC / 16;                       // MFMA K-steps per chunk
+    constexpr int SB = 4;
+    static_assert(NTAPS == 1 || NTAPS % D == 0, "ring depth must divide the taps");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int halo = g.halo;
+    const int arows = MT + 2 * halo;
+    int* rowa = (int*)smem;
+    int* rowy = rowa + MT;
+    float* tile_lds = smem + 2 * MT;
+    char* As0 = (char*)tile_lds;                       // two A buffers: chunk kc is read from buffer kc & 1
+    const int abytes = (arows * APB + 15) / 16 * 16;
+    constexpr int NA = (MT + 2 * 104) * (KC / 4) / 256 + 1;   // float4 per thread of one A tile (planes up to 100 wide + halo)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+    const int swz = asr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_m = swz / g.ntn, tile_n = swz - tile_m * g.ntn;
+    const long p0 = (long)tile_m * MT;
+    const int n0 = tile_n * NT;
+    const int K = g.K, N = g.N, Kp = args.Kp;
+
+    if (tid < MT) {
+        const long p = p0 + tid;
+        int ra = -1, ry = -1;
+        if (p < g.M) {
+            if (g.H == 0) {
+                ra = (int)p; ry = (int)p;
+            } else {
+                const int b = (int)(p / g.HPWP);
+                const int r = (int)(p - (long)b * g.HPWP);
+                const int hh = r / g.WP, ww = r - hh * g.WP;
+                if (hh >= 1 && hh <= g.H && ww >= 1 && ww <= g.Wd) {
+                    ra = (int)p;
+                    ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : (int)p;
+                }
+            }
+        }
+        rowa[tid] = ra; rowy[tid] = ry;
+    }
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nkc = (K + KC - 1) / KC;
+    // ring of D slots, one slot = the B fragments of ONE tap for the KS K-steps of a chunk
+    bf16x8 breg[D][KS][TN][3];
+    const int ncol = n0 + wn * (TN * 32) + li;
+
+    auto load_b = [&](bf16x8 (&dst)[KS][TN][3], int kc, int tap) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kk = kc * KC + ks * 16 + 8 * lh;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int n = ncol + b * 32;
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) {
+                    bf16x8 v;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+                    if (kk < Kp && n < N) v = *(const bf16x8*)(args.Ws + (((long)tap * 3 + pc) * N + n) * Kp + kk);
+                    dst[ks][b][pc] = v;
+                }
+            }
+        }
+    };
+    auto load_a_row = [&](int f, int kc) -> float4 {
+        const int row = f / (KC / 4), c4 = f - row * (KC / 4);
+        const long grow = p0 - halo + row;
+        const int kk = kc * KC + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grow >= g.rmin && grow < g.rmax && kk < K) v = *(const float4*)(g.A + grow * g.lda + kk);
+        return v;
+    };
+    const char* As = As0;
+    auto compute_tap = [&](const bf16x8 (&bb)[KS][TN][3], int tap) {
+        const int toff = halo + tap_row_offset<NTAPS, 0>(tap, g.WP);
+        const char* abase = As + (wm * (TM * 32) + li + toff) * APB + lh * 16;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const bf16x8 ah = *(const bf16x8*)(abase + a * 32 * APB + ks * 32);
+                const bf16x8 am = *(const bf16x8*)(abase + a * 32 * APB + ks * 32 + KC * 2);
+                const bf16x8 al = *(const bf16x8*)(abase + a * 32 * APB + ks * 32 + 2 * KC * 2);
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    floatx16 c = acc[a][b];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bb[ks][b][0], c, 0, 0, 0);      // small terms first
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bb[ks][b][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bb[ks][b][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bb[ks][b][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bb[ks][b][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bb[ks][b][0], c, 0, 0, 0);
+                    acc[a][b] = c;
+                }
+            }
+        }
+    };
+
+    // A pipeline: the loads of chunk kc+1 are issued before the MFMAs of chunk kc and split / written to the other LDS
+    // buffer after them -- one barrier per chunk, the global latency hides under the matrix work.
+    float4 areg[NA];
+    auto fetch_a = [&](int kc) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = tid + i * 256;
+            areg[i] = (f < arows * (KC / 4)) ? load_a_row(f, kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto write_a = [&](char* dstbuf) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int f = tid + i * 256;
+            if (f >= arows * (KC / 4)) continue;
+            const int row = f / (KC / 4), c4 = f - row * (KC / 4);
+            bf16x4 ph, pm, pl;
+            const float e[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __bf16 h, m, l;
+                split3(e[j], h, m, l);
+                ph[j] = h; pm[j] = m; pl[j] = l;
+            }
+            char* d = dstbuf + row * APB + c4 * 8;
+            *(bf16x4*)(d) = ph; *(bf16x4*)(d + KC * 2) = pm; *(bf16x4*)(d + 2 * KC * 2) = pl;
+        }
+    };
+
+    static_assert(NTAPS > 1, "pipelined variant is for the 3x3 convs");
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_b(breg[d], 0, d);
+    fetch_a(0);
+    __syncthreads();                                   // rowa / rowy visible; nobody reads LDS yet
+    write_a(As0);
+    __syncthreads();
+    for (int kc = 0; kc < nkc; ++kc) {
+        As = As0 + (kc & 1) * abytes;
+        if (kc + 1 < nkc) fetch_a(kc + 1);
+#pragma unroll 1
+        for (int t0 = 0; t0 < NTAPS; t0 += D) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int tap = t0 + d;
+                compute_tap(breg[d], tap);
+                int ntap = tap + D, nk = kc;
+                if (ntap >= NTAPS) { ntap -= NTAPS; ++nk; }
+                if (nk < nkc) load_b(breg[d], nk, ntap);
+            }
+        }
+        if (kc + 1 < nkc) write_a(As0 + ((kc + 1) & 1) * abytes);     // the other buffer: last read in chunk kc-1, before the barrier below
+        __syncthreads();
+    }
+
+    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
+}
+
+template <int MT, int NT, int WM, int WN, int NTAPS, int D, int KCV, int MINB>
+int launch_bx6p(const TapGemmArgs& a, const __bf16* Ws, int Kp, hipStream_t st) {
+    auto kern = tap_gemm_kernel_bx6p<MT, NT, WM, WN, NTAPS, D, KCV, MINB>;
+    const int arows = MT + 2 * a.halo;
+    if (a.halo > 104) return ASR_ERR_UNSUPPORTED;
+    const size_t abytes = ((size_t)arows * (3 * KCV * 2 + 16) + 15) / 16 * 16;
+    size_t lds = 2 * abytes + 2 * MT * sizeof(int);
+    if (lds < kEpilogueLds + 2 * MT * sizeof(int)) lds = kEpilogueLds + 2 * MT * sizeof(int);
+    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    BxArgs b;
+    b.g = a; b.Ws = Ws; b.Kp = Kp;
+    b.g.ntm = asr_cdiv(a.M, MT);
+    b.g.ntn = asr_cdiv(a.N, NT);
+    hipLaunchKernelGGL(kern, dim3(b.g.ntm * b.g.ntn), dim3(256), lds, st, b);
+    ASR_CHECK_LAUNCH("tap_gemm_bx6p");
+    return ASR_OK;
+}
+
+// W [ntaps][K][N] (HWIO; wmode 0) or its data-gradient view (wmode 1: taps mirrored, K and N swapped) ->
+// Ws [ntaps][3][Nout][Kp] bf16, Kp = K rounded up to 32 (zero-filled): the B fragments of tap_gemm_kernel_bx6
+__global__ void split_weights_kernel(const float* __restrict__ W, int ntaps, int K, int N, int ldw, int wmode, int Kp,
+                                     __bf16* __restrict__ out) {
+    const long total = (long)ntaps * N * Kp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % Kp);
+        const long r = i / Kp;
+        const int n = (int)(r % N), tap = (int)(r / N);
+        float x = 0.f;
+        if (k < K) x = (wmode == 0) ? W[((long)tap * K + k) * ldw + n] : W[((long)(ntaps - 1 - tap) * N + n) * ldw + k];
+        __bf16 h, m, l;
+        split3(x, h, m, l);
+        out[(((long)tap * 3 + 0) * N + n) * Kp + k] = h;
+        out[(((long)tap * 3 + 1) * N + n) * Kp + k] = m;
+        out[(((long)tap * 3 + 2) * N + n) * Kp + k] = l;
+    }
+}
+
+template <int MT, int NT, int WM, int WN, int NTAPS, int D, int KCV = 32, int MINB = 3>
+int launch_bx6(const TapGemmArgs& a, const __bf16* Ws, int Kp, hipStream_t st) {
+    auto kern = tap_gemm_kernel_bx6<MT, NT, WM, WN, NTAPS, D, KCV, MINB>;
+    const int arows = MT + 2 * a.halo;
+    size_t lds = (size_t)arows * (3 * KCV * 2 + 16) + 2 * MT * sizeof(int);
+    if (lds < kEpilogueLds + 2 * MT * sizeof(int)) lds = kEpilogueLds + 2 * MT * sizeof(int);
+    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    BxArgs b;
+    b.g = a; b.Ws = Ws; b.Kp = Kp;
+    b.g.ntm = asr_cdiv(a.M, MT);
+    b.g.ntn = asr_cdiv(a.N, NT);
+    hipLaunchKernelGGL(kern, dim3(b.g.ntm * b.g.ntn), dim3(256), lds, st, b);
+    ASR_CHECK_LAUNCH("tap_gemm_bx6");
+    return ASR_OK;
+}
+
 // Two generations of the main loop are kept because neither wins everywhere (tools/bench_layers.py,
 // MI355X): v1 (single-buffered tiles, two barriers per tap, 3 workgroups per CU) is faster wherever
 // thread-level parallelism hides the staging; v2 (double-buffered W, register-prefetched A, one barrier
@@ -985,4 +1415,65 @@ extern "C" int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float*
     if (d->ntaps == 9) return d->wmode ? launch_n<9, 1>(a, st) : launch_n<9, 0>(a, st);
     if (d->ntaps == 4) return d->wmode ? launch_n<4, 1>(a, st) : launch_n<4, 0>(a, st);
     return d->wmode ? launch_n<1, 1>(a, st) : launch_n<1, 0>(a, st);
+}
+
+
+// ---- EXPERIMENTAL split-bf16 path (include/asr_hip.h): weights pre-split by asr_split_weights, then asr_tap_gemm_bx6
+extern "C" size_t asr_split_weights_bytes(int ntaps, int K, int N) {
+    const int Kp = (K + 31) / 32 * 32;
+    return (size_t)ntaps * 3 * N * Kp * 2;
+}
+
+extern "C" int asr_split_weights(const float* W, int ntaps, int K, int N, int ldw, int wmode, void* out, void* stream) {
+    if (!W || !out || (ntaps != 1 && ntaps != 9) || K < 1 || N < 1) return ASR_ERR_BAD_ARG;
+    const int Kp = (K + 31) / 32 * 32;
+    const long total = (long)ntaps * N * Kp;
+    long nb = (total + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, W, ntaps, K, N, ldw, wmode, Kp,
+                       (__bf16*)out);
+    ASR_CHECK_LAUNCH("split_weights");
+    return ASR_OK;
+}
+
+extern "C" int asr_tap_gemm_bx6(const asr_gemm_desc* d, const float* A, const void* Wsplit,
+                                const float* bias, const float* scale, const float* shift,
+                                float* out_a, float* out_y, void* stream) {
+    if (!d || !A || !Wsplit || (!out_a && !out_y)) return ASR_ERR_BAD_ARG;
+    if (d->ntaps != 1 && d->ntaps != 9) return ASR_ERR_BAD_ARG;
+    if ((d->K & 3) || (d->N & 3) || (d->lda & 3)) return ASR_ERR_BAD_ARG;
+    if (d->ntaps == 9 && d->H <= 0) return ASR_ERR_BAD_ARG;
+    if (((uintptr_t)A | (uintptr_t)Wsplit) & 15) return ASR_ERR_BAD_ARG;
+    TapGemmArgs a;
+    a.A = A; a.W = nullptr; a.bias = bias; a.scale = scale; a.shift = shift;
+    a.out_a = out_a; a.out_y = out_y;
+    a.M = d->M; a.K = d->K; a.N = d->N; a.lda = d->lda; a.ldw = d->ldw;
+    a.ldo_a = d->ldo_a; a.ldo_y = d->ldo_y;
+    a.H = d->H; a.Wd = d->W; a.WP = d->W + 1; a.HPWP = (d->H + 1) * (d->W + 1);
+    if (d->H > 0 && d->M != d->B * a.HPWP) return ASR_ERR_BAD_ARG;
+    a.halo = (d->ntaps != 1) ? a.WP + 1 : 0;
+    a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
+    a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
+    a.ntm = a.ntn = 0; a.ablate = 0;
+    const int Kp = (d->K + 31) / 32 * 32;
+    hipStream_t st = (hipStream_t)stream;
+    const __bf16* Ws = (const __bf16*)Wsplit;
+    // Tile choice (tools/bench_bx6.py, MI355X): with the matrix pipe 2.6x faster the kernel is bound by operand traffic,
+    // and the per-wave weight fragments (global / L2 loads) dominate it: 128x32 wave tiles (256x64 workgroups, 2 waves
+    // per SIMD, no spills) reach 161-180 fp32-equivalent TFLOP/s where 64x32 wave tiles stop at 140-148 and 128x64
+    // ones spill.  Register-prefetching the A tile (one barrier per chunk) is slower, as for the fp32 kernels.
+    static int cfg = -1;
+    if (cfg < 0) { const char* e = getenv("ASR_BX6_CFG"); cfg = e ? atoi(e) : 0; }
+    if (d->ntaps == 9) {
+        if (d->N > 32) {
+            if (cfg == 2) return launch_bx6<128, 64, 2, 2, 9, 3, 16, 3>(a, Ws, Kp, st);
+            if (cfg == 6) return launch_bx6p<128, 64, 2, 2, 9, 3, 16, 3>(a, Ws, Kp, st);
+            if (cfg == 13 && d->N > 64) return launch_bx6<256, 128, 2, 2, 9, 3, 16, 2>(a, Ws, Kp, st);
+            return launch_bx6<256, 64, 2, 2, 9, 3, 16, 2>(a, Ws, Kp, st);
+        }
+        return launch_bx6<256, 32, 4, 1, 9, 3, 16, 3>(a, Ws, Kp, st);
+    }
+    if (d->N > 32 && cfg != 2) return launch_bx6<256, 64, 2, 2, 1, 2, 32, 2>(a, Ws, Kp, st);
+    if (d->N > 32) return launch_bx6<128, 64, 2, 2, 1, 2>(a, Ws, Kp, st);
+    return launch_bx6<256, 32, 4, 1, 1, 2>(a, Ws, Kp, st);
 }

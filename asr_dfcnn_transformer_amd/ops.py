@@ -452,3 +452,23 @@ def pix_ln_bwd(dy, xhat, rstd, gamma, dx, dgamma, dbeta, ws):
 def maxpool_bwd(dy, y, dx):
     """dy: pooled-gradient Plane, y: the pooled tensor's input Plane, dx: Plane like y."""
     check(_lib.load().asr_maxpool_bwd(dy.ptr, y.ptr, y.B, y.H, y.W, y.C, dx.ptr, _stream()), 'asr_maxpool_bwd')
+
+
+# ---------------------------------------------------------------------------- experimental split-bf16 contractions
+def split_weights(W, ntaps, K, N, ldw, wmode=0, out=None):
+    """bf16 [ntaps][3][N][Kp] pieces of a weight tensor (see include/asr_hip.h); returns the uint8 buffer."""
+    lib = _lib.load()
+    nbytes = lib.asr_split_weights_bytes(ntaps, K, N)
+    if out is None:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
+    check(lib.asr_split_weights(_ptr(W), ntaps, K, N, ldw, wmode, _ptr(out), _stream()), 'asr_split_weights')
+    return out
+
+
+def tap_gemm_bx6(desc, A, Wsplit, bias=None, scale=None, shift=None, out_a=None, out_y=None):
+    lib = _lib.load()
+    pa = A.ptr if isinstance(A, Plane) else _ptr(A)
+    po_a = out_a.ptr if isinstance(out_a, Plane) else _ptr(out_a)
+    po_y = out_y.ptr if isinstance(out_y, Plane) else _ptr(out_y)
+    check(lib.asr_tap_gemm_bx6(C.byref(desc), pa, _ptr(Wsplit), _ptr(bias), _ptr(scale), _ptr(shift), po_a, po_y, _stream()),
+          'asr_tap_gemm_bx6')

@@ -349,6 +349,19 @@ size_t asr_pix_ln_bwd_workspace(const asr_pixmap* m);
 int asr_pix_ln_bwd(const float* dy, const float* xhat, const float* rstd, const asr_pixmap* m, const float* gamma,
                    float* dx, float* dgamma, float* dbeta, float* workspace, void* stream);
 
+/* ====================================================================== EXPERIMENTAL: split-bf16 contractions
+ * (DESIGN.md section 9).  Same contraction and epilogue as asr_tap_gemm, computed as six v_mfma_f32_32x32x16_bf16
+ * products of the hi/mid/lo bf16 pieces of the fp32 operands with fp32 accumulation (fp32-chain accuracy, 2.6x the matrix
+ * pipe rate).  The weights are pre-split and transposed once per optimiser step:
+ *   asr_split_weights(W, ntaps, K, N, ldw, wmode, out): out = bf16 [ntaps][3][N][Kp], Kp = K rounded up to 32; wmode 1
+ *   takes the data-gradient view of a forward tensor (K, N = the GEMM's, i.e. swapped; taps mirrored), after which
+ *   asr_tap_gemm_bx6 is called with desc.wmode ignored.  NOT used by the engines / bench unless ASR_BX6=1. */
+size_t asr_split_weights_bytes(int ntaps, int K, int N);
+int asr_split_weights(const float* W, int ntaps, int K, int N, int ldw, int wmode, void* out, void* stream);
+int asr_tap_gemm_bx6(const asr_gemm_desc* d, const float* A, const void* Wsplit,
+                     const float* bias, const float* scale, const float* shift,
+                     float* out_a, float* out_y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
