@@ -310,6 +310,18 @@ class DFCNNEngine:
         # backward prologue can run while the previous weight-gradient (MFMA-bound) still reads the other one
         self.dz_alt = {geo: Plane(p.B, p.H, p.W, p.C, dev) for geo, p in self.dz_pool.items()} if self.side is not None else {}
         self._decode_done = None
+        # EXPERIMENTAL (ASR_BX6=1): forward and data-gradient of the 3x3 convs on the split-bf16
+        # kernels.  The fp32 weights stay the parameters; their hi/mid/lo bf16 pieces (forward view and mirrored
+        # data-gradient view) are regenerated at the start of every forward pass.
+        self.bx6 = os.environ.get('ASR_BX6', '0') == '1'
+        self.ws_f, self.ws_b = {}, {}
+        self._cell_dims = {op[2]: (op[3], op[4]) for op in self.g if op[0] == 'cell'}
+        if self.bx6:
+            for op in self.g:
+                if op[0] == 'cell' and op[1] != 'x' and op[5] == 3:
+                    _, src, dst, cin, cout, k, pool = op
+                    self.ws_f[dst] = torch.zeros(ops.split_weights_bytes(9, cin, cout), dtype=torch.uint8, device=dev)
+                    self.ws_b[dst] = torch.zeros(ops.split_weights_bytes(9, cout, cin), dtype=torch.uint8, device=dev)
         self.labels = torch.zeros(B, MAX_LABEL, dtype=torch.int32, device=dev)
         self.label_len = torch.zeros(B, dtype=torch.int32, device=dev)
         self.seq_len = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -349,6 +361,10 @@ class DFCNNEngine:
         assert x.is_contiguous() and tuple(x.shape) == (self.B, self.T, self.F)
         self.x = x
         self.refresh_bn()
+        for dst, buf in self.ws_f.items():
+            cin, cout = self._cell_dims[dst]
+            ops.split_weights(self.p(dst, 'w'), 9, cin, cout, cout, 0, buf)
+            ops.split_weights(self.p(dst, 'w'), 9, cout, cin, cout, 1, self.ws_b[dst])
         for op in self.g:
             if op[0] == 'cell':
                 _, src, dst, cin, cout, k, pool = op
@@ -358,8 +374,11 @@ class DFCNNEngine:
                     ops.cell1_fwd(x, self.p(dst, 'w'), self.p(dst, 'b'), sc, sh, pm, self.y[dst])
                     continue
                 out_y = None if pool else (self.flat[dst] if dst in self.flat else self.y[dst])
-                ops.tap_gemm(self.fdesc[dst], self.y[src], self.p(dst, 'w'), self.p(dst, 'b'), sc, sh,
-                             self.a[dst], out_y)
+                if dst in self.ws_f:
+                    ops.tap_gemm_bx6(self.fdesc[dst], self.y[src], self.ws_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], out_y)
+                else:
+                    ops.tap_gemm(self.fdesc[dst], self.y[src], self.p(dst, 'w'), self.p(dst, 'b'), sc, sh,
+                                 self.a[dst], out_y)
                 if pool:
                     ops.pool_fwd(self.a[dst], sc, sh, pm, self.y[dst])
             elif op[0] == 'se':
@@ -516,7 +535,10 @@ class DFCNNEngine:
                 dx, acc = grad_target(src)
                 d = self.bdesc[dst]
                 d.accumulate = 1 if acc else 0
-                ops.tap_gemm(d, dz, self.p(dst, 'w'), None, None, None, None, dx)
+                if dst in self.ws_b:
+                    ops.tap_gemm_bx6(d, dz, self.ws_b[dst], None, None, None, None, dx, dgrad=True)
+                else:
+                    ops.tap_gemm(d, dz, self.p(dst, 'w'), None, None, None, None, dx)
         if side_busy is not None:
             torch.cuda.current_stream().wait_event(side_busy)
         if self._decode_done is not None:

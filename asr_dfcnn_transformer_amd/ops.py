@@ -455,6 +455,10 @@ def maxpool_bwd(dy, y, dx):
 
 
 # ---------------------------------------------------------------------------- experimental split-bf16 contractions
+def split_weights_bytes(ntaps, K, N):
+    return _lib.load().asr_split_weights_bytes(ntaps, K, N)
+
+
 def split_weights(W, ntaps, K, N, ldw, wmode=0, out=None):
     """bf16 [ntaps][3][N][Kp] pieces of a weight tensor (see include/asr_hip.h); returns the uint8 buffer."""
     lib = _lib.load()
@@ -465,10 +469,26 @@ def split_weights(W, ntaps, K, N, ldw, wmode=0, out=None):
     return out
 
 
-def tap_gemm_bx6(desc, A, Wsplit, bias=None, scale=None, shift=None, out_a=None, out_y=None):
+def tap_gemm_bx6(desc, A, Wsplit, bias=None, scale=None, shift=None, out_a=None, out_y=None, dgrad=False):
     lib = _lib.load()
     pa = A.ptr if isinstance(A, Plane) else _ptr(A)
     po_a = out_a.ptr if isinstance(out_a, Plane) else _ptr(out_a)
     po_y = out_y.ptr if isinstance(out_y, Plane) else _ptr(out_y)
-    check(lib.asr_tap_gemm_bx6(C.byref(desc), pa, _ptr(Wsplit), _ptr(bias), _ptr(scale), _ptr(shift), po_a, po_y, _stream()),
-          'asr_tap_gemm_bx6')
+    t = TIMER
+    call = lambda: check(lib.asr_tap_gemm_bx6(C.byref(desc), pa, _ptr(Wsplit), _ptr(bias), _ptr(scale), _ptr(shift), po_a, po_y,
+                                              _stream()), 'asr_tap_gemm_bx6')
+    key = bx6_symbol(desc.ntaps, desc.N) + (' [dgrad]' if dgrad else '')      # one symbol serves both directions
+    if t is None or not t.want(key):
+        return call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call()
+    e1.record()
+    t.add(key, _flops(desc), e0, e1)
+
+
+def bx6_symbol(ntaps, N):
+    """kernel instantiation asr_tap_gemm_bx6 launches (mirrors the rules in csrc/tap_gemm.hip)"""
+    if ntaps == 9:
+        return 'tap_gemm_kernel_bx6<256, 64, 2, 2, 9, 3, 16, 2>' if N > 32 else 'tap_gemm_kernel_bx6<256, 32, 4, 1, 9, 3, 16, 3>'
+    return 'tap_gemm_kernel_bx6<256, 64, 2, 2, 1, 2, 32, 2>' if N > 32 else 'tap_gemm_kernel_bx6<256, 32, 4, 1, 1, 2, 32, 3>'

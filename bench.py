@@ -32,8 +32,16 @@ def kernel_name(key):
     return key
 
 
+def kernel_peak(sym):
+    """fp32 MFMA peak, or -- for the experimental split-bf16 kernels, whose fp32-equivalent flop is six bf16 MFMA flops --
+    the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md) divided by 6."""
+    return round(2500.0 / 6.0, 1) if sym.startswith('tap_gemm_kernel_bx6') else FP32_PEAK_TFLOPS
+
+
 def is_forward_symbol(sym):
     """tap_gemm_kernel[_v1]<MT, NT, WM, WN, NTAPS, WMODE[, KC]>: WMODE 0 = forward (conv / dense), 1 = data-gradient."""
+    if sym.startswith('tap_gemm_kernel_bx6'):          # split-bf16 kernels: one symbol for both directions, tagged by ops
+        return '[dgrad]' not in sym
     if not sym.startswith('tap_gemm_kernel'):
         return False
     args = [a.strip() for a in sym[sym.index('<') + 1:sym.rindex('>')].split(',')]
@@ -351,9 +359,11 @@ def main():
                        'step_tflops': round(utt_s / world * fstep / 1e12, 2),
                        'step_frac_of_fp32_peak': round(utt_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
                        'backward_streams': 2 if overlapped else 1, 'feature_prefetch': prefetch,
+                       'conv_arithmetic': ('split-bf16 x6 products, fp32 accumulate (EXPERIMENTAL, ASR_BX6=1) for conv fwd/dgrad; '
+                                           'fp32 MFMA elsewhere') if eng.bx6 else 'fp32 MFMA',
                        'mean_loss': round(mean_loss, 4)},
-            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / FP32_PEAK_TFLOPS, 4), 'traffic': None,
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': kernel_peak(dom), 'unit': 'TFLOP/s',
+                         'frac': round(achieved / kernel_peak(dom), 4), 'traffic': None,
                          'kernel': kernel_name(dom),
                          'launches_per_step': nl // args.steps, 'avg_launch_us': round(1e3 * ms / nl, 2),
                          'flop_per_launch': round(fl / nl / 1e9, 3), 'flop_unit': 'GFLOP',
