@@ -32,6 +32,7 @@ SIGNATURES = {
     'asr_split_weights_bytes': (_Z, [_I, _I, _I]),
     'asr_split_weights': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'asr_tap_gemm_bx6': (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    'asr_tap_wgrad_bx6': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _P, _P, _P]),
     'asr_tap_wgrad_workspace': (_Z, [C.POINTER(GemmDesc)]),
     'asr_tap_wgrad': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _P, _P, _P]),
     'asr_cell1_fwd': (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),

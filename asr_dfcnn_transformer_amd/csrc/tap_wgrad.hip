@@ -383,6 +383,153 @@ __global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_v1(WgradArgs g) {
             }
 }
 
+// ---- bx6: EXPERIMENTAL split-bf16 weight gradient (forward / data-gradient twin in tap_gemm.hip).
+// The contraction index is the PIXEL, so both MFMA operands need, per lane, 8 consecutive pixels of one channel --
+// a transposed view of the natural [pixel][channel] tiles.  The tiles are staged as they come (split into hi/mid/lo
+// bf16 pieces, channel-contiguous rows) and read with gfx950's transposing ds_read_b64_tr_b16: a 16-lane group fetches
+// a 4-pixel x 16-channel block and every lane receives its channel's 4 pixels.  A tap is a ROW offset of the A image,
+// so the nine taps need no alignment of any kind.  One workgroup = 32 input channels x 128 output channels x 9 taps.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+typedef short wshort4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wsplit3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+// 8 consecutive rows (pixels) of this lane's column, from a [row][column] bf16 image: two transposed 4 x 16 block reads.
+// `p` = address of (first row + (lane&15)>>2, first column of the lane's 16-group + 4*(lane&3)); EXEC must be all ones.
+__device__ __forceinline__ wbf16x8 tr_read8(const char* p, int pitch) {
+    typedef wshort4 __attribute__((address_space(3)))* lptr;
+    const wshort4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
+    const wshort4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 4 * pitch));
+    union { wshort4 s[2]; wbf16x8 v; } u;
+    u.s[0] = a; u.s[1] = b;
+    return u.v;
+}
+
+template <int PS>
+__global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_bx6(WgradArgs g) {
+    constexpr int KT = 32, NT = 128, NTAPS = 9;
+    constexpr int AP = KT * 2 + 8;        // bytes per A row of one piece
+    constexpr int ZP = NT * 2 + 8;        // bytes per dZ row of one piece
+    extern __shared__ __attribute__((aligned(16))) char wsm[];
+    const int halo = g.halo;
+    const int arows = PS + 2 * halo;
+    char* As = wsm;                                               // [3][arows][AP]
+    char* Zs = wsm + (3 * arows * AP + 15) / 16 * 16;             // [3][PS][ZP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+    const int lh = lane >> 5, gg = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3, li = lane & 31;
+    const int chunk = blockIdx.x;
+    const int k0 = blockIdx.y * KT, n0 = blockIdx.z * NT;
+    const long cbeg = (long)chunk * g.pch;
+    const long cend = (cbeg + g.pch < g.M) ? cbeg + g.pch : g.M;
+
+    floatx16 acc[NTAPS];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // per-lane byte offsets of the transposed block reads (row part is added per step / tap)
+    const int a_col = (8 * lh + q) * AP + (16 * gg + 4 * pp) * 2;
+    const int z_col = (8 * lh + q) * ZP + (wn * 32 + 16 * gg + 4 * pp) * 2;
+
+    for (long ps0 = cbeg; ps0 < cend; ps0 += PS) {
+        __syncthreads();
+        constexpr int SB = 4;
+        for (int base = 0; base < arows * (KT / 4); base += SB * 256) {
+            float4 t[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                const int row = f / (KT / 4), c4 = f - row * (KT / 4);
+                const long grow = ps0 - halo + row;
+                const int kk = k0 + c4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < arows * (KT / 4) && grow >= g.rmin && grow < g.rmax && kk < g.K) v = *(const float4*)(g.A + grow * g.lda + kk);
+                t[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                if (f >= arows * (KT / 4)) continue;
+                const int row = f / (KT / 4), c4 = f - row * (KT / 4);
+                wbf16x4 ph, pm, pl;
+                const float e[4] = {t[i].x, t[i].y, t[i].z, t[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { __bf16 h, m, l; wsplit3(e[j], h, m, l); ph[j] = h; pm[j] = m; pl[j] = l; }
+                char* d = As + row * AP + c4 * 8;
+                *(wbf16x4*)(d) = ph; *(wbf16x4*)(d + arows * AP) = pm; *(wbf16x4*)(d + 2 * arows * AP) = pl;
+            }
+        }
+        for (int base = 0; base < PS * (NT / 4); base += SB * 256) {
+            float4 t[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                const int row = f / (NT / 4), n4 = f - row * (NT / 4);
+                const long grow = ps0 + row;
+                const int nn = n0 + n4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (f < PS * (NT / 4) && grow < cend && nn < g.N) v = *(const float4*)(g.Z + grow * g.ldz + nn);
+                t[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                if (f >= PS * (NT / 4)) continue;
+                const int row = f / (NT / 4), n4 = f - row * (NT / 4);
+                wbf16x4 ph, pm, pl;
+                const float e[4] = {t[i].x, t[i].y, t[i].z, t[i].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { __bf16 h, m, l; wsplit3(e[j], h, m, l); ph[j] = h; pm[j] = m; pl[j] = l; }
+                char* d = Zs + row * ZP + n4 * 8;
+                *(wbf16x4*)(d) = ph; *(wbf16x4*)(d + PS * ZP) = pm; *(wbf16x4*)(d + 2 * PS * ZP) = pl;
+            }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int pix = 0; pix < PS; pix += 16) {
+            const char* zb = Zs + pix * ZP + z_col;
+            const wbf16x8 zh = tr_read8(zb, ZP), zm = tr_read8(zb + PS * ZP, ZP), zl = tr_read8(zb + 2 * PS * ZP, ZP);
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                const int off = ((t / 3) - 1) * g.WP + (t % 3) - 1;
+                const char* ab = As + (pix + halo + off) * AP + a_col;
+                const wbf16x8 ah = tr_read8(ab, AP), am = tr_read8(ab + arows * AP, AP), al = tr_read8(ab + 2 * arows * AP, AP);
+                floatx16 c = acc[t];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, zh, c, 0, 0, 0);      // small terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, zl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, zm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, zh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, zm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, zh, c, 0, 0, 0);
+                acc[t] = c;
+                // keep the compiler from hoisting all 27 A fragments of a step ahead of the MFMAs (144 accumulator
+                // registers leave no room for them); the reads of tap t+1 still overlap the queued MFMAs of tap t
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    float* out = g.out + (long)chunk * g.slab;
+    const int n = n0 + wn * 32 + li;
+    if (n < g.N) {
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (k < g.K) out[((long)t * g.K + k) * g.N + n] = acc[t][r];
+            }
+    }
+}
+
 // ---- v3: as v1, but dZ never touches LDS.  A wave only needs its own 32 output channels of dZ, and for a
 // pixel pair that is one coalesced 2 x 128-byte row segment per wave: it is loaded straight into registers
 // (all pairs of the run up front, before the A staging and its barriers, so the latency is covered) and used
@@ -660,6 +807,44 @@ extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float
         const int threads = 64;
         const int blocks = asr_cdiv(asr_cdiv(n, 4), threads);
         hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks), dim3(threads), 0, st, partials, dW, n, p.nchunks);
+        ASR_CHECK_LAUNCH("sum_chunks");
+    }
+    return ASR_OK;
+}
+
+
+// EXPERIMENTAL split-bf16 weight gradient (3x3 taps, N >= 128 and K >= 32): same contract as asr_tap_wgrad
+extern "C" int asr_tap_wgrad_bx6(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz,
+                                 float* dW, float* partials, void* stream) {
+    if (!d || !A || !dZ || !dW) return ASR_ERR_BAD_ARG;
+    if (d->ntaps != 9 || d->H <= 0 || d->N <= 64) return ASR_ERR_UNSUPPORTED;
+    if ((d->K & 3) || (d->N & 3) || (d->lda & 3) || (ldz & 3)) return ASR_ERR_BAD_ARG;
+    const Plan p = make_plan(d);                 // ktile 32, ntile 128, PS 64 for N > 64
+    if (p.nchunks > 1 && !partials) return ASR_ERR_BAD_ARG;
+    WgradArgs a;
+    a.A = A; a.Z = dZ; a.out = (p.nchunks > 1) ? partials : dW;
+    a.M = d->M; a.K = d->K; a.N = d->N; a.lda = d->lda; a.ldz = ldz;
+    a.WP = d->W + 1;
+    a.halo = a.WP + 1;
+    a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
+    a.pch = p.pch;
+    a.slab = (long)d->ntaps * d->K * d->N;
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int PS = 64;
+    const int arows = PS + 2 * a.halo;
+    const size_t lds = ((size_t)3 * arows * (32 * 2 + 8) + 15) / 16 * 16 + (size_t)3 * PS * (128 * 2 + 8);
+    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
+    auto kern = tap_wgrad_kernel_bx6<PS>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.nchunks, asr_cdiv(d->K, 32), asr_cdiv(d->N, 128)), dim3(256), lds, st, a);
+    ASR_CHECK_LAUNCH("tap_wgrad_bx6");
+    if (p.nchunks > 1) {
+        const long n = a.slab;
+        hipLaunchKernelGGL(sum_chunks_kernel, dim3(asr_cdiv(asr_cdiv(n, 4), 64)), dim3(64), 0, st, partials, dW, n, p.nchunks);
         ASR_CHECK_LAUNCH("sum_chunks");
     }
     return ASR_OK;

@@ -521,14 +521,16 @@ class DFCNNEngine:
                     torch.cuda.current_stream().wait_event(dz_reader.pop(id(dz)))
                 ops.cell_bwd_pre(dyv, layout, self.a[dst], sc, sh, pm, dz, self.dscale_of(dst),
                                  self.gview(dst, 'beta'), self.gview(dst, 'b'), self.ws)
+                # split-bf16 weight gradient where it wins (tools/bench_bx6.py): narrow planes (small halo) and >= 128 outputs
+                wgrad = ops.tap_wgrad_bx6 if (self.bx6 and k == 3 and cout >= 128 and W <= 32) else ops.tap_wgrad
                 if self.side is None:
-                    ops.tap_wgrad(self.wdesc[dst], self.y[src], dz, cout, self.gview(dst, 'w'), self.ws)
+                    wgrad(self.wdesc[dst], self.y[src], dz, cout, self.gview(dst, 'w'), self.ws)
                 else:
                     dz_ready = torch.cuda.Event()
                     dz_ready.record()
                     self.side.wait_event(dz_ready)
                     with torch.cuda.stream(self.side):
-                        ops.tap_wgrad(self.wdesc[dst], self.y[src], dz, cout, self.gview(dst, 'w'), self.ws_side)
+                        wgrad(self.wdesc[dst], self.y[src], dz, cout, self.gview(dst, 'w'), self.ws_side)
                         side_busy = torch.cuda.Event()
                         side_busy.record()
                         dz_reader[id(dz)] = side_busy

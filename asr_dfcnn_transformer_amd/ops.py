@@ -492,3 +492,10 @@ def bx6_symbol(ntaps, N):
     if ntaps == 9:
         return 'tap_gemm_kernel_bx6<256, 64, 2, 2, 9, 3, 16, 2>' if N > 32 else 'tap_gemm_kernel_bx6<256, 32, 4, 1, 9, 3, 16, 3>'
     return 'tap_gemm_kernel_bx6<256, 64, 2, 2, 1, 2, 32, 2>' if N > 32 else 'tap_gemm_kernel_bx6<256, 32, 4, 1, 1, 2, 32, 3>'
+
+
+def tap_wgrad_bx6(desc, A, dZ, ldz, dW, partials):
+    lib = _lib.load()
+    pa = A.ptr if isinstance(A, Plane) else _ptr(A)
+    pz = dZ.ptr if isinstance(dZ, Plane) else _ptr(dZ)
+    check(lib.asr_tap_wgrad_bx6(C.byref(desc), pa, pz, ldz, _ptr(dW), _ptr(partials), _stream()), 'asr_tap_wgrad_bx6')

@@ -105,6 +105,14 @@ class PreNetEngine:
         self.dz_alt = pl() if self.side is not None else None
         self._busy = {}            # id(plane) -> event of the last side-stream reader
         self._flip = False
+        # EXPERIMENTAL (ASR_BX6=1): the six 3x3 stride-1 convs (forward + data-gradient) on the split-bf16 kernels
+        self.bx6 = os.environ.get('ASR_BX6', '0') == '1'
+        self.ws_f, self.ws_b = {}, {}
+        if self.bx6:
+            for k, cin in (('q', CH), ('k', CH), ('v', CH), ('merge', 2 * CH), ('f1', CH), ('f2', CH)):
+                self.ws_f[k] = torch.zeros(ops.split_weights_bytes(9, cin, CH), dtype=torch.uint8, device=device)
+                self.ws_b[k] = torch.zeros(ops.split_weights_bytes(9, CH, cin), dtype=torch.uint8, device=device)
+            self._cin = {'q': CH, 'k': CH, 'v': CH, 'merge': 2 * CH, 'f1': CH, 'f2': CH}
 
     # ---- parameters
     def p(self, name, buf=None):
@@ -182,7 +190,10 @@ class PreNetEngine:
         self._last_side = done
 
     def _conv(self, name, src, dst):
-        ops.tap_gemm(self.d_conv[name], src, self.p(name + '/w'), self.p(name + '/b'), None, None, dst, None)
+        if name in self.ws_f:
+            ops.tap_gemm_bx6(self.d_conv[name], src, self.ws_f[name], self.p(name + '/b'), None, None, dst, None)
+        else:
+            ops.tap_gemm(self.d_conv[name], src, self.p(name + '/w'), self.p(name + '/b'), None, None, dst, None)
 
     def _conv_bwd(self, name, src, dz, dx, accumulate):
         """parameter gradients of conv `name` (input plane src, pre-activation gradient dz) and dx (+)= its data gradient"""
@@ -194,7 +205,10 @@ class PreNetEngine:
             self._wait_readers(dx)                  # dx may be a plane an earlier weight-gradient still reads (ds)
             d = self.d_dx[name]
             d.accumulate = 1 if accumulate else 0
-            ops.tap_gemm(d, dz, self.p(name + '/w'), None, None, None, None, dx)
+            if name in self.ws_b:
+                ops.tap_gemm_bx6(d, dz, self.ws_b[name], None, None, None, None, dx, dgrad=True)
+            else:
+                ops.tap_gemm(d, dz, self.p(name + '/w'), None, None, None, None, dx)
 
     # ---- forward / backward
     def forward(self, x):
@@ -202,6 +216,10 @@ class PreNetEngine:
         B, H2, W2 = self.B, self.H2, self.W2
         assert tuple(x.shape) == (B, self.T, self.F) and x.is_contiguous() and x.dtype == torch.float32
         self.x = x
+        for k, buf in self.ws_f.items():
+            cin = self._cin[k]
+            ops.split_weights(self.p(k + '/w'), 9, cin, CH, CH, 0, buf)
+            ops.split_weights(self.p(k + '/w'), 9, CH, cin, CH, 1, self.ws_b[k])
         ops.prenet_conv1_fwd(x, self.p('conv1/w'), self.p('conv1/b'), self.a1)
         self._bn('bn1', self.a1, self.x1s, dst_phase_split=True)
         ops.conv_s2_expand(self.p('conv2/w'), CH, CH, self.W4)

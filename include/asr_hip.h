@@ -358,6 +358,10 @@ int asr_pix_ln_bwd(const float* dy, const float* xhat, const float* rstd, const 
  *   asr_tap_gemm_bx6 is called with desc.wmode ignored.  NOT used by the engines / bench unless ASR_BX6=1. */
 size_t asr_split_weights_bytes(int ntaps, int K, int N);
 int asr_split_weights(const float* W, int ntaps, int K, int N, int ldw, int wmode, void* out, void* stream);
+/* split-bf16 weight gradient (3x3 taps, N > 64): same arguments and workspace as asr_tap_wgrad; operands are split at
+ * staging time and read transposed from LDS (ds_read_b64_tr_b16). */
+int asr_tap_wgrad_bx6(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz,
+                      float* dW, float* partials, void* stream);
 int asr_tap_gemm_bx6(const asr_gemm_desc* d, const float* A, const void* Wsplit,
                      const float* bias, const float* scale, const float* shift,
                      float* out_a, float* out_y, void* stream);

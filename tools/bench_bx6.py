@@ -67,3 +67,24 @@ for name, M, K, N in DENSE:
     print('%-22s fwd  fp32 %7.1f us %6.1f TF | bx6 %7.1f us %6.1f TF (x%.2f) | err vs f64: fp32 %.2e bx6 %.2e'
           % (name, 1e3 * t32, fl / t32 / 1e9, 1e3 * t6, fl / t6 / 1e9, t32 / t6,
              (y32[:256].double() - ref).abs().max().item(), (y6[:256].double() - ref).abs().max().item()))
+
+
+print('--- weight gradient')
+for name, H, W, cin, cout in SHAPES:
+    if cout <= 64:
+        continue
+    g = torch.Generator(device='cuda').manual_seed(2)
+    x = Plane(B, H, W, cin); x.set_interior(torch.randn(B, H, W, cin, device='cuda', generator=g))
+    dz = Plane(B, H, W, cout); dz.set_interior(torch.randn(B, H, W, cout, device='cuda', generator=g))
+    wd = ops.gemm_desc(x.NP, cin, cout, cin, cout, ntaps=9, B=B, H=H, W=W)
+    ws = torch.zeros(ops.tap_wgrad_workspace(wd) // 4 + 16, device='cuda')
+    g32, g6 = torch.zeros(3, 3, cin, cout, device='cuda'), torch.zeros(3, 3, cin, cout, device='cuda')
+    t32 = timeit(lambda: ops.tap_wgrad(wd, x, dz, cout, g32, ws))
+    t6 = timeit(lambda: ops.tap_wgrad_bx6(wd, x, dz, cout, g6, ws))
+    fl = 2.0 * B * H * W * 9 * cin * cout
+    # float64 reference of one tap (centre) on the whole batch
+    ref = torch.einsum('bhwk,bhwn->kn', x.interior().double(), dz.interior().double())
+    e32 = (g32[1, 1].double() - ref).abs().max().item() / ref.abs().max().item()
+    e6 = (g6[1, 1].double() - ref).abs().max().item() / ref.abs().max().item()
+    print('%-22s wgrad fp32 %7.1f us %6.1f TF | bx6 %7.1f us %6.1f TF (x%.2f) | max|fp32-bx6| %.2e (scale %.1f)  rel err vs f64: fp32 %.2e bx6 %.2e'
+          % (name, 1e3 * t32, fl / t32 / 1e9, 1e3 * t6, fl / t6 / 1e9, t32 / t6, (g32 - g6).abs().max().item(), g32.abs().max().item(), e32, e6))
