@@ -11,6 +11,7 @@
 // result is bitwise reproducible (no float atomics).
 #include "asr_common.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace {
 
@@ -21,6 +22,7 @@ struct WgradArgs {
     long rmin, rmax;
     int pch;                                      // pixels per chunk (multiple of PS)
     long slab;                                    // floats per chunk partial = ntaps*K*N
+    int ap, zp;                                   // bx6 only: LDS row pitches (bytes) of the A / dZ piece images
 };
 
 template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS>
@@ -414,8 +416,7 @@ __device__ __forceinline__ wbf16x8 tr_read8(const char* p, int pitch) {
 template <int PS>
 __global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_bx6(WgradArgs g) {
     constexpr int KT = 32, NT = 128, NTAPS = 9;
-    constexpr int AP = KT * 2 + 8;        // bytes per A row of one piece
-    constexpr int ZP = NT * 2 + 8;        // bytes per dZ row of one piece
+    const int AP = g.ap, ZP = g.zp;       // bytes per row of one piece image (multiples of 8; see the launcher)
     extern __shared__ __attribute__((aligned(16))) char wsm[];
     const int halo = g.halo;
     const int arows = PS + 2 * halo;
@@ -711,7 +712,7 @@ __global__ void sum_chunks_kernel(const float* __restrict__ part, float* __restr
 
 struct Plan { int ktile, ntile, ps, nchunks, pch; };
 
-Plan make_plan(const asr_gemm_desc* d) {
+Plan make_plan(const asr_gemm_desc* d, int target_blocks = 768, long cap_mb = 64) {
     Plan p;
     if (d->ntaps != 1) {
         p.ktile = 32;
@@ -721,10 +722,10 @@ Plan make_plan(const asr_gemm_desc* d) {
         p.ktile = 128; p.ntile = 128; p.ps = 64;
     }
     const long tiles = (long)asr_cdiv(d->K, p.ktile) * asr_cdiv(d->N, p.ntile);
-    long want = 768 / tiles;
+    long want = target_blocks / tiles;
     if (want < 1) want = 1;
     const long slab_bytes = (long)d->ntaps * d->K * d->N * 4;
-    const long cap = (64L << 20) / slab_bytes;
+    const long cap = (cap_mb << 20) / slab_bytes;      // fewer, longer chunks beat more slabs: 64 MB measured better than 128 for fp32
     if (want > cap) want = cap < 1 ? 1 : cap;
     const long maxc = asr_cdiv(d->M, 4 * p.ps);
     if (want > maxc) want = maxc;
@@ -766,9 +767,10 @@ int launch_wgrad(const WgradArgs& a, const Plan& p, int K, int N, hipStream_t st
 
 extern "C" size_t asr_tap_wgrad_workspace(const asr_gemm_desc* d) {
     if (!d) return 0;
-    const Plan p = make_plan(d);
-    if (p.nchunks <= 1) return 16;
-    return (size_t)p.nchunks * d->ntaps * d->K * d->N * sizeof(float);
+    const Plan p = make_plan(d), q = make_plan(d, 1024, 128);  // q: the most chunks any variant (bx6 sweeps included) asks for
+    const int nc = p.nchunks > q.nchunks ? p.nchunks : q.nchunks;
+    if (nc <= 1) return 16;
+    return (size_t)nc * d->ntaps * d->K * d->N * sizeof(float);
 }
 
 extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz,
@@ -819,7 +821,10 @@ extern "C" int asr_tap_wgrad_bx6(const asr_gemm_desc* d, const float* A, const f
     if (!d || !A || !dZ || !dW) return ASR_ERR_BAD_ARG;
     if (d->ntaps != 9 || d->H <= 0 || d->N <= 64) return ASR_ERR_UNSUPPORTED;
     if ((d->K & 3) || (d->N & 3) || (d->lda & 3) || (ldz & 3)) return ASR_ERR_BAD_ARG;
-    const Plan p = make_plan(d);                 // ktile 32, ntile 128, PS 64 for N > 64
+    // ktile 32, ntile 128, PS 64 for N > 64; two workgroups per CU (144 accumulator registers): aim at one or two full rounds
+    static int tb = 0;
+    if (!tb) { const char* e = getenv("ASR_BX6_WBLOCKS"); tb = e ? atoi(e) : 512; }
+    const Plan p = make_plan(d, tb, 128);
     if (p.nchunks > 1 && !partials) return ASR_ERR_BAD_ARG;
     WgradArgs a;
     a.A = A; a.Z = dZ; a.out = (p.nchunks > 1) ? partials : dW;
@@ -832,7 +837,17 @@ extern "C" int asr_tap_wgrad_bx6(const asr_gemm_desc* d, const float* A, const f
     hipStream_t st = (hipStream_t)stream;
     constexpr int PS = 64;
     const int arows = PS + 2 * a.halo;
-    const size_t lds = ((size_t)3 * arows * (32 * 2 + 8) + 15) / 16 * 16 + (size_t)3 * PS * (128 * 2 + 8);
+    // Row pitches of the piece images.  Measured on c4 / c6 (tools/bench_bx6.py): (72, 264) 373 / 692 us; the pitches that
+    // make the transposed reads conflict-free on paper, (64, 320), 536 / 1039 us -- the 8-byte staging WRITES (32 banks)
+    // then collide four ways.  ASR_BX6_PITCH="ap,zp" overrides for sweeps.
+    static int ap = 0, zp = 0;
+    if (!ap) {
+        ap = 72; zp = 264;
+        const char* e = getenv("ASR_BX6_PITCH");
+        if (e) { int x = 0, y = 0; if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 64 && y >= 256 && !(x & 7) && !(y & 7)) { ap = x; zp = y; } }
+    }
+    a.ap = ap; a.zp = zp;
+    const size_t lds = ((size_t)3 * arows * ap + 15) / 16 * 16 + (size_t)3 * PS * zp;
     if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
     auto kern = tap_wgrad_kernel_bx6<PS>;
     static bool attr_set = false;
