@@ -712,7 +712,7 @@ __global__ void sum_chunks_kernel(const float* __restrict__ part, float* __restr
 
 struct Plan { int ktile, ntile, ps, nchunks, pch; };
 
-Plan make_plan(const asr_gemm_desc* d, int target_blocks = 768, long cap_mb = 64) {
+Plan make_plan(const asr_gemm_desc* d, int target_blocks = 768, long cap_mb = 64, int ps_override = 0) {
     Plan p;
     if (d->ntaps != 1) {
         p.ktile = 32;
@@ -721,6 +721,7 @@ Plan make_plan(const asr_gemm_desc* d, int target_blocks = 768, long cap_mb = 64
     } else {
         p.ktile = 128; p.ntile = 128; p.ps = 64;
     }
+    if (ps_override) p.ps = ps_override;
     const long tiles = (long)asr_cdiv(d->K, p.ktile) * asr_cdiv(d->N, p.ntile);
     long want = target_blocks / tiles;
     if (want < 1) want = 1;
@@ -821,10 +822,20 @@ extern "C" int asr_tap_wgrad_bx6(const asr_gemm_desc* d, const float* A, const f
     if (!d || !A || !dZ || !dW) return ASR_ERR_BAD_ARG;
     if (d->ntaps != 9 || d->H <= 0 || d->N <= 64) return ASR_ERR_UNSUPPORTED;
     if ((d->K & 3) || (d->N & 3) || (d->lda & 3) || (ldz & 3)) return ASR_ERR_BAD_ARG;
-    // ktile 32, ntile 128, PS 64 for N > 64; two workgroups per CU (144 accumulator registers): aim at one or two full rounds
+    // ktile 32, ntile 128; two workgroups per CU (144 accumulator registers): aim at exactly one round of them.  The run
+    // length PS is 64 pixels while TWO workgroups' tiles fit the 160 KB of LDS, else 48 (planes 33..64 wide: the halo
+    // rows of the A image grow with the plane width) -- dropping to one workgroup per CU costs 40 %.
     static int tb = 0;
     if (!tb) { const char* e = getenv("ASR_BX6_WBLOCKS"); tb = e ? atoi(e) : 512; }
-    const Plan p = make_plan(d, tb, 128);
+    static int apz = 0, zpz = 0;
+    if (!apz) {
+        apz = 72; zpz = 264;
+        const char* e = getenv("ASR_BX6_PITCH");
+        if (e) { int x = 0, y = 0; if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 64 && y >= 256 && !(x & 7) && !(y & 7)) { apz = x; zpz = y; } }
+    }
+    auto lds_for = [&](int ps) { return ((size_t)3 * (ps + 2 * (d->W + 2)) * apz + 15) / 16 * 16 + (size_t)3 * ps * zpz; };
+    const int PSsel = (2 * lds_for(64) <= 160 * 1024) ? 64 : 48;
+    const Plan p = make_plan(d, tb, 128, PSsel);
     if (p.nchunks > 1 && !partials) return ASR_ERR_BAD_ARG;
     WgradArgs a;
     a.A = A; a.Z = dZ; a.out = (p.nchunks > 1) ? partials : dW;
@@ -835,27 +846,18 @@ extern "C" int asr_tap_wgrad_bx6(const asr_gemm_desc* d, const float* A, const f
     a.pch = p.pch;
     a.slab = (long)d->ntaps * d->K * d->N;
     hipStream_t st = (hipStream_t)stream;
-    constexpr int PS = 64;
-    const int arows = PS + 2 * a.halo;
-    // Row pitches of the piece images.  Measured on c4 / c6 (tools/bench_bx6.py): (72, 264) 373 / 692 us; the pitches that
-    // make the transposed reads conflict-free on paper, (64, 320), 536 / 1039 us -- the 8-byte staging WRITES (32 banks)
-    // then collide four ways.  ASR_BX6_PITCH="ap,zp" overrides for sweeps.
-    static int ap = 0, zp = 0;
-    if (!ap) {
-        ap = 72; zp = 264;
-        const char* e = getenv("ASR_BX6_PITCH");
-        if (e) { int x = 0, y = 0; if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 64 && y >= 256 && !(x & 7) && !(y & 7)) { ap = x; zp = y; } }
-    }
-    a.ap = ap; a.zp = zp;
-    const size_t lds = ((size_t)3 * arows * ap + 15) / 16 * 16 + (size_t)3 * PS * zp;
+    a.ap = apz; a.zp = zpz;
+    const size_t lds = lds_for(PSsel);
     if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
-    auto kern = tap_wgrad_kernel_bx6<PS>;
+    const dim3 grid(p.nchunks, asr_cdiv(d->K, 32), asr_cdiv(d->N, 128));
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tap_wgrad_kernel_bx6<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)tap_wgrad_kernel_bx6<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(p.nchunks, asr_cdiv(d->K, 32), asr_cdiv(d->N, 128)), dim3(256), lds, st, a);
+    if (PSsel == 64) hipLaunchKernelGGL(tap_wgrad_kernel_bx6<64>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(tap_wgrad_kernel_bx6<48>, grid, dim3(256), lds, st, a);
     ASR_CHECK_LAUNCH("tap_wgrad_bx6");
     if (p.nchunks > 1) {
         const long n = a.slab;

@@ -522,7 +522,7 @@ class DFCNNEngine:
                 ops.cell_bwd_pre(dyv, layout, self.a[dst], sc, sh, pm, dz, self.dscale_of(dst),
                                  self.gview(dst, 'beta'), self.gview(dst, 'b'), self.ws)
                 # split-bf16 weight gradient where it wins (tools/bench_bx6.py): narrow planes (small halo) and >= 128 outputs
-                wgrad = ops.tap_wgrad_bx6 if (self.bx6 and k == 3 and cout >= 128 and W <= 32) else ops.tap_wgrad
+                wgrad = ops.tap_wgrad_bx6 if (self.bx6 and k == 3 and cout >= 128 and W <= 64) else ops.tap_wgrad
                 if self.side is None:
                     wgrad(self.wdesc[dst], self.y[src], dz, cout, self.gview(dst, 'w'), self.ws)
                 else:
