@@ -20,6 +20,16 @@ for wl in dfcnn se_dfcnn; do
       python3 $ROOT/bench.py --workload $wl --steps 4 --warmup 2 --no-cpu-baseline --no-experimental --no-prefetch > $OUT/bench1_$wl.log 2>&1
   echo "single-stream stats $wl done"
 done
+# the opt-in split-bf16 convolution kernels, both streams
+export ASR_DUAL_STREAM=1
+export ASR_BX6=1
+for wl in dfcnn se_dfcnn; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/statsx_$wl -o $wl -- \
+      python3 $ROOT/bench.py --workload $wl --steps 4 --warmup 2 --no-cpu-baseline --no-experimental > $OUT/benchx_$wl.log 2>&1
+  echo "split-bf16 stats $wl done"
+done
+unset ASR_BX6
+export ASR_DUAL_STREAM=0
 for wl in dfcnn se_dfcnn; do
   i=0
   for ctr in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES"; do
@@ -36,7 +46,8 @@ for wl in dfcnn se_dfcnn transformer e2e_prenet; do
 done
 for wl in dfcnn se_dfcnn; do
   find $OUT/stats1_$wl -name "*kernel_stats.csv" -exec cp {} $OUT/${wl}_single_stream_kernel_stats.csv \;
+  find $OUT/statsx_$wl -name "*kernel_stats.csv" -exec cp {} $OUT/${wl}_split_bf16_kernel_stats.csv \;
 done
 # keep the merge-back small: drop raw traces
-rm -rf $OUT/stats_* $OUT/stats1_* $OUT/pmc_*_[0-9]
+rm -rf $OUT/stats_* $OUT/stats1_* $OUT/statsx_* $OUT/pmc_*_[0-9]
 ls -la $OUT
