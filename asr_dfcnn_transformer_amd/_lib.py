@@ -23,6 +23,7 @@ _I = C.c_int
 _F = C.c_float
 _D = C.c_double
 _Z = C.c_size_t
+_L = C.c_long
 
 SIGNATURES = {
     'asr_version': (C.c_int, []),
@@ -33,6 +34,9 @@ SIGNATURES = {
     'asr_split_weights': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'asr_tap_gemm_bx6': (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_wgrad_bx6': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _P, _P, _P]),
+    'asr_split_rows_bytes': (_Z, [_L, _I]),
+    'asr_split_rows': (_I, [_P, _L, _I, _I, _P, _P]),
+    'asr_gemm_bx6s': (_I, [_P, _P, _L, _I, _I, _P, _I, _I, _P, _I, _P, _P]),
     'asr_tap_wgrad_workspace': (_Z, [C.POINTER(GemmDesc)]),
     'asr_tap_wgrad': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _P, _P, _P]),
     'asr_cell1_fwd': (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),

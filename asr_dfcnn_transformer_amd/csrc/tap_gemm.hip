@@ -820,6 +820,9 @@ __global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_bx6(BxArgs args) {
     constexpr int KS = KC / 16;                       // MFMA K-steps per chunk
     constexpr int SB = 4;
     static_assert(NTAPS == 1 || NTAPS % D == 0, "ring depth must divide the taps");
+    // tap groups fully unrolled where the register budget (2 waves per SIMD) allows: straight-line code lets the
+    // compiler count the ring's outstanding loads exactly (s_waitcnt vmcnt(6..8) instead of 0 at a loop header)
+    constexpr int GU = (MINB >= 3) ? 1 : (NTAPS / D > 0 ? NTAPS / D : 1);
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int halo = g.halo;
@@ -868,23 +871,22 @@ __global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_bx6(BxArgs args) {
     const int nkc = (K + KC - 1) / KC;
     // ring of D slots, one slot = the B fragments of ONE tap for the KS K-steps of a chunk
     bf16x8 breg[D][KS][TN][3];
-    const int ncol = n0 + wn * (TN * 32) + li;
+    const int kst = Kp >> 4, nbt = (N + 31) >> 5;
+    int nbb[TN];                                       // column blocks of this wave (clamped: blocks past N are never stored)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) { nbb[b] = (n0 >> 5) + wn * TN + b; if (nbb[b] >= nbt) nbb[b] = nbt - 1; }
 
     auto load_b = [&](bf16x8 (&dst)[KS][TN][3], int kc, int tap) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const int kk = kc * KC + ks * 16 + 8 * lh;
+            const int kstep = kc * KS + ks;
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
-                const int n = ncol + b * 32;
+                // branch-free (the split tensor is zero-padded to whole K-steps and column blocks): with conditional
+                // loads the compiler falls back to s_waitcnt vmcnt(0) and the ring stops hiding latency
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc) {
-                    bf16x8 v;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
-                    if (kk < Kp && n < N) v = *(const bf16x8*)(args.Ws + (((long)tap * 3 + pc) * N + n) * Kp + kk);
-                    dst[ks][b][pc] = v;
-                }
+                for (int pc = 0; pc < 3; ++pc)
+                    dst[ks][b][pc] = *(const bf16x8*)(args.Ws + (((((long)tap * 3 + pc) * kst + kstep) * nbt + nbb[b]) * 64 + lane) * 8);
             }
         }
     };
@@ -956,7 +958,7 @@ __global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_bx6(BxArgs args) {
         for (int kc = 0; kc < nkc; ++kc) {
             stage_a(kc);
             // groups of D taps: the slot index is static inside a group, the group loop is not unrolled (registers)
-#pragma unroll 1
+#pragma unroll GU
             for (int t0 = 0; t0 < NTAPS; t0 += D) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
@@ -964,7 +966,10 @@ __global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_bx6(BxArgs args) {
                     compute_tap(breg[d], tap);
                     int ntap = tap + D, nk = kc;
                     if (ntap >= NTAPS) { ntap -= NTAPS; ++nk; }
-                    if (nk < nkc) load_b(breg[d], nk, ntap);
+                    if (nk >= nkc) nk = nkc - 1;      // the tail refills are valid reloads that nobody reads
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_b(breg[d], nk, ntap);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -980,7 +985,9 @@ __global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_bx6(BxArgs args) {
                 if (kc < nkc) {                       // uniform over the workgroup
                     stage_a(kc);
                     compute_tap(breg[d], 0);
-                    if (kc + D < nkc) load_b(breg[d], kc + D, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_b(breg[d], (kc + D < nkc) ? kc + D : nkc - 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -988,217 +995,32 @@ __global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_bx6(BxArgs args) {
 
     __syncthreads();
     tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
-}
-
-template <int MT, int NT, int WM, int WN, int NTAPS, int D, int KCV, int MINB>
-__global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_bx6p(BxArgs args) {
-    const TapGemmArgs& g = args.g;
-    constexpr int KC = KCV;
-    constexpr int APB = 3 * KC * 2 + 16;              // LDS bytes per pixel row: 3 pieces x KC bf16 + pad (13 x 16 B)
-    constexpr int TM = MT / WM / 32, TN = NT / WN / 32;
-    constexpr int KS = KC / 16;                       // MFMA K-steps per chunk
-    constexpr int SB = 4;
-    static_assert(NTAPS == 1 || NTAPS % D == 0, "ring depth must divide the taps");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int halo = g.halo;
-    const int arows = MT + 2 * halo;
-    int* rowa = (int*)smem;
-    int* rowy = rowa + MT;
-    float* tile_lds = smem + 2 * MT;
-    char* As0 = (char*)tile_lds;                       // two A buffers: chunk kc is read from buffer kc & 1
-    const int abytes = (arows * APB + 15) / 16 * 16;
-    constexpr int NA = (MT + 2 * 104) * (KC / 4) / 256 + 1;   // float4 per thread of one A tile (planes up to 100 wide + halo)
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = tid >> 6, wm = wave / WN, wn = wave % WN;
-    const int swz = asr_xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile_m = swz / g.ntn, tile_n = swz - tile_m * g.ntn;
-    const long p0 = (long)tile_m * MT;
-    const int n0 = tile_n * NT;
-    const int K = g.K, N = g.N, Kp = args.Kp;
-
-    if (tid < MT) {
-        const long p = p0 + tid;
-        int ra = -1, ry = -1;
-        if (p < g.M) {
-            if (g.H == 0) {
-                ra = (int)p; ry = (int)p;
-            } else {
-                const int b = (int)(p / g.HPWP);
-                const int r = (int)(p - (long)b * g.HPWP);
-                const int hh = r / g.WP, ww = r - hh * g.WP;
-                if (hh >= 1 && hh <= g.H && ww >= 1 && ww <= g.Wd) {
-                    ra = (int)p;
-                    ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : (int)p;
-                }
-            }
-        }
-        rowa[tid] = ra; rowy[tid] = ry;
-    }
-
-    floatx16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int nkc = (K + KC - 1) / KC;
-    // ring of D slots, one slot = the B fragments of ONE tap for the KS K-steps of a chunk
-    bf16x8 breg[D][KS][TN][3];
-    const int ncol = n0 + wn * (TN * 32) + li;
-
-    auto load_b = [&](bf16x8 (&dst)[KS][TN][3], int kc, int tap) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int kk = kc * KC + ks * 16 + 8 * lh;
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int n = ncol + b * 32;
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc) {
-                    bf16x8 v;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
-                    if (kk < Kp && n < N) v = *(const bf16x8*)(args.Ws + (((long)tap * 3 + pc) * N + n) * Kp + kk);
-                    dst[ks][b][pc] = v;
-                }
-            }
-        }
-    };
-    auto load_a_row = [&](int f, int kc) -> float4 {
-        const int row = f / (KC / 4), c4 = f - row * (KC / 4);
-        const long grow = p0 - halo + row;
-        const int kk = kc * KC + c4 * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (grow >= g.rmin && grow < g.rmax && kk < K) v = *(const float4*)(g.A + grow * g.lda + kk);
-        return v;
-    };
-    const char* As = As0;
-    auto compute_tap = [&](const bf16x8 (&bb)[KS][TN][3], int tap) {
-        const int toff = halo + tap_row_offset<NTAPS, 0>(tap, g.WP);
-        const char* abase = As + (wm * (TM * 32) + li + toff) * APB + lh * 16;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const bf16x8 ah = *(const bf16x8*)(abase + a * 32 * APB + ks * 32);
-                const bf16x8 am = *(const bf16x8*)(abase + a * 32 * APB + ks * 32 + KC * 2);
-                const bf16x8 al = *(const bf16x8*)(abase + a * 32 * APB + ks * 32 + 2 * KC * 2);
-#pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    floatx16 c = acc[a][b];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bb[ks][b][0], c, 0, 0, 0);      // small terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bb[ks][b][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bb[ks][b][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bb[ks][b][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bb[ks][b][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bb[ks][b][0], c, 0, 0, 0);
-                    acc[a][b] = c;
-                }
-            }
-        }
-    };
-
-    // A pipeline: the loads of chunk kc+1 are issued before the MFMAs of chunk kc and split / written to the other LDS
-    // buffer after them -- one barrier per chunk, the global latency hides under the matrix work.
-    float4 areg[NA];
-    auto fetch_a = [&](int kc) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int f = tid + i * 256;
-            areg[i] = (f < arows * (KC / 4)) ? load_a_row(f, kc) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto write_a = [&](char* dstbuf) {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int f = tid + i * 256;
-            if (f >= arows * (KC / 4)) continue;
-            const int row = f / (KC / 4), c4 = f - row * (KC / 4);
-            bf16x4 ph, pm, pl;
-            const float e[4] = {areg[i].x, areg[i].y, areg[i].z, areg[i].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                __bf16 h, m, l;
-                split3(e[j], h, m, l);
-                ph[j] = h; pm[j] = m; pl[j] = l;
-            }
-            char* d = dstbuf + row * APB + c4 * 8;
-            *(bf16x4*)(d) = ph; *(bf16x4*)(d + KC * 2) = pm; *(bf16x4*)(d + 2 * KC * 2) = pl;
-        }
-    };
-
-    static_assert(NTAPS > 1, "pipelined variant is for the 3x3 convs");
-#pragma unroll
-    for (int d = 0; d < D; ++d) load_b(breg[d], 0, d);
-    fetch_a(0);
-    __syncthreads();                                   // rowa / rowy visible; nobody reads LDS yet
-    write_a(As0);
-    __syncthreads();
-    for (int kc = 0; kc < nkc; ++kc) {
-        As = As0 + (kc & 1) * abytes;
-        if (kc + 1 < nkc) fetch_a(kc + 1);
-#pragma unroll 1
-        for (int t0 = 0; t0 < NTAPS; t0 += D) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const int tap = t0 + d;
-                compute_tap(breg[d], tap);
-                int ntap = tap + D, nk = kc;
-                if (ntap >= NTAPS) { ntap -= NTAPS; ++nk; }
-                if (nk < nkc) load_b(breg[d], nk, ntap);
-            }
-        }
-        if (kc + 1 < nkc) write_a(As0 + ((kc + 1) & 1) * abytes);     // the other buffer: last read in chunk kc-1, before the barrier below
-        __syncthreads();
-    }
-
-    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
-}
-
-template <int MT, int NT, int WM, int WN, int NTAPS, int D, int KCV, int MINB>
-int launch_bx6p(const TapGemmArgs& a, const __bf16* Ws, int Kp, hipStream_t st) {
-    auto kern = tap_gemm_kernel_bx6p<MT, NT, WM, WN, NTAPS, D, KCV, MINB>;
-    const int arows = MT + 2 * a.halo;
-    if (a.halo > 104) return ASR_ERR_UNSUPPORTED;
-    const size_t abytes = ((size_t)arows * (3 * KCV * 2 + 16) + 15) / 16 * 16;
-    size_t lds = 2 * abytes + 2 * MT * sizeof(int);
-    if (lds < kEpilogueLds + 2 * MT * sizeof(int)) lds = kEpilogueLds + 2 * MT * sizeof(int);
-    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    BxArgs b;
-    b.g = a; b.Ws = Ws; b.Kp = Kp;
-    b.g.ntm = asr_cdiv(a.M, MT);
-    b.g.ntn = asr_cdiv(a.N, NT);
-    hipLaunchKernelGGL(kern, dim3(b.g.ntm * b.g.ntn), dim3(256), lds, st, b);
-    ASR_CHECK_LAUNCH("tap_gemm_bx6p");
-    return ASR_OK;
 }
 
 // W [ntaps][K][N] (HWIO; wmode 0) or its data-gradient view (wmode 1: taps mirrored, K and N swapped) ->
-// Ws [ntaps][3][Nout][Kp] bf16, Kp = K rounded up to 32 (zero-filled): the B fragments of tap_gemm_kernel_bx6
+// Ws bf16 in FRAGMENT ORDER [ntaps][3 pieces][Kp/16 K-steps][ceil(N/32) column blocks][64 lanes][8]: lane = 32 * h + i
+// holds column 32 * block + i, k = 16 * step + 8 * h .. + 7, so that the B operand of one v_mfma_f32_32x32x16_bf16 is ONE
+// contiguous, fully coalesced 1 KB wave load (Kp = K rounded up to 32; k >= K and columns >= N are zero)
 __global__ void split_weights_kernel(const float* __restrict__ W, int ntaps, int K, int N, int ldw, int wmode, int Kp,
                                      __bf16* __restrict__ out) {
-    const long total = (long)ntaps * N * Kp;
+    const int NB = (N + 31) >> 5, KST = Kp >> 4;
+    const long per_piece = (long)KST * NB * 512;
+    const long total = (long)ntaps * per_piece;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % Kp);
-        const long r = i / Kp;
-        const int n = (int)(r % N), tap = (int)(r / N);
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        long r = i >> 9;
+        const int nb = (int)(r % NB); r /= NB;
+        const int ks = (int)(r % KST);
+        const int tap = (int)(r / KST);
+        const int n = nb * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8 + j;
         float x = 0.f;
-        if (k < K) x = (wmode == 0) ? W[((long)tap * K + k) * ldw + n] : W[((long)(ntaps - 1 - tap) * N + n) * ldw + k];
+        if (k < K && n < N) x = (wmode == 0) ? W[((long)tap * K + k) * ldw + n] : W[((long)(ntaps - 1 - tap) * N + n) * ldw + k];
         __bf16 h, m, l;
         split3(x, h, m, l);
-        out[(((long)tap * 3 + 0) * N + n) * Kp + k] = h;
-        out[(((long)tap * 3 + 1) * N + n) * Kp + k] = m;
-        out[(((long)tap * 3 + 2) * N + n) * Kp + k] = l;
+        const long o = (long)tap * 3 * per_piece + (i - (long)tap * per_piece);
+        out[o] = h;
+        out[o + per_piece] = m;
+        out[o + 2 * per_piece] = l;
     }
 }
 
@@ -1420,14 +1242,14 @@ extern "C" int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float*
 
 // ---- EXPERIMENTAL split-bf16 path (include/asr_hip.h): weights pre-split by asr_split_weights, then asr_tap_gemm_bx6
 extern "C" size_t asr_split_weights_bytes(int ntaps, int K, int N) {
-    const int Kp = (K + 31) / 32 * 32;
-    return (size_t)ntaps * 3 * N * Kp * 2;
+    const int Kp = (K + 31) / 32 * 32, Np = (N + 31) / 32 * 32;
+    return (size_t)ntaps * 3 * Np * Kp * 2;
 }
 
 extern "C" int asr_split_weights(const float* W, int ntaps, int K, int N, int ldw, int wmode, void* out, void* stream) {
     if (!W || !out || (ntaps != 1 && ntaps != 9) || K < 1 || N < 1) return ASR_ERR_BAD_ARG;
     const int Kp = (K + 31) / 32 * 32;
-    const long total = (long)ntaps * N * Kp;
+    const long total = (long)ntaps * ((N + 31) / 32 * 32) * Kp;
     long nb = (total + 255) / 256;
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(split_weights_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, W, ntaps, K, N, ldw, wmode, Kp,
@@ -1467,7 +1289,6 @@ extern "C" int asr_tap_gemm_bx6(const asr_gemm_desc* d, const float* A, const vo
     if (d->ntaps == 9) {
         if (d->N > 32) {
             if (cfg == 2) return launch_bx6<128, 64, 2, 2, 9, 3, 16, 3>(a, Ws, Kp, st);
-            if (cfg == 6) return launch_bx6p<128, 64, 2, 2, 9, 3, 16, 3>(a, Ws, Kp, st);
             if (cfg == 13 && d->N > 64) return launch_bx6<256, 128, 2, 2, 9, 3, 16, 2>(a, Ws, Kp, st);
             return launch_bx6<256, 64, 2, 2, 9, 3, 16, 2>(a, Ws, Kp, st);
         }

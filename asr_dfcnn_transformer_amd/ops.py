@@ -499,3 +499,18 @@ def tap_wgrad_bx6(desc, A, dZ, ldz, dW, partials):
     pa = A.ptr if isinstance(A, Plane) else _ptr(A)
     pz = dZ.ptr if isinstance(dZ, Plane) else _ptr(dZ)
     check(lib.asr_tap_wgrad_bx6(C.byref(desc), pa, pz, ldz, _ptr(dW), _ptr(partials), _stream()), 'asr_tap_wgrad_bx6')
+
+
+def split_rows(X, M, K, ldx, out=None):
+    """bf16 [3][M][Kp] hi / mid / lo planes of a row-major fp32 matrix (asr_split_rows); returns the uint8 buffer."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(lib.asr_split_rows_bytes(M, K), dtype=torch.uint8, device=X.device)
+    check(lib.asr_split_rows(_ptr(X), M, K, ldx, _ptr(out), _stream()), 'asr_split_rows')
+    return out
+
+
+def gemm_bx6s(As, Bs, M, K, N, bias=None, relu=0, accumulate=0, Y=None, ldy=0, Ysplit=None):
+    """Y [M][N] (+)= act(A . B^T + bias) on pre-split operands (asr_gemm_bx6s)."""
+    check(_lib.load().asr_gemm_bx6s(_ptr(As), _ptr(Bs), M, K, N, _ptr(bias), relu, accumulate, _ptr(Y), ldy, _ptr(Ysplit),
+                                    _stream()), 'asr_gemm_bx6s')

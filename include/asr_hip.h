@@ -353,7 +353,8 @@ int asr_pix_ln_bwd(const float* dy, const float* xhat, const float* rstd, const 
  * (DESIGN.md section 9).  Same contraction and epilogue as asr_tap_gemm, computed as six v_mfma_f32_32x32x16_bf16
  * products of the hi/mid/lo bf16 pieces of the fp32 operands with fp32 accumulation (fp32-chain accuracy, 2.6x the matrix
  * pipe rate).  The weights are pre-split and transposed once per optimiser step:
- *   asr_split_weights(W, ntaps, K, N, ldw, wmode, out): out = bf16 [ntaps][3][N][Kp], Kp = K rounded up to 32; wmode 1
+ *   asr_split_weights(W, ntaps, K, N, ldw, wmode, out): out = bf16 in MFMA fragment order [ntaps][3][Kp/16][ceil(N/32)]
+ *   [64 lanes][8] (lane 32h+i = column 32*block+i, k = 16*step+8h..+7; Kp = K rounded up to 32, zero padded); wmode 1
  *   takes the data-gradient view of a forward tensor (K, N = the GEMM's, i.e. swapped; taps mirrored), after which
  *   asr_tap_gemm_bx6 is called with desc.wmode ignored.  NOT used by the engines / bench unless ASR_BX6=1. */
 size_t asr_split_weights_bytes(int ntaps, int K, int N);
@@ -365,6 +366,15 @@ int asr_tap_wgrad_bx6(const asr_gemm_desc* d, const float* A, const float* dZ, i
 int asr_tap_gemm_bx6(const asr_gemm_desc* d, const float* A, const void* Wsplit,
                      const float* bias, const float* scale, const float* shift,
                      float* out_a, float* out_y, void* stream);
+/* Dense contraction on PRE-SPLIT operands (the Transformer projections / FFN, end2end/transformer.py:117-158,204-231):
+ *   asr_split_rows(X [M][K] fp32, row pitch ldx) -> bf16 [3][M][Kp] (hi, mid, lo planes; Kp = K rounded up to 32);
+ *   asr_gemm_bx6s: Y [M][N] (+)= act(A . B + bias) with A = split planes [3][M][Kp] and B = asr_split_weights(W, 1, K, N, ...)
+ *   (wmode 0 for the forward, wmode 1 with K and N swapped for the data-gradient); Ysplit, if given, also receives the
+ *   result as split planes [3][M][Np] for the next GEMM. */
+size_t asr_split_rows_bytes(long M, int K);
+int asr_split_rows(const float* X, long M, int K, int ldx, void* out, void* stream);
+int asr_gemm_bx6s(const void* Asplit, const void* Bsplit, long M, int K, int N, const float* bias, int relu,
+                  int accumulate, float* Y, int ldy, void* Ysplit, void* stream);
 
 #ifdef __cplusplus
 }
