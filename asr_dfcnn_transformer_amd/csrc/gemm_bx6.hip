@@ -3,7 +3,7 @@
 // tap_gemm_kernel_bx6 splits its A tile into hi / mid / lo bf16 pieces while staging it; a 3x3 convolution amortises that
 // over nine taps, a plain GEMM (the Transformer projections and FFN of end2end/transformer.py:117-158, 204-231) does
 // not and ends up slower than the fp32 MFMA kernel.  Here both operands arrive already split:
-//   asr_split_rows:  X [M][K] fp32 (row pitch ldx)  ->  Xs bf16 [3][M][Kp]   (Kp = K rounded up to 32, zero filled)
+//   asr_split_rows:  X [M][K] fp32 (row pitch ldx)  ->  Xs bf16 [3][Kp/32][M][32]  (Kp = K rounded up to 32, zero filled)
 //   asr_gemm_bx6s:   Y [M][N] = act(As . B + bias) with As [3][M][Kp] and B pre-split in fragment order (asr_split_weights), six
 //                    v_mfma_f32_32x32x16_bf16 products per K-step, fp32 accumulation; optionally also writes Y split
 //                    ([3][M][Np]) for the next GEMM.
@@ -23,6 +23,9 @@ __device__ __forceinline__ void gsplit3(float x, __bf16& h, __bf16& m, __bf16& l
     l = (__bf16)(r1 - (float)m);
 }
 
+// Split planes are stored K-CHUNK-MAJOR: Xs[piece][k / 32][row][k % 32] (bf16), so that the 32-deep K chunk of a block of
+// rows is one contiguous run (64 B per row): the GEMM's staging copy is fully coalesced and touches every cache line once
+// (row-major planes put consecutive rows a power of two apart: half-used lines that thrash the L1 sets).
 // one thread = 8 consecutive k of one row: two float4 loads, three 16-byte stores
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ X, long M, int K, int ldx, int Kp,
                                                          __bf16* __restrict__ out) {
@@ -30,8 +33,10 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     const long total = M * k8;
     const long ps = M * (long)Kp;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long row = i / k8;
-        const int k = (int)(i - row * k8) * 8;
+        // consecutive threads write consecutive 16-byte units of a plane: (chunk, row, unit) with the unit fastest
+        const long r4 = i >> 2;
+        const long row = r4 % M;
+        const int k = (int)(r4 / M) * 32 + (int)(i & 3) * 8;
         float e[8];
         const float* src = X + row * ldx + k;
         if (k + 8 <= K) {
@@ -44,7 +49,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
         bf16x8 h, m, l;
 #pragma unroll
         for (int j = 0; j < 8; ++j) { __bf16 a, b, c; gsplit3(e[j], a, b, c); h[j] = a; m[j] = b; l[j] = c; }
-        __bf16* d = out + row * Kp + k;
+        __bf16* d = out + ((long)(k >> 5) * M + row) * 32 + (k & 31);
         *(bf16x8*)d = h; *(bf16x8*)(d + ps) = m; *(bf16x8*)(d + 2 * ps) = l;
     }
 }
@@ -98,11 +103,13 @@ __global__ __launch_bounds__(256, MINB) void gemm_bx6s_kernel(GemmSArgs g) {
         const int row = r2 / U, c8 = r2 - row * U;
         long grow = p0 + row;
         if (grow >= g.M) grow = g.M - 1;              // rows past the end are computed and never stored
-        asrc[i] = g.As + pc * g.a_ps + grow * Kp + c8 * 8;
+        asrc[i] = g.As + pc * g.a_ps + grow * 32 + c8 * 8;       // chunk kc adds kc * M * 32
         adst[i] = row * APB + pc * (KC * 2) + c8 * 16;
     }
 
+    static_assert(KC == 32, "the split planes are stored in 32-deep K chunks");
     const int nkc = Kp / KC;
+    const long cstride = g.M * 32;
     bf16x8 breg[KS][TN][3];
     // B arrives in fragment order (asr_split_weights): [3][Kp/16][ceil(N/32)][64 lanes][8], one coalesced 1 KB load each
     const int kst = Kp >> 4, nbt = (N + 31) >> 5;
@@ -137,23 +144,35 @@ __global__ __launch_bounds__(256, MINB) void gemm_bx6s_kernel(GemmSArgs g) {
             // readers passed the barrier at the end of the previous iteration
             // (branch-free: the last iteration reloads its own chunk, so that the compiler's s_waitcnt counts stay exact)
 #pragma unroll
-            for (int i = 0; i < NU; ++i) t[i] = *(const bf16x8*)(asrc[i] + kn * KC);
+            for (int i = 0; i < NU; ++i) t[i] = *(const bf16x8*)(asrc[i] + kn * cstride);
             __builtin_amdgcn_sched_barrier(0);         // keep the loads up here: the scheduler otherwise sinks them past the MFMAs
         } else {
 #pragma unroll
-            for (int i = 0; i < NU; ++i) t[i] = *(const bf16x8*)(asrc[i] + kc * KC);
+            for (int i = 0; i < NU; ++i) t[i] = *(const bf16x8*)(asrc[i] + kc * cstride);
             __syncthreads();                           // the previous chunk's fragment reads are done
 #pragma unroll
             for (int i = 0; i < NU; ++i) *(bf16x8*)(As + adst[i]) = t[i];
             __syncthreads();
         }
+        // A fragments are read one (K-step, row block) ahead of the MFMAs that use them: with one or two waves per SIMD
+        // nothing else hides the LDS latency (the compiler alone issues each read right before its first use)
+        bf16x8 fa[2][3];
+        auto read_a = [&](bf16x8 (&f)[3], int ks, int a) {
+            f[0] = *(const bf16x8*)(abase + a * 32 * APB + ks * 32);
+            f[1] = *(const bf16x8*)(abase + a * 32 * APB + ks * 32 + KC * 2);
+            f[2] = *(const bf16x8*)(abase + a * 32 * APB + ks * 32 + 2 * KC * 2);
+        };
+        read_a(fa[0], 0, 0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
-                const bf16x8 ah = *(const bf16x8*)(abase + a * 32 * APB + ks * 32);
-                const bf16x8 am = *(const bf16x8*)(abase + a * 32 * APB + ks * 32 + KC * 2);
-                const bf16x8 al = *(const bf16x8*)(abase + a * 32 * APB + ks * 32 + 2 * KC * 2);
+                constexpr int dummy = 0; (void)dummy;
+                const int cur = (ks * TM + a) & 1;
+                if (a + 1 < TM) read_a(fa[cur ^ 1], ks, a + 1);
+                else if (ks + 1 < KS) read_a(fa[cur ^ 1], ks + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const bf16x8 ah = fa[cur][0], am = fa[cur][1], al = fa[cur][2];
 #pragma unroll
                 for (int b = 0; b < TN; ++b) {
                     floatx16 c = acc[a][b];
@@ -165,8 +184,8 @@ __global__ __launch_bounds__(256, MINB) void gemm_bx6s_kernel(GemmSArgs g) {
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, breg[ks][b][0], c, 0, 0, 0);
                     acc[a][b] = c;
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
             load_b(breg[ks], kn * KS + ks);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -210,7 +229,7 @@ __global__ __launch_bounds__(256, MINB) void gemm_bx6s_kernel(GemmSArgs g) {
                     const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { __bf16 x, y, z; gsplit3(e[j], x, y, z); h[j] = x; md[j] = y; l[j] = z; }
-                    __bf16* d = g.Ys + m * g.Np + n;
+                    __bf16* d = g.Ys + ((long)(n >> 5) * g.M + m) * 32 + (n & 31);
                     *(bf16x4*)d = h; *(bf16x4*)(d + g.y_ps) = md; *(bf16x4*)(d + 2 * g.y_ps) = l;
                 }
             }
@@ -274,7 +293,6 @@ extern "C" int asr_gemm_bx6s(const void* As, const void* Bs, long M, int K, int 
         case 1: return launch_s<256, 128, 2, 2, 32, 1>(g, st);
         case 2: return launch_s<128, 128, 2, 2, 32, 2>(g, st);
         case 3: return launch_s<128, 64, 2, 2, 32, 3>(g, st);
-        case 4: return launch_s<256, 64, 2, 2, 64, 1>(g, st);
         case 5: return launch_s<256, 128, 2, 2, 32, 2>(g, st);
         case 6: return launch_s<256, 64, 4, 1, 32, 2>(g, st);
         case 7: return launch_s<256, 128, 2, 2, 32, 1, true>(g, st);

@@ -367,10 +367,11 @@ int asr_tap_gemm_bx6(const asr_gemm_desc* d, const float* A, const void* Wsplit,
                      const float* bias, const float* scale, const float* shift,
                      float* out_a, float* out_y, void* stream);
 /* Dense contraction on PRE-SPLIT operands (the Transformer projections / FFN, end2end/transformer.py:117-158,204-231):
- *   asr_split_rows(X [M][K] fp32, row pitch ldx) -> bf16 [3][M][Kp] (hi, mid, lo planes; Kp = K rounded up to 32);
+ *   asr_split_rows(X [M][K] fp32, row pitch ldx) -> bf16 [3][Kp/32][M][32] (hi, mid, lo planes stored K-chunk-major;
+ *   Kp = K rounded up to 32);
  *   asr_gemm_bx6s: Y [M][N] (+)= act(A . B + bias) with A = split planes [3][M][Kp] and B = asr_split_weights(W, 1, K, N, ...)
  *   (wmode 0 for the forward, wmode 1 with K and N swapped for the data-gradient); Ysplit, if given, also receives the
- *   result as split planes [3][M][Np] for the next GEMM. */
+ *   result as split planes [3][Np/32][M][32] for the next GEMM. */
 size_t asr_split_rows_bytes(long M, int K);
 int asr_split_rows(const float* X, long M, int K, int ldx, void* out, void* stream);
 int asr_gemm_bx6s(const void* Asplit, const void* Bsplit, long M, int K, int N, const float* bias, int relu,
