@@ -793,6 +793,190 @@ int launch_v4(const TapGemmArgs& a, hipStream_t st) {
     return ASR_OK;
 }
 
+// ---- v5 ("pw"): v4 with the weights PRE-ARRANGED in MFMA fragment order (asr_arrange_weights, once per optimiser step):
+// Wf [tap][K/8 groups][ceil(N/32) column blocks][64 lanes][4] fp32, lane 32h+i = column 32*block+i, contraction indices
+// 8*group + 4h .. + 3 -- the B operands of four consecutive v_mfma_f32_32x32x2_f32 are ONE coalesced float4 per lane
+// (1 KB per wave), identical for the forward and the data-gradient view.  All ring loads are branch-free (zero padding,
+// clamped tails), so the compiler's s_waitcnt counts stay exact and the ring really runs D units ahead; the unit loop
+// is fully unrolled.  Two barriers per chunk, no weight tile in LDS.
+struct PwArgs { TapGemmArgs g; const float* Wf; int kg, nbt; };
+
+// DIR (0 forward, 1 data-gradient view) changes no code: it gives the two directions distinct symbols in a profile.
+template <int MT, int NT, int WM, int WN, int NTAPS, int KCV, int D, int MINB, int DIR>
+__global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_v5(PwArgs args) {
+    const TapGemmArgs& g = args.g;
+    constexpr int KC = KCV, AP = KCV + 4;
+    constexpr int TM = MT / WM / 32, TN = NT / WN / 32;
+    constexpr int GK = KC / 8;               // 8-wide contraction groups per chunk
+    constexpr int U = NTAPS * GK;            // pipeline units per chunk
+    constexpr int SB = 4;
+    static_assert(U % D == 0 && TM >= 1 && TN >= 1, "ring depth must divide the units of a chunk");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int halo = g.halo;
+    const int arows = MT + 2 * halo;
+    int* rowa = (int*)smem;
+    int* rowy = rowa + MT;
+    float* tile_lds = smem + 2 * MT;
+    float* As = tile_lds;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = tid >> 6, wm = wave / WN, wn = wave % WN;
+    const int swz = asr_xcd_swizzle(blockIdx.x, gridDim.x);
+    const int tile_m = swz / g.ntn, tile_n = swz - tile_m * g.ntn;
+    const long p0 = (long)tile_m * MT;
+    const int n0 = tile_n * NT;
+    const int K = g.K;
+
+    if (tid < MT) {
+        const long p = p0 + tid;
+        int ra = -1, ry = -1;
+        if (p < g.M) {
+            if (g.H == 0) {
+                ra = (int)p; ry = (int)p;
+            } else {
+                const int b = (int)(p / g.HPWP);
+                const int r = (int)(p - (long)b * g.HPWP);
+                const int hh = r / g.WP, ww = r - hh * g.WP;
+                if (hh >= 1 && hh <= g.H && ww >= 1 && ww <= g.Wd) {
+                    ra = (int)p;
+                    ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : (int)p;
+                }
+            }
+        }
+        rowa[tid] = ra; rowy[tid] = ry;
+    }
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nkc = (K + KC - 1) / KC;
+    float4 breg[D][TN];
+    const int kg = args.kg, nbt = args.nbt;
+    int nbb[TN];
+#pragma unroll
+    for (int b = 0; b < TN; ++b) { nbb[b] = (n0 >> 5) + wn * TN + b; if (nbb[b] >= nbt) nbb[b] = nbt - 1; }
+
+    auto load_b = [&](float4 (&dst)[TN], int kc, int u) {
+        const int tap = u / GK, gk = u - tap * GK;
+        int grp = kc * GK + gk;
+        if (grp >= kg) grp = kg - 1;                       // K tail of a 16/32-deep chunk: the A side is zero there
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+            dst[b] = *(const float4*)(args.Wf + ((((long)tap * kg + grp) * nbt + nbb[b]) * 64 + lane) * 4);
+    };
+    auto load_a_row = [&](int f, int kc) -> float4 {
+        const int row = f / (KC / 4), c4 = f - row * (KC / 4);
+        const long grow = p0 - halo + row;
+        const int kk = kc * KC + c4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grow >= g.rmin && grow < g.rmax && kk < K) v = *(const float4*)(g.A + grow * g.lda + kk);
+        return v;
+    };
+
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_b(breg[d], 0, d);
+
+    for (int kc = 0; kc < nkc; ++kc) {
+        __syncthreads();
+        for (int base = 0; base < arows * (KC / 4); base += SB * 256) {
+            float4 t[SB];
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                t[i] = (f < arows * (KC / 4)) ? load_a_row(f, kc) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < SB; ++i) {
+                const int f = base + tid + i * 256;
+                if (f < arows * (KC / 4)) *(float4*)(As + (f / (KC / 4)) * AP + (f % (KC / 4)) * 4) = t[i];
+            }
+        }
+        __syncthreads();
+        const int knext = (kc + 1 < nkc) ? kc + 1 : kc;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int tap = u / GK, gk = u - tap * GK;
+            const int toff = halo + tap_row_offset<NTAPS, 0>(tap, g.WP);
+            const float* abase = As + (wm * (TM * 32) + li + toff) * AP + 4 * lh + gk * 8;
+            float4 av[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) av[a] = *(const float4*)(abase + a * 32 * AP);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const float as = (s2 == 0) ? av[a].x : (s2 == 1) ? av[a].y : (s2 == 2) ? av[a].z : av[a].w;
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        const float4 bv = breg[u % D][b];
+                        const float bs = (s2 == 0) ? bv.x : (s2 == 1) ? bv.y : (s2 == 2) ? bv.z : bv.w;
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bs, acc[a][b], 0, 0, 0);
+                    }
+                }
+            }
+            // refill this ring slot with the unit D ahead (it may belong to the next chunk; the last chunk reloads itself)
+            __builtin_amdgcn_sched_barrier(0);
+            load_b(breg[u % D], (u + D) >= U ? knext : kc, (u + D) % U);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    __syncthreads();
+    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
+}
+
+template <int MT, int NT, int WM, int WN, int NTAPS, int KCV, int D, int MINB, int DIR>
+int launch_v5d(const TapGemmArgs& a, const float* Wf, hipStream_t st) {
+    auto kern = tap_gemm_kernel_v5<MT, NT, WM, WN, NTAPS, KCV, D, MINB, DIR>;
+    const int arows = MT + 2 * a.halo;
+    size_t lds = (size_t)arows * (KCV + 4) * sizeof(float) + 2 * MT * sizeof(int);
+    if (lds < kEpilogueLds + 2 * MT * sizeof(int)) lds = kEpilogueLds + 2 * MT * sizeof(int);
+    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    PwArgs p;
+    p.g = a; p.Wf = Wf; p.kg = (a.K + 7) / 8; p.nbt = (a.N + 31) / 32;
+    p.g.ntm = asr_cdiv(a.M, MT);
+    p.g.ntn = asr_cdiv(a.N, NT);
+    hipLaunchKernelGGL(kern, dim3(p.g.ntm * p.g.ntn), dim3(256), lds, st, p);
+    ASR_CHECK_LAUNCH("tap_gemm_pw");
+    return ASR_OK;
+}
+
+template <int MT, int NT, int WM, int WN, int NTAPS, int KCV, int D, int MINB>
+int launch_v5(const TapGemmArgs& a, const float* Wf, int dir, hipStream_t st) {
+    return dir ? launch_v5d<MT, NT, WM, WN, NTAPS, KCV, D, MINB, 1>(a, Wf, st) : launch_v5d<MT, NT, WM, WN, NTAPS, KCV, D, MINB, 0>(a, Wf, st);
+}
+
+// W [ntaps][K][N] (HWIO; wmode 0) or its data-gradient view (wmode 1: taps mirrored, K and N = the GEMM's, i.e. swapped)
+// -> Wf fp32 in fragment order (see tap_gemm_kernel_v5)
+__global__ void arrange_weights_kernel(const float* __restrict__ W, int ntaps, int K, int N, int ldw, int wmode,
+                                       float* __restrict__ out) {
+    const int KG = (K + 7) >> 3, NB = (N + 31) >> 5;
+    const long total = (long)ntaps * KG * NB * 256;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int s2 = (int)(i & 3), lane = (int)((i >> 2) & 63);
+        long r = i >> 8;
+        const int nb = (int)(r % NB); r /= NB;
+        const int g8 = (int)(r % KG);
+        const int tap = (int)(r / KG);
+        const int n = nb * 32 + (lane & 31), k = g8 * 8 + 4 * (lane >> 5) + s2;
+        float x = 0.f;
+        if (k < K && n < N) x = (wmode == 0) ? W[((long)tap * K + k) * ldw + n] : W[((long)(ntaps - 1 - tap) * N + n) * ldw + k];
+        out[i] = x;
+    }
+}
+
 // ---- bx6: EXPERIMENTAL split-bf16 contraction (tools/mfma_bf16x.hip).  Every fp32 operand is
 // written as hi + mid + lo bf16 pieces (3 x 8 mantissa bits = the 24 bits of fp32) and a product as SIX
 // v_mfma_f32_32x32x16_bf16 products accumulated in fp32 (hh, hm, mh, mm, hl, lh; the dropped terms are < 2^-32 relative):
@@ -1239,6 +1423,87 @@ extern "C" int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float*
     return d->wmode ? launch_n<1, 1>(a, st) : launch_n<1, 0>(a, st);
 }
 
+
+// ---- fp32 contraction on pre-arranged weights (include/asr_hip.h)
+extern "C" size_t asr_arrange_weights_bytes(int ntaps, int K, int N) {
+    return (size_t)ntaps * ((K + 7) / 8) * ((N + 31) / 32) * 256 * sizeof(float);
+}
+
+extern "C" int asr_arrange_weights(const float* W, int ntaps, int K, int N, int ldw, int wmode, float* out, void* stream) {
+    if (!W || !out || (ntaps != 1 && ntaps != 9) || K < 1 || N < 1) return ASR_ERR_BAD_ARG;
+    const long total = (long)ntaps * ((K + 7) / 8) * ((N + 31) / 32) * 256;
+    long nb = (total + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(arrange_weights_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, W, ntaps, K, N, ldw, wmode, out);
+    ASR_CHECK_LAUNCH("arrange_weights");
+    return ASR_OK;
+}
+
+extern "C" int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const float* Wf,
+                               const float* bias, const float* scale, const float* shift,
+                               float* out_a, float* out_y, void* stream) {
+    if (!d || !A || !Wf || (!out_a && !out_y)) return ASR_ERR_BAD_ARG;
+    if (d->ntaps != 1 && d->ntaps != 9) return ASR_ERR_BAD_ARG;
+    if ((d->K & 3) || (d->N & 3) || (d->lda & 3)) return ASR_ERR_BAD_ARG;
+    if (d->ntaps == 9 && d->H <= 0) return ASR_ERR_BAD_ARG;
+    if (d->M <= 0 || d->K <= 0 || d->N <= 0) return ASR_ERR_BAD_ARG;
+    if (((uintptr_t)A | (uintptr_t)Wf) & 15) return ASR_ERR_BAD_ARG;
+    TapGemmArgs a;
+    a.A = A; a.W = nullptr; a.bias = bias; a.scale = scale; a.shift = shift;
+    a.out_a = out_a; a.out_y = out_y;
+    a.M = d->M; a.K = d->K; a.N = d->N; a.lda = d->lda; a.ldw = d->ldw;
+    a.ldo_a = d->ldo_a; a.ldo_y = d->ldo_y;
+    a.H = d->H; a.Wd = d->W; a.WP = d->W + 1; a.HPWP = (d->H + 1) * (d->W + 1);
+    if (d->H > 0 && d->M != d->B * a.HPWP) return ASR_ERR_BAD_ARG;
+    a.halo = (d->ntaps != 1) ? a.WP + 1 : 0;
+    a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
+    a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
+    a.ntm = a.ntn = 0; a.ablate = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int dir = d->wmode ? 1 : 0;       // labels the launch only (distinct kernel symbols per direction)
+    static int cfg = -1;
+    if (cfg < 0) { const char* e = getenv("ASR_PW_CFG"); cfg = e ? atoi(e) : 0; }
+    if (d->ntaps == 9) {
+        if (d->N > 64) {
+            switch (cfg) {
+                case 1: return launch_v5<128, 128, 2, 2, 9, 16, 3, 2>(a, Wf, dir, st);
+                case 2: return launch_v5<256, 64, 4, 1, 9, 16, 3, 2>(a, Wf, dir, st);
+                case 3: return launch_v5<128, 64, 2, 2, 9, 32, 4, 3>(a, Wf, dir, st);
+                case 5: return launch_v5<128, 64, 2, 2, 9, 16, 6, 3>(a, Wf, dir, st);
+                case 6: return launch_v5<128, 64, 2, 2, 9, 16, 3, 4>(a, Wf, dir, st);
+                case 7: return launch_v5<128, 64, 2, 2, 9, 16, 9, 3>(a, Wf, dir, st);
+                case 8: return launch_v5<256, 64, 2, 2, 9, 16, 3, 2>(a, Wf, dir, st);
+                default: return launch_v5<128, 64, 2, 2, 9, 16, 3, 3>(a, Wf, dir, st);
+            }
+        }
+        if (d->N > 32) {
+            switch (cfg) {
+                case 5: return launch_v5<128, 64, 2, 2, 9, 16, 6, 3>(a, Wf, dir, st);
+                case 6: return launch_v5<128, 64, 2, 2, 9, 16, 3, 4>(a, Wf, dir, st);
+                case 7: return launch_v5<128, 64, 2, 2, 9, 16, 9, 3>(a, Wf, dir, st);
+                case 8: return launch_v5<256, 64, 2, 2, 9, 16, 3, 2>(a, Wf, dir, st);
+                case 2: return launch_v5<256, 64, 4, 1, 9, 16, 3, 2>(a, Wf, dir, st);
+                case 3: return launch_v5<128, 64, 2, 2, 9, 32, 4, 3>(a, Wf, dir, st);
+                default: return launch_v5<128, 64, 2, 2, 9, 16, 3, 3>(a, Wf, dir, st);
+            }
+        }
+        if (cfg == 3) return launch_v5<256, 32, 4, 1, 9, 32, 4, 3>(a, Wf, dir, st);
+        if (cfg == 5) return launch_v5<256, 32, 4, 1, 9, 16, 6, 3>(a, Wf, dir, st);
+        if (cfg == 6) return launch_v5<256, 32, 4, 1, 9, 16, 3, 4>(a, Wf, dir, st);
+        if (cfg == 8) return launch_v5<128, 32, 4, 1, 9, 16, 3, 4>(a, Wf, dir, st);
+        return launch_v5<256, 32, 4, 1, 9, 16, 3, 3>(a, Wf, dir, st);
+    }
+    if (d->N > 64) {
+        switch (cfg) {
+            case 1: return launch_v5<128, 128, 2, 2, 1, 32, 2, 2>(a, Wf, dir, st);
+            case 2: return launch_v5<256, 128, 2, 2, 1, 32, 2, 1>(a, Wf, dir, st);
+            case 3: return launch_v5<128, 64, 2, 2, 1, 32, 4, 3>(a, Wf, dir, st);
+            default: return launch_v5<128, 128, 2, 2, 1, 32, 4, 2>(a, Wf, dir, st);
+        }
+    }
+    if (d->N > 32) return launch_v5<128, 64, 2, 2, 1, 32, 4, 3>(a, Wf, dir, st);
+    return launch_v5<256, 32, 4, 1, 1, 32, 4, 3>(a, Wf, dir, st);
+}
 
 // ---- EXPERIMENTAL split-bf16 path (include/asr_hip.h): weights pre-split by asr_split_weights, then asr_tap_gemm_bx6
 extern "C" size_t asr_split_weights_bytes(int ntaps, int K, int N) {

@@ -322,6 +322,17 @@ class DFCNNEngine:
                     _, src, dst, cin, cout, k, pool = op
                     self.ws_f[dst] = torch.zeros(ops.split_weights_bytes(9, cin, cout), dtype=torch.uint8, device=dev)
                     self.ws_b[dst] = torch.zeros(ops.split_weights_bytes(9, cout, cin), dtype=torch.uint8, device=dev)
+        # 3x3 convs (forward and data-gradient) on weights pre-arranged in MFMA fragment order (asr_arrange_weights /
+        # asr_tap_gemm_pw: same fp32 arithmetic, no weight tile in LDS, +6..20 % per layer; ASR_PW=0 = asr_tap_gemm).
+        # Both views are regenerated from the fp32 parameters at the start of every forward pass.
+        self.pw = os.environ.get('ASR_PW', '1') == '1' and not self.bx6
+        self.wf_f, self.wf_b = {}, {}
+        if self.pw:
+            for op in self.g:
+                if op[0] == 'cell' and op[1] != 'x' and op[5] == 3:
+                    _, src, dst, cin, cout, k, pool = op
+                    self.wf_f[dst] = torch.zeros(ops._lib.load().asr_arrange_weights_bytes(9, cin, cout) // 4, dtype=torch.float32, device=dev)
+                    self.wf_b[dst] = torch.zeros(ops._lib.load().asr_arrange_weights_bytes(9, cout, cin) // 4, dtype=torch.float32, device=dev)
         self.labels = torch.zeros(B, MAX_LABEL, dtype=torch.int32, device=dev)
         self.label_len = torch.zeros(B, dtype=torch.int32, device=dev)
         self.seq_len = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -365,6 +376,10 @@ class DFCNNEngine:
             cin, cout = self._cell_dims[dst]
             ops.split_weights(self.p(dst, 'w'), 9, cin, cout, cout, 0, buf)
             ops.split_weights(self.p(dst, 'w'), 9, cout, cin, cout, 1, self.ws_b[dst])
+        for dst, buf in self.wf_f.items():
+            cin, cout = self._cell_dims[dst]
+            ops.arrange_weights(self.p(dst, 'w'), 9, cin, cout, cout, 0, buf)
+            ops.arrange_weights(self.p(dst, 'w'), 9, cout, cin, cout, 1, self.wf_b[dst])
         for op in self.g:
             if op[0] == 'cell':
                 _, src, dst, cin, cout, k, pool = op
@@ -376,6 +391,8 @@ class DFCNNEngine:
                 out_y = None if pool else (self.flat[dst] if dst in self.flat else self.y[dst])
                 if dst in self.ws_f:
                     ops.tap_gemm_bx6(self.fdesc[dst], self.y[src], self.ws_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], out_y)
+                elif dst in self.wf_f:
+                    ops.tap_gemm_pw(self.fdesc[dst], self.y[src], self.wf_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], out_y)
                 else:
                     ops.tap_gemm(self.fdesc[dst], self.y[src], self.p(dst, 'w'), self.p(dst, 'b'), sc, sh,
                                  self.a[dst], out_y)
@@ -539,6 +556,8 @@ class DFCNNEngine:
                 d.accumulate = 1 if acc else 0
                 if dst in self.ws_b:
                     ops.tap_gemm_bx6(d, dz, self.ws_b[dst], None, None, None, None, dx, dgrad=True)
+                elif dst in self.wf_b:
+                    ops.tap_gemm_pw(d, dz, self.wf_b[dst], None, None, None, None, dx)
                 else:
                     ops.tap_gemm(d, dz, self.p(dst, 'w'), None, None, None, None, dx)
         if side_busy is not None:

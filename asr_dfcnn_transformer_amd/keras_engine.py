@@ -12,6 +12,7 @@ distance.  Dropout(0.3) in front of both dense layers (cnn_ctc.py:38,40): `dropo
 mask of asr_dropout (Keras' own random stream cannot be reproduced); 0 = identity, which the parity runs use.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -67,6 +68,8 @@ class KerasDFCNNEngine:
         self.a, self.y, self.yp, self.stats = {}, {}, {}, {}
         self.dz, self.dplane = {}, {}
         self.fdesc, self.bdesc, self.wdesc = {}, {}, {}
+        self.pw = os.environ.get('ASR_PW', '1') == '1'
+        self.wf_f, self.wf_b, self._dims = {}, {}, {}
         ws = 1 << 20
         for idx, (n, cp, cout, H, W, pool_after) in enumerate(self.convs):
             last = idx == len(self.convs) - 1
@@ -88,6 +91,11 @@ class KerasDFCNNEngine:
                 self.dz[geo] = Plane(B, H, W, cout, device)
                 self.dplane[geo] = Plane(B, H, W, cout, device)           # d(BN output) at this geometry
             ws = max(ws, ops.tap_wgrad_workspace(self.wdesc[n]), ops.bn_workspace(self.a[n]), ops.colsum_workspace(NP, cout))
+            if self.pw:        # forward and data-gradient views of the weights in MFMA fragment order (asr_tap_gemm_pw)
+                nb = ops._lib.load().asr_arrange_weights_bytes
+                self.wf_f[n] = z(nb(9, cp, cout) // 4)
+                self.wf_b[n] = z(nb(9, cout, cp) // 4)
+                self._dims[n] = (cp, cout)
         rows = B * self.T8
         self.h7, self.d = z(rows * hidden).view(rows, hidden), z(rows * vocab).view(rows, vocab)
         self.dh6, self.dh7, self.dd = z(rows * self.din).view(rows, self.din), z(rows * hidden).view(rows, hidden), z(rows * vocab).view(rows, vocab)
@@ -164,7 +172,13 @@ class KerasDFCNNEngine:
         self.x4.interior()[..., 0].copy_(x)
         src = self.x4
         for n, cp, cout, H, W, pool_after in self.convs:
-            ops.tap_gemm(self.fdesc[n], src, self.p(n + '/w'), self.p(n + '/b'), None, None, self.a[n], None)
+            if self.pw:
+                cp_, cout_ = self._dims[n]
+                ops.arrange_weights(self.p(n + '/w'), 9, cp_, cout_, cout_, 0, self.wf_f[n])
+                ops.arrange_weights(self.p(n + '/w'), 9, cout_, cp_, cout_, 1, self.wf_b[n])
+                ops.tap_gemm_pw(self.fdesc[n], src, self.wf_f[n], self.p(n + '/b'), None, None, self.a[n], None)
+            else:
+                ops.tap_gemm(self.fdesc[n], src, self.p(n + '/w'), self.p(n + '/b'), None, None, self.a[n], None)
             mean, rstd = self.stats[n]
             ops.bn_stats(self.a[n], BN_EPS, mean, rstd, self.ws)
             ops.bn_apply(self.a[n], mean, rstd, self.p(n + '/g'), self.p(n + '/be'), self.y[n])
@@ -235,7 +249,10 @@ class KerasDFCNNEngine:
             if idx > 0:
                 pgeo = (src.H, src.W, src.C)
                 dst = self._dsrc(pgeo, pooled=self.convs[idx - 1][5])
-                ops.tap_gemm(self.bdesc[n], dz, self.p(n + '/w'), None, None, None, None, dst)
+                if self.pw:
+                    ops.tap_gemm_pw(self.bdesc[n], dz, self.wf_b[n], None, None, None, None, dst)
+                else:
+                    ops.tap_gemm(self.bdesc[n], dz, self.p(n + '/w'), None, None, None, None, dst)
                 dy = dst
 
     def _dsrc(self, geo, pooled):

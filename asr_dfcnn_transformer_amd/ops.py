@@ -514,3 +514,42 @@ def gemm_bx6s(As, Bs, M, K, N, bias=None, relu=0, accumulate=0, Y=None, ldy=0, Y
     """Y [M][N] (+)= act(A . B^T + bias) on pre-split operands (asr_gemm_bx6s)."""
     check(_lib.load().asr_gemm_bx6s(_ptr(As), _ptr(Bs), M, K, N, _ptr(bias), relu, accumulate, _ptr(Y), ldy, _ptr(Ysplit),
                                     _stream()), 'asr_gemm_bx6s')
+
+
+# ---------------------------------------------------------------------------- fp32 contraction on pre-arranged weights
+def arrange_weights(W, ntaps, K, N, ldw, wmode=0, out=None):
+    """fp32 weights in MFMA fragment order (asr_arrange_weights); returns the float32 buffer."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(lib.asr_arrange_weights_bytes(ntaps, K, N) // 4, dtype=torch.float32, device=W.device)
+    check(lib.asr_arrange_weights(_ptr(W), ntaps, K, N, ldw, wmode, _ptr(out), _stream()), 'asr_arrange_weights')
+    return out
+
+
+def pw_symbol(ntaps, wmode, K, N):
+    """kernel instantiation asr_tap_gemm_pw launches (mirrors the rules in csrc/tap_gemm.hip), as rocprofv3 prints it"""
+    d = 1 if wmode else 0
+    if ntaps == 9:
+        return 'tap_gemm_kernel_v5<%s, 9, 16, 3, 3, %d>' % ('128, 64, 2, 2' if N > 32 else '256, 32, 4, 1', d)
+    if N > 64:
+        return 'tap_gemm_kernel_v5<128, 128, 2, 2, 1, 32, 4, 2, %d>' % d
+    return 'tap_gemm_kernel_v5<%s, 1, 32, 4, 3, %d>' % ('128, 64, 2, 2' if N > 32 else '256, 32, 4, 1', d)
+
+
+def tap_gemm_pw(desc, A, Wf, bias=None, scale=None, shift=None, out_a=None, out_y=None):
+    """asr_tap_gemm on pre-arranged weights; desc.wmode only labels the launch (forward / data-gradient symbol)."""
+    lib = _lib.load()
+    pa = A.ptr if isinstance(A, Plane) else _ptr(A)
+    po_a = out_a.ptr if isinstance(out_a, Plane) else _ptr(out_a)
+    po_y = out_y.ptr if isinstance(out_y, Plane) else _ptr(out_y)
+    call = lambda: check(lib.asr_tap_gemm_pw(C.byref(desc), pa, _ptr(Wf), _ptr(bias), _ptr(scale), _ptr(shift), po_a, po_y,
+                                             _stream()), 'asr_tap_gemm_pw')
+    t = TIMER
+    key = pw_symbol(desc.ntaps, desc.wmode, desc.K, desc.N)
+    if t is None or not t.want(key):
+        return call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    call()
+    e1.record()
+    t.add(key, _flops(desc), e0, e1)

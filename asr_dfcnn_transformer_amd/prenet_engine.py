@@ -112,7 +112,14 @@ class PreNetEngine:
             for k, cin in (('q', CH), ('k', CH), ('v', CH), ('merge', 2 * CH), ('f1', CH), ('f2', CH)):
                 self.ws_f[k] = torch.zeros(ops.split_weights_bytes(9, cin, CH), dtype=torch.uint8, device=device)
                 self.ws_b[k] = torch.zeros(ops.split_weights_bytes(9, CH, cin), dtype=torch.uint8, device=device)
-            self._cin = {'q': CH, 'k': CH, 'v': CH, 'merge': 2 * CH, 'f1': CH, 'f2': CH}
+        self._cin = {'q': CH, 'k': CH, 'v': CH, 'merge': 2 * CH, 'f1': CH, 'f2': CH}
+        # default: the same six convs on weights pre-arranged in MFMA fragment order (asr_tap_gemm_pw; ASR_PW=0 turns it off)
+        self.wf_f, self.wf_b = {}, {}
+        if os.environ.get('ASR_PW', '1') == '1' and not self.bx6:
+            nb = ops._lib.load().asr_arrange_weights_bytes
+            for k, cin in self._cin.items():
+                self.wf_f[k] = torch.zeros(nb(9, cin, CH) // 4, dtype=torch.float32, device=device)
+                self.wf_b[k] = torch.zeros(nb(9, CH, cin) // 4, dtype=torch.float32, device=device)
 
     # ---- parameters
     def p(self, name, buf=None):
@@ -192,6 +199,8 @@ class PreNetEngine:
     def _conv(self, name, src, dst):
         if name in self.ws_f:
             ops.tap_gemm_bx6(self.d_conv[name], src, self.ws_f[name], self.p(name + '/b'), None, None, dst, None)
+        elif name in self.wf_f:
+            ops.tap_gemm_pw(self.d_conv[name], src, self.wf_f[name], self.p(name + '/b'), None, None, dst, None)
         else:
             ops.tap_gemm(self.d_conv[name], src, self.p(name + '/w'), self.p(name + '/b'), None, None, dst, None)
 
@@ -207,6 +216,8 @@ class PreNetEngine:
             d.accumulate = 1 if accumulate else 0
             if name in self.ws_b:
                 ops.tap_gemm_bx6(d, dz, self.ws_b[name], None, None, None, None, dx, dgrad=True)
+            elif name in self.wf_b:
+                ops.tap_gemm_pw(d, dz, self.wf_b[name], None, None, None, None, dx)
             else:
                 ops.tap_gemm(d, dz, self.p(name + '/w'), None, None, None, None, dx)
 
@@ -220,6 +231,10 @@ class PreNetEngine:
             cin = self._cin[k]
             ops.split_weights(self.p(k + '/w'), 9, cin, CH, CH, 0, buf)
             ops.split_weights(self.p(k + '/w'), 9, CH, cin, CH, 1, self.ws_b[k])
+        for k, buf in self.wf_f.items():
+            cin = self._cin[k]
+            ops.arrange_weights(self.p(k + '/w'), 9, cin, CH, CH, 0, buf)
+            ops.arrange_weights(self.p(k + '/w'), 9, CH, cin, CH, 1, self.wf_b[k])
         ops.prenet_conv1_fwd(x, self.p('conv1/w'), self.p('conv1/b'), self.a1)
         self._bn('bn1', self.a1, self.x1s, dst_phase_split=True)
         ops.conv_s2_expand(self.p('conv2/w'), CH, CH, self.W4)

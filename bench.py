@@ -45,6 +45,8 @@ def is_forward_symbol(sym):
     if not sym.startswith('tap_gemm_kernel'):
         return False
     args = [a.strip() for a in sym[sym.index('<') + 1:sym.rindex('>')].split(',')]
+    if sym.startswith('tap_gemm_kernel_v5'):           # <MT, NT, WM, WN, NTAPS, KC, D, MINB, DIR>
+        return args[8] == '0'
     return args[5] == '0'
 
 

@@ -349,6 +349,19 @@ size_t asr_pix_ln_bwd_workspace(const asr_pixmap* m);
 int asr_pix_ln_bwd(const float* dy, const float* xhat, const float* rstd, const asr_pixmap* m, const float* gamma,
                    float* dx, float* dgamma, float* dbeta, float* workspace, void* stream);
 
+/* fp32 contraction on PRE-ARRANGED weights: same arguments, arithmetic (v_mfma_f32_32x32x2_f32, fp32 accumulate) and
+ * epilogue as asr_tap_gemm; the weight tensor is first copied into MFMA fragment order, once per optimiser step:
+ *   asr_arrange_weights(W, ntaps, K, N, ldw, wmode, out): out = fp32 [ntaps][ceil(K/8)][ceil(N/32)][64 lanes][4], lane
+ *   32h+i = column 32*block+i, contraction indices 8*group+4h..+3, zero padded; wmode 1 takes the data-gradient view of a
+ *   forward tensor (K, N = the GEMM's, i.e. swapped; taps mirrored), after which desc.wmode is ignored.
+ * The B operands then arrive as one coalesced float4 per lane straight from L2 (no weight tile in LDS, two barriers per
+ * K chunk instead of two per tap). */
+size_t asr_arrange_weights_bytes(int ntaps, int K, int N);
+int asr_arrange_weights(const float* W, int ntaps, int K, int N, int ldw, int wmode, float* out, void* stream);
+int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const float* Warranged,
+                    const float* bias, const float* scale, const float* shift,
+                    float* out_a, float* out_y, void* stream);
+
 /* ====================================================================== EXPERIMENTAL: split-bf16 contractions
  * (DESIGN.md section 9).  Same contraction and epilogue as asr_tap_gemm, computed as six v_mfma_f32_32x32x16_bf16
  * products of the hi/mid/lo bf16 pieces of the fp32 operands with fp32 accumulation (fp32-chain accuracy, 2.6x the matrix
