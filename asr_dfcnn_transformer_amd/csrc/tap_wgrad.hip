@@ -741,7 +741,9 @@ template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS>
 int launch_wgrad(const WgradArgs& a, const Plan& p, int K, int N, hipStream_t st) {
     // 3x3: v1 (batched direct staging, 2 workgroups per CU) wins almost everywhere, v2 (register prefetch + LDS
     // double buffer, 1 workgroup per CU) only for the 64->64 class; dense / 1x1 (no halo): v3 (dZ in registers,
-    // half-length runs) is 10-30 % faster (tools/bench_layers.py).  ASR_WGRAD_VARIANT forces one.
+    // half-length runs) is 10-30 % faster (tools/bench_layers.py).  ASR_WGRAD_VARIANT forces one.  (A v1 with the next
+    // run register-prefetched at 2 workgroups per CU was tried again with pinned, branch-free loads: 144 accumulator +
+    // 56 prefetch registers spill, 66 vs 99 TFLOP/s -- removed.)
     static int forced = -1;
     if (forced < 0) { const char* e = getenv("ASR_WGRAD_VARIANT"); forced = e ? atoi(e) : 0; }
     const int variant = (NTAPS == 4) ? 1 : (forced >= 1 && forced <= 3) ? forced : (NTAPS == 1 ? 3 : ((WAVES_N == 2 && K >= 64) ? 2 : 1));
