@@ -483,317 +483,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
     tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
 }
 
-// ---- v3 (3x3 only): ALL NINE weight taps of a 16-channel chunk are staged together with the A tile, so a
-// workgroup synchronises twice per chunk (144 MFMAs per wave in between) instead of twice per tap.  Waves of one
-// workgroup sit on four different SIMDs, each shared with other workgroups, so they drift apart under contention;
-// every barrier re-aligns them, and with a barrier pair every 16-32 MFMAs the matrix pipe idled ~25 % of the time.
-template <int MT, int NT, int WM, int WN, int WMODE>
-__global__ __launch_bounds__(256) void tap_gemm_kernel_v3(TapGemmArgs g) {
-    constexpr int KC = 16, AP = KC + 4, NTAPS = 9;
-    constexpr int TM = MT / WM / 32, TN = NT / WN / 32;
-    constexpr int WTAP = (WMODE == 0) ? KC * NT : NT * (KC + 1);      // floats per tap in LDS
-    constexpr int WF4 = KC * NT / 4;                                   // float4 per tap in global memory
-    constexpr int SB = 4;
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int halo = g.halo;
-    const int arows = MT + 2 * halo;
-    int* rowa = (int*)smem;
-    int* rowy = rowa + MT;
-    float* tile_lds = smem + 2 * MT;
-    float* As = tile_lds;
-    float* Ws = As + arows * AP;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = tid >> 6, wm = wave / WN, wn = wave % WN;
-    const int swz = asr_xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile_m = swz / g.ntn, tile_n = swz - tile_m * g.ntn;
-    const long p0 = (long)tile_m * MT;
-    const int n0 = tile_n * NT;
-    const int K = g.K, N = g.N;
-
-    if (tid < MT) {
-        const long p = p0 + tid;
-        int ra = -1, ry = -1;
-        if (p < g.M) {
-            const int b = (int)(p / g.HPWP);
-            const int r = (int)(p - (long)b * g.HPWP);
-            const int hh = r / g.WP, ww = r - hh * g.WP;
-            if (hh >= 1 && hh <= g.H && ww >= 1 && ww <= g.Wd) {
-                ra = (int)p;
-                ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : (int)p;
-            }
-        }
-        rowa[tid] = ra; rowy[tid] = ry;
-    }
-
-    floatx16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int nkc = (K + KC - 1) / KC;
-    const int atotal = arows * (KC / 4);
-    for (int kc = 0; kc < nkc; ++kc) {
-        __syncthreads();
-        // ---- stage the A tile chunk and the nine weight tiles (batches of SB independent loads)
-        for (int base = 0; base < atotal; base += SB * 256) {
-            float4 t[SB];
-#pragma unroll
-            for (int i = 0; i < SB; ++i) {
-                const int f = base + tid + i * 256;
-                const int row = f / (KC / 4), c4 = f - row * (KC / 4);
-                const long grow = p0 - halo + row;
-                const int kk = kc * KC + c4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (f < atotal && grow >= g.rmin && grow < g.rmax && kk < K) v = *(const float4*)(g.A + grow * g.lda + kk);
-                t[i] = v;
-            }
-#pragma unroll
-            for (int i = 0; i < SB; ++i) {
-                const int f = base + tid + i * 256;
-                const int row = f / (KC / 4), c4 = f - row * (KC / 4);
-                if (f < atotal) *(float4*)(As + row * AP + c4 * 4) = t[i];
-            }
-        }
-        for (int base = 0; base < NTAPS * WF4; base += SB * 256) {
-            float4 t[SB];
-#pragma unroll
-            for (int i = 0; i < SB; ++i) {
-                const int f = base + tid + i * 256;
-                const int tap = f / WF4, q = f - tap * WF4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (f < NTAPS * WF4) {
-                    if (WMODE == 0) {
-                        const int k = q / (NT / 4), n4 = q - k * (NT / 4);
-                        const int kk = kc * KC + k, nn = n0 + n4 * 4;
-                        if (kk < K && nn < N) v = *(const float4*)(g.W + ((long)tap * K + kk) * g.ldw + nn);
-                    } else {
-                        const int n = q / (KC / 4), k4 = q - n * (KC / 4);
-                        const int kk = kc * KC + k4 * 4, nn = n0 + n;
-                        if (kk < K && nn < N) v = *(const float4*)(g.W + ((long)(NTAPS - 1 - tap) * N + nn) * g.ldw + kk);
-                    }
-                }
-                t[i] = v;
-            }
-#pragma unroll
-            for (int i = 0; i < SB; ++i) {
-                const int f = base + tid + i * 256;
-                const int tap = f / WF4, q = f - tap * WF4;
-                if (f < NTAPS * WF4) {
-                    if (WMODE == 0) {
-                        const int k = q / (NT / 4), n4 = q - k * (NT / 4);
-                        *(float4*)(Ws + tap * WTAP + k * NT + n4 * 4) = t[i];
-                    } else {
-                        const int n = q / (KC / 4), k4 = q - n * (KC / 4);
-                        float* d = Ws + tap * WTAP + n * (KC + 1) + k4 * 4;
-                        d[0] = t[i].x; d[1] = t[i].y; d[2] = t[i].z; d[3] = t[i].w;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // ---- 9 taps x 2 groups of 8 channels, no synchronisation in between
-        for (int tap = 0; tap < NTAPS; ++tap) {
-            const int toff = halo + ((tap / 3) - 1) * g.WP + (tap % 3) - 1;
-            const float* abase = As + (wm * (TM * 32) + li + toff) * AP + 4 * lh;
-            const float* wt = Ws + tap * WTAP;
-            const float* wbase = (WMODE == 0) ? (wt + (4 * lh) * NT + wn * (TN * 32) + li)
-                                              : (wt + (wn * (TN * 32) + li) * (KC + 1) + 4 * lh);
-#pragma unroll
-            for (int gk = 0; gk < KC / 8; ++gk) {
-                float4 av[TM];
-                float bv[TN][4];
-#pragma unroll
-                for (int a = 0; a < TM; ++a) av[a] = *(const float4*)(abase + a * 32 * AP + gk * 8);
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-#pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2)
-                        bv[b][s2] = (WMODE == 0) ? wbase[(gk * 8 + s2) * NT + b * 32]
-                                                 : wbase[b * 32 * (KC + 1) + gk * 8 + s2];
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) {
-#pragma unroll
-                    for (int a = 0; a < TM; ++a) {
-                        const float as = (s2 == 0) ? av[a].x : (s2 == 1) ? av[a].y : (s2 == 2) ? av[a].z : av[a].w;
-#pragma unroll
-                        for (int b = 0; b < TN; ++b)
-                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bv[b][s2], acc[a][b], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    }
-
-    // epilogue (tap_epilogue): transpose through LDS, float4 stores.  The staging tiles are dead by now.
-    __syncthreads();
-    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
-}
-
-
-// ---- v4: the weight operand never touches LDS.  A lane's B operand of v_mfma_f32_32x32x2 is W[k][n = lane & 31]:
-// rows of the HWIO tensor are contiguous in n, so one global dword load per (k, half-wave) is two coalesced 128-byte
-// rows (forward), and the data-gradient's transposed view is contiguous in k, i.e. one float4 per lane feeds four
-// MFMAs.  The loads run D pipeline units (one unit = 8 contraction indices of one tap) ahead in a register ring,
-// they survive the barriers, and the only LDS traffic left is the A tile: two barriers per CHUNK instead of two
-// per tap, no weight staging writes, and LDS small enough that registers alone set the occupancy.
-template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE, int KCV, int D>
-__global__ __launch_bounds__(256) void tap_gemm_kernel_v4(TapGemmArgs g) {
-    constexpr int KC = KCV, AP = KCV + 4;
-    constexpr int TM = MT / WM / 32, TN = NT / WN / 32;
-    constexpr int GK = KC / 8;               // 8-wide contraction groups per chunk
-    constexpr int U = NTAPS * GK;            // pipeline units per chunk
-    constexpr int SB = 4;
-    static_assert(U % D == 0 && TM >= 1 && TN >= 1, "ring depth must divide the units of a chunk");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int halo = g.halo;
-    const int arows = MT + 2 * halo;
-    int* rowa = (int*)smem;
-    int* rowy = rowa + MT;
-    float* tile_lds = smem + 2 * MT;
-    float* As = tile_lds;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = tid >> 6, wm = wave / WN, wn = wave % WN;
-    const int swz = asr_xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile_m = swz / g.ntn, tile_n = swz - tile_m * g.ntn;
-    const long p0 = (long)tile_m * MT;
-    const int n0 = tile_n * NT;
-    const int K = g.K, N = g.N;
-
-    if (tid < MT) {
-        const long p = p0 + tid;
-        int ra = -1, ry = -1;
-        if (p < g.M) {
-            if (g.H == 0) {
-                ra = (int)p; ry = (int)p;
-            } else {
-                const int b = (int)(p / g.HPWP);
-                const int r = (int)(p - (long)b * g.HPWP);
-                const int hh = r / g.WP, ww = r - hh * g.WP;
-                if (hh >= 1 && hh <= g.H && ww >= 1 && ww <= g.Wd) {
-                    ra = (int)p;
-                    ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : (int)p;
-                }
-            }
-        }
-        rowa[tid] = ra; rowy[tid] = ry;
-    }
-
-    floatx16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int nkc = (K + KC - 1) / KC;
-    float breg[D][TN][4];
-    const int ncol = n0 + wn * (TN * 32) + li;           // this lane's output column of sub-tile b = 0
-
-    // B operands of unit u (tap = u / GK, group = u % GK) of chunk kc into ring slot `slot`
-    auto load_b = [&](float (&dst)[TN][4], int kc, int u) {
-        const int tap = u / GK, gk = u - tap * GK;
-        const int kk = kc * KC + gk * 8 + 4 * lh;
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-            const int n = ncol + b * 32;
-            if (WMODE == 0) {
-                const float* src = g.W + ((long)tap * K + kk) * g.ldw + n;
-#pragma unroll
-                for (int s2 = 0; s2 < 4; ++s2) dst[b][s2] = (kk + s2 < K && n < N) ? src[(long)s2 * g.ldw] : 0.f;
-            } else {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kk < K && n < N) v = *(const float4*)(g.W + ((long)(NTAPS - 1 - tap) * N + n) * g.ldw + kk);
-                dst[b][0] = v.x; dst[b][1] = v.y; dst[b][2] = v.z; dst[b][3] = v.w;
-            }
-        }
-    };
-    auto load_a_row = [&](int f, int kc) -> float4 {
-        const int row = f / (KC / 4), c4 = f - row * (KC / 4);
-        const long grow = p0 - halo + row;
-        const int kk = kc * KC + c4 * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (grow >= g.rmin && grow < g.rmax && kk < K) v = *(const float4*)(g.A + grow * g.lda + kk);
-        return v;
-    };
-
-#pragma unroll
-    for (int d = 0; d < D; ++d) load_b(breg[d], 0, d);
-
-    for (int kc = 0; kc < nkc; ++kc) {
-        __syncthreads();
-        for (int base = 0; base < arows * (KC / 4); base += SB * 256) {
-            float4 t[SB];
-#pragma unroll
-            for (int i = 0; i < SB; ++i) {
-                const int f = base + tid + i * 256;
-                t[i] = (f < arows * (KC / 4)) ? load_a_row(f, kc) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int i = 0; i < SB; ++i) {
-                const int f = base + tid + i * 256;
-                if (f < arows * (KC / 4)) *(float4*)(As + (f / (KC / 4)) * AP + (f % (KC / 4)) * 4) = t[i];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int tap = u / GK, gk = u - tap * GK;
-            const int toff = halo + ((NTAPS == 9) ? ((tap / 3) - 1) * g.WP + (tap % 3) - 1 : 0);
-            const float* abase = As + (wm * (TM * 32) + li + toff) * AP + 4 * lh + gk * 8;
-            float4 av[TM];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) av[a] = *(const float4*)(abase + a * 32 * AP);
-#pragma unroll
-            for (int s2 = 0; s2 < 4; ++s2) {
-#pragma unroll
-                for (int a = 0; a < TM; ++a) {
-                    const float as = (s2 == 0) ? av[a].x : (s2 == 1) ? av[a].y : (s2 == 2) ? av[a].z : av[a].w;
-#pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, breg[u % D][b][s2], acc[a][b], 0, 0, 0);
-                }
-            }
-            // refill this ring slot with the unit D ahead (it may belong to the next chunk)
-            const int nu = (u + D) % U, nk = kc + ((u + D) >= U ? 1 : 0);
-            if (nk < nkc) load_b(breg[u % D], nk, nu);
-        }
-    }
-
-    __syncthreads();
-    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
-}
-
-template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE, int KCV, int D>
-int launch_v4(const TapGemmArgs& a, hipStream_t st) {
-    auto kern = tap_gemm_kernel_v4<MT, NT, WM, WN, NTAPS, WMODE, KCV, D>;
-    const int arows = MT + 2 * a.halo;
-    size_t lds = (size_t)arows * (KCV + 4) * sizeof(float) + 2 * MT * sizeof(int);
-    if (lds < kEpilogueLds + 2 * MT * sizeof(int)) lds = kEpilogueLds + 2 * MT * sizeof(int);
-    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    TapGemmArgs g = a;
-    g.ntm = asr_cdiv(a.M, MT);
-    g.ntn = asr_cdiv(a.N, NT);
-    hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn), dim3(256), lds, st, g);
-    ASR_CHECK_LAUNCH("tap_gemm");
-    return ASR_OK;
-}
-
-// ---- v5 ("pw"): v4 with the weights PRE-ARRANGED in MFMA fragment order (asr_arrange_weights, once per optimiser step):
+// ---- v5 ("pw"): the weight operand never touches LDS -- it is PRE-ARRANGED in MFMA fragment order (asr_arrange_weights, once per optimiser step):
 // Wf [tap][K/8 groups][ceil(N/32) column blocks][64 lanes][4] fp32, lane 32h+i = column 32*block+i, contraction indices
 // 8*group + 4h .. + 3 -- the B operands of four consecutive v_mfma_f32_32x32x2_f32 are ONE coalesced float4 per lane
 // (1 KB per wave), identical for the forward and the data-gradient view.  All ring loads are branch-free (zero padding,
@@ -1263,28 +953,6 @@ int launch_v1(const TapGemmArgs& a, hipStream_t st) {
     return ASR_OK;
 }
 
-template <int MT, int NT, int WM, int WN, int WMODE>
-int launch_v3(const TapGemmArgs& a, hipStream_t st) {
-    auto kern = tap_gemm_kernel_v3<MT, NT, WM, WN, WMODE>;
-    constexpr int KCV = 16;
-    const int arows = MT + 2 * a.halo;
-    const size_t wfl = (size_t)(9 * ((WMODE == 0) ? KCV * NT : NT * (KCV + 1)) + 3) / 4 * 4;
-    size_t lds = ((size_t)arows * (KCV + 4) + wfl) * sizeof(float) + 2 * MT * sizeof(int);
-    if (lds < kEpilogueLds + 2 * MT * sizeof(int)) lds = kEpilogueLds + 2 * MT * sizeof(int);
-    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    TapGemmArgs g = a;
-    g.ntm = asr_cdiv(a.M, MT);
-    g.ntn = asr_cdiv(a.N, NT);
-    hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn), dim3(256), lds, st, g);
-    ASR_CHECK_LAUNCH("tap_gemm");
-    return ASR_OK;
-}
-
 template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE>
 int launch_v2(const TapGemmArgs& a, hipStream_t st) {
     auto kern = tap_gemm_kernel<MT, NT, WM, WN, NTAPS, WMODE>;
@@ -1346,26 +1014,6 @@ int launch_n(const TapGemmArgs& a, hipStream_t st) {
             if (a.N > 64 && tiles <= 1024) return launch_v1<128, 128, 2, 2, NTAPS, WMODE, 16>(a, st);
         }
     }
-    {
-        const int ex = tap_gemm_experiment();
-        if (ex == 7 || ex == 8) {       // v4 (weights straight from global memory)
-            if constexpr (NTAPS == 9) {
-                if (a.N > 128) return launch_v4<128, 128, 2, 2, NTAPS, WMODE, 16, 3>(a, st);
-                if (a.N > 32) {
-                    if (ex == 8) return launch_v4<128, 64, 2, 2, NTAPS, WMODE, 32, 3>(a, st);
-                    return launch_v4<128, 64, 2, 2, NTAPS, WMODE, 16, 3>(a, st);
-                }
-                return launch_v4<256, 32, 4, 1, NTAPS, WMODE, 16, 3>(a, st);
-            } else {
-                if (a.N > 64) {
-                    if (ex == 8) return launch_v4<128, 64, 2, 2, NTAPS, WMODE, 32, 2>(a, st);
-                    return launch_v4<128, 128, 2, 2, NTAPS, WMODE, 32, 2>(a, st);
-                }
-                if (a.N > 32) return launch_v4<128, 64, 2, 2, NTAPS, WMODE, 32, 2>(a, st);
-                return launch_v4<256, 32, 4, 1, NTAPS, WMODE, 32, 2>(a, st);
-            }
-        }
-    }
     if (NTAPS == 9) {
         const int ex = tap_gemm_experiment();
         if (ex == 1 && a.N > 64) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
@@ -1373,8 +1021,6 @@ int launch_n(const TapGemmArgs& a, hipStream_t st) {
         if (ex == 2 && a.N > 32) return launch_v1<256, 64, 4, 1, NTAPS, WMODE, 16>(a, st);
         if (ex == 3 && a.N > 32 && a.N <= 64) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
         if (ex == 4 && a.N > 32) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 16>(a, st);
-        if (ex == 5 && a.N > 32) return launch_v3<128, 64, 2, 2, WMODE>(a, st);
-        if (ex == 6) { if (a.N > 32) return launch_v3<128, 64, 2, 2, WMODE>(a, st); return launch_v3<256, 32, 4, 1, WMODE>(a, st); }
         if (ex == 0) {
             // measured on the DFCNN layer shapes (tools/bench_layers.py, profiles/r01b_layer_tiles.txt):
             // 128x64 tiles (more, smaller workgroups per CU) win up to 128 output channels; a 16-deep
@@ -1461,46 +1107,15 @@ extern "C" int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const flo
     a.ntm = a.ntn = 0; a.ablate = 0;
     hipStream_t st = (hipStream_t)stream;
     const int dir = d->wmode ? 1 : 0;       // labels the launch only (distinct kernel symbols per direction)
-    static int cfg = -1;
-    if (cfg < 0) { const char* e = getenv("ASR_PW_CFG"); cfg = e ? atoi(e) : 0; }
+    // tile choice (tools/bench_pw.py, MI355X): 128x64 workgroup tiles with a 16-deep chunk and a 3-unit ring win on every
+    // 3x3 layer (deeper rings, 32-deep chunks, 256-row or 128-column tiles: -1..-8 %); for the 1-tap GEMMs the LDS-staged
+    // asr_tap_gemm stays faster (0.86-0.97x here: no tap reuse to pay for the direct weight loads), so the engines use
+    // this entry point for ntaps = 9 only -- the 1-tap configurations exist for completeness and tests
     if (d->ntaps == 9) {
-        if (d->N > 64) {
-            switch (cfg) {
-                case 1: return launch_v5<128, 128, 2, 2, 9, 16, 3, 2>(a, Wf, dir, st);
-                case 2: return launch_v5<256, 64, 4, 1, 9, 16, 3, 2>(a, Wf, dir, st);
-                case 3: return launch_v5<128, 64, 2, 2, 9, 32, 4, 3>(a, Wf, dir, st);
-                case 5: return launch_v5<128, 64, 2, 2, 9, 16, 6, 3>(a, Wf, dir, st);
-                case 6: return launch_v5<128, 64, 2, 2, 9, 16, 3, 4>(a, Wf, dir, st);
-                case 7: return launch_v5<128, 64, 2, 2, 9, 16, 9, 3>(a, Wf, dir, st);
-                case 8: return launch_v5<256, 64, 2, 2, 9, 16, 3, 2>(a, Wf, dir, st);
-                default: return launch_v5<128, 64, 2, 2, 9, 16, 3, 3>(a, Wf, dir, st);
-            }
-        }
-        if (d->N > 32) {
-            switch (cfg) {
-                case 5: return launch_v5<128, 64, 2, 2, 9, 16, 6, 3>(a, Wf, dir, st);
-                case 6: return launch_v5<128, 64, 2, 2, 9, 16, 3, 4>(a, Wf, dir, st);
-                case 7: return launch_v5<128, 64, 2, 2, 9, 16, 9, 3>(a, Wf, dir, st);
-                case 8: return launch_v5<256, 64, 2, 2, 9, 16, 3, 2>(a, Wf, dir, st);
-                case 2: return launch_v5<256, 64, 4, 1, 9, 16, 3, 2>(a, Wf, dir, st);
-                case 3: return launch_v5<128, 64, 2, 2, 9, 32, 4, 3>(a, Wf, dir, st);
-                default: return launch_v5<128, 64, 2, 2, 9, 16, 3, 3>(a, Wf, dir, st);
-            }
-        }
-        if (cfg == 3) return launch_v5<256, 32, 4, 1, 9, 32, 4, 3>(a, Wf, dir, st);
-        if (cfg == 5) return launch_v5<256, 32, 4, 1, 9, 16, 6, 3>(a, Wf, dir, st);
-        if (cfg == 6) return launch_v5<256, 32, 4, 1, 9, 16, 3, 4>(a, Wf, dir, st);
-        if (cfg == 8) return launch_v5<128, 32, 4, 1, 9, 16, 3, 4>(a, Wf, dir, st);
+        if (d->N > 32) return launch_v5<128, 64, 2, 2, 9, 16, 3, 3>(a, Wf, dir, st);
         return launch_v5<256, 32, 4, 1, 9, 16, 3, 3>(a, Wf, dir, st);
     }
-    if (d->N > 64) {
-        switch (cfg) {
-            case 1: return launch_v5<128, 128, 2, 2, 1, 32, 2, 2>(a, Wf, dir, st);
-            case 2: return launch_v5<256, 128, 2, 2, 1, 32, 2, 1>(a, Wf, dir, st);
-            case 3: return launch_v5<128, 64, 2, 2, 1, 32, 4, 3>(a, Wf, dir, st);
-            default: return launch_v5<128, 128, 2, 2, 1, 32, 4, 2>(a, Wf, dir, st);
-        }
-    }
+    if (d->N > 64) return launch_v5<128, 128, 2, 2, 1, 32, 4, 2>(a, Wf, dir, st);
     if (d->N > 32) return launch_v5<128, 64, 2, 2, 1, 32, 4, 3>(a, Wf, dir, st);
     return launch_v5<256, 32, 4, 1, 1, 32, 4, 3>(a, Wf, dir, st);
 }

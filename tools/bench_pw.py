@@ -1,6 +1,6 @@
 """A/B of the fp32 contraction on pre-arranged weights (asr_arrange_weights + asr_tap_gemm_pw, tap_gemm_kernel_v5) against
 asr_tap_gemm on the DFCNN layer shapes (forward conv and data-gradient) and the dense / Transformer GEMM shapes.
-ASR_PW_CFG=n selects a tile configuration of the kernel under test."""
+(The tile sweeps behind the launcher's rules used an ASR_PW_CFG switch that has since been removed.)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,7 +22,7 @@ def timeit(fn, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
-for name, H, W, cin, cout in SHAPES:
+for name, H, W, cin, cout in ([] if os.environ.get('DENSE_ONLY') else SHAPES):
     g = torch.Generator(device='cuda').manual_seed(0)
     x = Plane(B, H, W, cin); x.set_interior(torch.randn(B, H, W, cin, device='cuda', generator=g))
     w = torch.randn(3, 3, cin, cout, device='cuda', generator=g) * (2.0 / (9 * cin)) ** 0.5
