@@ -652,18 +652,31 @@ int launch_v5(const TapGemmArgs& a, const float* Wf, int dir, hipStream_t st) {
 // -> Wf fp32 in fragment order (see tap_gemm_kernel_v5)
 __global__ void arrange_weights_kernel(const float* __restrict__ W, int ntaps, int K, int N, int ldw, int wmode,
                                        float* __restrict__ out) {
+    // one thread = one lane's float4 (4 consecutive contraction indices of one column): the forward view reads four
+    // rows (each coalesced over the 32 columns of a block), the data-gradient view one float4; the store is coalesced
     const int KG = (K + 7) >> 3, NB = (N + 31) >> 5;
-    const long total = (long)ntaps * KG * NB * 256;
+    const long total = (long)ntaps * KG * NB * 64;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int s2 = (int)(i & 3), lane = (int)((i >> 2) & 63);
-        long r = i >> 8;
+        const int lane = (int)(i & 63);
+        long r = i >> 6;
         const int nb = (int)(r % NB); r /= NB;
         const int g8 = (int)(r % KG);
         const int tap = (int)(r / KG);
-        const int n = nb * 32 + (lane & 31), k = g8 * 8 + 4 * (lane >> 5) + s2;
-        float x = 0.f;
-        if (k < K && n < N) x = (wmode == 0) ? W[((long)tap * K + k) * ldw + n] : W[((long)(ntaps - 1 - tap) * N + n) * ldw + k];
-        out[i] = x;
+        const int n = nb * 32 + (lane & 31), k = g8 * 8 + 4 * (lane >> 5);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N) {
+            if (wmode == 0) {
+                const float* src = W + ((long)tap * K + k) * ldw + n;
+                if (k < K) v.x = src[0];
+                if (k + 1 < K) v.y = src[ldw];
+                if (k + 2 < K) v.z = src[2 * (long)ldw];
+                if (k + 3 < K) v.w = src[3 * (long)ldw];
+            } else {
+                const float* src = W + ((long)(ntaps - 1 - tap) * N + n) * ldw + k;
+                if (k + 3 < K) v = *(const float4*)src;      // K (= ldw-contiguous) is a multiple of 4 (checked by the caller)
+            }
+        }
+        *(float4*)(out + i * 4) = v;
     }
 }
 
@@ -877,24 +890,37 @@ __global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_bx6(BxArgs args) {
 // contiguous, fully coalesced 1 KB wave load (Kp = K rounded up to 32; k >= K and columns >= N are zero)
 __global__ void split_weights_kernel(const float* __restrict__ W, int ntaps, int K, int N, int ldw, int wmode, int Kp,
                                      __bf16* __restrict__ out) {
+    // one thread = one lane's 8 contraction indices of one column: 8 row reads (forward view; each coalesced over the 32
+    // columns of a block) or two float4 (data-gradient view), three coalesced 16-byte stores
     const int NB = (N + 31) >> 5, KST = Kp >> 4;
     const long per_piece = (long)KST * NB * 512;
-    const long total = (long)ntaps * per_piece;
+    const long total = (long)ntaps * KST * NB * 64;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        long r = i >> 9;
+        const int lane = (int)(i & 63);
+        long r = i >> 6;
         const int nb = (int)(r % NB); r /= NB;
         const int ks = (int)(r % KST);
         const int tap = (int)(r / KST);
-        const int n = nb * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8 + j;
-        float x = 0.f;
-        if (k < K && n < N) x = (wmode == 0) ? W[((long)tap * K + k) * ldw + n] : W[((long)(ntaps - 1 - tap) * N + n) * ldw + k];
-        __bf16 h, m, l;
-        split3(x, h, m, l);
-        const long o = (long)tap * 3 * per_piece + (i - (long)tap * per_piece);
-        out[o] = h;
-        out[o + per_piece] = m;
-        out[o + 2 * per_piece] = l;
+        const int n = nb * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8;
+        float e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = 0.f;
+        if (n < N) {
+            if (wmode == 0) {
+                const float* src = W + ((long)tap * K + k) * ldw + n;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (k + j < K) e[j] = src[(long)j * ldw];
+            } else {
+                const float* src = W + ((long)(ntaps - 1 - tap) * N + n) * ldw + k;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (k + j < K) e[j] = src[j];
+            }
+        }
+        bf16x8 h, m, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { __bf16 a, b, c; split3(e[j], a, b, c); h[j] = a; m[j] = b; l[j] = c; }
+        __bf16* d = out + (long)tap * 3 * per_piece + (i - (long)tap * KST * NB * 64) * 8;
+        *(bf16x8*)d = h; *(bf16x8*)(d + per_piece) = m; *(bf16x8*)(d + 2 * per_piece) = l;
     }
 }
 
@@ -1077,7 +1103,8 @@ extern "C" size_t asr_arrange_weights_bytes(int ntaps, int K, int N) {
 
 extern "C" int asr_arrange_weights(const float* W, int ntaps, int K, int N, int ldw, int wmode, float* out, void* stream) {
     if (!W || !out || (ntaps != 1 && ntaps != 9) || K < 1 || N < 1) return ASR_ERR_BAD_ARG;
-    const long total = (long)ntaps * ((K + 7) / 8) * ((N + 31) / 32) * 256;
+    if ((K & 3) || (ldw & 3) || (((uintptr_t)W | (uintptr_t)out) & 15)) return ASR_ERR_BAD_ARG;
+    const long total = (long)ntaps * ((K + 7) / 8) * ((N + 31) / 32) * 64;
     long nb = (total + 255) / 256;
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(arrange_weights_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, W, ntaps, K, N, ldw, wmode, out);
@@ -1129,7 +1156,7 @@ extern "C" size_t asr_split_weights_bytes(int ntaps, int K, int N) {
 extern "C" int asr_split_weights(const float* W, int ntaps, int K, int N, int ldw, int wmode, void* out, void* stream) {
     if (!W || !out || (ntaps != 1 && ntaps != 9) || K < 1 || N < 1) return ASR_ERR_BAD_ARG;
     const int Kp = (K + 31) / 32 * 32;
-    const long total = (long)ntaps * ((N + 31) / 32 * 32) * Kp;
+    const long total = (long)ntaps * ((N + 31) / 32 * 32) * Kp / 8;
     long nb = (total + 255) / 256;
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(split_weights_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, W, ntaps, K, N, ldw, wmode, Kp,
