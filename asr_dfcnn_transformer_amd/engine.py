@@ -6,6 +6,7 @@ Graphs follow the reference model files:
   'm2'  lm_and_am/model/acoustic_model2.py:37-74   SE-DFCNN, "maxpool" = average pool
   'm1'  lm_and_am/model/acoustic_model.py:37-62    plain DFCNN, max pool, NiN cell, 6400->128->V head
   'm3'  lm_and_am/model/acoustic_model3.py:37-67   SE applied to the pooled cell itself, no BN in SE
+  'amlm' lm_and_am/model/am_lm_model.py:56-66      acoustic half of the joint AM+LM graph (joint_engine.py)
 Every cell is conv -> +bias -> ReLU -> frozen-affine BN -> [pool].
 """
 import math
@@ -60,6 +61,15 @@ def graph(model, vocab, widths=None, feat=200):
              ('cell', 'h3s', 'h3b', c3, c3, 3, None),
              ('cell', 'h3b', 'h6a', c3, c3, 3, None), ('cell', 'h6a', 'h6', c3, c6, 3, None),
              ('dense', 'h6', 'd', (feat // 8) * c6, vocab, 'softmax')]
+    elif model == 'amlm':
+        # acoustic half of the joint graph, am_lm_model.py:56-66,163-175: cnn_cell(32), cnn_cell(64), three NiN cells of
+        # 128 (3x3 -> 1x1 to 32 -> 3x3; the first one pooled), dense(128, relu) = h7 (fed to the language half), dense(V)
+        c1, c2, c3, nin, hid = widths or (32, 64, 128, 32, 128)
+        g = [('cell', 'x', 'h1', 1, c1, 3, 'max'), ('cell', 'h1', 'h2', c1, c2, 3, 'max'),
+             ('cell', 'h2', 'h3a', c2, c3, 3, None), ('cell', 'h3a', 'h3n', c3, nin, 1, None), ('cell', 'h3n', 'h3', nin, c3, 3, 'max'),
+             ('cell', 'h3', 'h4a', c3, c3, 3, None), ('cell', 'h4a', 'h4n', c3, nin, 1, None), ('cell', 'h4n', 'h4', nin, c3, 3, None),
+             ('cell', 'h4', 'h5a', c3, c3, 3, None), ('cell', 'h5a', 'h5n', c3, nin, 1, None), ('cell', 'h5n', 'h5', nin, c3, 3, None),
+             ('dense', 'h5', 'h7', (feat // 8) * c3, hid, 'relu'), ('dense', 'h7', 'd', hid, vocab, 'softmax')]
     else:
         raise ValueError('unknown model %r' % (model,))
     return g
@@ -418,16 +428,18 @@ class DFCNNEngine:
         return self.ones[:Cc], self.ones[1024:1024 + Cc]
 
     # ------------------------------------------------------------------ loss / decode
-    def set_targets(self, logits_length, target_py):
+    def set_targets(self, logits_length, target_py, target_length=None):
         """logits_length [B] ints, target_py [B, <=64] zero-padded ids.  Mirrors
         tf.contrib.layers.dense_to_sparse (acoustic_model2.py:71): every 0 is dropped (Q6).
+        With ``target_length`` [B] the labels are the DENSE form of tf.nn.ctc_loss_v2(labels=target_py,
+        label_length=target_length) (am_lm_model.py:72): the first target_length ids of each row, zeros kept.
         Raises ValueError where TF raises InvalidArgumentError (no valid CTC alignment)."""
         tp = np.asarray(target_py)
         lab = np.zeros((self.B, MAX_LABEL), dtype=np.int32)
         ll = np.zeros(self.B, dtype=np.int32)
         sl = np.asarray(logits_length, dtype=np.int32).reshape(self.B)
         for b in range(self.B):
-            ids = tp[b][tp[b] != 0]
+            ids = tp[b][tp[b] != 0] if target_length is None else np.asarray(tp[b])[:int(target_length[b])]
             if len(ids) > MAX_LABEL:
                 raise ValueError('label longer than %d' % MAX_LABEL)
             rep = int(np.sum(ids[1:] == ids[:-1]))
@@ -472,7 +484,9 @@ class DFCNNEngine:
             torch.cuda.current_stream().wait_event(self._decode_done)
 
     # ------------------------------------------------------------------ backward
-    def backward(self, on_dense_grads_ready=None):
+    def backward(self, on_dense_grads_ready=None, extra=None):
+        """``extra`` = {dense activation name: device tensor}: an additional dL/d(activation) from a second consumer of
+        that activation (the language half of the joint graph reads h7), added before the layer's own backward."""
         B, T8, V = self.B, self.T8, self.V
         last = self.g[-1][2]
         ops.softmax_log_bwd(self.logits, self.ctc_grad, B, T8, V, K_EPSILON, 1.0 / B, self.dflat[last])
@@ -490,6 +504,8 @@ class DFCNNEngine:
             if op[0] == 'dense':
                 _, src, dst, cin, cout, act = op
                 dz = self.dflat[dst]
+                if extra is not None and dst in extra:
+                    ops.axpy(dz, extra[dst], 1.0, True)
                 if act == 'relu':
                     ops.relu_bwd(dz, self.flat[dst], dz)
                 rows = dz.shape[0]

@@ -5,6 +5,7 @@ Graphs restated from
   'm2'  lm_and_am/model/acoustic_model2.py:37-74   (SE-DFCNN; avg-pool; the model train.py:8 imports)
   'm1'  lm_and_am/model/acoustic_model.py:37-62    (plain DFCNN; max-pool; NiN cell; 6400->128->V head)
   'm3'  lm_and_am/model/acoustic_model3.py:37-67   (SE on the pooled cell itself, no BN inside SE)
+  'amlm' lm_and_am/model/am_lm_model.py:56-66      (acoustic half of the joint AM+LM graph; see oracle/amlm.py)
 Loss: acoustic_model2.py:76-83; optimiser: acoustic_model2.py:85-91.
 """
 import numpy as np
@@ -51,6 +52,17 @@ def graph(model, vocab, widths=None, feat=200):
                ('cell', 'h3s', 'h3b', c3, c3, 3, None),
                ('cell', 'h3b', 'h6a', c3, c3, 3, None), ('cell', 'h6a', 'h6', c3, c6, 3, None),
                ('dense', 'h6', 'd', (feat // 8) * c6, vocab, 'softmax')]
+    elif model == 'amlm':
+        # am_lm_model.py:56-66,163-175: cnn_cell(32), cnn_cell(64), then three NiN cells of 128 (3x3 -> 1x1 to 32 -> 3x3),
+        # pooled after the first one only; Reshape; dense(128, relu) = h7; dense(V_pinyin, softmax).  BN frozen
+        # (tf.layers.batch_normalization without training=True), dropout(…, 0.3) without training=True = identity.
+        c1, c2, c3, nin, hid = widths or (32, 64, 128, 32, 128)
+        ops = [('cell', 'x', 'h1', 1, c1, 3, 'max'), ('cell', 'h1', 'h2', c1, c2, 3, 'max'),
+               ('cell', 'h2', 'h3a', c2, c3, 3, None), ('cell', 'h3a', 'h3n', c3, nin, 1, None), ('cell', 'h3n', 'h3', nin, c3, 3, 'max'),
+               ('cell', 'h3', 'h4a', c3, c3, 3, None), ('cell', 'h4a', 'h4n', c3, nin, 1, None), ('cell', 'h4n', 'h4', nin, c3, 3, None),
+               ('cell', 'h4', 'h5a', c3, c3, 3, None), ('cell', 'h5a', 'h5n', c3, nin, 1, None), ('cell', 'h5n', 'h5', nin, c3, 3, None),
+               ('dense', 'h5', 'h7', (feat // 8) * c3, hid, 'relu'),
+               ('dense', 'h7', 'd', hid, vocab, 'softmax')]
     else:
         raise ValueError(model)
     return ops
@@ -124,11 +136,14 @@ def forward(ops, P, x):
     return acts[ops[-1][2]], (acts, caches)
 
 
-def backward(ops, P, state, dd):
-    """dd = dL/d(dense pre-activation of the last layer).  Returns grads dict."""
+def backward(ops, P, state, dd, extra=None):
+    """dd = dL/d(dense pre-activation of the last layer); extra = {activation name: additional dL/d(activation)} (the
+    joint AM+LM graph feeds h7 to a second branch).  Returns grads dict."""
     acts, caches = state
     G = {}
     dacts = {ops[-1][2]: dd}
+    for k, v in (extra or {}).items():
+        dacts[k] = dacts.get(k, 0) + np.asarray(v, dtype=np.float64).reshape(acts[k].shape)
     for op in reversed(ops):
         if op[0] == 'dense':
             _, src, dst, cin, cout, act = op
