@@ -11,7 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle import fbank as ofb, ctc as octc, dfcnn, optim as oopt, prenet as opn  # noqa: E402
+from oracle import fbank as ofb, ctc as octc, dfcnn, optim as oopt, prenet as opn, amlm as oam  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
 
@@ -102,8 +102,42 @@ def prenet_case():
     np.savez_compressed(os.path.join(OUT, 'prenet.npz'), **z)
 
 
+AMLM = dict(vp=24, vh=41, feat=16, widths=(4, 8, 16, 4, 128), heads=2, blocks=2, pos_max=16, B=3, T=64)
+
+
+def amlm_case():
+    """joint acoustic + language model step (oracle/amlm.py, am_lm_model.py): both logit tensors, the three losses and a
+    selection of gradients from both halves."""
+    c = AMLM
+    P, ops = oam.init_params(c['vp'], c['vh'], feat=c['feat'], widths=c['widths'], heads=c['heads'], blocks=c['blocks'],
+                             pos_max=c['pos_max'], seed=0, perturb=True)
+    P = {'am': {l: {k: np.asarray(v, np.float32).astype(np.float64) for k, v in d.items()} for l, d in P['am'].items()},
+         'lm': {k: ({kk: np.asarray(vv, np.float32).astype(np.float64) for kk, vv in v.items()} if isinstance(v, dict)
+                    else np.asarray(v, np.float32).astype(np.float64)) for k, v in P['lm'].items()}}
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((c['B'], c['T'], c['feat'])).astype(np.float32)
+    tp = np.zeros((c['B'], 8), dtype=np.int32)
+    tp[0, :3] = [3, 0, 7]; tp[1, :2] = [5, 5]; tp[2, :4] = [1, 2, 2, 9]
+    tl, wl = np.array([3, 2, 4]), np.array([8, 6, 7])
+    out = oam.train_step(P, ops, x.astype(np.float64)[..., None], list(wl), tp, list(tl), c['heads'], c['blocks'])
+    z = {'x': x, 'target_py': tp, 'target_len': tl, 'wav_len': wl, 'am_logits': out['am_logits'].astype(np.float32),
+         'lm_logits': out['lm_logits'].astype(np.float32),
+         'losses': np.array([out['am_mean_loss'], out['lm_mean_loss'], out['mean_loss']])}
+    for l, d in P['am'].items():
+        for k, v in d.items():
+            z['pa/%s/%s' % (l, k)] = v.astype(np.float32)
+            z['ga/%s/%s' % (l, k)] = out['grads']['am'][l][k].astype(np.float32)
+    for k, v in P['lm'].items():
+        for kk, vv in (v.items() if isinstance(v, dict) else [(None, v)]):
+            name = k if kk is None else '%s/%s' % (k, kk)
+            g = out['grads']['lm'][k] if kk is None else out['grads']['lm'][k][kk]
+            z['pl/' + name] = np.asarray(vv).astype(np.float32)
+            z['gl/' + name] = np.asarray(g).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, 'amlm.npz'), **z)
+
+
 if __name__ == '__main__':
-    fbank_cases(); ctc_cases(); misc(); prenet_case()
+    fbank_cases(); ctc_cases(); misc(); prenet_case(); amlm_case()
     model_case('m2', (8, 16, 32, 64), 'm2')
     model_case('m1', (8, 16, 32, 64, 8, 32), 'm1')
     print('golden vectors written to', OUT)
