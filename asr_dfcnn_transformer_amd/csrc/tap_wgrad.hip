@@ -728,7 +728,9 @@ Plan make_plan(const asr_gemm_desc* d, int target_blocks = 768, long cap_mb = 64
     const long slab_bytes = (long)d->ntaps * d->K * d->N * 4;
     const long cap = (cap_mb << 20) / slab_bytes;      // fewer, longer chunks beat more slabs: 64 MB measured better than 128 for fp32
     if (want > cap) want = cap < 1 ? 1 : cap;
-    const long maxc = asr_cdiv(d->M, 4 * p.ps);
+    // at least four runs per chunk -- except for the few-tile outputs of narrow dense layers (the 128-wide language half of
+    // the joint graph: 1-4 tiles), where that leaves 25 workgroups on 256 CUs: one run per chunk there
+    const long maxc = asr_cdiv(d->M, (d->ntaps == 1 && tiles <= 4 ? 1 : 4) * p.ps);
     if (want > maxc) want = maxc;
     if (want < 1) want = 1;
     long pch = ((long)asr_cdiv(d->M, want) + p.ps - 1) / p.ps * p.ps;

@@ -112,6 +112,101 @@ def cpu_baseline(variant, t_pad, vocab, seconds=10.0, budget_s=15.0):
                       'torch-CPU fp32 + numpy fbank) after 1 warm-up' % (n, Bc, t_pad)}
 
 
+def run_am_lm(args):
+    """BASELINE.json configs[4]: the joint acoustic + language model graph of lm_and_am/model/am_lm_model.py (SURVEY 8f.2;
+    DESIGN.md section 10 lists how the non-runnable source was read): DFCNN with NiN cells -> h7 -> 12 non-causal MHA
+    blocks + FFN -> two CTC heads, one Adam; fbank + fwd + both CTC + decode + bwd + Adam per step.  Secondary workload."""
+    from asr_dfcnn_transformer_amd import ops
+    from asr_dfcnn_transformer_amd.parallel import init_from_env, BucketedAllReduce
+    from asr_dfcnn_transformer_amd.joint_engine import AMLMEngine
+    from asr_dfcnn_transformer_amd.engine import step_flops_per_utt
+    from asr_dfcnn_transformer_amd.wav_util import FbankExtractor
+    rank, world, local = init_from_env()
+    torch.cuda.set_device(local)
+    B, T, F, VP, VH, blocks = args.batch, args.tpad, 200, 1536, 6345, 12
+    eng = AMLMEngine(v_pinyin=VP, v_hanzi=VH, B=B, T=T, F=F, blocks=blocks, pos_max=T // 8, dropout_rate=args.dropout,
+                     drop_seed=rank)
+    am, lm = eng.am, eng.lm
+    red_am = BucketedAllReduce(am.grad, [(am.n_gamma, am.dense_end), (0, am.n_gamma), (am.dense_end, am.grad.numel())])
+    red_lm = BucketedAllReduce(lm.grad, [(0, lm.grad.numel())])
+    fb = FbankExtractor(nfilt=F, device='cuda')
+    ns = 160000
+    host = np.stack([(0.1 * np.random.default_rng(1234 + rank * B + b).standard_normal(ns)).astype(np.float32) for b in range(B)])
+    signal = torch.from_numpy(host).cuda()
+    nsamp = torch.full((B,), ns, dtype=torch.int32, device='cuda')
+    feat = torch.empty(B, T, F, dtype=torch.float32, device='cuda')
+    rng = np.random.default_rng(99 + rank)
+    tp = np.zeros((B, 64), dtype=np.int32); tp[:, :32] = rng.integers(1, VP - 1, (B, 32))
+    hz = np.zeros((B, 64), dtype=np.int32); hz[:, :32] = rng.integers(1, VH, (B, 32))
+    tl = np.full(B, 32, dtype=np.int32)
+    wl = np.full(B, min(200, 999 // 8 + 1), dtype=np.int32)
+
+    def step():
+        fb.batch(signal, nsamp, T, out=feat)
+        eng.forward(feat)
+        eng.set_targets(wl, tp, tl, hz)
+        eng.loss_and_decode()
+        dh7 = lm.backward()
+        red_lm.launch(0)
+        am.backward(on_dense_grads_ready=lambda: red_am.launch(0), extra={'h7': dh7})
+        red_am.launch(1); red_am.launch(2)
+        red_lm.wait(); red_am.wait()
+        lm.apply_adam(red_lm.grad_scale)
+        am.apply_adam(red_am.grad_scale)
+
+    nwarm = max(1, args.warmup)
+    for i in range(nwarm):
+        if i == nwarm - 1:
+            torch.cuda.synchronize(); ops.TIMER = ops.KernelTimer()
+        step()
+    torch.cuda.synchronize(); table = ops.TIMER.summary(); ops.TIMER = None
+    overlapped = am.side is not None
+    dom = max([k for k in table if not overlapped or is_forward_symbol(k)], key=lambda k: table[k]['total_ms'])
+    ops.TIMER = ops.KernelTimer(only={dom})
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timed = ops.TIMER.summary(); ops.TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda'); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    if rank == 0:
+        T8, C = T // 8, lm.C
+        lm_fwd = blocks * (4 * 2 * T8 * C * C + 2 * 2 * T8 * T8 * C) + 2 * 2 * T8 * C * 4 * C + 2 * T8 * C * VH
+        fstep = step_flops_per_utt(am.g, T, F) + 3.0 * lm_fwd
+        r = timed[dom]
+        utt_s = world * B * args.steps / dt
+        am_mean, lm_mean, mean, err = eng.fetch()
+        out = {'metric': 'utterances/sec (10 s audio, B=32) joint AM+LM (am_lm_model.py) fwd+bwd', 'value': round(utt_s, 2),
+               'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+               'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+               'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
+               'config': {'workload': 'joint acoustic + language model graph (am_lm_model.py as read in DESIGN.md section 10): fbank + NiN DFCNN '
+                                      '+ 12 non-causal MHA blocks on h7 + FFN + two CTC heads (V 1536 / 6345) + decode + bwd + Adam, '
+                                      '10 s/16 kHz audio, T_pad %d' % T,
+                          'global_batch': world * B, 'batch_per_gpu': B, 't_pad': T, 'parallelism': 'dp%d' % world,
+                          'gflop_per_utt_fwd_bwd': round(fstep / 1e9, 3), 'step_tflops': round(utt_s / world * fstep / 1e12, 2),
+                          'step_frac_of_fp32_peak': round(utt_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
+                          'backward_streams': 2 if overlapped else 1, 'dropout_rate': args.dropout,
+                          'am_mean_loss': round(am_mean, 4), 'lm_mean_loss': round(lm_mean, 4)},
+               'roofline': {'bound': 'mfma', 'achieved': round(r['tflops'], 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                            'frac': round(r['tflops'] / FP32_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': kernel_name(dom),
+                            'launches_per_step': r['launches'] // args.steps, 'avg_launch_us': round(r['avg_us'], 2)}}
+        if args.kernel_table:
+            for key, rr in sorted(table.items(), key=lambda kv: -kv[1]['total_ms']):
+                print('%-48s launches %3d  total %8.3f ms  avg %9.1f us  %7.2f TFLOP/s' %
+                      (key, rr['launches'], rr['total_ms'], rr['avg_us'], rr['tflops']), file=sys.stderr)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def run_transformer(args):
     """BASELINE.json configs[3]: pinyin->hanzi encoder-decoder (6+6 MHA sub-layers, d_model 512, 8 heads),
     batch 64 x seq 512, as-written live graph, fwd + bwd + Adam.  Secondary workload.
@@ -219,7 +314,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='dfcnn', choices=['dfcnn', 'se_dfcnn', 'transformer', 'e2e_prenet'])
+    ap.add_argument('--workload', default='dfcnn', choices=['dfcnn', 'se_dfcnn', 'transformer', 'e2e_prenet', 'am_lm'])
     ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
     ap.add_argument('--tpad', type=int, default=1600)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -233,6 +328,8 @@ def main():
     args = ap.parse_args()
     if args.workload in ('transformer', 'e2e_prenet'):
         return run_transformer(args)
+    if args.workload == 'am_lm':
+        return run_am_lm(args)
 
     from asr_dfcnn_transformer_amd import ops
     from asr_dfcnn_transformer_amd.engine import DFCNNEngine, step_flops_per_utt, fwd_flops_per_utt
