@@ -1,6 +1,6 @@
 """Joint acoustic + language model training graph of lm_and_am/model/am_lm_model.py (BASELINE configs[4])
 on the existing kernels.  The reference file does not run as written; the graph built here is its evident one, with the
-forced deviations D1-D3 and the kept-as-written oddities K1-K4 listed in DESIGN.md section 10 (and in oracle/amlm.py,
+forced deviations D1-D5 and the kept-as-written oddities K1-K3 listed in DESIGN.md section 10 (and in oracle/amlm.py,
 the CPU restatement the parity tests compare against):
 
   acoustic half  (am_lm_model.py:56-80)   DFCNNEngine graph 'amlm' -> h7 = dense(128, relu) -> dense(V_pinyin, softmax)

@@ -13,12 +13,16 @@ As written (am_lm_model.py):
                      target_py_length, wav_length, blank = V_pinyin - 1) -> lm_mean_loss
   calc_loss :145-154 mean_loss = am_mean_loss + lm_mean_loss;  opt_init :133-139 Adam(am_lr, 0.9, 0.999, 1e-8), constant lr
 
-Deviations forced by the source not running:
+Deviations forced by the source not running (same numbering as DESIGN.md section 10):
   D1  `self.am_out` is never assigned (:84).  The only [B, 200, ...] tensor the acoustic half leaves behind that can be
       added to a position embedding is h7 (:64, width 128), so am_out := h7 and hidden_units := 128; with the 64-wide
       heads of the attention kernels that makes num_heads = 2 (hparams.py's 512 / 8 cannot be added to a 128-wide tensor).
-  D2  build_model() is called before calc_loss(), but language_model() already references nothing from it: order kept.
-  D3  opt_init() re-creates global_step (:135) -- harmless, one counter here.
+  D2  position_max_length (100) is smaller than the 200 positions it is indexed with (:85-87): the table gets T/8 rows.
+  D3  opt_init() re-creates global_step (:135) -- one counter here.
+  D4  ctc_greedy_decoder is given target_py_length as sequence length (:75,120); the metrics here decode over wav_length
+      instead (summaries only, no effect on losses or gradients).
+  D5  feedforward(self.enc, num_units=[...]) (:108) omits the required dropout_rate / is_training arguments
+      (transformer.py:204): the model's own values are used, as language_model.py does.
 Kept AS WRITTEN although they look unintended (they define the arithmetic):
   K1  both CTC losses take the DENSE pinyin labels and target_py_length: the first target_py_length ids of each row, zeros
       included (ctc_loss_v2 with dense labels; same rule as K.ctc_batch_cost in cnn_ctc.py), NOT dense_to_sparse.
@@ -26,8 +30,6 @@ Kept AS WRITTEN although they look unintended (they define the arithmetic):
       (:117-118); target_hanzi only feeds the han_wer summary.
   K3  each block's feedforward overwrites self.outputs and does not feed the next block (:108): one live FFN, as in
       language_model.py.
-  K4  ctc_greedy_decoder is given target_py_length as sequence length (:75,120); the metrics here decode over wav_length
-      instead (summaries only, no effect on losses or gradients).
 """
 import numpy as np
 
