@@ -130,3 +130,20 @@ def test_reference_named_shim_runs_a_training_step():
     truth = [[30, 31], [12], [7, 8, 9]]
     want = np.mean([ctc.edit_distance_normalized(h, t) for h, t in zip(hyp, truth)])
     assert abs(m.run(m.han_wer, feed) - want) < 1e-6
+
+
+def test_dense_label_mode_keeps_zeros_and_rejects_infeasible_alignments():
+    """am_lm_model.py:72 hands ctc_loss_v2 DENSE labels + lengths: zeros inside the first target_py_length ids are labels
+    (K1); where TF raises InvalidArgumentError (not enough frames for the label + the blanks between repeats) so do we."""
+    eng, P, ops, x, tp, tl, wl = _build()
+    eng.set_targets(wl, tp, tl)
+    assert eng.am._host_labels == [[3, 0, 7], [5, 5], [1, 2, 2, 9]]
+    eng.am.set_targets(wl, tp)                                   # the sparse path of acoustic_model*.py drops the zero
+    assert eng.am._host_labels[0] == [3, 7]
+    with pytest.raises(ValueError):
+        eng.set_targets([8, 2, 7], tp, tl)                       # [5, 5] needs 3 frames (a blank between the repeats)
+    with pytest.raises(ValueError):
+        eng.set_targets([8, 6, 9], tp, tl)                       # T/8 = 8 frames exist
+    tp_long = np.zeros((B, 8), dtype=np.int32); tp_long[:, :8] = 1 + np.arange(8)
+    with pytest.raises(ValueError):
+        eng.set_targets([8, 6, 7], tp_long, [8, 8, 8])           # 8 labels in 6 / 7 frames
