@@ -207,6 +207,71 @@ def run_am_lm(args):
         dist.barrier(); dist.destroy_process_group()
 
 
+def run_lm(args):
+    """Language_Model (lm_and_am/model/language_model.py:22-78, driver train.py:100-165): pinyin ids -> 12 causal
+    self-attention MHA blocks (d_model 512, 8 heads) -> one FFN -> dense(6345) -> label-smoothed CE; B = 64 (hparams.py:16),
+    T = 100 (the position table, hparams.py:23); fwd + bwd + Adam.  Secondary workload."""
+    from asr_dfcnn_transformer_amd import ops
+    from asr_dfcnn_transformer_amd.parallel import init_from_env, BucketedAllReduce
+    from asr_dfcnn_transformer_amd.transformer_engine import LMEngine
+    rank, world, local = init_from_env()
+    torch.cuda.set_device(local)
+    N, T, C, H, blocks, Vin, Vout = (args.batch if args.batch != 32 else 64), 100, 512, 8, 12, 1536, 6345
+    eng = LMEngine(vin=Vin, vout=Vout, N=N, T=T, C=C, heads=H, blocks=blocks, pos_max=100, dropout_rate=args.dropout, drop_seed=rank)
+    red = BucketedAllReduce(eng.grad, [(0, eng.grad.numel())])
+    rng = np.random.default_rng(11 + rank)
+    x = rng.integers(1, Vin, (N, T)); y = rng.integers(1, Vout, (N, T))
+
+    def step():
+        eng.forward(x, y)
+        eng.backward()
+        red.launch(0); red.wait()
+        eng.apply_adam(red.grad_scale)
+
+    nwarm = max(1, args.warmup)
+    for i in range(nwarm):
+        if i == nwarm - 1:
+            torch.cuda.synchronize(); ops.TIMER = ops.KernelTimer()
+        step()
+    torch.cuda.synchronize(); table = ops.TIMER.summary(); ops.TIMER = None
+    overlapped = eng.side is not None
+    dom = max([k for k in table if not overlapped or is_forward_symbol(k)], key=lambda k: table[k]['total_ms'])
+    ops.TIMER = ops.KernelTimer(only={dom})
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timed = ops.TIMER.summary(); ops.TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device='cuda'); dist.all_reduce(t, op=dist.ReduceOp.MAX); dt = float(t.item())
+    if rank == 0:
+        fwd = blocks * (4 * 2 * T * C * C + 2 * 2 * (T * (T + 1) // 2) * C) + 2 * 2 * T * C * 4 * C + 2 * T * C * Vout
+        fstep = 3.0 * fwd
+        r = timed[dom]
+        seq_s = world * N * args.steps / dt
+        out = {'metric': 'sequences/sec (B=64, T=100) Language_Model fwd+bwd', 'value': round(seq_s, 2), 'unit': 'sequences/s',
+               'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
+               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
+               'config': {'workload': 'Language_Model (language_model.py): pinyin ids -> 12 causal MHA blocks (d 512, 8 heads) + FFN -> '
+                                      'dense(6345) -> label-smoothed CE, fwd+bwd+Adam', 'global_batch': world * N, 'seq_len': T,
+                          'parallelism': 'dp%d' % world, 'gflop_per_seq_fwd_bwd': round(fstep / 1e9, 3),
+                          'step_tflops': round(seq_s / world * fstep / 1e12, 2),
+                          'step_frac_of_fp32_peak': round(seq_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
+                          'dropout_rate': args.dropout, 'mean_loss': round(eng.fetch()[0], 4)},
+               'roofline': {'bound': 'mfma', 'achieved': round(r['tflops'], 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                            'frac': round(r['tflops'] / FP32_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': kernel_name(dom),
+                            'launches_per_step': r['launches'] // args.steps, 'avg_launch_us': round(r['avg_us'], 2)}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
+
+
 def run_transformer(args):
     """BASELINE.json configs[3]: pinyin->hanzi encoder-decoder (6+6 MHA sub-layers, d_model 512, 8 heads),
     batch 64 x seq 512, as-written live graph, fwd + bwd + Adam.  Secondary workload.
@@ -314,7 +379,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='dfcnn', choices=['dfcnn', 'se_dfcnn', 'transformer', 'e2e_prenet', 'am_lm'])
+    ap.add_argument('--workload', default='dfcnn', choices=['dfcnn', 'se_dfcnn', 'transformer', 'e2e_prenet', 'am_lm', 'lm'])
     ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
     ap.add_argument('--tpad', type=int, default=1600)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -330,6 +395,8 @@ def main():
         return run_transformer(args)
     if args.workload == 'am_lm':
         return run_am_lm(args)
+    if args.workload == 'lm':
+        return run_lm(args)
 
     from asr_dfcnn_transformer_amd import ops
     from asr_dfcnn_transformer_amd.engine import DFCNNEngine, step_flops_per_utt, fwd_flops_per_utt
