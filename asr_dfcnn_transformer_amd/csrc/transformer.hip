@@ -99,7 +99,7 @@ __device__ __forceinline__ void attn_block_coords(int H, bool longest_is_last, i
 template <bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                        const float* __restrict__ V, float* __restrict__ O,
-                                                       float* __restrict__ lse, int Tq, int Tk, int C, int H,
+                                                       float* __restrict__ lse, int Tq, int Tk, int C, int H, int ldq, int ldk,
                                                        uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
     __shared__ __attribute__((aligned(16))) float kv_lds[2 * 64 * KP];   // also the epilogue's transpose scratch
     float* Ks = kv_lds;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const flo
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < Tq) v = *(const float4*)(Q + (qbase + q) * C + hoff + 8 * g + 4 * lh);
+        if (q < Tq) v = *(const float4*)(Q + (qbase + q) * ldq + hoff + 8 * g + 4 * lh);
         qabs += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
         qreg[g * 4 + 0] = v.x * 0.125f; qreg[g * 4 + 1] = v.y * 0.125f;
         qreg[g * 4 + 2] = v.z * 0.125f; qreg[g * 4 + 3] = v.w * 0.125f;
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const flo
             if (__syncthreads_and((q >= Tq) || (m_run > -1.0e9f))) break;
         }
         __syncthreads();
-        stage_tile(Ks, K, kbase, k0, 64, Tk, C, hoff, tid, 1.f, kstat, 0);
-        stage_tile(Vs, V, kbase, k0, 64, Tk, C, hoff, tid, 1.f, nullptr, 0);
+        stage_tile(Ks, K, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, kstat, 0);
+        stage_tile(Vs, V, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, nullptr, 0);
         __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
                                                           const float* __restrict__ V, const float* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           float* __restrict__ dK, float* __restrict__ dV,
-                                                          int Tq, int Tk, int C, int H, int relu_grad,
+                                                          int Tq, int Tk, int C, int H, int ldq, int ldk, int relu_grad,
                                                           uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
     constexpr int QT = 64;                       // queries staged per barrier round (two 32-row MFMA sub-tiles)
     __shared__ __attribute__((aligned(16))) float Qs[QT * KP];
@@ -254,8 +254,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
     for (int g = 0; g < 8; ++g) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
         if (key < Tk) {
-            a = *(const float4*)(K + (kbase + key) * C + hoff + 8 * g + 4 * lh);
-            b = *(const float4*)(V + (kbase + key) * C + hoff + 8 * g + 4 * lh);
+            a = *(const float4*)(K + (kbase + key) * ldk + hoff + 8 * g + 4 * lh);
+            b = *(const float4*)(V + (kbase + key) * ldk + hoff + 8 * g + 4 * lh);
         }
         ksum += a.x + a.y + a.z + a.w;
         kreg[g * 4 + 0] = a.x; kreg[g * 4 + 1] = a.y; kreg[g * 4 + 2] = a.z; kreg[g * 4 + 3] = a.w;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
             if (!__syncthreads_or(degenerate)) continue;
         }
         __syncthreads();
-        stage_tile(Qs, Q, qbase, q0, QT, Tq, C, hoff, tid, 1.f, qstat, 1);
+        stage_tile(Qs, Q, qbase, q0, QT, Tq, ldq, hoff, tid, 1.f, qstat, 1);
         if (tid < QT) {
             const int q = q0 + tid;
             lse_s[tid] = (q < Tq) ? lse[lrow + q] : INFINITY;
@@ -345,8 +345,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
             }
         }
     }
-    store_tile_T(dK, scratch + wave * (32 * 65), dk, 1.f, kbase, k0, Tk, C, hoff, lane, relu_grad ? K : nullptr);
-    store_tile_T(dV, scratch + wave * (32 * 65), dv, 1.f, kbase, k0, Tk, C, hoff, lane, relu_grad ? V : nullptr);
+    store_tile_T(dK, scratch + wave * (32 * 65), dk, 1.f, kbase, k0, Tk, ldk, hoff, lane, relu_grad ? K : nullptr);
+    store_tile_T(dV, scratch + wave * (32 * 65), dv, 1.f, kbase, k0, Tk, ldk, hoff, lane, relu_grad ? V : nullptr);
 }
 
 // ------------------------------------------------------------------ attention backward: dQ
@@ -354,7 +354,7 @@ template <bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                          const float* __restrict__ V, const float* __restrict__ dO,
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                         float* __restrict__ dQ, int Tq, int Tk, int C, int H, int relu_grad,
+                                                         float* __restrict__ dQ, int Tq, int Tk, int C, int H, int ldq, int ldk, int relu_grad,
                                                          uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
     __shared__ __attribute__((aligned(16))) float kv_lds[2 * 64 * KP];   // also the epilogue's transpose scratch
     float* Ks = kv_lds;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
     for (int g = 0; g < 8; ++g) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
         if (q < Tq) {
-            a = *(const float4*)(Q + (qbase + q) * C + hoff + 8 * g + 4 * lh);
+            a = *(const float4*)(Q + (qbase + q) * ldq + hoff + 8 * g + 4 * lh);
             b = *(const float4*)(dO + (qbase + q) * C + hoff + 8 * g + 4 * lh);
         }
         qabs += fabsf(a.x) + fabsf(a.y) + fabsf(a.z) + fabsf(a.w);
@@ -396,8 +396,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
     for (int k0 = 0; k0 < Tk; k0 += 64) {
         if (CAUSAL && k0 > qtile * 128 + 127) break;     // masked scores get no gradient: nothing for dQ there
         __syncthreads();
-        stage_tile(Ks, K, kbase, k0, 64, Tk, C, hoff, tid, 1.f, kstat, 0);
-        stage_tile(Vs, V, kbase, k0, 64, Tk, C, hoff, tid, 1.f, nullptr, 0);
+        stage_tile(Ks, K, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, kstat, 0);
+        stage_tile(Vs, V, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, nullptr, 0);
         __syncthreads();
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
         }
     }
     __syncthreads();
-    store_tile_T(dQ, Ks + wave * (32 * 65), dq, 1.f, qbase, q0, Tq, C, hoff, lane, relu_grad ? Q : nullptr);
+    store_tile_T(dQ, Ks + wave * (32 * 65), dq, 1.f, qbase, q0, Tq, ldq, hoff, lane, relu_grad ? Q : nullptr);
 }
 
 // ------------------------------------------------------------------ (add +) LayerNorm
@@ -819,29 +819,37 @@ static inline uint32_t drop_threshold(float rate) {
     return (uint32_t)(t + 0.5);
 }
 
-extern "C" int asr_attention_fwd(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
-                                 int causal, float dropout_rate, unsigned int seed, float* O, float* lse, void* stream) {
+extern "C" int asr_attention_fwd_p(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
+                                   int ldq, int ldk, int causal, float dropout_rate, unsigned int seed, float* O, float* lse,
+                                   void* stream) {
     if (!Q || !K || !V || !O || !lse || N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
+    if (ldq < C || ldk < C || (ldq & 3) || (ldk & 3)) return ASR_ERR_BAD_ARG;
     if (dropout_rate < 0.f || dropout_rate >= 1.f || (double)N * H * Tq * Tk >= 4294967296.0) return ASR_ERR_BAD_ARG;
     dim3 grid(asr_cdiv(Tq, 128), H, N), grid_causal(N * H, asr_cdiv(Tq, 128), 1);      // see attn_block_coords
     hipStream_t st = (hipStream_t)stream;
     const uint32_t thr = drop_threshold(dropout_rate);
     const float sc = 1.0f / (1.0f - dropout_rate);
     if (dropout_rate > 0.f) {
-        if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid_causal, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, thr, seed, sc);
-        else hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, thr, seed, sc);
+        if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid_causal, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, ldq, ldk, thr, seed, sc);
+        else hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, ldq, ldk, thr, seed, sc);
     } else {
-        if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid_causal, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, thr, seed, sc);
-        else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, thr, seed, sc);
+        if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid_causal, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, ldq, ldk, thr, seed, sc);
+        else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, ldq, ldk, thr, seed, sc);
     }
     ASR_CHECK_LAUNCH("attention_fwd");
     return ASR_OK;
 }
 
-extern "C" int asr_attention_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO,
-                                 const float* lse, int N, int Tq, int Tk, int C, int H, int causal, int relu_grad,
-                                 float dropout_rate, unsigned int seed,
-                                 float* dQ, float* dK, float* dV, float* delta_ws, void* stream) {
+extern "C" int asr_attention_fwd(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
+                                 int causal, float dropout_rate, unsigned int seed, float* O, float* lse, void* stream) {
+    return asr_attention_fwd_p(Q, K, V, N, Tq, Tk, C, H, C, C, causal, dropout_rate, seed, O, lse, stream);
+}
+
+extern "C" int asr_attention_bwd_p(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                                   const float* lse, int N, int Tq, int Tk, int C, int H, int ldq, int ldk, int causal,
+                                   int relu_grad, float dropout_rate, unsigned int seed,
+                                   float* dQ, float* dK, float* dV, float* delta_ws, void* stream) {
+    if (ldq < C || ldk < C || (ldq & 3) || (ldk & 3)) return ASR_ERR_BAD_ARG;
     if (!Q || !K || !V || !O || !dO || !lse || !dQ || !dK || !dV || !delta_ws) return ASR_ERR_BAD_ARG;
     if (N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
     if (dropout_rate < 0.f || dropout_rate >= 1.f || (double)N * H * Tq * Tk >= 4294967296.0) return ASR_ERR_BAD_ARG;
@@ -856,9 +864,9 @@ extern "C" int asr_attention_bwd(const float* Q, const float* K, const float* V,
 #define ASR_ATTN_BWD(CA, DR, GKV, GQ)                                                                                          \
     do {                                                                                                                       \
         hipLaunchKernelGGL((attn_bwd_kv_kernel<CA, DR>), GKV, dim3(256), 0, st, Q, K, V, dO, lse, dl, dK, dV, Tq, Tk, C, H,    \
-                           relu_grad, thr, seed, sc);                                                                          \
+                           ldq, ldk, relu_grad, thr, seed, sc);                                                                          \
         hipLaunchKernelGGL((attn_bwd_q_kernel<CA, DR>), GQ, dim3(256), 0, st, Q, K, V, dO, lse, dl, dQ, Tq, Tk, C, H,           \
-                           relu_grad, thr, seed, sc);                                                                          \
+                           ldq, ldk, relu_grad, thr, seed, sc);                                                                          \
     } while (0)
     if (dropout_rate > 0.f) {
         if (causal) ASR_ATTN_BWD(true, true, ckv, cq); else ASR_ATTN_BWD(false, true, gkv, gq);
@@ -867,6 +875,36 @@ extern "C" int asr_attention_bwd(const float* Q, const float* K, const float* V,
     }
 #undef ASR_ATTN_BWD
     ASR_CHECK_LAUNCH("attention_bwd");
+    return ASR_OK;
+}
+
+extern "C" int asr_attention_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                                 const float* lse, int N, int Tq, int Tk, int C, int H, int causal, int relu_grad,
+                                 float dropout_rate, unsigned int seed,
+                                 float* dQ, float* dK, float* dV, float* delta_ws, void* stream) {
+    return asr_attention_bwd_p(Q, K, V, O, dO, lse, N, Tq, Tk, C, H, C, C, causal, relu_grad, dropout_rate, seed, dQ, dK, dV,
+                               delta_ws, stream);
+}
+
+__global__ void copy2d_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds, int rows, int c4n,
+                              int accumulate) {
+    const long total = (long)rows * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c4n;
+        const int c = (int)(i - r * c4n) * 4;
+        float4 v = *(const float4*)(src + r * lds + c);
+        float* d = dst + r * ldd + c;
+        if (accumulate) { const float4 o = *(const float4*)d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *(float4*)d = v;
+    }
+}
+
+extern "C" int asr_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int cols, int accumulate, void* stream) {
+    if (!dst || !src || rows < 1 || cols < 4 || (cols & 3) || (ldd & 3) || (lds & 3) || ldd < cols || lds < cols) return ASR_ERR_BAD_ARG;
+    if (((uintptr_t)dst | (uintptr_t)src) & 15) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(copy2d_kernel, dim3(grid_for((long)rows * (cols / 4), 256)), dim3(256), 0, (hipStream_t)stream, dst, ldd, src,
+                       lds, rows, cols / 4, accumulate);
+    ASR_CHECK_LAUNCH("copy2d");
     return ASR_OK;
 }
 

@@ -284,16 +284,23 @@ def fbank(signal, nsamples, frame_len, frame_step, nfft, preemph, nfilt, fb_star
 
 
 # ------------------------------------------------------------------ Transformer path
-def attention_fwd(Q, K, V, N, Tq, Tk, Cc, H, causal, O, lse, dropout_rate=0.0, seed=0):
-    check(_lib.load().asr_attention_fwd(_ptr(Q), _ptr(K), _ptr(V), N, Tq, Tk, Cc, H, int(causal), float(dropout_rate),
-                                        int(seed) & 0xffffffff, _ptr(O), _ptr(lse), _stream()), 'asr_attention_fwd')
+def attention_fwd(Q, K, V, N, Tq, Tk, Cc, H, causal, O, lse, dropout_rate=0.0, seed=0, ldq=None, ldk=None):
+    """ldq / ldk: row pitches of Q and of K, V when they are column blocks of a fused projection buffer (default Cc)."""
+    check(_lib.load().asr_attention_fwd_p(_ptr(Q), _ptr(K), _ptr(V), N, Tq, Tk, Cc, H, ldq or Cc, ldk or Cc, int(causal),
+                                          float(dropout_rate), int(seed) & 0xffffffff, _ptr(O), _ptr(lse), _stream()),
+          'asr_attention_fwd')
 
 
-def attention_bwd(Q, K, V, O, dO, lse, N, Tq, Tk, Cc, H, causal, dQ, dK, dV, delta_ws, relu_grad=False, dropout_rate=0.0, seed=0):
-    check(_lib.load().asr_attention_bwd(_ptr(Q), _ptr(K), _ptr(V), _ptr(O), _ptr(dO), _ptr(lse), N, Tq, Tk, Cc, H,
-                                        int(causal), int(relu_grad), float(dropout_rate), int(seed) & 0xffffffff,
-                                        _ptr(dQ), _ptr(dK), _ptr(dV), _ptr(delta_ws), _stream()),
+def attention_bwd(Q, K, V, O, dO, lse, N, Tq, Tk, Cc, H, causal, dQ, dK, dV, delta_ws, relu_grad=False, dropout_rate=0.0, seed=0,
+                  ldq=None, ldk=None):
+    check(_lib.load().asr_attention_bwd_p(_ptr(Q), _ptr(K), _ptr(V), _ptr(O), _ptr(dO), _ptr(lse), N, Tq, Tk, Cc, H,
+                                          ldq or Cc, ldk or Cc, int(causal), int(relu_grad), float(dropout_rate),
+                                          int(seed) & 0xffffffff, _ptr(dQ), _ptr(dK), _ptr(dV), _ptr(delta_ws), _stream()),
           'asr_attention_bwd')
+
+
+def copy2d(dst, ldd, src, lds, rows, cols, accumulate=False):
+    check(_lib.load().asr_copy2d(_ptr(dst), ldd, _ptr(src), lds, rows, cols, int(accumulate), _stream()), 'asr_copy2d')
 
 
 def dropout(x, rate, seed, y=None):

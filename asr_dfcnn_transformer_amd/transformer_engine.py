@@ -183,6 +183,29 @@ class _Base:
             launch(self.ws_side)
             self._side_dirty = True
 
+    def _wgrad_ld(self, x, dy, rows, K, N, name, ldz):
+        """_wgrad for a dy that is a column block of a wider matrix (row pitch ldz)."""
+        d = ops.gemm_desc(rows, K, N, K, N, ntaps=1)
+        shared = name_off(self, name) in self._written
+        self._written.add(name_off(self, name))
+
+        def launch(ws):
+            if shared:
+                ops.tap_wgrad(d, x, dy, ldz, self._wtmp[:K * N], ws)
+                ops.axpy(self.g(name), self._wtmp[:K * N], 1.0, True)
+            else:
+                ops.tap_wgrad(d, x, dy, ldz, self.g(name), ws)
+
+        if self.side is None:
+            launch(self.ws)
+            return
+        ready = torch.cuda.Event()
+        ready.record()
+        self.side.wait_event(ready)
+        with torch.cuda.stream(self.side):
+            launch(self.ws_side)
+            self._side_dirty = True
+
     def _begin_block(self):
         """Backward of one sub-layer starts: take the other scratch set and wait for the weight-gradients that still read it."""
         if self.side is None:
@@ -222,20 +245,46 @@ class _Base:
     # ---- blocks
     def _mha_alloc(self, N, Tq, Tk):
         C, H = self.C, self.H
-        return {'Q': self._t(N * Tq, C), 'K': self._t(N * Tk, C), 'V': self._t(N * Tk, C), 'A': self._t(N * Tq, C),
+        # Q | K | V live in ONE buffer so that the projections can run as one GEMM (see _mha_fwd): [rows][3C] for
+        # self-attention, [rq][C] followed by [rk][2C] when queries and keys come from different tensors
+        return {'QKV': self._t(N * Tq * C + 2 * N * Tk * C), 'W3': self._t(C, 3 * C), 'A': self._t(N * Tq, C),
                 'Z': self._t(N * Tq, C), 'xhat': self._t(N * Tq, C), 'rstd': self._t(N * Tq), 'lse': self._t(2 * N * H * Tq),
                 'out': self._t(N * Tq, C), 'N': N, 'Tq': Tq, 'Tk': Tk}
 
+    def _qkv_views(self, st, fused3):
+        C, rq, rk = self.C, st['N'] * st['Tq'], st['N'] * st['Tk']
+        buf = st['QKV']
+        if fused3:                                   # Q, K, V = column blocks of one [rows][3C] matrix
+            return buf[0:], buf[C:], buf[2 * C:], 3 * C, 3 * C
+        kv = buf[rq * C:]                            # Q dense [rq][C]; K, V = column blocks of [rk][2C]
+        return buf[0:], kv[0:], kv[C:], C, 2 * C
+
     def _mha_fwd(self, name, st, q_in, k_in, causal):
+        """multihead_attention (transformer.py:117-158).  The three projections Dense(relu) of a block read at most two
+        inputs, so they run as ONE GEMM against [wq | wk | wv] (self-attention, N = 3C) or as wq plus ONE GEMM against
+        [wk | wv] (keys from another tensor): the weight matrices are packed side by side once per step (asr_copy2d) and
+        the attention kernels take Q, K, V as column blocks of the result (row pitches, asr_attention_fwd_p).  Same
+        arithmetic per output element; a 32768 x 512 x 1536 GEMM runs at ~120 TFLOP/s where three x512 ones reach ~106."""
         C, N, Tq, Tk = self.C, st['N'], st['Tq'], st['Tk']
+        rq, rk = N * Tq, N * Tk
         st['q_in'], st['k_in'], st['causal'] = q_in, k_in, causal
-        self._dense(q_in, N * Tq, C, C, self.p(name + '/wq'), None, st['Q'], True)
-        self._dense(k_in, N * Tk, C, C, self.p(name + '/wk'), None, st['K'], True)
-        self._dense(k_in, N * Tk, C, C, self.p(name + '/wv'), None, st['V'], True)
+        fused3 = (q_in is k_in) and rq == rk
+        st['fused3'] = fused3
+        W3 = st['W3']
+        for j, k in enumerate(('wq', 'wk', 'wv')):
+            ops.copy2d(W3.view(-1)[j * C:], 3 * C, self.p('%s/%s' % (name, k)), C, C, C)
+        Q, K, V, ldq, ldk = self._qkv_views(st, fused3)
+        if fused3:
+            d = ops.gemm_desc(rq, C, 3 * C, C, 3 * C, 0, 3 * C, ntaps=1, relu=1)
+            ops.tap_gemm(d, q_in, W3, None, None, None, None, Q)
+        else:
+            self._dense(q_in, rq, C, C, self.p(name + '/wq'), None, Q, True)
+            d = ops.gemm_desc(rk, C, 2 * C, C, 3 * C, 0, 2 * C, ntaps=1, relu=1)
+            ops.tap_gemm(d, k_in, W3.view(-1)[C:], None, None, None, None, K)
         rate = self._rate
         kind, blk = self._block_site(name)
         st['seed_att'], st['seed_out'] = self._drop_seed((kind, blk, 'att')), self._drop_seed((kind, blk, 'out'))
-        ops.attention_fwd(st['Q'], st['K'], st['V'], N, Tq, Tk, C, self.H, causal, st['A'], st['lse'], rate, st['seed_att'])
+        ops.attention_fwd(Q, K, V, N, Tq, Tk, C, self.H, causal, st['A'], st['lse'], rate, st['seed_att'], ldq=ldq, ldk=ldk)
         self._dense(st['A'], N * Tq, C, C, self.p(name + '/wo'), None, st['Z'], True)
         if rate > 0:
             ops.dropout(st['Z'], rate, st['seed_out'])          # in place: Z > 0 now also means "kept"
@@ -243,13 +292,24 @@ class _Base:
                               st['out'], st['xhat'], st['rstd'])
         return st['out']
 
+    def _wgrad_packed(self, x, dy, rows, K, names, ldz):
+        """[g(names[0]) | g(names[1]) | ...] += x^T dy for weight matrices packed side by side (dy [rows][len(names) * C],
+        row pitch ldz): one weight-gradient GEMM into scratch, scattered back into the separate gradient tensors."""
+        C = self.C
+        Nf = len(names) * C
+        tmp = self._wtmp[:K * Nf]
+        d = ops.gemm_desc(rows, K, Nf, K, Nf, ntaps=1)
+        ops.tap_wgrad(d, x, dy, ldz, tmp, self.ws)
+        for j, nm in enumerate(names):
+            ops.copy2d(self.g(nm), C, tmp[j * C:], Nf, K, C, True)      # the gradient buffer was zeroed at the start of backward
+            self._written.add(name_off(self, nm))
+
     def _mha_bwd(self, name, st, dout, dq_in, dq_acc, dk_in, dk_acc):
         """dq_in (+)= dL/d(queries), dk_in (+)= dL/d(keys); dk_in may be dq_in (self-attention)."""
         C, N, Tq, Tk = self.C, st['N'], st['Tq'], st['Tk']
         rq, rk = N * Tq, N * Tk
         self._begin_block()
         dr, dZ, dA = self.sc['a'][:rq * C], self.sc['b'][:rq * C], self.sc['c'][:rq * C]
-        dQ, dK, dV = self.sc['d'][:rq * C], self.sc['e'][:rk * C], self.sc['f'][:rk * C]
         ops.layernorm_bwd(dout, st['xhat'], st['rstd'], self.p(name + '/ln_g'), rq, C, dr, False,
                           self.g(name + '/ln_g'), self.g(name + '/ln_b'), self.ws)
         ops.axpy(dq_in, dr, 1.0, dq_acc)
@@ -258,15 +318,35 @@ class _Base:
             ops.dropout(dZ, self._rate, st['seed_out'])  # the 1/(1-rate) factor (the mask itself is already in Z > 0)
         self._wgrad(st['A'], dZ, rq, C, C, name + '/wo')
         self._dense_dgrad(dZ, rq, C, C, self.p(name + '/wo'), dA, False)
-        ops.attention_bwd(st['Q'], st['K'], st['V'], st['A'], dA, st['lse'], N, Tq, Tk, C, self.H, st['causal'],
+        fused3 = st['fused3']
+        Q, K, V, ldq, ldk = self._qkv_views(st, fused3)
+        dbuf = self.sc['qkv']
+        if fused3:
+            dQ, dK, dV = dbuf[0:], dbuf[C:], dbuf[2 * C:]
+        else:
+            dkv = dbuf[rq * C:]
+            dQ, dK, dV = dbuf[0:], dkv[0:], dkv[C:]
+        ops.attention_bwd(Q, K, V, st['A'], dA, st['lse'], N, Tq, Tk, C, self.H, st['causal'],
                           dQ, dK, dV, self.ws, relu_grad=True,      # gradients of the pre-ReLU projections
-                          dropout_rate=self._rate, seed=st['seed_att'])
-        self._wgrad(st['q_in'], dQ, rq, C, C, name + '/wq')
-        self._wgrad(st['k_in'], dK, rk, C, C, name + '/wk')
-        self._wgrad(st['k_in'], dV, rk, C, C, name + '/wv')
-        self._dense_dgrad(dQ, rq, C, C, self.p(name + '/wq'), dq_in, True)
-        self._dense_dgrad(dK, rk, C, C, self.p(name + '/wk'), dk_in, dk_acc or (dk_in is dq_in))
-        self._dense_dgrad(dV, rk, C, C, self.p(name + '/wv'), dk_in, True)
+                          dropout_rate=self._rate, seed=st['seed_att'], ldq=ldq, ldk=ldk)
+        W3 = st['W3']
+        if fused3 and self.side is None:
+            self._wgrad_packed(st['q_in'], dQ, rq, C, [name + '/wq', name + '/wk', name + '/wv'], 3 * C)
+            self._dense_dgrad(dQ, rq, C, 3 * C, W3, dq_in, True)              # dx += [dQ | dK | dV] . [wq | wk | wv]^T
+        elif fused3:
+            for nm, dy in (('/wq', dQ), ('/wk', dK), ('/wv', dV)):
+                self._wgrad_ld(st['q_in'], dy, rq, C, C, name + nm, 3 * C)
+            self._dense_dgrad(dQ, rq, C, 3 * C, W3, dq_in, True)
+        else:
+            self._wgrad(st['q_in'], dQ, rq, C, C, name + '/wq')
+            self._dense_dgrad(dQ, rq, C, C, self.p(name + '/wq'), dq_in, True)
+            if self.side is None:
+                self._wgrad_packed(st['k_in'], dK, rk, C, [name + '/wk', name + '/wv'], 2 * C)
+            else:
+                self._wgrad_ld(st['k_in'], dK, rk, C, C, name + '/wk', 2 * C)
+                self._wgrad_ld(st['k_in'], dV, rk, C, C, name + '/wv', 2 * C)
+            d = ops.gemm_desc(rk, 2 * C, C, 2 * C, 3 * C, 0, C, ntaps=1, wmode=1, accumulate=1 if dk_acc else 0)
+            ops.tap_gemm(d, dK, W3.view(-1)[C:], None, None, None, None, dk_in)   # dk_in (+)= [dK | dV] . [wk | wv]^T
         self._end_block()
 
     def _ffn_alloc(self, rows):
@@ -323,12 +403,13 @@ class _Base:
         for _ in range(nsets):
             sc = {k: self._t(max_rows * C) for k in 'abcdef'}
             sc['h'] = self._t(max_rows * 4 * C)
+            sc['qkv'] = self._t(max_rows * 3 * C)            # d[Q | K | V] of a block (see _mha_bwd)
             self.sc_sets.append(sc)
         self.sc, self._blk, self._sc_busy = self.sc_sets[0], 0, [None] * nsets
         self._wtmp = self._t(max_w)
         ws = max(ops.layernorm_bwd_workspace(max_rows, C), ops.colsum_workspace(max_rows, 4 * C),
                  ops.colsum_workspace(max_rows, self.Vp), 4 * (max_rows * self.H + 64), 1 << 20)
-        for rows, K, N in gemms:
+        for rows, K, N in list(gemms) + [(max_rows, C, 3 * C), (max_rows, C, 2 * C)]:
             ws = max(ws, ops.tap_wgrad_workspace(ops.gemm_desc(rows, K, N, K, N, ntaps=1)))
         self.ws = self._t(ws // 4 + 64)
         self.ws_side = self._t(ws // 4 + 64) if self.side is not None else None

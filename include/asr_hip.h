@@ -241,6 +241,19 @@ int asr_attention_bwd(const float* Q, const float* K, const float* V, const floa
                       const float* lse, int N, int Tq, int Tk, int C, int H, int causal, int relu_grad,
                       float dropout_rate, unsigned int seed,
                       float* dQ, float* dK, float* dV, float* delta_ws, void* stream);
+/* The same with row pitches: Q (and dQ) rows are ldq floats apart, K, V (and dK, dV) rows ldk floats apart (>= C, multiples
+ * of 4); O, dO stay dense [.][C].  This is how the engines run the three projections of a block as ONE GEMM: Q, K and V are
+ * column blocks of one [rows][3C] buffer (self-attention) or K, V of one [rows][2C] buffer (encoder-decoder attention). */
+int asr_attention_fwd_p(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
+                        int ldq, int ldk, int causal, float dropout_rate, unsigned int seed, float* O, float* lse,
+                        void* stream);
+int asr_attention_bwd_p(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                        const float* lse, int N, int Tq, int Tk, int C, int H, int ldq, int ldk, int causal,
+                        int relu_grad, float dropout_rate, unsigned int seed,
+                        float* dQ, float* dK, float* dV, float* delta_ws, void* stream);
+/* dst[r][0..cols) (+)= src[r][0..cols) for r < rows, with row pitches ldd / lds (floats; everything a multiple of 4):
+ * packs separate weight matrices into the column blocks of a fused one and scatters its gradient back. */
+int asr_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int cols, int accumulate, void* stream);
 /* tf.layers.dropout(x, rate, training=True) (transformer.py:154,226; model.py:290; language_model.py:34):
  *   y[i] = keep(i, seed) ? x[i] / (1 - rate) : 0 with keep(i, seed) = (murmur3_fmix(i * 0x9E3779B1 + seed) >> 8) >= rate * 2^24.
  *   In place is allowed; the same call on the gradient is the backward.  TensorFlow's random stream is not reproduced. */
