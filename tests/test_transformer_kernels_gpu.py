@@ -182,3 +182,37 @@ def test_attention_with_weight_dropout(ops, N, Tq, Tk, H, causal):
     report('attention dQ (dropout)', gq.cpu().numpy(), gq_ref, 5e-5)
     report('attention dK (dropout)', gk.cpu().numpy(), gk_ref, 5e-5)
     report('attention dV (dropout)', gv.cpu().numpy(), gv_ref, 5e-5)
+
+
+@pytest.mark.parametrize("causal,rate", [(False, 0.0), (True, 0.25)])
+def test_attention_with_row_pitches_equals_the_dense_form(causal, rate):
+    """asr_attention_fwd_p / _bwd_p: Q, K, V (and dQ, dK, dV) as column blocks of one [rows][3C] buffer give bitwise the
+    results of the dense call (the engines run the three projections of a block as one GEMM); asr_copy2d packs / scatters."""
+    import torch
+    from asr_dfcnn_transformer_amd import ops
+    N, T, H = 3, 150, 2
+    C = 64 * H
+    g = torch.Generator(device='cuda').manual_seed(4)
+    q, k, v = [torch.relu(torch.randn(N * T, C, device='cuda', generator=g)) for _ in range(3)]
+    do = torch.randn(N * T, C, device='cuda', generator=g)
+    o1, lse1 = torch.zeros(N * T, C, device='cuda'), torch.zeros(2 * N * H * T, device='cuda')
+    ops.attention_fwd(q, k, v, N, T, T, C, H, causal, o1, lse1, rate, 7)
+    dq1, dk1, dv1 = [torch.zeros(N * T, C, device='cuda') for _ in range(3)]
+    ws = torch.zeros(N * H * T + 64, device='cuda')
+    ops.attention_bwd(q, k, v, o1, do, lse1, N, T, T, C, H, causal, dq1, dk1, dv1, ws, relu_grad=True, dropout_rate=rate, seed=7)
+    qkv = torch.zeros(N * T, 3 * C, device='cuda')
+    for j, t in enumerate((q, k, v)):
+        ops.copy2d(qkv.view(-1)[j * C:], 3 * C, t, C, N * T, C)
+    assert torch.equal(qkv[:, C:2 * C], k)
+    o2, lse2 = torch.zeros_like(o1), torch.zeros_like(lse1)
+    f = qkv.view(-1)
+    ops.attention_fwd(f, f[C:], f[2 * C:], N, T, T, C, H, causal, o2, lse2, rate, 7, ldq=3 * C, ldk=3 * C)
+    assert torch.equal(o1, o2) and torch.equal(lse1, lse2)
+    dqkv = torch.full((N * T, 3 * C), 9.0, device='cuda')
+    d = dqkv.view(-1)
+    ops.attention_bwd(f, f[C:], f[2 * C:], o2, do, lse2, N, T, T, C, H, causal, d, d[C:], d[2 * C:], ws, relu_grad=True,
+                      dropout_rate=rate, seed=7, ldq=3 * C, ldk=3 * C)
+    assert torch.equal(dqkv[:, :C], dq1) and torch.equal(dqkv[:, C:2 * C], dk1) and torch.equal(dqkv[:, 2 * C:], dv1)
+    acc = torch.ones(N * T, C, device='cuda')
+    ops.copy2d(acc, C, d[C:], 3 * C, N * T, C, True)                       # scatter-accumulate a column block
+    assert torch.equal(acc, dk1 + 1.0)
