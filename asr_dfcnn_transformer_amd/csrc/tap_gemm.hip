@@ -1038,6 +1038,10 @@ int launch_n(const TapGemmArgs& a, hipStream_t st) {
             // one round only at 4 workgroups/CU, which the 16-deep chunk allows (+14 % on 32768x512x512)
             if (a.N > 64 && tiles <= 768) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
             if (a.N > 64 && tiles <= 1024) return launch_v1<128, 128, 2, 2, NTAPS, WMODE, 16>(a, st);
+        } else {
+            // data-gradient GEMMs of under one round of 128x128 tiles (the 6 400-row language models: 200 tiles): 128x64
+            // tiles (+1.3 % on the Language_Model step)
+            if (a.N > 64 && tiles <= 512) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
         }
     }
     if (NTAPS == 9) {

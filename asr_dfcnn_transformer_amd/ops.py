@@ -100,6 +100,8 @@ def kernel_symbol(family, ntaps, wmode, M, K, N):
         cfg, kc = '128, 64, 2, 2', 32
     elif ntaps == 1 and wmode == 0 and N > 64 and t128 <= 1024:
         cfg, kc = '128, 128, 2, 2', 16
+    elif ntaps == 1 and wmode == 1 and N > 64 and t128 <= 512:
+        cfg, kc = '128, 64, 2, 2', 32
     elif ntaps == 9 and 32 < N <= 64:
         cfg, kc, v2 = '128, 64, 2, 2', 16, False
     elif ntaps == 9 and 64 < N <= 128:
