@@ -1,5 +1,5 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): kernel-trace stats for the five bench workloads and the separate PMC passes for
+# Runs on the GPU box (via gpurun): kernel-trace stats for the six bench workloads and the separate PMC passes for
 # the headline one.  usage: bash tools/collect_profiles.sh <tag>   (outputs under gpurun_out/<tag>/, summaries are
 # then copied into profiles/ by hand).  rocprofv3 gets the python program directly after `--` (no wrapper hops).
 set -e -o pipefail
@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for wl in dfcnn se_dfcnn transformer e2e_prenet am_lm; do
+for wl in dfcnn se_dfcnn transformer e2e_prenet am_lm lm; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -o $wl -- \
       python3 $ROOT/bench.py --workload $wl --steps 4 --warmup 2 --no-cpu-baseline --no-experimental > $OUT/bench_$wl.log 2>&1
   echo "stats $wl done"
@@ -41,7 +41,7 @@ for wl in dfcnn se_dfcnn; do
   python3 $ROOT/tools/pmc_summary.py $OUT/${wl}_pmc_summary.csv $OUT/pmc_${wl}_1 $OUT/pmc_${wl}_2 $OUT/pmc_${wl}_3 $OUT/pmc_${wl}_4 \
       --traffic $OUT/${wl}_traffic.json
 done
-for wl in dfcnn se_dfcnn transformer e2e_prenet am_lm; do
+for wl in dfcnn se_dfcnn transformer e2e_prenet am_lm lm; do
   find $OUT/stats_$wl -name "*kernel_stats.csv" -exec cp {} $OUT/${wl}_kernel_stats.csv \;
 done
 for wl in dfcnn se_dfcnn; do
