@@ -74,39 +74,47 @@ class CNNCTCModel:
         if not torch.is_tensor(x):
             x = torch.as_tensor(np.asarray(x, dtype=np.float32))
         x = x.to(e.device, dtype=torch.float32).reshape(x.shape[0], e.T, e.F).contiguous()
-        if x.shape[0] != e.B:
-            raise ValueError('batch %d != engine batch %d (build the model with batch_size=...)' % (x.shape[0], e.B))
+        n = x.shape[0]                       # B' <= B rows survived the loader (data_loader.py:149-156); the rest is padding
+        if n > e.B:
+            raise ValueError('batch %d > engine batch %d (build the model with batch_size=...)' % (n, e.B))
+        r = self.reducer
+        dp = r is not None and r.world > 1
         need_loss = any(f in (self.loss, self.mean_loss, self.label_err, self.train_op, self.log_prob) or f is self.decoded
                         or f == self.decoded[0] for f in flist)
         e.forward(x)
         lr = None
+        denom = n
         if need_loss:
             tp = feed_dict.get(self.target_py)
             if tp is None:      # decode only (lm_and_am/test.py:48-50)
                 self._decode_only(feed_dict)
             else:
-                e.set_targets(np.asarray(feed_dict[self.logits_length]), np.asarray(tp))
+                # reduce_mean over the rows of the (global) batch, acoustic_model2.py:83: under data parallelism every rank
+                # divides by the GLOBAL number of surviving rows, so the summed all-reduce is that mean whatever each
+                # rank's B' is (a rank may even hold 0 rows: it still enters every collective)
+                denom = r.sum_count(n) if (dp and self.train_op in flist) else n
+                e.set_targets(np.asarray(feed_dict[self.logits_length]), np.asarray(tp), n_valid=n,
+                              loss_denom=max(denom, 1))
                 e.loss_and_decode(defer_decode_join=self.train_op in flist)
         if self.train_op in flist:
             if not self.is_training:
                 raise RuntimeError('train_op needs is_training=True')
-            r = self.reducer
-            if r is not None and r.world > 1:
+            if dp:
                 e.backward(on_dense_grads_ready=lambda: r.launch(0))
                 r.launch(1)
                 r.launch(2)
                 r.wait()
-                lr = e.apply_adam(r.grad_scale)
             else:
                 e.backward()
-                lr = e.apply_adam(1.0)
+            if denom > 0:                   # a step whose every row was dropped (on every rank) updates nothing
+                lr = e.apply_adam(1.0)      # the 1/rows factor is already in the gradient (loss_denom)
         out = []
         scal = None
         for f in flist:
             if f == self.logits:
                 out.append(e.logits)
             elif f == self.loss:
-                out.append(e.loss.cpu().numpy().reshape(-1, 1))
+                out.append(e.loss.cpu().numpy()[:n].reshape(-1, 1))
             elif f in (self.mean_loss, self.label_err):
                 scal = scal or e.fetch_scalars()
                 out.append(scal[0] if f == self.mean_loss else scal[1])
@@ -120,7 +128,7 @@ class CNNCTCModel:
             elif f is self.decoded or f == self.decoded[0]:
                 out.append(SparseTensorValue(e.decoded_lists()))
             elif f == self.log_prob:
-                out.append(e.neg_sum.cpu().numpy().reshape(-1, 1))
+                out.append(e.neg_sum.cpu().numpy()[:n].reshape(-1, 1))
             else:
                 raise KeyError(f)
         return out[0] if single else out
@@ -128,8 +136,11 @@ class CNNCTCModel:
     def _decode_only(self, feed_dict):
         from . import ops
         e = self.engine
-        sl = torch.as_tensor(np.asarray(feed_dict[self.logits_length], dtype=np.int32)).to(e.device)
-        e.seq_len.copy_(sl)
+        sl = np.zeros(e.B, dtype=np.int32)
+        ln = np.asarray(feed_dict[self.logits_length], dtype=np.int32).reshape(-1)
+        sl[:len(ln)] = ln
+        e.n_valid = len(ln)
+        e.seq_len.copy_(torch.from_numpy(sl).to(e.device))
         ops.ctc_greedy(e.logits, e.T8, e.B, e.V, e.seq_len, e.V - 1, e.dec_ids, e.dec_len, e.neg_sum, e.dec_ws)
 
 

@@ -56,6 +56,7 @@ __global__ void ctc_check_kernel(const int32_t* __restrict__ labels, int max_lab
     if (b >= B) return;
     const int L = label_len[b], Tb = seq_len[b];
     int bad = (L < 0 || L > max_label || Tb <= 0 || Tb > T) ? 1 : 0;
+    if (Tb == 0 && L == 0) bad = 2;          // padding row of a short batch: loss 0, gradient 0
     if (!bad) {
         int rep = 0;
         for (int i = 1; i < L; ++i) rep += labels[(long)b * max_label + i] == labels[(long)b * max_label + i - 1];
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (status[b] != 0) {
-        if (tid == 0) loss[b] = INFINITY;
+        if (tid == 0) loss[b] = (status[b] == 2) ? 0.f : INFINITY;
         return;
     }
     const int L = label_len[b], Tb = seq_len[b], S = 2 * L + 1;

@@ -39,19 +39,42 @@ class SyntheticSource:
     """Seeded stand-in for DataUtil (util/data_util.py): 10 s / 16 kHz Gaussian 'audio' and
     random pinyin ids, as BASELINE.md section 3 prescribes."""
 
-    def __init__(self, n_utts, seconds=10.0, sample_rate=16000, label_len=32, vocab=1536, seed=1234, shuffle=False):
+    FAULTS = ('long_audio', 'long_label', 'label_ge_input', 'unknown_token', 'long_hanzi')
+
+    def __init__(self, n_utts, seconds=10.0, sample_rate=16000, label_len=32, vocab=1536, seed=1234, shuffle=False,
+                 faults=None):
+        """``faults`` = {utterance index: one of FAULTS} plants a sample that one of the reference's checks rejects
+        (data_loader.py:139-147, pny2id / han2id KeyError -> ValueError): audio longer than feature_max_length frames,
+        more than 64 labels, at least as many labels as CTC input frames, a token outside the dictionary, more than 64
+        hanzi."""
         self.n, self.ns, self.sr, self.L, self.V, self.seed = n_utts, int(seconds * sample_rate), sample_rate, label_len, vocab, seed
         self.shuffle = shuffle
+        self.faults = dict(faults or {})
         self.path_lst = ['synthetic_%06d' % i for i in range(n_utts)]
         rng = np.random.default_rng(seed)
         self.labels = rng.integers(1, vocab - 1, size=(n_utts, label_len))       # never 0 (Q6), never blank
         self.pny_lst = [' '.join(str(v) for v in row) for row in self.labels]
         self.han_lst = ['' for _ in range(n_utts)]
+        for i, kind in self.faults.items():
+            if kind not in self.FAULTS:
+                raise ValueError(kind)
+            if kind == 'long_label':
+                self.pny_lst[i] = ' '.join(str(v) for v in rng.integers(1, vocab - 1, 65))
+            elif kind == 'unknown_token':
+                self.pny_lst[i] = self.pny_lst[i] + ' zzz9'
+            elif kind == 'long_hanzi':
+                self.han_lst[i] = '\u4e00' * 65            # 65 x the first hanzi of hanzi.txt
 
     def read_audio(self, path):
         i = int(path.rsplit('_', 1)[1])
         rng = np.random.default_rng(self.seed + i)
-        return (0.1 * rng.standard_normal(self.ns)).astype(np.float32), self.sr
+        ns = self.ns
+        kind = self.faults.get(i)
+        if kind == 'long_audio':
+            ns = int(17.0 * self.sr)                 # 1699 frames > feature_max_length 1600
+        elif kind == 'label_ge_input':
+            ns = 160 * 8 * (self.L - 2)              # T//8 + 1 <= label_len
+        return (0.1 * rng.standard_normal(ns)).astype(np.float32), self.sr
 
 
 class DataLoader:
@@ -109,6 +132,11 @@ class DataLoader:
                 hz = self.han2id(han_label_datas[i])
                 if nf > self.feature_max_length or len(ids) > 64 or len(ids) >= data_length:
                     raise ValueError
+                if len(hz) > 64:
+                    # data_loader.py:147 `batch_han_data[i, 0:len(seq_ids)] = seq_ids` cannot broadcast -> numpy ValueError
+                    # -> the row is deleted.  (The reference has by then appended the row's lengths, :143-145, so ITS
+                    # length arrays run one entry ahead of the rows from there on; here rows and lengths stay aligned.)
+                    raise ValueError
                 keep.append(i); sigs.append(np.asarray(signal, dtype=np.float32))
                 in_len.append(data_length); py.append(ids); han.append(hz)
             except ValueError:
@@ -118,9 +146,12 @@ class DataLoader:
         batch_han = np.zeros((n, 64), dtype=np.int32)
         for r in range(n):
             batch_label[r, :len(py[r])] = py[r]
-            batch_han[r, :min(64, len(han[r]))] = han[r][:64]
-        if n == 0:
-            return None
+            batch_han[r, :len(han[r])] = han[r]
+        self.last_kept = keep
+        if n == 0:                    # every row deleted: the reference returns arrays with a 0-row batch axis
+            empty = torch.zeros(0, self.feature_max_length, self.feature_dim, 1, dtype=torch.float32, device=self.device)
+            z = np.zeros(0, dtype=np.int64)
+            return empty, z, batch_label, z, batch_han, z
         mx = max(len(s) for s in sigs)
         host = np.zeros((n, mx), dtype=np.float32)
         for r, s in enumerate(sigs):
@@ -138,6 +169,4 @@ class DataLoader:
 
     def am_generator(self):
         for i in range(len(self)):
-            item = self[i]
-            if item is not None:
-                yield item
+            yield self[i]

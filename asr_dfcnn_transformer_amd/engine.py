@@ -70,6 +70,14 @@ def graph(model, vocab, widths=None, feat=200):
              ('cell', 'h3', 'h4a', c3, c3, 3, None), ('cell', 'h4a', 'h4n', c3, nin, 1, None), ('cell', 'h4n', 'h4', nin, c3, 3, None),
              ('cell', 'h4', 'h5a', c3, c3, 3, None), ('cell', 'h5a', 'h5n', c3, nin, 1, None), ('cell', 'h5n', 'h5', nin, c3, 3, None),
              ('dense', 'h5', 'h7', (feat // 8) * c3, hid, 'relu'), ('dense', 'h7', 'd', hid, vocab, 'softmax')]
+    elif model == 'small':
+        # BASELINE.json configs[0] "DFCNN-small (32ch, 4 conv blocks) + CTC" (channels (32, 32, 32, 32), 4 conv
+        # cells, B = 4): four cnn_cell()s of acoustic_model2.py:126-133 (conv3x3 + bias -> ReLU -> frozen BN -> avg "maxpool"),
+        # the first three pooled so that the CTC axis is T/8 as the data loader assumes (data_loader.py:132), then the
+        # reshape + dense(V, softmax) head of acoustic_model2.py:62-68
+        c1, c2, c3, c4 = widths or (32, 32, 32, 32)
+        g = [('cell', 'x', 'h1', 1, c1, 3, 'avg'), ('cell', 'h1', 'h2', c1, c2, 3, 'avg'), ('cell', 'h2', 'h3', c2, c3, 3, 'avg'),
+               ('cell', 'h3', 'h4', c3, c4, 3, None), ('dense', 'h4', 'd', (feat // 8) * c4, vocab, 'softmax')]
     else:
         raise ValueError('unknown model %r' % (model,))
     return g
@@ -104,6 +112,44 @@ def step_flops_per_utt(g, T, F):
     return 3.0 * total - first
 
 
+def param_layout(g):
+    """Flat fp32 parameter layout of a graph: [all BN gammas][dense layers][everything else], every tensor 16-byte
+    aligned.  Returns (entries {(layer, key): (offset, shape)}, n_gamma, dense_end, total floats).  The gamma segment
+    lets one launch derive every bn_scale; the dense segment is the first gradient bucket that is final in backward
+    (its all-reduce overlaps the conv-stack backward); the three data-parallel buckets are
+    [n_gamma, dense_end), [0, n_gamma), [dense_end, total)."""
+    ent = {}
+    off = 0
+
+    def add(layer, key, shape):
+        nonlocal off
+        n = int(np.prod(shape))
+        ent[(layer, key)] = (off, tuple(shape))
+        off += (n + 3) // 4 * 4
+
+    for op in g:
+        if op[0] == 'cell':
+            add(op[2], 'gamma', (op[4],))
+        elif op[0] == 'se' and op[6]:
+            add(op[3], 'gamma', (op[4],))
+    n_gamma = off
+    for op in g:
+        if op[0] == 'dense':
+            add(op[2], 'w', (op[3], op[4]))
+            add(op[2], 'b', (op[4],))
+    dense_end = off
+    for op in g:
+        if op[0] == 'cell':
+            _, src, dst, cin, cout, k, pool = op
+            add(dst, 'w', (k, k, cin, cout)); add(dst, 'b', (cout,)); add(dst, 'beta', (cout,))
+        elif op[0] == 'se':
+            _, main, br, dst, Cc, hid, use_bn = op
+            if use_bn:
+                add(dst, 'beta', (Cc,))
+            add(dst, 'w1', (Cc, hid)); add(dst, 'b1', (hid,)); add(dst, 'w2', (hid, Cc)); add(dst, 'b2', (Cc,))
+    return ent, n_gamma, dense_end, off
+
+
 class DFCNNEngine:
     def __init__(self, model='m2', vocab=1536, B=32, T=1600, F=200, widths=None, seed=0, device='cuda',
                  lr=7e-4, decay_steps=5000, min_lr=1e-6, beta1=0.9, beta2=0.999, adam_eps=1e-8):
@@ -114,44 +160,14 @@ class DFCNNEngine:
         self.lr0, self.decay_steps, self.min_lr = lr, decay_steps, min_lr
         self.beta1, self.beta2, self.adam_eps = beta1, beta2, adam_eps
         self.global_step = 0
+        self.n_valid, self.loss_denom = B, float(B)
         self._layout_params()
         self.init_params(seed)
         self._alloc_buffers()
 
     # ------------------------------------------------------------------ parameters
     def _layout_params(self):
-        """Flat fp32 buffer: [all BN gammas][dense layers][everything else].  The gamma segment
-        lets one launch derive every bn_scale; the dense segment is the first gradient bucket
-        ready in backward (all-reduce overlaps the conv-stack backward)."""
-        ent = {}            # (layer, key) -> (offset, shape)
-        off = 0
-
-        def add(layer, key, shape):
-            nonlocal off
-            n = int(np.prod(shape))
-            ent[(layer, key)] = (off, tuple(shape))
-            off += (n + 3) // 4 * 4          # keep every tensor 16-byte aligned
-
-        for op in self.g:
-            if op[0] == 'cell':
-                add(op[2], 'gamma', (op[4],))
-            elif op[0] == 'se' and op[6]:
-                add(op[3], 'gamma', (op[4],))
-        self.n_gamma = off
-        for op in self.g:
-            if op[0] == 'dense':
-                add(op[2], 'w', (op[3], op[4]))
-                add(op[2], 'b', (op[4],))
-        self.dense_end = off
-        for op in self.g:
-            if op[0] == 'cell':
-                _, src, dst, cin, cout, k, pool = op
-                add(dst, 'w', (k, k, cin, cout)); add(dst, 'b', (cout,)); add(dst, 'beta', (cout,))
-            elif op[0] == 'se':
-                _, main, br, dst, Cc, hid, use_bn = op
-                if use_bn:
-                    add(dst, 'beta', (Cc,))
-                add(dst, 'w1', (Cc, hid)); add(dst, 'b1', (hid,)); add(dst, 'w2', (hid, Cc)); add(dst, 'b2', (Cc,))
+        ent, self.n_gamma, self.dense_end, off = param_layout(self.g)
         self.entries = ent
         self.n_params_padded = off
         self.n_params = sum(int(np.prod(s)) for _, s in ent.values())
@@ -377,8 +393,27 @@ class DFCNNEngine:
         if self.n_gamma:
             ops.axpy(self.bn_scale[:self.n_gamma], self.theta[:self.n_gamma], RS, False)
 
+    def pad_batch(self, x):
+        """The reference feeds the B' <= B rows that survived the data loader's checks (placeholders with a None batch
+        dimension, acoustic_model2.py:29-32; data_loader.py:149-156).  The engine's planes are sized for B rows, so a
+        short batch is copied into a persistent [B, T, F] buffer whose remaining rows are zero; set_targets(...,
+        n_valid=B') then marks those rows as padding (CTC loss 0, gradient 0, not counted in any mean)."""
+        n = x.shape[0]
+        if n == self.B:
+            return x
+        if n > self.B:
+            raise ValueError('batch of %d rows for an engine built for %d' % (n, self.B))
+        if getattr(self, '_xpad', None) is None:
+            self._xpad = torch.zeros(self.B, self.T, self.F, dtype=torch.float32, device=self.device)
+        self._xpad[:n].copy_(x)
+        self._xpad[n:].zero_()
+        return self._xpad
+
     def forward(self, x):
-        """x: [B, T, F] float32 on the device (the wav_input placeholder without its last axis)."""
+        """x: [B, T, F] float32 on the device (the wav_input placeholder without its last axis); fewer rows are padded
+        (pad_batch)."""
+        if x.shape[0] != self.B:
+            x = self.pad_batch(x)
         assert x.is_contiguous() and tuple(x.shape) == (self.B, self.T, self.F)
         self.x = x
         self.refresh_bn()
@@ -428,17 +463,26 @@ class DFCNNEngine:
         return self.ones[:Cc], self.ones[1024:1024 + Cc]
 
     # ------------------------------------------------------------------ loss / decode
-    def set_targets(self, logits_length, target_py, target_length=None):
-        """logits_length [B] ints, target_py [B, <=64] zero-padded ids.  Mirrors
+    def set_targets(self, logits_length, target_py, target_length=None, n_valid=None, loss_denom=None):
+        """logits_length [B'] ints, target_py [B', <=64] zero-padded ids, B' = n_valid <= B (default B): rows
+        n_valid..B-1 are padding (sequence length 0, no labels: asr_ctc_loss status 2).  ``loss_denom`` is the row count the
+        gradient of the mean loss is divided by (reduce_mean, acoustic_model2.py:83): B' by default; under data
+        parallelism the GLOBAL number of surviving rows, so that the summed all-reduce is the global-batch mean.  Mirrors
         tf.contrib.layers.dense_to_sparse (acoustic_model2.py:71): every 0 is dropped (Q6).
         With ``target_length`` [B] the labels are the DENSE form of tf.nn.ctc_loss_v2(labels=target_py,
         label_length=target_length) (am_lm_model.py:72): the first target_length ids of each row, zeros kept.
         Raises ValueError where TF raises InvalidArgumentError (no valid CTC alignment)."""
         tp = np.asarray(target_py)
+        nv = self.B if n_valid is None else int(n_valid)
+        if not 0 <= nv <= self.B:
+            raise ValueError('n_valid %d outside [0, %d]' % (nv, self.B))
+        self.n_valid = nv
+        self.loss_denom = float(loss_denom if loss_denom is not None else max(nv, 1))
         lab = np.zeros((self.B, MAX_LABEL), dtype=np.int32)
         ll = np.zeros(self.B, dtype=np.int32)
-        sl = np.asarray(logits_length, dtype=np.int32).reshape(self.B)
-        for b in range(self.B):
+        sl = np.zeros(self.B, dtype=np.int32)
+        sl[:nv] = np.asarray(logits_length, dtype=np.int32).reshape(-1)[:nv]
+        for b in range(nv):
             ids = tp[b][tp[b] != 0] if target_length is None else np.asarray(tp[b])[:int(target_length[b])]
             if len(ids) > MAX_LABEL:
                 raise ValueError('label longer than %d' % MAX_LABEL)
@@ -451,7 +495,7 @@ class DFCNNEngine:
         self.labels.copy_(torch.from_numpy(lab), non_blocking=True)
         self.label_len.copy_(torch.from_numpy(ll), non_blocking=True)
         self.seq_len.copy_(torch.from_numpy(sl), non_blocking=True)
-        self._host_labels = [lab[b, :ll[b]].tolist() for b in range(self.B)]
+        self._host_labels = [lab[b, :ll[b]].tolist() for b in range(nv)]
 
     def loss_and_decode(self, defer_decode_join=False):
         """CTC loss + gradient, greedy decode, edit distance.  With the side stream the decode runs beside the CTC
@@ -489,7 +533,7 @@ class DFCNNEngine:
         that activation (the language half of the joint graph reads h7), added before the layer's own backward."""
         B, T8, V = self.B, self.T8, self.V
         last = self.g[-1][2]
-        ops.softmax_log_bwd(self.logits, self.ctc_grad, B, T8, V, K_EPSILON, 1.0 / B, self.dflat[last])
+        ops.softmax_log_bwd(self.logits, self.ctc_grad, B, T8, V, K_EPSILON, 1.0 / self.loss_denom, self.dflat[last])
         ready = set()          # gradient planes that already hold a value this step
 
         def grad_target(name):
@@ -603,10 +647,12 @@ class DFCNNEngine:
 
     # ------------------------------------------------------------------ fetches (host sync)
     def fetch_scalars(self):
+        """(mean_loss, label_err): means over the n_valid rows of the batch (padding rows contribute 0 to both sums)."""
         s = self.scalars.cpu().numpy()
-        return float(s[0]) / self.B, float(s[1]) / self.B
+        n = max(self.n_valid, 1)
+        return float(s[0]) / n, float(s[1]) / n
 
     def decoded_lists(self):
         ids = self.dec_ids.cpu().numpy()
         n = self.dec_len.cpu().numpy()
-        return [ids[b, :n[b]].tolist() for b in range(self.B)]
+        return [ids[b, :n[b]].tolist() for b in range(self.n_valid)]

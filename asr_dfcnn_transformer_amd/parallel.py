@@ -59,6 +59,16 @@ class BucketedAllReduce:
             w.wait()
         self.pending = []
 
+    def sum_count(self, n):
+        """Sum of a per-rank integer over the ranks (rows that survived the loader: the denominator of the global
+        mean).  One tiny blocking all-reduce; every rank must call it the same number of times."""
+        if self.world == 1:
+            return int(n)
+        dev = self.flat.device if dist.get_backend(self.group) == 'nccl' else 'cpu'
+        t = torch.tensor([int(n)], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return int(t.item())
+
     @property
     def grad_scale(self):
         return 1.0 / self.world

@@ -23,29 +23,65 @@ def _engine_of(obj):
     return getattr(obj, 'engine', obj)
 
 
+def _parts(model):
+    """name -> sub-engine that owns flat theta / Adam buffers.  A plain engine (or a shim around one) is one part '';
+    the joint model is {'am', 'lm'} (joint_engine.AMLMEngine), the speech Transformer is {'engine', 'prenet'}
+    (e2e_model.Transformer_Model: pre_net + encoder-decoder under ONE AdamOptimizer, end2end/model.py:366-370)."""
+    parts = {}
+    e = _engine_of(model)
+    if hasattr(e, 'theta'):
+        parts[''] = e
+    for holder in (model, e):
+        for name in ('am', 'lm', 'prenet'):
+            sub = getattr(holder, name, None)
+            if sub is not None and hasattr(sub, 'theta') and sub not in parts.values():
+                parts[name] = sub
+    if not parts:
+        raise ValueError('%s owns no engine with parameters (build it / run one step first)' % type(model).__name__)
+    return parts
+
+
+def _state(e):
+    return {'theta': e.theta.cpu(), 'adam_m': e.adam_m.cpu(), 'adam_v': e.adam_v.cpu(), 'global_step': int(e.global_step),
+            'variant': str(getattr(e, 'model', type(e).__name__)),
+            'entries': {str(k): (int(v[0]), tuple(int(d) for d in v[1])) for k, v in e.entries.items()}}
+
+
 def save_checkpoint(model, path):
     """Everything tf.train.Saver keeps for the reference (train.py:38,91-96; model.py:81-88): the variables, the Adam
-    slots and global_step -- of any engine here (DFCNN variants, Keras DFCNN, LM, encoder-decoder, pre-net) or of a
-    shim that owns one.  Own format (torch.save); TF checkpoint compatibility is out of scope."""
-    e = _engine_of(model)
-    torch.save({'theta': e.theta.cpu(), 'adam_m': e.adam_m.cpu(), 'adam_v': e.adam_v.cpu(),
-                'global_step': e.global_step, 'variant': getattr(e, 'model', type(e).__name__),
-                'entries': {str(k): v for k, v in e.entries.items()}}, path)
+    slots and global_step -- of any engine here (DFCNN variants, Keras DFCNN, LM, encoder-decoder, pre-net), of a shim
+    that owns one, or of a composite (joint AM+LM, pre-net + encoder-decoder): one state per part.  Own format
+    (torch.save of tensors / ints / strings / tuples only); TF checkpoint compatibility is out of scope."""
+    torch.save({'format': 2, 'parts': {name: _state(e) for name, e in _parts(model).items()}}, path)
 
 
 def load_checkpoint(model, path):
-    e = _engine_of(model)
-    ck = torch.load(path, map_location='cpu', weights_only=False)
-    if ck['variant'] != getattr(e, 'model', type(e).__name__) or ck['entries'] != {str(k): v for k, v in e.entries.items()}:
-        raise ValueError('checkpoint %s was written by a different model (%s)' % (path, ck['variant']))
-    e.theta.copy_(ck['theta']); e.adam_m.copy_(ck['adam_m']); e.adam_v.copy_(ck['adam_v'])
-    e.global_step = int(ck['global_step'])
+    ck = torch.load(path, map_location='cpu', weights_only=True)      # plain data only: nothing is unpickled into code
+    parts = _parts(model)
+    if ck.get('format') != 2 or set(ck['parts']) != set(parts):
+        raise ValueError('checkpoint %s holds parts %s, the model has %s' % (path, sorted(ck.get('parts', {})), sorted(parts)))
+    for name, e in parts.items():
+        st, mine = ck['parts'][name], _state(e)
+        if st['variant'] != mine['variant'] or st['entries'] != mine['entries']:
+            raise ValueError('checkpoint %s was written by a different model (%s)' % (path, st['variant']))
+    for name, e in parts.items():
+        st = ck['parts'][name]
+        e.theta.copy_(st['theta']); e.adam_m.copy_(st['adam_m']); e.adam_v.copy_(st['adam_v'])
+        e.global_step = int(st['global_step'])
 
 
-def train_acoustic_model(data_args, am_hp, train_source, dev_source=None, ckpt_dir=None, log_every=2, model_cls=CNNCTCModel):
+def rank_batches(batch_nums, world, rank):
+    """Batch indices rank ``rank`` of ``world`` trains on in one epoch: r, r + world, ... -- the SAME count
+    (batch_nums // world) on every rank, so that all ranks issue the same collectives."""
+    return [it * world + rank for it in range(batch_nums // world)]
+
+
+def train_acoustic_model(data_args, am_hp, train_source, dev_source=None, ckpt_dir=None, log_every=2, model_cls=CNNCTCModel,
+                         loader_cls=DataLoader):
     rank, world, local = init_from_env()
-    torch.cuda.set_device(local)
-    train_loader = DataLoader(train_source, data_args, am_hp)
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    train_loader = loader_cls(train_source, data_args, am_hp)
     model = model_cls(am_hp, train_loader.acoustic_vocab_size, train_loader.language_vocab_size)
     if ckpt_dir and os.path.exists(os.path.join(ckpt_dir, 'final_model.pt')):
         load_checkpoint(model, os.path.join(ckpt_dir, 'final_model.pt'))
@@ -54,11 +90,13 @@ def train_acoustic_model(data_args, am_hp, train_source, dev_source=None, ckpt_d
     for epoch in range(am_hp.epochs):
         total_loss = 0.0
         steps = 0
-        for train_step in range(rank, batch_nums, world):           # utterance shards: independent batches per rank
-            item = train_loader[train_step]
-            if item is None or item[0].shape[0] != model.engine.B:
-                continue                                           # rows were dropped (data_loader.py:149-156)
-            x, in_len, y, y_len, _, _ = item
+        # utterance shards: rank r takes batches r, r + world, ...  EVERY rank takes batch_nums // world steps (the
+        # batch_nums % world left-over batches are dropped, as the loader itself drops the utterances beyond a whole
+        # batch, data_loader.py:279-280), and a batch that lost rows -- even all of them -- is still fed: the model
+        # trains on the B' surviving rows (train.py:59-69 feeds whatever data_generation returned) and every rank
+        # enters the same collectives in the same order.
+        for train_step in rank_batches(batch_nums, world, rank):
+            x, in_len, y, y_len, _, _ = train_loader[train_step]
             feed = {model.wav_input: x, model.logits_length: in_len, model.target_py: y,
                     model.target_length: y_len, model.drop_rate: am_hp.dropout_rate}
             loss, mean_loss, lr, summary, label_err, _ = model.run(
@@ -71,12 +109,12 @@ def train_acoustic_model(data_args, am_hp, train_source, dev_source=None, ckpt_d
                       % (epoch + 1, train_step + 1, batch_nums, mean_loss, total_loss / steps, lr, label_err), flush=True)
             history.append((mean_loss, lr, label_err))
         if dev_source is not None:
-            dev_loader = DataLoader(dev_source, data_args, am_hp)
+            dev_loader = loader_cls(dev_source, data_args, am_hp)
             tot_l, tot_e, n = 0.0, 0.0, 0
             for item in dev_loader.am_generator():
-                if item[0].shape[0] != model.engine.B:
-                    continue
                 x, in_len, y, y_len, _, _ = item
+                if x.shape[0] == 0:
+                    continue
                 ml, le = model.run([model.mean_loss, model.label_err],
                                    {model.wav_input: x, model.logits_length: in_len, model.target_py: y,
                                     model.target_length: y_len, model.drop_rate: 0})

@@ -236,8 +236,9 @@ class _Base:
 
     def _bgrad(self, dy, rows, N, name):
         if name_off(self, name) in self._written:
-            ops.colsum(dy, rows, N, N, self._wtmp[:N], self.ws)
-            ops.axpy(self.g(name), self._wtmp[:N], 1.0, True)
+            # own scratch: _wtmp belongs to the weight-gradients, which may be running on the side stream right now
+            ops.colsum(dy, rows, N, N, self._btmp[:N], self.ws)
+            ops.axpy(self.g(name), self._btmp[:N], 1.0, True)
         else:
             ops.colsum(dy, rows, N, N, self.g(name), self.ws)
             self._written.add(name_off(self, name))
@@ -407,6 +408,7 @@ class _Base:
             self.sc_sets.append(sc)
         self.sc, self._blk, self._sc_busy = self.sc_sets[0], 0, [None] * nsets
         self._wtmp = self._t(max_w)
+        self._btmp = self._t(max(4 * C, self.Vp, 1024))      # bias-gradient scratch of the main stream (_bgrad)
         ws = max(ops.layernorm_bwd_workspace(max_rows, C), ops.colsum_workspace(max_rows, 4 * C),
                  ops.colsum_workspace(max_rows, self.Vp), 4 * (max_rows * self.H + 64), 1 << 20)
         for rows, K, N in list(gemms) + [(max_rows, C, 3 * C), (max_rows, C, 2 * C)]:

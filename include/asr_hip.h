@@ -186,7 +186,10 @@ int asr_colsum(const float* x, int rows, int cols, int ldx, float* out, float* p
  *   labels [B][max_label] i32 (already without zeros: see dense_to_sparse), label_len [B],
  *   seq_len [B];  loss [B] f32;  grad [T][B][V] f32 (zero for t >= seq_len[b]);
  *   status [B] i32: 0 ok, 1 = "not enough time for target transition sequence"
- *   (loss = +inf, grad = 0 for that utterance -- TF raises InvalidArgumentError).
+ *   (loss = +inf, grad = 0 for that utterance -- TF raises InvalidArgumentError),
+ *   2 = padding row: seq_len[b] == 0 and label_len[b] == 0 mark a row that is not part of
+ *   the batch (the reference feeds B' <= B surviving rows, lm_and_am/data_loader.py:149-156;
+ *   a fixed-size device batch carries the missing rows as padding): loss = 0, grad = 0.
  * workspace: asr_ctc_workspace() bytes.  alpha/beta recursion runs in float64.
  */
 size_t asr_ctc_workspace(int T, int B, int max_label);

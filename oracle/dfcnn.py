@@ -63,6 +63,14 @@ def graph(model, vocab, widths=None, feat=200):
                ('cell', 'h4', 'h5a', c3, c3, 3, None), ('cell', 'h5a', 'h5n', c3, nin, 1, None), ('cell', 'h5n', 'h5', nin, c3, 3, None),
                ('dense', 'h5', 'h7', (feat // 8) * c3, hid, 'relu'),
                ('dense', 'h7', 'd', hid, vocab, 'softmax')]
+    elif model == 'small':
+        # BASELINE.json configs[0] "DFCNN-small (32ch, 4 conv blocks) + CTC" (channels (32, 32, 32, 32), 4 conv
+        # cells, B = 4): four cnn_cell()s of acoustic_model2.py:126-133 (conv3x3 + bias -> ReLU -> frozen BN -> avg "maxpool"),
+        # the first three pooled so that the CTC axis is T/8 as the data loader assumes (data_loader.py:132), then the
+        # reshape + dense(V, softmax) head of acoustic_model2.py:62-68
+        c1, c2, c3, c4 = widths or (32, 32, 32, 32)
+        ops = [('cell', 'x', 'h1', 1, c1, 3, 'avg'), ('cell', 'h1', 'h2', c1, c2, 3, 'avg'), ('cell', 'h2', 'h3', c2, c3, 3, 'avg'),
+               ('cell', 'h3', 'h4', c3, c4, 3, None), ('dense', 'h4', 'd', (feat // 8) * c4, vocab, 'softmax')]
     else:
         raise ValueError(model)
     return ops
