@@ -685,6 +685,186 @@ __global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_v3(WgradArgs g) {
             }
 }
 
+// ---- v6: as v1, but the runs arrive by LDS-DMA (global_load_lds_dwordx4: global -> LDS with no register in between)
+// into TWO run buffers: the DMA of run i+1 is issued before the MFMAs of run i and has the whole run (9-18k matrix-pipe
+// cycles) to land, so a wave never waits on memory -- v1 spends a third of its time in its two staging barriers with the
+// matrix pipe idle (PMC: busy 0.62-0.67), and 144 accumulator registers leave no room for a register prefetch.  One barrier
+// per run.  A DMA piece is one wave instruction = 64 lanes x 16 B = 1 KiB, contiguous in LDS (destination = wave-uniform
+// base + 16 * lane) with a per-lane SOURCE address: 8 rows of 32 channels, or 2 rows of 128, per piece; the images are the
+// plain [row][channel] tiles v1 reads (conflict-free ds_read_b32: 32 consecutive floats per half wave).  Needs whole
+// k / n tiles (K % KT == 0, N % NT == 0) and sources whose rows are all inside their allocation: true for every full run
+// (planes carry W + 3 zero guard pixels >= the halo); the ONE ragged run at the end of the pixel axis is staged through
+// registers with masks, like v1.
+typedef __attribute__((address_space(3))) float wg_lds_f;
+typedef const __attribute__((address_space(1))) float wg_glb_f;
+
+template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS, int MINB>
+__global__ __launch_bounds__(256, MINB) void tap_wgrad_kernel_v6(WgradArgs g) {
+    constexpr int WAVES_P = 4 / WAVES_N;
+    constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32;
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int halo = g.halo;
+    const int arows = PS + 2 * halo;
+    const int atotal = arows * (KT / 4);            // float4 of the A image
+    const int asz = (arows * KT + 255) & ~255;      // floats, rounded up to whole 1-KiB pieces
+    const int bufsz = asz + PS * NT;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = tid >> 6, wn = wave % WAVES_N, wp = wave / WAVES_N;
+    const int chunk = blockIdx.x;
+    const int k0 = blockIdx.y * KT, n0 = blockIdx.z * NT;
+    const long cbeg = (long)chunk * g.pch;
+    const long cend = (cbeg + g.pch < g.M) ? cbeg + g.pch : g.M;
+
+    floatx16 acc[NTAPS][TKW][TNW];
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int a = 0; a < TKW; ++a)
+#pragma unroll
+            for (int b = 0; b < TNW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
+
+    constexpr int ARP = 256 / KT, ZRP = 256 / NT;   // rows per DMA piece
+    const int apieces = (atotal + 63) >> 6;
+    constexpr int zpieces = PS * (NT / 4) / 64;
+    static_assert((PS * (NT / 4)) % 64 == 0, "whole dZ pieces");
+    const int arow_l = lane / (KT / 4), ac4 = lane % (KT / 4);
+    const int zrow_l = lane / (NT / 4), zc4 = lane % (NT / 4);
+
+    auto stage_dma = [&](long ps0, float* buf) {
+        const float* asrc = g.A + (ps0 - halo + arow_l) * (long)g.lda + k0 + ac4 * 4;
+        for (int p = wave; p < apieces; p += 4)
+            if (p * 64 + lane < atotal)
+                __builtin_amdgcn_global_load_lds((wg_glb_f*)(asrc + (long)p * ARP * g.lda), (wg_lds_f*)(buf + p * 256), 16, 0, 0);
+        const float* zsrc = g.Z + (ps0 + zrow_l) * (long)g.ldz + n0 + zc4 * 4;
+        float* zb = buf + asz;
+#pragma unroll
+        for (int p = wave; p < zpieces; p += 4)
+            __builtin_amdgcn_global_load_lds((wg_glb_f*)(zsrc + (long)p * ZRP * g.ldz), (wg_lds_f*)(zb + p * 256), 16, 0, 0);
+    };
+    auto stage_masked = [&](long ps0, float* buf) {     // ragged last run: rows past the end read as zero
+        float* Zs = buf + asz;
+        for (int f = tid; f < atotal; f += 256) {
+            const int row = f / (KT / 4), c4 = f - row * (KT / 4);
+            const long grow = ps0 - halo + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grow >= g.rmin && grow < g.rmax) v = *(const float4*)(g.A + grow * g.lda + k0 + c4 * 4);
+            *(float4*)(buf + row * KT + c4 * 4) = v;
+        }
+        for (int f = tid; f < PS * (NT / 4); f += 256) {
+            const int row = f / (NT / 4), n4 = f - row * (NT / 4);
+            const long grow = ps0 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (grow < cend) v = *(const float4*)(g.Z + grow * g.ldz + n0 + n4 * 4);
+            *(float4*)(Zs + row * NT + n4 * 4) = v;
+        }
+    };
+    auto stage = [&](long ps0, float* buf) {
+        if (ps0 + PS <= g.M) stage_dma(ps0, buf); else stage_masked(ps0, buf);
+    };
+
+    stage(cbeg, smem);
+    __syncthreads();                     // vmcnt(0) + barrier: run 0 has landed for every wave
+    int cur = 0;
+    for (long ps0 = cbeg; ps0 < cend; ps0 += PS) {
+        const float* As = smem + cur * bufsz;
+        const float* Zs = As + asz;
+        // the other buffer was last read in the previous iteration, which every wave has left (barrier below)
+        if (ps0 + PS < cend) stage(ps0 + PS, smem + (cur ^ 1) * bufsz);
+        {
+            // fully unrolled run (compile-time trip count): pixel offsets become immediates and the two operand sets are
+            // plain renamed registers -- the rolled form of v1 carries them through v_mov copies behind an lgkmcnt(0)
+            float a0[NTAPS][TKW], b0[TNW], a1[NTAPS][TKW], b1[TNW];
+            constexpr int RS = 2 * WAVES_P;             // pixel stride between this wave's pairs
+            constexpr int NP = PS / RS;                 // pairs per wave and run
+            static_assert(NP % 2 == 0, "unroll by two");
+            const float* Zw = Zs + (2 * wp + lh) * NT + wn * TNW * 32 + li;
+            const float* Aw = As + (2 * wp + lh + halo) * KT + li;
+            int toff[NTAPS];
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) toff[t] = ((NTAPS == 9) ? ((t / 3) - 1) * g.WP + (t % 3) - 1 : 0) * KT;
+            auto fetch = [&](float (&an)[NTAPS][TKW], float (&bn)[TNW], int r) {
+#pragma unroll
+                for (int b = 0; b < TNW; ++b) bn[b] = Zw[r * NT + b * 32];
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                    for (int a = 0; a < TKW; ++a) an[t][a] = Aw[toff[t] + r * KT + a * 32];
+            };
+            auto fma_all = [&](const float (&ac)[NTAPS][TKW], const float (&bc)[TNW]) {
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                    for (int a = 0; a < TKW; ++a)
+#pragma unroll
+                        for (int b = 0; b < TNW; ++b)
+                            acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][a], bc[b], acc[t][a][b], 0, 0, 0);
+            };
+            fetch(a0, b0, 0);
+#pragma unroll
+            for (int i = 0; i < NP; i += 2) {
+                fetch(a1, b1, (i + 1) * RS);
+                fma_all(a0, b0);
+                if (i + 2 < NP) fetch(a0, b0, (i + 2) * RS);
+                fma_all(a1, b1);
+            }
+        }
+        __syncthreads();                 // this wave's DMA of the next run has landed (vmcnt(0)), then all waves meet
+        cur ^= 1;
+    }
+
+    if (WAVES_P > 1) {
+        float* red = smem;   // [WAVES_P-1][WAVES_N][TKW*TNW*16][64]
+#pragma unroll
+        for (int t = 0; t < NTAPS; ++t) {
+            __syncthreads();
+            if (wp > 0) {
+                float* dst = red + (((wp - 1) * WAVES_N + wn) * (TKW * TNW * 16)) * 64 + lane;
+#pragma unroll
+                for (int a = 0; a < TKW; ++a)
+#pragma unroll
+                    for (int b = 0; b < TNW; ++b)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            dst[((a * TNW + b) * 16 + r) * 64] = acc[t][a][b][r];
+            }
+            __syncthreads();
+            if (wp == 0) {
+                for (int src = 1; src < WAVES_P; ++src) {
+                    const float* sp = red + (((src - 1) * WAVES_N + wn) * (TKW * TNW * 16)) * 64 + lane;
+#pragma unroll
+                    for (int a = 0; a < TKW; ++a)
+#pragma unroll
+                        for (int b = 0; b < TNW; ++b)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                acc[t][a][b][r] += sp[((a * TNW + b) * 16 + r) * 64];
+                }
+            }
+        }
+    }
+    if (wp != 0) return;
+
+    float* out = g.out + (long)chunk * g.slab;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+        for (int a = 0; a < TKW; ++a)
+#pragma unroll
+            for (int b = 0; b < TNW; ++b) {
+                const int n = n0 + (wn * TNW + b) * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = k0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    out[((long)t * g.K + k) * g.N + n] = acc[t][a][b][r];
+                }
+            }
+}
+
 __global__ void sum_chunks_kernel(const float* __restrict__ part, float* __restrict__ out,
                                   long n, int nchunks) {
     const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -768,12 +948,81 @@ int launch_wgrad(const WgradArgs& a, const Plan& p, int K, int N, hipStream_t st
     return ASR_OK;
 }
 
+// v6 (LDS-DMA, two run buffers): run length and workgroups per CU from what fits the 160 KB of LDS -- two workgroups per
+// CU with 32-pixel runs when two double-buffered images fit in 80 KB each, else one with 64- or 32-pixel runs -- and a
+// grid of exactly one round of resident workgroups (512 or 256): every workgroup runs beside the same neighbours from
+// start to end, no partial round.  ASR_WGRAD6_PS / ASR_WGRAD6_BLOCKS override (experiments).
+struct Plan6 { Plan p; int ps, minb; size_t lds; };
+
+template <int KT, int NT>
+Plan6 make_plan6(const asr_gemm_desc* d) {
+    static int ps_force = -1, blocks_force = -1;
+    if (ps_force < 0) { const char* e = getenv("ASR_WGRAD6_PS"); ps_force = e ? atoi(e) : 0; }
+    if (blocks_force < 0) { const char* e = getenv("ASR_WGRAD6_BLOCKS"); blocks_force = e ? atoi(e) : 0; }
+    const int halo = (d->ntaps != 1) ? d->W + 2 : 0;
+    auto lds_for = [&](int ps) { return (size_t)2 * ((((size_t)(ps + 2 * halo) * KT + 255) & ~(size_t)255) + (size_t)ps * NT) * sizeof(float); };
+    Plan6 q;
+    if (ps_force == 32 || ps_force == 64) { q.ps = ps_force; q.minb = (2 * lds_for(q.ps) <= 160 * 1024) ? 2 : 1; }
+    else if (2 * lds_for(32) <= 160 * 1024) { q.ps = 32; q.minb = 2; }
+    else if (lds_for(64) <= 160 * 1024) { q.ps = 64; q.minb = 1; }
+    else { q.ps = 32; q.minb = 1; }
+    q.lds = lds_for(q.ps);
+    q.p = make_plan(d, blocks_force > 0 ? blocks_force : 256 * q.minb, 128, q.ps);
+    q.p.ktile = KT; q.p.ntile = NT;
+    return q;
+}
+
+inline bool v6_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ASR_WGRAD_V6"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
+
+template <int NTAPS, int TKW, int WAVES_N, int TNW>
+bool v6_ok(const asr_gemm_desc* d, int ldz) {
+    constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32;
+    if (!v6_enabled() || d->K % KT || d->N % NT || (d->lda & 3) || (ldz & 3)) return false;
+    const Plan6 q = make_plan6<KT, NT>(d);
+    const size_t red = (size_t)(4 / WAVES_N - 1) * WAVES_N * TKW * TNW * 16 * 64 * sizeof(float);
+    return q.lds <= 160 * 1024 && red <= q.lds;
+}
+
+template <int NTAPS, int TKW, int WAVES_N, int TNW>
+int launch_wgrad6(WgradArgs a, const asr_gemm_desc* d, float* dW, float* partials, hipStream_t st, Plan* used) {
+    constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32;
+    const Plan6 q = make_plan6<KT, NT>(d);
+    *used = q.p;
+    if (q.p.nchunks > 1 && !partials) return ASR_ERR_BAD_ARG;
+    a.out = (q.p.nchunks > 1) ? partials : dW;
+    a.pch = q.p.pch;
+    const dim3 grid(q.p.nchunks, d->K / KT, d->N / NT);
+#define ASR_V6_LAUNCH(PSV, MB)                                                                                            \
+    do {                                                                                                                 \
+        auto kern = tap_wgrad_kernel_v6<NTAPS, TKW, WAVES_N, TNW, PSV, MB>;                                               \
+        static bool attr = false;                                                                                        \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL(kern, grid, dim3(256), q.lds, st, a);                                                         \
+    } while (0)
+    if (q.ps == 32 && q.minb == 2) ASR_V6_LAUNCH(32, 2);
+    else if (q.ps == 32) ASR_V6_LAUNCH(32, 1);
+    else if (q.minb == 2) ASR_V6_LAUNCH(64, 2);
+    else ASR_V6_LAUNCH(64, 1);
+#undef ASR_V6_LAUNCH
+    ASR_CHECK_LAUNCH("tap_wgrad_v6");
+    return ASR_OK;
+}
+
 }  // namespace
 
 extern "C" size_t asr_tap_wgrad_workspace(const asr_gemm_desc* d) {
     if (!d) return 0;
     const Plan p = make_plan(d), q = make_plan(d, 1024, 128);  // q: the most chunks any variant (bx6 sweeps included) asks for
-    const int nc = p.nchunks > q.nchunks ? p.nchunks : q.nchunks;
+    int nc = p.nchunks > q.nchunks ? p.nchunks : q.nchunks;
+    if (d->ntaps == 9) {                                       // the LDS-DMA variant plans its own (shorter) runs
+        const int n6 = d->N > 64 ? make_plan6<32, 128>(d).p.nchunks : d->N > 32 ? make_plan6<32, 64>(d).p.nchunks
+                                                                                 : make_plan6<32, 32>(d).p.nchunks;
+        if (n6 > nc) nc = n6;
+    }
     if (nc <= 1) return 16;
     return (size_t)nc * d->ntaps * d->K * d->N * sizeof(float);
 }
@@ -797,6 +1046,21 @@ extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float
     a.slab = (long)d->ntaps * d->K * d->N;
     hipStream_t st = (hipStream_t)stream;
     int rc;
+    Plan p6 = p;
+    bool is6 = true;
+    if (d->ntaps == 9 && d->N > 64 && v6_ok<9, 1, 4, 1>(d, ldz)) rc = launch_wgrad6<9, 1, 4, 1>(a, d, dW, partials, st, &p6);
+    else if (d->ntaps == 9 && d->N > 32 && d->N <= 64 && v6_ok<9, 1, 2, 1>(d, ldz)) rc = launch_wgrad6<9, 1, 2, 1>(a, d, dW, partials, st, &p6);
+    else if (d->ntaps == 9 && d->N <= 32 && v6_ok<9, 1, 1, 1>(d, ldz)) rc = launch_wgrad6<9, 1, 1, 1>(a, d, dW, partials, st, &p6);
+    else is6 = false;
+    if (is6) {
+        if (rc != ASR_OK) return rc;
+        if (p6.nchunks > 1) {
+            const long n = a.slab;
+            hipLaunchKernelGGL(sum_chunks_kernel, dim3(asr_cdiv(asr_cdiv(n, 4), 64)), dim3(64), 0, st, partials, dW, n, p6.nchunks);
+            ASR_CHECK_LAUNCH("sum_chunks");
+        }
+        return ASR_OK;
+    }
     if (d->ntaps == 9) {
         if (d->N > 64) rc = launch_wgrad<9, 1, 4, 1, 64>(a, p, d->K, d->N, st);
         else if (d->N > 32) rc = launch_wgrad<9, 1, 2, 1, 64>(a, p, d->K, d->N, st);
