@@ -10,6 +10,18 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 #define ASR_WAVE 64
 
 void asr_set_error(const char* what, hipError_t e);
+// name of the contraction kernel instantiation a launcher has just enqueued (asr_last_kernel(), include/asr_hip.h)
+void asr_set_last_kernel(const char* name);
+
+#include <stdio.h>
+// one formatted name per launcher instantiation (built on first use), then a pointer store per launch
+#define ASR_NOTE_KERNEL(...)                                            \
+    do {                                                                \
+        static char nm__[160];                                          \
+        static bool done__ = false;                                     \
+        if (!done__) { snprintf(nm__, sizeof(nm__), __VA_ARGS__); done__ = true; } \
+        asr_set_last_kernel(nm__);                                      \
+    } while (0)
 
 #define ASR_CHECK_LAUNCH(name)                                   \
     do {                                                         \

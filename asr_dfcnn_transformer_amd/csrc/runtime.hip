@@ -8,5 +8,10 @@ void asr_set_error(const char* what, hipError_t e) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
 }
 
-extern "C" int asr_version(void) { return 100; }
+static thread_local const char* g_last_kernel = "";
+
+void asr_set_last_kernel(const char* name) { g_last_kernel = name; }
+
+extern "C" int asr_version(void) { return 101; }
+extern "C" const char* asr_last_kernel(void) { return g_last_kernel; }
 extern "C" const char* asr_last_error(void) { return g_err; }

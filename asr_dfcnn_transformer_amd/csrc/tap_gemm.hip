@@ -640,6 +640,7 @@ int launch_v5d(const TapGemmArgs& a, const float* Wf, hipStream_t st) {
     p.g.ntn = asr_cdiv(a.N, NT);
     hipLaunchKernelGGL(kern, dim3(p.g.ntm * p.g.ntn), dim3(256), lds, st, p);
     ASR_CHECK_LAUNCH("tap_gemm_pw");
+    ASR_NOTE_KERNEL("tap_gemm_kernel_v5<%d, %d, %d, %d, %d, %d, %d, %d, %d>", MT, NT, WM, WN, NTAPS, KCV, D, MINB, DIR);
     return ASR_OK;
 }
 
@@ -942,6 +943,7 @@ int launch_bx6(const TapGemmArgs& a, const __bf16* Ws, int Kp, hipStream_t st) {
     b.g.ntn = asr_cdiv(a.N, NT);
     hipLaunchKernelGGL(kern, dim3(b.g.ntm * b.g.ntn), dim3(256), lds, st, b);
     ASR_CHECK_LAUNCH("tap_gemm_bx6");
+    ASR_NOTE_KERNEL("tap_gemm_kernel_bx6<%d, %d, %d, %d, %d, %d, %d, %d>", MT, NT, WM, WN, NTAPS, D, KCV, MINB);
     return ASR_OK;
 }
 
@@ -976,6 +978,7 @@ int launch_v1(const TapGemmArgs& a, hipStream_t st) {
     g.ntn = asr_cdiv(a.N, NT);
     hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn), dim3(256), lds, st, g);
     ASR_CHECK_LAUNCH("tap_gemm");
+    ASR_NOTE_KERNEL("tap_gemm_kernel_v1<%d, %d, %d, %d, %d, %d, %d>", MT, NT, WM, WN, NTAPS, WMODE, KCV);
     return ASR_OK;
 }
 
@@ -997,6 +1000,7 @@ int launch_v2(const TapGemmArgs& a, hipStream_t st) {
     g.ntn = asr_cdiv(a.N, NT);
     hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn), dim3(256), lds, st, g);
     ASR_CHECK_LAUNCH("tap_gemm");
+    ASR_NOTE_KERNEL("tap_gemm_kernel<%d, %d, %d, %d, %d, %d>", MT, NT, WM, WN, NTAPS, WMODE);
     return ASR_OK;
 }
 

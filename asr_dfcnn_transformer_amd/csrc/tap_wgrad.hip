@@ -736,15 +736,19 @@ __global__ __launch_bounds__(256, MINB) void tap_wgrad_kernel_v6(WgradArgs g) {
     const int zrow_l = lane / (NT / 4), zc4 = lane % (NT / 4);
 
     auto stage_dma = [&](long ps0, float* buf) {
+        // channels past K / N (ragged last tile) are not fetched: their LDS words keep whatever they held and only feed
+        // accumulators of weight rows / columns that are never stored
         const float* asrc = g.A + (ps0 - halo + arow_l) * (long)g.lda + k0 + ac4 * 4;
+        const bool aok = k0 + ac4 * 4 < g.K, zok = n0 + zc4 * 4 < g.N;
         for (int p = wave; p < apieces; p += 4)
-            if (p * 64 + lane < atotal)
+            if (aok && p * 64 + lane < atotal)
                 __builtin_amdgcn_global_load_lds((wg_glb_f*)(asrc + (long)p * ARP * g.lda), (wg_lds_f*)(buf + p * 256), 16, 0, 0);
         const float* zsrc = g.Z + (ps0 + zrow_l) * (long)g.ldz + n0 + zc4 * 4;
         float* zb = buf + asz;
 #pragma unroll
         for (int p = wave; p < zpieces; p += 4)
-            __builtin_amdgcn_global_load_lds((wg_glb_f*)(zsrc + (long)p * ZRP * g.ldz), (wg_lds_f*)(zb + p * 256), 16, 0, 0);
+            if (zok)
+                __builtin_amdgcn_global_load_lds((wg_glb_f*)(zsrc + (long)p * ZRP * g.ldz), (wg_lds_f*)(zb + p * 256), 16, 0, 0);
     };
     auto stage_masked = [&](long ps0, float* buf) {     // ragged last run: rows past the end read as zero
         float* Zs = buf + asz;
@@ -752,14 +756,14 @@ __global__ __launch_bounds__(256, MINB) void tap_wgrad_kernel_v6(WgradArgs g) {
             const int row = f / (KT / 4), c4 = f - row * (KT / 4);
             const long grow = ps0 - halo + row;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (grow >= g.rmin && grow < g.rmax) v = *(const float4*)(g.A + grow * g.lda + k0 + c4 * 4);
+            if (grow >= g.rmin && grow < g.rmax && k0 + c4 * 4 < g.K) v = *(const float4*)(g.A + grow * g.lda + k0 + c4 * 4);
             *(float4*)(buf + row * KT + c4 * 4) = v;
         }
         for (int f = tid; f < PS * (NT / 4); f += 256) {
             const int row = f / (NT / 4), n4 = f - row * (NT / 4);
             const long grow = ps0 + row;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (grow < cend) v = *(const float4*)(g.Z + grow * g.ldz + n0 + n4 * 4);
+            if (grow < cend && n0 + n4 * 4 < g.N) v = *(const float4*)(g.Z + grow * g.ldz + n0 + n4 * 4);
             *(float4*)(Zs + row * NT + n4 * 4) = v;
         }
     };
@@ -857,10 +861,11 @@ __global__ __launch_bounds__(256, MINB) void tap_wgrad_kernel_v6(WgradArgs g) {
 #pragma unroll
             for (int b = 0; b < TNW; ++b) {
                 const int n = n0 + (wn * TNW + b) * 32 + li;
+                if (n >= g.N) continue;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int k = k0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    out[((long)t * g.K + k) * g.N + n] = acc[t][a][b][r];
+                    if (k < g.K) out[((long)t * g.K + k) * g.N + n] = acc[t][a][b][r];
                 }
             }
 }
@@ -945,6 +950,9 @@ int launch_wgrad(const WgradArgs& a, const Plan& p, int K, int N, hipStream_t st
     }
     hipLaunchKernelGGL(kern, dim3(p.nchunks, asr_cdiv(K, KT), asr_cdiv(N, NT)), dim3(256), lds, st, a);
     ASR_CHECK_LAUNCH("tap_wgrad");
+    if (variant == 1) ASR_NOTE_KERNEL("tap_wgrad_kernel_v1<%d, %d, %d, %d, %d>", NTAPS, TKW, WAVES_N, TNW, PS);
+    else if (variant == 3) ASR_NOTE_KERNEL("tap_wgrad_kernel_v3<%d, %d, %d, %d, %d>", NTAPS, TKW, WAVES_N, TNW, PS3);
+    else ASR_NOTE_KERNEL("tap_wgrad_kernel<%d, %d, %d, %d, %d>", NTAPS, TKW, WAVES_N, TNW, PS);
     return ASR_OK;
 }
 
@@ -962,10 +970,16 @@ Plan6 make_plan6(const asr_gemm_desc* d) {
     const int halo = (d->ntaps != 1) ? d->W + 2 : 0;
     auto lds_for = [&](int ps) { return (size_t)2 * ((((size_t)(ps + 2 * halo) * KT + 255) & ~(size_t)255) + (size_t)ps * NT) * sizeof(float); };
     Plan6 q;
-    if (ps_force == 32 || ps_force == 64) { q.ps = ps_force; q.minb = (2 * lds_for(q.ps) <= 160 * 1024) ? 2 : 1; }
-    else if (2 * lds_for(32) <= 160 * 1024) { q.ps = 32; q.minb = 2; }
-    else if (lds_for(64) <= 160 * 1024) { q.ps = 64; q.minb = 1; }
-    else { q.ps = 32; q.minb = 1; }
+    auto fits = [&](int ps) { return lds_for(ps) <= 160 * 1024; };
+    // measured on the DFCNN layers (tools/bench_layers.py wgrad, gpurun_out/r02b): with >= 128 output channels the dZ image
+    // dominates and 32-pixel runs at two workgroups per CU win (126-131 TFLOP/s); with <= 64 the A image and its halo (two
+    // plane rows: 2 x (W + 2) pixels re-staged per run) dominate, so longer runs: 64 pixels, or 128 on planes wider than 64
+    // (800x100: 88 / 114 TFLOP/s at N = 32 / 64 against 78 / 103 with 32-pixel runs)
+    int ps = (d->ntaps == 1 || NT > 64) ? 32 : (d->W > 64 ? 128 : 64);
+    if (ps_force == 32 || ps_force == 64 || ps_force == 128) ps = ps_force;
+    while (ps > 32 && !fits(ps)) ps >>= 1;
+    q.ps = ps;
+    q.minb = (2 * lds_for(ps) <= 160 * 1024) ? 2 : 1;
     q.lds = lds_for(q.ps);
     q.p = make_plan(d, blocks_force > 0 ? blocks_force : 256 * q.minb, 128, q.ps);
     q.p.ktile = KT; q.p.ntile = NT;
@@ -978,10 +992,16 @@ inline bool v6_enabled() {
     return on != 0;
 }
 
+inline bool v6_dense_enabled() {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ASR_WGRAD_V6_DENSE"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
+
 template <int NTAPS, int TKW, int WAVES_N, int TNW>
 bool v6_ok(const asr_gemm_desc* d, int ldz) {
     constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32;
-    if (!v6_enabled() || d->K % KT || d->N % NT || (d->lda & 3) || (ldz & 3)) return false;
+    if (!v6_enabled() || (d->K & 3) || (d->N & 3) || (d->lda & 3) || (ldz & 3)) return false;
     const Plan6 q = make_plan6<KT, NT>(d);
     const size_t red = (size_t)(4 / WAVES_N - 1) * WAVES_N * TKW * TNW * 16 * 64 * sizeof(float);
     return q.lds <= 160 * 1024 && red <= q.lds;
@@ -995,15 +1015,17 @@ int launch_wgrad6(WgradArgs a, const asr_gemm_desc* d, float* dW, float* partial
     if (q.p.nchunks > 1 && !partials) return ASR_ERR_BAD_ARG;
     a.out = (q.p.nchunks > 1) ? partials : dW;
     a.pch = q.p.pch;
-    const dim3 grid(q.p.nchunks, d->K / KT, d->N / NT);
+    const dim3 grid(q.p.nchunks, asr_cdiv(d->K, KT), asr_cdiv(d->N, NT));
 #define ASR_V6_LAUNCH(PSV, MB)                                                                                            \
     do {                                                                                                                 \
         auto kern = tap_wgrad_kernel_v6<NTAPS, TKW, WAVES_N, TNW, PSV, MB>;                                               \
         static bool attr = false;                                                                                        \
         if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
         hipLaunchKernelGGL(kern, grid, dim3(256), q.lds, st, a);                                                         \
+        ASR_NOTE_KERNEL("tap_wgrad_kernel_v6<%d, %d, %d, %d, %d, %d>", NTAPS, TKW, WAVES_N, TNW, PSV, MB);                \
     } while (0)
-    if (q.ps == 32 && q.minb == 2) ASR_V6_LAUNCH(32, 2);
+    if (q.ps == 128) { if (q.minb == 2) ASR_V6_LAUNCH(128, 2); else ASR_V6_LAUNCH(128, 1); }
+    else if (q.ps == 32 && q.minb == 2) ASR_V6_LAUNCH(32, 2);
     else if (q.ps == 32) ASR_V6_LAUNCH(32, 1);
     else if (q.minb == 2) ASR_V6_LAUNCH(64, 2);
     else ASR_V6_LAUNCH(64, 1);
@@ -1021,6 +1043,9 @@ extern "C" size_t asr_tap_wgrad_workspace(const asr_gemm_desc* d) {
     if (d->ntaps == 9) {                                       // the LDS-DMA variant plans its own (shorter) runs
         const int n6 = d->N > 64 ? make_plan6<32, 128>(d).p.nchunks : d->N > 32 ? make_plan6<32, 64>(d).p.nchunks
                                                                                  : make_plan6<32, 32>(d).p.nchunks;
+        if (n6 > nc) nc = n6;
+    } else if (d->ntaps == 1) {
+        const int n6 = make_plan6<128, 128>(d).p.nchunks;
         if (n6 > nc) nc = n6;
     }
     if (nc <= 1) return 16;
@@ -1051,6 +1076,7 @@ extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float
     if (d->ntaps == 9 && d->N > 64 && v6_ok<9, 1, 4, 1>(d, ldz)) rc = launch_wgrad6<9, 1, 4, 1>(a, d, dW, partials, st, &p6);
     else if (d->ntaps == 9 && d->N > 32 && d->N <= 64 && v6_ok<9, 1, 2, 1>(d, ldz)) rc = launch_wgrad6<9, 1, 2, 1>(a, d, dW, partials, st, &p6);
     else if (d->ntaps == 9 && d->N <= 32 && v6_ok<9, 1, 1, 1>(d, ldz)) rc = launch_wgrad6<9, 1, 1, 1>(a, d, dW, partials, st, &p6);
+    else if (d->ntaps == 1 && v6_dense_enabled() && (long)asr_cdiv(d->K, 128) * asr_cdiv(d->N, 128) >= 4 && v6_ok<1, 4, 4, 1>(d, ldz)) rc = launch_wgrad6<1, 4, 4, 1>(a, d, dW, partials, st, &p6);
     else is6 = false;
     if (is6) {
         if (rc != ASR_OK) return rc;
@@ -1124,8 +1150,8 @@ extern "C" int asr_tap_wgrad_bx6(const asr_gemm_desc* d, const float* A, const f
         (void)hipFuncSetAttribute((const void*)tap_wgrad_kernel_bx6<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    if (PSsel == 64) hipLaunchKernelGGL(tap_wgrad_kernel_bx6<64>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(tap_wgrad_kernel_bx6<48>, grid, dim3(256), lds, st, a);
+    if (PSsel == 64) { hipLaunchKernelGGL(tap_wgrad_kernel_bx6<64>, grid, dim3(256), lds, st, a); ASR_NOTE_KERNEL("tap_wgrad_kernel_bx6<64>"); }
+    else { hipLaunchKernelGGL(tap_wgrad_kernel_bx6<48>, grid, dim3(256), lds, st, a); ASR_NOTE_KERNEL("tap_wgrad_kernel_bx6<48>"); }
     ASR_CHECK_LAUNCH("tap_wgrad_bx6");
     if (p.nchunks > 1) {
         const long n = a.slab;

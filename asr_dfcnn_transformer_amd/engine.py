@@ -331,6 +331,13 @@ class DFCNNEngine:
         # HBM-bound prologues hide under MFMA work (+6 % M1, +8 % M2 at B = 32).  Per-kernel durations of the
         # overlapped kernels then overlap in any profile.  Results are bitwise the same as with one stream.
         self.side = torch.cuda.Stream(device=dev) if os.environ.get('ASR_DUAL_STREAM', '1') == '1' else None
+        self.wgrad_first = os.environ.get('ASR_WGRAD_FIRST', '0') == '1'
+        # measured (gpurun_out/r02b/bench6.txt): +1.6 % on the SE graphs (whose backward has more HBM-bound kernels between the
+        # contractions: SE backward, two prologues per block), -1 % on the plain chain of acoustic_model.py
+        has_se = any(op[0] == 'se' for op in self.g)
+        self.wgrad_after_dgrad = os.environ.get('ASR_WGRAD_AFTER_DGRAD', '1' if has_se else '0') == '1'
+        if os.environ.get('ASR_SIDE_PRIO'):              # experiment: explicit priority of the side stream
+            self.side = torch.cuda.Stream(device=dev, priority=int(os.environ['ASR_SIDE_PRIO']))
         self.ws_side = torch.zeros_like(self.ws) if self.side is not None else None
         # with the side stream every geometry gets a second dZ plane, used alternately, so the next cell's (HBM-bound)
         # backward prologue can run while the previous weight-gradient (MFMA-bound) still reads the other one
@@ -600,17 +607,25 @@ class DFCNNEngine:
                                  self.gview(dst, 'beta'), self.gview(dst, 'b'), self.ws)
                 # split-bf16 weight gradient where it wins (tools/bench_bx6.py): narrow planes (small halo) and >= 128 outputs
                 wgrad = ops.tap_wgrad_bx6 if (self.bx6 and k == 3 and cout >= 128 and W <= 64) else ops.tap_wgrad
-                if self.side is None:
-                    wgrad(self.wdesc[dst], self.y[src], dz, cout, self.gview(dst, 'w'), self.ws)
-                else:
-                    dz_ready = torch.cuda.Event()
-                    dz_ready.record()
+                def run_wgrad():
+                    nonlocal side_busy
+                    if self.side is None:
+                        wgrad(self.wdesc[dst], self.y[src], dz, cout, self.gview(dst, 'w'), self.ws)
+                        return
                     self.side.wait_event(dz_ready)
                     with torch.cuda.stream(self.side):
                         wgrad(self.wdesc[dst], self.y[src], dz, cout, self.gview(dst, 'w'), self.ws_side)
                         side_busy = torch.cuda.Event()
                         side_busy.record()
                         dz_reader[id(dz)] = side_busy
+                if self.side is not None:
+                    dz_ready = torch.cuda.Event()
+                    dz_ready.record()
+                # The data-gradient is on the critical path (the next cell's prologue waits for it); the weight-gradient
+                # is needed only at the end of backward.  With ASR_WGRAD_FIRST=0 (default) the data-gradient is enqueued
+                # first, so that its workgroups are not locked out by the weight-gradient's one-round grid.
+                if self.wgrad_first:
+                    run_wgrad()
                 dx, acc = grad_target(src)
                 d = self.bdesc[dst]
                 d.accumulate = 1 if acc else 0
@@ -620,6 +635,14 @@ class DFCNNEngine:
                     ops.tap_gemm_pw(d, dz, self.wf_b[dst], None, None, None, None, dx)
                 else:
                     ops.tap_gemm(d, dz, self.p(dst, 'w'), None, None, None, None, dx)
+                if not self.wgrad_first:
+                    if self.side is not None and self.wgrad_after_dgrad:
+                        # the side stream starts this weight-gradient only when the data-gradient has FINISHED: two MFMA-bound
+                        # kernels that start together also end together and leave the next HBM-bound prologue alone on the
+                        # chip; started late, the weight-gradient runs beside that prologue instead
+                        dz_ready = torch.cuda.Event()
+                        dz_ready.record()
+                    run_wgrad()
         if side_busy is not None:
             torch.cuda.current_stream().wait_event(side_busy)
         if self._decode_done is not None:

@@ -76,49 +76,10 @@ class KernelTimer:
 TIMER = None
 
 
-def kernel_symbol(family, ntaps, wmode, M, K, N):
-    """The kernel instantiation libasrhip launches for a descriptor (mirrors launch_n / launch_wgrad in
-    csrc/tap_gemm.hip and csrc/tap_wgrad.hip), as rocprofv3 --stats prints it."""
-    if family == 'tap_wgrad':
-        if ntaps == 1:
-            return 'tap_wgrad_kernel_v3<1, 4, 4, 1, 32>'
-        if ntaps == 4:
-            return 'tap_wgrad_kernel_v1<4, 1, %d, 1, %d>' % ((4, 64) if N > 64 else (2, 64) if N > 32 else (1, 128))
-        if N > 64:
-            return 'tap_wgrad_kernel_v1<9, 1, 4, 1, 64>'
-        if N > 32:
-            return 'tap_wgrad_kernel<9, 1, 2, 1, 64>' if K >= 64 else 'tap_wgrad_kernel_v1<9, 1, 2, 1, 64>'
-        return 'tap_wgrad_kernel_v1<9, 1, 1, 1, 128>'
-    if ntaps == 4:
-        cfg = '128, 64, 2, 2' if N > 32 else '256, 32, 4, 1'
-        return 'tap_gemm_kernel_v1<%s, 4, %d, 32>' % (cfg, wmode)
-    v2 = ntaps == 9 and wmode == 1 and N <= 64 and (N > 32 or K >= 64)
-    t128 = -(-M // 128) * -(-N // 128)
-    if ntaps == 1 and N > 32 and t128 < 160:
-        cfg, kc = '64, 64, 2, 2', 32
-    elif ntaps == 1 and wmode == 0 and N > 64 and t128 <= 768:
-        cfg, kc = '128, 64, 2, 2', 32
-    elif ntaps == 1 and wmode == 0 and N > 64 and t128 <= 1024:
-        cfg, kc = '128, 128, 2, 2', 16
-    elif ntaps == 1 and wmode == 1 and N > 64 and t128 <= 512:
-        cfg, kc = '128, 64, 2, 2', 32
-    elif ntaps == 9 and 32 < N <= 64:
-        cfg, kc, v2 = '128, 64, 2, 2', 16, False
-    elif ntaps == 9 and 64 < N <= 128:
-        cfg, kc, v2 = '128, 64, 2, 2', (32 if K >= 128 else 16), False
-    elif N > 64:
-        cfg, kc = '128, 128, 2, 2', 32
-    elif N > 32:
-        cfg, kc = '256, 64, 4, 1', 32
-    else:
-        cfg, kc = '256, 32, 4, 1', 32
-    if v2:
-        return 'tap_gemm_kernel<%s, %d, %d>' % (cfg, ntaps, wmode)
-    return 'tap_gemm_kernel_v1<%s, %d, %d, %d>' % (cfg, ntaps, wmode, kc)
-
-
-def _key(family, d):
-    return kernel_symbol(family, d.ntaps, d.wmode, d.M, d.K, d.N)
+def last_kernel():
+    """Symbol of the contraction kernel the library launched in this thread's last tap_gemm / tap_wgrad call
+    (asr_last_kernel, include/asr_hip.h) -- the launcher's own dispatch decision, spelled as in a rocprofv3 trace."""
+    return _lib.load().asr_last_kernel().decode()
 
 
 def _flops(d):
@@ -126,18 +87,19 @@ def _flops(d):
     return 2.0 * rows * d.K * d.N * d.ntaps
 
 
-def _timed(family, d, fn):
+def _timed(d, fn, tag=''):
+    """Runs fn(); with a KernelTimer installed, brackets it with HIP events on the launch stream and files the pair
+    under the kernel symbol the library reports (+ ``tag``, for kernels that serve two directions under one symbol)."""
     t = TIMER
     if t is None:
-        return fn()
-    key = _key(family, d)
-    if not t.want(key):
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     fn()
     e1.record()
-    t.add(key, _flops(d), e0, e1)
+    key = last_kernel() + tag
+    if t.want(key):
+        t.add(key, _flops(d), e0, e1)
 
 
 def gemm_desc(M, K, N, lda, ldw, ldo_a=0, ldo_y=0, ntaps=1, B=0, H=0, W=0, wmode=0, relu=0,
@@ -150,7 +112,7 @@ def tap_gemm(desc, A, W, bias=None, scale=None, shift=None, out_a=None, out_y=No
     pa = A.ptr if isinstance(A, Plane) else _ptr(A)
     po_a = out_a.ptr if isinstance(out_a, Plane) else _ptr(out_a)
     po_y = out_y.ptr if isinstance(out_y, Plane) else _ptr(out_y)
-    _timed('tap_gemm', desc, lambda: check(
+    _timed(desc, lambda: check(
         lib.asr_tap_gemm(C.byref(desc), pa, _ptr(W), _ptr(bias), _ptr(scale), _ptr(shift), po_a, po_y, _stream()),
         'asr_tap_gemm'))
 
@@ -163,7 +125,7 @@ def tap_wgrad(desc, A, dZ, ldz, dW, partials):
     lib = _lib.load()
     pa = A.ptr if isinstance(A, Plane) else _ptr(A)
     pz = dZ.ptr if isinstance(dZ, Plane) else _ptr(dZ)
-    _timed('tap_wgrad', desc, lambda: check(
+    _timed(desc, lambda: check(
         lib.asr_tap_wgrad(C.byref(desc), pa, pz, ldz, _ptr(dW), _ptr(partials), _stream()), 'asr_tap_wgrad'))
 
 
@@ -483,31 +445,17 @@ def tap_gemm_bx6(desc, A, Wsplit, bias=None, scale=None, shift=None, out_a=None,
     pa = A.ptr if isinstance(A, Plane) else _ptr(A)
     po_a = out_a.ptr if isinstance(out_a, Plane) else _ptr(out_a)
     po_y = out_y.ptr if isinstance(out_y, Plane) else _ptr(out_y)
-    t = TIMER
-    call = lambda: check(lib.asr_tap_gemm_bx6(C.byref(desc), pa, _ptr(Wsplit), _ptr(bias), _ptr(scale), _ptr(shift), po_a, po_y,
-                                              _stream()), 'asr_tap_gemm_bx6')
-    key = bx6_symbol(desc.ntaps, desc.N) + (' [dgrad]' if dgrad else '')      # one symbol serves both directions
-    if t is None or not t.want(key):
-        return call()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    call()
-    e1.record()
-    t.add(key, _flops(desc), e0, e1)
-
-
-def bx6_symbol(ntaps, N):
-    """kernel instantiation asr_tap_gemm_bx6 launches (mirrors the rules in csrc/tap_gemm.hip)"""
-    if ntaps == 9:
-        return 'tap_gemm_kernel_bx6<256, 64, 2, 2, 9, 3, 16, 2>' if N > 32 else 'tap_gemm_kernel_bx6<256, 32, 4, 1, 9, 3, 16, 3>'
-    return 'tap_gemm_kernel_bx6<256, 64, 2, 2, 1, 2, 32, 2>' if N > 32 else 'tap_gemm_kernel_bx6<256, 32, 4, 1, 1, 2, 32, 3>'
+    _timed(desc, lambda: check(lib.asr_tap_gemm_bx6(C.byref(desc), pa, _ptr(Wsplit), _ptr(bias), _ptr(scale), _ptr(shift), po_a,
+                                                    po_y, _stream()), 'asr_tap_gemm_bx6'),
+           tag=' [dgrad]' if dgrad else '')              # one symbol serves both directions
 
 
 def tap_wgrad_bx6(desc, A, dZ, ldz, dW, partials):
     lib = _lib.load()
     pa = A.ptr if isinstance(A, Plane) else _ptr(A)
     pz = dZ.ptr if isinstance(dZ, Plane) else _ptr(dZ)
-    check(lib.asr_tap_wgrad_bx6(C.byref(desc), pa, pz, ldz, _ptr(dW), _ptr(partials), _stream()), 'asr_tap_wgrad_bx6')
+    _timed(desc, lambda: check(lib.asr_tap_wgrad_bx6(C.byref(desc), pa, pz, ldz, _ptr(dW), _ptr(partials), _stream()),
+                               'asr_tap_wgrad_bx6'))
 
 
 def split_rows(X, M, K, ldx, out=None):
@@ -535,30 +483,11 @@ def arrange_weights(W, ntaps, K, N, ldw, wmode=0, out=None):
     return out
 
 
-def pw_symbol(ntaps, wmode, K, N):
-    """kernel instantiation asr_tap_gemm_pw launches (mirrors the rules in csrc/tap_gemm.hip), as rocprofv3 prints it"""
-    d = 1 if wmode else 0
-    if ntaps == 9:
-        return 'tap_gemm_kernel_v5<%s, 9, 16, 3, 3, %d>' % ('128, 64, 2, 2' if N > 32 else '256, 32, 4, 1', d)
-    if N > 64:
-        return 'tap_gemm_kernel_v5<128, 128, 2, 2, 1, 32, 4, 2, %d>' % d
-    return 'tap_gemm_kernel_v5<%s, 1, 32, 4, 3, %d>' % ('128, 64, 2, 2' if N > 32 else '256, 32, 4, 1', d)
-
-
 def tap_gemm_pw(desc, A, Wf, bias=None, scale=None, shift=None, out_a=None, out_y=None):
     """asr_tap_gemm on pre-arranged weights; desc.wmode only labels the launch (forward / data-gradient symbol)."""
     lib = _lib.load()
     pa = A.ptr if isinstance(A, Plane) else _ptr(A)
     po_a = out_a.ptr if isinstance(out_a, Plane) else _ptr(out_a)
     po_y = out_y.ptr if isinstance(out_y, Plane) else _ptr(out_y)
-    call = lambda: check(lib.asr_tap_gemm_pw(C.byref(desc), pa, _ptr(Wf), _ptr(bias), _ptr(scale), _ptr(shift), po_a, po_y,
-                                             _stream()), 'asr_tap_gemm_pw')
-    t = TIMER
-    key = pw_symbol(desc.ntaps, desc.wmode, desc.K, desc.N)
-    if t is None or not t.want(key):
-        return call()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    call()
-    e1.record()
-    t.add(key, _flops(desc), e0, e1)
+    _timed(desc, lambda: check(lib.asr_tap_gemm_pw(C.byref(desc), pa, _ptr(Wf), _ptr(bias), _ptr(scale), _ptr(shift), po_a, po_y,
+                                                   _stream()), 'asr_tap_gemm_pw'))

@@ -28,7 +28,7 @@ FP32_PEAK_TFLOPS = 157.3        # MI355X dense fp32 (vector = matrix), MI355X_MI
 
 
 def kernel_name(key):
-    """KernelTimer keys are the kernel symbols themselves (ops.kernel_symbol)."""
+    """KernelTimer keys are the kernel symbols themselves, as libasrhip reports them (asr_last_kernel)."""
     return key
 
 

@@ -41,6 +41,12 @@ typedef enum {
 } asr_status;
 
 int asr_version(void);
+/* Name of the contraction kernel instantiation the calling thread's last asr_tap_gemm / asr_tap_gemm_pw /
+ * asr_tap_gemm_bx6 / asr_tap_wgrad / asr_tap_wgrad_bx6 call enqueued, spelled as rocprofv3 --kernel-trace prints it
+ * without the namespace (e.g. "tap_gemm_kernel_v5<128, 64, 2, 2, 9, 16, 3, 3, 0>"); "" before the first such call.
+ * bench.py keys its HIP-event timings by it, so that `roofline.kernel` always names the row of the rocprof summary
+ * the launcher's dispatch rules really picked.  The pointer stays valid for the life of the library. */
+const char* asr_last_kernel(void);
 /* Last HIP error string seen by the library on this thread (host pointer, static). */
 const char* asr_last_error(void);
 
