@@ -112,10 +112,18 @@ def num_frames(nsamples, frame_len=400, frame_step=160):
 
 
 def build_LFR_features(inputs, m, n):
-    """util/utils.py:7-31 (stack m frames, hop n, tail padded with the last frame)."""
+    """util/utils.py:7-31, restated rule by rule (docstring :9-13): output frame i stacks the m input frames that start
+    at i*n; T_lfr = ceil(T / n) frames; a frame that runs past the end is completed with copies of the LAST input frame
+    (:25-29).  m = n = 1 returns the input; m = 1 skips; n = 1 stacks.  Written as explicit loops on purpose: the product
+    (asr_dfcnn_transformer_amd.utils.build_LFR_features and the device kernel asr_lfr) gathers by a clamped index, and the
+    two are compared in tests/test_oracle_cpu.py next to a hand-written fixture."""
     inputs = np.asarray(inputs)
     T, D = inputs.shape
-    T_lfr = -(-T // n)
-    # frame i stacks rows i*n .. i*n+m-1; rows past the end repeat row T-1
-    rows = np.minimum(np.arange(T_lfr)[:, None] * n + np.arange(m)[None, :], T - 1)
-    return inputs[rows].reshape(T_lfr, m * D)
+    T_lfr = (T + n - 1) // n
+    out = np.empty((T_lfr, m * D), dtype=inputs.dtype)
+    for i in range(T_lfr):
+        for j in range(m):
+            t = i * n + j
+            src = inputs[t] if t < T else inputs[T - 1]
+            out[i, j * D:(j + 1) * D] = src
+    return out

@@ -299,14 +299,22 @@ def lm_step(P, x, y, heads, blocks, want_grads=True, drop=None):
 
 
 # ----------------------------------------------------------------- end2end enc-dec (model.py:267-370)
-def init_e2e(din, vout, C, heads, blocks, pos_max, seed=0, perturb=False, tie=True):
+def init_e2e(din, vout, C, heads, blocks, pos_max, seed=0, perturb=False, tie=True, vin=None):
+    """``vin``: the encoder input is a sequence of ids (BASELINE.json configs[3], pinyin -> hanzi) looked up in an
+    embedding table with the language model's input convention (language_model.py:28: zero_pad, scale by sqrt(C),
+    transformer.py:47-53) instead of the dense(relu) + LayerNorm of embedding_input over pre-net features."""
     rng = np.random.default_rng(seed)
-    P = {'in_w': _glorot(rng, (din, C)), 'in_b': np.zeros(C), 'in_ln_g': np.ones(C), 'in_ln_b': np.zeros(C),
-         'enc_pe': _glorot(rng, (pos_max, C)), 'dec_pe': _glorot(rng, (pos_max, C)), 'dec_input': _glorot(rng, (vout, C)),
+    P = {'enc_pe': _glorot(rng, (pos_max, C)), 'dec_pe': _glorot(rng, (pos_max, C)), 'dec_input': _glorot(rng, (vout, C)),
          'out_w': _glorot(rng, (C, vout)), 'out_b': np.zeros(vout)}
+    if vin is None:
+        P.update({'in_w': _glorot(rng, (din, C)), 'in_b': np.zeros(C), 'in_ln_g': np.ones(C), 'in_ln_b': np.zeros(C)})
+    else:
+        P['enc_emb'] = _glorot(rng, (vin, C))
     if perturb:
-        P['in_b'] = 0.1 * rng.standard_normal(C); P['out_b'] = 0.1 * rng.standard_normal(vout)
-        P['in_ln_g'] = 1 + 0.1 * rng.standard_normal(C); P['in_ln_b'] = 0.1 * rng.standard_normal(C)
+        P['out_b'] = 0.1 * rng.standard_normal(vout)
+        if vin is None:
+            P['in_b'] = 0.1 * rng.standard_normal(C)
+            P['in_ln_g'] = 1 + 0.1 * rng.standard_normal(C); P['in_ln_b'] = 0.1 * rng.standard_normal(C)
     for i in range(blocks):
         P['enc%d' % i] = init_mha(rng, C, perturb)
         d = init_mha(rng, C, perturb)
@@ -324,13 +332,22 @@ def init_e2e(din, vout, C, heads, blocks, pos_max, seed=0, perturb=False, tie=Tr
 
 def e2e_step(P, x_feat, y_in, y_tgt, heads, blocks, tie=True, want_grads=True, drop=None):
     """x_feat [N,T,Din] (the flattened pre_net output fed to embedding_input), y_in/y_tgt [N,L]."""
-    N, T, Din = x_feat.shape
-    C = P['in_w'].shape[1]
+    ids_in = 'enc_emb' in P                       # x_feat is then [N,T] ids (init_e2e(vin=...))
+    if ids_in:
+        x_ids = np.asarray(x_feat)
+        N, T = x_ids.shape
+        C = P['enc_emb'].shape[1]
+    else:
+        N, T, Din = x_feat.shape
+        C = P['in_w'].shape[1]
     L = y_in.shape[1]
-    u = np.maximum(x_feat @ P['in_w'] + P['in_b'], 0)
-    iv, c_inln = layer_norm(u, P['in_ln_g'], P['in_ln_b'])
     posx = np.broadcast_to(np.arange(T)[None, :], (N, T))
-    enc = iv + embedding(P['enc_pe'], posx, False, False)
+    if ids_in:
+        enc = embedding(P['enc_emb'], x_ids, True, True) + embedding(P['enc_pe'], posx, False, False)
+    else:
+        u = np.maximum(x_feat @ P['in_w'] + P['in_b'], 0)
+        iv, c_inln = layer_norm(u, P['in_ln_g'], P['in_ln_b'])
+        enc = iv + embedding(P['enc_pe'], posx, False, False)
     posy = np.broadcast_to(np.arange(L)[None, :], (N, L))
     dec = embedding(P['dec_input'], y_in, False, False) + embedding(P['dec_pe'], posy, False, False)
     # model.py:290 drops the encoder input only (the decoder input goes into its blocks as it is, :312-329)
@@ -367,11 +384,14 @@ def e2e_step(P, x_feat, y_in, y_tgt, heads, blocks, tie=True, want_grads=True, d
     if m_enc is not None:
         de = de * m_enc
     G['enc_pe'] = embedding_bwd(P['enc_pe'].shape, posx, de, False, False)
-    du, G['in_ln_g'], G['in_ln_b'] = layer_norm_bwd(c_inln, P['in_ln_g'], de)
-    du = du * (u > 0)
-    G['in_w'] = x_feat.reshape(-1, Din).T @ du.reshape(-1, C)
-    G['in_b'] = du.reshape(-1, C).sum(axis=0)
-    out['dx_feat'] = du @ P['in_w'].T            # dL/d(x_feat): what the pre-net (oracle/prenet.py) backpropagates
+    if ids_in:
+        G['enc_emb'] = embedding_bwd(P['enc_emb'].shape, x_ids, de, True, True)
+    else:
+        du, G['in_ln_g'], G['in_ln_b'] = layer_norm_bwd(c_inln, P['in_ln_g'], de)
+        du = du * (u > 0)
+        G['in_w'] = x_feat.reshape(-1, Din).T @ du.reshape(-1, C)
+        G['in_b'] = du.reshape(-1, C).sum(axis=0)
+        out['dx_feat'] = du @ P['in_w'].T            # dL/d(x_feat): what the pre-net (oracle/prenet.py) backpropagates
     if tie:          # shared tensors receive the sum of both uses
         for i in range(blocks):
             for k in ('wq', 'wk', 'wv', 'wo'):

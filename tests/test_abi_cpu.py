@@ -43,7 +43,23 @@ def test_host_utils_match_oracle():
     from asr_dfcnn_transformer_amd import utils
     from oracle import fbank as ofb, ctc as octc
     x = np.arange(33, dtype=np.float64).reshape(11, 3)
-    assert np.array_equal(utils.build_LFR_features(x, 4, 3), ofb.build_LFR_features(x, 4, 3))
+    assert np.array_equal(utils.build_LFR_features(x, 4, 3), ofb.build_LFR_features(x, 4, 3))   # gather vs explicit loops
+    # hand-written fixture ([10, 3], (m, n) = (4, 3); util/utils.py:9-31): T_lfr = ceil(10 / 3) = 4; frame i starts at
+    # input row 3 i; frame 3 starts at row 9, the last one, and is completed with three more copies of it (:25-29)
+    r = lambda t: [3 * t, 3 * t + 1, 3 * t + 2]
+    x10 = np.arange(30, dtype=np.float32).reshape(10, 3)
+    want = np.array([r(0) + r(1) + r(2) + r(3),
+                     r(3) + r(4) + r(5) + r(6),
+                     r(6) + r(7) + r(8) + r(9),
+                     r(9) + r(9) + r(9) + r(9)], dtype=np.float32)
+    got = utils.build_LFR_features(x10, 4, 3)
+    assert got.shape == (4, 12) and got.dtype == np.float32 and np.array_equal(got, want)
+    # T = 8: frame 2 starts at row 6 and has rows 6, 7 left -> two copies of row 7 follow
+    x8 = x10[:8]
+    assert np.array_equal(utils.build_LFR_features(x8, 4, 3)[2], np.array(r(6) + r(7) + r(7) + r(7), dtype=np.float32))
+    assert np.array_equal(utils.build_LFR_features(x10, 1, 1), x10)                  # m = n = 1: identity (:10)
+    assert np.array_equal(utils.build_LFR_features(x10, 1, 3), x10[::3])             # m = 1: skipping (:11)
+    assert np.array_equal(utils.build_LFR_features(x10, 2, 1)[:9], np.hstack([x10[:-1], x10[1:]]))   # n = 1: right-stacking (:12)
     assert utils.GetEditDistance('abcd', 'abxyd') == octc.get_edit_distance_difflib('abcd', 'abxyd') == 2
     ind, val, shp = utils.sparse_tuple_from([[1, 2], [], [3]])
     assert ind.tolist() == [[0, 0], [0, 1], [2, 0]] and val.tolist() == [1, 2, 3] and shp.tolist() == [3, 2]

@@ -27,7 +27,7 @@ def _inputs(B, seed=0):
     return x, target, seq
 
 
-@pytest.mark.parametrize("model", ["m2", "m1"])
+@pytest.mark.parametrize("model", ["m2", "m1", "small"])
 def test_one_utterance_full_width_vs_float64_reference(model):
     from asr_dfcnn_transformer_amd.engine import DFCNNEngine
     x, target, seq = _inputs(1)
@@ -54,7 +54,7 @@ def test_one_utterance_full_width_vs_float64_reference(model):
     # max-pool graphs (m1): a near-tie inside a 2x2 window can pick a different arg-max in float32 than in the
     # float64 reference, which re-routes single gradient elements; the bar for its conv gradients is 5e-3
     tol = 5e-3 if model == 'm1' else 1e-3
-    for layer in ('d', g[1][2], g[-2][2]):               # head, an early conv, the last conv/dense before the head
+    for layer in P:                                       # EVERY layer of the graph
         for key in P[layer]:
             ref = tP[layer][key].grad.numpy()
             rel = np.abs(G[layer][key] - ref).max() / max(1e-12, np.abs(ref).max())
@@ -62,11 +62,12 @@ def test_one_utterance_full_width_vs_float64_reference(model):
             assert rel < tol, (layer, key, rel)
 
 
-def test_batch32_properties():
+@pytest.mark.parametrize("model,B", [("m2", 32), ("m1", 32), ("small", 4)])
+def test_batch32_properties(model, B):
+    """BASELINE configs[2] / configs[1] (batch 32) and configs[0] (DFCNN-small, batch 4) at full size."""
     from asr_dfcnn_transformer_amd.engine import DFCNNEngine
-    B = 32
     x, target, seq = _inputs(B, seed=1)
-    eng = DFCNNEngine(model='m2', vocab=V, B=B, T=T, F=F, seed=5)
+    eng = DFCNNEngine(model=model, vocab=V, B=B, T=T, F=F, seed=5)
     xd = torch.tensor(x, device='cuda')
     logits = eng.forward(xd).clone()
     eng.set_targets(seq, target)
@@ -78,7 +79,7 @@ def test_batch32_properties():
     cg = eng.ctc_grad.cpu().numpy()
     rows = cg.sum(axis=2)
     assert np.abs(rows).max() < 2e-4
-    for b in (0, 7, 31):
+    for b in (0, B // 4, B - 1):
         assert np.all(cg[seq[b]:, b, :] == 0)
     loss = eng.loss.cpu().numpy()
     assert np.all(np.isfinite(loss)) and np.all(loss > 0)
@@ -88,10 +89,25 @@ def test_batch32_properties():
     assert torch.equal(g1, eng.grad)
     # (3) utterances are independent (frozen BN, per-sample SE and CTC): utterance 5 alone gives bitwise the
     #     same logits as inside the batch of 32
-    e1 = DFCNNEngine(model='m2', vocab=V, B=1, T=T, F=F, seed=5)
-    l1 = e1.forward(xd[5:6].contiguous())
+    u = min(5, B - 1)
+    e1 = DFCNNEngine(model=model, vocab=V, B=1, T=T, F=F, seed=5)
+    l1 = e1.forward(xd[u:u + 1].contiguous())
     torch.cuda.synchronize()
-    assert torch.equal(l1[:, 0, :], logits[:, 5, :])
+    assert torch.equal(l1[:, 0, :], logits[:, u, :])
+    # (4) ... and so are their gradients: the batch gradient is the mean of the per-utterance gradients (reduce_mean,
+    #     acoustic_model2.py:83).  Checked on utterance u's CTC gradient rows (bitwise) and on the whole step for the
+    #     small model, where 4 single-utterance steps are cheap
+    e1.set_targets(seq[u:u + 1], target[u:u + 1]); e1.loss_and_decode(); e1.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(e1.ctc_grad[:, 0, :], eng.ctc_grad[:, u, :]) and torch.equal(e1.loss[0], eng.loss[u])
+    if B <= 4:
+        tot = torch.zeros_like(eng.grad, dtype=torch.float64)
+        for b in range(B):
+            e1.forward(xd[b:b + 1].contiguous()); e1.set_targets(seq[b:b + 1], target[b:b + 1]); e1.loss_and_decode(); e1.backward()
+            tot += e1.grad.double()
+        torch.cuda.synchronize()
+        diff = (tot / B - g1.double()).abs().max().item()
+        assert diff <= 1e-6 * g1.abs().max().item(), diff
 
 
 def test_fbank_full_length_batch_matches_oracle_and_is_ragged_safe():

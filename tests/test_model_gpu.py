@@ -17,6 +17,7 @@ CASES = [
     ('m2', (16, 32, 32, 64), 3, 64, 24, 20),
     ('m1', (8, 16, 32, 64, 8, 32), 2, 32, 16, 12),
     ('m3', (8, 16, 32, 64), 2, 48, 16, 12),
+    ('small', (32, 32, 32, 32), 4, 64, 24, 20),      # BASELINE configs[0]: DFCNN-small, 4 cells x 32 channels, batch 4
 ]
 
 

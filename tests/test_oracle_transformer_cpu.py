@@ -137,6 +137,44 @@ def test_e2e_step_vs_torch(tie):
     check_grads(out['grads'], tP)
 
 
+def test_e2e_step_with_id_input_vs_torch():
+    """init_e2e(vin=...) / e2e_step on ids (BASELINE configs[3], pinyin -> hanzi): encoder input = embedding with zero_pad
+    and sqrt(C) scale (language_model.py:28) + positions; checked against torch autograd, incl. the never-updated row 0."""
+    rng = np.random.default_rng(4)
+    N, T, L, C, h, blocks, Vin, Vout = 2, 7, 5, 16, 4, 2, 11, 13
+    P = otr.init_e2e(None, Vout, C, h, blocks, pos_max=9, seed=3, perturb=True, tie=True, vin=Vin)
+    assert 'enc_emb' in P and 'in_w' not in P
+    x = rng.integers(1, Vin, (N, T)); x[0, T - 2:] = 0              # padded positions: zero rows -> key-masked
+    y_in = rng.integers(1, Vout, (N, L)); y_tgt = rng.integers(1, Vout, (N, L)); y_tgt[1, L - 1] = -1
+    out = otr.e2e_step(P, x, y_in, y_tgt, h, blocks, tie=True)
+    tP, shared = {}, {}
+    for k, v in P.items():
+        if isinstance(v, dict):
+            tP[k] = {}
+            for kk, vv in v.items():
+                if id(vv) not in shared:
+                    shared[id(vv)] = t64(vv)
+                tP[k][kk] = shared[id(vv)]
+        else:
+            tP[k] = t64(v)
+    xt = torch.tensor(x)
+    emb = tP['enc_emb'][xt] * (xt != 0).unsqueeze(-1) * (C ** 0.5)
+    enc = emb + tP['enc_pe'][torch.arange(T)][None]
+    dec = tP['dec_input'][torch.tensor(y_in)] + tP['dec_pe'][torch.arange(L)][None]
+    for i in range(blocks):
+        enc = t_mha(enc, enc, tP['enc%d' % i], h, False)
+    mem = t_ffn(enc, tP['enc_ffn'])
+    for i in range(blocks):
+        dec = t_mha(dec, mem, tP['dec%d' % i], h, True)
+    logits = t_ffn(dec, tP['dec_ffn']) @ tP['out_w'] + tP['out_b']
+    loss = t_ce(logits, torch.tensor(y_tgt))
+    assert np.allclose(out['logits'], logits.detach().numpy(), atol=1e-10)
+    assert np.isclose(out['mean_loss'], loss.item(), atol=1e-12)
+    loss.backward()
+    check_grads(out['grads'], tP)
+    assert np.all(out['grads']['enc_emb'][0] == 0)                    # zero_pad: row 0 never receives gradient
+
+
 def test_all_keys_masked_row_is_uniform_and_has_no_score_gradient():
     # one head whose keys are all zero rows -> every score is the fill value -> uniform softmax
     rng = np.random.default_rng(2)
