@@ -30,6 +30,7 @@ SIGNATURES = {
     'asr_last_error': (C.c_char_p, []),
     'asr_last_kernel': (C.c_char_p, []),
     'asr_fbank': (_I, [_P, _P, _I, _I, _I, _I, _I, _D, _I, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P]),
+    'asr_lfr': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'asr_tap_gemm': (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_split_weights_bytes': (_Z, [_I, _I, _I]),
     'asr_split_weights': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),

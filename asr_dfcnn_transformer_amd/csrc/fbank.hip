@@ -121,7 +121,39 @@ __global__ __launch_bounds__(256) void fbank_scale_kernel(const double* __restri
     }
 }
 
+// Low-frame-rate stacking (util/utils.py:7-31): out[b][i][j*D + d] = feat[b][min(i*n + j, frames[b] - 1)][d] for
+// i < ceil(frames[b] / n), zero rows after that.  One thread per output float4; pure gather, HBM-bound.
+__global__ __launch_bounds__(256) void lfr_kernel(const float* __restrict__ feat, const int32_t* __restrict__ frames,
+                                                  int t_pad, int D, int m, int n, int t_out, float* __restrict__ out, long total4) {
+    const long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 >= total4) return;
+    const int row4 = (m * D) >> 2;
+    const long r = i4 / row4;
+    const int c = (int)(i4 - r * row4) << 2;
+    const int b = (int)(r / t_out), i = (int)(r - (long)b * t_out);
+    const int nf = frames[b];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((long)i * n < nf) {
+        const int j = c / D, d = c - j * D;
+        int t = i * n + j;
+        if (t > nf - 1) t = nf - 1;
+        v = *(const float4*)(feat + ((long)b * t_pad + t) * D + d);
+    }
+    *(float4*)(out + i4 * 4) = v;
+}
+
 }  // namespace
+
+extern "C" int asr_lfr(const float* feat, const int32_t* frames, int B, int t_pad, int D, int m, int n, int t_out,
+                       float* out, void* stream) {
+    if (!feat || !frames || !out) return ASR_ERR_BAD_ARG;
+    if (B < 1 || t_pad < 1 || D < 4 || (D & 3) || m < 1 || n < 1 || t_out < 1) return ASR_ERR_BAD_ARG;
+    const long total4 = (long)B * t_out * m * D / 4;
+    hipLaunchKernelGGL(lfr_kernel, dim3(asr_cdiv(total4, 256)), dim3(256), 0, (hipStream_t)stream, feat, frames, t_pad, D, m, n,
+                       t_out, out, total4);
+    ASR_CHECK_LAUNCH("lfr");
+    return ASR_OK;
+}
 
 extern "C" int asr_fbank(const float* signal, const int32_t* nsamples, int B, int max_samples,
                          int frame_len, int frame_step, int nfft, double preemph, int nfilt,

@@ -97,6 +97,8 @@ class DataLoader:
         self._fbank = None
 
     def pny2id(self, line):
+        # any lookup failure becomes the ValueError the callers catch (the reference's `except ValueError: raise
+        # ValueError`, data_loader.py:52-53, lets the KeyError of an unknown token escape and end the epoch)
         try:
             if isinstance(self.data, SyntheticSource):
                 return [int(t) for t in line.strip().split(' ')]
@@ -161,6 +163,59 @@ class DataLoader:
         feat, _ = self._fbank.batch(sig, ns, self.feature_max_length)
         return (feat.unsqueeze(-1), np.array(in_len), batch_label, np.array([len(p) for p in py]),
                 batch_han, np.array([len(p) for p in py]))
+
+    def get_lm_batch(self, rng=None, select=None):
+        """Batches for the language model, pinyin ids -> hanzi ids (lm_and_am/data_loader.py:164-193): every
+        lm_batch_size consecutive (or shuffled) transcripts, each row zero-padded to the longest pinyin sequence of the
+        batch; yields (input_data [B', L] , input_length [B'], label_data [B', L]).  As in the reference, input_length is the
+        CHARACTER length of the pinyin string (:190 ``len(self.pny_lst[i])``; nothing downstream reads it) and rows whose
+        tokens are not in the dictionaries are skipped (:192).  A transcript whose hanzi count differs from its pinyin count
+        would give a ragged row there (np.array of unequal lists); it is skipped here."""
+        import random
+        order = list(range(len(self.pny_lst)))
+        if self.shuffle:
+            (rng or random).shuffle(order)
+        for k in range(len(self.pny_lst) // self.lm_batch_size):
+            if select is not None and k not in select:           # another rank's batch (train.rank_batches)
+                continue
+            index_list = order[k * self.lm_batch_size:(k + 1) * self.lm_batch_size]
+            max_len = max(len(str(self.pny_lst[i]).strip().split(' ')) for i in index_list)
+            input_data, label_data, input_length = [], [], []
+            for i in index_list:
+                try:
+                    py = self.pny2id(str(self.pny_lst[i]))
+                    han = self.han2id(str(self.han_lst[i]))
+                    if len(han) != len(py):
+                        raise ValueError
+                    input_data.append(py + [0] * (max_len - len(py)))
+                    label_data.append(han + [0] * (max_len - len(han)))
+                    input_length.append(len(str(self.pny_lst[i])))
+                except ValueError:
+                    continue
+            yield (np.array(input_data, dtype=np.int32).reshape(len(input_data), max_len), np.array(input_length),
+                   np.array(label_data, dtype=np.int32).reshape(len(label_data), max_len))
+
+    def get_fbank_and_pinyin_data(self, index):
+        """One utterance for the evaluation loop (lm_and_am/data_loader.py:217-245; test.py:47): (wav [1, 1600, F, 1] device
+        tensor, data_length [1] = T // 8 + 1 -- NOT capped at 200 here, unlike data_generation :132 --, label ids, len_label).
+        Raises ValueError for more than 64 labels or more labels than CTC frames (:238-239)."""
+        import torch
+        from .wav_util import FbankExtractor, num_frames
+        if self._fbank is None:
+            self._fbank = FbankExtractor(nfilt=self.feature_dim, device=self.device)
+        signal, sr = self.read_audio(self.path_lst[index])
+        signal = np.asarray(signal, dtype=np.float32)
+        nf = num_frames(len(signal), self._fbank.frame_len, self._fbank.frame_step)
+        data_length = nf // 8 + 1
+        label = np.array(self.pny2id(str(self.pny_lst[index])))
+        if nf > self.feature_max_length:          # wav_data[0, 0:len(input_data)] = input_data cannot broadcast (:231)
+            raise ValueError
+        if len(label) > 64 or len(label) > data_length:
+            raise ValueError
+        sig = torch.from_numpy(signal).reshape(1, -1).to(self.device)
+        ns = torch.tensor([len(signal)], dtype=torch.int32, device=self.device)
+        feat, _ = self._fbank.batch(sig, ns, self.feature_max_length)
+        return feat.unsqueeze(-1), np.array([data_length]), label, len(label)
 
     def __getitem__(self, index):
         idx = self.indexes[index * self.am_batch_size:(index + 1) * self.am_batch_size]

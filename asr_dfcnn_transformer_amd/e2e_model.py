@@ -72,6 +72,13 @@ class Transformer_Model:
         raw = x.shape[2] == self.raw_dim and x.shape[2] != self.input_dim
         pre = None
         if raw:
+            if x.shape[1] % 4:
+                # the pre-net kernels take whole 4-frame groups (two stride-2 convs): zero frames are appended, as
+                # wav_padding (end2end/data_loader.py:84-99) appends them behind every shorter utterance of a batch.
+                # (For a T that is not a multiple of 4 TensorFlow's 'same' padding would put one of its pad rows in
+                # FRONT of an odd-length axis: results on such batches differ from the reference by that shift.)
+                pad = 4 - x.shape[1] % 4
+                x = torch.cat([x, torch.zeros(x.shape[0], pad, x.shape[2], dtype=x.dtype, device=x.device)], dim=1).contiguous()
             pre = self._prenet_for(x.shape[1])
             x = pre.forward(x)                          # [B, T/4, 80*64]
         elif x.shape[2] != self.input_dim:
@@ -83,12 +90,18 @@ class Transformer_Model:
         e.forward(x, y_in, np.zeros_like(y_in) if y_tgt is None else np.asarray(y_tgt), train=train)
         lr = None
         if train:
+            from .parallel import BucketedAllReduce
             e.backward()
+            red = BucketedAllReduce(e.grad, [(0, e.grad.numel())])          # data parallel: summed over ranks, Adam averages
+            red.launch(0)
             if pre is not None:
                 pre.backward(e.dx_feat)
-            lr = e.apply_adam()
+                red_pre = BucketedAllReduce(pre.grad, [(0, pre.grad.numel())])
+                red_pre.launch(0); red_pre.wait()
+            red.wait()
+            lr = e.apply_adam(red.grad_scale)
             if pre is not None:
-                pre.apply_adam(lr)                      # one AdamOptimizer over all variables (model.py:366-370)
+                pre.apply_adam(lr, red.grad_scale)      # one AdamOptimizer over all variables (model.py:366-370)
         out, sc = [], None
         for f in flist:
             if f in (self.mean_loss, self.acc):
@@ -111,8 +124,10 @@ class Transformer_Model:
 
 
 class E2EHparams:
-    """The module-level argparse defaults of end2end/model.py:15-55."""
-    batch_size, num_blocks, hidden_units, num_heads = 8, 6, 512, 8
-    position_max_length, dropout_rate, feature_dim, dimension = 600, 0.2, 80, 80
+    """The module-level argparse defaults of end2end/model.py:15-55 (the ones the path reads)."""
+    gpu_nums, mode, is_training, batch_size, epochs = 1, 'train', True, 8, 100
+    feature_max_length, dimension, shuffle, data_length, save_nums = 1600, 80, True, None, 3
+    num_blocks, hidden_units, num_heads = 6, 512, 8
+    position_max_length, dropout_rate, feature_dim = 600, 0.2, 80
+    summary_step, save_every_n, log_every_n = 200, 1000, 2
     learning_rate, dacay_step, min_learning_rate = 5e-4, 5000, 1e-6
-    is_training = True

@@ -59,7 +59,8 @@ class LmDataHparams(AmDataHparams):
 
 
 class TransDataHparams(AmDataHparams):
-    """util/hparams.py:75-91"""
+    """util/hparams.py:75-91: as AmDataHparams except that prime and stcmd default to False (:79-80)."""
+    _spec = tuple((n, (False if n in ('prime', 'stcmd') else d), t) for n, d, t in AmDataHparams._spec)
 
 
 for _c in (AmLmHparams, AmDataHparams, LmDataHparams, TransDataHparams):

@@ -38,6 +38,12 @@ class Language_Model:
     def global_step(self):
         return self.engine.global_step
 
+    def _reducer(self):
+        from .parallel import BucketedAllReduce
+        if getattr(self, '_red', None) is None or self._red.flat is not self.engine.grad:
+            self._red = BucketedAllReduce(self.engine.grad, [(0, self.engine.grad.numel())])
+        return self._red
+
     def _pad(self, a):
         e = self.engine
         a = np.asarray(a)
@@ -60,7 +66,11 @@ class Language_Model:
         lr = None
         if train:
             e.backward()
-            lr = e.apply_adam()
+            # one process per GPU: sum the flat gradient over the ranks (RCCL), Adam averages (parallel.py); every rank
+            # trains on its own batch of the same step, so the update is the mean of the per-rank mean-token losses
+            red = self._reducer()
+            red.launch(0); red.wait()
+            lr = e.apply_adam(red.grad_scale)
         out, sc = [], None
         for f in flist:
             if f in (self.mean_loss, self.acc):

@@ -247,6 +247,15 @@ def fbank(signal, nsamples, frame_len, frame_step, nfft, preemph, nfilt, fb_star
                                 _ptr(logfb), max_frames, _ptr(out), t_pad, _ptr(frames), _stream()), 'asr_fbank')
 
 
+def lfr(feat, frames, m, n, t_out, out=None):
+    """feat [B, t_pad, D] f32, frames [B] i32 (device) -> [B, t_out, m*D] stacked / skipped frames (asr_lfr)."""
+    B, t_pad, D = feat.shape
+    if out is None:
+        out = torch.empty(B, t_out, m * D, dtype=torch.float32, device=feat.device)
+    check(_lib.load().asr_lfr(_ptr(feat), _ptr(frames), B, t_pad, D, m, n, t_out, _ptr(out), _stream()), 'asr_lfr')
+    return out
+
+
 # ------------------------------------------------------------------ Transformer path
 def attention_fwd(Q, K, V, N, Tq, Tk, Cc, H, causal, O, lse, dropout_rate=0.0, seed=0, ldq=None, ldk=None):
     """ldq / ldk: row pitches of Q and of K, V when they are column blocks of a fused projection buffer (default Cc)."""

@@ -32,6 +32,17 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def all_agree(ok):
+    """True only when ``ok`` holds on every rank (one blocking MIN all-reduce of a flag; a no-op in a single process).
+    Collective: every rank must call it at the same point."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return bool(ok)
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(t.item())
+
+
 class BucketedAllReduce:
     """Sum-all-reduce of a flat gradient tensor in contiguous buckets ``ranges`` =
     [(lo, hi), ...], each launched asynchronously as soon as the caller says its range is

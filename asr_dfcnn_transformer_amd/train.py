@@ -16,7 +16,7 @@ import torch
 from .acoustic_model import CNNCTCModel
 from .data_loader import DataLoader, SyntheticSource
 from .hparams import AmLmHparams, AmDataHparams
-from .parallel import init_from_env
+from .parallel import init_from_env, all_agree
 
 
 def _engine_of(obj):
@@ -124,6 +124,108 @@ def train_acoustic_model(data_args, am_hp, train_source, dev_source=None, ckpt_d
         if ckpt_dir and rank == 0:
             os.makedirs(ckpt_dir, exist_ok=True)
             save_checkpoint(model, os.path.join(ckpt_dir, 'final_model.pt'))
+    return model, history
+
+
+def train_language_model(data_args, am_hp, train_source, dev_source=None, ckpt_dir=None, log_every=10, model_cls=None,
+                         loader_cls=DataLoader, seed=0):
+    """Counterpart of ``train_language_model`` (lm_and_am/train.py:100-165): per epoch every lm_batch_size-sized batch of
+    ``DataLoader.get_lm_batch()`` is fed as ``{x: input_batch, y: label_batch}`` and ``[mean_loss, current_learning,
+    train_op]`` fetched (:138-141); then the dev set's mean accuracy (:152-160) decides whether ``final_model`` is kept.
+    One process per GPU: all ranks draw the same (seeded) batch order and rank r trains on batches r, r + world, ...
+    (rank_batches), gradients summed over RCCL inside ``Language_Model.run``.  (The reference's dev loop adds the last
+    TRAINING cost to its loss total, :157 ``total_loss += cost``; the dev loss is accumulated here.)"""
+    import random
+    from .language_model import Language_Model
+    model_cls = model_cls or Language_Model
+    rank, world, local = init_from_env()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    loader = loader_cls(train_source, data_args, am_hp)
+    model = model_cls(am_hp, loader.acoustic_vocab_size, loader.language_vocab_size)
+    if ckpt_dir and os.path.exists(os.path.join(ckpt_dir, 'final_model.pt')):
+        load_checkpoint(model, os.path.join(ckpt_dir, 'final_model.pt'))
+    batch_num = len(loader.pny_lst) // am_hp.lm_batch_size
+    mine = set(rank_batches(batch_num, world, rank))
+    history, old_acc = [], 0.0
+    for epoch in range(am_hp.epochs):
+        total_loss, steps = 0.0, 0
+        for i, (input_batch, _, label_batch) in zip(sorted(mine), loader.get_lm_batch(rng=random.Random(seed + epoch), select=mine)):
+            cost, cur_lr, _ = model.run([model.mean_loss, model.current_learning, model.train_op],
+                                        feed_dict={model.x: input_batch, model.y: label_batch})
+            total_loss += cost
+            steps += 1
+            if rank == 0 and i % log_every == 0:
+                print("epoch: %d    step: %d/%d lr:%.6f train loss=%.6f" % (epoch + 1, i, batch_num, cur_lr, cost), flush=True)
+            history.append((cost, cur_lr))
+        if rank == 0 and steps:
+            print('epochs', epoch + 1, ': average loss = ', total_loss / steps, flush=True)
+        if dev_source is not None:
+            dev_loader = loader_cls(dev_source, data_args, am_hp)
+            tot_acc, tot_loss, n = 0.0, 0.0, 0
+            for input_batch, _, label_batch in dev_loader.get_lm_batch(rng=random.Random(seed)):
+                if input_batch.shape[0] == 0:
+                    continue
+                loss, acc = model.run([model.mean_loss, model.acc], feed_dict={model.x: input_batch, model.y: label_batch})
+                tot_loss += loss; tot_acc += acc; n += 1
+            if n:
+                acc = tot_acc / n
+                if rank == 0:
+                    print("epoch: %d test acc:%.4f  test loss=%.6f" % (epoch + 1, acc, tot_loss / n), flush=True)
+                if acc > old_acc:
+                    old_acc = acc
+                    if ckpt_dir and rank == 0:
+                        os.makedirs(ckpt_dir, exist_ok=True)
+                        save_checkpoint(model, os.path.join(ckpt_dir, 'final_model_%d.pt' % (epoch + 1)))
+        if ckpt_dir and rank == 0:
+            os.makedirs(ckpt_dir, exist_ok=True)
+            save_checkpoint(model, os.path.join(ckpt_dir, 'final_model.pt'))
+    return model, history
+
+
+def train_transformer(args, loader, model=None, ckpt_dir=None, seed=0):
+    """Counterpart of ``transformerTrain.train`` (end2end/model.py:74-126): every batch of
+    ``dataloader.get_transformer_batch()`` is fed as ``{x_input, y_input, y_target, learning_rate}`` and ``[mean_loss, merged,
+    current_learning, train_op]`` fetched (:104-109); a checkpoint every ``save_every_n`` steps and as ``final_model``
+    (:114-120), a log line every ``log_every_n`` (:122-126).  ``args``: the module-level argparse namespace of
+    end2end/model.py:15-55 (e2e_model.E2EHparams).  One process per GPU as in train_language_model."""
+    import random
+    from datetime import datetime
+    from .e2e_model import Transformer_Model
+    rank, world, local = init_from_env()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    model = model or Transformer_Model(args, label_vocab_size=loader.language_vocab_size)
+    model.build_transformer()
+    if ckpt_dir and os.path.exists(os.path.join(ckpt_dir, 'final_model.pt')) and model.engine is not None:
+        load_checkpoint(model, os.path.join(ckpt_dir, 'final_model.pt'))
+    batch_nums = len(loader)
+    mine = set(rank_batches(batch_nums, world, rank))
+    train_steps, history = 0, []
+    save_every_n, log_every_n = getattr(args, 'save_every_n', 1000), getattr(args, 'log_every_n', 10)
+    for epoch in range(args.epochs):
+        total_loss, done = 0.0, 0
+        for the_inputs, the_labels, ground_truth in loader.get_transformer_batch(rng=random.Random(seed + epoch), select=mine):
+            # x_input has a STATIC batch dimension (model.py:195: [batch_size, None, 320]): a batch that lost rows cannot
+            # be fed.  The decision to skip a step is taken by ALL ranks together (one MIN all-reduce), so that no rank
+            # enters a gradient all-reduce the others skip.
+            if not all_agree(the_inputs.shape[0] == model.batch_size):
+                continue
+            train_steps += 1
+            feed = {model.x_input: the_inputs, model.y_input: the_labels, model.y_target: ground_truth,
+                    model.learning_rate: args.learning_rate}
+            train_loss, summary, lr, _ = model.run([model.mean_loss, model.merged, model.current_learning, model.train_op],
+                                                   feed_dict=feed)
+            total_loss += train_loss
+            done += 1
+            history.append((train_loss, lr))
+            if ckpt_dir and rank == 0 and train_steps % save_every_n == 0:
+                os.makedirs(ckpt_dir, exist_ok=True)
+                save_checkpoint(model, os.path.join(ckpt_dir, 'model_%d.pt' % train_steps))
+                save_checkpoint(model, os.path.join(ckpt_dir, 'final_model.pt'))
+            if rank == 0 and train_steps % log_every_n == 0:
+                print('Epoch: {0:>3}, Iter: {1:>6}, LR:{2:>10.6f} Average Loss: {3:>6.6f}, Time: {4}'.format(
+                    epoch + 1, train_steps, lr, total_loss / done, datetime.now()), flush=True)
     return model, history
 
 

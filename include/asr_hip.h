@@ -69,6 +69,17 @@ int asr_fbank(const float* signal, const int32_t* nsamples, int B, int max_sampl
               const double* twiddle, double* logfb, int max_frames,
               float* out, int t_pad, int32_t* frames, void* stream);
 
+/* ------------------------------------------------------------------ K1b low-frame-rate stacking
+ * build_LFR_features(inputs, m, n) (util/utils.py:7-31, called per utterance by get_transformer_batch,
+ * end2end/data_loader.py:284) on the padded feature batch asr_fbank wrote, for the whole batch at once:
+ *   feat   [B][t_pad][D] f32, frames [B] i32 (device; valid rows of each utterance)
+ *   out    [B][t_out][m*D] f32: out[b][i] = rows i*n .. i*n+m-1 of utterance b side by side, rows past its end
+ *          replaced by its LAST row (:25-29), for i < ceil(frames[b] / n); all-zero rows after that
+ *          (wav_padding, end2end/data_loader.py:84-99).  D % 4 == 0.
+ */
+int asr_lfr(const float* feat, const int32_t* frames, int B, int t_pad, int D, int m, int n, int t_out,
+            float* out, void* stream);
+
 /* ------------------------------------------------------------------ K2/K6 tap-GEMM
  * One kernel family serves conv3x3/conv1x1 forward, their data-gradient, and dense
  * layers (tf.layers.conv2d / tf.layers.dense: lm_and_am/model/acoustic_model2.py:102-121):
