@@ -10,6 +10,7 @@
 // HBM-bound (0.64 MB in, 0.8 MB out per 10 s utterance); the float64 math is noise.
 #include "asr_common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -121,6 +122,235 @@ __global__ __launch_bounds__(256) void fbank_scale_kernel(const double* __restri
     }
 }
 
+// ---- v2 (nfft = 512, the only size the reference uses): the frame is real, so its spectrum comes from ONE 256-point
+// complex FFT of z[n] = x[2n] + i x[2n+1] plus an untangling pass -- half the butterflies -- run as four radix-4 Stockham
+// passes (natural order out, no bit reversal): every lane does one radix-4 butterfly per pass, 4 LDS exchanges per frame
+// instead of 9, conflict-free 16-byte reads, and NO workgroup barrier: a wave owns its frame, and the LDS executes one
+// wave's requests in order.  The 256 twiddles sit in LDS once per workgroup; a wave handles FPW frames in a row.
+// Still float64 throughout (python_speech_features computes in float64): results equal the radix-2 kernel's to ~1e-15
+// relative, i.e. the same float32 features.
+struct dcomplex { double x, y; };
+
+__device__ __forceinline__ void wave_lds_sync() {
+    // same-wave LDS hand-over: ordering is the hardware's (DS ops of one wave execute in issue order); this only stops
+    // the compiler from moving LDS accesses across it
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int FPW>
+__global__ __launch_bounds__(256) void fbank_logmel_v2_kernel(const float* __restrict__ signal, const int32_t* __restrict__ nsamples,
+                                                              int max_samples, int frame_len, int frame_step, double preemph, int nfilt,
+                                                              const int32_t* __restrict__ fb_start, const int32_t* __restrict__ fb_count,
+                                                              const double* __restrict__ fb_weight, int fb_width,
+                                                              const double* __restrict__ twiddle, double* __restrict__ logfb,
+                                                              int max_frames, int32_t* __restrict__ frames_out) {
+    constexpr int N = 256;                                    // complex FFT length = nfft / 2
+    __shared__ __attribute__((aligned(16))) dcomplex tw[N];   // W_512^k = exp(-2 pi i k / 512), k < 256
+    __shared__ __attribute__((aligned(16))) dcomplex buf[4][2][N];
+    extern __shared__ __attribute__((aligned(16))) double fbw[];      // [nfilt][fb_width]: the banded filterbank, once per workgroup
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int ns = nsamples[b];
+    int nf = num_frames_of(ns, frame_len, frame_step);
+    if (nf > max_frames) nf = max_frames;
+    if (blockIdx.x == 0 && tid == 0) frames_out[b] = nf;
+    tw[tid].x = twiddle[2 * tid]; tw[tid].y = twiddle[2 * tid + 1];
+    for (int i = tid; i < nfilt * fb_width; i += 256) fbw[i] = fb_weight[i];
+    // this lane's filters (j = lane, lane + 64, ...) do not change from frame to frame
+    constexpr int JMAX = 4;                                            // nfilt <= 256
+    int fst[JMAX], fcn[JMAX];
+#pragma unroll
+    for (int r = 0; r < JMAX; ++r) {
+        const int j = lane + 64 * r;
+        fst[r] = (j < nfilt) ? fb_start[j] : 0;
+        fcn[r] = (j < nfilt) ? fb_count[j] : 0;
+    }
+    const double log_eps = log(2.220446049250313e-16);                 // what an empty filter yields (43 of 200 at nfilt 200)
+    __syncthreads();
+    const float* sig = signal + (long)b * max_samples;
+    dcomplex* A = buf[wave][0];
+    dcomplex* Bf = buf[wave][1];
+    double* ps = (double*)Bf;                                 // the power spectrum reuses the buffer the last pass left free
+
+    auto twid = [&](int idx) -> dcomplex {                    // W_512^idx for 0 <= idx < 512
+        dcomplex w = tw[idx & 255];
+        if (idx & 256) { w.x = -w.x; w.y = -w.y; }
+        return w;
+    };
+
+    // framing: lane l packs samples (2n, 2n+1), n = l, l+64, l+128, l+192, into z[n].  All 16 loads of a lane are
+    // unconditional (clamped addresses) and issued together, and the NEXT frame's samples are fetched while this one is
+    // transformed (a wave walks its FPW frames one after the other)
+    float cur[8], prv[8], ncur[8], nprv[8];
+    auto fetch = [&](int f, float (&c)[8], float (&pv)[8]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                long idx = (long)f * frame_step + 2 * (lane + 64 * r) + h;
+                if (idx > max_samples - 1) idx = max_samples - 1;
+                c[2 * r + h] = sig[idx];
+                pv[2 * r + h] = sig[idx > 0 ? idx - 1 : 0];
+            }
+    };
+    const int f0 = (blockIdx.x * 4 + wave) * FPW;
+    fetch(f0, ncur, nprv);
+    for (int q = 0; q < FPW; ++q) {
+        const int f = f0 + q;
+        if (f >= nf) break;                                   // wave-uniform
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { cur[i] = ncur[i]; prv[i] = nprv[i]; }
+        if (q + 1 < FPW) fetch(f + 1, ncur, nprv);
+        // z[n], n = lane + 64 r, are exactly the four inputs of this lane's first butterfly: pass 0 runs from registers
+        dcomplex zin[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = lane + 64 * r;
+            double v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int i = 2 * n + h;
+                const long idx = (long)f * frame_step + i;
+                const double x = (idx > 0) ? (double)cur[2 * r + h] - preemph * (double)prv[2 * r + h] : (double)cur[2 * r + h];
+                v[h] = (i < frame_len && idx < ns) ? x : 0.0;
+            }
+            zin[r].x = v[0]; zin[r].y = v[1];
+        }
+        // four radix-4 Stockham passes, Ns = 1, 4, 16, 64.  The buffer between pass 0 and pass 1 is XOR-swizzled inside
+        // aligned groups of four elements (element p sits at (p & ~3) | ((p ^ (p >> 3)) & 3)): pass 0 writes with a
+        // 4-element lane stride, which would be a 4-way bank conflict on 16-byte stores; pass 1 reads consecutive elements,
+        // for which a permutation inside 64-byte groups changes nothing.
+        dcomplex* src = A; dcomplex* dst = Bf;
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+            const int Ns = 1 << (2 * pass);
+            const int k = lane & (Ns - 1);
+            const int tstep = 128 >> (2 * pass);              // W_{4 Ns}^{k} = W_512^{k * 128 / Ns}
+            dcomplex v0, v1, v2, v3;
+            if (pass == 0) { v0 = zin[0]; v1 = zin[1]; v2 = zin[2]; v3 = zin[3]; }
+            else if (pass == 1) {
+                const int sw = (lane >> 3) & 3;               // (p >> 3) & 3 for p = lane + 64 r
+                const int q = (lane & ~3) | ((lane ^ sw) & 3);
+                v0 = src[q]; v1 = src[q + 64]; v2 = src[q + 128]; v3 = src[q + 192];
+            } else { v0 = src[lane]; v1 = src[lane + 64]; v2 = src[lane + 128]; v3 = src[lane + 192]; }
+            if (pass > 0) {
+                const dcomplex w1 = twid(k * tstep), w2 = twid(2 * k * tstep), w3 = twid(3 * k * tstep);
+                dcomplex t;
+                t.x = v1.x * w1.x - v1.y * w1.y; t.y = v1.x * w1.y + v1.y * w1.x; v1 = t;
+                t.x = v2.x * w2.x - v2.y * w2.y; t.y = v2.x * w2.y + v2.y * w2.x; v2 = t;
+                t.x = v3.x * w3.x - v3.y * w3.y; t.y = v3.x * w3.y + v3.y * w3.x; v3 = t;
+            }
+            const double ax = v0.x + v2.x, ay = v0.y + v2.y, bx = v0.x - v2.x, by = v0.y - v2.y;
+            const double cx = v1.x + v3.x, cy = v1.y + v3.y;
+            const double dx = v1.y - v3.y, dy = -(v1.x - v3.x);          // (v1 - v3) * (-i)
+            const int j0 = ((lane >> (2 * pass)) << (2 * pass + 2)) + k;
+            dcomplex o;
+            if (pass == 0) {                                   // positions 4 lane + r, swizzled: r ^ ((lane >> 1) & 3)
+                const int sw = (lane >> 1) & 3;
+                o.x = ax + cx; o.y = ay + cy; dst[j0 + (0 ^ sw)] = o;
+                o.x = bx + dx; o.y = by + dy; dst[j0 + (1 ^ sw)] = o;
+                o.x = ax - cx; o.y = ay - cy; dst[j0 + (2 ^ sw)] = o;
+                o.x = bx - dx; o.y = by - dy; dst[j0 + (3 ^ sw)] = o;
+            } else {
+                o.x = ax + cx; o.y = ay + cy; dst[j0] = o;
+                o.x = bx + dx; o.y = by + dy; dst[j0 + Ns] = o;
+                o.x = ax - cx; o.y = ay - cy; dst[j0 + 2 * Ns] = o;
+                o.x = bx - dx; o.y = by - dy; dst[j0 + 3 * Ns] = o;
+            }
+            wave_lds_sync();
+            dcomplex* t2 = src; src = dst; dst = t2;
+        }
+        // src = Z (256-point spectrum of z).  Untangle: X[k] = E[k] + W_512^k O[k], E = (Z[k] + conj Z[N-k]) / 2,
+        // O = (Z[k] - conj Z[N-k]) / (2 i); power spectrum |X|^2 / 512 for k = 0 .. 256
+        const double invn = 1.0 / 512.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = lane + 64 * r;
+            const dcomplex zk = src[k], zc = src[(N - k) & (N - 1)];
+            const double ex = 0.5 * (zk.x + zc.x), ey = 0.5 * (zk.y - zc.y);
+            const double ox = 0.5 * (zk.y + zc.y), oy = -0.5 * (zk.x - zc.x);
+            const dcomplex w = tw[k];
+            const double xr = ex + (w.x * ox - w.y * oy), xi = ey + (w.x * oy + w.y * ox);
+            ps[k] = (xr * xr + xi * xi) * invn;
+            if (k == 0) { const double nr = ex - ox, ni = ey - oy; ps[N] = (nr * nr + ni * ni) * invn; }
+        }
+        wave_lds_sync();
+        double* o = logfb + ((long)b * max_frames + f) * nfilt;
+#pragma unroll
+        for (int r = 0; r < JMAX; ++r) {
+            const int j = lane + 64 * r;
+            if (j < nfilt) {
+                // the table rows are zero beyond a filter's own taps: a zero weight leaves e unchanged (fma(x, 0, e) == e),
+                // so all fb_width taps are taken, with the bin index clamped to the last one
+                const double* wrow = fbw + j * fb_width;
+                double e = 0.0;
+                for (int i = 0; i < fcn[r]; ++i) e = fma(ps[fst[r] + i], wrow[i], e);
+                o[j] = (e == 0.0) ? log_eps : log(e);
+            }
+        }
+        wave_lds_sync();                                       // ps / A are rewritten by the next frame
+    }
+}
+
+// scale v2: one workgroup per (utterance, 8 columns): 8 columns x 32 time slices; a thread keeps its <= RMAX rows of the
+// column in registers, so the float64 log-energies are read ONCE and the four sklearn passes (mean, variance + first-order
+// correction, re-centre, write) run from registers.  Same arithmetic and summation order per slice as the v1 kernel.
+template <int RMAX>
+__global__ __launch_bounds__(256) void fbank_scale_v2_kernel(const double* __restrict__ logfb, const int32_t* __restrict__ frames,
+                                                             int max_frames, int nfilt, float* __restrict__ out, int t_pad) {
+    __shared__ double red[32][8];
+    const int tid = threadIdx.x, cl = tid & 7, ts = tid >> 3;
+    const int b = blockIdx.y;
+    const int col = blockIdx.x * 8 + cl;
+    const bool ok = col < nfilt;
+    int nf = frames[b];
+    if (nf > t_pad) nf = t_pad;
+    const double* x = logfb + (long)b * max_frames * nfilt + col;
+    const double dn = (double)nf;
+    double v[RMAX];
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) {
+        const int t = ts + 32 * i;
+        v[i] = (ok && t < nf) ? x[(long)t * nfilt] : 0.0;
+    }
+    auto block_sum = [&](double s) -> double {
+        red[ts][cl] = s;
+        __syncthreads();
+        double tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) tot += red[k][cl];
+        __syncthreads();
+        return tot;
+    };
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) if (ts + 32 * i < nf) acc += v[i];
+    const double mean = block_sum(acc) / dn;
+    double a2 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) if (ts + 32 * i < nf) { const double d = v[i] - mean; a2 += d * d; a1 += d; }
+    const double var = block_sum(a2) / dn;
+    double mean1 = block_sum(a1) / dn;
+    if (!(fabs(mean1) > 1e-8)) mean1 = 0.0;
+    double sd = sqrt(var);
+    if (sd < 10.0 * 2.220446049250313e-16) sd = 1.0;
+    double a3 = 0.0;
+#pragma unroll
+    for (int i = 0; i < RMAX; ++i) if (ts + 32 * i < nf) { v[i] = (v[i] - mean - mean1) / sd; a3 += v[i]; }
+    const double mean2 = block_sum(a3) / dn;
+    if (ok) {
+        float* o = out + (long)b * t_pad * nfilt + col;
+#pragma unroll
+        for (int i = 0; i < RMAX; ++i) {
+            const int t = ts + 32 * i;
+            if (t < nf) o[(long)t * nfilt] = (float)(v[i] - mean2);
+        }
+        for (int t = nf + ts; t < t_pad; t += 32) o[(long)t * nfilt] = 0.f;
+    }
+}
+
 // Low-frame-rate stacking (util/utils.py:7-31): out[b][i][j*D + d] = feat[b][min(i*n + j, frames[b] - 1)][d] for
 // i < ceil(frames[b] / n), zero rows after that.  One thread per output float4; pure gather, HBM-bound.
 __global__ __launch_bounds__(256) void lfr_kernel(const float* __restrict__ feat, const int32_t* __restrict__ frames,
@@ -174,11 +404,35 @@ extern "C" int asr_fbank(const float* signal, const int32_t* nsamples, int B, in
         (void)hipFuncSetAttribute((const void*)fbank_logmel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(fbank_logmel_kernel, dim3(asr_cdiv(max_frames, 4), B), dim3(256), lds, st, signal, nsamples, max_samples,
-                       frame_len, frame_step, nfft, log2n, preemph, nfilt, fb_start, fb_count, fb_weight, fb_width, twiddle,
-                       logfb, max_frames, frames);
-    hipLaunchKernelGGL(fbank_scale_kernel, dim3(asr_cdiv(nfilt, 32), B), dim3(256), 0, st, (const double*)logfb,
-                       (const int32_t*)frames, max_frames, nfilt, out, t_pad);
+    static int v2 = -1;
+    if (v2 < 0) { const char* e = getenv("ASR_FBANK_V2"); v2 = e ? atoi(e) : 1; }
+    const size_t lds2 = (size_t)nfilt * fb_width * sizeof(double);
+    if (v2 && nfft == 512 && frame_len <= 512 && nfilt <= 256 && lds2 <= 96 * 1024) {
+        constexpr int FPW = 5;
+        static bool attr2 = false;
+        if (!attr2) {
+            (void)hipFuncSetAttribute((const void*)fbank_logmel_v2_kernel<FPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(fbank_logmel_v2_kernel<FPW>, dim3(asr_cdiv(max_frames, 4 * FPW), B), dim3(256), lds2, st, signal, nsamples,
+                           max_samples, frame_len, frame_step, preemph, nfilt, fb_start, fb_count, fb_weight, fb_width, twiddle,
+                           logfb, max_frames, frames);
+    } else {
+        hipLaunchKernelGGL(fbank_logmel_kernel, dim3(asr_cdiv(max_frames, 4), B), dim3(256), lds, st, signal, nsamples, max_samples,
+                           frame_len, frame_step, nfft, log2n, preemph, nfilt, fb_start, fb_count, fb_weight, fb_width, twiddle,
+                           logfb, max_frames, frames);
+    }
+    const int tmax = max_frames < t_pad ? max_frames : t_pad;          // rows a column can have
+    if (v2 && tmax <= 32 * 32) {
+        hipLaunchKernelGGL(fbank_scale_v2_kernel<32>, dim3(asr_cdiv(nfilt, 8), B), dim3(256), 0, st, (const double*)logfb,
+                           (const int32_t*)frames, max_frames, nfilt, out, t_pad);
+    } else if (v2 && tmax <= 32 * 64) {
+        hipLaunchKernelGGL(fbank_scale_v2_kernel<64>, dim3(asr_cdiv(nfilt, 8), B), dim3(256), 0, st, (const double*)logfb,
+                           (const int32_t*)frames, max_frames, nfilt, out, t_pad);
+    } else {
+        hipLaunchKernelGGL(fbank_scale_kernel, dim3(asr_cdiv(nfilt, 32), B), dim3(256), 0, st, (const double*)logfb,
+                           (const int32_t*)frames, max_frames, nfilt, out, t_pad);
+    }
     ASR_CHECK_LAUNCH("fbank");
     return ASR_OK;
 }
