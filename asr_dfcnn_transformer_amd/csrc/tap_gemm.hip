@@ -1147,7 +1147,24 @@ extern "C" int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const flo
     // asr_tap_gemm stays faster (0.86-0.97x here: no tap reuse to pay for the direct weight loads), so the engines use
     // this entry point for ntaps = 9 only -- the 1-tap configurations exist for completeness and tests
     if (d->ntaps == 9) {
-        if (d->N > 32) return launch_v5<128, 64, 2, 2, 9, 16, 3, 3>(a, Wf, dir, st);
+        static int mt = -1;
+        if (mt < 0) { const char* e = getenv("ASR_PW_MT"); mt = e ? atoi(e) : 0; }
+        if (d->N > 32) {
+            if (mt == 192) return launch_v5<192, 64, 2, 2, 9, 16, 3, 3>(a, Wf, dir, st);
+            if (mt == 64) return launch_v5<64, 64, 2, 2, 9, 16, 3, 3>(a, Wf, dir, st);
+            if (mt == 256) return launch_v5<256, 64, 2, 2, 9, 16, 3, 2>(a, Wf, dir, st);
+            if (mt == 128) return launch_v5<128, 64, 2, 2, 9, 16, 3, 3>(a, Wf, dir, st);
+            // The kernel advances in beats of one tile per CU (tools/exp_tail.py: its duration is ceil(tiles / 256) x the time
+            // of one tile, whatever the three co-resident workgroups overlap), so the partial last beat is lost: 2 614 tiles
+            // of 128 rows = 10.2 beats cost 11.  Rows per tile are therefore picked per launch, 128 or 192 (2 x 2 waves of
+            // 2 or 3 row blocks), whichever needs fewer row-beats; at equal cost 192 wins by its smaller halo share
+            // (gpurun_out/r02e/mt.log: 128->128 and 128->256 at 200x25 +2..5 %, the 400x50 layers stay on 128).
+            const long nt = asr_cdiv(d->N, 64);
+            const long c128 = (long)asr_cdiv((long)asr_cdiv(d->M, 128) * nt, 256) * 128;
+            const long c192 = (long)asr_cdiv((long)asr_cdiv(d->M, 192) * nt, 256) * 192;
+            if (c192 <= c128) return launch_v5<192, 64, 2, 2, 9, 16, 3, 3>(a, Wf, dir, st);
+            return launch_v5<128, 64, 2, 2, 9, 16, 3, 3>(a, Wf, dir, st);
+        }
         return launch_v5<256, 32, 4, 1, 9, 16, 3, 3>(a, Wf, dir, st);
     }
     if (d->N > 64) return launch_v5<128, 128, 2, 2, 1, 32, 4, 2>(a, Wf, dir, st);
