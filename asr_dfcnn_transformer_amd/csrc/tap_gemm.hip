@@ -683,7 +683,9 @@ __global__ void arrange_weights_kernel(const float* __restrict__ W, int ntaps, i
 
 // ---- bx6: EXPERIMENTAL split-bf16 contraction (tools/mfma_bf16x.hip).  Every fp32 operand is
 // written as hi + mid + lo bf16 pieces (3 x 8 mantissa bits = the 24 bits of fp32) and a product as SIX
-// v_mfma_f32_32x32x16_bf16 products accumulated in fp32 (hh, hm, mh, mm, hl, lh; the dropped terms are < 2^-32 relative):
+// v_mfma_f32_32x32x16_bf16 products accumulated in fp32 (hh, hm, mh, mm, hl, lh).  Dropped: mid x low, low x mid, low x low;
+// with 8-bit pieces |mid| <= 2^-8 |x| and |low| <= 2^-17 |x|, i.e. <= 2^-24 |x y| per product in the worst case (typically
+// 2^-28) -- one rounding unit of the fp32 chain it replaces (tests/test_bx6_gpu.py::test_split_bf16_worst_case_dropped_terms):
 // fp32-chain accuracy at 2.6x the matrix-pipe rate.  Structure = v4: the A tile is split once when it is staged
 // (3 x KC bf16 per pixel row), the weights arrive pre-split and transposed ([tap][piece][n][Kp], asr_split_weights) so a
 // lane's B fragment is one 16-byte global load per piece, kept D units ahead in a register ring; two barriers per chunk.

@@ -55,7 +55,7 @@ def pmc_traffic(workload, symbol):
     written from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs with the gfx950 x2 FETCH correction of
     MI355X_MICROARCH.md).  Returns (bytes or None, source file or None)."""
     import glob
-    tag = {'dfcnn': 'dfcnn_m1', 'se_dfcnn': 'se_dfcnn_m2', 'transformer': 'transformer', 'e2e_prenet': 'e2e_prenet'}[workload]
+    tag = {'dfcnn': 'dfcnn_m1', 'se_dfcnn': 'se_dfcnn_m2'}.get(workload, workload)
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_%s_traffic.json' % tag)))
     if not files:
         return None, None
@@ -64,6 +64,15 @@ def pmc_traffic(workload, symbol):
         return (d[symbol]['hbm_bytes_per_launch'] if symbol in d else None), os.path.relpath(files[-1], ROOT)
     except Exception:
         return None, None
+
+
+def attach_traffic(out, workload, dom, default_config):
+    """roofline.traffic = HBM bytes per launch of the dominant kernel from the committed PMC pass of this workload (null when
+    the run is not the configuration that pass was taken on)."""
+    tr, src = pmc_traffic(workload, dom) if default_config else (None, None)
+    out['roofline']['traffic'] = tr
+    if src:
+        out['roofline']['traffic_unit'] = 'bytes/launch (PMC pass: %s)' % src
 
 
 def cpu_baseline(variant, t_pad, vocab, seconds=10.0, budget_s=15.0):
@@ -198,6 +207,7 @@ def run_am_lm(args):
                'roofline': {'bound': 'mfma', 'achieved': round(r['tflops'], 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                             'frac': round(r['tflops'] / FP32_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': kernel_name(dom),
                             'launches_per_step': r['launches'] // args.steps, 'avg_launch_us': round(r['avg_us'], 2)}}
+        attach_traffic(out, 'am_lm', dom, args.batch == 32 and args.tpad == 1600)
         if args.kernel_table:
             for key, rr in sorted(table.items(), key=lambda kv: -kv[1]['total_ms']):
                 print('%-48s launches %3d  total %8.3f ms  avg %9.1f us  %7.2f TFLOP/s' %
@@ -267,6 +277,7 @@ def run_lm(args):
                'roofline': {'bound': 'mfma', 'achieved': round(r['tflops'], 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                             'frac': round(r['tflops'] / FP32_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': kernel_name(dom),
                             'launches_per_step': r['launches'] // args.steps, 'avg_launch_us': round(r['avg_us'], 2)}}
+        attach_traffic(out, 'lm', dom, N == 64)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
@@ -365,6 +376,7 @@ def run_transformer(args):
                'roofline': {'bound': 'mfma', 'achieved': round(r['tflops'], 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                             'frac': round(r['tflops'] / FP32_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': kernel_name(dom),
                             'launches_per_step': r['launches'] // args.steps, 'avg_launch_us': round(r['avg_us'], 2)}}
+        attach_traffic(out, args.workload, dom, N == 64)
         if prenet:
             out['dp_semantics'] = ('per-replica BN: the batch-statistics BatchNorm of the pre-net normalises over the batch of each rank '
                                    'batch (no SyncBN), so the N-rank step is not the single-process global-batch step')

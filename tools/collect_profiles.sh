@@ -30,7 +30,9 @@ for wl in dfcnn se_dfcnn; do
 done
 unset ASR_BX6
 export ASR_DUAL_STREAM=0
-for wl in dfcnn se_dfcnn; do
+# PMC passes (counters only with --kernel-trace; FETCH_SIZE and WRITE_SIZE in passes of their own): every workload, so
+# that each bench line can carry roofline.traffic for its dominant kernel
+for wl in dfcnn se_dfcnn transformer e2e_prenet am_lm lm; do
   i=0
   for ctr in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES"; do
     i=$((i+1))
