@@ -8,6 +8,8 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+PHASE=${PHASE:-all}          # stats | pmc | all  (two gpurun calls of <= 20 min each)
+if [ "$PHASE" != "pmc" ]; then
 for wl in dfcnn se_dfcnn transformer e2e_prenet am_lm lm; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -o $wl -- \
       python3 $ROOT/bench.py --workload $wl --steps 4 --warmup 2 --no-cpu-baseline --no-experimental > $OUT/bench_$wl.log 2>&1
@@ -29,6 +31,16 @@ for wl in dfcnn se_dfcnn; do
   echo "split-bf16 stats $wl done"
 done
 unset ASR_BX6
+for wl in dfcnn se_dfcnn transformer e2e_prenet am_lm lm; do
+  find $OUT/stats_$wl -name "*kernel_stats.csv" -exec cp {} $OUT/${wl}_kernel_stats.csv \;
+done
+for wl in dfcnn se_dfcnn; do
+  find $OUT/stats1_$wl -name "*kernel_stats.csv" -exec cp {} $OUT/${wl}_single_stream_kernel_stats.csv \;
+  find $OUT/statsx_$wl -name "*kernel_stats.csv" -exec cp {} $OUT/${wl}_split_bf16_kernel_stats.csv \;
+done
+rm -rf $OUT/stats_* $OUT/stats1_* $OUT/statsx_*
+fi
+if [ "$PHASE" != "stats" ]; then
 export ASR_DUAL_STREAM=0
 # PMC passes (counters only with --kernel-trace; FETCH_SIZE and WRITE_SIZE in passes of their own): every workload, so
 # that each bench line can carry roofline.traffic for its dominant kernel
@@ -43,13 +55,6 @@ for wl in dfcnn se_dfcnn transformer e2e_prenet am_lm lm; do
   python3 $ROOT/tools/pmc_summary.py $OUT/${wl}_pmc_summary.csv $OUT/pmc_${wl}_1 $OUT/pmc_${wl}_2 $OUT/pmc_${wl}_3 $OUT/pmc_${wl}_4 \
       --traffic $OUT/${wl}_traffic.json
 done
-for wl in dfcnn se_dfcnn transformer e2e_prenet am_lm lm; do
-  find $OUT/stats_$wl -name "*kernel_stats.csv" -exec cp {} $OUT/${wl}_kernel_stats.csv \;
-done
-for wl in dfcnn se_dfcnn; do
-  find $OUT/stats1_$wl -name "*kernel_stats.csv" -exec cp {} $OUT/${wl}_single_stream_kernel_stats.csv \;
-  find $OUT/statsx_$wl -name "*kernel_stats.csv" -exec cp {} $OUT/${wl}_split_bf16_kernel_stats.csv \;
-done
-# keep the merge-back small: drop raw traces
-rm -rf $OUT/stats_* $OUT/stats1_* $OUT/statsx_* $OUT/pmc_*_[0-9]
+rm -rf $OUT/pmc_*_[0-9]
+fi
 ls -la $OUT
