@@ -971,11 +971,13 @@ Plan6 make_plan6(const asr_gemm_desc* d) {
     auto lds_for = [&](int ps) { return (size_t)2 * ((((size_t)(ps + 2 * halo) * KT + 255) & ~(size_t)255) + (size_t)ps * NT) * sizeof(float); };
     Plan6 q;
     auto fits = [&](int ps) { return lds_for(ps) <= 160 * 1024; };
-    // measured on the DFCNN layers (tools/bench_layers.py wgrad, gpurun_out/r02b): with >= 128 output channels the dZ image
-    // dominates and 32-pixel runs at two workgroups per CU win (126-131 TFLOP/s); with <= 64 the A image and its halo (two
-    // plane rows: 2 x (W + 2) pixels re-staged per run) dominate, so longer runs: 64 pixels, or 128 on planes wider than 64
-    // (800x100: 88 / 114 TFLOP/s at N = 32 / 64 against 78 / 103 with 32-pixel runs)
-    int ps = (d->ntaps == 1 || NT > 64) ? 32 : (d->W > 64 ? 128 : 64);
+    // measured on the DFCNN layers (tools/bench_layers.py wgrad, gpurun_out/r02b): with <= 64 output channels the A image and
+    // its halo (two plane rows: 2 x (W + 2) pixels re-staged per run) dominate, so longer runs: 64 pixels, or 128 on planes
+    // wider than 64 (800x100: 88 / 114 TFLOP/s at N = 32 / 64 against 78 / 103 with 32-pixel runs)
+    // >= 128 outputs, 3x3: 64-pixel runs at ONE workgroup per CU tie with 32-pixel runs at two in isolation (127 vs 126
+    // TFLOP/s) but leave half of every CU's registers and wave slots to the HBM-bound kernels that run beside the weight
+    // gradient on the other stream, and halve the partial slab (256 workgroups): whole step -1 % (gpurun_out/r02g/ps.log)
+    int ps = (d->ntaps == 1) ? 32 : (NT > 64 ? 64 : (d->W > 64 ? 128 : 64));
     if (ps_force == 32 || ps_force == 64 || ps_force == 128) ps = ps_force;
     while (ps > 32 && !fits(ps)) ps >>= 1;
     q.ps = ps;
