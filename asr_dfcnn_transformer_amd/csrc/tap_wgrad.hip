@@ -12,6 +12,7 @@
 #include "asr_common.h"
 #include <stdlib.h>
 #include <stdio.h>
+#include <stdint.h>
 
 namespace {
 
@@ -1074,8 +1075,10 @@ extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float
     hipStream_t st = (hipStream_t)stream;
     int rc;
     Plan p6 = p;
-    bool is6 = true;
-    if (d->ntaps == 9 && d->N > 64 && v6_ok<9, 1, 4, 1>(d, ldz)) rc = launch_wgrad6<9, 1, 4, 1>(a, d, dW, partials, st, &p6);
+    // the LDS-DMA kernels fetch 16 bytes per lane: both operands must be 16-byte aligned (row pitches are checked above)
+    bool is6 = ((((uintptr_t)A) | ((uintptr_t)dZ)) & 15) == 0;
+    if (!is6) { /* fall through to the register-staged kernels */ }
+    else if (d->ntaps == 9 && d->N > 64 && v6_ok<9, 1, 4, 1>(d, ldz)) rc = launch_wgrad6<9, 1, 4, 1>(a, d, dW, partials, st, &p6);
     else if (d->ntaps == 9 && d->N > 32 && d->N <= 64 && v6_ok<9, 1, 2, 1>(d, ldz)) rc = launch_wgrad6<9, 1, 2, 1>(a, d, dW, partials, st, &p6);
     else if (d->ntaps == 9 && d->N <= 32 && v6_ok<9, 1, 1, 1>(d, ldz)) rc = launch_wgrad6<9, 1, 1, 1>(a, d, dW, partials, st, &p6);
     else if (d->ntaps == 1 && v6_dense_enabled() && (long)asr_cdiv(d->K, 128) * asr_cdiv(d->N, 128) >= 4 && v6_ok<1, 4, 4, 1>(d, ldz)) rc = launch_wgrad6<1, 4, 4, 1>(a, d, dW, partials, st, &p6);
