@@ -39,6 +39,8 @@ SIGNATURES = {
     'asr_arrange_weights_bytes': (_Z, [_I, _I, _I]),
     'asr_arrange_weights': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'asr_tap_gemm_pw': (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    'asr_tap_gemm_gated_workspace': (_Z, [C.POINTER(GemmDesc)]),
+    'asr_tap_gemm_gated': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_split_rows_bytes': (_Z, [_L, _I]),
     'asr_split_rows': (_I, [_P, _L, _I, _I, _P, _P]),
     'asr_gemm_bx6s': (_I, [_P, _P, _L, _I, _I, _P, _I, _I, _P, _I, _P, _P]),

@@ -16,6 +16,7 @@
 //     tap run (issue-early / write-late staging); 2-3 blocks per CU cover the rest;
 //   * epilogue fuses bias + ReLU (+ the frozen-BN affine) and skips border pixels.
 #include "asr_common.h"
+#include "reduce.h"
 #include <stdlib.h>
 
 namespace {
@@ -34,6 +35,14 @@ struct TapGemmArgs {
     int relu, accumulate, y_unpadded;
     int ntm, ntn;
     int ablate;          // timing experiments only (ASR_TG_ABLATE): 1 skip A restaging, 2 skip W restaging, 4 skip epilogue
+    // fused backward prologue of the cell whose gradient this data-gradient completes (asr_tap_gemm_gated): instead of
+    // writing dL/dy of that cell, the epilogue routes it through the cell's pool / BN / ReLU backward and writes dZ
+    int gate_mode;       // 0 off, 1 no pool, 2 average pool 2x2, 3 max pool 2x2
+    int gate_H, gate_W;  // the gated cell's pre-pool plane (= H, Wd here for mode 1, 2H x 2W for modes 2, 3)
+    const float* gate_a; // its post-ReLU pre-BN activations, padded plane [B][gate_H+1][gate_W+1][N]
+    float* gate_dz;      // out: dL/d(conv + bias) of that cell, same layout as gate_a (scale / shift = its BN affine)
+    float* gate_part;    // out: [rows][3][N] per-(tile row, wave row) sums of dscale, dshift, dbias
+    int* gate_rows;      // host out: rows of gate_part the launched configuration writes
 };
 
 // Row offset of tap `tap` in the flattened padded plane, and the tap of the weight tensor it multiplies.
@@ -54,9 +63,134 @@ __device__ __forceinline__ int tap_weight_index(int tap) { return (NTAPS == 9 &&
 // the pixel row in the register, which makes the natural store 4 bytes per lane (two 128-byte rows per wave
 // instruction, 32 instructions per tile and tensor).  Each wave instead transposes its tile through a private
 // 32x33 LDS scratch and stores float4 rows: 4x fewer, 16-byte store instructions (+8 % on the conv kernels).
+__device__ __forceinline__ float gate_pick(float y0, float y1, float y2, float y3, int k, float dp) {
+    int arg = 0; float m = y0;                  // first maximum in row-major window order (TF's max-pool gradient)
+    if (y1 > m) { m = y1; arg = 1; }
+    if (y2 > m) { m = y2; arg = 2; }
+    if (y3 > m) { m = y3; arg = 3; }
+    return arg == k ? dp : 0.f;
+}
+
+// Gated epilogue (g.gate_mode != 0): the tile holds dL/dy of the cell in front (its own pixels: pooled resolution for
+// modes 2, 3).  Per output pixel and channel quad: g_k = the gradient routed to pre-pool position k (the value itself /
+// a quarter of it to each of four / all of it to the first maximum of scale * a + shift), dZ_k = g_k * scale where
+// a_k > 0, plus the three per-channel sums of asr_cell_bwd_pre -- whose arithmetic this restates -- reduced over the
+// wave's rows in a fixed order and written as one partial row per (tile row, wave row).
+template <int TM, int TN>
+__device__ __forceinline__ void tap_epilogue_gated(const TapGemmArgs& g, const floatx16 (&acc)[TM][TN], float* scratch,
+                                                   const int* rowa, int* rowf, int row0, int col0, int lane, int part_row) {
+    const int li = lane & 31, lh = lane >> 5;
+    const int c4 = lane & 7, rsub = lane >> 3;
+    const int C = g.N;
+    const int WPf = g.gate_W + 1;
+    if (g.gate_mode >= 2) {
+        // full-resolution pixel of window position 0 for each of this wave's rows (wave-private slice of the table)
+        for (int r = lane; r < TM * 32; r += 64) {
+            const int m = row0 + r;
+            const int ra = rowa[m];
+            int pf = -1;
+            if (ra >= 0) {
+                const int b = ra / g.HPWP;
+                const int rr = ra - b * g.HPWP;
+                const int hq = rr / g.WP, wq = rr - hq * g.WP;
+                pf = (b * (g.gate_H + 1) + 2 * hq - 1) * WPf + 2 * wq - 1;
+            }
+            rowf[m] = pf;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = col0 + b * 32 + c4 * 4;
+        const bool ncol = n < g.N;
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ncol) { sc = *(const float4*)(g.scale + n); sh = *(const float4*)(g.shift + n); }
+        float s_scale[4] = {0.f, 0.f, 0.f, 0.f}, s_shift[4] = {0.f, 0.f, 0.f, 0.f}, s_bias[4] = {0.f, 0.f, 0.f, 0.f};
+        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = acc[a][b][r];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int row = it * 8 + rsub;
+                const int m = row0 + a * 32 + row;
+                const int ra = rowa[m];
+                const float* sp = scratch + row * 33 + c4 * 4;
+                float v[4] = {sp[0], sp[1], sp[2], sp[3]};
+                if (ra < 0 || !ncol) continue;
+                if (g.accumulate) {
+                    const float4 p = *(const float4*)(g.out_y + (long)ra * g.ldo_y + n);
+                    v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
+                }
+                if (g.gate_mode == 1) {
+                    const float4 a4 = *(const float4*)(g.gate_a + (long)ra * C + n);
+                    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+                    float d[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s_shift[e] += v[e];
+                        s_scale[e] = fmaf(v[e], av[e], s_scale[e]);
+                        d[e] = av[e] > 0.f ? v[e] * scv[e] : 0.f;
+                        s_bias[e] += d[e];
+                    }
+                    *(float4*)(g.gate_dz + (long)ra * C + n) = make_float4(d[0], d[1], d[2], d[3]);
+                } else {
+                    const long pf = rowf[m];
+                    const long off[4] = {pf, pf + 1, pf + WPf, pf + WPf + 1};
+                    float av[4][4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float4 a4 = *(const float4*)(g.gate_a + off[k] * C + n);
+                        av[k][0] = a4.x; av[k][1] = a4.y; av[k][2] = a4.z; av[k][3] = a4.w;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        float d[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float gk;
+                            if (g.gate_mode == 2) gk = 0.25f * v[e];
+                            else gk = gate_pick(fmaf(scv[e], av[0][e], shv[e]), fmaf(scv[e], av[1][e], shv[e]),
+                                                fmaf(scv[e], av[2][e], shv[e]), fmaf(scv[e], av[3][e], shv[e]), k, v[e]);
+                            s_shift[e] += gk;
+                            s_scale[e] = fmaf(gk, av[k][e], s_scale[e]);
+                            d[e] = av[k][e] > 0.f ? gk * scv[e] : 0.f;
+                            s_bias[e] += d[e];
+                        }
+                        *(float4*)(g.gate_dz + off[k] * C + n) = make_float4(d[0], d[1], d[2], d[3]);
+                    }
+                }
+            }
+        }
+        // rows of this wave: lanes with equal c4 differ in bits 3..5 of the lane id; fixed shuffle order
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                s_scale[e] += __shfl_xor(s_scale[e], o, 64);
+                s_shift[e] += __shfl_xor(s_shift[e], o, 64);
+                s_bias[e] += __shfl_xor(s_bias[e], o, 64);
+            }
+        }
+        if (rsub == 0 && ncol) {
+            float* pr = g.gate_part + (long)part_row * 3 * C + n;
+            *(float4*)(pr) = make_float4(s_scale[0], s_scale[1], s_scale[2], s_scale[3]);
+            *(float4*)(pr + C) = make_float4(s_shift[0], s_shift[1], s_shift[2], s_shift[3]);
+            *(float4*)(pr + 2 * C) = make_float4(s_bias[0], s_bias[1], s_bias[2], s_bias[3]);
+        }
+    }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void tap_epilogue(const TapGemmArgs& g, const floatx16 (&acc)[TM][TN], float* scratch,
-                                             const int* rowa, const int* rowy, int row0, int col0, int lane) {
+                                             const int* rowa, const int* rowy, int row0, int col0, int lane, int part_row = 0) {
+    if (g.gate_mode) {
+        tap_epilogue_gated<TM, TN>(g, acc, scratch, rowa, const_cast<int*>(rowy), row0, col0, lane, part_row);
+        return;
+    }
     const int li = lane & 31, lh = lane >> 5;
     const int c4 = lane & 7, rsub = lane >> 3;
 #pragma unroll
@@ -281,7 +415,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel(TapGemmArgs g) {
 
     // epilogue (tap_epilogue): transpose through LDS, float4 stores.  The staging tiles are dead by now.
     __syncthreads();
-    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane, tile_m * WM + wm);
 }
 
 // ---- v1: single-buffered W, direct A staging, two barriers per tap, 3 blocks per CU
@@ -480,7 +614,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
     // epilogue (tap_epilogue): transpose through LDS, float4 stores.  The staging tiles are dead by now.
     __syncthreads();
     if ((g.ablate & 4) && acc[0][0][0] != 123.456f) return;
-    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane, tile_m * WM + wm);
 }
 
 // ---- v5 ("pw"): the weight operand never touches LDS -- it is PRE-ARRANGED in MFMA fragment order (asr_arrange_weights, once per optimiser step):
@@ -619,7 +753,7 @@ __global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_v5(PwArgs args) {
     }
 
     __syncthreads();
-    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane, tile_m * WM + wm);
 }
 
 template <int MT, int NT, int WM, int WN, int NTAPS, int KCV, int D, int MINB, int DIR>
@@ -638,6 +772,7 @@ int launch_v5d(const TapGemmArgs& a, const float* Wf, hipStream_t st) {
     p.g = a; p.Wf = Wf; p.kg = (a.K + 7) / 8; p.nbt = (a.N + 31) / 32;
     p.g.ntm = asr_cdiv(a.M, MT);
     p.g.ntn = asr_cdiv(a.N, NT);
+    if (a.gate_rows) *a.gate_rows = p.g.ntm * WM;
     hipLaunchKernelGGL(kern, dim3(p.g.ntm * p.g.ntn), dim3(256), lds, st, p);
     ASR_CHECK_LAUNCH("tap_gemm_pw");
     ASR_NOTE_KERNEL("tap_gemm_kernel_v5<%d, %d, %d, %d, %d, %d, %d, %d, %d>", MT, NT, WM, WN, NTAPS, KCV, D, MINB, DIR);
@@ -884,7 +1019,7 @@ __global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_bx6(BxArgs args) {
     }
 
     __syncthreads();
-    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane, tile_m * WM + wm);
 }
 
 // W [ntaps][K][N] (HWIO; wmode 0) or its data-gradient view (wmode 1: taps mirrored, K and N swapped) ->
@@ -978,6 +1113,7 @@ int launch_v1(const TapGemmArgs& a, hipStream_t st) {
     TapGemmArgs g = a;
     g.ntm = asr_cdiv(a.M, MT);
     g.ntn = asr_cdiv(a.N, NT);
+    if (a.gate_rows) *a.gate_rows = g.ntm * WM;
     hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn), dim3(256), lds, st, g);
     ASR_CHECK_LAUNCH("tap_gemm");
     ASR_NOTE_KERNEL("tap_gemm_kernel_v1<%d, %d, %d, %d, %d, %d, %d>", MT, NT, WM, WN, NTAPS, WMODE, KCV);
@@ -1000,6 +1136,7 @@ int launch_v2(const TapGemmArgs& a, hipStream_t st) {
     TapGemmArgs g = a;
     g.ntm = asr_cdiv(a.M, MT);
     g.ntn = asr_cdiv(a.N, NT);
+    if (a.gate_rows) *a.gate_rows = g.ntm * WM;
     hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn), dim3(256), lds, st, g);
     ASR_CHECK_LAUNCH("tap_gemm");
     ASR_NOTE_KERNEL("tap_gemm_kernel<%d, %d, %d, %d, %d, %d>", MT, NT, WM, WN, NTAPS, WMODE);
@@ -1076,10 +1213,17 @@ int launch_n(const TapGemmArgs& a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float* W,
-                            const float* bias, const float* scale, const float* shift,
-                            float* out_a, float* out_y, void* stream) {
-    if (!d || !A || !W || (!out_a && !out_y)) return ASR_ERR_BAD_ARG;
+struct GateSpec { int mode, H, W; const float* a; float* dz; float* part; int* rows; };
+
+static void set_gate(TapGemmArgs& a, const GateSpec* gs) {
+    a.gate_mode = 0; a.gate_H = a.gate_W = 0; a.gate_a = nullptr; a.gate_dz = nullptr; a.gate_part = nullptr; a.gate_rows = nullptr;
+    if (gs) { a.gate_mode = gs->mode; a.gate_H = gs->H; a.gate_W = gs->W; a.gate_a = gs->a; a.gate_dz = gs->dz; a.gate_part = gs->part; a.gate_rows = gs->rows; }
+}
+
+static int tap_gemm_impl(const asr_gemm_desc* d, const float* A, const float* W,
+                         const float* bias, const float* scale, const float* shift,
+                         float* out_a, float* out_y, void* stream, const GateSpec* gs) {
+    if (!d || !A || !W || (!out_a && !out_y && !gs)) return ASR_ERR_BAD_ARG;
     if (d->ntaps != 1 && d->ntaps != 9 && d->ntaps != 4) return ASR_ERR_BAD_ARG;
     if ((d->K & 3) || (d->N & 3) || (d->lda & 3) || (d->ldw & 3)) return ASR_ERR_BAD_ARG;
     if (d->ntaps != 1 && d->H <= 0) return ASR_ERR_BAD_ARG;
@@ -1096,6 +1240,7 @@ extern "C" int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float*
     a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
     a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
     a.ntm = a.ntn = 0;
+    set_gate(a, gs);
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("ASR_TG_ABLATE"); ablate = e ? atoi(e) : 0; }
     a.ablate = ablate;
@@ -1103,6 +1248,12 @@ extern "C" int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float*
     if (d->ntaps == 9) return d->wmode ? launch_n<9, 1>(a, st) : launch_n<9, 0>(a, st);
     if (d->ntaps == 4) return d->wmode ? launch_n<4, 1>(a, st) : launch_n<4, 0>(a, st);
     return d->wmode ? launch_n<1, 1>(a, st) : launch_n<1, 0>(a, st);
+}
+
+extern "C" int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float* W,
+                            const float* bias, const float* scale, const float* shift,
+                            float* out_a, float* out_y, void* stream) {
+    return tap_gemm_impl(d, A, W, bias, scale, shift, out_a, out_y, stream, nullptr);
 }
 
 
@@ -1122,10 +1273,10 @@ extern "C" int asr_arrange_weights(const float* W, int ntaps, int K, int N, int 
     return ASR_OK;
 }
 
-extern "C" int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const float* Wf,
-                               const float* bias, const float* scale, const float* shift,
-                               float* out_a, float* out_y, void* stream) {
-    if (!d || !A || !Wf || (!out_a && !out_y)) return ASR_ERR_BAD_ARG;
+static int tap_gemm_pw_impl(const asr_gemm_desc* d, const float* A, const float* Wf,
+                            const float* bias, const float* scale, const float* shift,
+                            float* out_a, float* out_y, void* stream, const GateSpec* gs) {
+    if (!d || !A || !Wf || (!out_a && !out_y && !gs)) return ASR_ERR_BAD_ARG;
     if (d->ntaps != 1 && d->ntaps != 9) return ASR_ERR_BAD_ARG;
     if ((d->K & 3) || (d->N & 3) || (d->lda & 3)) return ASR_ERR_BAD_ARG;
     if (d->ntaps == 9 && d->H <= 0) return ASR_ERR_BAD_ARG;
@@ -1142,6 +1293,7 @@ extern "C" int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const flo
     a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
     a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
     a.ntm = a.ntn = 0; a.ablate = 0;
+    set_gate(a, gs);
     hipStream_t st = (hipStream_t)stream;
     const int dir = d->wmode ? 1 : 0;       // labels the launch only (distinct kernel symbols per direction)
     // tile choice (tools/bench_pw.py, MI355X): 128x64 workgroup tiles with a 16-deep chunk and a 3-unit ring win on every
@@ -1172,6 +1324,43 @@ extern "C" int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const flo
     if (d->N > 64) return launch_v5<128, 128, 2, 2, 1, 32, 4, 2>(a, Wf, dir, st);
     if (d->N > 32) return launch_v5<128, 64, 2, 2, 1, 32, 4, 3>(a, Wf, dir, st);
     return launch_v5<256, 32, 4, 1, 1, 32, 4, 3>(a, Wf, dir, st);
+}
+
+extern "C" int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const float* Wf,
+                               const float* bias, const float* scale, const float* shift,
+                               float* out_a, float* out_y, void* stream) {
+    return tap_gemm_pw_impl(d, A, Wf, bias, scale, shift, out_a, out_y, stream, nullptr);
+}
+
+// Data-gradient GEMM whose epilogue IS the backward prologue of the cell in front (tap_epilogue_gated).
+extern "C" size_t asr_tap_gemm_gated_workspace(const asr_gemm_desc* d) {
+    if (!d) return 0;
+    const int rows = asr_cdiv(d->M, 32) + 4;                  // every launch configuration has >= 32 tile rows per wave row (+ the ragged last tile)
+    return ((size_t)rows * 3 * d->N + asr_reduce::colsum_tmp_floats(rows, 3 * d->N)) * sizeof(float);
+}
+
+extern "C" int asr_tap_gemm_gated(const asr_gemm_desc* d, const float* dZ, const float* W, int prearranged,
+                                  int pool, int gate_H, int gate_W, const float* gate_a,
+                                  const float* bn_scale, const float* bn_shift, const float* dy_prev,
+                                  float* dz_out, float* dscale, float* dshift, float* dbias, float* partials, void* stream) {
+    if (!d || !dZ || !W || !gate_a || !bn_scale || !bn_shift || !dz_out || !dscale || !dshift || !dbias || !partials)
+        return ASR_ERR_BAD_ARG;
+    if (pool < 0 || pool > 2 || d->wmode != 1 || d->relu != 0 || d->y_unpadded) return ASR_ERR_BAD_ARG;
+    if (d->accumulate && !dy_prev) return ASR_ERR_BAD_ARG;
+    if (d->H <= 0) return ASR_ERR_UNSUPPORTED;                 // pixel-indexed outputs only
+    if (pool == 0 ? (gate_H != d->H || gate_W != d->W) : (gate_H != 2 * d->H || gate_W != 2 * d->W)) return ASR_ERR_BAD_ARG;
+    if (d->ldo_y != d->N) return ASR_ERR_BAD_ARG;
+    int rows = 0;
+    GateSpec gs;
+    gs.mode = pool + 1; gs.H = gate_H; gs.W = gate_W; gs.a = gate_a; gs.dz = dz_out; gs.part = partials; gs.rows = &rows;
+    const int rc = prearranged ? tap_gemm_pw_impl(d, dZ, W, nullptr, bn_scale, bn_shift, nullptr, (float*)dy_prev, stream, &gs)
+                               : tap_gemm_impl(d, dZ, W, nullptr, bn_scale, bn_shift, nullptr, (float*)dy_prev, stream, &gs);
+    if (rc != ASR_OK) return rc;
+    if (rows <= 0 || rows > asr_cdiv(d->M, 32) + 4) return ASR_ERR_UNSUPPORTED;
+    asr_reduce::Multi m;
+    m.nseg = 3; m.width[0] = d->N; m.width[1] = d->N; m.width[2] = d->N; m.width[3] = 0;
+    m.out[0] = dscale; m.out[1] = dshift; m.out[2] = dbias; m.out[3] = nullptr;
+    return asr_reduce::colsum_multi(partials, rows, 3L * d->N, m, partials + (size_t)rows * 3 * d->N, (hipStream_t)stream);
 }
 
 // ---- EXPERIMENTAL split-bf16 path (include/asr_hip.h): weights pre-split by asr_split_weights, then asr_tap_gemm_bx6
@@ -1211,6 +1400,7 @@ extern "C" int asr_tap_gemm_bx6(const asr_gemm_desc* d, const float* A, const vo
     a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
     a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
     a.ntm = a.ntn = 0; a.ablate = 0;
+    set_gate(a, nullptr);
     const int Kp = (d->K + 31) / 32 * 32;
     hipStream_t st = (hipStream_t)stream;
     const __bf16* Ws = (const __bf16*)Wsplit;

@@ -382,6 +382,34 @@ class DFCNNEngine:
             if op[0] == 'se':
                 self._dplane(op[2])
                 self._dplane(op[3])
+        self._plan_fused_prologues()
+        if self.ws_gate > self.ws.numel() * 4:
+            self.ws = torch.zeros(self.ws_gate // 4 + 64, dtype=torch.float32, device=dev)
+            self.ws_side = torch.zeros_like(self.ws) if self.side is not None else None
+
+    def _plan_fused_prologues(self):
+        """Cells whose backward prologue (pool -> BN -> ReLU backward + the three channel sums, asr_cell_bwd_pre) moves into
+        the epilogue of the data-gradient GEMM that COMPLETES their output gradient (asr_tap_gemm_gated): {writer cell ->
+        gated cell}.  The gradient plane of a cell's output may receive several contributions (an SE block's identity
+        branch is the plane itself, other consumers accumulate); the prologue can only run on the sum, i.e. in the LAST
+        writer of the backward pass = the FIRST writer in graph order, and only if that writer is a conv cell.  Not fused:
+        cells read by a dense layer (their gradient arrives in the dense layout), the first cell (own kernel), pooled cells
+        with odd plane sizes, and everything in split-bf16 mode."""
+        self.fuse, self.ws_gate = {}, 0
+        if self.bx6 or os.environ.get('ASR_FUSE_PRE', '1') != '1':
+            return
+        for c in self.g:
+            if c[0] != 'cell' or c[1] == 'x' or c[2] in self.dflat:
+                continue
+            H, W, _ = self.res[c[1]]
+            if c[6] and (H % 2 or W % 2):
+                continue
+            P = self._root(c[2])
+            writers = [o for o in self.g if (o[0] == 'cell' and o[1] != 'x' and self._root(o[1]) == P)
+                       or (o[0] == 'se' and self._root(o[2]) == P)]
+            if writers and writers[0][0] == 'cell' and writers[0][2] not in self.fuse:
+                self.fuse[writers[0][2]] = c[2]
+                self.ws_gate = max(self.ws_gate, ops.tap_gemm_gated_workspace(self.bdesc[writers[0][2]]))
 
     def _root(self, name):
         while name in self.alias:
@@ -551,6 +579,19 @@ class DFCNNEngine:
 
         dense_pending = sum(1 for op in self.g if op[0] == 'dense')
         side_busy, dz_reader, flip = None, {}, {}
+        fused_dz = {}          # cell name -> dZ plane already written by the data-gradient that completed its gradient
+
+        def acquire_dz(geo):
+            """The dZ plane of this geometry to write next (two per geometry, used alternately, when the weight-gradients
+            run on the side stream), after waiting for the weight-gradient that may still read it."""
+            dzp = self.dz_pool[geo]
+            if self.side is not None:
+                flip[geo] = not flip.get(geo, False)
+                if flip[geo]:
+                    dzp = self.dz_alt[geo]
+            if id(dzp) in dz_reader:
+                torch.cuda.current_stream().wait_event(dz_reader.pop(id(dzp)))
+            return dzp
         for op in reversed(self.g):
             if op[0] == 'dense':
                 _, src, dst, cin, cout, act = op
@@ -592,19 +633,16 @@ class DFCNNEngine:
                                   self.gview(dst, 'beta'), self.ws)
                     continue
                 H, W, _ = self.res[src]
-                dz = self.dz_pool[(H, W, cout)]
-                if self.side is not None:
-                    flip[(H, W, cout)] = not flip.get((H, W, cout), False)
-                    if flip[(H, W, cout)]:
-                        dz = self.dz_alt[(H, W, cout)]
-                if dst in self.dflat:
-                    dyv, layout = self.dflat[dst], 2
+                if dst in fused_dz:
+                    dz = fused_dz.pop(dst)           # written (with the channel sums) by the GEMM that completed dL/dy
                 else:
-                    dyv, layout = self._dplane(dst), (1 if pool else 0)
-                if id(dz) in dz_reader:              # an earlier weight-gradient may still read this dZ plane
-                    torch.cuda.current_stream().wait_event(dz_reader.pop(id(dz)))
-                ops.cell_bwd_pre(dyv, layout, self.a[dst], sc, sh, pm, dz, self.dscale_of(dst),
-                                 self.gview(dst, 'beta'), self.gview(dst, 'b'), self.ws)
+                    dz = acquire_dz((H, W, cout))
+                    if dst in self.dflat:
+                        dyv, layout = self.dflat[dst], 2
+                    else:
+                        dyv, layout = self._dplane(dst), (1 if pool else 0)
+                    ops.cell_bwd_pre(dyv, layout, self.a[dst], sc, sh, pm, dz, self.dscale_of(dst),
+                                     self.gview(dst, 'beta'), self.gview(dst, 'b'), self.ws)
                 # split-bf16 weight gradient where it wins (tools/bench_bx6.py): narrow planes (small halo) and >= 128 outputs
                 wgrad = ops.tap_wgrad_bx6 if (self.bx6 and k == 3 and cout >= 128 and W <= 64) else ops.tap_wgrad
                 def run_wgrad():
@@ -629,7 +667,19 @@ class DFCNNEngine:
                 dx, acc = grad_target(src)
                 d = self.bdesc[dst]
                 d.accumulate = 1 if acc else 0
-                if dst in self.ws_b:
+                tgt = self.fuse.get(dst)
+                if tgt is not None:
+                    # this GEMM completes dL/dy of cell `tgt`: its epilogue applies tgt's pool / BN / ReLU backward and
+                    # writes dZ(tgt) and the channel sums -- no asr_cell_bwd_pre pass for tgt
+                    top = next(o for o in self.g if o[0] == 'cell' and o[2] == tgt)
+                    Hf, Wf, _ = self.res[top[1]]
+                    dzt = acquire_dz((Hf, Wf, top[4]))
+                    ops.tap_gemm_gated(d, dz, self.wf_b[dst] if dst in self.wf_b else self.p(dst, 'w'), dst in self.wf_b,
+                                       {None: 0, 'avg': 1, 'max': 2}[top[6]], self.a[tgt], self.scale_of(tgt), self.p(tgt, 'beta'),
+                                       dx if acc else None, dzt, self.dscale_of(tgt), self.gview(tgt, 'beta'),
+                                       self.gview(tgt, 'b'), self.ws)
+                    fused_dz[tgt] = dzt
+                elif dst in self.ws_b:
                     ops.tap_gemm_bx6(d, dz, self.ws_b[dst], None, None, None, None, dx, dgrad=True)
                 elif dst in self.wf_b:
                     ops.tap_gemm_pw(d, dz, self.wf_b[dst], None, None, None, None, dx)

@@ -117,6 +117,22 @@ def tap_gemm(desc, A, W, bias=None, scale=None, shift=None, out_a=None, out_y=No
         'asr_tap_gemm'))
 
 
+def tap_gemm_gated_workspace(desc):
+    return _lib.load().asr_tap_gemm_gated_workspace(C.byref(desc))
+
+
+def tap_gemm_gated(desc, dZ, W, prearranged, pool, gate_a, bn_scale, bn_shift, dy_prev, dz_out, dscale, dshift, dbias, partials):
+    """Data-gradient of a cell with the backward prologue of the cell in front fused into its epilogue
+    (asr_tap_gemm_gated): gate_a / dz_out are Planes of that cell's pre-pool geometry."""
+    lib = _lib.load()
+    pz = dZ.ptr if isinstance(dZ, Plane) else _ptr(dZ)
+    pp = dy_prev.ptr if isinstance(dy_prev, Plane) else _ptr(dy_prev)
+    _timed(desc, lambda: check(
+        lib.asr_tap_gemm_gated(C.byref(desc), pz, _ptr(W), int(prearranged), int(pool), gate_a.H, gate_a.W, gate_a.ptr,
+                               _ptr(bn_scale), _ptr(bn_shift), pp, dz_out.ptr, _ptr(dscale), _ptr(dshift), _ptr(dbias),
+                               _ptr(partials), _stream()), 'asr_tap_gemm_gated'))
+
+
 def tap_wgrad_workspace(desc):
     return _lib.load().asr_tap_wgrad_workspace(C.byref(desc))
 

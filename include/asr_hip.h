@@ -395,6 +395,25 @@ int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const float* Warrang
                     const float* bias, const float* scale, const float* shift,
                     float* out_a, float* out_y, void* stream);
 
+/* ------------------------------------------------------------------ fused backward prologue (round 2)
+ * The data-gradient of cell k, with the backward of cell k-1's [pool ->] BN -> ReLU (what asr_cell_bwd_pre computes in a
+ * pass of its own: tf.gradients through average_pooling2d / max_pooling2d, batch_normalization and relu,
+ * acoustic_model2.py:107-133, acoustic_model.py:103-130) applied in the GEMM's epilogue: the tile of dL/dy(k-1) never
+ * goes to memory, dZ(k-1) is written directly, and the per-channel sums come out as tile partials folded in a fixed order.
+ *   d          the data-gradient descriptor (wmode 1, ntaps 9 or 1, pixel-indexed: H, W = the plane of cell k-1's OUTPUT)
+ *   dZ, W      as for asr_tap_gemm (W HWIO) or asr_tap_gemm_pw (prearranged != 0: data-gradient view from asr_arrange_weights)
+ *   pool       0 none, 1 average 2x2, 2 maximum 2x2 (first maximum of bn_scale * a + bn_shift in row-major window order)
+ *   gate_H/W   cell k-1's pre-pool plane: H x W for pool 0, 2H x 2W otherwise (odd sizes are not supported: use asr_cell_bwd_pre)
+ *   gate_a     cell k-1's post-ReLU pre-BN activations, padded plane [B][gate_H+1][gate_W+1][N]
+ *   dy_prev    with d->accumulate: the plane holding the gradient contributions already made to y(k-1) (read only)
+ *   dz_out     padded plane like gate_a: dL/d(conv + bias) of cell k-1; every interior pixel is written
+ *   dscale, dshift, dbias [N];  partials: asr_tap_gemm_gated_workspace(d) bytes */
+size_t asr_tap_gemm_gated_workspace(const asr_gemm_desc* d);
+int asr_tap_gemm_gated(const asr_gemm_desc* d, const float* dZ, const float* W, int prearranged,
+                       int pool, int gate_H, int gate_W, const float* gate_a,
+                       const float* bn_scale, const float* bn_shift, const float* dy_prev,
+                       float* dz_out, float* dscale, float* dshift, float* dbias, float* partials, void* stream);
+
 /* ====================================================================== EXPERIMENTAL: split-bf16 contractions
  * (DESIGN.md section 9).  Same contraction and epilogue as asr_tap_gemm, computed as six v_mfma_f32_32x32x16_bf16
  * products of the hi/mid/lo bf16 pieces of the fp32 operands with fp32 accumulation (fp32-chain accuracy, 2.6x the matrix
