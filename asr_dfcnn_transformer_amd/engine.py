@@ -332,10 +332,11 @@ class DFCNNEngine:
         # overlapped kernels then overlap in any profile.  Results are bitwise the same as with one stream.
         self.side = torch.cuda.Stream(device=dev) if os.environ.get('ASR_DUAL_STREAM', '1') == '1' else None
         self.wgrad_first = os.environ.get('ASR_WGRAD_FIRST', '0') == '1'
-        # measured (gpurun_out/r02b/bench6.txt): +1.6 % on the SE graphs (whose backward has more HBM-bound kernels between the
-        # contractions: SE backward, two prologues per block), -1 % on the plain chain of acoustic_model.py
-        has_se = any(op[0] == 'se' for op in self.g)
-        self.wgrad_after_dgrad = os.environ.get('ASR_WGRAD_AFTER_DGRAD', '1' if has_se else '0') == '1'
+        # experiment switch: start a weight-gradient only when its data-gradient has finished.  Before the backward
+        # prologues were fused into the data-gradient epilogues it was worth +1.6 % on the SE graphs (more HBM-bound kernels
+        # between the contractions to run beside), -1 % on acoustic_model.py; with the fusion it loses on both
+        # (gpurun_out/r02b/bench6.txt, r02h): off
+        self.wgrad_after_dgrad = os.environ.get('ASR_WGRAD_AFTER_DGRAD', '0') == '1'
         if os.environ.get('ASR_SIDE_PRIO'):              # experiment: explicit priority of the side stream
             self.side = torch.cuda.Stream(device=dev, priority=int(os.environ['ASR_SIDE_PRIO']))
         self.ws_side = torch.zeros_like(self.ws) if self.side is not None else None
