@@ -384,6 +384,10 @@ class DFCNNEngine:
                 self._dplane(op[2])
                 self._dplane(op[3])
         self._plan_fused_prologues()
+        if self.fuse and not self.dz_alt:
+            # a fused data-gradient reads dZ of its own cell while its epilogue writes dZ of the cell in front: two planes
+            # per geometry are needed on one stream as well (the two cells may share a geometry)
+            self.dz_alt = {geo: Plane(p.B, p.H, p.W, p.C, dev) for geo, p in self.dz_pool.items()}
         if self.ws_gate > self.ws.numel() * 4:
             self.ws = torch.zeros(self.ws_gate // 4 + 64, dtype=torch.float32, device=dev)
             self.ws_side = torch.zeros_like(self.ws) if self.side is not None else None
@@ -586,7 +590,7 @@ class DFCNNEngine:
             """The dZ plane of this geometry to write next (two per geometry, used alternately, when the weight-gradients
             run on the side stream), after waiting for the weight-gradient that may still read it."""
             dzp = self.dz_pool[geo]
-            if self.side is not None:
+            if geo in self.dz_alt:
                 flip[geo] = not flip.get(geo, False)
                 if flip[geo]:
                     dzp = self.dz_alt[geo]

@@ -152,3 +152,37 @@ def test_session_style_model_trains_and_checkpoints(tmp_path):
     m2 = CNNCTCModel(hp, 12, 6345, widths=(8, 16, 32, 64), seed=5)
     tr.load_checkpoint(m2, p)
     assert torch.equal(m2.engine.theta, m.engine.theta) and m2.global_step == 25
+
+
+@pytest.mark.parametrize("model,widths", [('m2', (16, 32, 32, 64)), ('m1', (8, 16, 32, 64, 8, 32)), ('m3', (8, 16, 32, 64))])
+def test_stream_and_fusion_modes_give_the_same_bits(model, widths, monkeypatch):
+    """The same step with the backward on one stream or two, and with the backward prologues fused into the data-gradient
+    epilogues or run as passes of their own: dZ is the same arithmetic either way, so the weight / bias gradients are
+    bitwise equal; the three BN / bias channel sums of fused cells are folded in another (fixed) order -> 1e-6."""
+    from asr_dfcnn_transformer_amd.engine import DFCNNEngine
+    rng = np.random.default_rng(5)
+    B, T, F, V = 2, 64, 24, 20
+    x = torch.tensor(rng.standard_normal((B, T, F)).astype(np.float32), device='cuda')
+    tgt = np.zeros((B, 64), dtype=np.int32)
+    tgt[:, :3] = rng.integers(1, V - 1, (B, 3))
+    grads = {}
+    for dual in ('1', '0'):
+        for fuse in ('1', '0'):
+            monkeypatch.setenv('ASR_DUAL_STREAM', dual); monkeypatch.setenv('ASR_FUSE_PRE', fuse)
+            eng = DFCNNEngine(model=model, vocab=V, B=B, T=T, F=F, widths=widths, seed=1)
+            assert bool(eng.fuse) == (fuse == '1') and (eng.side is not None) == (dual == '1')
+            for _ in range(2):
+                eng.forward(x); eng.set_targets([8, 8], tgt); eng.loss_and_decode(); eng.backward()
+            torch.cuda.synchronize()
+            grads[(dual, fuse)] = (eng.grad.clone(), eng)
+    assert torch.equal(grads[('1', '1')][0], grads[('0', '1')][0])          # streams: same bits
+    assert torch.equal(grads[('1', '0')][0], grads[('0', '0')][0])
+    a, e = grads[('1', '1')]
+    b, _ = grads[('1', '0')]
+    for (layer, key), (off, shape) in e.entries.items():
+        n = int(np.prod(shape))
+        ga, gb = a[off:off + n], b[off:off + n]
+        if key in ('w', 'w1', 'w2', 'b1', 'b2'):
+            assert torch.equal(ga, gb), (layer, key)
+        else:
+            assert (ga - gb).abs().max().item() <= 1e-6 * max(1e-6, gb.abs().max().item()), (layer, key)
