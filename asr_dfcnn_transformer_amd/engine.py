@@ -461,10 +461,25 @@ class DFCNNEngine:
             cin, cout = self._cell_dims[dst]
             ops.split_weights(self.p(dst, 'w'), 9, cin, cout, cout, 0, buf)
             ops.split_weights(self.p(dst, 'w'), 9, cout, cin, cout, 1, self.ws_b[dst])
-        for dst, buf in self.wf_f.items():
-            cin, cout = self._cell_dims[dst]
-            ops.arrange_weights(self.p(dst, 'w'), 9, cin, cout, cout, 0, buf)
-            ops.arrange_weights(self.p(dst, 'w'), 9, cout, cin, cout, 1, self.wf_b[dst])
+        # the fragment-order weight copies (two small launches per 3x3 layer, ~20 in all) are not needed before the second
+        # cell: they run on the side stream beside the VALU-bound first cell instead of in front of it
+        wf_ready = None
+        if self.wf_f and self.side is not None:
+            params_final = torch.cuda.Event()
+            params_final.record()                         # Adam of the previous step / load_params are on the main stream
+            self.side.wait_event(params_final)
+            with torch.cuda.stream(self.side):
+                for dst, buf in self.wf_f.items():
+                    cin, cout = self._cell_dims[dst]
+                    ops.arrange_weights(self.p(dst, 'w'), 9, cin, cout, cout, 0, buf)
+                    ops.arrange_weights(self.p(dst, 'w'), 9, cout, cin, cout, 1, self.wf_b[dst])
+                wf_ready = torch.cuda.Event()
+                wf_ready.record()
+        else:
+            for dst, buf in self.wf_f.items():
+                cin, cout = self._cell_dims[dst]
+                ops.arrange_weights(self.p(dst, 'w'), 9, cin, cout, cout, 0, buf)
+                ops.arrange_weights(self.p(dst, 'w'), 9, cout, cin, cout, 1, self.wf_b[dst])
         for op in self.g:
             if op[0] == 'cell':
                 _, src, dst, cin, cout, k, pool = op
@@ -473,6 +488,9 @@ class DFCNNEngine:
                 if src == 'x':
                     ops.cell1_fwd(x, self.p(dst, 'w'), self.p(dst, 'b'), sc, sh, pm, self.y[dst])
                     continue
+                if wf_ready is not None:
+                    torch.cuda.current_stream().wait_event(wf_ready)
+                    wf_ready = None
                 out_y = None if pool else (self.flat[dst] if dst in self.flat else self.y[dst])
                 if dst in self.ws_f:
                     ops.tap_gemm_bx6(self.fdesc[dst], self.y[src], self.ws_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], out_y)
