@@ -110,15 +110,25 @@ __global__ __launch_bounds__(256) void cell1_kernel(const float* __restrict__ x,
         }
     }
     if (BWD) {
-        __syncthreads();
-        float* red = smem;               // [nslots][12][C]
+        // C = 32: the two slots of a wave meet by one shuffle first, which halves the scratch (6 KB) -- small enough to
+        // run beside a one-workgroup-per-CU weight-gradient kernel that holds 150 KB of the CU's LDS
+        const bool pair = (C == 32);
+        if (pair) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) red[(slot * 12 + k) * C + c] = gsum[k];
+            for (int k = 0; k < 12; ++k) gsum[k] += __shfl_xor(gsum[k], 32, 64);
+        }
+        const int rslot = pair ? slot >> 1 : slot, rslots = pair ? nslots >> 1 : nslots;
+        __syncthreads();
+        float* red = smem;               // [rslots][12][C]
+        if (!pair || !(slot & 1)) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) red[(rslot * 12 + k) * C + c] = gsum[k];
+        }
         __syncthreads();
         float* out = partials + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 12 * C;
         for (int i = tid; i < 12 * C; i += 256) {
             float sum = 0.f;
-            for (int sl = 0; sl < nslots; ++sl) sum += red[sl * 12 * C + i];
+            for (int sl = 0; sl < rslots; ++sl) sum += red[sl * 12 * C + i];
             out[i] = sum;
         }
     }
@@ -481,7 +491,7 @@ extern "C" int asr_cell1_bwd(const float* x, int B, int T, int F, int C, const f
     dim3 grid(asr_cdiv(H2, kCell1RPB), B);
     const int nblk = grid.x * grid.y;
     size_t lds = (size_t)4 * (F + 2) * sizeof(float);
-    const size_t red = (size_t)(256 / C) * 12 * C * sizeof(float);
+    const size_t red = (size_t)(C == 32 ? 4 : 256 / C) * 12 * C * sizeof(float);
     if (red > lds) lds = red;
     hipStream_t st = (hipStream_t)stream;
     if (pool == 1)

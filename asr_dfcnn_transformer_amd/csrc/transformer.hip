@@ -22,6 +22,15 @@ namespace {
 constexpr float MASK_FILL = -4294967296.0f;     // float32(-2**32 + 1)
 constexpr int DH = 64;                          // head width (hidden_units / num_heads = 512 / 8)
 constexpr int KP = DH + 4;                      // LDS pitch of tiles read with ds_read_b128
+// The fp32 MFMA shares the SIMD's vector issue with every other vector instruction (tools/mfma_valu.hip: an MFMA-only
+// wave and a VALU-only wave on one SIMD take the SUM of their times), so each vector instruction of the softmax costs
+// its full issue time.  The scores are therefore kept in base-2 units (q pre-scaled by log2(e) / sqrt(d)): one v_sub +
+// one v_exp_f32 per element instead of expf's 13 instructions, and the key mask is one compare + select against a per-key
+// bias staged with the tile (a wave-uniform branch around the mask code cost 300 spilled registers instead).
+constexpr float LOG2E = 1.44269504088896340736f;
+constexpr float QSCALE2 = 0.125f * LOG2E;        // 1 / sqrt(64), in base-2 units
+constexpr float FILL2 = MASK_FILL * LOG2E;       // the fill value in the same units
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 __device__ __forceinline__ int rowidx(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
@@ -36,7 +45,9 @@ __device__ __forceinline__ bool drop_keep(uint32_t idx, uint32_t seed, uint32_t 
 }
 
 // stage a [rows x 64] head slice of X[n][t][C] into LDS with pitch KP; rows beyond T are zero.
-// 16 consecutive lanes own one row, so a 16-lane xor-reduction gives per-row statistics.
+// 16 consecutive lanes own one row, so a 16-lane xor-reduction gives per-row statistics: the row sum (stat_mode 0), the
+// sum of magnitudes (1), or the key bias of the row (2): 0 for a real key, the fill value for a key-masked one (zero row
+// sum), -inf for a row past the end -- what a score is replaced by when the bias is not 0.
 __device__ __forceinline__ void stage_tile(float* dst, const float* __restrict__ X, long base_row, int row0, int nrows,
                                            int T, int C, int hoff, int tid, float scale, float* rowstat, int stat_mode) {
     for (int f = tid; f < nrows * 16; f += 256) {
@@ -44,9 +55,10 @@ __device__ __forceinline__ void stage_tile(float* dst, const float* __restrict__
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row0 + row < T) v = *(const float4*)(X + (base_row + row0 + row) * C + hoff + c4 * 4);
         if (rowstat) {
-            float s = (stat_mode == 0) ? (v.x + v.y + v.z + v.w) : (fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w));
+            float s = (stat_mode != 1) ? (v.x + v.y + v.z + v.w) : (fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w));
 #pragma unroll
             for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (stat_mode == 2) s = (row0 + row < T) ? (s != 0.f ? 0.f : FILL2) : -INFINITY;
             if (c4 == 0) rowstat[row] = s;
         }
         v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
@@ -120,8 +132,8 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const flo
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < Tq) v = *(const float4*)(Q + (qbase + q) * ldq + hoff + 8 * g + 4 * lh);
         qabs += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
-        qreg[g * 4 + 0] = v.x * 0.125f; qreg[g * 4 + 1] = v.y * 0.125f;
-        qreg[g * 4 + 2] = v.z * 0.125f; qreg[g * 4 + 3] = v.w * 0.125f;
+        qreg[g * 4 + 0] = v.x * QSCALE2; qreg[g * 4 + 1] = v.y * QSCALE2;
+        qreg[g * 4 + 2] = v.z * QSCALE2; qreg[g * 4 + 3] = v.w * QSCALE2;
     }
     qabs += __shfl_xor(qabs, 32, 64);
     const float qmask = (qabs != 0.f) ? 1.f : 0.f;
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const flo
             if (__syncthreads_and((q >= Tq) || (m_run > -1.0e9f))) break;
         }
         __syncthreads();
-        stage_tile(Ks, K, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, kstat, 0);
+        stage_tile(Ks, K, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, kstat, 2);
         stage_tile(Vs, V, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, nullptr, 0);
         __syncthreads();
 #pragma unroll
@@ -162,20 +174,20 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const flo
             float mt = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kl = sub * 32 + rowidx(r, lh), key = k0 + kl;
+                const int kl = sub * 32 + rowidx(r, lh);
+                const float kb = kstat[kl];                      // key bias (stage_tile, mode 2)
                 float v = s[r];
-                const bool keep = (kstat[kl] != 0.f) && (!CAUSAL || key <= q);
-                v = keep ? v : MASK_FILL;
-                v = (key < Tk) ? v : -INFINITY;
+                if (CAUSAL) v = (k0 + kl <= q) ? v : FILL2;
+                v = (kb == 0.f) ? v : kb;
                 s[r] = v;
                 mt = fmaxf(mt, v);
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float m_new = fmaxf(m_run, mt);
-            const float alpha = expf(m_run - m_new);
+            const float alpha = ex2(m_run - m_new);
             float lt = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_new); lt += s[r]; }
+            for (int r = 0; r < 16; ++r) { s[r] = ex2(s[r] - m_new); lt += s[r]; }
             lt += __shfl_xor(lt, 32, 64);
             l_run = l_run * alpha + lt;
             m_run = m_new;
@@ -195,9 +207,9 @@ __global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const flo
         }
     }
     __syncthreads();
-    if (q < Tq && lh == 0) {      // kept as (max, log-sum) pair: max may be the -2^32+1 fill, which would swallow log(l)
+    if (q < Tq && lh == 0) {      // kept as (max, log-sum) pair, both in base-2 units: max may be the fill, which would swallow log(l)
         lse[((long)n * H + head) * Tq + q] = m_run;
-        lse[(long)Nn * H * Tq + ((long)n * H + head) * Tq + q] = logf(l_run);
+        lse[(long)Nn * H * Tq + ((long)n * H + head) * Tq + q] = log2f(l_run);
     }
     store_tile_T(O, Ks + wave * (32 * 65), oacc, qmask / l_run, qbase, q0, Tq, C, hoff, lane);
 }
@@ -258,11 +270,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
             b = *(const float4*)(V + (kbase + key) * ldk + hoff + 8 * g + 4 * lh);
         }
         ksum += a.x + a.y + a.z + a.w;
-        kreg[g * 4 + 0] = a.x; kreg[g * 4 + 1] = a.y; kreg[g * 4 + 2] = a.z; kreg[g * 4 + 3] = a.w;
+        // K only feeds the score recomputation here: pre-scaled to base-2 units of the scaled scores
+        kreg[g * 4 + 0] = a.x * QSCALE2; kreg[g * 4 + 1] = a.y * QSCALE2; kreg[g * 4 + 2] = a.z * QSCALE2; kreg[g * 4 + 3] = a.w * QSCALE2;
         vreg[g * 4 + 0] = b.x; vreg[g * 4 + 1] = b.y; vreg[g * 4 + 2] = b.z; vreg[g * 4 + 3] = b.w;
     }
     ksum += __shfl_xor(ksum, 32, 64);
-    const bool kkeep = (ksum != 0.f);
+    const bool kkeep = (ksum != 0.f) && (key < Tk);
+    const float kfill = (key < Tk) ? FILL2 : -INFINITY;
 
     floatx16 dk[2], dv[2];
 #pragma unroll
@@ -319,19 +333,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
                 dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.w, vreg[g * 4 + 3], dp, 0, 0, 0);
             }
             // rows of s/dp = queries rowidx(r, lh), column = this lane's key
+            // s <- P (as dV sees it), dp <- dS / 0.125 (the 1 / sqrt(d) is applied when dK is stored)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ql = rowidx(r, lh), q = q0 + sub * 32 + ql;
                 const bool keep = kkeep && (!CAUSAL || key <= q);
-                const float sv = keep ? s[r] * 0.125f : MASK_FILL;
-                const float p = (key < Tk) ? expf((sv - lse_t[ql]) - lsl_t[ql]) : 0.f;
+                const float sv = keep ? s[r] : kfill;            // fill value, or -inf (p = 0) for a key past the end
+                const float p = ex2((sv - lse_t[ql]) - lsl_t[ql]);
                 float pd = p, dpe = dp[r];
                 if (DROP) {        // O = (P o M / (1-rate)) V: dV sees the dropped weights, dP arrives through the same mask
                     const bool dm = drop_keep((uint32_t)(((n * H + head) * Tq + q) * Tk + key), drop_seed, drop_thr);
                     pd = dm ? p * drop_scale : 0.f;
                     dpe = dm ? dpe * drop_scale : 0.f;
                 }
-                const float ds = keep ? p * (dpe - del_t[ql]) * 0.125f : 0.f;
+                const float ds = keep ? p * (dpe - del_t[ql]) : 0.f;
                 s[r] = pd; dp[r] = ds;
             }
 #pragma unroll
@@ -345,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
             }
         }
     }
-    store_tile_T(dK, scratch + wave * (32 * 65), dk, 1.f, kbase, k0, Tk, ldk, hoff, lane, relu_grad ? K : nullptr);
+    store_tile_T(dK, scratch + wave * (32 * 65), dk, 0.125f, kbase, k0, Tk, ldk, hoff, lane, relu_grad ? K : nullptr);
     store_tile_T(dV, scratch + wave * (32 * 65), dv, 1.f, kbase, k0, Tk, ldk, hoff, lane, relu_grad ? V : nullptr);
 }
 
@@ -378,7 +393,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
             b = *(const float4*)(dO + (qbase + q) * C + hoff + 8 * g + 4 * lh);
         }
         qabs += fabsf(a.x) + fabsf(a.y) + fabsf(a.z) + fabsf(a.w);
-        qreg[g * 4 + 0] = a.x * 0.125f; qreg[g * 4 + 1] = a.y * 0.125f; qreg[g * 4 + 2] = a.z * 0.125f; qreg[g * 4 + 3] = a.w * 0.125f;
+        qreg[g * 4 + 0] = a.x * QSCALE2; qreg[g * 4 + 1] = a.y * QSCALE2; qreg[g * 4 + 2] = a.z * QSCALE2; qreg[g * 4 + 3] = a.w * QSCALE2;
         doreg[g * 4 + 0] = b.x; doreg[g * 4 + 1] = b.y; doreg[g * 4 + 2] = b.z; doreg[g * 4 + 3] = b.w;
     }
     qabs += __shfl_xor(qabs, 32, 64);
@@ -396,7 +411,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
     for (int k0 = 0; k0 < Tk; k0 += 64) {
         if (CAUSAL && k0 > qtile * 128 + 127) break;     // masked scores get no gradient: nothing for dQ there
         __syncthreads();
-        stage_tile(Ks, K, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, kstat, 0);
+        stage_tile(Ks, K, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, kstat, 2);
         stage_tile(Vs, V, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, nullptr, 0);
         __syncthreads();
 #pragma unroll
@@ -418,15 +433,19 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
                 dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.z, doreg[g * 4 + 2], dp, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.w, doreg[g * 4 + 3], dp, 0, 0, 0);
             }
+            // dp <- dS / 0.125 (the 1 / sqrt(d) is applied when dQ is stored)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kl = sub * 32 + rowidx(r, lh), key = k0 + kl;
-                const bool keep = (kstat[kl] != 0.f) && (!CAUSAL || key <= q);
-                const float sv = keep ? s[r] : MASK_FILL;
-                const float p = (key < Tk) ? expf((sv - my_lse) - my_lsl) : 0.f;
+                const int kl = sub * 32 + rowidx(r, lh);
+                const float kb = kstat[kl];                      // key bias (stage_tile, mode 2)
+                const bool keep = (kb == 0.f) && (!CAUSAL || k0 + kl <= q);
+                float sv = s[r];
+                if (CAUSAL) sv = (k0 + kl <= q) ? sv : FILL2;
+                sv = (kb == 0.f) ? sv : kb;
+                const float p = ex2((sv - my_lse) - my_lsl);
                 float dpe = dp[r];
-                if (DROP) dpe = drop_keep((uint32_t)(((n * H + head) * Tq + q) * Tk + key), drop_seed, drop_thr) ? dpe * drop_scale : 0.f;
-                dp[r] = keep ? p * (dpe - my_del) * 0.125f : 0.f;
+                if (DROP) dpe = drop_keep((uint32_t)(((n * H + head) * Tq + q) * Tk + k0 + kl), drop_seed, drop_thr) ? dpe * drop_scale : 0.f;
+                dp[r] = keep ? p * (dpe - my_del) : 0.f;
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -437,7 +456,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
         }
     }
     __syncthreads();
-    store_tile_T(dQ, Ks + wave * (32 * 65), dq, 1.f, qbase, q0, Tq, ldq, hoff, lane, relu_grad ? Q : nullptr);
+    store_tile_T(dQ, Ks + wave * (32 * 65), dq, 0.125f, qbase, q0, Tq, ldq, hoff, lane, relu_grad ? Q : nullptr);
 }
 
 // ------------------------------------------------------------------ (add +) LayerNorm

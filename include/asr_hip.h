@@ -247,7 +247,8 @@ int asr_adam_tf(float* theta, const float* grad, float* m, float* v, size_t n,
  *   causal: keys > query get -2^32+1; softmax; rows whose per-head |Q| sum is 0 are zeroed
  *   (query mask, applied AFTER the softmax); O = P V_h merged back to [N][Tq][C].
  *   lse [2][N][H][Tq] (row max and log of the row sum of the masked scores, kept apart because
- *   the max can be the -2^32+1 fill value) is saved for the backward.
+ *   the max can be the -2^32+1 fill value; both in base-2 units of the scaled scores, i.e. times
+ *   log2(e): the kernels exponentiate with v_exp_f32) is saved for the backward -- an opaque carry.
  * Backward: dQ, dK, dV (=).  Masked scores receive no gradient (tf.where), V still does.
  *   relu_grad != 0: Q, K, V are outputs of Dense(activation=relu) (transformer.py:139-141) and the
  *   returned gradients are those of the pre-activations, i.e. dQ *= (Q > 0) etc., fused in the store.

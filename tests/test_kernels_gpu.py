@@ -162,7 +162,7 @@ def test_dense_wgrad(ops, M, K, N):
 
 # ------------------------------------------------------------------ first cell
 @pytest.mark.parametrize("pool", ['avg', 'max'])
-@pytest.mark.parametrize("B,T,F,C", [(2, 16, 12, 32), (1, 33, 21, 8), (2, 24, 200, 32)])
+@pytest.mark.parametrize("B,T,F,C", [(2, 16, 12, 32), (1, 33, 21, 8), (2, 24, 200, 32), (1, 35, 37, 32), (3, 18, 16, 32)])
 def test_cell1_fwd_bwd(ops, pool, B, T, F, C):
     rng = np.random.default_rng(6)
     x = rng.standard_normal((B, T, F, 1)).astype(np.float32)

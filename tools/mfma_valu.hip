@@ -1,0 +1,135 @@
+// Do VALU instructions hide under fp32 MFMAs?  (a) one wave per SIMD: NV independent v_fma between consecutive
+// v_mfma_f32_32x32x2_f32; (b) two waves per SIMD, one MFMA-only and one VALU-only (even / odd workgroups of a CU share SIMDs).
+// hipcc --offload-arch=gfx950 -O3 tools/mfma_valu.hip -o tools/mfma_valu.bin
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+// the same pairing with v_mfma_f32_16x16x4_f32 (two independent accumulators = the flops of one 32x32x2)
+template <int NV>
+__global__ __launch_bounds__(512) void split16_loop(float* out, int iters, float a0, float b0, int mode) {
+    floatx4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    float a = a0 + threadIdx.x * 1e-6f, b = b0;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = a + i;
+    const int wv = threadIdx.x >> 6;
+    const bool do_mfma = (mode == 0 || mode == 2) && wv < 4;
+    const bool do_valu = (mode == 1 || mode == 2) && wv >= 4;
+    if (do_mfma) {
+        for (int it = 0; it < iters; ++it) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc1, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (do_valu) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i % 16] = __builtin_fmaf(v[i % 16], b, a);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = acc0[0] + acc1[3];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+template <int NV, int MF>
+__global__ __launch_bounds__(256) void mix_loop(float* out, int iters, float a0, float b0) {
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float a = a0 + threadIdx.x * 1e-6f, b = b0;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = a + i;
+    for (int it = 0; it < iters; ++it) {
+        if (MF) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i % 16] = __builtin_fmaf(v[i % 16], b, a);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = acc[0] + acc[15];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// role by wave of a 512-thread workgroup: waves 0-3 MFMA-only, waves 4-7 VALU-only (NV v_fma per iteration); wave w and
+// wave w + 4 share a SIMD
+template <int NV>
+__global__ __launch_bounds__(512) void split_loop(float* out, int iters, float a0, float b0, int mode) {
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float a = a0 + threadIdx.x * 1e-6f, b = b0;
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = a + i;
+    const int wv = threadIdx.x >> 6;
+    const bool do_mfma = (mode == 0 || mode == 2) && wv < 4;
+    const bool do_valu = (mode == 1 || mode == 2) && wv >= 4;
+    if (do_mfma) {
+        for (int it = 0; it < iters; ++it) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    if (do_valu) {
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) v[i % 16] = __builtin_fmaf(v[i % 16], b, a);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = acc[0] + acc[15];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += v[i];
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
+template <typename F>
+float timeit(F launch) {
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    launch(); hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int r = 0; r < 3; ++r) launch();
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    return ms / 3;
+}
+
+template <int NV>
+void run_mix(float* out, int iters) {
+    float t1 = timeit([&] { hipLaunchKernelGGL((mix_loop<NV, 1>), dim3(256), dim3(256), 0, 0, out, iters, 1.0f, 0.5f); });
+    float t0 = timeit([&] { hipLaunchKernelGGL((mix_loop<NV, 0>), dim3(256), dim3(256), 0, 0, out, iters, 1.0f, 0.5f); });
+    printf("one wave/SIMD: 1 MFMA + %2d v_fma per iteration: %.1f cyc/iter at 2.4 GHz   (v_fma alone %.1f)\n", NV, t1 * 1e-3 * 2.4e9 / iters, t0 * 1e-3 * 2.4e9 / iters);
+}
+
+template <int NV>
+void run_split(float* out, int iters) {
+    float tm = timeit([&] { hipLaunchKernelGGL((split_loop<NV>), dim3(256), dim3(512), 0, 0, out, iters, 1.0f, 0.5f, 0); });
+    float tv = timeit([&] { hipLaunchKernelGGL((split_loop<NV>), dim3(256), dim3(512), 0, 0, out, iters, 1.0f, 0.5f, 1); });
+    float tb = timeit([&] { hipLaunchKernelGGL((split_loop<NV>), dim3(256), dim3(512), 0, 0, out, iters, 1.0f, 0.5f, 2); });
+    printf("two waves/SIMD, NV %2d: MFMA-only wave %.3f ms, VALU-only wave %.3f ms, both side by side %.3f ms\n", NV, tm, tv, tb);
+}
+
+template <int NV>
+void run_split16(float* out, int iters) {
+    float tm = timeit([&] { hipLaunchKernelGGL((split16_loop<NV>), dim3(256), dim3(512), 0, 0, out, iters, 1.0f, 0.5f, 0); });
+    float tv = timeit([&] { hipLaunchKernelGGL((split16_loop<NV>), dim3(256), dim3(512), 0, 0, out, iters, 1.0f, 0.5f, 1); });
+    float tb = timeit([&] { hipLaunchKernelGGL((split16_loop<NV>), dim3(256), dim3(512), 0, 0, out, iters, 1.0f, 0.5f, 2); });
+    printf("16x16x4 x2, two waves/SIMD, NV %2d: MFMA-only wave %.3f ms, VALU-only wave %.3f ms, both side by side %.3f ms\n", NV, tm, tv, tb);
+}
+
+int main() {
+    float* out; hipMalloc(&out, 512 * 512 * sizeof(float));
+    const int iters = 200000;
+    run_mix<0>(out, iters); run_mix<4>(out, iters); run_mix<8>(out, iters); run_mix<12>(out, iters); run_mix<16>(out, iters); run_mix<24>(out, iters); run_mix<32>(out, iters);
+    run_split<8>(out, iters); run_split<16>(out, iters); run_split<32>(out, iters);
+    run_split16<8>(out, iters); run_split16<16>(out, iters); run_split16<32>(out, iters);
+    return 0;
+}
