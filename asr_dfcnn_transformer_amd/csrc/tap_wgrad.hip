@@ -986,6 +986,31 @@ Plan6 make_plan6(const asr_gemm_desc* d) {
     q.lds = lds_for(q.ps);
     q.p = make_plan(d, blocks_force > 0 ? blocks_force : 256 * q.minb, 128, q.ps);
     q.p.ktile = KT; q.p.ntile = NT;
+    if (d->ntaps == 1 && blocks_force <= 0) {
+        // Dense layers: the chunk count is picked from the beat model (a CU finishes its workgroups at a fixed aggregate
+        // rate, so a grid costs ceil(workgroups / 256) beats of one chunk each) plus the price of summing the slabs:
+        //   t(nc) = ceil(tiles * nc / 256) / nc * t_rows + nc * slab traffic
+        // e.g. 6400 x 6400 x 1536 (600 tiles): one chunk = 3 beats, two chunks = 5 half-beats (1388 -> 1156 us measured);
+        // 32768 x 512 x 6348 (200 tiles): 2 chunks 2266 us, 15 chunks 1894 us; the 16- and 64-tile projection / FFN shapes
+        // keep 512 workgroups (tools/bench_wgrad1.py, ASR_WGRAD6_BLOCKS sweeps)
+        const long tiles = (long)asr_cdiv(d->K, KT) * asr_cdiv(d->N, NT);
+        const double slab = (double)d->K * d->N * 4.0;
+        const double t_rows = (double)d->M * KT * NT * 2.0 / (0.75 * 157.3e12 / 256);
+        long cap = (long)((128.0 * (1 << 20)) / slab); if (cap < 1) cap = 1;
+        long maxc = asr_cdiv(d->M, (tiles <= 4 ? 1 : 4) * q.ps); if (maxc < 1) maxc = 1;
+        long lim = cap < maxc ? cap : maxc; if (lim > 512) lim = 512;
+        auto cost = [&](long nc) { return (double)asr_cdiv(tiles * nc, 256) / nc * t_rows + (nc > 1 ? (nc + 1) * slab / 3.0e12 : 0.0); };
+        long best = 1; double tbest = 1e30;
+        for (long nc = 1; nc <= lim; ++nc) {
+            const double t = cost(nc);
+            if (t < tbest * 0.995) { tbest = t; best = nc; }      // fewer chunks on (near) ties
+        }
+        // ... but not fewer workgroups than fit side by side (two per CU cover each other's staging) when more cost the same
+        while (tiles * best < 256L * q.minb && 2 * best <= lim && cost(2 * best) <= 1.06 * tbest) best *= 2;
+        long pch = ((long)asr_cdiv(d->M, best) + q.ps - 1) / q.ps * q.ps;
+        q.p.pch = (int)pch;
+        q.p.nchunks = asr_cdiv(d->M, pch);
+    }
     return q;
 }
 
