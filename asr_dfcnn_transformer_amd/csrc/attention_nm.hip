@@ -12,6 +12,11 @@ namespace {
 
 __device__ __forceinline__ int rowidx(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 
+// scores are kept in base-2 units (the recomputed operand is pre-scaled by log2(e) / sqrt(d)): a probability is one
+// v_sub + one v_exp_f32 -- vector instructions beside fp32 MFMAs cost their full issue time (transformer.hip)
+constexpr float LOG2E = 1.44269504088896340736f;
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 template <int DH>
 struct Cfg {
     static constexpr int KP = DH + 4;             // LDS pitch (floats): conflict-free ds_read_b128
@@ -63,6 +68,7 @@ template <int DH>
 __global__ __launch_bounds__(256, 2) void nm_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                         const float* __restrict__ V, float* __restrict__ O,
                                                         float* __restrict__ lse, int Tq, int Tk, int C, int H, float scale) {
+    const float scale2 = scale * LOG2E;
     constexpr int KP = Cfg<DH>::KP, GK = Cfg<DH>::GK, DT = Cfg<DH>::DT;
     __shared__ __attribute__((aligned(16))) float kv_lds[2 * (64 * KP + Cfg<DH>::PADF)];
     static_assert(4 * 32 * 65 <= 2 * (64 * KP + Cfg<DH>::PADF), "transpose scratch must fit in the K/V tiles");
@@ -78,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void nm_fwd_kernel(const float* __restrict_
     for (int g = 0; g < GK; ++g) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < Tq) v = *(const float4*)(Q + (qbase + q) * C + hoff + 8 * g + 4 * lh);
-        qreg[g * 4 + 0] = v.x * scale; qreg[g * 4 + 1] = v.y * scale; qreg[g * 4 + 2] = v.z * scale; qreg[g * 4 + 3] = v.w * scale;
+        qreg[g * 4 + 0] = v.x * scale2; qreg[g * 4 + 1] = v.y * scale2; qreg[g * 4 + 2] = v.z * scale2; qreg[g * 4 + 3] = v.w * scale2;
     }
     floatx16 oacc[DT];
 #pragma unroll
@@ -115,10 +121,10 @@ __global__ __launch_bounds__(256, 2) void nm_fwd_kernel(const float* __restrict_
             }
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             const float m_new = fmaxf(m_run, mt);
-            const float alpha = expf(m_run - m_new);
+            const float alpha = ex2(m_run - m_new);
             float lt = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - m_new); lt += s[r]; }
+            for (int r = 0; r < 16; ++r) { s[r] = ex2(s[r] - m_new); lt += s[r]; }
             lt += __shfl_xor(lt, 32, 64);
             l_run = l_run * alpha + lt;
             m_run = m_new;
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void nm_fwd_kernel(const float* __restrict_
         }
     }
     __syncthreads();
-    if (q < Tq && lh == 0) lse[((long)n * H + head) * Tq + q] = m_run + logf(l_run);
+    if (q < Tq && lh == 0) lse[((long)n * H + head) * Tq + q] = m_run + log2f(l_run);      // base-2 units
     store_T<DH>(O, Ks + wave * (32 * 65), oacc, 1.f / l_run, qbase, q0, Tq, C, hoff, lane);
 }
 
@@ -170,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void nm_bwd_kv_kernel(const float* __restri
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            float* __restrict__ dK, float* __restrict__ dV,
                                                            int Tq, int Tk, int C, int H, float scale) {
+    const float scale2 = scale * LOG2E;
     constexpr int KP = Cfg<DH>::KP, GK = Cfg<DH>::GK, DT = Cfg<DH>::DT;
     __shared__ __attribute__((aligned(16))) float Qs[32 * KP + Cfg<DH>::PADF];
     __shared__ __attribute__((aligned(16))) float Ds[32 * KP + Cfg<DH>::PADF];
@@ -188,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void nm_bwd_kv_kernel(const float* __restri
             a = *(const float4*)(K + (kbase + key) * C + hoff + 8 * g + 4 * lh);
             b = *(const float4*)(V + (kbase + key) * C + hoff + 8 * g + 4 * lh);
         }
-        kreg[g * 4 + 0] = a.x * scale; kreg[g * 4 + 1] = a.y * scale; kreg[g * 4 + 2] = a.z * scale; kreg[g * 4 + 3] = a.w * scale;
+        kreg[g * 4 + 0] = a.x * scale2; kreg[g * 4 + 1] = a.y * scale2; kreg[g * 4 + 2] = a.z * scale2; kreg[g * 4 + 3] = a.w * scale2;
         vreg[g * 4 + 0] = b.x; vreg[g * 4 + 1] = b.y; vreg[g * 4 + 2] = b.z; vreg[g * 4 + 3] = b.w;
     }
     floatx16 dk[DT], dv[DT];
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void nm_bwd_kv_kernel(const float* __restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ql = rowidx(r, lh);
-            const float p = (key < Tk) ? expf(s[r] - lse_s[ql]) : 0.f;        // lse = +inf for rows past Tq -> p = 0
+            const float p = (key < Tk) ? ex2(s[r] - lse_s[ql]) : 0.f;        // lse = +inf for rows past Tq -> p = 0
             const float ds = p * (dp[r] - del_s[ql]) * scale;
             s[r] = p; dp[r] = ds;
         }
@@ -252,6 +259,7 @@ __global__ __launch_bounds__(256, 2) void nm_bwd_q_kernel(const float* __restric
                                                           const float* __restrict__ V, const float* __restrict__ dO,
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           float* __restrict__ dQ, int Tq, int Tk, int C, int H, float scale) {
+    const float scale2 = scale * LOG2E;
     constexpr int KP = Cfg<DH>::KP, GK = Cfg<DH>::GK, DT = Cfg<DH>::DT;
     __shared__ __attribute__((aligned(16))) float kv_lds[2 * (64 * KP + Cfg<DH>::PADF)];
     float* Ks = kv_lds;
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void nm_bwd_q_kernel(const float* __restric
             a = *(const float4*)(Q + (qbase + q) * C + hoff + 8 * g + 4 * lh);
             b = *(const float4*)(dO + (qbase + q) * C + hoff + 8 * g + 4 * lh);
         }
-        qreg[g * 4 + 0] = a.x * scale; qreg[g * 4 + 1] = a.y * scale; qreg[g * 4 + 2] = a.z * scale; qreg[g * 4 + 3] = a.w * scale;
+        qreg[g * 4 + 0] = a.x * scale2; qreg[g * 4 + 1] = a.y * scale2; qreg[g * 4 + 2] = a.z * scale2; qreg[g * 4 + 3] = a.w * scale2;
         doreg[g * 4 + 0] = b.x; doreg[g * 4 + 1] = b.y; doreg[g * 4 + 2] = b.z; doreg[g * 4 + 3] = b.w;
     }
     const float my_lse = (q < Tq) ? lse[((long)n * H + head) * Tq + q] : INFINITY;
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void nm_bwd_q_kernel(const float* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = k0 + sub * 32 + rowidx(r, lh);
-                const float p = (key < Tk) ? expf(s[r] - my_lse) : 0.f;
+                const float p = (key < Tk) ? ex2(s[r] - my_lse) : 0.f;
                 dp[r] = p * (dp[r] - my_del) * scale;
             }
 #pragma unroll
