@@ -74,6 +74,7 @@ SIGNATURES = {
     'asr_attention_fwd_p': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint, _P, _P, _P]),
     'asr_attention_bwd_p': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint, _P, _P, _P, _P, _P]),
     'asr_copy2d': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
+    'asr_copy2d_batch': (_I, [_P, _I, _I, _I, _P]),
     'asr_dropout': (_I, [_P, _Z, _F, C.c_uint, _P, _P]),
     'asr_add_layernorm_fwd': (_I, [_P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
     'asr_layernorm_bwd_workspace': (_Z, [_I, _I]),

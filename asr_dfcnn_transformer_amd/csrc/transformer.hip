@@ -927,6 +927,29 @@ extern "C" int asr_copy2d(float* dst, int ldd, const float* src, int lds, int ro
     return ASR_OK;
 }
 
+// several strided copies in ONE launch: the table (asr_copy2d_item, device memory) is built once by the caller
+__global__ void copy2d_batch_kernel(const asr_copy2d_item* __restrict__ items, int accumulate) {
+    const asr_copy2d_item it = items[blockIdx.y];
+    const int c4n = it.cols >> 2;
+    const long total = (long)it.rows * c4n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c4n;
+        const int c = (int)(i - r * c4n) * 4;
+        float4 v = *(const float4*)(it.src + r * it.lds + c);
+        float* d = it.dst + r * it.ldd + c;
+        if (accumulate) { const float4 o = *(const float4*)d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *(float4*)d = v;
+    }
+}
+
+extern "C" int asr_copy2d_batch(const asr_copy2d_item* items_dev, int n_items, int max_elems, int accumulate, void* stream) {
+    if (!items_dev || n_items < 1 || n_items > 65535 || max_elems < 4) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(copy2d_batch_kernel, dim3(grid_for((long)max_elems / 4, 256), n_items), dim3(256), 0, (hipStream_t)stream,
+                       items_dev, accumulate);
+    ASR_CHECK_LAUNCH("copy2d_batch");
+    return ASR_OK;
+}
+
 extern "C" int asr_dropout(const float* x, size_t n, float rate, unsigned int seed, float* y, void* stream) {
     if (!x || !y || n == 0 || rate < 0.f || rate >= 1.f || n >= 4294967296ull) return ASR_ERR_BAD_ARG;
     long b = (long)((n + 255) / 256);

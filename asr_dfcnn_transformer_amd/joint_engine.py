@@ -76,6 +76,7 @@ class _LanguageHalf(_Base):
         return flat
 
     def forward(self, h7, train=True):
+        self._begin_forward()
         N, T, C = self.N, self.T, self.C
         rows = N * T
         ops.embed_fwd(None, self.tidx, self.p('pos'), N, T, C, False, 1.0, self.x0)       # x0 = pos[t]

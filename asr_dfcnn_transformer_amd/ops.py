@@ -292,6 +292,25 @@ def copy2d(dst, ldd, src, lds, rows, cols, accumulate=False):
     check(_lib.load().asr_copy2d(_ptr(dst), ldd, _ptr(src), lds, rows, cols, int(accumulate), _stream()), 'asr_copy2d')
 
 
+class Copy2dBatch:
+    """A table of strided copies run as one launch (asr_copy2d_batch).  ``items``: (dst, ldd, src, lds, rows, cols) with dst /
+    src device tensors (views allowed); the tensors must outlive the batch and keep their storage."""
+
+    def __init__(self, items):
+        import struct
+        assert items
+        raw = b''.join(struct.pack('<QQiiii', _ptr(d).value or 0, _ptr(s_).value or 0, ldd, lds, rows, cols)
+                       for d, ldd, s_, lds, rows, cols in items)
+        self._keep = [(d, s_) for d, _, s_, _, _, _ in items]
+        self.n = len(items)
+        self.max_elems = max(rows * cols for _, _, _, _, rows, cols in items)
+        dev = items[0][0].device
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+
+    def run(self, accumulate=False):
+        check(_lib.load().asr_copy2d_batch(_ptr(self.table), self.n, self.max_elems, int(accumulate), _stream()), 'asr_copy2d_batch')
+
+
 def dropout(x, rate, seed, y=None):
     """y = keep(i, seed) ? x / (1 - rate) : 0 (in place when y is None); the same call on a gradient is the backward."""
     y = x if y is None else y

@@ -272,8 +272,7 @@ class _Base:
         fused3 = (q_in is k_in) and rq == rk
         st['fused3'] = fused3
         W3 = st['W3']
-        for j, k in enumerate(('wq', 'wk', 'wv')):
-            ops.copy2d(W3.view(-1)[j * C:], 3 * C, self.p('%s/%s' % (name, k)), C, C, C)
+        self._pack_qkv(name, st)
         Q, K, V, ldq, ldk = self._qkv_views(st, fused3)
         if fused3:
             d = ops.gemm_desc(rq, C, 3 * C, C, 3 * C, 0, 3 * C, ntaps=1, relu=1)
@@ -293,6 +292,31 @@ class _Base:
                               st['out'], st['xhat'], st['rstd'])
         return st['out']
 
+    def _pack_qkv(self, name, st):
+        """[wq | wk | wv] of every attention block, packed side by side for the fused projection GEMMs.  The first forward
+        copies block by block and records the copies; afterwards the first block of a forward runs them all as ONE launch
+        (asr_copy2d_batch; 3 x blocks launches per step before)."""
+        C = self.C
+        reg = self.__dict__.setdefault('_pack_reg', {})
+        key = (name, id(st))
+        if key not in reg:
+            items = [(st['W3'].view(-1)[j * C:], 3 * C, self.p('%s/%s' % (name, k)), C, C, C) for j, k in enumerate(('wq', 'wk', 'wv'))]
+            for it in items:
+                ops.copy2d(*it)
+            reg[key] = items
+            self._pack_batch = None
+            return
+        if self.__dict__.get('_pack_dirty', True):
+            if self.__dict__.get('_pack_batch') is None:
+                self._pack_batch = ops.Copy2dBatch([it for items in reg.values() for it in items])
+            self._pack_batch.run(False)
+            self._pack_dirty = False
+
+    def _begin_forward(self):
+        """Start of a forward pass: the packed projection weights are rebuilt from the parameters once (they may have
+        been stepped, loaded or perturbed since the last forward)."""
+        self._pack_dirty = True
+
     def _wgrad_packed(self, x, dy, rows, K, names, ldz):
         """[g(names[0]) | g(names[1]) | ...] += x^T dy for weight matrices packed side by side (dy [rows][len(names) * C],
         row pitch ldz): one weight-gradient GEMM into scratch, scattered back into the separate gradient tensors."""
@@ -301,8 +325,12 @@ class _Base:
         tmp = self._wtmp[:K * Nf]
         d = ops.gemm_desc(rows, K, Nf, K, Nf, ntaps=1)
         ops.tap_wgrad(d, x, dy, ldz, tmp, self.ws)
-        for j, nm in enumerate(names):
-            ops.copy2d(self.g(nm), C, tmp[j * C:], Nf, K, C, True)      # the gradient buffer was zeroed at the start of backward
+        cache = self.__dict__.setdefault('_unpack_batches', {})
+        key = (tuple(names), K, tmp.data_ptr())
+        if key not in cache:
+            cache[key] = ops.Copy2dBatch([(self.g(nm), C, tmp[j * C:], Nf, K, C) for j, nm in enumerate(names)])
+        cache[key].run(True)                                            # the gradient buffer was zeroed at the start of backward
+        for nm in names:
             self._written.add(name_off(self, nm))
 
     def _mha_bwd(self, name, st, dout, dq_in, dq_acc, dk_in, dk_acc):
@@ -506,6 +534,7 @@ class LMEngine(_Base):
         return flat
 
     def forward(self, x_ids, y=None, train=True):
+        self._begin_forward()
         N, T, C = self.N, self.T, self.C
         xi = np.ascontiguousarray(np.asarray(x_ids, dtype=np.int32))
         assert xi.shape == (N, T)
@@ -605,6 +634,7 @@ class E2EEngine(_Base):
         return flat
 
     def forward(self, x, y_in, y_tgt=None, train=True):
+        self._begin_forward()
         N, T, L, C = self.N, self.T, self.L, self.C
         re, rd = N * T, N * L
         self._rate = self.dropout_rate if train else 0.0

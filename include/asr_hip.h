@@ -275,6 +275,12 @@ int asr_attention_bwd_p(const float* Q, const float* K, const float* V, const fl
 /* dst[r][0..cols) (+)= src[r][0..cols) for r < rows, with row pitches ldd / lds (floats; everything a multiple of 4):
  * packs separate weight matrices into the column blocks of a fused one and scatters its gradient back. */
 int asr_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int cols, int accumulate, void* stream);
+/* The same for a table of copies in one launch (the [wq | wk | wv] packs of every attention block of a step, the three
+ * gradient blocks of a packed weight gradient).  items_dev: n_items asr_copy2d_item in DEVICE memory, written once by the
+ * caller; every item obeys asr_copy2d's rules (cols % 4 == 0, pitches % 4 == 0, 16-byte aligned pointers); max_elems =
+ * the largest rows * cols among them (sizes the grid). */
+typedef struct asr_copy2d_item { float* dst; const float* src; int ldd, lds, rows, cols; } asr_copy2d_item;
+int asr_copy2d_batch(const asr_copy2d_item* items_dev, int n_items, int max_elems, int accumulate, void* stream);
 /* tf.layers.dropout(x, rate, training=True) (transformer.py:154,226; model.py:290; language_model.py:34):
  *   y[i] = keep(i, seed) ? x[i] / (1 - rate) : 0 with keep(i, seed) = (murmur3_fmix(i * 0x9E3779B1 + seed) >> 8) >= rate * 2^24.
  *   In place is allowed; the same call on the gradient is the backward.  TensorFlow's random stream is not reproduced. */
