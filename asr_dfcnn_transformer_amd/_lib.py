@@ -61,6 +61,7 @@ SIGNATURES = {
     'asr_softmax_log_fwd': (_I, [_P, _I, _I, _I, _F, _P, _P]),
     'asr_softmax_log_bwd': (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P]),
     'asr_relu_bwd': (_I, [_P, _P, _Z, _P, _P]),
+    'asr_relu_bwd_scaled': (_I, [_P, _P, _Z, _F, _P, _P]),
     'asr_colsum_workspace': (_Z, [_I, _I]),
     'asr_colsum': (_I, [_P, _I, _I, _I, _P, _P, _P]),
     'asr_ctc_workspace': (_Z, [_I, _I, _I]),

@@ -451,6 +451,17 @@ __global__ void relu_bwd4_kernel(const float* __restrict__ dy, const float* __re
     }
 }
 
+// dz = (h > 0) ? dy * scale : 0  (n4 float4 elements): the ReLU backward of an activation that was dropped out IN PLACE --
+// its zeros already carry the dropout mask, so the backward of the dropout is only its 1 / (1 - rate) factor
+__global__ void relu_bwd4_scaled_kernel(const float* __restrict__ dy, const float* __restrict__ h, size_t n4, float scale,
+                                        float* __restrict__ dz) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 d = ld4(dy + i * 4), a = ld4(h + i * 4);
+        st4(dz + i * 4, make_float4(a.x > 0.f ? d.x * scale : 0.f, a.y > 0.f ? d.y * scale : 0.f, a.z > 0.f ? d.z * scale : 0.f,
+                                    a.w > 0.f ? d.w * scale : 0.f));
+    }
+}
+
 inline bool chan_ok(int C) { return C >= 4 && (C & 3) == 0 && (256 % (C / 4)) == 0 && C <= 1024; }
 inline int grid_for(long total, int threads) {
     long b = (total + threads - 1) / threads;
@@ -641,6 +652,15 @@ extern "C" int asr_relu_bwd(const float* dy, const float* h, size_t n, float* dz
         hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for((long)n, 256)), dim3(256), 0, (hipStream_t)stream, dy, h, n, dz);
     }
     ASR_CHECK_LAUNCH("relu_bwd");
+    return ASR_OK;
+}
+
+extern "C" int asr_relu_bwd_scaled(const float* dy, const float* h, size_t n, float scale, float* dz, void* stream) {
+    if (!dy || !h || !dz || n == 0 || (n & 3) || (((uintptr_t)dy | (uintptr_t)h | (uintptr_t)dz) & 15)) return ASR_ERR_BAD_ARG;
+    long b = (long)((n / 4 + 255) / 256);
+    if (b > 16384) b = 16384;
+    hipLaunchKernelGGL(relu_bwd4_scaled_kernel, dim3((int)b), dim3(256), 0, (hipStream_t)stream, dy, h, n / 4, scale, dz);
+    ASR_CHECK_LAUNCH("relu_bwd_scaled");
     return ASR_OK;
 }
 

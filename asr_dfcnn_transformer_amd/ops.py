@@ -218,6 +218,11 @@ def relu_bwd(dy, h, dz):
     check(_lib.load().asr_relu_bwd(_ptr(dy), _ptr(h), dy.numel(), _ptr(dz), _stream()), 'asr_relu_bwd')
 
 
+def relu_bwd_scaled(dy, h, scale, dz):
+    """dz = (h > 0) ? dy * scale : 0 (see asr_relu_bwd_scaled)."""
+    check(_lib.load().asr_relu_bwd_scaled(_ptr(dy), _ptr(h), dy.numel(), float(scale), _ptr(dz), _stream()), 'asr_relu_bwd_scaled')
+
+
 def colsum_workspace(rows, cols):
     return _lib.load().asr_colsum_workspace(rows, cols)
 

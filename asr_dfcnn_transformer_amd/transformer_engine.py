@@ -342,9 +342,11 @@ class _Base:
         ops.layernorm_bwd(dout, st['xhat'], st['rstd'], self.p(name + '/ln_g'), rq, C, dr, False,
                           self.g(name + '/ln_g'), self.g(name + '/ln_b'), self.ws)
         ops.axpy(dq_in, dr, 1.0, dq_acc)
-        ops.relu_bwd(dr, st['Z'], dZ)
         if self._rate > 0:
-            ops.dropout(dZ, self._rate, st['seed_out'])  # the 1/(1-rate) factor (the mask itself is already in Z > 0)
+            # Z was dropped out in place: Z > 0 means active AND kept, the dropout backward is its 1 / (1 - rate) factor
+            ops.relu_bwd_scaled(dr, st['Z'], 1.0 / (1.0 - self._rate), dZ)
+        else:
+            ops.relu_bwd(dr, st['Z'], dZ)
         self._wgrad(st['A'], dZ, rq, C, C, name + '/wo')
         self._dense_dgrad(dZ, rq, C, C, self.p(name + '/wo'), dA, False)
         fused3 = st['fused3']

@@ -193,6 +193,10 @@ int asr_softmax_log_bwd(const float* logits_tm, const float* g_tm, int B, int T,
                         float gscale, float* dd, void* stream);
 /* dense + ReLU backward helper: dz = dy * (h > 0) where h is the post-ReLU output. */
 int asr_relu_bwd(const float* dy, const float* h, size_t n, float* dz, void* stream);
+/* dz = (h > 0) ? dy * scale : 0.  Backward of Dense(relu) followed by tf.layers.dropout (transformer.py:139-154) when the
+ * forward dropped h out in place: a dropped element is 0 like an inactive one, so the mask needs no second draw and the
+ * dropout backward is its 1 / (1 - rate) factor.  n % 4 == 0, 16-byte aligned pointers. */
+int asr_relu_bwd_scaled(const float* dy, const float* h, size_t n, float scale, float* dz, void* stream);
 /* column sums of a [rows][cols] matrix (bias gradients), fixed order. */
 size_t asr_colsum_workspace(int rows, int cols);
 int asr_colsum(const float* x, int rows, int cols, int ldx, float* out, float* partials, void* stream);
