@@ -4,9 +4,11 @@ GPU-busy time (union of all kernel intervals), idle gaps, and per-stream sums.  
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 iv = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Stream_Id', '0')) for r in rows)
-# steps are delimited by the Adam kernel
+# steps are delimited by the Adam kernel (ADAMS=<n> in the environment: n Adam launches per step, e.g. 2 for the joint graph)
+import os
 adam = [i for i, v in enumerate(iv) if 'adam_tf' in v[2]]
-a, b = adam[-2] + 1, adam[-1] + 1
+na = int(os.environ.get('ADAMS', '1'))
+a, b = adam[-1 - na] + 1, adam[-1] + 1
 step = iv[a:b]
 t0, t1 = step[0][0], max(v[1] for v in step)
 busy, cur_s, cur_e = 0, None, None
