@@ -1,0 +1,308 @@
+// EXPERIMENTAL: 3x3 convolution (forward and data-gradient view) by Winograd F(2x2, 3x3) on the fp32 MFMA pipe.
+//
+//   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A        16 multiplies per 2x2 output tile, input and output channel
+//                                                        instead of 36; still fp32 ("Next")
+//
+// One GEMM per transform position xi = 0..15:  M_xi[tile][co] = sum_ci V_xi[tile][ci] * U_xi[ci][co].
+//   * U = G g G^T is prepared once per optimiser step (asr_winograd_weights: [16][K][N], forward or data-gradient view);
+//   * a workgroup owns 64 consecutive tiles x 64 output channels: 2 x 2 waves, each wave 32 tiles x 32 channels with
+//     SIXTEEN 32x32 accumulators (256 registers, one wave per SIMD -- what tap_wgrad_kernel_v6 lives with);
+//   * per chunk of 8 input channels the raw 4x4 patches of the 64 tiles ([pixel 16][tile 64][quad 2] 16-byte slots) and
+//     the 16 weight matrices ([xi][ci 8][co 64]) arrive by LDS-DMA in two buffers each, one barrier per chunk;
+//   * the lanes transform their own patch: lane (tile, half) reads the channel pair of its half with one ds_read_b64 per
+//     pixel, B^T d B is 32 adds per 16 MFMAs (vector instructions are not free beside fp32 MFMAs: +12 %), and V goes
+//     straight into the MFMAs as the A operand -- the transformed input never exists in memory;
+//   * the inverse transform A^T M A is lane-local (register r of all 16 accumulators = one tile, 24 adds) and yields four
+//     32-row blocks -- the four pixels of the tiles -- which go through the SAME epilogues as the tap-GEMM kernels
+//     (tap_epilogue: bias / ReLU / BN affine / accumulate / the gated backward prologues) via their row tables.
+// Planes as everywhere else ([B][H+1][W+1][C], zero borders): patch rows / columns that stick out read the border; an odd
+// plane width needs the fourth patch column of the last tile column zeroed (it would wrap into the next pixel row).
+#include "asr_common.h"
+#include "reduce.h"
+#include "tap_epilogue.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((address_space(3))) float wn_lds_f;
+typedef const __attribute__((address_space(1))) float wn_glb_f;
+
+struct WinoArgs {
+    TapGemmArgs g;
+    const float* Ut;        // [16][K][N]
+    int TH, TW;             // tile rows / columns per image
+    long ntiles;            // B * TH * TW
+    int wodd;               // plane width is odd
+};
+
+constexpr int WT = 64;                      // tiles per workgroup
+constexpr int WC = 64;                      // output channels per workgroup
+constexpr int WKC = 8;                      // input channels per chunk
+constexpr int RAW_F = 16 * 2 * WT * 4;      // floats of one raw buffer   ([pixel][quad][tile] slots of 4 floats)
+constexpr int U_F = 16 * WKC * WC;          // floats of one weight buffer ([xi][ci][co])
+
+// U = G g G^T for every (k, n): g(kh, kw) = W[kh][kw][k][n] (forward) or W[2-kh][2-kw][n][k] (data-gradient view)
+__global__ void wino_weights_kernel(const float* __restrict__ W, int K, int N, int ldw, int wmode, float* __restrict__ out) {
+    const long total = (long)K * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i / N), n = (int)(i - (long)k * N);
+        float g[3][3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                g[kh][kw] = (wmode == 0) ? W[((long)(kh * 3 + kw) * K + k) * ldw + n]
+                                         : W[((long)((2 - kh) * 3 + (2 - kw)) * N + n) * ldw + k];
+        float t[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            t[0][c] = g[0][c];
+            t[1][c] = 0.5f * ((g[0][c] + g[1][c]) + g[2][c]);
+            t[2][c] = 0.5f * ((g[0][c] - g[1][c]) + g[2][c]);
+            t[3][c] = g[2][c];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float u0 = t[r][0], u1 = 0.5f * ((t[r][0] + t[r][1]) + t[r][2]), u2 = 0.5f * ((t[r][0] - t[r][1]) + t[r][2]), u3 = t[r][2];
+            out[((long)(r * 4 + 0) * K + k) * N + n] = u0;
+            out[((long)(r * 4 + 1) * K + k) * N + n] = u1;
+            out[((long)(r * 4 + 2) * K + k) * N + n] = u2;
+            out[((long)(r * 4 + 3) * K + k) * N + n] = u3;
+        }
+    }
+}
+
+// DMA of one chunk: the raw patches (32 pieces: pixel x quad, 64 tiles each) and the weights (32 pieces of 4 rows x 64 channels);
+// wave w issues pieces w, w + 4, ...
+__device__ __forceinline__ void wino_stage(float* __restrict__ raw, float* __restrict__ ub, const float* __restrict__ src_t0,
+                                           const float* __restrict__ src_t1, const float* __restrict__ src_u, int WPl, int lda,
+                                           long ustride_xi, int N, int kc, int wave, int ablate = 0) {
+    // raw: piece = pixel * 2 + tile half; a lane fetches quad (lane & 1) of tile half * 32 + lane / 2 -- the two quads of a
+    // pixel are 32 contiguous bytes fetched by neighbouring lanes (one 64-byte request instead of two)
+    if (!(ablate & 1))
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int p = wave + 4 * j;
+        const int px = p >> 1, th = p & 1;
+        const int r = px >> 2, c = px & 3;
+        const float* base = th ? src_t1 : src_t0;
+        __builtin_amdgcn_global_load_lds((wn_glb_f*)(base + ((long)r * WPl + c) * lda + kc * WKC),
+                                         (wn_lds_f*)(raw + p * 256), 16, 0, 0);
+    }
+    if (!(ablate & 2))
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int p = wave + 4 * j;                  // piece = xi * 2 + (ci >> 2)
+        const int xi = p >> 1, cig = p & 1;
+        __builtin_amdgcn_global_load_lds((wn_glb_f*)(src_u + xi * ustride_xi + (long)(kc * WKC + cig * 4) * N),
+                                         (wn_lds_f*)(ub + p * 256), 16, 0, 0);
+    }
+}
+
+// one chunk of 8 input channels: for each channel quad the lanes read their pair, transform the patch and run 2 x 16 MFMAs
+__device__ __forceinline__ void wino_chunk(const float* __restrict__ raw, const float* __restrict__ ub, float* __restrict__ rawn,
+                                           float* __restrict__ ubn, bool prefetch, const float* __restrict__ src_t0,
+                                           const float* __restrict__ src_t1, const float* __restrict__ src_u, int WPl, int lda, long ustride_xi, int N, int kcn, int wave,
+                                           int aoff, int boff, bool wodd, bool zero_c3, floatx16 (&acc)[16], int ablate) {
+    if (prefetch) wino_stage(rawn, ubn, src_t0, src_t1, src_u, WPl, lda, ustride_xi, N, kcn, wave, ablate);
+#pragma unroll
+    for (int quad = 0; quad < 2; ++quad) {
+        float2 d[16];
+#pragma unroll
+        for (int px = 0; px < 16; ++px) d[px] = *(const float2*)(raw + (px * WT * 2 + quad) * 4 + aoff);
+        if (wodd) {              // uniform: only odd-width planes pay for the selects
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (zero_c3) d[r * 4 + 3] = make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            float t[4][4], v[16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float d0 = kk ? d[0 + c].y : d[0 + c].x, d1 = kk ? d[4 + c].y : d[4 + c].x;
+                const float d2 = kk ? d[8 + c].y : d[8 + c].x, d3 = kk ? d[12 + c].y : d[12 + c].x;
+                t[0][c] = d0 - d2; t[1][c] = d1 + d2; t[2][c] = d2 - d1; t[3][c] = d1 - d3;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r * 4 + 0] = t[r][0] - t[r][2]; v[r * 4 + 1] = t[r][1] + t[r][2];
+                v[r * 4 + 2] = t[r][2] - t[r][1]; v[r * 4 + 3] = t[r][1] - t[r][3];
+            }
+            // channel of this lane in the chunk: 4 quad + 2 half + kk (the pairing of channels into MFMA k-pairs is free)
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) {
+                const float u = ub[(xi * WKC + quad * 4 + kk) * WC + boff];
+                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[xi], u, acc[xi], 0, 0, 0);
+            }
+        }
+    }
+}
+
+template <int DIR>
+__global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs args) {
+    const TapGemmArgs& g = args.g;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int* rowa = (int*)smem;                          // [2 wave rows][4 pixels][32 tiles]
+    int* rowy = rowa + 256;
+    float* bufs = smem + 512;                        // raw0 | raw1 | u0 | u1
+    static_assert(4 * 32 * 33 <= 2 * RAW_F, "epilogue scratch must fit in the raw buffers");
+
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int nnb = g.ntn;                           // channel blocks
+    const int blk = blockIdx.x / nnb, nb = blockIdx.x - blk * nnb;
+    const long t0 = (long)blk * WT;
+    const int n0 = nb * WC;
+
+    // this lane as a DMA lane: quad (lane & 1) of tiles t0 + lane / 2 and t0 + 32 + lane / 2 (clamped), top-left pixel of the patch
+    const float* src_t[2];
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+        long t = t0 + th * 32 + (lane >> 1);
+        if (t > args.ntiles - 1) t = args.ntiles - 1;
+        const int per = args.TH * args.TW;
+        const int b = (int)(t / per);
+        const int rr = (int)(t - (long)b * per);
+        const int ti = rr / args.TW, tj = rr - ti * args.TW;
+        src_t[th] = g.A + ((long)b * g.HPWP + (long)(2 * ti) * g.WP + 2 * tj) * g.lda + (lane & 1) * 4;
+    }
+    // ... and as a weight DMA lane: row lane / 16 of a 4-row piece, column quad lane % 16
+    const float* src_u = args.Ut + (long)(lane >> 4) * g.N + n0 + (lane & 15) * 4;
+    const long ustride_xi = (long)g.K * g.N;
+
+    // row tables of the epilogue: local row = wm * 128 + pixel * 32 + tile
+    {
+        const int tl = tid & 63, pl = tid >> 6;      // 64 tiles x 4 pixels = 256 entries
+        const long t = t0 + tl;
+        int ra = -1, ry = -1;
+        if (t < args.ntiles) {
+            const int per = args.TH * args.TW;
+            const int b = (int)(t / per);
+            const int rr = (int)(t - (long)b * per);
+            const int ti = rr / args.TW, tj = rr - ti * args.TW;
+            const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
+            if (ww <= g.Wd) {
+                ra = (int)((long)b * g.HPWP + (long)hh * g.WP + ww);
+                ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : ra;
+            }
+        }
+        const int m = (tl >> 5) * 128 + pl * 32 + (tl & 31);
+        rowa[m] = ra; rowy[m] = ry;
+    }
+    // does this lane's (compute) tile sit in the last tile column of an odd-width plane?
+    bool zero_c3 = false;
+    if (args.wodd) {
+        long t = t0 + wm * 32 + li;
+        if (t > args.ntiles - 1) t = args.ntiles - 1;
+        zero_c3 = (int)(t % args.TW) == args.TW - 1;
+    }
+
+    floatx16 acc[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+
+    const int aoff = (wm * 32 + li) * 8 + lh * 2;    // this lane's pair: slot (tile, quad) of a pixel row, half lh
+    const int boff = lh * 2 * WC + wn * 32 + li;     // half 1 reads channel + 2
+    const int nkc = g.K / WKC;
+
+    wino_stage(bufs, bufs + 2 * RAW_F, src_t[0], src_t[1], src_u, g.WP, g.lda, ustride_xi, g.N, 0, wave);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+
+    int cur = 0;
+    for (int kc = 0; kc < nkc; ++kc) {
+        wino_chunk(bufs + cur * RAW_F, bufs + 2 * RAW_F + cur * U_F, bufs + (cur ^ 1) * RAW_F, bufs + 2 * RAW_F + (cur ^ 1) * U_F,
+                   kc + 1 < nkc, src_t[0], src_t[1], src_u, g.WP, g.lda, ustride_xi, g.N, kc + 1, wave, aoff, boff, args.wodd != 0, zero_c3, acc, g.ablate);
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // the next chunk has landed
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // inverse transform, lane-local: register r of the 16 accumulators is one tile
+    floatx16 out[4][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            s0[c] = (acc[0 + c][r] + acc[4 + c][r]) + acc[8 + c][r];
+            s1[c] = (acc[4 + c][r] - acc[8 + c][r]) - acc[12 + c][r];
+        }
+        out[0][0][r] = (s0[0] + s0[1]) + s0[2];
+        out[1][0][r] = (s0[1] - s0[2]) - s0[3];
+        out[2][0][r] = (s1[0] + s1[1]) + s1[2];
+        out[3][0][r] = (s1[1] - s1[2]) - s1[3];
+    }
+    if ((g.ablate & 4) && out[0][0][0] != 123.456f) return;          // timing experiments only
+    tap_epilogue<4, 1>(g, out, bufs + wave * (32 * 33), rowa, rowy, wm * 128, n0 + wn * 32, lane, blk * 2 + wm);
+}
+
+}  // namespace
+
+extern "C" size_t asr_winograd_weights_bytes(int K, int N) { return (size_t)16 * K * N * sizeof(float); }
+
+extern "C" int asr_winograd_weights(const float* W, int K, int N, int ldw, int wmode, float* out, void* stream) {
+    if (!W || !out || K < 1 || N < 1 || ldw < 1) return ASR_ERR_BAD_ARG;
+    long nb = ((long)K * N + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, W, K, N, ldw, wmode, out);
+    ASR_CHECK_LAUNCH("winograd_weights");
+    return ASR_OK;
+}
+
+extern "C" int asr_winograd_supported(const asr_gemm_desc* d) {
+    return d && d->ntaps == 9 && d->H > 0 && (d->H & 1) == 0 && d->W >= 2 && (d->K % WKC) == 0 && (d->N % WC) == 0 &&
+           (d->lda & 3) == 0 && d->M == d->B * (d->H + 1) * (d->W + 1);
+}
+
+struct WinoGate { int mode, H, W; const float* a; float* dz; float* part; int* rows; };
+
+static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale, const float* shift,
+                     float* out_a, float* out_y, void* stream, const WinoGate* gs) {
+    if (!d || !A || !Ut || (!out_a && !out_y && !gs)) return ASR_ERR_BAD_ARG;
+    if (!asr_winograd_supported(d)) return ASR_ERR_UNSUPPORTED;
+    if ((((uintptr_t)A) | ((uintptr_t)Ut)) & 15) return ASR_ERR_BAD_ARG;
+    WinoArgs w;
+    TapGemmArgs& a = w.g;
+    a.A = A; a.W = nullptr; a.bias = bias; a.scale = scale; a.shift = shift;
+    a.out_a = out_a; a.out_y = out_y;
+    a.M = d->M; a.K = d->K; a.N = d->N; a.lda = d->lda; a.ldw = d->ldw;
+    a.ldo_a = d->ldo_a; a.ldo_y = d->ldo_y;
+    a.H = d->H; a.Wd = d->W; a.WP = d->W + 1; a.HPWP = (d->H + 1) * (d->W + 1);
+    a.halo = a.WP + 1;
+    a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
+    a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
+    { static int abl = -1; if (abl < 0) { const char* e = getenv("ASR_WINO_ABLATE"); abl = e ? atoi(e) : 0; } a.ablate = abl; }
+    a.gate_mode = 0; a.gate_H = a.gate_W = 0; a.gate_a = nullptr; a.gate_dz = nullptr; a.gate_part = nullptr; a.gate_rows = nullptr;
+    if (gs) { a.gate_mode = gs->mode; a.gate_H = gs->H; a.gate_W = gs->W; a.gate_a = gs->a; a.gate_dz = gs->dz; a.gate_part = gs->part; a.gate_rows = gs->rows; }
+    w.Ut = Ut;
+    w.TH = d->H / 2; w.TW = (d->W + 1) / 2;
+    w.ntiles = (long)d->B * w.TH * w.TW;
+    w.wodd = d->W & 1;
+    const int nblk = asr_cdiv(w.ntiles, WT);
+    a.ntm = nblk; a.ntn = d->N / WC;
+    if (a.gate_rows) *a.gate_rows = nblk * 2;
+    const size_t lds = (size_t)(512 + 2 * RAW_F + 2 * U_F) * sizeof(float);
+    auto k0 = wino_kernel<0>;
+    auto k1 = wino_kernel<1>;
+    static bool attr0 = false, attr1 = false;
+    hipStream_t st = (hipStream_t)stream;
+    if (d->wmode) {
+        if (!attr1) { (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
+        hipLaunchKernelGGL(k1, dim3(nblk * a.ntn), dim3(256), lds, st, w);
+    } else {
+        if (!attr0) { (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr0 = true; }
+        hipLaunchKernelGGL(k0, dim3(nblk * a.ntn), dim3(256), lds, st, w);
+    }
+    ASR_CHECK_LAUNCH("tap_gemm_wino");
+    ASR_NOTE_KERNEL("wino_kernel<%d>", d->wmode ? 1 : 0);
+    return ASR_OK;
+}
+
+extern "C" int asr_tap_gemm_wino(const asr_gemm_desc* d, const float* A, const float* Ut,
+                                 const float* bias, const float* scale, const float* shift,
+                                 float* out_a, float* out_y, void* stream) {
+    return wino_impl(d, A, Ut, bias, scale, shift, out_a, out_y, stream, nullptr);
+}

@@ -532,6 +532,29 @@ def arrange_weights(W, ntaps, K, N, ldw, wmode=0, out=None):
     return out
 
 
+def winograd_weights(W, K, N, ldw, wmode=0, out=None):
+    """U = G g G^T of a 3x3 layer, [16][K][N] (asr_winograd_weights); EXPERIMENTAL."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(lib.asr_winograd_weights_bytes(K, N) // 4, dtype=torch.float32, device=W.device)
+    check(lib.asr_winograd_weights(_ptr(W), K, N, ldw, wmode, _ptr(out), _stream()), 'asr_winograd_weights')
+    return out
+
+
+def winograd_supported(desc):
+    return bool(_lib.load().asr_winograd_supported(C.byref(desc)))
+
+
+def tap_gemm_wino(desc, A, Wt, bias=None, scale=None, shift=None, out_a=None, out_y=None):
+    """asr_tap_gemm on Winograd-transformed weights (3x3 only); EXPERIMENTAL."""
+    lib = _lib.load()
+    pa = A.ptr if isinstance(A, Plane) else _ptr(A)
+    po_a = out_a.ptr if isinstance(out_a, Plane) else _ptr(out_a)
+    po_y = out_y.ptr if isinstance(out_y, Plane) else _ptr(out_y)
+    _timed(desc, lambda: check(lib.asr_tap_gemm_wino(C.byref(desc), pa, _ptr(Wt), _ptr(bias), _ptr(scale), _ptr(shift), po_a, po_y,
+                                                     _stream()), 'asr_tap_gemm_wino'))
+
+
 def tap_gemm_pw(desc, A, Wf, bias=None, scale=None, shift=None, out_a=None, out_y=None):
     """asr_tap_gemm on pre-arranged weights; desc.wmode only labels the launch (forward / data-gradient symbol)."""
     lib = _lib.load()

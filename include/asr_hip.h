@@ -406,6 +406,21 @@ int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const float* Warrang
                     const float* bias, const float* scale, const float* shift,
                     float* out_a, float* out_y, void* stream);
 
+/* ------------------------------------------------------------------ EXPERIMENTAL: Winograd F(2x2, 3x3) (round 2)
+ * The 3x3 convolution of asr_tap_gemm (ntaps 9; forward, or data-gradient view with wmode 1) with 16 instead of 36
+ * multiplies per 2x2 output tile, input and output channel -- still fp32, results agree with asr_tap_gemm to rounding
+ * (tests/test_wino_gpu.py).  Weights are transformed once per optimiser step:
+ *   asr_winograd_weights(W HWIO [3][3][Cin][Cout] with pitch ldw, K, N, ldw, wmode, out [16][K][N])
+ *     wmode 0: K = Cin, N = Cout;  wmode 1: the data-gradient view, K = Cout, N = Cin, taps mirrored (as asr_arrange_weights)
+ * asr_winograd_supported(d): ntaps 9, even plane height, K % 8 == 0, N % 64 == 0 (otherwise use asr_tap_gemm[_pw]).
+ * asr_tap_gemm_wino: same contract and epilogue options as asr_tap_gemm_pw. */
+size_t asr_winograd_weights_bytes(int K, int N);
+int asr_winograd_weights(const float* W, int K, int N, int ldw, int wmode, float* out, void* stream);
+int asr_winograd_supported(const asr_gemm_desc* d);
+int asr_tap_gemm_wino(const asr_gemm_desc* d, const float* A, const float* Wt,
+                      const float* bias, const float* scale, const float* shift,
+                      float* out_a, float* out_y, void* stream);
+
 /* ------------------------------------------------------------------ fused backward prologue (round 2)
  * The data-gradient of cell k, with the backward of cell k-1's [pool ->] BN -> ReLU (what asr_cell_bwd_pre computes in a
  * pass of its own: tf.gradients through average_pooling2d / max_pooling2d, batch_normalization and relu,
