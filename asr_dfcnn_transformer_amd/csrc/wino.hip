@@ -1,4 +1,7 @@
 // EXPERIMENTAL: 3x3 convolution (forward and data-gradient view) by Winograd F(2x2, 3x3) on the fp32 MFMA pipe.
+// Status (round 2): correct on every layer shape (tests/test_wino_gpu.py), but only as fast as tap_gemm_kernel_v5 (0.86-1.11x:
+// 2.25x fewer MFMAs at a third of the pipe's rate instead of three quarters) -- not used by the engines.  DESIGN.md section 9
+// has the measurements and what is in the way.
 //
 //   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A        16 multiplies per 2x2 output tile, input and output channel
 //                                                        instead of 36; still fp32 ("Next")
@@ -76,10 +79,9 @@ __global__ void wino_weights_kernel(const float* __restrict__ W, int K, int N, i
 // wave w issues pieces w, w + 4, ...
 __device__ __forceinline__ void wino_stage(float* __restrict__ raw, float* __restrict__ ub, const float* __restrict__ src_t0,
                                            const float* __restrict__ src_t1, const float* __restrict__ src_u, int WPl, int lda,
-                                           long ustride_xi, int N, int kc, int wave, int ablate = 0) {
+                                           long ustride_xi, int N, int kc, int wave) {
     // raw: piece = pixel * 2 + tile half; a lane fetches quad (lane & 1) of tile half * 32 + lane / 2 -- the two quads of a
     // pixel are 32 contiguous bytes fetched by neighbouring lanes (one 64-byte request instead of two)
-    if (!(ablate & 1))
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int p = wave + 4 * j;
@@ -89,7 +91,6 @@ __device__ __forceinline__ void wino_stage(float* __restrict__ raw, float* __res
         __builtin_amdgcn_global_load_lds((wn_glb_f*)(base + ((long)r * WPl + c) * lda + kc * WKC),
                                          (wn_lds_f*)(raw + p * 256), 16, 0, 0);
     }
-    if (!(ablate & 2))
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int p = wave + 4 * j;                  // piece = xi * 2 + (ci >> 2)
@@ -99,43 +100,78 @@ __device__ __forceinline__ void wino_stage(float* __restrict__ raw, float* __res
     }
 }
 
-// one chunk of 8 input channels: for each channel quad the lanes read their pair, transform the patch and run 2 x 16 MFMAs
+// one chunk of 8 input channels = four batches (channel quad x pair member) of one patch transform + 16 MFMAs.  One wave
+// per SIMD: nothing hides an LDS wait, so the operands of batch b + 1 (its 16 weights, and the raw pixels of the next
+// quad) are requested BEFORE the transform and the MFMAs of batch b.
+__device__ __forceinline__ void wino_transform(const float2 (&d)[16], int kk, float (&v)[16]) {
+    float t[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float d0 = kk ? d[0 + c].y : d[0 + c].x, d1 = kk ? d[4 + c].y : d[4 + c].x;
+        const float d2 = kk ? d[8 + c].y : d[8 + c].x, d3 = kk ? d[12 + c].y : d[12 + c].x;
+        t[0][c] = d0 - d2; t[1][c] = d1 + d2; t[2][c] = d2 - d1; t[3][c] = d1 - d3;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        v[r * 4 + 0] = t[r][0] - t[r][2]; v[r * 4 + 1] = t[r][1] + t[r][2];
+        v[r * 4 + 2] = t[r][2] - t[r][1]; v[r * 4 + 3] = t[r][1] - t[r][3];
+    }
+}
+
 __device__ __forceinline__ void wino_chunk(const float* __restrict__ raw, const float* __restrict__ ub, float* __restrict__ rawn,
                                            float* __restrict__ ubn, bool prefetch, const float* __restrict__ src_t0,
-                                           const float* __restrict__ src_t1, const float* __restrict__ src_u, int WPl, int lda, long ustride_xi, int N, int kcn, int wave,
-                                           int aoff, int boff, bool wodd, bool zero_c3, floatx16 (&acc)[16], int ablate) {
-    if (prefetch) wino_stage(rawn, ubn, src_t0, src_t1, src_u, WPl, lda, ustride_xi, N, kcn, wave, ablate);
-#pragma unroll
-    for (int quad = 0; quad < 2; ++quad) {
-        float2 d[16];
+                                           const float* __restrict__ src_t1, const float* __restrict__ src_u,
+                                           int WPl, int lda, long ustride_xi, int N, int kcn, int wave,
+                                           int aoff, int boff, bool wodd, bool zero_c3, floatx16 (&acc)[16]) {
+    auto load_d = [&](float2 (&d)[16], int quad) {
 #pragma unroll
         for (int px = 0; px < 16; ++px) d[px] = *(const float2*)(raw + (px * WT * 2 + quad) * 4 + aoff);
+    };
+    // channel of this lane in the chunk: 4 quad + 2 half + kk (the pairing of channels into MFMA k-pairs is free)
+    auto load_u = [&](float (&u)[16], int quad, int kk) {
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) u[xi] = ub[(xi * WKC + quad * 4 + kk) * WC + boff];
+    };
+    auto fix_d = [&](float2 (&d)[16]) {
         if (wodd) {              // uniform: only odd-width planes pay for the selects
 #pragma unroll
             for (int r = 0; r < 4; ++r) if (zero_c3) d[r * 4 + 3] = make_float2(0.f, 0.f);
         }
+    };
+    auto mfmas = [&](const float (&v)[16], const float (&u)[16]) {
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            float t[4][4], v[16];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float d0 = kk ? d[0 + c].y : d[0 + c].x, d1 = kk ? d[4 + c].y : d[4 + c].x;
-                const float d2 = kk ? d[8 + c].y : d[8 + c].x, d3 = kk ? d[12 + c].y : d[12 + c].x;
-                t[0][c] = d0 - d2; t[1][c] = d1 + d2; t[2][c] = d2 - d1; t[3][c] = d1 - d3;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r * 4 + 0] = t[r][0] - t[r][2]; v[r * 4 + 1] = t[r][1] + t[r][2];
-                v[r * 4 + 2] = t[r][2] - t[r][1]; v[r * 4 + 3] = t[r][1] - t[r][3];
-            }
-            // channel of this lane in the chunk: 4 quad + 2 half + kk (the pairing of channels into MFMA k-pairs is free)
-#pragma unroll
-            for (int xi = 0; xi < 16; ++xi) {
-                const float u = ub[(xi * WKC + quad * 4 + kk) * WC + boff];
-                acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[xi], u, acc[xi], 0, 0, 0);
-            }
-        }
-    }
+        for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[xi], u[xi], acc[xi], 0, 0, 0);
+    };
+    float2 d0[16], d1[16];
+    float ua[16], ubb[16], v[16];
+    load_d(d0, 0);
+    load_u(ua, 0, 0);
+    if (prefetch) wino_stage(rawn, ubn, src_t0, src_t1, src_u, WPl, lda, ustride_xi, N, kcn, wave);
+    __builtin_amdgcn_sched_barrier(0);
+    // batch 0
+    load_u(ubb, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fix_d(d0);
+    wino_transform(d0, 0, v);
+    mfmas(v, ua);
+    __builtin_amdgcn_sched_barrier(0);
+    // batch 1
+    load_d(d1, 1);
+    load_u(ua, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    wino_transform(d0, 1, v);
+    mfmas(v, ubb);
+    __builtin_amdgcn_sched_barrier(0);
+    // batch 2
+    load_u(ubb, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    fix_d(d1);
+    wino_transform(d1, 0, v);
+    mfmas(v, ua);
+    __builtin_amdgcn_sched_barrier(0);
+    // batch 3
+    wino_transform(d1, 1, v);
+    mfmas(v, ubb);
 }
 
 template <int DIR>
@@ -214,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs args) {
     int cur = 0;
     for (int kc = 0; kc < nkc; ++kc) {
         wino_chunk(bufs + cur * RAW_F, bufs + 2 * RAW_F + cur * U_F, bufs + (cur ^ 1) * RAW_F, bufs + 2 * RAW_F + (cur ^ 1) * U_F,
-                   kc + 1 < nkc, src_t[0], src_t[1], src_u, g.WP, g.lda, ustride_xi, g.N, kc + 1, wave, aoff, boff, args.wodd != 0, zero_c3, acc, g.ablate);
+                   kc + 1 < nkc, src_t[0], src_t[1], src_u, g.WP, g.lda, ustride_xi, g.N, kc + 1, wave, aoff, boff, args.wodd != 0, zero_c3, acc);
         __builtin_amdgcn_s_waitcnt(0x0F70);          // the next chunk has landed
         __syncthreads();
         cur ^= 1;
@@ -235,7 +271,6 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs args) {
         out[2][0][r] = (s1[0] + s1[1]) + s1[2];
         out[3][0][r] = (s1[1] - s1[2]) - s1[3];
     }
-    if ((g.ablate & 4) && out[0][0][0] != 123.456f) return;          // timing experiments only
     tap_epilogue<4, 1>(g, out, bufs + wave * (32 * 33), rowa, rowy, wm * 128, n0 + wn * 32, lane, blk * 2 + wm);
 }
 
@@ -274,7 +309,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     a.halo = a.WP + 1;
     a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
     a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
-    { static int abl = -1; if (abl < 0) { const char* e = getenv("ASR_WINO_ABLATE"); abl = e ? atoi(e) : 0; } a.ablate = abl; }
+    a.ablate = 0;
     a.gate_mode = 0; a.gate_H = a.gate_W = 0; a.gate_a = nullptr; a.gate_dz = nullptr; a.gate_part = nullptr; a.gate_rows = nullptr;
     if (gs) { a.gate_mode = gs->mode; a.gate_H = gs->H; a.gate_W = gs->W; a.gate_a = gs->a; a.gate_dz = gs->dz; a.gate_part = gs->part; a.gate_rows = gs->rows; }
     w.Ut = Ut;

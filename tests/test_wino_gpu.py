@@ -1,0 +1,62 @@
+"""EXPERIMENTAL Winograd F(2x2,3x3) convolution (asr_tap_gemm_wino) against the tap-GEMM (asr_tap_gemm) and float64: forward with
+bias + ReLU + BN affine on both outputs, the data-gradient view with accumulation, even / odd plane widths, tile counts that
+do not fill a workgroup, borders left untouched."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from asr_dfcnn_transformer_amd import ops as o
+    return o
+
+
+def conv_ref(x, w, b=None):
+    import torch.nn.functional as F
+    y = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(3, 2, 0, 1), None if b is None else b.double(), padding=1)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 6, 5, 8, 64), (3, 4, 2, 16, 64), (2, 8, 12, 24, 128), (1, 16, 25, 32, 64), (5, 10, 7, 8, 192)])
+def test_forward_matches_tap_gemm_and_float64(ops, B, H, W, cin, cout):
+    g = torch.Generator(device='cuda').manual_seed(11)
+    x = ops.Plane(B, H, W, cin); xi = torch.randn(B, H, W, cin, device='cuda', generator=g); x.set_interior(xi)
+    w = torch.randn(3, 3, cin, cout, device='cuda', generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, device='cuda', generator=g) * 0.1
+    sc = 1 + 0.2 * torch.randn(cout, device='cuda', generator=g); sh = 0.1 * torch.randn(cout, device='cuda', generator=g)
+    d = ops.gemm_desc(x.NP, cin, cout, cin, cout, cout, cout, ntaps=9, B=B, H=H, W=W, relu=1)
+    assert ops.winograd_supported(d)
+    a0, y0, a1, y1 = (ops.Plane(B, H, W, cout) for _ in range(4))
+    ops.tap_gemm(d, x, w, bias, sc, sh, a0, y0)
+    ops.tap_gemm_wino(d, x, ops.winograd_weights(w, cin, cout, cout, 0), bias, sc, sh, a1, y1)
+    ref = torch.relu(conv_ref(xi, w, bias))
+    ea = (a1.interior().double() - ref).abs().max().item()
+    assert ea < 2e-5 * max(1.0, ref.abs().max().item()), ea
+    assert (a1.interior() - a0.interior()).abs().max().item() < 3e-5
+    assert (y1.interior() - y0.interior()).abs().max().item() < 3e-5
+    for p in (a1, y1):                                   # borders and guards stay zero
+        assert p.buf.abs().sum().item() == pytest.approx(p.interior().abs().sum().item(), rel=1e-5)
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 6, 5, 64, 8), (1, 12, 25, 128, 32), (3, 4, 4, 64, 16)])
+def test_data_gradient_view_with_accumulation(ops, B, H, W, cin, cout):
+    g = torch.Generator(device='cuda').manual_seed(12)
+    w = torch.randn(3, 3, cin, cout, device='cuda', generator=g) * 0.1
+    dz = ops.Plane(B, H, W, cout); dzi = torch.randn(B, H, W, cout, device='cuda', generator=g); dz.set_interior(dzi)
+    prev = torch.randn(B, H, W, cin, device='cuda', generator=g)
+    dx0, dx1 = ops.Plane(B, H, W, cin), ops.Plane(B, H, W, cin)
+    dx0.set_interior(prev); dx1.set_interior(prev)
+    bd = ops.gemm_desc(dz.NP, cout, cin, cout, cout, 0, cin, ntaps=9, B=B, H=H, W=W, wmode=1, accumulate=1)
+    if not ops.winograd_supported(bd):
+        pytest.skip('N % 64 != 0 for this view')
+    ops.tap_gemm(bd, dz, w, None, None, None, None, dx0)
+    ops.tap_gemm_wino(bd, dz, ops.winograd_weights(w, cout, cin, cout, 1), None, None, None, None, dx1)
+    assert (dx1.interior() - dx0.interior()).abs().max().item() < 3e-5
+
+
+def test_unsupported_shapes_are_reported(ops):
+    d = ops.gemm_desc(2 * 6 * 7, 8, 32, 8, 32, 32, 0, ntaps=9, B=2, H=5, W=6)      # odd height, N % 64 != 0
+    assert not ops.winograd_supported(d)
