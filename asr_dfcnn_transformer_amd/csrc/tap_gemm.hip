@@ -1128,6 +1128,10 @@ extern "C" int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const flo
     return tap_gemm_pw_impl(d, A, Wf, bias, scale, shift, out_a, out_y, stream, nullptr);
 }
 
+extern "C" int asr_tap_gemm_wino_gated_launch(const asr_gemm_desc* d, const float* dZ, const float* Ut, int mode, int gate_H, int gate_W,
+                                              const float* gate_a, const float* scale, const float* shift, float* dy_prev,
+                                              float* dz_out, float* partials, int* rows, void* stream);      // wino.hip
+
 // Data-gradient GEMM whose epilogue IS the backward prologue of the cell in front (tap_epilogue_gated).
 extern "C" size_t asr_tap_gemm_gated_workspace(const asr_gemm_desc* d) {
     if (!d) return 0;
@@ -1149,7 +1153,9 @@ extern "C" int asr_tap_gemm_gated(const asr_gemm_desc* d, const float* dZ, const
     int rows = 0;
     GateSpec gs;
     gs.mode = pool + 1; gs.H = gate_H; gs.W = gate_W; gs.a = gate_a; gs.dz = dz_out; gs.part = partials; gs.rows = &rows;
-    const int rc = prearranged ? tap_gemm_pw_impl(d, dZ, W, nullptr, bn_scale, bn_shift, nullptr, (float*)dy_prev, stream, &gs)
+    const int rc = prearranged == 2 ? asr_tap_gemm_wino_gated_launch(d, dZ, W, gs.mode, gs.H, gs.W, gs.a, bn_scale, bn_shift, (float*)dy_prev,
+                                                                     gs.dz, gs.part, gs.rows, stream)
+                 : prearranged ? tap_gemm_pw_impl(d, dZ, W, nullptr, bn_scale, bn_shift, nullptr, (float*)dy_prev, stream, &gs)
                                : tap_gemm_impl(d, dZ, W, nullptr, bn_scale, bn_shift, nullptr, (float*)dy_prev, stream, &gs);
     if (rc != ASR_OK) return rc;
     if (rows <= 0 || rows > asr_cdiv(d->M, 32) + 4) return ASR_ERR_UNSUPPORTED;

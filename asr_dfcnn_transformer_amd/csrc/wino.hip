@@ -77,9 +77,11 @@ __global__ void wino_weights_kernel(const float* __restrict__ W, int K, int N, i
 
 // DMA of one chunk: the raw patches (32 pieces: pixel x quad, 64 tiles each) and the weights (32 pieces of 4 rows x 64 channels);
 // wave w issues pieces w, w + 4, ...
-__device__ __forceinline__ void wino_stage(float* __restrict__ raw, float* __restrict__ ub, const float* __restrict__ src_t0,
-                                           const float* __restrict__ src_t1, const float* __restrict__ src_u, int WPl, int lda,
-                                           long ustride_xi, int N, int kc, int wave) {
+// Addresses are a wave-uniform pointer (scalar registers, scalar arithmetic) plus a 32-bit per-lane byte offset that never
+// changes: no vector instruction per piece.
+__device__ __forceinline__ void wino_stage(float* __restrict__ raw, float* __restrict__ ub, const char* __restrict__ abase,
+                                           unsigned off_t0, unsigned off_t1, const char* __restrict__ ubase, unsigned off_u,
+                                           int WPl, int lda, long ustride_xi, int N, int kc, int wave) {
     // raw: piece = pixel * 2 + tile half; a lane fetches quad (lane & 1) of tile half * 32 + lane / 2 -- the two quads of a
     // pixel are 32 contiguous bytes fetched by neighbouring lanes (one 64-byte request instead of two)
 #pragma unroll
@@ -87,22 +89,24 @@ __device__ __forceinline__ void wino_stage(float* __restrict__ raw, float* __res
         const int p = wave + 4 * j;
         const int px = p >> 1, th = p & 1;
         const int r = px >> 2, c = px & 3;
-        const float* base = th ? src_t1 : src_t0;
-        __builtin_amdgcn_global_load_lds((wn_glb_f*)(base + ((long)r * WPl + c) * lda + kc * WKC),
-                                         (wn_lds_f*)(raw + p * 256), 16, 0, 0);
+        const char* pb = abase + (((long)r * WPl + c) * lda + kc * WKC) * 4;          // uniform
+        __builtin_amdgcn_global_load_lds((wn_glb_f*)(pb + (th ? off_t1 : off_t0)), (wn_lds_f*)(raw + p * 256), 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int p = wave + 4 * j;                  // piece = xi * 2 + (ci >> 2)
         const int xi = p >> 1, cig = p & 1;
-        __builtin_amdgcn_global_load_lds((wn_glb_f*)(src_u + xi * ustride_xi + (long)(kc * WKC + cig * 4) * N),
-                                         (wn_lds_f*)(ub + p * 256), 16, 0, 0);
+        const char* pb = ubase + (xi * ustride_xi + (long)(kc * WKC + cig * 4) * N) * 4;   // uniform
+        __builtin_amdgcn_global_load_lds((wn_glb_f*)(pb + off_u), (wn_lds_f*)(ub + p * 256), 16, 0, 0);
     }
 }
 
 // one chunk of 8 input channels = four batches (channel quad x pair member) of one patch transform + 16 MFMAs.  One wave
 // per SIMD: nothing hides an LDS wait, so the operands of batch b + 1 (its 16 weights, and the raw pixels of the next
-// quad) are requested BEFORE the transform and the MFMAs of batch b.
+// quad) are requested BEFORE the transform and the MFMAs of batch b.  The transform's adds must NOT be interleaved with
+// the MFMAs (hipcc sinks each add to just before the MFMA that consumes it): on this pipe a vector instruction behind an
+// fp32 MFMA waits for the MFMA to finish and the next MFMA pays again (tools/mfma_valu.hip: 1 MFMA + 4 v_fma = 129
+// cycles, not 64 + 16) -- alternating costs a whole extra MFMA time per MFMA.
 __device__ __forceinline__ void wino_transform(const float2 (&d)[16], int kk, float (&v)[16]) {
     float t[4][4];
 #pragma unroll
@@ -119,8 +123,8 @@ __device__ __forceinline__ void wino_transform(const float2 (&d)[16], int kk, fl
 }
 
 __device__ __forceinline__ void wino_chunk(const float* __restrict__ raw, const float* __restrict__ ub, float* __restrict__ rawn,
-                                           float* __restrict__ ubn, bool prefetch, const float* __restrict__ src_t0,
-                                           const float* __restrict__ src_t1, const float* __restrict__ src_u,
+                                           float* __restrict__ ubn, bool prefetch, const char* __restrict__ abase,
+                                           unsigned off_t0, unsigned off_t1, const char* __restrict__ ubase, unsigned off_u,
                                            int WPl, int lda, long ustride_xi, int N, int kcn, int wave,
                                            int aoff, int boff, bool wodd, bool zero_c3, floatx16 (&acc)[16]) {
     auto load_d = [&](float2 (&d)[16], int quad) {
@@ -142,38 +146,65 @@ __device__ __forceinline__ void wino_chunk(const float* __restrict__ raw, const 
 #pragma unroll
         for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[xi], u[xi], acc[xi], 0, 0, 0);
     };
-    float2 d0[16], d1[16];
+    float2 d[16];
     float ua[16], ubb[16], v[16];
-    load_d(d0, 0);
+    load_d(d, 0);
     load_u(ua, 0, 0);
-    if (prefetch) wino_stage(rawn, ubn, src_t0, src_t1, src_u, WPl, lda, ustride_xi, N, kcn, wave);
+    if (prefetch) wino_stage(rawn, ubn, abase, off_t0, off_t1, ubase, off_u, WPl, lda, ustride_xi, N, kcn, wave);
     __builtin_amdgcn_sched_barrier(0);
     // batch 0
     load_u(ubb, 0, 1);
     __builtin_amdgcn_sched_barrier(0);
-    fix_d(d0);
-    wino_transform(d0, 0, v);
+    fix_d(d);
+    wino_transform(d, 0, v);
+    __builtin_amdgcn_sched_barrier(0);     // all 32 adds first, then 16 MFMAs back to back (see above)
     mfmas(v, ua);
     __builtin_amdgcn_sched_barrier(0);
-    // batch 1
-    load_d(d1, 1);
+    // batch 1: the raw pixels of quad 0 are dead after this transform -- quad 1 is fetched into the same registers
     load_u(ua, 1, 0);
     __builtin_amdgcn_sched_barrier(0);
-    wino_transform(d0, 1, v);
+    wino_transform(d, 1, v);
+    __builtin_amdgcn_sched_barrier(0);
+    load_d(d, 1);
+    __builtin_amdgcn_sched_barrier(0);
     mfmas(v, ubb);
     __builtin_amdgcn_sched_barrier(0);
     // batch 2
     load_u(ubb, 1, 1);
     __builtin_amdgcn_sched_barrier(0);
-    fix_d(d1);
-    wino_transform(d1, 0, v);
+    fix_d(d);
+    wino_transform(d, 0, v);
+    __builtin_amdgcn_sched_barrier(0);
     mfmas(v, ua);
     __builtin_amdgcn_sched_barrier(0);
     // batch 3
-    wino_transform(d1, 1, v);
+    wino_transform(d, 1, v);
+    __builtin_amdgcn_sched_barrier(0);
     mfmas(v, ubb);
 }
 
+// per-lane DMA offsets of one work item (tile block blk, channel block nb)
+__device__ __forceinline__ void wino_offsets(const WinoArgs& args, long t0, int n0, int lane, unsigned (&off_t)[2], unsigned& off_u) {
+    const TapGemmArgs& g = args.g;
+#pragma unroll
+    for (int th = 0; th < 2; ++th) {
+        // quad (lane & 1) of tiles t0 + lane / 2 and t0 + 32 + lane / 2 (clamped): byte offset of the top-left pixel of the
+        // patch in the plane (planes are < 4 GB)
+        long t = t0 + th * 32 + (lane >> 1);
+        if (t > args.ntiles - 1) t = args.ntiles - 1;
+        const int per = args.TH * args.TW;
+        const int b = (int)(t / per);
+        const int rr = (int)(t - (long)b * per);
+        const int ti = rr / args.TW, tj = rr - ti * args.TW;
+        off_t[th] = (unsigned)((((long)b * g.HPWP + (long)(2 * ti) * g.WP + 2 * tj) * g.lda + (lane & 1) * 4) * 4);
+    }
+    // weights: row lane / 16 of a 4-row piece, column quad lane % 16
+    off_u = (unsigned)(((long)(lane >> 4) * g.N + n0 + (lane & 15) * 4) * 4);
+}
+
+// Persistent workgroups (one per CU): work item = (tile block, channel block), channel blocks of one tile block adjacent.
+// The first chunk of the NEXT item is requested before the epilogue of the current one, so its latency and the epilogue's
+// stores overlap -- with one workgroup per CU nothing else would cover them.
 template <int DIR>
 __global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs args) {
     const TapGemmArgs& g = args.g;
@@ -181,97 +212,108 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs args) {
     int* rowa = (int*)smem;                          // [2 wave rows][4 pixels][32 tiles]
     int* rowy = rowa + 256;
     float* bufs = smem + 512;                        // raw0 | raw1 | u0 | u1
-    static_assert(4 * 32 * 33 <= 2 * RAW_F, "epilogue scratch must fit in the raw buffers");
+    float* scratch = bufs + 2 * RAW_F + 2 * U_F;     // epilogue transpose scratch, 4 waves x 32 x 33
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
     const int nnb = g.ntn;                           // channel blocks
-    const int blk = blockIdx.x / nnb, nb = blockIdx.x - blk * nnb;
-    const long t0 = (long)blk * WT;
-    const int n0 = nb * WC;
-
-    // this lane as a DMA lane: quad (lane & 1) of tiles t0 + lane / 2 and t0 + 32 + lane / 2 (clamped), top-left pixel of the patch
-    const float* src_t[2];
-#pragma unroll
-    for (int th = 0; th < 2; ++th) {
-        long t = t0 + th * 32 + (lane >> 1);
-        if (t > args.ntiles - 1) t = args.ntiles - 1;
-        const int per = args.TH * args.TW;
-        const int b = (int)(t / per);
-        const int rr = (int)(t - (long)b * per);
-        const int ti = rr / args.TW, tj = rr - ti * args.TW;
-        src_t[th] = g.A + ((long)b * g.HPWP + (long)(2 * ti) * g.WP + 2 * tj) * g.lda + (lane & 1) * 4;
-    }
-    // ... and as a weight DMA lane: row lane / 16 of a 4-row piece, column quad lane % 16
-    const float* src_u = args.Ut + (long)(lane >> 4) * g.N + n0 + (lane & 15) * 4;
+    const int nwork = g.ntm * nnb;
+    const char* abase = (const char*)g.A;
+    const char* ubase = (const char*)args.Ut;
     const long ustride_xi = (long)g.K * g.N;
-
-    // row tables of the epilogue: local row = wm * 128 + pixel * 32 + tile
-    {
-        const int tl = tid & 63, pl = tid >> 6;      // 64 tiles x 4 pixels = 256 entries
-        const long t = t0 + tl;
-        int ra = -1, ry = -1;
-        if (t < args.ntiles) {
-            const int per = args.TH * args.TW;
-            const int b = (int)(t / per);
-            const int rr = (int)(t - (long)b * per);
-            const int ti = rr / args.TW, tj = rr - ti * args.TW;
-            const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
-            if (ww <= g.Wd) {
-                ra = (int)((long)b * g.HPWP + (long)hh * g.WP + ww);
-                ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : ra;
-            }
-        }
-        const int m = (tl >> 5) * 128 + pl * 32 + (tl & 31);
-        rowa[m] = ra; rowy[m] = ry;
-    }
-    // does this lane's (compute) tile sit in the last tile column of an odd-width plane?
-    bool zero_c3 = false;
-    if (args.wodd) {
-        long t = t0 + wm * 32 + li;
-        if (t > args.ntiles - 1) t = args.ntiles - 1;
-        zero_c3 = (int)(t % args.TW) == args.TW - 1;
-    }
-
-    floatx16 acc[16];
-#pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
-
     const int aoff = (wm * 32 + li) * 8 + lh * 2;    // this lane's pair: slot (tile, quad) of a pixel row, half lh
     const int boff = lh * 2 * WC + wn * 32 + li;     // half 1 reads channel + 2
     const int nkc = g.K / WKC;
 
-    wino_stage(bufs, bufs + 2 * RAW_F, src_t[0], src_t[1], src_u, g.WP, g.lda, ustride_xi, g.N, 0, wave);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
-
+    int w = blockIdx.x;
+    if (w >= nwork) return;
+    unsigned off_t[2], off_u;
+    {
+        const int blk = w / nnb, nb = w - blk * nnb;
+        wino_offsets(args, (long)blk * WT, nb * WC, lane, off_t, off_u);
+    }
     int cur = 0;
-    for (int kc = 0; kc < nkc; ++kc) {
-        wino_chunk(bufs + cur * RAW_F, bufs + 2 * RAW_F + cur * U_F, bufs + (cur ^ 1) * RAW_F, bufs + 2 * RAW_F + (cur ^ 1) * U_F,
-                   kc + 1 < nkc, src_t[0], src_t[1], src_u, g.WP, g.lda, ustride_xi, g.N, kc + 1, wave, aoff, boff, args.wodd != 0, zero_c3, acc);
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // the next chunk has landed
-        __syncthreads();
-        cur ^= 1;
-    }
+    wino_stage(bufs, bufs + 2 * RAW_F, abase, off_t[0], off_t[1], ubase, off_u, g.WP, g.lda, ustride_xi, g.N, 0, wave);
 
-    // inverse transform, lane-local: register r of the 16 accumulators is one tile
-    floatx16 out[4][1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float s0[4], s1[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            s0[c] = (acc[0 + c][r] + acc[4 + c][r]) + acc[8 + c][r];
-            s1[c] = (acc[4 + c][r] - acc[8 + c][r]) - acc[12 + c][r];
+    for (; w < nwork; w += gridDim.x) {
+        const int blk = w / nnb, nb = w - blk * nnb;
+        const long t0 = (long)blk * WT;
+        const int n0 = nb * WC;
+        // row tables of the epilogue: local row = wm * 128 + pixel * 32 + tile (the previous item's epilogue has finished
+        // with them: it ends with a barrier)
+        {
+            const int tl = tid & 63, pl = tid >> 6;      // 64 tiles x 4 pixels = 256 entries
+            const long t = t0 + tl;
+            int ra = -1, ry = -1;
+            if (t < args.ntiles) {
+                const int per = args.TH * args.TW;
+                const int b = (int)(t / per);
+                const int rr = (int)(t - (long)b * per);
+                const int ti = rr / args.TW, tj = rr - ti * args.TW;
+                const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
+                if (ww <= g.Wd) {
+                    ra = (int)((long)b * g.HPWP + (long)hh * g.WP + ww);
+                    ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : ra;
+                }
+            }
+            const int m = (tl >> 5) * 128 + pl * 32 + (tl & 31);
+            rowa[m] = ra; rowy[m] = ry;
         }
-        out[0][0][r] = (s0[0] + s0[1]) + s0[2];
-        out[1][0][r] = (s0[1] - s0[2]) - s0[3];
-        out[2][0][r] = (s1[0] + s1[1]) + s1[2];
-        out[3][0][r] = (s1[1] - s1[2]) - s1[3];
+        // does this lane's (compute) tile sit in the last tile column of an odd-width plane?
+        bool zero_c3 = false;
+        if (args.wodd) {
+            long t = t0 + wm * 32 + li;
+            if (t > args.ntiles - 1) t = args.ntiles - 1;
+            zero_c3 = (int)(t % args.TW) == args.TW - 1;
+        }
+
+        floatx16 acc[16];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // chunk 0 of this item (requested before the previous epilogue) has landed
+        __syncthreads();
+
+        for (int kc = 0; kc < nkc; ++kc) {
+            wino_chunk(bufs + cur * RAW_F, bufs + 2 * RAW_F + cur * U_F, bufs + (cur ^ 1) * RAW_F, bufs + 2 * RAW_F + (cur ^ 1) * U_F,
+                       kc + 1 < nkc, abase, off_t[0], off_t[1], ubase, off_u, g.WP, g.lda, ustride_xi, g.N, kc + 1, wave, aoff, boff,
+                       args.wodd != 0, zero_c3, acc);
+            if (kc + 1 < nkc) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);  // the next chunk has landed
+                __syncthreads();
+                cur ^= 1;
+            }
+        }
+        // every wave has issued its last reads of buffer `cur`; the other buffer is free: the next item's first chunk goes there
+        const int wnext = w + gridDim.x;
+        if (wnext < nwork) {
+            const int blk2 = wnext / nnb, nb2 = wnext - blk2 * nnb;
+            wino_offsets(args, (long)blk2 * WT, nb2 * WC, lane, off_t, off_u);
+            wino_stage(bufs + (cur ^ 1) * RAW_F, bufs + 2 * RAW_F + (cur ^ 1) * U_F, abase, off_t[0], off_t[1], ubase, off_u, g.WP, g.lda,
+                       ustride_xi, g.N, 0, wave);
+        }
+        cur ^= 1;
+
+        // inverse transform, lane-local: register r of the 16 accumulators is one tile.  Two pixel rows of the tiles at a
+        // time (32 live output registers beside the 256 accumulators instead of 64)
+#pragma unroll
+        for (int pair = 0; pair < 2; ++pair) {
+            floatx16 out[2][1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float sx[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    sx[c] = pair == 0 ? (acc[0 + c][r] + acc[4 + c][r]) + acc[8 + c][r] : (acc[4 + c][r] - acc[8 + c][r]) - acc[12 + c][r];
+                out[0][0][r] = (sx[0] + sx[1]) + sx[2];
+                out[1][0][r] = (sx[1] - sx[2]) - sx[3];
+            }
+            tap_epilogue<2, 1>(g, out, scratch + wave * (32 * 33), rowa, rowy, wm * 128 + pair * 64, n0 + wn * 32, lane, (blk * 2 + wm) * 2 + pair);
+        }
+        __syncthreads();                             // the row tables are rewritten by the next item
     }
-    tap_epilogue<4, 1>(g, out, bufs + wave * (32 * 33), rowa, rowy, wm * 128, n0 + wn * 32, lane, blk * 2 + wm);
 }
 
 }  // namespace
@@ -318,18 +360,27 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     w.wodd = d->W & 1;
     const int nblk = asr_cdiv(w.ntiles, WT);
     a.ntm = nblk; a.ntn = d->N / WC;
-    if (a.gate_rows) *a.gate_rows = nblk * 2;
-    const size_t lds = (size_t)(512 + 2 * RAW_F + 2 * U_F) * sizeof(float);
+    if (a.gate_rows) *a.gate_rows = nblk * 4;
+    const size_t lds = (size_t)(512 + 2 * RAW_F + 2 * U_F + 4 * 32 * 33) * sizeof(float);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    const int nwork = nblk * a.ntn;
+    static int gmul = -1;
+    if (gmul < 0) { const char* e = getenv("ASR_WINO_GRID"); gmul = e ? atoi(e) : 1; }       // 0: one workgroup per work item
+    const int grid = (gmul <= 0 || nwork < ncu * gmul) ? nwork : ncu * gmul;
     auto k0 = wino_kernel<0>;
     auto k1 = wino_kernel<1>;
     static bool attr0 = false, attr1 = false;
     hipStream_t st = (hipStream_t)stream;
     if (d->wmode) {
         if (!attr1) { (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
-        hipLaunchKernelGGL(k1, dim3(nblk * a.ntn), dim3(256), lds, st, w);
+        hipLaunchKernelGGL(k1, dim3(grid), dim3(256), lds, st, w);
     } else {
         if (!attr0) { (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr0 = true; }
-        hipLaunchKernelGGL(k0, dim3(nblk * a.ntn), dim3(256), lds, st, w);
+        hipLaunchKernelGGL(k0, dim3(grid), dim3(256), lds, st, w);
     }
     ASR_CHECK_LAUNCH("tap_gemm_wino");
     ASR_NOTE_KERNEL("wino_kernel<%d>", d->wmode ? 1 : 0);
@@ -340,4 +391,13 @@ extern "C" int asr_tap_gemm_wino(const asr_gemm_desc* d, const float* A, const f
                                  const float* bias, const float* scale, const float* shift,
                                  float* out_a, float* out_y, void* stream) {
     return wino_impl(d, A, Ut, bias, scale, shift, out_a, out_y, stream, nullptr);
+}
+
+// Launch of the gated data-gradient (asr_tap_gemm_gated with prearranged == 2; the caller folds the partial rows)
+extern "C" int asr_tap_gemm_wino_gated_launch(const asr_gemm_desc* d, const float* dZ, const float* Ut, int mode, int gate_H, int gate_W,
+                                              const float* gate_a, const float* scale, const float* shift, float* dy_prev,
+                                              float* dz_out, float* partials, int* rows, void* stream) {
+    WinoGate gs;
+    gs.mode = mode; gs.H = gate_H; gs.W = gate_W; gs.a = gate_a; gs.dz = dz_out; gs.part = partials; gs.rows = rows;
+    return wino_impl(d, dZ, Ut, nullptr, scale, shift, nullptr, dy_prev, stream, &gs);
 }

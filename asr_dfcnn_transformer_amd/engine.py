@@ -367,6 +367,18 @@ class DFCNNEngine:
                     _, src, dst, cin, cout, k, pool = op
                     self.wf_f[dst] = torch.zeros(ops._lib.load().asr_arrange_weights_bytes(9, cin, cout) // 4, dtype=torch.float32, device=dev)
                     self.wf_b[dst] = torch.zeros(ops._lib.load().asr_arrange_weights_bytes(9, cout, cin) // 4, dtype=torch.float32, device=dev)
+        # EXPERIMENTAL (ASR_WINO=1): Winograd F(2x2,3x3) kernels for the layers / directions they support (wino.hip)
+        self.wino = os.environ.get('ASR_WINO', '0') == '1' and self.pw
+        self.wt_f, self.wt_b = {}, {}
+        if self.wino:
+            which = os.environ.get('ASR_WINO_DIRS', 'fb')
+            for op in self.g:
+                if op[0] == 'cell' and op[1] != 'x' and op[5] == 3:
+                    _, src, dst, cin, cout, k, pool = op
+                    if 'f' in which and ops.winograd_supported(self.fdesc[dst]):
+                        self.wt_f[dst] = torch.zeros(16 * cin * cout, dtype=torch.float32, device=dev)
+                    if 'b' in which and ops.winograd_supported(self.bdesc[dst]):
+                        self.wt_b[dst] = torch.zeros(16 * cin * cout, dtype=torch.float32, device=dev)
         self.labels = torch.zeros(B, MAX_LABEL, dtype=torch.int32, device=dev)
         self.label_len = torch.zeros(B, dtype=torch.int32, device=dev)
         self.seq_len = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -449,6 +461,14 @@ class DFCNNEngine:
         self._xpad[n:].zero_()
         return self._xpad
 
+    def _winograd_weights(self):
+        for dst, buf in self.wt_f.items():
+            cin, cout = self._cell_dims[dst]
+            ops.winograd_weights(self.p(dst, 'w'), cin, cout, cout, 0, buf)
+        for dst, buf in self.wt_b.items():
+            cin, cout = self._cell_dims[dst]
+            ops.winograd_weights(self.p(dst, 'w'), cout, cin, cout, 1, buf)
+
     def forward(self, x):
         """x: [B, T, F] float32 on the device (the wav_input placeholder without its last axis); fewer rows are padded
         (pad_batch)."""
@@ -473,6 +493,7 @@ class DFCNNEngine:
                     cin, cout = self._cell_dims[dst]
                     ops.arrange_weights(self.p(dst, 'w'), 9, cin, cout, cout, 0, buf)
                     ops.arrange_weights(self.p(dst, 'w'), 9, cout, cin, cout, 1, self.wf_b[dst])
+                self._winograd_weights()
                 wf_ready = torch.cuda.Event()
                 wf_ready.record()
         else:
@@ -480,6 +501,7 @@ class DFCNNEngine:
                 cin, cout = self._cell_dims[dst]
                 ops.arrange_weights(self.p(dst, 'w'), 9, cin, cout, cout, 0, buf)
                 ops.arrange_weights(self.p(dst, 'w'), 9, cout, cin, cout, 1, self.wf_b[dst])
+            self._winograd_weights()
         for op in self.g:
             if op[0] == 'cell':
                 _, src, dst, cin, cout, k, pool = op
@@ -494,6 +516,8 @@ class DFCNNEngine:
                 out_y = None if pool else (self.flat[dst] if dst in self.flat else self.y[dst])
                 if dst in self.ws_f:
                     ops.tap_gemm_bx6(self.fdesc[dst], self.y[src], self.ws_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], out_y)
+                elif dst in self.wt_f:
+                    ops.tap_gemm_wino(self.fdesc[dst], self.y[src], self.wt_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], out_y)
                 elif dst in self.wf_f:
                     ops.tap_gemm_pw(self.fdesc[dst], self.y[src], self.wf_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], out_y)
                 else:
@@ -697,13 +721,16 @@ class DFCNNEngine:
                     top = next(o for o in self.g if o[0] == 'cell' and o[2] == tgt)
                     Hf, Wf, _ = self.res[top[1]]
                     dzt = acquire_dz((Hf, Wf, top[4]))
-                    ops.tap_gemm_gated(d, dz, self.wf_b[dst] if dst in self.wf_b else self.p(dst, 'w'), dst in self.wf_b,
+                    ops.tap_gemm_gated(d, dz, self.wt_b[dst] if dst in self.wt_b else self.wf_b[dst] if dst in self.wf_b else self.p(dst, 'w'),
+                                       2 if dst in self.wt_b else 1 if dst in self.wf_b else 0,
                                        {None: 0, 'avg': 1, 'max': 2}[top[6]], self.a[tgt], self.scale_of(tgt), self.p(tgt, 'beta'),
                                        dx if acc else None, dzt, self.dscale_of(tgt), self.gview(tgt, 'beta'),
                                        self.gview(tgt, 'b'), self.ws)
                     fused_dz[tgt] = dzt
                 elif dst in self.ws_b:
                     ops.tap_gemm_bx6(d, dz, self.ws_b[dst], None, None, None, None, dx, dgrad=True)
+                elif dst in self.wt_b:
+                    ops.tap_gemm_wino(d, dz, self.wt_b[dst], None, None, None, None, dx)
                 elif dst in self.wf_b:
                     ops.tap_gemm_pw(d, dz, self.wf_b[dst], None, None, None, None, dx)
                 else:

@@ -427,7 +427,8 @@ int asr_tap_gemm_wino(const asr_gemm_desc* d, const float* A, const float* Wt,
  * acoustic_model2.py:107-133, acoustic_model.py:103-130) applied in the GEMM's epilogue: the tile of dL/dy(k-1) never
  * goes to memory, dZ(k-1) is written directly, and the per-channel sums come out as tile partials folded in a fixed order.
  *   d          the data-gradient descriptor (wmode 1, ntaps 9 or 1, pixel-indexed: H, W = the plane of cell k-1's OUTPUT)
- *   dZ, W      as for asr_tap_gemm (W HWIO) or asr_tap_gemm_pw (prearranged != 0: data-gradient view from asr_arrange_weights)
+ *   dZ, W      as for asr_tap_gemm (W HWIO), asr_tap_gemm_pw (prearranged == 1: data-gradient view from asr_arrange_weights) or
+ *              asr_tap_gemm_wino (prearranged == 2: asr_winograd_weights with wmode 1; EXPERIMENTAL)
  *   pool       0 none, 1 average 2x2, 2 maximum 2x2 (first maximum of bn_scale * a + bn_shift in row-major window order)
  *   gate_H/W   cell k-1's pre-pool plane: H x W for pool 0, 2H x 2W otherwise (odd sizes are not supported: use asr_cell_bwd_pre)
  *   gate_a     cell k-1's post-ReLU pre-BN activations, padded plane [B][gate_H+1][gate_W+1][N]
