@@ -316,6 +316,217 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs args) {
     }
 }
 
+// ---- eight waves per workgroup: the same 64 tiles x 64 channels, the sixteen positions split between the two waves of a
+// SIMD (wave xh owns transform columns 2 xh and 2 xh + 1: 8 accumulators = 128 registers), so that two waves cover each
+// other's stalls -- with one wave per SIMD the pipe was busy 34 % of the time.  A wave needs three patch columns (12
+// pixels, 20 adds per 8 MFMAs); the two halves meet once per item: each wave finishes one pixel ROW of the tiles and gets
+// the two column sums it lacks from its partner through LDS.
+// Raw layout of this kernel: [pixel 16][quad 2][tile 64] 16-byte slots.  Lane half lh reads quad lh of its tile with ONE
+// conflict-free ds_read_b128 per pixel and chunk: the MFMA k-pair kp contracts channels kp (half 0) and 4 + kp (half 1) of the
+// chunk -- the pairing of channels into k-pairs is free as long as the weights follow it -- so all four floats are used.
+template <int XH>
+__device__ __forceinline__ void wino8_transform(const float4 (&d)[12], int kp, float (&v)[8]) {
+    // d[r * 3 + cc] = patch pixel (r, XH + cc), component kp
+    auto comp = [&](const float4& q) { return kp == 0 ? q.x : kp == 1 ? q.y : kp == 2 ? q.z : q.w; };
+    float t[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float d0 = comp(d[0 + c]), d1 = comp(d[3 + c]), d2 = comp(d[6 + c]), d3 = comp(d[9 + c]);
+        t[0][c] = d0 - d2; t[1][c] = d1 + d2; t[2][c] = d2 - d1; t[3][c] = d1 - d3;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (XH == 0) { v[r * 2 + 0] = t[r][0] - t[r][2]; v[r * 2 + 1] = t[r][1] + t[r][2]; }       // columns 0, 1 of V
+        else         { v[r * 2 + 0] = t[r][1] - t[r][0]; v[r * 2 + 1] = t[r][0] - t[r][2]; }       // columns 2, 3 of V
+    }
+}
+
+// DMA of one chunk by eight waves: raw piece = pixel * 2 + quad (64 tiles), weight piece = xi * 2 + (ci >> 2)
+__device__ __forceinline__ void wino8_stage(float* __restrict__ raw, float* __restrict__ ub, const char* __restrict__ abase,
+                                            unsigned off_t, const char* __restrict__ ubase, unsigned off_u,
+                                            int WPl, int lda, long ustride_xi, int N, int kc, int wave) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = wave + 8 * j;
+        const int px = p >> 1, quad = p & 1;
+        const int r = px >> 2, c = px & 3;
+        const char* pb = abase + (((long)r * WPl + c) * lda + kc * WKC + quad * 4) * 4;      // uniform
+        __builtin_amdgcn_global_load_lds((wn_glb_f*)(pb + off_t), (wn_lds_f*)(raw + p * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = wave + 8 * j;
+        const int xi = p >> 1, cig = p & 1;
+        const char* pb = ubase + (xi * ustride_xi + (long)(kc * WKC + cig * 4) * N) * 4;     // uniform
+        __builtin_amdgcn_global_load_lds((wn_glb_f*)(pb + off_u), (wn_lds_f*)(ub + p * 256), 16, 0, 0);
+    }
+}
+
+template <int XH>
+__device__ __forceinline__ void wino8_chunk(const float* __restrict__ raw, const float* __restrict__ ub, float* __restrict__ rawn,
+                                            float* __restrict__ ubn, bool prefetch, const char* __restrict__ abase,
+                                            unsigned off_t, const char* __restrict__ ubase, unsigned off_u,
+                                            int WPl, int lda, long ustride_xi, int N, int kcn, int wave,
+                                            int aoff, int boff, bool wodd, bool zero_c3, floatx16 (&acc)[8]) {
+    auto load_u = [&](float (&u)[8], int kp) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) u[r * 2 + j] = ub[((r * 4 + 2 * XH + j) * WKC + kp) * WC + boff];
+    };
+    auto mfmas = [&](const float (&v)[8], const float (&u)[8]) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i], u[i], acc[i], 0, 0, 0);
+    };
+    float4 d[12];
+    float ua[8], ubb[8], v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d[r * 3 + c] = *(const float4*)(raw + (r * 4 + XH + c) * (2 * WT * 4) + aoff);
+    load_u(ua, 0);
+    if (prefetch) wino8_stage(rawn, ubn, abase, off_t, ubase, off_u, WPl, lda, ustride_xi, N, kcn, wave);
+    __builtin_amdgcn_sched_barrier(0);
+    if (XH == 1 && wodd) {       // patch column 3 is this half's third column
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (zero_c3) d[r * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // four batches (k-pairs): the next batch's weights are requested before this batch's adds and MFMAs; the adds of a batch
+    // all come before its MFMAs (an add behind an fp32 MFMA waits for it, and the next MFMA pays again)
+    load_u(ubb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    wino8_transform<XH>(d, 0, v);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(v, ua);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(ua, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    wino8_transform<XH>(d, 1, v);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(v, ubb);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(ubb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    wino8_transform<XH>(d, 2, v);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(v, ua);
+    __builtin_amdgcn_sched_barrier(0);
+    wino8_transform<XH>(d, 3, v);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(v, ubb);
+}
+
+template <int XH>
+__device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem, int blk, int nb) {
+    const TapGemmArgs& g = args.g;
+    int* rowa = (int*)smem;                          // [2 wave rows][4 pixels][32 tiles]
+    int* rowy = rowa + 256;
+    float* bufs = smem + 512;                        // raw0 | raw1 | u0 | u1
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = tid >> 6, wm = (wave >> 1) & 1, wn = wave & 1;      // wave = xh * 4 + wm * 2 + wn
+    const long t0 = (long)blk * WT;
+    const int n0 = nb * WC;
+    const char* abase = (const char*)g.A;
+    const char* ubase = (const char*)args.Ut;
+    const long ustride_xi = (long)g.K * g.N;
+    const int aoff = (lh * WT + wm * 32 + li) * 4;   // slot (quad = lh, tile) of a pixel
+    const int boff = lh * 4 * WC + wn * 32 + li;     // half 1 contracts channels 4 .. 7 of the chunk
+    const int nkc = g.K / WKC;
+
+    // this lane as a DMA lane: tile t0 + lane (clamped): byte offset of the top-left pixel of its patch (planes are < 4 GB);
+    // weights: row lane / 16 of a 4-row piece, column quad lane % 16
+    unsigned off_t, off_u;
+    {
+        long t = t0 + lane;
+        if (t > args.ntiles - 1) t = args.ntiles - 1;
+        const int per = args.TH * args.TW;
+        const int b = (int)(t / per);
+        const int rr = (int)(t - (long)b * per);
+        const int ti = rr / args.TW, tj = rr - ti * args.TW;
+        off_t = (unsigned)((((long)b * g.HPWP + (long)(2 * ti) * g.WP + 2 * tj) * g.lda) * 4);
+        off_u = (unsigned)(((long)(lane >> 4) * g.N + n0 + (lane & 15) * 4) * 4);
+    }
+    wino8_stage(bufs, bufs + 2 * RAW_F, abase, off_t, ubase, off_u, g.WP, g.lda, ustride_xi, g.N, 0, wave);
+    if (tid < 256) {
+        const int tl = tid & 63, pl = tid >> 6;      // 64 tiles x 4 pixels = 256 entries
+        const long t = t0 + tl;
+        int ra = -1, ry = -1;
+        if (t < args.ntiles) {
+            const int per = args.TH * args.TW;
+            const int b = (int)(t / per);
+            const int rr = (int)(t - (long)b * per);
+            const int ti = rr / args.TW, tj = rr - ti * args.TW;
+            const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
+            if (ww <= g.Wd) {
+                ra = (int)((long)b * g.HPWP + (long)hh * g.WP + ww);
+                ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : ra;
+            }
+        }
+        const int m = (tl >> 5) * 128 + pl * 32 + (tl & 31);
+        rowa[m] = ra; rowy[m] = ry;
+    }
+    bool zero_c3 = false;
+    if (args.wodd) {
+        long t = t0 + wm * 32 + li;
+        if (t > args.ntiles - 1) t = args.ntiles - 1;
+        zero_c3 = (int)(t % args.TW) == args.TW - 1;
+    }
+    floatx16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    int cur = 0;
+    for (int kc = 0; kc < nkc; ++kc) {
+        wino8_chunk<XH>(bufs + cur * RAW_F, bufs + 2 * RAW_F + cur * U_F, bufs + (cur ^ 1) * RAW_F, bufs + 2 * RAW_F + (cur ^ 1) * U_F,
+                        kc + 1 < nkc, abase, off_t, ubase, off_u, g.WP, g.lda, ustride_xi, g.N, kc + 1, wave, aoff, boff,
+                        args.wodd != 0, zero_c3, acc);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // own column sums: m(r, j) = acc[r * 2 + j], transform column c = 2 XH + j
+    floatx16 s0[2], s1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[j][r] = (acc[0 + j][r] + acc[2 + j][r]) + acc[4 + j][r];
+            s1[j][r] = (acc[2 + j][r] - acc[4 + j][r]) - acc[6 + j][r];
+        }
+    // half 0 finishes pixel row 0 and needs s0 of columns 2, 3; half 1 finishes pixel row 1 and needs s1 of columns 0, 1
+    float* xch = bufs + (wave & 3) * 4096 + XH * 2048;             // [32 registers][64 lanes] per wave (the tile buffers are free)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(j * 16 + r) * 64 + lane] = XH == 0 ? s1[j][r] : s0[j][r];
+    __syncthreads();
+    const float* pch = bufs + (wave & 3) * 4096 + (XH ^ 1) * 2048;
+    floatx16 out[2][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float c0, c1, c2, c3;
+        if (XH == 0) { c0 = s0[0][r]; c1 = s0[1][r]; c2 = pch[(0 * 16 + r) * 64 + lane]; c3 = pch[(1 * 16 + r) * 64 + lane]; }
+        else         { c0 = pch[(0 * 16 + r) * 64 + lane]; c1 = pch[(1 * 16 + r) * 64 + lane]; c2 = s1[0][r]; c3 = s1[1][r]; }
+        out[0][0][r] = (c0 + c1) + c2;
+        out[1][0][r] = (c1 - c2) - c3;
+    }
+    float* scratch = bufs + 2 * RAW_F;                             // the weight buffers: 8 waves x 32 x 33 floats
+    tap_epilogue<2, 1>(g, out, scratch + wave * (32 * 33), rowa, rowy, wm * 128 + XH * 64, n0 + wn * 32, lane, (blk * 2 + wm) * 2 + XH);
+}
+
+template <int DIR>
+__global__ __launch_bounds__(512) void wino8_kernel(WinoArgs args) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nnb = args.g.ntn;
+    const int blk = blockIdx.x / nnb, nb = blockIdx.x - blk * nnb;
+    if ((threadIdx.x >> 8) == 0) wino8_body<0>(args, smem, blk, nb);
+    else wino8_body<1>(args, smem, blk, nb);
+}
+
 }  // namespace
 
 extern "C" size_t asr_winograd_weights_bytes(int K, int N) { return (size_t)16 * K * N * sizeof(float); }
@@ -368,6 +579,26 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
         ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
     }
     const int nwork = nblk * a.ntn;
+    static int w8 = -1;
+    if (w8 < 0) { const char* e = getenv("ASR_WINO8"); w8 = e ? atoi(e) : 1; }
+    if (w8) {
+        const size_t lds8 = (size_t)(512 + 2 * RAW_F + 2 * U_F) * sizeof(float);
+        static_assert(8 * 32 * 33 <= 2 * U_F && 4 * 4096 <= 2 * RAW_F, "epilogue scratch / exchange must fit in the buffers");
+        auto q0 = wino8_kernel<0>;
+        auto q1 = wino8_kernel<1>;
+        static bool b0 = false, b1 = false;
+        hipStream_t st8 = (hipStream_t)stream;
+        if (d->wmode) {
+            if (!b1) { (void)hipFuncSetAttribute((const void*)q1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); b1 = true; }
+            hipLaunchKernelGGL(q1, dim3(nblk * a.ntn), dim3(512), lds8, st8, w);
+        } else {
+            if (!b0) { (void)hipFuncSetAttribute((const void*)q0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); b0 = true; }
+            hipLaunchKernelGGL(q0, dim3(nblk * a.ntn), dim3(512), lds8, st8, w);
+        }
+        ASR_CHECK_LAUNCH("tap_gemm_wino8");
+        ASR_NOTE_KERNEL("wino8_kernel<%d>", d->wmode ? 1 : 0);
+        return ASR_OK;
+    }
     static int gmul = -1;
     if (gmul < 0) { const char* e = getenv("ASR_WINO_GRID"); gmul = e ? atoi(e) : 1; }       // 0: one workgroup per work item
     const int grid = (gmul <= 0 || nwork < ncu * gmul) ? nwork : ncu * gmul;
