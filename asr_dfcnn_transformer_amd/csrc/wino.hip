@@ -423,7 +423,10 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem, in
     int* rowy = rowa + 256;
     float* bufs = smem + 512;                        // raw0 | raw1 | u0 | u1
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = tid >> 6, wm = (wave >> 1) & 1, wn = wave & 1;      // wave = xh * 4 + wm * 2 + wn
+    // the wave id is wave-uniform, but only the hardware knows: read it into a scalar register so that piece numbers and LDS
+    // destinations of the DMA are scalar arithmetic (else every piece costs a v_readfirstlane and vector adds)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 1) & 1, wn = wave & 1;                       // wave = xh * 4 + wm * 2 + wn
     const long t0 = (long)blk * WT;
     const int n0 = nb * WC;
     const char* abase = (const char*)g.A;

@@ -42,6 +42,8 @@ def is_forward_symbol(sym):
     """tap_gemm_kernel[_v1]<MT, NT, WM, WN, NTAPS, WMODE[, KC]>: WMODE 0 = forward (conv / dense), 1 = data-gradient."""
     if sym.startswith('tap_gemm_kernel_bx6'):          # split-bf16 kernels: one symbol for both directions, tagged by ops
         return '[dgrad]' not in sym
+    if sym.startswith('wino8_kernel') or sym.startswith('wino_kernel'):      # <DIR>: Winograd F(2x2,3x3) conv (wino.hip)
+        return sym[sym.index('<') + 1:sym.rindex('>')].strip() == '0'
     if not sym.startswith('tap_gemm_kernel'):
         return False
     args = [a.strip() for a in sym[sym.index('<') + 1:sym.rindex('>')].split(',')]
@@ -639,7 +641,8 @@ def main():
                        'backward_streams': 2 if overlapped else 1, 'feature_prefetch': prefetch,
                        'host_input': bool(args.host_input),
                        'conv_arithmetic': ('split-bf16 x6 products, fp32 accumulate (EXPERIMENTAL, ASR_BX6=1) for conv fwd/dgrad; '
-                                           'fp32 MFMA elsewhere') if eng.bx6 else 'fp32 MFMA',
+                                           'fp32 MFMA elsewhere') if eng.bx6 else
+                                          ('fp32 MFMA; forward 3x3 convs by Winograd F(2x2,3x3) in fp32 (ASR_WINO=0: direct)' if eng.wt_f else 'fp32 MFMA'),
                        'mean_loss': round(mean_loss, 4)},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': kernel_peak(dom), 'unit': 'TFLOP/s',
                          'frac': round(achieved / kernel_peak(dom), 4), 'traffic': None,
@@ -652,6 +655,11 @@ def main():
             out['roofline']['note'] = ('backward runs on two streams (weight-gradient beside data-gradient + next prologue), so '
                                        'backward kernel durations overlap; this is the dominant contraction that runs alone '
                                        '(forward).  ASR_DUAL_STREAM=0 gives the single-stream step and per-kernel numbers.')
+        if dom.startswith('wino'):
+            out['roofline']['algorithm'] = ('Winograd F(2x2,3x3), fp32: `achieved` counts the ALGORITHMIC flops of the direct 3x3 '
+                                            'convolution (SURVEY 8d: 2 x MACs); the kernel issues 2.25x fewer MFMA multiplies, so '
+                                            'its matrix-pipe utilisation is achieved / 2.25 / peak')
+            out['roofline']['mfma_pipe_frac'] = round(achieved / 2.25 / kernel_peak(dom), 4)
         # the committed PMC pass was taken on the default configuration only
         tr, src = pmc_traffic(args.workload, dom) if (args.tpad == 1600 and args.batch == 32) else (None, None)
         out['roofline']['traffic'] = tr
