@@ -121,6 +121,17 @@ class PreNetEngine:
                 self.wf_f[k] = torch.zeros(nb(9, cin, CH) // 4, dtype=torch.float32, device=device)
                 self.wf_b[k] = torch.zeros(nb(9, CH, cin) // 4, dtype=torch.float32, device=device)
 
+        # the same convs on the Winograd F(2x2,3x3) kernel (wino.hip; see engine.py): forward by default, ASR_WINO_DIRS=fb adds
+        # the data-gradients, ASR_WINO=0 turns it off
+        self.wt_f, self.wt_b = {}, {}
+        if os.environ.get('ASR_WINO', '1') == '1' and self.wf_f:
+            which = os.environ.get('ASR_WINO_DIRS', 'f')
+            for k, cin in self._cin.items():
+                if 'f' in which and ops.winograd_supported(self.d_conv[k]):
+                    self.wt_f[k] = torch.zeros(16 * cin * CH, dtype=torch.float32, device=device)
+                if 'b' in which and ops.winograd_supported(self.d_dx[k]):
+                    self.wt_b[k] = torch.zeros(16 * cin * CH, dtype=torch.float32, device=device)
+
     # ---- parameters
     def p(self, name, buf=None):
         off, shape = self.entries[name]
@@ -199,6 +210,8 @@ class PreNetEngine:
     def _conv(self, name, src, dst):
         if name in self.ws_f:
             ops.tap_gemm_bx6(self.d_conv[name], src, self.ws_f[name], self.p(name + '/b'), None, None, dst, None)
+        elif name in self.wt_f:
+            ops.tap_gemm_wino(self.d_conv[name], src, self.wt_f[name], self.p(name + '/b'), None, None, dst, None)
         elif name in self.wf_f:
             ops.tap_gemm_pw(self.d_conv[name], src, self.wf_f[name], self.p(name + '/b'), None, None, dst, None)
         else:
@@ -216,6 +229,8 @@ class PreNetEngine:
             d.accumulate = 1 if accumulate else 0
             if name in self.ws_b:
                 ops.tap_gemm_bx6(d, dz, self.ws_b[name], None, None, None, None, dx, dgrad=True)
+            elif name in self.wt_b:
+                ops.tap_gemm_wino(d, dz, self.wt_b[name], None, None, None, None, dx)
             elif name in self.wf_b:
                 ops.tap_gemm_pw(d, dz, self.wf_b[name], None, None, None, None, dx)
             else:
@@ -235,6 +250,10 @@ class PreNetEngine:
             cin = self._cin[k]
             ops.arrange_weights(self.p(k + '/w'), 9, cin, CH, CH, 0, buf)
             ops.arrange_weights(self.p(k + '/w'), 9, CH, cin, CH, 1, self.wf_b[k])
+        for k, buf in self.wt_f.items():
+            ops.winograd_weights(self.p(k + '/w'), self._cin[k], CH, CH, 0, buf)
+        for k, buf in self.wt_b.items():
+            ops.winograd_weights(self.p(k + '/w'), CH, self._cin[k], CH, 1, buf)
         ops.prenet_conv1_fwd(x, self.p('conv1/w'), self.p('conv1/b'), self.a1)
         self._bn('bn1', self.a1, self.x1s, dst_phase_split=True)
         ops.conv_s2_expand(self.p('conv2/w'), CH, CH, self.W4)
