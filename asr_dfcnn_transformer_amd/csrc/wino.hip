@@ -416,8 +416,26 @@ __device__ __forceinline__ void wino8_chunk(const float* __restrict__ raw, const
     mfmas(v, ubb);
 }
 
+// per-lane DMA offsets of one work item of the eight-wave kernel: tile t0 + lane (clamped): byte offset of the top-left pixel
+// of its patch (planes are < 4 GB); weights: row lane / 16 of a 4-row piece, column quad lane % 16
+__device__ __forceinline__ void wino8_offsets(const WinoArgs& args, long t0, int n0, int lane, unsigned& off_t, unsigned& off_u) {
+    const TapGemmArgs& g = args.g;
+    long t = t0 + lane;
+    if (t > args.ntiles - 1) t = args.ntiles - 1;
+    const int per = args.TH * args.TW;
+    const int b = (int)(t / per);
+    const int rr = (int)(t - (long)b * per);
+    const int ti = rr / args.TW, tj = rr - ti * args.TW;
+    off_t = (unsigned)((((long)b * g.HPWP + (long)(2 * ti) * g.WP + 2 * tj) * g.lda) * 4);
+    off_u = (unsigned)(((long)(lane >> 4) * g.N + n0 + (lane & 15) * 4) * 4);
+}
+
+// Persistent workgroups (one per CU; work item = (tile block, channel block), channel blocks of a tile block adjacent).  After
+// the last chunk of an item both buffer sets are free: the first chunk of the NEXT item is requested into one of them, the
+// exchange of the two halves and the epilogue's transpose scratch use the other -- the epilogue (5 us) and the next item's
+// first fetch overlap, and there is no workgroup dispatch between items (7 us per item before).
 template <int XH>
-__device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem, int blk, int nb) {
+__device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
     const TapGemmArgs& g = args.g;
     int* rowa = (int*)smem;                          // [2 wave rows][4 pixels][32 tiles]
     int* rowy = rowa + 256;
@@ -427,107 +445,113 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem, in
     // destinations of the DMA are scalar arithmetic (else every piece costs a v_readfirstlane and vector adds)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave >> 1) & 1, wn = wave & 1;                       // wave = xh * 4 + wm * 2 + wn
-    const long t0 = (long)blk * WT;
-    const int n0 = nb * WC;
     const char* abase = (const char*)g.A;
     const char* ubase = (const char*)args.Ut;
     const long ustride_xi = (long)g.K * g.N;
     const int aoff = (lh * WT + wm * 32 + li) * 4;   // slot (quad = lh, tile) of a pixel
     const int boff = lh * 4 * WC + wn * 32 + li;     // half 1 contracts channels 4 .. 7 of the chunk
     const int nkc = g.K / WKC;
+    const int nnb = g.ntn, nwork = g.ntm * nnb;
 
-    // this lane as a DMA lane: tile t0 + lane (clamped): byte offset of the top-left pixel of its patch (planes are < 4 GB);
-    // weights: row lane / 16 of a 4-row piece, column quad lane % 16
+    int w = blockIdx.x;
+    if (w >= nwork) return;
     unsigned off_t, off_u;
-    {
-        long t = t0 + lane;
-        if (t > args.ntiles - 1) t = args.ntiles - 1;
-        const int per = args.TH * args.TW;
-        const int b = (int)(t / per);
-        const int rr = (int)(t - (long)b * per);
-        const int ti = rr / args.TW, tj = rr - ti * args.TW;
-        off_t = (unsigned)((((long)b * g.HPWP + (long)(2 * ti) * g.WP + 2 * tj) * g.lda) * 4);
-        off_u = (unsigned)(((long)(lane >> 4) * g.N + n0 + (lane & 15) * 4) * 4);
-    }
-    wino8_stage(bufs, bufs + 2 * RAW_F, abase, off_t, ubase, off_u, g.WP, g.lda, ustride_xi, g.N, 0, wave);
-    if (tid < 256) {
-        const int tl = tid & 63, pl = tid >> 6;      // 64 tiles x 4 pixels = 256 entries
-        const long t = t0 + tl;
-        int ra = -1, ry = -1;
-        if (t < args.ntiles) {
-            const int per = args.TH * args.TW;
-            const int b = (int)(t / per);
-            const int rr = (int)(t - (long)b * per);
-            const int ti = rr / args.TW, tj = rr - ti * args.TW;
-            const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
-            if (ww <= g.Wd) {
-                ra = (int)((long)b * g.HPWP + (long)hh * g.WP + ww);
-                ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : ra;
-            }
-        }
-        const int m = (tl >> 5) * 128 + pl * 32 + (tl & 31);
-        rowa[m] = ra; rowy[m] = ry;
-    }
-    bool zero_c3 = false;
-    if (args.wodd) {
-        long t = t0 + wm * 32 + li;
-        if (t > args.ntiles - 1) t = args.ntiles - 1;
-        zero_c3 = (int)(t % args.TW) == args.TW - 1;
-    }
-    floatx16 acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
+    wino8_offsets(args, (long)(w / nnb) * WT, (w % nnb) * WC, lane, off_t, off_u);
     int cur = 0;
-    for (int kc = 0; kc < nkc; ++kc) {
-        wino8_chunk<XH>(bufs + cur * RAW_F, bufs + 2 * RAW_F + cur * U_F, bufs + (cur ^ 1) * RAW_F, bufs + 2 * RAW_F + (cur ^ 1) * U_F,
-                        kc + 1 < nkc, abase, off_t, ubase, off_u, g.WP, g.lda, ustride_xi, g.N, kc + 1, wave, aoff, boff,
-                        args.wodd != 0, zero_c3, acc);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        cur ^= 1;
-    }
-    // own column sums: m(r, j) = acc[r * 2 + j], transform column c = 2 XH + j
-    floatx16 s0[2], s1[2];
+    wino8_stage(bufs, bufs + 2 * RAW_F, abase, off_t, ubase, off_u, g.WP, g.lda, ustride_xi, g.N, 0, wave);
+
+    for (; w < nwork; w += gridDim.x) {
+        const int blk = w / nnb, nb = w - blk * nnb;
+        const long t0 = (long)blk * WT;
+        const int n0 = nb * WC;
+        if (tid < 256) {
+            const int tl = tid & 63, pl = tid >> 6;      // 64 tiles x 4 pixels = 256 entries
+            const long t = t0 + tl;
+            int ra = -1, ry = -1;
+            if (t < args.ntiles) {
+                const int per = args.TH * args.TW;
+                const int b = (int)(t / per);
+                const int rr = (int)(t - (long)b * per);
+                const int ti = rr / args.TW, tj = rr - ti * args.TW;
+                const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
+                if (ww <= g.Wd) {
+                    ra = (int)((long)b * g.HPWP + (long)hh * g.WP + ww);
+                    ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : ra;
+                }
+            }
+            const int m = (tl >> 5) * 128 + pl * 32 + (tl & 31);
+            rowa[m] = ra; rowy[m] = ry;
+        }
+        bool zero_c3 = false;
+        if (args.wodd) {
+            long t = t0 + wm * 32 + li;
+            if (t > args.ntiles - 1) t = args.ntiles - 1;
+            zero_c3 = (int)(t % args.TW) == args.TW - 1;
+        }
+        floatx16 acc[8];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // chunk 0 of this item (requested before the previous epilogue) has landed
+        __syncthreads();
+        for (int kc = 0; kc < nkc; ++kc) {
+            wino8_chunk<XH>(bufs + cur * RAW_F, bufs + 2 * RAW_F + cur * U_F, bufs + (cur ^ 1) * RAW_F, bufs + 2 * RAW_F + (cur ^ 1) * U_F,
+                            kc + 1 < nkc, abase, off_t, ubase, off_u, g.WP, g.lda, ustride_xi, g.N, kc + 1, wave, aoff, boff,
+                            args.wodd != 0, zero_c3, acc);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            __syncthreads();
+            cur ^= 1;
+        }
+        // both sets are free now: the next item's first chunk goes into set `cur`, exchange and scratch use set `cur ^ 1`
+        const int wnext = w + gridDim.x;
+        if (wnext < nwork) {
+            wino8_offsets(args, (long)(wnext / nnb) * WT, (wnext % nnb) * WC, lane, off_t, off_u);
+            wino8_stage(bufs + cur * RAW_F, bufs + 2 * RAW_F + cur * U_F, abase, off_t, ubase, off_u, g.WP, g.lda, ustride_xi, g.N, 0, wave);
+        }
+        // own column sums: m(r, j) = acc[r * 2 + j], transform column c = 2 XH + j
+        floatx16 s0[2], s1[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[j][r] = (acc[0 + j][r] + acc[2 + j][r]) + acc[4 + j][r];
+                s1[j][r] = (acc[2 + j][r] - acc[4 + j][r]) - acc[6 + j][r];
+            }
+        // half 0 finishes pixel row 0 and needs s0 of columns 2, 3; half 1 finishes pixel row 1 and needs s1 of columns 0, 1
+        // each wave hands its partner 2 x 16 registers x 64 lanes = 2048 floats: waves 0-3 through the raw set, waves 4-7
+        // through the weight set of `cur ^ 1` (8192 floats each)
+        float* xbase = bufs + (cur ^ 1) * RAW_F;
+        float* xch = (XH == 0 ? xbase : bufs + 2 * RAW_F + (cur ^ 1) * U_F) + (wave & 3) * 2048;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xch[(j * 16 + r) * 64 + lane] = XH == 0 ? s1[j][r] : s0[j][r];
+        __syncthreads();
+        const float* pch = (XH == 0 ? bufs + 2 * RAW_F + (cur ^ 1) * U_F : xbase) + (wave & 3) * 2048;
+        floatx16 out[2][1];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[j][r] = (acc[0 + j][r] + acc[2 + j][r]) + acc[4 + j][r];
-            s1[j][r] = (acc[2 + j][r] - acc[4 + j][r]) - acc[6 + j][r];
+            float c0, c1, c2, c3;
+            if (XH == 0) { c0 = s0[0][r]; c1 = s0[1][r]; c2 = pch[(0 * 16 + r) * 64 + lane]; c3 = pch[(1 * 16 + r) * 64 + lane]; }
+            else         { c0 = pch[(0 * 16 + r) * 64 + lane]; c1 = pch[(1 * 16 + r) * 64 + lane]; c2 = s1[0][r]; c3 = s1[1][r]; }
+            out[0][0][r] = (c0 + c1) + c2;
+            out[1][0][r] = (c1 - c2) - c3;
         }
-    // half 0 finishes pixel row 0 and needs s0 of columns 2, 3; half 1 finishes pixel row 1 and needs s1 of columns 0, 1
-    float* xch = bufs + (wave & 3) * 4096 + XH * 2048;             // [32 registers][64 lanes] per wave (the tile buffers are free)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) xch[(j * 16 + r) * 64 + lane] = XH == 0 ? s1[j][r] : s0[j][r];
-    __syncthreads();
-    const float* pch = bufs + (wave & 3) * 4096 + (XH ^ 1) * 2048;
-    floatx16 out[2][1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float c0, c1, c2, c3;
-        if (XH == 0) { c0 = s0[0][r]; c1 = s0[1][r]; c2 = pch[(0 * 16 + r) * 64 + lane]; c3 = pch[(1 * 16 + r) * 64 + lane]; }
-        else         { c0 = pch[(0 * 16 + r) * 64 + lane]; c1 = pch[(1 * 16 + r) * 64 + lane]; c2 = s1[0][r]; c3 = s1[1][r]; }
-        out[0][0][r] = (c0 + c1) + c2;
-        out[1][0][r] = (c1 - c2) - c3;
+        __syncthreads();                             // every wave has read its partner's values: the weight set becomes scratch
+        // transpose scratch (32 x 33 floats per wave): waves 0-3 in the raw set, waves 4-7 in the weight set of `cur ^ 1`
+        float* scratch = (wave < 4 ? xbase : bufs + 2 * RAW_F + (cur ^ 1) * U_F) + (wave & 3) * (32 * 33);
+        tap_epilogue<2, 1>(g, out, scratch, rowa, rowy, wm * 128 + XH * 64, n0 + wn * 32, lane, (blk * 2 + wm) * 2 + XH);
+        __syncthreads();                             // row tables and buffer set `cur ^ 1` are reused by the next item
     }
-    float* scratch = bufs + 2 * RAW_F;                             // the weight buffers: 8 waves x 32 x 33 floats
-    tap_epilogue<2, 1>(g, out, scratch + wave * (32 * 33), rowa, rowy, wm * 128 + XH * 64, n0 + wn * 32, lane, (blk * 2 + wm) * 2 + XH);
 }
 
 template <int DIR>
 __global__ __launch_bounds__(512) void wino8_kernel(WinoArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int nnb = args.g.ntn;
-    const int blk = blockIdx.x / nnb, nb = blockIdx.x - blk * nnb;
-    if ((threadIdx.x >> 8) == 0) wino8_body<0>(args, smem, blk, nb);
-    else wino8_body<1>(args, smem, blk, nb);
+    if ((threadIdx.x >> 8) == 0) wino8_body<0>(args, smem);
+    else wino8_body<1>(args, smem);
 }
 
 }  // namespace
@@ -586,17 +610,26 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     if (w8 < 0) { const char* e = getenv("ASR_WINO8"); w8 = e ? atoi(e) : 1; }
     if (w8) {
         const size_t lds8 = (size_t)(512 + 2 * RAW_F + 2 * U_F) * sizeof(float);
-        static_assert(8 * 32 * 33 <= 2 * U_F && 4 * 4096 <= 2 * RAW_F, "epilogue scratch / exchange must fit in the buffers");
+        static_assert(4 * 2048 <= RAW_F && 4 * 2048 <= U_F && 4 * 32 * 33 <= RAW_F && 4 * 32 * 33 <= U_F, "exchange / scratch must fit in one buffer set");
+        static int ncu8 = 0;
+        if (!ncu8) {
+            int dev = 0; hipDeviceProp_t pr;
+            ncu8 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+        }
+        static int pers = -1;
+        if (pers < 0) { const char* e = getenv("ASR_WINO_PERSIST"); pers = e ? atoi(e) : 1; }
+        const int nwork8 = nblk * a.ntn;
+        const int grid8 = (pers && nwork8 > ncu8) ? ncu8 : nwork8;
         auto q0 = wino8_kernel<0>;
         auto q1 = wino8_kernel<1>;
         static bool b0 = false, b1 = false;
         hipStream_t st8 = (hipStream_t)stream;
         if (d->wmode) {
             if (!b1) { (void)hipFuncSetAttribute((const void*)q1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); b1 = true; }
-            hipLaunchKernelGGL(q1, dim3(nblk * a.ntn), dim3(512), lds8, st8, w);
+            hipLaunchKernelGGL(q1, dim3(grid8), dim3(512), lds8, st8, w);
         } else {
             if (!b0) { (void)hipFuncSetAttribute((const void*)q0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); b0 = true; }
-            hipLaunchKernelGGL(q0, dim3(nblk * a.ntn), dim3(512), lds8, st8, w);
+            hipLaunchKernelGGL(q0, dim3(grid8), dim3(512), lds8, st8, w);
         }
         ASR_CHECK_LAUNCH("tap_gemm_wino8");
         ASR_NOTE_KERNEL("wino8_kernel<%d>", d->wmode ? 1 : 0);
