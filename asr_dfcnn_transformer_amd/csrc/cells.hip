@@ -27,6 +27,16 @@ __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 
 // ------------------------------------------------------------------ first cell
+// One lane owns a PAIR of output channels of one pooled pixel, so that the 36 multiply-adds of the four pre-pool positions
+// are packed fp32 instructions (v_pk_fma_f32: the patch value is the splat operand).  This kernel is vector-ALU work and
+// nothing else; beside the fp32 MFMA kernels of the other stream every instruction of it costs its full issue time
+// (DESIGN section 4), so the backward also skips what max-pooling makes zero: only the winning position of a window
+// carries gradient, its 3x3 patch is re-read from the staged rows (LDS, not the vector pipe) and nine multiply-adds per
+// channel replace thirty-six.  (Adding the three zero terms left the sums bit-identical, so dropping them does too.)
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 template <int POOL, bool BWD>
 __global__ __launch_bounds__(256) void cell1_kernel(const float* __restrict__ x, int B, int T, int F, int C,
                                                     const float* __restrict__ w, const float* __restrict__ bias,
@@ -35,94 +45,132 @@ __global__ __launch_bounds__(256) void cell1_kernel(const float* __restrict__ x,
                                                     float* __restrict__ partials, int RPB) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int FP = F + 2;
-    float* xs = smem;                    // [4][F+2]
-    const int H2 = T / 2, W2 = F / 2, WP2 = W2 + 1, HP2 = H2 + 1;
+    const int H2 = T / 2, W2 = F / 2, WP2 = W2 + 1, HP2 = H2 + 1;     // smem: two buffers of [4][F+2]
     const int tid = threadIdx.x;
-    const int c = tid % C, slot = tid / C, nslots = 256 / C;
+    const int CH = C >> 1;               // lanes per pixel
+    const int c = 2 * (tid % CH), slot = tid / CH, nslots = 256 / CH;
     const int b = blockIdx.y;
-    float wr[9];
+    f2 wr[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wr[k] = w[k * C + c];
-    const float bs = bias[c], s = sc[c], h = sh[c];
-    float gsum[12];
+    for (int k = 0; k < 9; ++k) wr[k] = f2{w[k * C + c], w[k * C + c + 1]};
+    const f2 bs = f2{bias[c], bias[c + 1]}, s = f2{sc[c], sc[c + 1]}, h = f2{sh[c], sh[c + 1]};
+    f2 gsum[12];
 #pragma unroll
-    for (int k = 0; k < 12; ++k) gsum[k] = 0.f;
+    for (int k = 0; k < 12; ++k) gsum[k] = splat2(0.f);
 
     const int h2beg = blockIdx.x * RPB;
     const int h2end = (h2beg + RPB < H2) ? h2beg + RPB : H2;
-    for (int h2 = h2beg; h2 < h2end; ++h2) {
-        __syncthreads();
-        for (int i = tid; i < 4 * FP; i += 256) {
-            const int r = i / FP, col = i - r * FP - 1;
-            const int row = 2 * h2 - 1 + r;
-            float v = 0.f;
-            if (row >= 0 && row < T && col >= 0 && col < F) v = x[((long)b * T + row) * F + col];
-            xs[i] = v;
-        }
-        __syncthreads();
+    // the four spectrogram rows of a pooled row are staged one pooled row ahead: fetched into registers before the
+    // arithmetic of the current row, written to the other LDS buffer after it (one barrier per row, no exposed load)
+    auto value = [&](int h2n, int i) {
+        const int r = i / FP, col = i - r * FP - 1;
+        const int row = 2 * h2n - 1 + r;
+        return (row >= 0 && row < T && col >= 0 && col < F) ? x[((long)b * T + row) * F + col] : 0.f;
+    };
+    auto fetch = [&](int h2n, float (&nv)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int i = tid + 256 * j; nv[j] = (i < 4 * FP) ? value(h2n, i) : 0.f; }
+    };
+    auto put = [&](int h2n, float* dst, const float (&nv)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int i = tid + 256 * j; if (i < 4 * FP) dst[i] = nv[j]; }
+        for (int i = tid + 1024; i < 4 * FP; i += 256) dst[i] = value(h2n, i);     // F > 254 only
+    };
+    float nv[4];
+    if (h2beg < h2end) { fetch(h2beg, nv); put(h2beg, smem, nv); }
+    __syncthreads();
+    int cur = 0;
+    for (int h2 = h2beg; h2 < h2end; ++h2, cur ^= 1) {
+        const float* xs = smem + cur * 4 * FP;
+        const bool more = h2 + 1 < h2end;
+        if (more) fetch(h2 + 1, nv);
         for (int w2 = slot; w2 < W2; w2 += nslots) {
             float p[4][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) p[r][q] = xs[r * FP + 2 * w2 + q];
-            float a[4], yv[4];
+            f2 a[4], yv[4];
 #pragma unroll
             for (int pos = 0; pos < 4; ++pos) {
                 const int dyy = pos >> 1, dxx = pos & 1;
-                float z = bs;
+                f2 z = bs;
 #pragma unroll
                 for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                    for (int kw = 0; kw < 3; ++kw) z = fmaf(p[dyy + kh][dxx + kw], wr[kh * 3 + kw], z);
-                a[pos] = fmaxf(z, 0.f);
-                yv[pos] = fmaf(s, a[pos], h);
+                    for (int kw = 0; kw < 3; ++kw) z = fma2(splat2(p[dyy + kh][dxx + kw]), wr[kh * 3 + kw], z);
+                a[pos] = f2{fmaxf(z.x, 0.f), fmaxf(z.y, 0.f)};
+                yv[pos] = fma2(s, a[pos], h);
             }
             const long po = (((long)b * HP2 + h2 + 1) * WP2 + w2 + 1) * C + c;
             if (!BWD) {
-                float o;
+                f2 o;
                 if (POOL == 1) o = 0.25f * ((yv[0] + yv[1]) + (yv[2] + yv[3]));
-                else o = fmaxf(fmaxf(yv[0], yv[1]), fmaxf(yv[2], yv[3]));
-                y[po] = o;
-            } else {
-                const float dp = dy[po];
-                int arg = 0;
-                if (POOL == 2) {
-                    float m = yv[0];
-#pragma unroll
-                    for (int pos = 1; pos < 4; ++pos) if (yv[pos] > m) { m = yv[pos]; arg = pos; }
-                }
+                else o = f2{fmaxf(fmaxf(yv[0].x, yv[1].x), fmaxf(yv[2].x, yv[3].x)), fmaxf(fmaxf(yv[0].y, yv[1].y), fmaxf(yv[2].y, yv[3].y))};
+                *(f2*)(y + po) = o;
+            } else if (POOL == 1) {
+                const f2 gy = 0.25f * *(const f2*)(dy + po);
+                const f2 gs = gy * s;
 #pragma unroll
                 for (int pos = 0; pos < 4; ++pos) {
                     const int dyy = pos >> 1, dxx = pos & 1;
-                    const float gy = (POOL == 1) ? 0.25f * dp : (pos == arg ? dp : 0.f);
-                    gsum[11] += gy;                       // dshift
-                    gsum[10] = fmaf(gy, a[pos], gsum[10]); // dscale
-                    const float dz = (a[pos] > 0.f) ? gy * s : 0.f;
-                    gsum[9] += dz;                        // dbias
+                    gsum[11] += gy;                          // dshift
+                    gsum[10] = fma2(gy, a[pos], gsum[10]);   // dscale
+                    const f2 dz = f2{a[pos].x > 0.f ? gs.x : 0.f, a[pos].y > 0.f ? gs.y : 0.f};
+                    gsum[9] += dz;                           // dbias
 #pragma unroll
                     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                         for (int kw = 0; kw < 3; ++kw)
-                            gsum[kh * 3 + kw] = fmaf(p[dyy + kh][dxx + kw], dz, gsum[kh * 3 + kw]);
+                            gsum[kh * 3 + kw] = fma2(splat2(p[dyy + kh][dxx + kw]), dz, gsum[kh * 3 + kw]);
                 }
+            } else {
+                const f2 gy = *(const f2*)(dy + po);
+                // the first maximum of the window (strict >, as the forward's max and the oracle's argmax pick it)
+                float m0 = yv[0].x, m1 = yv[0].y, a0 = a[0].x, a1 = a[0].y;
+                int q0 = 0, q1 = 0;
+#pragma unroll
+                for (int pos = 1; pos < 4; ++pos) {
+                    const int off = (pos >> 1) * FP + (pos & 1);
+                    if (yv[pos].x > m0) { m0 = yv[pos].x; a0 = a[pos].x; q0 = off; }
+                    if (yv[pos].y > m1) { m1 = yv[pos].y; a1 = a[pos].y; q1 = off; }
+                }
+                gsum[11] += gy;
+                gsum[10] = fma2(gy, f2{a0, a1}, gsum[10]);
+                const f2 gs = gy * s;
+                const f2 dz = f2{a0 > 0.f ? gs.x : 0.f, a1 > 0.f ? gs.y : 0.f};
+                gsum[9] += dz;
+                const float* p0 = xs + 2 * w2 + q0;
+                const float* p1 = xs + 2 * w2 + q1;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        gsum[kh * 3 + kw] = fma2(f2{p0[kh * FP + kw], p1[kh * FP + kw]}, dz, gsum[kh * 3 + kw]);
             }
         }
+        if (more) put(h2 + 1, smem + (cur ^ 1) * 4 * FP, nv);
+        __syncthreads();
     }
     if (BWD) {
-        // C = 32: the two slots of a wave meet by one shuffle first, which halves the scratch (6 KB) -- small enough to
-        // run beside a one-workgroup-per-CU weight-gradient kernel that holds 150 KB of the CU's LDS
-        const bool pair = (C == 32);
-        if (pair) {
+        // fewer than 64 lanes per pixel: the slots of a wave meet by shuffles first, so the scratch is one row set per
+        // wave (6 KB at C = 32) -- small enough to run beside a one-workgroup-per-CU weight-gradient kernel that holds
+        // 150 KB of the CU's LDS
+        const bool fold = CH < 64;       // 256 % CH == 0, so CH is a power of two
+        if (fold) {
+            for (int off = CH; off < 64; off <<= 1)
 #pragma unroll
-            for (int k = 0; k < 12; ++k) gsum[k] += __shfl_xor(gsum[k], 32, 64);
+                for (int k = 0; k < 12; ++k) {
+                    gsum[k].x += __shfl_xor(gsum[k].x, off, 64);
+                    gsum[k].y += __shfl_xor(gsum[k].y, off, 64);
+                }
         }
-        const int rslot = pair ? slot >> 1 : slot, rslots = pair ? nslots >> 1 : nslots;
+        const int rslot = fold ? tid >> 6 : slot, rslots = fold ? 4 : nslots;
         __syncthreads();
         float* red = smem;               // [rslots][12][C]
-        if (!pair || !(slot & 1)) {
+        if (!fold || (tid & 63) < CH) {
 #pragma unroll
-            for (int k = 0; k < 12; ++k) red[(rslot * 12 + k) * C + c] = gsum[k];
+            for (int k = 0; k < 12; ++k) *(f2*)(red + (rslot * 12 + k) * C + c) = gsum[k];
         }
         __syncthreads();
         float* out = partials + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 12 * C;
@@ -474,10 +522,11 @@ inline int grid_for(long total, int threads) {
 extern "C" int asr_cell1_fwd(const float* x, int B, int T, int F, int C, const float* w, const float* bias,
                              const float* bn_scale, const float* bn_shift, int pool, float* y, void* stream) {
     if (!x || !w || !bias || !bn_scale || !bn_shift || !y) return ASR_ERR_BAD_ARG;
-    if (C < 1 || C > 256 || (256 % C) != 0 || T < 2 || F < 2 || (pool != 1 && pool != 2)) return ASR_ERR_BAD_ARG;
+    // two channels per lane: C even, C / 2 lanes per pixel dividing the 256-thread workgroup; y rows read / written as pairs
+    if (C < 2 || C > 256 || (256 % C) != 0 || T < 2 || F < 2 || (pool != 1 && pool != 2) || ((size_t)y & 7)) return ASR_ERR_BAD_ARG;
     const int H2 = T / 2;
     dim3 grid(asr_cdiv(H2, kCell1RPB), B);
-    const size_t lds = (size_t)4 * (F + 2) * sizeof(float);
+    const size_t lds = (size_t)8 * (F + 2) * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (pool == 1)
         hipLaunchKernelGGL((cell1_kernel<1, false>), grid, dim3(256), lds, st, x, B, T, F, C, w, bias, bn_scale, bn_shift, y, (const float*)nullptr, (float*)nullptr, kCell1RPB);
@@ -497,12 +546,12 @@ extern "C" int asr_cell1_bwd(const float* x, int B, int T, int F, int C, const f
                              float* dw, float* db, float* dscale, float* dshift, float* partials, void* stream) {
     if (!x || !w || !bias || !bn_scale || !bn_shift || !dy || !dw || !db || !dscale || !dshift || !partials)
         return ASR_ERR_BAD_ARG;
-    if (C < 1 || C > 256 || (256 % C) != 0 || T < 2 || F < 2 || (pool != 1 && pool != 2)) return ASR_ERR_BAD_ARG;
+    if (C < 2 || C > 256 || (256 % C) != 0 || T < 2 || F < 2 || (pool != 1 && pool != 2) || ((size_t)dy & 7)) return ASR_ERR_BAD_ARG;
     const int H2 = T / 2;
     dim3 grid(asr_cdiv(H2, kCell1RPB), B);
     const int nblk = grid.x * grid.y;
-    size_t lds = (size_t)4 * (F + 2) * sizeof(float);
-    const size_t red = (size_t)(C == 32 ? 4 : 256 / C) * 12 * C * sizeof(float);
+    size_t lds = (size_t)8 * (F + 2) * sizeof(float);
+    const size_t red = (size_t)(C < 128 ? 4 : 512 / C) * 12 * C * sizeof(float);
     if (red > lds) lds = red;
     hipStream_t st = (hipStream_t)stream;
     if (pool == 1)

@@ -367,14 +367,15 @@ class DFCNNEngine:
                     _, src, dst, cin, cout, k, pool = op
                     self.wf_f[dst] = torch.zeros(ops._lib.load().asr_arrange_weights_bytes(9, cin, cout) // 4, dtype=torch.float32, device=dev)
                     self.wf_b[dst] = torch.zeros(ops._lib.load().asr_arrange_weights_bytes(9, cout, cin) // 4, dtype=torch.float32, device=dev)
-        # Winograd F(2x2,3x3) kernels (wino.hip) for the FORWARD 3x3 convs they support: 16 instead of 36 multiplies per 2x2
-        # output tile, still fp32; 1.15-1.3x the tap-GEMM per layer, step -2.4 % (M1) / -1.7 % (M2).  The data-gradients stay
-        # on the tap-GEMM: a Winograd workgroup takes a whole CU, so beside the weight-gradient stream it loses what it gains
-        # (ASR_WINO_DIRS=fb to try; ASR_WINO=0 turns the forward off too).
+        # Winograd F(2x2,3x3) kernels (wino.hip) for the 3x3 convs they support, forward and data-gradient (plain and gated):
+        # 16 instead of 36 multiplies per 2x2 output tile, still fp32; 1.15-1.35x the tap-GEMM per layer.  Forward alone is
+        # step -2.4 % (M1) / -1.7 % (M2); the data-gradients add -1.7 % / -3.2 % with the persistent kernel (its workgroups
+        # take whole CUs, so beside the weight-gradient stream the two kernels take turns rather than share CUs).
+        # ASR_WINO_DIRS=f keeps the data-gradients on the tap-GEMM; ASR_WINO=0 turns all of it off.
         self.wino = os.environ.get('ASR_WINO', '1') == '1' and self.pw
         self.wt_f, self.wt_b = {}, {}
         if self.wino:
-            which = os.environ.get('ASR_WINO_DIRS', 'f')
+            which = os.environ.get('ASR_WINO_DIRS', 'fb')
             for op in self.g:
                 if op[0] == 'cell' and op[1] != 'x' and op[5] == 3:
                     _, src, dst, cin, cout, k, pool = op

@@ -121,11 +121,11 @@ class PreNetEngine:
                 self.wf_f[k] = torch.zeros(nb(9, cin, CH) // 4, dtype=torch.float32, device=device)
                 self.wf_b[k] = torch.zeros(nb(9, CH, cin) // 4, dtype=torch.float32, device=device)
 
-        # the same convs on the Winograd F(2x2,3x3) kernel (wino.hip; see engine.py): forward by default, ASR_WINO_DIRS=fb adds
-        # the data-gradients, ASR_WINO=0 turns it off
+        # the same convs on the Winograd F(2x2,3x3) kernel (wino.hip; see engine.py): forward and data-gradients
+        # (ASR_WINO_DIRS=f: forward only), ASR_WINO=0 turns it off
         self.wt_f, self.wt_b = {}, {}
         if os.environ.get('ASR_WINO', '1') == '1' and self.wf_f:
-            which = os.environ.get('ASR_WINO_DIRS', 'f')
+            which = os.environ.get('ASR_WINO_DIRS', 'fb')
             for k, cin in self._cin.items():
                 if 'f' in which and ops.winograd_supported(self.d_conv[k]):
                     self.wt_f[k] = torch.zeros(16 * cin * CH, dtype=torch.float32, device=device)

@@ -642,7 +642,7 @@ def main():
                        'host_input': bool(args.host_input),
                        'conv_arithmetic': ('split-bf16 x6 products, fp32 accumulate (EXPERIMENTAL, ASR_BX6=1) for conv fwd/dgrad; '
                                            'fp32 MFMA elsewhere') if eng.bx6 else
-                                          ('fp32 MFMA; forward 3x3 convs by Winograd F(2x2,3x3) in fp32 (ASR_WINO=0: direct)' if eng.wt_f else 'fp32 MFMA'),
+                                          ('fp32 MFMA; 3x3 convs %s by Winograd F(2x2,3x3) in fp32 (ASR_WINO=0: direct)' % ('forward + data-gradient' if eng.wt_b else 'forward') if eng.wt_f else 'fp32 MFMA'),
                        'mean_loss': round(mean_loss, 4)},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': kernel_peak(dom), 'unit': 'TFLOP/s',
                          'frac': round(achieved / kernel_peak(dom), 4), 'traffic': None,

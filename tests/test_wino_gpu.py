@@ -63,8 +63,8 @@ def test_unsupported_shapes_are_reported(ops):
 
 
 def test_engine_opt_in_gives_the_same_step(ops, monkeypatch):
-    """ASR_WINO=1 with ASR_WINO_DIRS=fb routes the supported 3x3 layers (forward, data-gradient and gated data-gradient) through the
-    Winograd kernel (the default is forward only):
+    """ASR_WINO=1 (the default, with ASR_WINO_DIRS=fb) routes the supported 3x3 layers (forward, data-gradient and gated
+    data-gradient) through the Winograd kernel; ASR_WINO=0 keeps all of them on the tap-GEMM:
     logits, loss and every gradient agree with the default engine to rounding."""
     from asr_dfcnn_transformer_amd.engine import DFCNNEngine
     rng = np.random.default_rng(3)
