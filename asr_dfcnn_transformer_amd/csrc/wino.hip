@@ -324,14 +324,30 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs args) {
 // Raw layout of this kernel: [pixel 16][quad 2][tile 64] 16-byte slots.  Lane half lh reads quad lh of its tile with ONE
 // conflict-free ds_read_b128 per pixel and chunk: the MFMA k-pair kp contracts channels kp (half 0) and 4 + kp (half 1) of the
 // chunk -- the pairing of channels into k-pairs is free as long as the weights follow it -- so all four floats are used.
+typedef float wn_f2 __attribute__((ext_vector_type(2)));
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access of the wave
+// (vmcnt(0)) -- the next item's DMA and the epilogue's stores, which nothing in the workgroup is waiting for
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+#ifdef WINO_TRACE
+__device__ long long wino_trace_buf[4 * 8 * 16];          // [item 4][wave 8][stamp 16], workgroup 0 only
+#define WTRACE(k) do { if (blockIdx.x == 0 && titem < 4 && lane == 0) wino_trace_buf[(titem * 8 + wave) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WTRACE(k) do { } while (0)
+#endif
+// two k-pairs at a time: components (x, y) or (z, w) of the float4s are aligned register pairs, so the 20 adds of a batch
+// become 20 packed adds for TWO batches (v_pk_add_f32) -- on this pipe every vector instruction costs matrix time
 template <int XH>
-__device__ __forceinline__ void wino8_transform(const float4 (&d)[12], int kp, float (&v)[8]) {
-    // d[r * 3 + cc] = patch pixel (r, XH + cc), component kp
-    auto comp = [&](const float4& q) { return kp == 0 ? q.x : kp == 1 ? q.y : kp == 2 ? q.z : q.w; };
-    float t[4][3];
+__device__ __forceinline__ void wino8_transform(const float4 (&d)[12], int half, wn_f2 (&v)[8]) {
+    // d[r * 3 + cc] = patch pixel (r, XH + cc)
+    auto comp = [&](const float4& q) { return half == 0 ? wn_f2{q.x, q.y} : wn_f2{q.z, q.w}; };
+    wn_f2 t[4][3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float d0 = comp(d[0 + c]), d1 = comp(d[3 + c]), d2 = comp(d[6 + c]), d3 = comp(d[9 + c]);
+        const wn_f2 d0 = comp(d[0 + c]), d1 = comp(d[3 + c]), d2 = comp(d[6 + c]), d3 = comp(d[9 + c]);
         t[0][c] = d0 - d2; t[1][c] = d1 + d2; t[2][c] = d2 - d1; t[3][c] = d1 - d3;
     }
 #pragma unroll
@@ -341,32 +357,38 @@ __device__ __forceinline__ void wino8_transform(const float4 (&d)[12], int kp, f
     }
 }
 
-// DMA of one chunk by eight waves: raw piece = pixel * 2 + quad (64 tiles), weight piece = xi * 2 + (ci >> 2)
-__device__ __forceinline__ void wino8_stage(float* __restrict__ raw, float* __restrict__ ub, const char* __restrict__ abase,
-                                            unsigned off_t, const char* __restrict__ ubase, unsigned off_u,
-                                            int WPl, int lda, long ustride_xi, int N, int kc, int wave) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = wave + 8 * j;
+// DMA of one chunk by eight waves, eight pieces per wave: raw piece = pixel * 2 + quad (64 tiles), weight piece = xi * 2 +
+// (ci >> 2).  A raw piece is 64 lanes on 64 different 128-byte lines: the texture addresser takes them one per clock, so
+// the 32 raw pieces of a chunk occupy it for half the chunk's MFMA time -- and a wave whose DMA instruction waits for the
+// addresser issues nothing else.  The pieces are therefore handed out ONE at a time (wino8_piece) and the callers put
+// them between MFMAs, so that the other wave of the SIMD (and this wave's MFMAs in flight) keep the matrix pipe busy.
+struct Wino8Dma {
+    const char* abase; const char* ubase;
+    unsigned off_t, off_u;
+    int WPl, lda, N, wave;
+    long ustride_xi;
+};
+__device__ __forceinline__ void wino8_piece(const Wino8Dma& q, float* __restrict__ raw, float* __restrict__ ub, int kc, int j) {
+    const int p = q.wave + 8 * (j & 3);
+    if (j < 4) {
         const int px = p >> 1, quad = p & 1;
         const int r = px >> 2, c = px & 3;
-        const char* pb = abase + (((long)r * WPl + c) * lda + kc * WKC + quad * 4) * 4;      // uniform
-        __builtin_amdgcn_global_load_lds((wn_glb_f*)(pb + off_t), (wn_lds_f*)(raw + p * 256), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = wave + 8 * j;
+        const char* pb = q.abase + (((long)r * q.WPl + c) * q.lda + kc * WKC + quad * 4) * 4;      // uniform
+        __builtin_amdgcn_global_load_lds((wn_glb_f*)(pb + q.off_t), (wn_lds_f*)(raw + p * 256), 16, 0, 0);
+    } else {
         const int xi = p >> 1, cig = p & 1;
-        const char* pb = ubase + (xi * ustride_xi + (long)(kc * WKC + cig * 4) * N) * 4;     // uniform
-        __builtin_amdgcn_global_load_lds((wn_glb_f*)(pb + off_u), (wn_lds_f*)(ub + p * 256), 16, 0, 0);
+        const char* pb = q.ubase + (xi * q.ustride_xi + (long)(kc * WKC + cig * 4) * q.N) * 4;     // uniform
+        __builtin_amdgcn_global_load_lds((wn_glb_f*)(pb + q.off_u), (wn_lds_f*)(ub + p * 256), 16, 0, 0);
     }
+}
+__device__ __forceinline__ void wino8_stage(const Wino8Dma& q, float* __restrict__ raw, float* __restrict__ ub, int kc) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wino8_piece(q, raw, ub, kc, j);
 }
 
 template <int XH>
 __device__ __forceinline__ void wino8_chunk(const float* __restrict__ raw, const float* __restrict__ ub, float* __restrict__ rawn,
-                                            float* __restrict__ ubn, bool prefetch, const char* __restrict__ abase,
-                                            unsigned off_t, const char* __restrict__ ubase, unsigned off_u,
-                                            int WPl, int lda, long ustride_xi, int N, int kcn, int wave,
+                                            float* __restrict__ ubn, bool prefetch, const Wino8Dma& q, int kcn,
                                             int aoff, int boff, bool wodd, bool zero_c3, floatx16 (&acc)[8]) {
     auto load_u = [&](float (&u)[8], int kp) {
 #pragma unroll
@@ -374,46 +396,50 @@ __device__ __forceinline__ void wino8_chunk(const float* __restrict__ raw, const
 #pragma unroll
             for (int j = 0; j < 2; ++j) u[r * 2 + j] = ub[((r * 4 + 2 * XH + j) * WKC + kp) * WC + boff];
     };
-    auto mfmas = [&](const float (&v)[8], const float (&u)[8]) {
+    // eight MFMAs; behind MFMA 1, 3, 5, 7 one DMA piece of the next chunk (pieces first .. first + 3), if any
+    auto mfmas = [&](const wn_f2 (&v)[8], int h, const float (&u)[8], int first) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i], u[i], acc[i], 0, 0, 0);
+        for (int i = 0; i < 8; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[i].y : v[i].x, u[i], acc[i], 0, 0, 0);
+            if (first >= 0 && (i & 1)) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (prefetch) wino8_piece(q, rawn, ubn, kcn, first + (i >> 1));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
     };
     float4 d[12];
-    float ua[8], ubb[8], v[8];
+    float ua[8], ubb[8];
+    wn_f2 v[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) d[r * 3 + c] = *(const float4*)(raw + (r * 4 + XH + c) * (2 * WT * 4) + aoff);
     load_u(ua, 0);
-    if (prefetch) wino8_stage(rawn, ubn, abase, off_t, ubase, off_u, WPl, lda, ustride_xi, N, kcn, wave);
+    load_u(ubb, 1);
     __builtin_amdgcn_sched_barrier(0);
     if (XH == 1 && wodd) {       // patch column 3 is this half's third column
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (zero_c3) d[r * 3 + 2] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // four batches (k-pairs): the next batch's weights are requested before this batch's adds and MFMAs; the adds of a batch
-    // all come before its MFMAs (an add behind an fp32 MFMA waits for it, and the next MFMA pays again)
-    load_u(ubb, 1);
-    __builtin_amdgcn_sched_barrier(0);
+    // two double batches (k-pairs 0, 1 and 2, 3): the adds of a double batch all come before its sixteen MFMAs (an add behind
+    // an fp32 MFMA waits for it, and the next MFMA pays again); the weights of the next double batch are requested as soon as
+    // the MFMAs that read the current ones have issued.  Raw pieces (j 0..3) and weight pieces (4..7) alternate.
     wino8_transform<XH>(d, 0, v);
     __builtin_amdgcn_sched_barrier(0);
-    mfmas(v, ua);
+    mfmas(v, 0, ua, 0);
     __builtin_amdgcn_sched_barrier(0);
     load_u(ua, 2);
     __builtin_amdgcn_sched_barrier(0);
-    wino8_transform<XH>(d, 1, v);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(v, ubb);
+    mfmas(v, 1, ubb, 4);
     __builtin_amdgcn_sched_barrier(0);
     load_u(ubb, 3);
     __builtin_amdgcn_sched_barrier(0);
-    wino8_transform<XH>(d, 2, v);
+    wino8_transform<XH>(d, 1, v);
     __builtin_amdgcn_sched_barrier(0);
-    mfmas(v, ua);
+    mfmas(v, 0, ua, -1);
     __builtin_amdgcn_sched_barrier(0);
-    wino8_transform<XH>(d, 3, v);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(v, ubb);
+    mfmas(v, 1, ubb, -1);
 }
 
 // per-lane DMA offsets of one work item of the eight-wave kernel: tile t0 + lane (clamped): byte offset of the top-left pixel
@@ -430,10 +456,13 @@ __device__ __forceinline__ void wino8_offsets(const WinoArgs& args, long t0, int
     off_u = (unsigned)(((long)(lane >> 4) * g.N + n0 + (lane & 15) * 4) * 4);
 }
 
-// Persistent workgroups (one per CU; work item = (tile block, channel block), channel blocks of a tile block adjacent).  After
-// the last chunk of an item both buffer sets are free: the first chunk of the NEXT item is requested into one of them, the
-// exchange of the two halves and the epilogue's transpose scratch use the other -- the epilogue (5 us) and the next item's
-// first fetch overlap, and there is no workgroup dispatch between items (7 us per item before).
+// Persistent workgroups (one per CU; work item = (tile block, channel block), channel blocks of a tile block adjacent).  The
+// LAST chunk of an item requests chunk 0 of the NEXT item where the other chunks request their successor (between its
+// MFMAs), so after it one buffer set is filling for the next item and the other is free for the exchange of the two halves
+// and the epilogue's transpose scratch; the barriers of that tail order LDS only (lds_barrier), they do not wait for the
+// DMA in flight or the epilogue's stores.  In-kernel stamps (WINO_TRACE, 64 -> 128 channels at 400 x 50): 8 chunks 26.4 us
+// (2.9 each; 4.2-4.6 where the fetch crossed into new 128-byte lines or a new item), exchange 1.1 us, epilogue 3.2 us
+// (store issue), 0.6 us set-up -- before the DMA moved between the MFMAs a chunk took 3.2 us and the tail 9 us.
 template <int XH>
 __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
     const TapGemmArgs& g = args.g;
@@ -455,12 +484,16 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
 
     int w = blockIdx.x;
     if (w >= nwork) return;
-    unsigned off_t, off_u;
-    wino8_offsets(args, (long)(w / nnb) * WT, (w % nnb) * WC, lane, off_t, off_u);
+    Wino8Dma q;
+    q.abase = abase; q.ubase = ubase; q.WPl = g.WP; q.lda = g.lda; q.N = g.N; q.wave = wave; q.ustride_xi = ustride_xi;
+    wino8_offsets(args, (long)(w / nnb) * WT, (w % nnb) * WC, lane, q.off_t, q.off_u);
     int cur = 0;
-    wino8_stage(bufs, bufs + 2 * RAW_F, abase, off_t, ubase, off_u, g.WP, g.lda, ustride_xi, g.N, 0, wave);
+    wino8_stage(q, bufs, bufs + 2 * RAW_F, 0);
 
+    int titem = -1;
     for (; w < nwork; w += gridDim.x) {
+        ++titem;
+        WTRACE(0);
         const int blk = w / nnb, nb = w - blk * nnb;
         const long t0 = (long)blk * WT;
         const int n0 = nb * WC;
@@ -494,22 +527,27 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
+        WTRACE(1);
         __builtin_amdgcn_s_waitcnt(0x0F70);          // chunk 0 of this item (requested before the previous epilogue) has landed
         __syncthreads();
+        WTRACE(2);
+        // the last chunk of an item requests chunk 0 of the NEXT item instead of a next chunk (same places between the MFMAs):
+        // after it one set is being filled for the next item, the other is free for the exchange and the epilogue
+        const int wnext = w + gridDim.x;
+        unsigned otn = q.off_t, oun = q.off_u;
+        if (wnext < nwork) wino8_offsets(args, (long)(wnext / nnb) * WT, (wnext % nnb) * WC, lane, otn, oun);
         for (int kc = 0; kc < nkc; ++kc) {
+            const bool last = kc + 1 == nkc;
+            if (last) { q.off_t = otn; q.off_u = oun; }
             wino8_chunk<XH>(bufs + cur * RAW_F, bufs + 2 * RAW_F + cur * U_F, bufs + (cur ^ 1) * RAW_F, bufs + 2 * RAW_F + (cur ^ 1) * U_F,
-                            kc + 1 < nkc, abase, off_t, ubase, off_u, g.WP, g.lda, ustride_xi, g.N, kc + 1, wave, aoff, boff,
-                            args.wodd != 0, zero_c3, acc);
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            __syncthreads();
+                            last ? wnext < nwork : true, q, last ? 0 : kc + 1, aoff, boff, args.wodd != 0, zero_c3, acc);
+            if (!last) { __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); }
+            else lds_barrier();
+            if (kc < 5) WTRACE(11 + kc);
             cur ^= 1;
         }
-        // both sets are free now: the next item's first chunk goes into set `cur`, exchange and scratch use set `cur ^ 1`
-        const int wnext = w + gridDim.x;
-        if (wnext < nwork) {
-            wino8_offsets(args, (long)(wnext / nnb) * WT, (wnext % nnb) * WC, lane, off_t, off_u);
-            wino8_stage(bufs + cur * RAW_F, bufs + 2 * RAW_F + cur * U_F, abase, off_t, ubase, off_u, g.WP, g.lda, ustride_xi, g.N, 0, wave);
-        }
+        WTRACE(3);
+        WTRACE(4);
         // own column sums: m(r, j) = acc[r * 2 + j], transform column c = 2 XH + j
         floatx16 s0[2], s1[2];
 #pragma unroll
@@ -528,7 +566,9 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) xch[(j * 16 + r) * 64 + lane] = XH == 0 ? s1[j][r] : s0[j][r];
-        __syncthreads();
+        WTRACE(5);
+        lds_barrier();
+        WTRACE(6);
         const float* pch = (XH == 0 ? bufs + 2 * RAW_F + (cur ^ 1) * U_F : xbase) + (wave & 3) * 2048;
         floatx16 out[2][1];
 #pragma unroll
@@ -539,11 +579,15 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
             out[0][0][r] = (c0 + c1) + c2;
             out[1][0][r] = (c1 - c2) - c3;
         }
-        __syncthreads();                             // every wave has read its partner's values: the weight set becomes scratch
+        WTRACE(7);
+        lds_barrier();                               // every wave has read its partner's values: the weight set becomes scratch
+        WTRACE(8);
         // transpose scratch (32 x 33 floats per wave): waves 0-3 in the raw set, waves 4-7 in the weight set of `cur ^ 1`
         float* scratch = (wave < 4 ? xbase : bufs + 2 * RAW_F + (cur ^ 1) * U_F) + (wave & 3) * (32 * 33);
         tap_epilogue<2, 1>(g, out, scratch, rowa, rowy, wm * 128 + XH * 64, n0 + wn * 32, lane, (blk * 2 + wm) * 2 + XH);
-        __syncthreads();                             // row tables and buffer set `cur ^ 1` are reused by the next item
+        WTRACE(9);
+        lds_barrier();                               // row tables and buffer set `cur ^ 1` are reused by the next item
+        WTRACE(10);
     }
 }
 
@@ -555,6 +599,12 @@ __global__ __launch_bounds__(512) void wino8_kernel(WinoArgs args) {
 }
 
 }  // namespace
+
+#ifdef WINO_TRACE
+extern "C" int asr_wino_trace_dump(long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(wino_trace_buf), sizeof(long long) * 4 * 8 * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 
 extern "C" size_t asr_winograd_weights_bytes(int K, int N) { return (size_t)16 * K * N * sizeof(float); }
 
