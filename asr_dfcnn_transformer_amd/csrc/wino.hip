@@ -682,7 +682,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
             hipLaunchKernelGGL(q0, dim3(grid8), dim3(512), lds8, st8, w);
         }
         ASR_CHECK_LAUNCH("tap_gemm_wino8");
-        ASR_NOTE_KERNEL("wino8_kernel<%d>", d->wmode ? 1 : 0);
+        if (d->wmode) ASR_NOTE_KERNEL("wino8_kernel<1>"); else ASR_NOTE_KERNEL("wino8_kernel<0>");     // one name per call site
         return ASR_OK;
     }
     static int gmul = -1;
@@ -700,7 +700,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
         hipLaunchKernelGGL(k0, dim3(grid), dim3(256), lds, st, w);
     }
     ASR_CHECK_LAUNCH("tap_gemm_wino");
-    ASR_NOTE_KERNEL("wino_kernel<%d>", d->wmode ? 1 : 0);
+    if (d->wmode) ASR_NOTE_KERNEL("wino_kernel<1>"); else ASR_NOTE_KERNEL("wino_kernel<0>");
     return ASR_OK;
 }
 

@@ -406,7 +406,8 @@ int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const float* Warrang
                     const float* bias, const float* scale, const float* shift,
                     float* out_a, float* out_y, void* stream);
 
-/* ------------------------------------------------------------------ EXPERIMENTAL: Winograd F(2x2, 3x3) (round 2)
+/* ------------------------------------------------------------------ Winograd F(2x2, 3x3) (round 2; the engines' default
+ * for the 3x3 convolutions it supports, forward and data-gradient)
  * The 3x3 convolution of asr_tap_gemm (ntaps 9; forward, or data-gradient view with wmode 1) with 16 instead of 36
  * multiplies per 2x2 output tile, input and output channel -- still fp32, results agree with asr_tap_gemm to rounding
  * (tests/test_wino_gpu.py).  Weights are transformed once per optimiser step:
@@ -428,7 +429,7 @@ int asr_tap_gemm_wino(const asr_gemm_desc* d, const float* A, const float* Wt,
  * goes to memory, dZ(k-1) is written directly, and the per-channel sums come out as tile partials folded in a fixed order.
  *   d          the data-gradient descriptor (wmode 1, ntaps 9 or 1, pixel-indexed: H, W = the plane of cell k-1's OUTPUT)
  *   dZ, W      as for asr_tap_gemm (W HWIO), asr_tap_gemm_pw (prearranged == 1: data-gradient view from asr_arrange_weights) or
- *              asr_tap_gemm_wino (prearranged == 2: asr_winograd_weights with wmode 1; EXPERIMENTAL)
+ *              asr_tap_gemm_wino (prearranged == 2: asr_winograd_weights with wmode 1)
  *   pool       0 none, 1 average 2x2, 2 maximum 2x2 (first maximum of bn_scale * a + bn_shift in row-major window order)
  *   gate_H/W   cell k-1's pre-pool plane: H x W for pool 0, 2H x 2W otherwise (odd sizes are not supported: use asr_cell_bwd_pre)
  *   gate_a     cell k-1's post-ReLU pre-BN activations, padded plane [B][gate_H+1][gate_W+1][N]
