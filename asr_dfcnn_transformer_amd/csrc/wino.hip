@@ -36,6 +36,7 @@ struct WinoArgs {
     int TH, TW;             // tile rows / columns per image
     long ntiles;            // B * TH * TW
     int wodd;               // plane width is odd
+    int xcd_order;          // eight-wave kernel: items of a round grouped by XCD (ASR_WINO_XCD, default 1)
 };
 
 constexpr int WT = 64;                      // tiles per workgroup
@@ -484,9 +485,20 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
 
     int w = blockIdx.x;
     if (w >= nwork) return;
+    // Which item a workgroup takes in a round: workgroup b runs on XCD b % 8 (round-robin dispatch), each XCD has its own L2.
+    // Within a full round of G items XCD x takes the CONTIGUOUS items x G/8 .. (x + 1) G/8 - 1, so the channel blocks of a
+    // tile block (adjacent items: the same input tiles) and neighbouring tile blocks (shared patch rows) are fetched through
+    // one L2 at about the same time.  A partial last round keeps the plain order.
+    const int G = gridDim.x;
+    auto item_of = [&](int wl) {
+        const int r0 = (wl / G) * G;
+        if ((G & 7) || args.xcd_order == 0 || r0 + G > nwork) return wl;
+        const int p = wl - r0;
+        return r0 + (p & 7) * (G >> 3) + (p >> 3);
+    };
     Wino8Dma q;
     q.abase = abase; q.ubase = ubase; q.WPl = g.WP; q.lda = g.lda; q.N = g.N; q.wave = wave; q.ustride_xi = ustride_xi;
-    wino8_offsets(args, (long)(w / nnb) * WT, (w % nnb) * WC, lane, q.off_t, q.off_u);
+    { const int it = item_of(w); wino8_offsets(args, (long)(it / nnb) * WT, (it % nnb) * WC, lane, q.off_t, q.off_u); }
     int cur = 0;
     wino8_stage(q, bufs, bufs + 2 * RAW_F, 0);
 
@@ -494,7 +506,8 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
     for (; w < nwork; w += gridDim.x) {
         ++titem;
         WTRACE(0);
-        const int blk = w / nnb, nb = w - blk * nnb;
+        const int item = item_of(w);
+        const int blk = item / nnb, nb = item - blk * nnb;
         const long t0 = (long)blk * WT;
         const int n0 = nb * WC;
         if (tid < 256) {
@@ -535,7 +548,7 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
         // after it one set is being filled for the next item, the other is free for the exchange and the epilogue
         const int wnext = w + gridDim.x;
         unsigned otn = q.off_t, oun = q.off_u;
-        if (wnext < nwork) wino8_offsets(args, (long)(wnext / nnb) * WT, (wnext % nnb) * WC, lane, otn, oun);
+        if (wnext < nwork) { const int it = item_of(wnext); wino8_offsets(args, (long)(it / nnb) * WT, (it % nnb) * WC, lane, otn, oun); }
         for (int kc = 0; kc < nkc; ++kc) {
             const bool last = kc + 1 == nkc;
             if (last) { q.off_t = otn; q.off_u = oun; }
@@ -646,6 +659,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     w.TH = d->H / 2; w.TW = (d->W + 1) / 2;
     w.ntiles = (long)d->B * w.TH * w.TW;
     w.wodd = d->W & 1;
+    { static int xo = -1; if (xo < 0) { const char* e = getenv("ASR_WINO_XCD"); xo = e ? atoi(e) : 1; } w.xcd_order = xo; }
     const int nblk = asr_cdiv(w.ntiles, WT);
     a.ntm = nblk; a.ntn = d->N / WC;
     if (a.gate_rows) *a.gate_rows = nblk * 4;
