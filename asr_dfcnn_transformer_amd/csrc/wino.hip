@@ -37,6 +37,8 @@ struct WinoArgs {
     long ntiles;            // B * TH * TW
     int wodd;               // plane width is odd
     int xcd_order;          // eight-wave kernel: items of a round grouped by XCD (ASR_WINO_XCD, default 1)
+    float* pool_y;          // eight-wave kernel: pooled BN output plane [B][H/2+1][W/2+1][N] of a fused 2x2 pool, or null
+    int pool_mode, H2, W2;  // 1 average, 2 maximum
 };
 
 constexpr int WT = 64;                      // tiles per workgroup
@@ -469,7 +471,8 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
     const TapGemmArgs& g = args.g;
     int* rowa = (int*)smem;                          // [2 wave rows][4 pixels][32 tiles]
     int* rowy = rowa + 256;
-    float* bufs = smem + 512;                        // raw0 | raw1 | u0 | u1
+    int* prow = rowy + 256;                          // [64 tiles]: row of the tile's pooled pixel (fused 2x2 pool), or -1
+    float* bufs = smem + 576;                        // raw0 | raw1 | u0 | u1
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     // the wave id is wave-uniform, but only the hardware knows: read it into a scalar register so that piece numbers and LDS
     // destinations of the DMA are scalar arithmetic (else every piece costs a v_readfirstlane and vector adds)
@@ -527,12 +530,31 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
             }
             const int m = (tl >> 5) * 128 + pl * 32 + (tl & 31);
             rowa[m] = ra; rowy[m] = ry;
+            if (pl == 0) {
+                int pr = -1;
+                if (args.pool_y && t < args.ntiles) {
+                    const int per = args.TH * args.TW;
+                    const int b = (int)(t / per);
+                    const int rr = (int)(t - (long)b * per);
+                    const int ti = rr / args.TW, tj = rr - ti * args.TW;
+                    if (tj < args.W2 && ti < args.H2) pr = (b * (args.H2 + 1) + ti + 1) * (args.W2 + 1) + tj + 1;
+                }
+                prow[tl] = pr;
+            }
         }
         bool zero_c3 = false;
         if (args.wodd) {
             long t = t0 + wm * 32 + li;
             if (t > args.ntiles - 1) t = args.ntiles - 1;
             zero_c3 = (int)(t % args.TW) == args.TW - 1;
+        }
+        // fused pool: this lane's channel constants, requested now so that the tail does not wait for them
+        const int pool_n = n0 + wn * 32 + li;
+        float pool_bs = 0.f, pool_sc = 1.f, pool_sh = 0.f;
+        if (args.pool_y && pool_n < g.N) {
+            if (g.bias) pool_bs = g.bias[pool_n];
+            if (g.scale) pool_sc = g.scale[pool_n];
+            if (g.shift) pool_sh = g.shift[pool_n];
         }
         floatx16 acc[8];
 #pragma unroll
@@ -595,6 +617,42 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
         WTRACE(7);
         lds_barrier();                               // every wave has read its partner's values: the weight set becomes scratch
         WTRACE(8);
+        if (args.pool_y) {
+            // Fused 2x2 pool (a Winograd tile IS a pooling window): this wave holds pixels (XH, 0) and (XH, 1) of its tiles as
+            // out[0] / out[1], lane = output channel.  BN(ReLU(x + bias)) and the row's pair lane-locally, then half 1 hands its
+            // pair to half 0 through LDS (behind the scratch areas) and half 0 stores the pooled pixel: 128-byte rows of 32
+            // channels.  Same arithmetic and association as asr_pool_fwd on the stored activation: bit-identical.
+            const float bs = pool_bs, scv = pool_sc, shv = pool_sh;
+            floatx16 pm;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x0 = out[0][0][r] + bs, x1 = out[1][0][r] + bs;
+                if (g.relu == 1) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+                else if (g.relu == 2) { x0 = tanhf(x0); x1 = tanhf(x1); }
+                const float v0 = fmaf(scv, x0, shv), v1 = fmaf(scv, x1, shv);
+                pm[r] = args.pool_mode == 1 ? v0 + v1 : fmaxf(v0, v1);
+            }
+            float* pex = (wave & 2 ? bufs + 2 * RAW_F + (cur ^ 1) * U_F : xbase) + 4 * (32 * 33) + (wave & 1) * 1024;    // pair (wm, wn)
+            if (XH == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pex[r * 64 + lane] = pm[r];
+            }
+            lds_barrier();
+            if (XH == 0) {
+                floatx16 po[1][1];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float qv = pex[r * 64 + lane];
+                    po[0][0][r] = args.pool_mode == 1 ? 0.25f * (pm[r] + qv) : fmaxf(pm[r], qv);
+                }
+                // stored through the shared epilogue (one 32 x 32 block, float4 rows: 4 store instructions instead of 16 scalar
+                // ones -- the tail is store-issue bound), row table = the pooled rows of this wave's 32 tiles
+                TapGemmArgs gp = g;
+                gp.out_a = args.pool_y; gp.ldo_a = g.N; gp.out_y = nullptr; gp.bias = nullptr; gp.relu = 0; gp.accumulate = 0; gp.gate_mode = 0;
+                float* pscr = (wave < 4 ? xbase : bufs + 2 * RAW_F + (cur ^ 1) * U_F) + (wave & 3) * (32 * 33);
+                tap_epilogue<1, 1>(gp, po, pscr, prow, prow, wm * 32, n0 + wn * 32, lane, 0);
+            }
+        }
         // transpose scratch (32 x 33 floats per wave): waves 0-3 in the raw set, waves 4-7 in the weight set of `cur ^ 1`
         float* scratch = (wave < 4 ? xbase : bufs + 2 * RAW_F + (cur ^ 1) * U_F) + (wave & 3) * (32 * 33);
         tap_epilogue<2, 1>(g, out, scratch, rowa, rowy, wm * 128 + XH * 64, n0 + wn * 32, lane, (blk * 2 + wm) * 2 + XH);
@@ -638,7 +696,7 @@ extern "C" int asr_winograd_supported(const asr_gemm_desc* d) {
 struct WinoGate { int mode, H, W; const float* a; float* dz; float* part; int* rows; };
 
 static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale, const float* shift,
-                     float* out_a, float* out_y, void* stream, const WinoGate* gs) {
+                     float* out_a, float* out_y, void* stream, const WinoGate* gs, float* pool_y = nullptr, int pool_mode = 0) {
     if (!d || !A || !Ut || (!out_a && !out_y && !gs)) return ASR_ERR_BAD_ARG;
     if (!asr_winograd_supported(d)) return ASR_ERR_UNSUPPORTED;
     if ((((uintptr_t)A) | ((uintptr_t)Ut)) & 15) return ASR_ERR_BAD_ARG;
@@ -659,6 +717,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     w.TH = d->H / 2; w.TW = (d->W + 1) / 2;
     w.ntiles = (long)d->B * w.TH * w.TW;
     w.wodd = d->W & 1;
+    w.pool_y = pool_y; w.pool_mode = pool_mode; w.H2 = d->H / 2; w.W2 = d->W / 2;
     { static int xo = -1; if (xo < 0) { const char* e = getenv("ASR_WINO_XCD"); xo = e ? atoi(e) : 1; } w.xcd_order = xo; }
     const int nblk = asr_cdiv(w.ntiles, WT);
     a.ntm = nblk; a.ntn = d->N / WC;
@@ -673,8 +732,8 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     static int w8 = -1;
     if (w8 < 0) { const char* e = getenv("ASR_WINO8"); w8 = e ? atoi(e) : 1; }
     if (w8) {
-        const size_t lds8 = (size_t)(512 + 2 * RAW_F + 2 * U_F) * sizeof(float);
-        static_assert(4 * 2048 <= RAW_F && 4 * 2048 <= U_F && 4 * 32 * 33 <= RAW_F && 4 * 32 * 33 <= U_F, "exchange / scratch must fit in one buffer set");
+        const size_t lds8 = (size_t)(576 + 2 * RAW_F + 2 * U_F) * sizeof(float);
+        static_assert(4 * 2048 <= RAW_F && 4 * 2048 <= U_F && 4 * 32 * 33 + 2 * 1024 <= RAW_F && 4 * 32 * 33 + 2 * 1024 <= U_F, "exchange / scratch + pool hand-over must fit in one buffer set");
         static int ncu8 = 0;
         if (!ncu8) {
             int dev = 0; hipDeviceProp_t pr;
@@ -699,6 +758,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
         if (d->wmode) ASR_NOTE_KERNEL("wino8_kernel<1>"); else ASR_NOTE_KERNEL("wino8_kernel<0>");     // one name per call site
         return ASR_OK;
     }
+    if (pool_y) return ASR_ERR_UNSUPPORTED;             // the fused pool lives in the eight-wave kernel only
     static int gmul = -1;
     if (gmul < 0) { const char* e = getenv("ASR_WINO_GRID"); gmul = e ? atoi(e) : 1; }       // 0: one workgroup per work item
     const int grid = (gmul <= 0 || nwork < ncu * gmul) ? nwork : ncu * gmul;
@@ -722,6 +782,24 @@ extern "C" int asr_tap_gemm_wino(const asr_gemm_desc* d, const float* A, const f
                                  const float* bias, const float* scale, const float* shift,
                                  float* out_a, float* out_y, void* stream) {
     return wino_impl(d, A, Ut, bias, scale, shift, out_a, out_y, stream, nullptr);
+}
+
+extern "C" int asr_pool_fwd(const float* a, int B, int H, int W, int C, const float* bn_scale, const float* bn_shift, int pool,
+                            float* y, void* stream);
+
+// Forward conv of a POOLED cell in one launch: out_a = ReLU(conv + bias) as asr_tap_gemm_wino writes it, and
+// y_pooled = 2x2 pool (1 average / 2 maximum) of bn_scale * out_a + bn_shift -- what asr_pool_fwd would compute from out_a,
+// bit for bit, without reading it back (the four pixels of a Winograd tile are one pooling window).
+extern "C" int asr_tap_gemm_wino_pool(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale,
+                                      const float* shift, float* out_a, int pool, float* y_pooled, void* stream) {
+    if (!d || !out_a || !y_pooled || !scale || !shift || (pool != 1 && pool != 2) || d->ldo_a != d->N) return ASR_ERR_BAD_ARG;
+    static int w8 = -1;
+    if (w8 < 0) { const char* e = getenv("ASR_WINO8"); w8 = e ? atoi(e) : 1; }
+    if (!w8) {                                       // four-wave fallback kernel: two launches
+        const int rc = wino_impl(d, A, Ut, bias, scale, shift, out_a, nullptr, stream, nullptr);
+        return rc != ASR_OK ? rc : asr_pool_fwd(out_a, d->B, d->H, d->W, d->N, scale, shift, pool, y_pooled, stream);
+    }
+    return wino_impl(d, A, Ut, bias, scale, shift, out_a, nullptr, stream, nullptr, y_pooled, pool);
 }
 
 // Launch of the gated data-gradient (asr_tap_gemm_gated with prearranged == 2; the caller folds the partial rows)

@@ -374,6 +374,7 @@ class DFCNNEngine:
         # ASR_WINO_DIRS=f keeps the data-gradients on the tap-GEMM; ASR_WINO=0 turns all of it off.
         self.wino = os.environ.get('ASR_WINO', '1') == '1' and self.pw
         self.wt_f, self.wt_b = {}, {}
+        self.fuse_pool = os.environ.get('ASR_WINO_POOL', '1') == '1'      # pooled cells: pool inside the Winograd forward launch
         if self.wino:
             which = os.environ.get('ASR_WINO_DIRS', 'fb')
             for op in self.g:
@@ -520,6 +521,10 @@ class DFCNNEngine:
                 out_y = None if pool else (self.flat[dst] if dst in self.flat else self.y[dst])
                 if dst in self.ws_f:
                     ops.tap_gemm_bx6(self.fdesc[dst], self.y[src], self.ws_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], out_y)
+                elif dst in self.wt_f and pool and self.fuse_pool:
+                    # conv + bias + ReLU -> BN -> 2x2 pool in one launch: a Winograd tile is a pooling window
+                    ops.tap_gemm_wino_pool(self.fdesc[dst], self.y[src], self.wt_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], pm, self.y[dst])
+                    continue
                 elif dst in self.wt_f:
                     ops.tap_gemm_wino(self.fdesc[dst], self.y[src], self.wt_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], out_y)
                 elif dst in self.wf_f:

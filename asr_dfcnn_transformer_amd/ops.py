@@ -546,13 +546,22 @@ def winograd_supported(desc):
 
 
 def tap_gemm_wino(desc, A, Wt, bias=None, scale=None, shift=None, out_a=None, out_y=None):
-    """asr_tap_gemm on Winograd-transformed weights (3x3 only); EXPERIMENTAL."""
+    """asr_tap_gemm on Winograd-transformed weights (3x3 convs that asr_winograd_supported accepts)."""
     lib = _lib.load()
     pa = A.ptr if isinstance(A, Plane) else _ptr(A)
     po_a = out_a.ptr if isinstance(out_a, Plane) else _ptr(out_a)
     po_y = out_y.ptr if isinstance(out_y, Plane) else _ptr(out_y)
     _timed(desc, lambda: check(lib.asr_tap_gemm_wino(C.byref(desc), pa, _ptr(Wt), _ptr(bias), _ptr(scale), _ptr(shift), po_a, po_y,
                                                      _stream()), 'asr_tap_gemm_wino'))
+
+
+def tap_gemm_wino_pool(desc, A, Wt, bias, scale, shift, out_a, pool, y_pooled):
+    """Forward conv of a pooled cell in one launch (asr_tap_gemm_wino_pool): out_a as tap_gemm_wino writes it, y_pooled =
+    pool_fwd(out_a) bit for bit."""
+    lib = _lib.load()
+    pa = A.ptr if isinstance(A, Plane) else _ptr(A)
+    _timed(desc, lambda: check(lib.asr_tap_gemm_wino_pool(C.byref(desc), pa, _ptr(Wt), _ptr(bias), _ptr(scale), _ptr(shift), out_a.ptr,
+                                                          int(pool), y_pooled.ptr, _stream()), 'asr_tap_gemm_wino_pool'))
 
 
 def tap_gemm_pw(desc, A, Wf, bias=None, scale=None, shift=None, out_a=None, out_y=None):

@@ -421,6 +421,13 @@ int asr_winograd_supported(const asr_gemm_desc* d);
 int asr_tap_gemm_wino(const asr_gemm_desc* d, const float* A, const float* Wt,
                       const float* bias, const float* scale, const float* shift,
                       float* out_a, float* out_y, void* stream);
+/* Forward conv of a POOLED cell in one launch (replaces asr_tap_gemm_wino + asr_pool_fwd, acoustic_model.py:120-130 /
+ * acoustic_model2.py:126-133: conv + bias + ReLU -> BN -> 2x2 pool): out_a = ReLU(conv + bias) as asr_tap_gemm_wino writes
+ * it (ldo_a == N), y_pooled [B][H/2+1][W/2+1][N] = pool (1 average, 2 maximum) of bn_scale * out_a + bn_shift, bit-identical
+ * to asr_pool_fwd on the stored activation -- the four pixels of a Winograd tile are one pooling window, so the activation
+ * is not read back. */
+int asr_tap_gemm_wino_pool(const asr_gemm_desc* d, const float* A, const float* Wt, const float* bias, const float* bn_scale,
+                           const float* bn_shift, float* out_a, int pool, float* y_pooled, void* stream);
 
 /* ------------------------------------------------------------------ fused backward prologue (round 2)
  * The data-gradient of cell k, with the backward of cell k-1's [pool ->] BN -> ReLU (what asr_cell_bwd_pre computes in a

@@ -1,6 +1,7 @@
-"""EXPERIMENTAL Winograd F(2x2,3x3) convolution (asr_tap_gemm_wino) against the tap-GEMM (asr_tap_gemm) and float64: forward with
+"""Winograd F(2x2,3x3) convolution (asr_tap_gemm_wino) against the tap-GEMM (asr_tap_gemm) and float64: forward with
 bias + ReLU + BN affine on both outputs, the data-gradient view with accumulation, even / odd plane widths, tile counts that
-do not fill a workgroup, borders left untouched."""
+do not fill a workgroup, borders left untouched; the forward with the 2x2 pool fused in (asr_tap_gemm_wino_pool) against
+asr_tap_gemm_wino + asr_pool_fwd, bit for bit."""
 import numpy as np
 import pytest
 import torch
@@ -39,6 +40,30 @@ def test_forward_matches_tap_gemm_and_float64(ops, B, H, W, cin, cout):
     assert (y1.interior() - y0.interior()).abs().max().item() < 3e-5
     for p in (a1, y1):                                   # borders and guards stay zero
         assert p.buf.abs().sum().item() == pytest.approx(p.interior().abs().sum().item(), rel=1e-5)
+
+
+@pytest.mark.parametrize("pool", [1, 2])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 6, 5, 8, 64), (3, 4, 2, 16, 64), (2, 8, 12, 24, 128), (1, 16, 26, 32, 64), (2, 40, 100, 32, 64),
+                                            (32, 30, 50, 16, 128)])
+def test_fused_pool_equals_conv_then_pool_bitwise(ops, pool, B, H, W, cin, cout):
+    """One launch writes the activation AND its pooled BN output; the pooled plane equals asr_pool_fwd of the stored activation
+    bit for bit (average and maximum, odd widths drop the last column as asr_pool_fwd does, several items per workgroup)."""
+    g = torch.Generator(device='cuda').manual_seed(21)
+    x = ops.Plane(B, H, W, cin); x.set_interior(torch.randn(B, H, W, cin, device='cuda', generator=g))
+    w = torch.randn(3, 3, cin, cout, device='cuda', generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, device='cuda', generator=g) * 0.1
+    sc = 1 + 0.2 * torch.randn(cout, device='cuda', generator=g); sh = 0.1 * torch.randn(cout, device='cuda', generator=g)
+    d = ops.gemm_desc(x.NP, cin, cout, cin, cout, cout, 0, ntaps=9, B=B, H=H, W=W, relu=1)
+    wt = ops.winograd_weights(w, cin, cout, cout, 0)
+    a0, a1 = ops.Plane(B, H, W, cout), ops.Plane(B, H, W, cout)
+    y0, y1 = ops.Plane(B, H // 2, W // 2, cout), ops.Plane(B, H // 2, W // 2, cout)
+    ops.tap_gemm_wino(d, x, wt, bias, sc, sh, a0, None)
+    ops.pool_fwd(a0, sc, sh, pool, y0)
+    ops.tap_gemm_wino_pool(d, x, wt, bias, sc, sh, a1, pool, y1)
+    torch.cuda.synchronize()
+    assert torch.equal(a0.buf, a1.buf)
+    assert torch.equal(y0.buf, y1.buf)
+    assert y1.interior().abs().sum().item() > 0
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 6, 5, 64, 8), (1, 12, 25, 128, 32), (3, 4, 4, 64, 16)])
