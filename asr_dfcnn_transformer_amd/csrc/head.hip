@@ -93,12 +93,6 @@ __global__ __launch_bounds__(256) void ctc_rows_kernel(const float* __restrict__
     for (int k = lane; k < V; k += 64) gr[k] = expf(x[k] - lf);
 }
 
-__device__ __forceinline__ double lse3(double a, double b, double c) {
-    const double m = fmax(a, fmax(b, c));
-    if (m == -INFINITY) return -INFINITY;
-    return m + log(exp(a - m) + exp(b - m) + exp(c - m));
-}
-
 // One workgroup of 512 threads per utterance.  Phase 1: threads 0-255 run the alpha recursion while threads
 // 256-511 run the beta recursion (thread s / s-256 owns lattice state s), one barrier per time step, both
 // lattices go to the float64 workspace.  Phase 2 has no sequential dependency: the eight waves walk the time
@@ -110,6 +104,7 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
                                                           const int32_t* __restrict__ seq_len, int blank,
                                                           const int32_t* __restrict__ status, const double* __restrict__ lse,
                                                           double* __restrict__ alpha_ws, double* __restrict__ beta_ws,
+                                                          double* __restrict__ prob_ws,
                                                           float* __restrict__ loss, float* __restrict__ grad) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -120,13 +115,15 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
     const int L = label_len[b], Tb = seq_len[b], S = 2 * L + 1;
     const int SMAX = 2 * max_label + 1;
     const int half = tid >> 8, s = tid & 255;           // half 0: alpha, half 1: beta
-    double* abuf0 = (double*)smraw;                     // alpha ping/pong with two leading -inf sentinels
+    double* abuf0 = (double*)smraw;                     // alpha ping/pong with two leading zero sentinels
     double* abuf1 = abuf0 + SMAX + 4;
-    double* bbuf0 = abuf1 + SMAX + 4;                   // beta ping/pong with two trailing -inf sentinels
+    double* bbuf0 = abuf1 + SMAX + 4;                   // beta ping/pong with two trailing zero sentinels
     double* bbuf1 = bbuf0 + SMAX + 4;
-    double* occ = bbuf1 + SMAX + 4;                     // [8 waves][SMAX + 1]
-    double* lse_t = occ + 8 * (SMAX + 1);               // [T]
-    double* llp = lse_t + T;                            // [1] log-likelihood
+    double* occ = bbuf1 + SMAX + 4;                     // [16 wave sums] + [8 waves][SMAX + 1]
+    double* lse_t = occ + 16 + 8 * (SMAX + 1);          // [T]
+    double* sca = lse_t + T;                            // [T] cumulative log scale of alpha per frame
+    double* scb = sca + T;                              // [T] the same for beta
+    double* llp = scb + T;                              // [1] log-likelihood
     int* ext = (int*)(llp + 2);                         // [SMAX + 1]
     int* nxt = ext + SMAX + 1;                          // [SMAX + 1] next state with the same label (or -1)
     int* lead = nxt + SMAX + 1;                         // [SMAX + 1] 1 = first odd state of its label
@@ -150,64 +147,160 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
             nxt[s] = n; lead[s] = ld;
         }
     }
-    for (int i = tid; i < Tb * S; i += 512) {
-        const int t = i / S, q = i - t * S;
-        lg[i] = logits[((long)t * B + b) * V + ext[q]];
+    // gathered in batches of eight independent loads (one load per iteration left its whole latency exposed: 50 round trips)
+    for (int i0 = tid; i0 < Tb * S; i0 += 512 * 8) {
+        float gv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 512;
+            const int t = i / S, q = i - t * S;
+            gv[u] = (i < Tb * S) ? logits[((long)t * B + b) * V + ext[q]] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 512;
+            if (i < Tb * S) lg[i] = gv[u];
+        }
     }
-    if (tid < 2) { abuf0[tid] = -INFINITY; abuf1[tid] = -INFINITY; }
-    if (tid >= 2 && tid < 4) { bbuf0[2 + S + tid - 2] = -INFINITY; bbuf1[2 + S + tid - 2] = -INFINITY; }
+    if (tid < 2) { abuf0[tid] = 0.0; abuf1[tid] = 0.0; }                 // linear domain: the sentinels are zeros
+    if (tid >= 2 && tid < 4) { bbuf0[2 + S + tid - 2] = 0.0; bbuf1[2 + S + tid - 2] = 0.0; }
     __syncthreads();
 
     double* aw = alpha_ws + (long)b * T * SMAX;
     double* bw = beta_ws + (long)b * T * SMAX;
-    double* prev = (half == 0 ? abuf0 : bbuf0) + 2;
-    double* cur = (half == 0 ? abuf1 : bbuf1) + 2;
-    // ---- phase 1: alpha forward in time, beta backward in time, concurrently
-    if (s < S) {
-        if (half == 0) {
-            const double v = (s < 2) ? (double)lg[s] - lse_t[0] : -INFINITY;
-            prev[s] = v; aw[s] = v;
-        } else {
-            const int t = Tb - 1;
-            const double v = (s >= S - 2) ? (double)lg[t * S + s] - lse_t[t] : -INFINITY;
-            prev[s] = v; bw[(long)t * SMAX + s] = v;
-        }
+    double* pw = prob_ws + (long)b * T * SMAX;
+    // ---- phase 0: emission probabilities p_t(s) = exp(logit - lse) of the lattice states in float64, all threads
+    for (int i = tid; i < Tb * S; i += 512) {
+        const int t = i / S, q = i - t * S;
+        pw[(long)t * SMAX + q] = exp((double)lg[i] - lse_t[t]);
     }
-    for (int k = 1; k < Tb; ++k) {
-        __syncthreads();
-        if (s < S) {
-            if (half == 0) {
-                const int t = k;
-                const double a0 = prev[s], a1 = prev[s - 1], a2 = skip_f ? prev[s - 2] : -INFINITY;
-                const double v = lse3(a0, a1, a2) + ((double)lg[t * S + s] - lse_t[t]);
-                cur[s] = v; aw[(long)t * SMAX + s] = v;
-            } else {
-                const int t = Tb - 1 - k;
-                const double b0 = prev[s], b1 = prev[s + 1], b2 = skip_b ? prev[s + 2] : -INFINITY;
-                const double v = lse3(b0, b1, b2) + ((double)lg[t * S + s] - lse_t[t]);
-                cur[s] = v; bw[(long)t * SMAX + s] = v;
+    __threadfence_block();
+    __syncthreads();
+    // ---- phase 1: alpha forward in time (wave 0), beta backward in time (wave 1), concurrently, in the LINEAR domain with
+    // rescaling: a_t(s) = (a_{t-1}(s) + a_{t-1}(s-1) + [skip] a_{t-1}(s-2)) p_t(s) is two adds and a multiply where the
+    // log-domain form (the oracle's) pays three exps and a log per state and step on the serial path.  ONE wave per
+    // direction holds the whole vector in registers, four states per lane, neighbours by lane shifts: no barrier and no LDS
+    // round trip per frame (the 512-thread form with a barrier per frame spent 0.25 us per frame on exactly those).
+    // Every RS frames the vector is divided by its sum and the log of the divisor is carried along: true alpha_t = stored
+    // alpha_t * exp(sca[t]); between two rescalings a state loses at most RS emission factors.
+    constexpr int RS = 16, NPL = 4, PD = 8;             // rescale period, states per lane, prefetch distance (frames)
+    const int wv = tid >> 6, ln = tid & 63;
+    if (wv < 2 && S <= 64 * NPL) {
+        const bool fwd = wv == 0;
+        double* scl = fwd ? sca : scb;
+        double* xw = fwd ? aw : bw;
+        auto frame = [&](int k) { return fwd ? k : Tb - 1 - k; };
+        const int s0 = ln * NPL;
+        bool sk[NPL];
+#pragma unroll
+        for (int j = 0; j < NPL; ++j) {
+            const int q = s0 + j;
+            sk[j] = false;
+            if (q < S) {
+                const int e = ext[q];
+                sk[j] = fwd ? ((q >= 2) && (e != blank) && (e != ext[q - 2])) : ((q + 2 < S) && (e != blank) && (e != ext[q + 2]));
             }
         }
-        double* tmp = prev; prev = cur; cur = tmp;
+        double v[NPL], pr[PD][NPL];
+        auto fetch = [&](double (&dst)[NPL], int k) {
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) dst[j] = (k < Tb && s0 + j < S) ? pw[(long)frame(k) * SMAX + s0 + j] : 0.0;
+        };
+        {
+            const int t = frame(0);
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const int q = s0 + j;
+                const bool on = fwd ? (q < 2) : (q >= S - 2);
+                v[j] = (q < S && on) ? pw[(long)t * SMAX + q] : 0.0;
+                if (q < S) xw[(long)t * SMAX + q] = v[j];
+            }
+            if (ln == 0) scl[t] = 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < PD; ++u) fetch(pr[u], 1 + u);
+        double lsc = 0.0;
+        for (int k0 = 1; k0 < Tb; k0 += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int k = k0 + u;
+                if (k < Tb) {                            // uniform
+                    double inv = 1.0;
+                    if (k % RS == 0) {                   // uniform: rescale by the sum of the previous frame's vector
+                        const double tot = asr_wave_sum_d((v[0] + v[1]) + (v[2] + v[3]));
+                        if (tot > 0.0) { inv = 1.0 / tot; lsc += log(tot); }
+                    }
+                    double nv[NPL];
+                    if (fwd) {
+                        // neighbours below: states s0 - 1, s0 - 2 live in lane - 1 (its v[3], v[2]); lane 0 has none
+                        double m1 = __shfl_up(v[NPL - 1], 1, 64), m2 = __shfl_up(v[NPL - 2], 1, 64);
+                        if (ln == 0) { m1 = 0.0; m2 = 0.0; }
+                        nv[0] = ((v[0] + m1) + (sk[0] ? m2 : 0.0)) * inv * pr[u][0];
+                        nv[1] = ((v[1] + v[0]) + (sk[1] ? m1 : 0.0)) * inv * pr[u][1];
+                        nv[2] = ((v[2] + v[1]) + (sk[2] ? v[0] : 0.0)) * inv * pr[u][2];
+                        nv[3] = ((v[3] + v[2]) + (sk[3] ? v[1] : 0.0)) * inv * pr[u][3];
+                    } else {
+                        double p1 = __shfl_down(v[0], 1, 64), p2 = __shfl_down(v[1], 1, 64);
+                        if (ln == 63) { p1 = 0.0; p2 = 0.0; }
+                        nv[3] = ((v[3] + p1) + (sk[3] ? p2 : 0.0)) * inv * pr[u][3];
+                        nv[2] = ((v[2] + v[3]) + (sk[2] ? p1 : 0.0)) * inv * pr[u][2];
+                        nv[1] = ((v[1] + v[2]) + (sk[1] ? v[3] : 0.0)) * inv * pr[u][1];
+                        nv[0] = ((v[0] + v[1]) + (sk[0] ? v[2] : 0.0)) * inv * pr[u][0];
+                    }
+                    const int t = frame(k);
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j) {
+                        v[j] = nv[j];
+                        if (s0 + j < S) xw[(long)t * SMAX + s0 + j] = nv[j];
+                    }
+                    if (ln == 0) scl[t] = lsc;
+                    fetch(pr[u], k + PD);
+                }
+            }
+        }
+        // the last frame's vector of alpha, for the likelihood
+        if (fwd) {
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) if (s0 + j < S) abuf0[2 + s0 + j] = v[j];
+        }
     }
     __syncthreads();
-    if (tid == 0) {       // half 0's `prev` holds alpha at the last frame
-        const double ll = (S > 1) ? lse3(prev[S - 1], prev[S - 2], -INFINITY) : prev[0];
+    if (tid == 0) {       // abuf0 holds the scaled alpha at the last frame
+        const double* prev = abuf0 + 2;
+        const double tail = (S > 1) ? prev[S - 1] + prev[S - 2] : prev[0];
+        const double ll = log(tail) + sca[Tb - 1];
         llp[0] = ll;
         loss[b] = (float)(-ll);
     }
     __threadfence_block();
     __syncthreads();
     const double ll = llp[0];
-    // ---- phase 2: occupancies and the sparse part of the gradient, time steps in parallel over the waves
+    // ---- phase 2: occupancies alpha_t(s) beta_t(s) / (p_t(s) P) and the sparse part of the gradient, time steps in parallel
+    // over the waves; the scales of a frame enter as ONE factor exp(sca[t] + scb[t] - ll)
     const int wave = tid >> 6, lane = tid & 63;
-    double* oc = occ + wave * (SMAX + 1);
-    for (int t = wave; t < Tb; t += 8) {
-        for (int q = lane; q < S; q += 64) {
-            const double lp = (double)lg[t * S + q] - lse_t[t];
-            const double ab = aw[(long)t * SMAX + q] + bw[(long)t * SMAX + q];
-            oc[q] = (ab == -INFINITY) ? 0.0 : exp(ab - lp - ll);
+    double* oc = occ + 16 + wave * (SMAX + 1);
+    constexpr int QL = 4;                               // states per lane: S <= 256
+    double ra[QL], rb[QL], rp[QL];
+    auto fetch3 = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < QL; ++j) {
+            const int q = lane + 64 * j;
+            const bool ok = t < Tb && q < S;
+            ra[j] = ok ? aw[(long)t * SMAX + q] : 0.0;
+            rb[j] = ok ? bw[(long)t * SMAX + q] : 0.0;
+            rp[j] = ok ? pw[(long)t * SMAX + q] : 1.0;
         }
+    };
+    fetch3(wave);
+    for (int t = wave; t < Tb; t += 8) {
+        const double ft = exp(sca[t] + scb[t] - ll);
+#pragma unroll
+        for (int j = 0; j < QL; ++j) {
+            const int q = lane + 64 * j;
+            const double ab = ra[j] * rb[j];
+            if (q < S) oc[q] = (ab == 0.0) ? 0.0 : ab / rp[j] * ft;
+        }
+        fetch3(t + 8);                                  // the next frame's values travel while this frame's sums are formed
         // (the wave's LDS writes are ordered before its own later reads)
         float* gr = grad + ((long)t * B + b) * V;
         double bsum = 0.0;
@@ -349,7 +442,7 @@ __global__ void adam_tf_kernel(float* __restrict__ theta, const float* __restric
 
 inline size_t ctc_lds_bytes(int T, int max_label) {
     const size_t SMAX = 2 * (size_t)max_label + 1;
-    return (4 * (SMAX + 4) + 8 * (SMAX + 1) + (size_t)T + 2) * sizeof(double) + 3 * (SMAX + 1) * sizeof(int) +
+    return (4 * (SMAX + 4) + 16 + 8 * (SMAX + 1) + 3 * (size_t)T + 2) * sizeof(double) + 3 * (SMAX + 1) * sizeof(int) +
            (size_t)T * SMAX * sizeof(float) + 16;
 }
 
@@ -372,7 +465,7 @@ extern "C" int asr_softmax_log_bwd(const float* logits_tm, const float* g_tm, in
 
 extern "C" size_t asr_ctc_workspace(int T, int B, int max_label) {
     const size_t SMAX = 2 * (size_t)max_label + 1;
-    return ((size_t)T * B + 2 * (size_t)B * T * SMAX) * sizeof(double) + 64;
+    return ((size_t)T * B + 3 * (size_t)B * T * SMAX) * sizeof(double) + 64;
 }
 
 extern "C" int asr_ctc_loss(const float* logits_tm, int T, int B, int V, const int32_t* labels, int max_label,
@@ -387,6 +480,7 @@ extern "C" int asr_ctc_loss(const float* logits_tm, int T, int B, int V, const i
     double* lse = (double*)workspace;
     double* alpha_ws = lse + (size_t)T * B;
     double* beta_ws = alpha_ws + (size_t)B * T * (2 * (size_t)max_label + 1);
+    double* prob_ws = beta_ws + (size_t)B * T * (2 * (size_t)max_label + 1);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)ctc_lattice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -394,7 +488,7 @@ extern "C" int asr_ctc_loss(const float* logits_tm, int T, int B, int V, const i
     }
     hipLaunchKernelGGL(ctc_check_kernel, dim3(asr_cdiv(B, 64)), dim3(64), 0, st, labels, max_label, label_len, seq_len, T, B, status);
     hipLaunchKernelGGL(ctc_rows_kernel, dim3(asr_cdiv((long)T * B, 4)), dim3(256), 0, st, logits_tm, T, B, V, seq_len, (const int32_t*)status, lse, grad);
-    hipLaunchKernelGGL(ctc_lattice_kernel, dim3(B), dim3(512), lds, st, logits_tm, T, B, V, labels, max_label, label_len, seq_len, blank, (const int32_t*)status, (const double*)lse, alpha_ws, beta_ws, loss, grad);
+    hipLaunchKernelGGL(ctc_lattice_kernel, dim3(B), dim3(512), lds, st, logits_tm, T, B, V, labels, max_label, label_len, seq_len, blank, (const int32_t*)status, (const double*)lse, alpha_ws, beta_ws, prob_ws, loss, grad);
     ASR_CHECK_LAUNCH("ctc_loss");
     return ASR_OK;
 }
