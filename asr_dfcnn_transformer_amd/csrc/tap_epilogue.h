@@ -26,6 +26,10 @@ struct TapGemmArgs {
     float* gate_dz;      // out: dL/d(conv + bias) of that cell, same layout as gate_a (scale / shift = its BN affine)
     float* gate_part;    // out: [rows][3][N] per-(tile row, wave row) sums of dscale, dshift, dbias
     int* gate_rows;      // host out: rows of gate_part the launched configuration writes
+    // split-K (asr_tap_gemm_splitk; 1-tap forward only): workgroup row blockIdx.y contracts K / ksplit channels and writes its raw
+    // partial sums to split_out + y * M * N; a second pass adds them and applies the epilogue
+    int ksplit = 1;
+    float* split_out = nullptr;
 };
 
 // Row offset of tap `tap` in the flattened padded plane, and the tap of the weight tensor it multiplies.

@@ -237,6 +237,12 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = tid >> 6, wm = wave / WN, wn = wave % WN;
 
+    if (NTAPS == 1 && WMODE == 0 && g.ksplit > 1) {      // split-K: this grid row's slice of the contraction, raw partial sums out
+        const int z = blockIdx.y, kper = g.K / g.ksplit;
+        g.A += (long)z * kper; g.W += (long)z * kper * g.ldw; g.K = kper;
+        g.out_a = g.split_out + (long)z * g.M * g.N; g.ldo_a = g.N; g.out_y = nullptr;
+        g.bias = nullptr; g.scale = nullptr; g.shift = nullptr; g.relu = 0; g.accumulate = 0;
+    }
     const int swz = asr_xcd_swizzle(blockIdx.x, gridDim.x);
     const int tile_m = swz / g.ntn, tile_n = swz - tile_m * g.ntn;
     const long p0 = (long)tile_m * MT;
@@ -910,7 +916,7 @@ int launch_v1(const TapGemmArgs& a, hipStream_t st) {
     g.ntm = asr_cdiv(a.M, MT);
     g.ntn = asr_cdiv(a.N, NT);
     if (a.gate_rows) *a.gate_rows = g.ntm * WM;
-    hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn), dim3(256), lds, st, g);
+    hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn, (NTAPS == 1 && WMODE == 0 && g.ksplit > 1) ? g.ksplit : 1), dim3(256), lds, st, g);
     ASR_CHECK_LAUNCH("tap_gemm");
     ASR_NOTE_KERNEL("tap_gemm_kernel_v1<%d, %d, %d, %d, %d, %d, %d>", MT, NT, WM, WN, NTAPS, WMODE, KCV);
     return ASR_OK;
@@ -1044,6 +1050,71 @@ static int tap_gemm_impl(const asr_gemm_desc* d, const float* A, const float* W,
     if (d->ntaps == 9) return d->wmode ? launch_n<9, 1>(a, st) : launch_n<9, 0>(a, st);
     if (d->ntaps == 4) return d->wmode ? launch_n<4, 1>(a, st) : launch_n<4, 0>(a, st);
     return d->wmode ? launch_n<1, 1>(a, st) : launch_n<1, 0>(a, st);
+}
+
+namespace {
+// second pass of the split-K form: sum of the partial planes in a fixed order, then bias / ReLU|tanh / BN affine as tap_epilogue
+__global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits, long MN, int N, const float* __restrict__ bias,
+                                     const float* __restrict__ scale, const float* __restrict__ shift, int relu, int accumulate,
+                                     float* __restrict__ out_a, int ldo_a, float* __restrict__ out_y, int ldo_y) {
+    const long n4 = MN / 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = *(const float4*)(part + i * 4);
+        for (int z = 1; z < splits; ++z) {
+            const float4 q = *(const float4*)(part + (long)z * MN + i * 4);
+            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+        }
+        const long e = i * 4;
+        const long row = e / N;
+        const int n = (int)(e - row * N);
+        if (bias) { const float4 b = *(const float4*)(bias + n); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        else if (relu == 2) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
+        if (out_a) *(float4*)(out_a + row * ldo_a + n) = v;
+        if (out_y) {
+            float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (scale) sc = *(const float4*)(scale + n);
+            if (shift) sh = *(const float4*)(shift + n);
+            float4 y = make_float4(sc.x * v.x + sh.x, sc.y * v.y + sh.y, sc.z * v.z + sh.z, sc.w * v.w + sh.w);
+            float* o = out_y + row * ldo_y + n;
+            if (accumulate) { const float4 p = *(const float4*)o; y.x += p.x; y.y += p.y; y.z += p.z; y.w += p.w; }
+            *(float4*)o = y;
+        }
+    }
+}
+}  // namespace
+
+extern "C" size_t asr_tap_gemm_splitk_workspace(const asr_gemm_desc* d, int splits) {
+    return (d && splits > 1) ? (size_t)splits * d->M * d->N * sizeof(float) : 0;
+}
+
+// Dense forward GEMM (ntaps 1, wmode 0, no plane geometry) with the contraction split `splits` ways over the grid: for a deep K
+// and few output tiles (6400 -> 128 hidden dense of acoustic_model.py:53: 200 tiles on 256 CUs, 200 chunk steps each).
+// Same result up to the order of the K sum (partials are added in a fixed order: reproducible).
+extern "C" int asr_tap_gemm_splitk(const asr_gemm_desc* d, const float* A, const float* W, const float* bias, const float* scale,
+                                   const float* shift, float* out_a, float* out_y, int splits, void* workspace, void* stream) {
+    if (!d || !A || !W || (!out_a && !out_y) || !workspace) return ASR_ERR_BAD_ARG;
+    if (d->ntaps != 1 || d->wmode != 0 || d->H > 0 || d->y_unpadded || splits < 2 || splits > 16) return ASR_ERR_BAD_ARG;
+    if ((d->K % (splits * 32)) || (d->N & 3) || (d->lda & 3) || (d->ldw & 3) || (((uintptr_t)A | (uintptr_t)W | (uintptr_t)workspace) & 15)) return ASR_ERR_BAD_ARG;
+    TapGemmArgs a;
+    a.A = A; a.W = W; a.bias = nullptr; a.scale = nullptr; a.shift = nullptr;
+    a.out_a = (float*)workspace; a.out_y = nullptr;
+    a.M = d->M; a.K = d->K; a.N = d->N; a.lda = d->lda; a.ldw = d->ldw; a.ldo_a = d->N; a.ldo_y = 0;
+    a.H = 0; a.Wd = 0; a.WP = 1; a.HPWP = 1; a.halo = 0;
+    a.rmin = 0; a.rmax = d->M;
+    a.relu = 0; a.accumulate = 0; a.y_unpadded = 0;
+    a.ntm = a.ntn = 0; a.ablate = 0;
+    set_gate(a, nullptr);
+    a.ksplit = splits; a.split_out = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = launch_v1<64, 64, 2, 2, 1, 0, 32>(a, st);
+    if (rc != ASR_OK) return rc;
+    const long MN = (long)d->M * d->N;
+    int blocks = (int)((MN / 4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, (const float*)workspace, splits, MN, d->N, bias, scale, shift,
+                       d->relu, d->accumulate, out_a, d->ldo_a, out_y, d->ldo_y);
+    ASR_CHECK_LAUNCH("tap_gemm_splitk");
+    return ASR_OK;
 }
 
 extern "C" int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float* W,

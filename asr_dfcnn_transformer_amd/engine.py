@@ -255,6 +255,7 @@ class DFCNNEngine:
         self.dy = {}         # name -> Plane gradient buffers (allocated lazily per geometry)
         self.fdesc, self.bdesc, self.wdesc = {}, {}, {}
         ws_bytes = 1 << 20
+        self.splitk = {}
         consumers = {}
         for op in self.g:
             srcs = [op[1]] if op[0] != 'se' else [op[1], op[2]]
@@ -308,6 +309,13 @@ class DFCNNEngine:
                 self.bdesc[dst] = ops.gemm_desc(rows, cout, cin, cout, cout, 0, cin, ntaps=1, wmode=1)
                 self.wdesc[dst] = ops.gemm_desc(rows, cin, cout, cin, cout, ntaps=1)
                 ws_bytes = max(ws_bytes, ops.tap_wgrad_workspace(self.wdesc[dst]), ops.colsum_workspace(rows, cout))
+                # a deep contraction with few output tiles (6400 -> 128: 200 workgroups of 200 chunk steps) is split eight ways
+                # over the grid (asr_tap_gemm_splitk: 185 -> 124 us with the second pass; ASR_SPLITK=0: off)
+                # (decided by the layer's widths only, never by the batch: an utterance alone must give bitwise the logits it
+                # gives inside a batch, tests/test_fullsize_gpu.py)
+                if os.environ.get('ASR_SPLITK', '1') == '1' and cout <= 128 and cin >= 2048 and cin % 256 == 0:
+                    self.splitk[dst] = 8
+                    ws_bytes = max(ws_bytes, ops.tap_gemm_splitk_workspace(self.fdesc[dst], 8))
         self.T8 = self.res[self.g[-1][2]][0]
         T8, V = self.T8, self.V
         self.logits = torch.zeros(T8, B, V, dtype=torch.float32, device=dev)      # self.logits of the reference
@@ -541,8 +549,12 @@ class DFCNNEngine:
                            self.p(dst, 'w2'), self.p(dst, 'b2'), self.se_state[dst], self.ws, self.y[dst])
             elif op[0] == 'dense':
                 _, src, dst, cin, cout, act = op
-                ops.tap_gemm(self.fdesc[dst], self.flat[src], self.p(dst, 'w'), self.p(dst, 'b'), None, None,
-                             None, self.flat[dst])
+                if dst in self.splitk:
+                    ops.tap_gemm_splitk(self.fdesc[dst], self.flat[src], self.p(dst, 'w'), self.p(dst, 'b'), None, None,
+                                        None, self.flat[dst], self.splitk[dst], self.ws)
+                else:
+                    ops.tap_gemm(self.fdesc[dst], self.flat[src], self.p(dst, 'w'), self.p(dst, 'b'), None, None,
+                                 None, self.flat[dst])
         ops.softmax_log_fwd(self.flat[self.g[-1][2]], self.B, self.T8, self.V, K_EPSILON, self.logits)
         return self.logits
 

@@ -117,6 +117,17 @@ def tap_gemm(desc, A, W, bias=None, scale=None, shift=None, out_a=None, out_y=No
         'asr_tap_gemm'))
 
 
+def tap_gemm_splitk_workspace(desc, splits):
+    return _lib.load().asr_tap_gemm_splitk_workspace(C.byref(desc), int(splits))
+
+
+def tap_gemm_splitk(desc, A, W, bias, scale, shift, out_a, out_y, splits, workspace):
+    """Dense forward GEMM with the contraction split over the grid (asr_tap_gemm_splitk)."""
+    lib = _lib.load()
+    _timed(desc, lambda: check(lib.asr_tap_gemm_splitk(C.byref(desc), _ptr(A), _ptr(W), _ptr(bias), _ptr(scale), _ptr(shift), _ptr(out_a),
+                                                       _ptr(out_y), int(splits), _ptr(workspace), _stream()), 'asr_tap_gemm_splitk'))
+
+
 def tap_gemm_gated_workspace(desc):
     return _lib.load().asr_tap_gemm_gated_workspace(C.byref(desc))
 

@@ -393,6 +393,15 @@ size_t asr_pix_ln_bwd_workspace(const asr_pixmap* m);
 int asr_pix_ln_bwd(const float* dy, const float* xhat, const float* rstd, const asr_pixmap* m, const float* gamma,
                    float* dx, float* dgamma, float* dbeta, float* workspace, void* stream);
 
+/* Dense forward GEMM of asr_tap_gemm (ntaps 1, wmode 0, H = 0) with the contraction split `splits` ways over the grid and a
+ * second pass that adds the partial planes in a fixed order and applies bias / ReLU / affine: for a deep K with few output
+ * tiles (tf.layers.dense(128) on the 6400-wide reshape, acoustic_model.py:53).  K % (32 * splits) == 0, 2 <= splits <= 16;
+ * workspace = asr_tap_gemm_splitk_workspace(d, splits) bytes, 16-byte aligned.  Equal to asr_tap_gemm up to the order of the K
+ * sum; reproducible run to run. */
+size_t asr_tap_gemm_splitk_workspace(const asr_gemm_desc* d, int splits);
+int asr_tap_gemm_splitk(const asr_gemm_desc* d, const float* A, const float* W, const float* bias, const float* scale,
+                        const float* shift, float* out_a, float* out_y, int splits, void* workspace, void* stream);
+
 /* fp32 contraction on PRE-ARRANGED weights: same arguments, arithmetic (v_mfma_f32_32x32x2_f32, fp32 accumulate) and
  * epilogue as asr_tap_gemm; the weight tensor is first copied into MFMA fragment order, once per optimiser step:
  *   asr_arrange_weights(W, ntaps, K, N, ldw, wmode, out): out = fp32 [ntaps][ceil(K/8)][ceil(N/32)][64 lanes][4], lane
