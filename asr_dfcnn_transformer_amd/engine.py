@@ -356,6 +356,10 @@ class DFCNNEngine:
         # kernels.  The fp32 weights stay the parameters; their hi/mid/lo bf16 pieces (forward view and mirrored
         # data-gradient view) are regenerated at the start of every forward pass.
         self.bx6 = os.environ.get('ASR_BX6', '0') == '1'
+        if self.bx6 and B < 2:
+            # known issue of the EXPERIMENTAL mode: the full-width one-utterance SE-DFCNN step faults in one of
+            # the split-bf16 kernels; the mode is measured and tested at B >= 2 only -- refuse rather than fault
+            raise ValueError('ASR_BX6=1 (experimental split-bf16 convolutions) needs a batch of at least 2 utterances')
         self.ws_f, self.ws_b = {}, {}
         self._cell_dims = {op[2]: (op[3], op[4]) for op in self.g if op[0] == 'cell'}
         if self.bx6:

@@ -160,6 +160,9 @@ def test_stream_and_fusion_modes_give_the_same_bits(model, widths, monkeypatch):
     epilogues or run as passes of their own: dZ is the same arithmetic either way, so the weight / bias gradients are
     bitwise equal; the three BN / bias channel sums of fused cells are folded in another (fixed) order -> 1e-6."""
     from asr_dfcnn_transformer_amd.engine import DFCNNEngine
+    import os
+    if os.environ.get('ASR_BX6') == '1':
+        pytest.skip('the opt-in split-bf16 mode runs the backward prologues as passes of their own (no fused form to compare)')
     rng = np.random.default_rng(5)
     B, T, F, V = 2, 64, 24, 20
     x = torch.tensor(rng.standard_normal((B, T, F)).astype(np.float32), device='cuda')
