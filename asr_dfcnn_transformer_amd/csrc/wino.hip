@@ -1,23 +1,23 @@
-// EXPERIMENTAL: 3x3 convolution (forward and data-gradient view) by Winograd F(2x2, 3x3) on the fp32 MFMA pipe.
-// Status (round 2): correct on every layer shape (tests/test_wino_gpu.py), but only as fast as tap_gemm_kernel_v5 (0.86-1.11x:
-// 2.25x fewer MFMAs at a third of the pipe's rate instead of three quarters) -- not used by the engines.  DESIGN.md section 9
-// has the measurements and what is in the way.
+// 3x3 convolution (forward and data-gradient view) by Winograd F(2x2, 3x3) on the fp32 MFMA pipe: the engines' default for the
+// 3x3 layers with N % 64 == 0 (asr_winograd_supported), 1.3-1.6x tap_gemm_kernel_v5 per layer.  DESIGN.md section 9 item 4 has
+// the design decisions, every measurement and the dead ends; tests/test_wino_gpu.py, tools/bench_wino.py, tools/trace_wino.py.
 //
 //   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A        16 multiplies per 2x2 output tile, input and output channel
-//                                                        instead of 36; still fp32 ("Next")
+//                                                        instead of 36; still fp32
 //
 // One GEMM per transform position xi = 0..15:  M_xi[tile][co] = sum_ci V_xi[tile][ci] * U_xi[ci][co].
 //   * U = G g G^T is prepared once per optimiser step (asr_winograd_weights: [16][K][N], forward or data-gradient view);
-//   * a workgroup owns 64 consecutive tiles x 64 output channels: 2 x 2 waves, each wave 32 tiles x 32 channels with
-//     SIXTEEN 32x32 accumulators (256 registers, one wave per SIMD -- what tap_wgrad_kernel_v6 lives with);
-//   * per chunk of 8 input channels the raw 4x4 patches of the 64 tiles ([pixel 16][tile 64][quad 2] 16-byte slots) and
-//     the 16 weight matrices ([xi][ci 8][co 64]) arrive by LDS-DMA in two buffers each, one barrier per chunk;
-//   * the lanes transform their own patch: lane (tile, half) reads the channel pair of its half with one ds_read_b64 per
-//     pixel, B^T d B is 32 adds per 16 MFMAs (vector instructions are not free beside fp32 MFMAs: +12 %), and V goes
-//     straight into the MFMAs as the A operand -- the transformed input never exists in memory;
-//   * the inverse transform A^T M A is lane-local (register r of all 16 accumulators = one tile, 24 adds) and yields four
-//     32-row blocks -- the four pixels of the tiles -- which go through the SAME epilogues as the tap-GEMM kernels
-//     (tap_epilogue: bias / ReLU / BN affine / accumulate / the gated backward prologues) via their row tables.
+//   * a work item is 64 consecutive tiles x 64 output channels, the input channels come in chunks of 8: the raw 4x4 patches of
+//     the tiles and the 16 weight matrices ([xi][ci 8][co 64]) arrive by LDS-DMA in two buffer sets, one barrier per chunk;
+//   * the lanes transform their own patch (B^T d B) and V goes straight into the MFMAs as the A operand -- the transformed
+//     input never exists in memory;
+//   * the inverse transform A^T M A is lane-local per accumulator register and yields four 32-row blocks -- the four pixels
+//     of the tiles -- which go through the SAME epilogues as the tap-GEMM kernels (tap_epilogue: bias / ReLU / BN affine /
+//     accumulate / the gated backward prologues) via their row tables; for a pooled cell the 2x2 pool of the BN output is
+//     formed from those four pixels in registers (asr_tap_gemm_wino_pool).
+// Two kernels: wino8_kernel (default; eight waves, the sixteen positions split 8 + 8 over the two waves of a SIMD, persistent
+// workgroups, DMA pieces between the MFMAs) and the first, four-wave wino_kernel (sixteen accumulators per wave, one wave per
+// SIMD; ASR_WINO8=0), kept as the reference form of the same arithmetic.
 // Planes as everywhere else ([B][H+1][W+1][C], zero borders): patch rows / columns that stick out read the border; an odd
 // plane width needs the fourth patch column of the last tile column zeroed (it would wrap into the next pixel row).
 #include "asr_common.h"
