@@ -699,12 +699,14 @@ __global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_v3(WgradArgs g) {
 typedef __attribute__((address_space(3))) float wg_lds_f;
 typedef const __attribute__((address_space(1))) float wg_glb_f;
 
-template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS, int MINB>
-__global__ __launch_bounds__(256, MINB) void tap_wgrad_kernel_v6(WgradArgs g) {
+// Body of tap_wgrad_kernel_v6 for the taps T0 .. T1 - 1 of a workgroup of NW waves (4: all nine taps per wave, the round-2 form;
+// 8: tap_wgrad_kernel_v6s, where the two waves of a SIMD share a weight block and split its taps 5 + 4).
+template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS, int T0, int T1, int NW>
+__device__ __forceinline__ void v6_body(const WgradArgs& g, float* smem) {
+    constexpr int NTL = T1 - T0;                    // taps of this wave
     constexpr int WAVES_P = 4 / WAVES_N;
     constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32;
 
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int halo = g.halo;
     const int arows = PS + 2 * halo;
     const int atotal = arows * (KT / 4);            // float4 of the A image
@@ -713,21 +715,22 @@ __global__ __launch_bounds__(256, MINB) void tap_wgrad_kernel_v6(WgradArgs g) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = tid >> 6, wn = wave % WAVES_N, wp = wave / WAVES_N;
+    const int wave8 = tid >> 6;                      // DMA piece owner (0 .. NW - 1)
+    const int wave = wave8 & 3, wn = wave % WAVES_N, wp = wave / WAVES_N;
     const int chunk = blockIdx.x;
     const int k0 = blockIdx.y * KT, n0 = blockIdx.z * NT;
     const long cbeg = (long)chunk * g.pch;
     const long cend = (cbeg + g.pch < g.M) ? cbeg + g.pch : g.M;
 
-    floatx16 acc[NTAPS][TKW][TNW];
+    floatx16 acc[NTL][TKW][TNW];
 #pragma unroll
-    for (int t = 0; t < NTAPS; ++t)
+    for (int t = T0; t < T1; ++t)
 #pragma unroll
         for (int a = 0; a < TKW; ++a)
 #pragma unroll
             for (int b = 0; b < TNW; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[t - T0][a][b][r] = 0.f;
 
     constexpr int ARP = 256 / KT, ZRP = 256 / NT;   // rows per DMA piece
     const int apieces = (atotal + 63) >> 6;
@@ -741,26 +744,26 @@ __global__ __launch_bounds__(256, MINB) void tap_wgrad_kernel_v6(WgradArgs g) {
         // accumulators of weight rows / columns that are never stored
         const float* asrc = g.A + (ps0 - halo + arow_l) * (long)g.lda + k0 + ac4 * 4;
         const bool aok = k0 + ac4 * 4 < g.K, zok = n0 + zc4 * 4 < g.N;
-        for (int p = wave; p < apieces; p += 4)
+        for (int p = wave8; p < apieces; p += NW)
             if (aok && p * 64 + lane < atotal)
                 __builtin_amdgcn_global_load_lds((wg_glb_f*)(asrc + (long)p * ARP * g.lda), (wg_lds_f*)(buf + p * 256), 16, 0, 0);
         const float* zsrc = g.Z + (ps0 + zrow_l) * (long)g.ldz + n0 + zc4 * 4;
         float* zb = buf + asz;
 #pragma unroll
-        for (int p = wave; p < zpieces; p += 4)
+        for (int p = wave8; p < zpieces; p += NW)
             if (zok)
                 __builtin_amdgcn_global_load_lds((wg_glb_f*)(zsrc + (long)p * ZRP * g.ldz), (wg_lds_f*)(zb + p * 256), 16, 0, 0);
     };
     auto stage_masked = [&](long ps0, float* buf) {     // ragged last run: rows past the end read as zero
         float* Zs = buf + asz;
-        for (int f = tid; f < atotal; f += 256) {
+        for (int f = tid; f < atotal; f += 64 * NW) {
             const int row = f / (KT / 4), c4 = f - row * (KT / 4);
             const long grow = ps0 - halo + row;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (grow >= g.rmin && grow < g.rmax && k0 + c4 * 4 < g.K) v = *(const float4*)(g.A + grow * g.lda + k0 + c4 * 4);
             *(float4*)(buf + row * KT + c4 * 4) = v;
         }
-        for (int f = tid; f < PS * (NT / 4); f += 256) {
+        for (int f = tid; f < PS * (NT / 4); f += 64 * NW) {
             const int row = f / (NT / 4), n4 = f - row * (NT / 4);
             const long grow = ps0 + row;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -783,31 +786,31 @@ __global__ __launch_bounds__(256, MINB) void tap_wgrad_kernel_v6(WgradArgs g) {
         {
             // fully unrolled run (compile-time trip count): pixel offsets become immediates and the two operand sets are
             // plain renamed registers -- the rolled form of v1 carries them through v_mov copies behind an lgkmcnt(0)
-            float a0[NTAPS][TKW], b0[TNW], a1[NTAPS][TKW], b1[TNW];
+            float a0[NTL][TKW], b0[TNW], a1[NTL][TKW], b1[TNW];
             constexpr int RS = 2 * WAVES_P;             // pixel stride between this wave's pairs
             constexpr int NP = PS / RS;                 // pairs per wave and run
             static_assert(NP % 2 == 0, "unroll by two");
             const float* Zw = Zs + (2 * wp + lh) * NT + wn * TNW * 32 + li;
             const float* Aw = As + (2 * wp + lh + halo) * KT + li;
-            int toff[NTAPS];
+            int toff[NTL];
 #pragma unroll
-            for (int t = 0; t < NTAPS; ++t) toff[t] = ((NTAPS == 9) ? ((t / 3) - 1) * g.WP + (t % 3) - 1 : 0) * KT;
-            auto fetch = [&](float (&an)[NTAPS][TKW], float (&bn)[TNW], int r) {
+            for (int t = T0; t < T1; ++t) toff[t - T0] = ((NTAPS == 9) ? ((t / 3) - 1) * g.WP + (t % 3) - 1 : 0) * KT;
+            auto fetch = [&](float (&an)[NTL][TKW], float (&bn)[TNW], int r) {
 #pragma unroll
                 for (int b = 0; b < TNW; ++b) bn[b] = Zw[r * NT + b * 32];
 #pragma unroll
-                for (int t = 0; t < NTAPS; ++t)
+                for (int t = T0; t < T1; ++t)
 #pragma unroll
-                    for (int a = 0; a < TKW; ++a) an[t][a] = Aw[toff[t] + r * KT + a * 32];
+                    for (int a = 0; a < TKW; ++a) an[t - T0][a] = Aw[toff[t - T0] + r * KT + a * 32];
             };
-            auto fma_all = [&](const float (&ac)[NTAPS][TKW], const float (&bc)[TNW]) {
+            auto fma_all = [&](const float (&ac)[NTL][TKW], const float (&bc)[TNW]) {
 #pragma unroll
-                for (int t = 0; t < NTAPS; ++t)
+                for (int t = T0; t < T1; ++t)
 #pragma unroll
                     for (int a = 0; a < TKW; ++a)
 #pragma unroll
                         for (int b = 0; b < TNW; ++b)
-                            acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][a], bc[b], acc[t][a][b], 0, 0, 0);
+                            acc[t - T0][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t - T0][a], bc[b], acc[t - T0][a][b], 0, 0, 0);
             };
             fetch(a0, b0, 0);
 #pragma unroll
@@ -822,10 +825,11 @@ __global__ __launch_bounds__(256, MINB) void tap_wgrad_kernel_v6(WgradArgs g) {
         cur ^= 1;
     }
 
+    static_assert(NW == 4 || WAVES_P == 1, "the tap-split form has no cross-wave pixel reduction");
     if (WAVES_P > 1) {
         float* red = smem;   // [WAVES_P-1][WAVES_N][TKW*TNW*16][64]
 #pragma unroll
-        for (int t = 0; t < NTAPS; ++t) {
+        for (int t = T0; t < T1; ++t) {
             __syncthreads();
             if (wp > 0) {
                 float* dst = red + (((wp - 1) * WAVES_N + wn) * (TKW * TNW * 16)) * 64 + lane;
@@ -835,7 +839,7 @@ __global__ __launch_bounds__(256, MINB) void tap_wgrad_kernel_v6(WgradArgs g) {
                     for (int b = 0; b < TNW; ++b)
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
-                            dst[((a * TNW + b) * 16 + r) * 64] = acc[t][a][b][r];
+                            dst[((a * TNW + b) * 16 + r) * 64] = acc[t - T0][a][b][r];
             }
             __syncthreads();
             if (wp == 0) {
@@ -847,7 +851,7 @@ __global__ __launch_bounds__(256, MINB) void tap_wgrad_kernel_v6(WgradArgs g) {
                         for (int b = 0; b < TNW; ++b)
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
-                                acc[t][a][b][r] += sp[((a * TNW + b) * 16 + r) * 64];
+                                acc[t - T0][a][b][r] += sp[((a * TNW + b) * 16 + r) * 64];
                 }
             }
         }
@@ -856,7 +860,7 @@ __global__ __launch_bounds__(256, MINB) void tap_wgrad_kernel_v6(WgradArgs g) {
 
     float* out = g.out + (long)chunk * g.slab;
 #pragma unroll
-    for (int t = 0; t < NTAPS; ++t)
+    for (int t = T0; t < T1; ++t)
 #pragma unroll
         for (int a = 0; a < TKW; ++a)
 #pragma unroll
@@ -866,9 +870,25 @@ __global__ __launch_bounds__(256, MINB) void tap_wgrad_kernel_v6(WgradArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int k = k0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (k < g.K) out[((long)t * g.K + k) * g.N + n] = acc[t][a][b][r];
+                    if (k < g.K) out[((long)t * g.K + k) * g.N + n] = acc[t - T0][a][b][r];
                 }
             }
+}
+
+template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS, int MINB>
+__global__ __launch_bounds__(256, MINB) void tap_wgrad_kernel_v6(WgradArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    v6_body<NTAPS, TKW, WAVES_N, TNW, PS, 0, NTAPS, 4>(g, smem);
+}
+
+// Eight waves: waves w and w + 4 share a SIMD and a 32 x 32 weight block and split its nine taps 5 + 4 (80 / 64 accumulator
+// registers), so that a wave held at a DMA piece or an LDS read leaves the matrix pipe to its partner -- with one wave per
+// SIMD the DMA of the next run costs 5-19 % of the kernel and cannot be moved out of the way.
+template <int TKW, int WAVES_N, int TNW, int PS>
+__global__ __launch_bounds__(512, 1) void tap_wgrad_kernel_v6s(WgradArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((threadIdx.x >> 8) == 0) v6_body<9, TKW, WAVES_N, TNW, PS, 0, 5, 8>(g, smem);
+    else v6_body<9, TKW, WAVES_N, TNW, PS, 5, 9, 8>(g, smem);
 }
 
 __global__ void sum_chunks_kernel(const float* __restrict__ part, float* __restrict__ out,
@@ -1052,6 +1072,19 @@ int launch_wgrad6(WgradArgs a, const asr_gemm_desc* d, float* dW, float* partial
         hipLaunchKernelGGL(kern, grid, dim3(256), q.lds, st, a);                                                         \
         ASR_NOTE_KERNEL("tap_wgrad_kernel_v6<%d, %d, %d, %d, %d, %d>", NTAPS, TKW, WAVES_N, TNW, PSV, MB);                \
     } while (0)
+    static int tsplit = -1;
+    if (tsplit < 0) { const char* e = getenv("ASR_WG_SPLIT"); tsplit = e ? atoi(e) : 1; }
+    if constexpr (NTAPS == 9 && WAVES_N == 4) {
+        if (tsplit && q.minb == 1 && q.ps == 64) {
+            auto kern = tap_wgrad_kernel_v6s<TKW, WAVES_N, TNW, 64>;
+            static bool attr = false;
+            if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+            hipLaunchKernelGGL(kern, grid, dim3(512), q.lds, st, a);
+            ASR_NOTE_KERNEL("tap_wgrad_kernel_v6s<%d, %d, %d, %d>", TKW, WAVES_N, TNW, 64);
+            ASR_CHECK_LAUNCH("tap_wgrad_v6s");
+            return ASR_OK;
+        }
+    }
     if (q.ps == 128) { if (q.minb == 2) ASR_V6_LAUNCH(128, 2); else ASR_V6_LAUNCH(128, 1); }
     else if (q.ps == 32 && q.minb == 2) ASR_V6_LAUNCH(32, 2);
     else if (q.ps == 32) ASR_V6_LAUNCH(32, 1);
