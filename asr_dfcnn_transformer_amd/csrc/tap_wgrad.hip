@@ -825,13 +825,15 @@ __device__ __forceinline__ void v6_body(const WgradArgs& g, float* smem) {
         cur ^= 1;
     }
 
-    static_assert(NW == 4 || WAVES_P == 1, "the tap-split form has no cross-wave pixel reduction");
     if (WAVES_P > 1) {
+        // every wave takes every barrier; a wave of the tap-split form only moves data for its own taps (tq)
         float* red = smem;   // [WAVES_P-1][WAVES_N][TKW*TNW*16][64]
 #pragma unroll
-        for (int t = T0; t < T1; ++t) {
+        for (int tq = 0; tq < NTAPS; ++tq) {
+            const bool mine = tq >= T0 && tq < T1;
+            const int t = mine ? tq : T0;
             __syncthreads();
-            if (wp > 0) {
+            if (mine && wp > 0) {
                 float* dst = red + (((wp - 1) * WAVES_N + wn) * (TKW * TNW * 16)) * 64 + lane;
 #pragma unroll
                 for (int a = 0; a < TKW; ++a)
@@ -842,7 +844,7 @@ __device__ __forceinline__ void v6_body(const WgradArgs& g, float* smem) {
                             dst[((a * TNW + b) * 16 + r) * 64] = acc[t - T0][a][b][r];
             }
             __syncthreads();
-            if (wp == 0) {
+            if (mine && wp == 0) {
                 for (int src = 1; src < WAVES_P; ++src) {
                     const float* sp = red + (((src - 1) * WAVES_N + wn) * (TKW * TNW * 16)) * 64 + lane;
 #pragma unroll
@@ -1074,16 +1076,21 @@ int launch_wgrad6(WgradArgs a, const asr_gemm_desc* d, float* dW, float* partial
     } while (0)
     static int tsplit = -1;
     if (tsplit < 0) { const char* e = getenv("ASR_WG_SPLIT"); tsplit = e ? atoi(e) : 1; }
-    if constexpr (NTAPS == 9 && WAVES_N == 4) {
-        if (tsplit && q.minb == 1 && q.ps == 64) {
-            auto kern = tap_wgrad_kernel_v6s<TKW, WAVES_N, TNW, 64>;
-            static bool attr = false;
-            if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-            hipLaunchKernelGGL(kern, grid, dim3(512), q.lds, st, a);
-            ASR_NOTE_KERNEL("tap_wgrad_kernel_v6s<%d, %d, %d, %d>", TKW, WAVES_N, TNW, 64);
-            ASR_CHECK_LAUNCH("tap_wgrad_v6s");
-            return ASR_OK;
-        }
+    if constexpr (NTAPS == 9) {
+#define ASR_V6S_LAUNCH(PSV)                                                                                               \
+        do {                                                                                                             \
+            auto kern = tap_wgrad_kernel_v6s<TKW, WAVES_N, TNW, PSV>;                                                     \
+            static bool attr = false;                                                                                    \
+            if (!attr) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+            hipLaunchKernelGGL(kern, grid, dim3(512), q.lds, st, a);                                                     \
+            ASR_NOTE_KERNEL("tap_wgrad_kernel_v6s<%d, %d, %d, %d>", TKW, WAVES_N, TNW, PSV);                              \
+            ASR_CHECK_LAUNCH("tap_wgrad_v6s");                                                                           \
+            return ASR_OK;                                                                                               \
+        } while (0)
+        // one workgroup per CU (minb 1): eight waves instead of four, two per SIMD
+        if (tsplit && q.minb == 1 && q.ps == 64) ASR_V6S_LAUNCH(64);
+        if (tsplit && q.minb == 1 && q.ps == 128) ASR_V6S_LAUNCH(128);
+#undef ASR_V6S_LAUNCH
     }
     if (q.ps == 128) { if (q.minb == 2) ASR_V6_LAUNCH(128, 2); else ASR_V6_LAUNCH(128, 1); }
     else if (q.ps == 32 && q.minb == 2) ASR_V6_LAUNCH(32, 2);
