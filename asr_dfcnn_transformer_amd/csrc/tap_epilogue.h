@@ -30,6 +30,7 @@ struct TapGemmArgs {
     // partial sums to split_out + y * M * N; a second pass adds them and applies the epilogue
     int ksplit = 1;
     float* split_out = nullptr;
+    int nt_store = 0;    // non-temporal stores in the plain epilogue (the Winograd launches set it)
 };
 
 // Row offset of tap `tap` in the flattened padded plane, and the tap of the weight tensor it multiplies.
@@ -204,12 +205,17 @@ __device__ __forceinline__ void tap_epilogue(const TapGemmArgs& g, const floatx1
                 if (ra < 0 || !ncol) continue;
                 if (g.relu == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
                 else if (g.relu == 2) { v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w); }
-                if (g.out_a) *(float4*)(g.out_a + (long)ra * g.ldo_a + n) = v;
+                typedef float nt_f4 __attribute__((ext_vector_type(4)));
+                if (g.out_a) {
+                    if (g.nt_store) __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, (nt_f4*)(g.out_a + (long)ra * g.ldo_a + n));
+                    else *(float4*)(g.out_a + (long)ra * g.ldo_a + n) = v;
+                }
                 if (g.out_y) {
                     float4 y = make_float4(sc.x * v.x + sh.x, sc.y * v.y + sh.y, sc.z * v.z + sh.z, sc.w * v.w + sh.w);
                     float* o = g.out_y + (long)rowy[m] * g.ldo_y + n;
                     if (g.accumulate) { const float4 p = *(const float4*)o; y.x += p.x; y.y += p.y; y.z += p.z; y.w += p.w; }
-                    *(float4*)o = y;
+                    if (g.nt_store) __builtin_nontemporal_store(nt_f4{y.x, y.y, y.z, y.w}, (nt_f4*)o);
+                    else *(float4*)o = y;
                 }
             }
         }

@@ -711,6 +711,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
     a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
     a.ablate = 0;
+    { static int nts = -1; if (nts < 0) { const char* e = getenv("ASR_WINO_NT"); nts = e ? atoi(e) : 1; } a.nt_store = nts; }     // streaming stores: -2..3 % per layer (the planes do not fit L2 anyway)
     a.gate_mode = 0; a.gate_H = a.gate_W = 0; a.gate_a = nullptr; a.gate_dz = nullptr; a.gate_part = nullptr; a.gate_rows = nullptr;
     if (gs) { a.gate_mode = gs->mode; a.gate_H = gs->H; a.gate_W = gs->W; a.gate_a = gs->a; a.gate_dz = gs->dz; a.gate_part = gs->part; a.gate_rows = gs->rows; }
     w.Ut = Ut;
