@@ -8,6 +8,8 @@ namespace {
 
 constexpr size_t kEpilogueLds = 4 * 32 * 33 * sizeof(float);   // per-wave transpose scratch of the epilogue
 
+typedef float ep_nt_f4 __attribute__((ext_vector_type(4)));
+
 struct TapGemmArgs {
     const float* A; const float* W; const float* bias; const float* scale; const float* shift;
     float* out_a; float* out_y;
@@ -124,7 +126,8 @@ __device__ __forceinline__ void tap_epilogue_gated(const TapGemmArgs& g, const f
                         d[e] = av[e] > 0.f ? v[e] * scv[e] : 0.f;
                         s_bias[e] += d[e];
                     }
-                    *(float4*)(g.gate_dz + (long)ra * C + n) = make_float4(d[0], d[1], d[2], d[3]);
+                    if (g.nt_store) __builtin_nontemporal_store(ep_nt_f4{d[0], d[1], d[2], d[3]}, (ep_nt_f4*)(g.gate_dz + (long)ra * C + n));
+                    else *(float4*)(g.gate_dz + (long)ra * C + n) = make_float4(d[0], d[1], d[2], d[3]);
                 } else {
                     const long pf = rowf[m];
                     const long off[4] = {pf, pf + 1, pf + WPf, pf + WPf + 1};
@@ -148,7 +151,8 @@ __device__ __forceinline__ void tap_epilogue_gated(const TapGemmArgs& g, const f
                             d[e] = av[k][e] > 0.f ? gk * scv[e] : 0.f;
                             s_bias[e] += d[e];
                         }
-                        *(float4*)(g.gate_dz + off[k] * C + n) = make_float4(d[0], d[1], d[2], d[3]);
+                        if (g.nt_store) __builtin_nontemporal_store(ep_nt_f4{d[0], d[1], d[2], d[3]}, (ep_nt_f4*)(g.gate_dz + off[k] * C + n));
+                        else *(float4*)(g.gate_dz + off[k] * C + n) = make_float4(d[0], d[1], d[2], d[3]);
                     }
                 }
             }

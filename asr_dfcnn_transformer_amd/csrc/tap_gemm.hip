@@ -1161,6 +1161,7 @@ static int tap_gemm_pw_impl(const asr_gemm_desc* d, const float* A, const float*
     a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
     a.ntm = a.ntn = 0; a.ablate = 0;
     set_gate(a, gs);
+    { static int nts = -1; if (nts < 0) { const char* e = getenv("ASR_PW_NT"); nts = e ? atoi(e) : 0; } a.nt_store = nts; }
     hipStream_t st = (hipStream_t)stream;
     const int dir = d->wmode ? 1 : 0;       // labels the launch only (distinct kernel symbols per direction)
     // tile choice (tools/bench_pw.py, MI355X): 128x64 workgroup tiles with a 16-deep chunk and a 3-unit ring win on every
