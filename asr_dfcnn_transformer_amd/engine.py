@@ -478,13 +478,24 @@ class DFCNNEngine:
         self._xpad[n:].zero_()
         return self._xpad
 
-    def _winograd_weights(self):
-        for dst, buf in self.wt_f.items():
+    def _forward_weights(self):
+        """Per-step weight views the FORWARD convs read: Winograd-transformed where the layer runs on that kernel, else
+        MFMA fragment order (a layer never needs both)."""
+        for dst, buf in self.wf_f.items():
             cin, cout = self._cell_dims[dst]
-            ops.winograd_weights(self.p(dst, 'w'), cin, cout, cout, 0, buf)
-        for dst, buf in self.wt_b.items():
+            if dst in self.wt_f:
+                ops.winograd_weights(self.p(dst, 'w'), cin, cout, cout, 0, self.wt_f[dst])
+            else:
+                ops.arrange_weights(self.p(dst, 'w'), 9, cin, cout, cout, 0, buf)
+
+    def _backward_weights(self):
+        """The same for the data-gradient views (mirrored taps); not needed before the backward pass."""
+        for dst, buf in self.wf_b.items():
             cin, cout = self._cell_dims[dst]
-            ops.winograd_weights(self.p(dst, 'w'), cout, cin, cout, 1, buf)
+            if dst in self.wt_b:
+                ops.winograd_weights(self.p(dst, 'w'), cout, cin, cout, 1, self.wt_b[dst])
+            else:
+                ops.arrange_weights(self.p(dst, 'w'), 9, cout, cin, cout, 1, buf)
 
     def forward(self, x):
         """x: [B, T, F] float32 on the device (the wav_input placeholder without its last axis); fewer rows are padded
@@ -500,25 +511,24 @@ class DFCNNEngine:
             ops.split_weights(self.p(dst, 'w'), 9, cout, cin, cout, 1, self.ws_b[dst])
         # the fragment-order weight copies (two small launches per 3x3 layer, ~20 in all) are not needed before the second
         # cell: they run on the side stream beside the VALU-bound first cell instead of in front of it
+        # The forward views first: the second cell waits for them only (they used to sit behind the backward views: 36 us of
+        # an idle main stream per step); the backward pass waits for the rest (self._wb_ready).
         wf_ready = None
+        self._wb_ready = None
         if self.wf_f and self.side is not None:
             params_final = torch.cuda.Event()
             params_final.record()                         # Adam of the previous step / load_params are on the main stream
             self.side.wait_event(params_final)
             with torch.cuda.stream(self.side):
-                for dst, buf in self.wf_f.items():
-                    cin, cout = self._cell_dims[dst]
-                    ops.arrange_weights(self.p(dst, 'w'), 9, cin, cout, cout, 0, buf)
-                    ops.arrange_weights(self.p(dst, 'w'), 9, cout, cin, cout, 1, self.wf_b[dst])
-                self._winograd_weights()
+                self._forward_weights()
                 wf_ready = torch.cuda.Event()
                 wf_ready.record()
+                self._backward_weights()
+                self._wb_ready = torch.cuda.Event()
+                self._wb_ready.record()
         else:
-            for dst, buf in self.wf_f.items():
-                cin, cout = self._cell_dims[dst]
-                ops.arrange_weights(self.p(dst, 'w'), 9, cin, cout, cout, 0, buf)
-                ops.arrange_weights(self.p(dst, 'w'), 9, cout, cin, cout, 1, self.wf_b[dst])
-            self._winograd_weights()
+            self._forward_weights()
+            self._backward_weights()
         for op in self.g:
             if op[0] == 'cell':
                 _, src, dst, cin, cout, k, pool = op
@@ -640,6 +650,9 @@ class DFCNNEngine:
         that activation (the language half of the joint graph reads h7), added before the layer's own backward."""
         B, T8, V = self.B, self.T8, self.V
         last = self.g[-1][2]
+        if getattr(self, '_wb_ready', None) is not None:          # the data-gradient weight views (side stream, forward())
+            torch.cuda.current_stream().wait_event(self._wb_ready)
+            self._wb_ready = None
         ops.softmax_log_bwd(self.logits, self.ctc_grad, B, T8, V, K_EPSILON, 1.0 / self.loss_denom, self.dflat[last])
         ready = set()          # gradient planes that already hold a value this step
 

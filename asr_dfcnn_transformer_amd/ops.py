@@ -544,7 +544,7 @@ def arrange_weights(W, ntaps, K, N, ldw, wmode=0, out=None):
 
 
 def winograd_weights(W, K, N, ldw, wmode=0, out=None):
-    """U = G g G^T of a 3x3 layer, [16][K][N] (asr_winograd_weights); EXPERIMENTAL."""
+    """U = G g G^T of a 3x3 layer, [16][K][N] (asr_winograd_weights)."""
     lib = _lib.load()
     if out is None:
         out = torch.empty(lib.asr_winograd_weights_bytes(K, N) // 4, dtype=torch.float32, device=W.device)
