@@ -32,18 +32,11 @@ SIGNATURES = {
     'asr_fbank': (_I, [_P, _P, _I, _I, _I, _I, _I, _D, _I, _P, _P, _P, _I, _P, _P, _I, _P, _I, _P, _P]),
     'asr_lfr': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     'asr_tap_gemm': (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
-    'asr_split_weights_bytes': (_Z, [_I, _I, _I]),
-    'asr_split_weights': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
-    'asr_tap_gemm_bx6': (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
-    'asr_tap_wgrad_bx6': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _P, _P, _P]),
     'asr_arrange_weights_bytes': (_Z, [_I, _I, _I]),
     'asr_arrange_weights': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'asr_tap_gemm_pw': (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_gemm_gated_workspace': (_Z, [C.POINTER(GemmDesc)]),
     'asr_tap_gemm_gated': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
-    'asr_split_rows_bytes': (_Z, [_L, _I]),
-    'asr_split_rows': (_I, [_P, _L, _I, _I, _P, _P]),
-    'asr_gemm_bx6s': (_I, [_P, _P, _L, _I, _I, _P, _I, _I, _P, _I, _P, _P]),
     'asr_tap_wgrad_workspace': (_Z, [C.POINTER(GemmDesc)]),
     'asr_tap_wgrad': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _P, _P, _P]),
     'asr_cell1_fwd': (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),

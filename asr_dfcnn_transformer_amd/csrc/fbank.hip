@@ -404,10 +404,8 @@ extern "C" int asr_fbank(const float* signal, const int32_t* nsamples, int B, in
         (void)hipFuncSetAttribute((const void*)fbank_logmel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    static int v2 = -1;
-    if (v2 < 0) { const char* e = getenv("ASR_FBANK_V2"); v2 = e ? atoi(e) : 1; }
     const size_t lds2 = (size_t)nfilt * fb_width * sizeof(double);
-    if (v2 && nfft == 512 && frame_len <= 512 && nfilt <= 256 && lds2 <= 96 * 1024) {
+    if (nfft == 512 && frame_len <= 512 && nfilt <= 256 && lds2 <= 96 * 1024) {
         constexpr int FPW = 5;
         static bool attr2 = false;
         if (!attr2) {
@@ -423,10 +421,10 @@ extern "C" int asr_fbank(const float* signal, const int32_t* nsamples, int B, in
                            logfb, max_frames, frames);
     }
     const int tmax = max_frames < t_pad ? max_frames : t_pad;          // rows a column can have
-    if (v2 && tmax <= 32 * 32) {
+    if (tmax <= 32 * 32) {
         hipLaunchKernelGGL(fbank_scale_v2_kernel<32>, dim3(asr_cdiv(nfilt, 8), B), dim3(256), 0, st, (const double*)logfb,
                            (const int32_t*)frames, max_frames, nfilt, out, t_pad);
-    } else if (v2 && tmax <= 32 * 64) {
+    } else if (tmax <= 32 * 64) {
         hipLaunchKernelGGL(fbank_scale_v2_kernel<64>, dim3(asr_cdiv(nfilt, 8), B), dim3(256), 0, st, (const double*)logfb,
                            (const int32_t*)frames, max_frames, nfilt, out, t_pad);
     } else {

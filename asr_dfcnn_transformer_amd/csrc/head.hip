@@ -185,7 +185,10 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
     // alpha_t * exp(sca[t]); between two rescalings a state loses at most RS emission factors.
     constexpr int RS = 16, NPL = 4, PD = 8;             // rescale period, states per lane, prefetch distance (frames)
     const int wv = tid >> 6, ln = tid & 63;
-    if (wv < 2 && S <= 64 * NPL) {
+    const bool fast = S <= 64 * NPL;                    // the register-resident form holds 256 states; longer label rows go to the log-domain form
+    int* badp = (int*)(llp + 1);
+    if (tid == 0) *badp = fast ? 0 : 1;
+    if (fast && wv < 2) {
         const bool fwd = wv == 0;
         double* scl = fwd ? sca : scb;
         double* xw = fwd ? aw : bw;
@@ -265,43 +268,23 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
         }
     }
     __syncthreads();
-    if (tid == 0) {       // abuf0 holds the scaled alpha at the last frame
+    if (fast && tid == 0) {       // abuf0 holds the scaled alpha at the last frame
         const double* prev = abuf0 + 2;
         const double tail = (S > 1) ? prev[S - 1] + prev[S - 2] : prev[0];
         const double ll = log(tail) + sca[Tb - 1];
         llp[0] = ll;
         loss[b] = (float)(-ll);
+        // A state more than ~708 nats below the frame's dominant state flushes to zero in float64 (the vector is rescaled by
+        // its SUM): with the softmax saturated at the eps floor (16 nats per label emission) and >= ~45 labels the final
+        // states do.  Then the log-domain form below redoes this utterance (tf.nn.ctc_loss returns a finite loss there).
+        if (!(tail > 0.0) || !(fabs(ll) < 1e300)) *badp = 1;
     }
     __threadfence_block();
     __syncthreads();
-    const double ll = llp[0];
-    // ---- phase 2: occupancies alpha_t(s) beta_t(s) / (p_t(s) P) and the sparse part of the gradient, time steps in parallel
-    // over the waves; the scales of a frame enter as ONE factor exp(sca[t] + scb[t] - ll)
     const int wave = tid >> 6, lane = tid & 63;
     double* oc = occ + 16 + wave * (SMAX + 1);
-    constexpr int QL = 4;                               // states per lane: S <= 256
-    double ra[QL], rb[QL], rp[QL];
-    auto fetch3 = [&](int t) {
-#pragma unroll
-        for (int j = 0; j < QL; ++j) {
-            const int q = lane + 64 * j;
-            const bool ok = t < Tb && q < S;
-            ra[j] = ok ? aw[(long)t * SMAX + q] : 0.0;
-            rb[j] = ok ? bw[(long)t * SMAX + q] : 0.0;
-            rp[j] = ok ? pw[(long)t * SMAX + q] : 1.0;
-        }
-    };
-    fetch3(wave);
-    for (int t = wave; t < Tb; t += 8) {
-        const double ft = exp(sca[t] + scb[t] - ll);
-#pragma unroll
-        for (int j = 0; j < QL; ++j) {
-            const int q = lane + 64 * j;
-            const double ab = ra[j] * rb[j];
-            if (q < S) oc[q] = (ab == 0.0) ? 0.0 : ab / rp[j] * ft;
-        }
-        fetch3(t + 8);                                  // the next frame's values travel while this frame's sums are formed
-        // (the wave's LDS writes are ordered before its own later reads)
+    // subtracts the per-label sums of one frame's occupancies oc[0..S) from the dense softmax term of its gradient row
+    auto scatter_frame = [&](int t) {
         float* gr = grad + ((long)t * B + b) * V;
         double bsum = 0.0;
         for (int q = 2 * lane; q < S; q += 128) bsum += oc[q];
@@ -313,6 +296,107 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
                 for (int j = nxt[q]; j >= 0; j = nxt[j]) sum += oc[j];
                 gr[ext[q]] -= (float)sum;
             }
+        }
+    };
+    if (*badp == 0) {
+        const double ll = llp[0];
+        // ---- phase 2: occupancies alpha_t(s) beta_t(s) / (p_t(s) P) and the sparse part of the gradient, time steps in
+        // parallel over the waves; the scales of a frame enter as ONE factor exp(sca[t] + scb[t] - ll).  The occupancies of
+        // a frame are a probability distribution over its states: a sum off 1 means that states the gradient needs were
+        // flushed to zero in one of the two recursions -> the utterance is redone in the log domain.
+        constexpr int QL = 4;                               // states per lane: S <= 256
+        double ra[QL], rb[QL], rp[QL];
+        auto fetch3 = [&](int t) {
+#pragma unroll
+            for (int j = 0; j < QL; ++j) {
+                const int q = lane + 64 * j;
+                const bool ok = t < Tb && q < S;
+                ra[j] = ok ? aw[(long)t * SMAX + q] : 0.0;
+                rb[j] = ok ? bw[(long)t * SMAX + q] : 0.0;
+                rp[j] = ok ? pw[(long)t * SMAX + q] : 1.0;
+            }
+        };
+        bool off = false;
+        fetch3(wave);
+        for (int t = wave; t < Tb; t += 8) {
+            const double ft = exp(sca[t] + scb[t] - ll);
+            double tot = 0.0;
+#pragma unroll
+            for (int j = 0; j < QL; ++j) {
+                const int q = lane + 64 * j;
+                const double ab = ra[j] * rb[j];
+                const double o = (ab == 0.0) ? 0.0 : ab / rp[j] * ft;
+                if (q < S) { oc[q] = o; tot += o; }
+            }
+            fetch3(t + 8);                                  // the next frame's values travel while this frame's sums are formed
+            tot = asr_wave_sum_d(tot);
+            off = off || !(fabs(tot - 1.0) <= 1e-6);
+            // (the wave's LDS writes are ordered before its own later reads)
+            scatter_frame(t);
+        }
+        if (off && lane == 0) *badp = 1;
+    }
+    __syncthreads();
+    if (*badp == 0) return;
+
+    // ---- log-domain form (the oracle's recursion; Appendix A7): alpha by threads 0-255, beta by threads 256-511, a state per
+    // thread (and stride), one barrier per frame; the float64 workspaces now hold log alpha / log beta.  Slow (a barrier per
+    // frame) and rare: only utterances whose linear-domain lattice lost states it needs.
+    {
+        const double NEG = -INFINITY;
+        auto lse3 = [&](double a, double b2, double c) {
+            const double m = fmax(a, fmax(b2, c));
+            if (m == NEG) return NEG;
+            return m + log(exp(a - m) + exp(b2 - m) + exp(c - m));
+        };
+        auto lpr = [&](int t, int q) { return (double)lg[t * S + q] - lse_t[t]; };
+        const int h = tid >> 8, s1 = tid & 255;
+        for (int k = 0; k < Tb; ++k) {
+            const int t = h == 0 ? k : Tb - 1 - k;
+            double* xw = h == 0 ? aw : bw;
+            for (int q = s1; q < S; q += 256) {
+                double val;
+                if (k == 0) {
+                    const bool on = h == 0 ? (q < 2) : (q >= S - 2);
+                    val = on ? lpr(t, q) : NEG;
+                } else {
+                    const double* pv = xw + (long)(h == 0 ? t - 1 : t + 1) * SMAX;
+                    const int e = ext[q];
+                    if (h == 0) {
+                        const bool skp = (q >= 2) && (e != blank) && (e != ext[q - 2]);
+                        val = lpr(t, q) + lse3(pv[q], q >= 1 ? pv[q - 1] : NEG, skp ? pv[q - 2] : NEG);
+                    } else {
+                        const bool skp = (q + 2 < S) && (e != blank) && (e != ext[q + 2]);
+                        val = lpr(t, q) + lse3(pv[q], q + 1 < S ? pv[q + 1] : NEG, skp ? pv[q + 2] : NEG);
+                    }
+                }
+                xw[(long)t * SMAX + q] = val;
+            }
+            __threadfence_block();
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const double* la = aw + (long)(Tb - 1) * SMAX;
+            const double ll = (S > 1) ? lse3(la[S - 1], la[S - 2], NEG) : la[0];
+            llp[0] = ll;
+            loss[b] = (float)(-ll);
+        }
+        __threadfence_block();
+        __syncthreads();
+        const double ll = llp[0];
+        for (int t = wave; t < Tb; t += 8) {
+            // the dense softmax term of the entries the linear-domain pass may have touched, exactly as ctc_rows_kernel wrote them
+            float* gr = grad + ((long)t * B + b) * V;
+            const float* x = logits + ((long)t * B + b) * V;
+            const float lf = (float)lse_t[t];
+            if (lane == 0) gr[blank] = expf(x[blank] - lf);
+            for (int q = 2 * lane + 1; q < S; q += 128)
+                if (lead[q]) gr[ext[q]] = expf(x[ext[q]] - lf);
+            for (int q = lane; q < S; q += 64) {
+                const double e = aw[(long)t * SMAX + q] + bw[(long)t * SMAX + q] - lpr(t, q) - ll;
+                oc[q] = (e == e && e > -745.0) ? exp(e) : 0.0;
+            }
+            scatter_frame(t);
         }
     }
 }

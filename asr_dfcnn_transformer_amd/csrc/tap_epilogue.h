@@ -19,7 +19,6 @@ struct TapGemmArgs {
     long rmin, rmax;
     int relu, accumulate, y_unpadded;
     int ntm, ntn;
-    int ablate;          // timing experiments only (ASR_TG_ABLATE): 1 skip A restaging, 2 skip W restaging, 4 skip epilogue
     // fused backward prologue of the cell whose gradient this data-gradient completes (asr_tap_gemm_gated): instead of
     // writing dL/dy of that cell, the epilogue routes it through the cell's pool / BN / ReLU backward and writes dZ
     int gate_mode;       // 0 off, 1 no pool, 2 average pool 2x2, 3 max pool 2x2

@@ -22,198 +22,6 @@
 
 namespace {
 
-constexpr int KC = 32;       // contraction chunk staged per step
-constexpr int AP = KC + 4;   // LDS pitch of an A row (floats): conflict-free ds_read_b128
-
-template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE>
-__global__ __launch_bounds__(256) void tap_gemm_kernel(TapGemmArgs g) {
-    constexpr int TM = MT / WM / 32, TN = NT / WN / 32;
-    constexpr int WREG = KC * NT / 4 / 256;            // float4 per thread per weight tile
-    // float4 per thread of the A-tile register prefetch: the whole tile for the shapes of the
-    // DFCNN planes (W+2 <= 52 at MT = 128, <= 102 at MT = 256); wider planes stage the rest directly
-    constexpr int AREG = (NTAPS == 1) ? MT * 8 / 256 : (MT <= 128 ? 8 : 15);
-    constexpr int WSZ = ((WMODE == 0) ? KC * NT : NT * (KC + 1) + 3) / 4 * 4;
-    static_assert(WREG >= 1 && TM >= 1 && TN >= 1, "tile");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int halo = g.halo;
-    const int arows = MT + 2 * halo;
-    const int asz = arows * AP;
-    int* rowa = (int*)smem;                             // [MT] output row of out_a (or -1), [MT] of out_y
-    int* rowy = rowa + MT;
-    float* tile_lds = smem + 2 * MT;                    // staging tiles; reused as the epilogue's transpose scratch
-    float* As = tile_lds;                               // NTAPS == 1: two buffers
-    float* Ws = As + ((NTAPS == 1) ? 2 * asz : asz);    // two buffers of WSZ floats
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = tid >> 6, wm = wave / WN, wn = wave % WN;
-
-    const int swz = asr_xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile_m = swz / g.ntn, tile_n = swz - tile_m * g.ntn;
-    const long p0 = (long)tile_m * MT;
-    const int n0 = tile_n * NT;
-    const int K = g.K, N = g.N;
-
-    if (tid < MT) {
-        const long p = p0 + tid;
-        int ra = -1, ry = -1;
-        if (p < g.M) {
-            if (g.H == 0) {
-                ra = (int)p; ry = (int)p;
-            } else {
-                const int b = (int)(p / g.HPWP);
-                const int r = (int)(p - (long)b * g.HPWP);
-                const int hh = r / g.WP, ww = r - hh * g.WP;
-                if (hh >= 1 && hh <= g.H && ww >= 1 && ww <= g.Wd) {
-                    ra = (int)p;
-                    ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : (int)p;
-                }
-            }
-        }
-        rowa[tid] = ra; rowy[tid] = ry;
-    }
-
-    floatx16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int nkc = (K + KC - 1) / KC;
-    const int nsteps = nkc * NTAPS;
-    const int atotal = arows * 8;                       // float4 of one A chunk tile
-    float4 wreg[WREG];
-    float4 areg[AREG];
-
-    auto load_w = [&](int step) {
-        const int kc = step / NTAPS, tap = step - kc * NTAPS;
-#pragma unroll
-        for (int i = 0; i < WREG; ++i) {
-            const int f = tid + i * 256;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (WMODE == 0) {
-                const int k = f / (NT / 4), n4 = f - k * (NT / 4);
-                const int kk = kc * KC + k, nn = n0 + n4 * 4;
-                if (kk < K && nn < N)
-                    v = *(const float4*)(g.W + ((long)tap * K + kk) * g.ldw + nn);
-            } else {
-                const int n = f >> 3, k4 = f & 7;
-                const int kk = kc * KC + k4 * 4, nn = n0 + n;
-                if (kk < K && nn < N)
-                    v = *(const float4*)(g.W + ((long)(NTAPS - 1 - tap) * N + nn) * g.ldw + kk);
-            }
-            wreg[i] = v;
-        }
-    };
-    auto store_w = [&](float* dst) {
-#pragma unroll
-        for (int i = 0; i < WREG; ++i) {
-            const int f = tid + i * 256;
-            if (WMODE == 0) {
-                const int k = f / (NT / 4), n4 = f - k * (NT / 4);
-                *(float4*)(dst + k * NT + n4 * 4) = wreg[i];
-            } else {
-                const int n = f >> 3, k4 = f & 7;
-                float* d = dst + n * (KC + 1) + k4 * 4;
-                d[0] = wreg[i].x; d[1] = wreg[i].y; d[2] = wreg[i].z; d[3] = wreg[i].w;
-            }
-        }
-    };
-    auto load_a_row = [&](int f, int kc) -> float4 {
-        const int row = f >> 3, c4 = f & 7;
-        const long grow = p0 - halo + row;
-        const int kk = kc * KC + c4 * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (grow >= g.rmin && grow < g.rmax && kk < K)
-            v = *(const float4*)(g.A + grow * g.lda + kk);
-        return v;
-    };
-    auto load_a = [&](int kc) {          // issue-early half of the A staging
-#pragma unroll
-        for (int i = 0; i < AREG; ++i) {
-            const int f = tid + i * 256;
-            areg[i] = (f < atotal) ? load_a_row(f, kc) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_a = [&](float* dst, int kc) {   // write-late half (+ direct staging of rows beyond the prefetch)
-#pragma unroll
-        for (int i = 0; i < AREG; ++i) {
-            const int f = tid + i * 256;
-            if (f < atotal) *(float4*)(dst + (f >> 3) * AP + (f & 7) * 4) = areg[i];
-        }
-        for (int f = tid + AREG * 256; f < atotal; f += 256)
-            *(float4*)(dst + (f >> 3) * AP + (f & 7) * 4) = load_a_row(f, kc);
-    };
-
-    // prologue: tile 0 of A and W
-    load_w(0);
-    load_a(0);
-    store_a(As, 0);
-    store_w(Ws);
-    __syncthreads();
-    if (nsteps > 1) load_w(1);
-    if (NTAPS == 1 && nkc > 1) load_a(1);
-
-    int cur = 0;
-    for (int step = 0; step < nsteps; ++step) {
-        const int kc = step / NTAPS, tap = step - kc * NTAPS;
-        const bool more = step + 1 < nsteps;
-        if (NTAPS == 9 && tap == 3 && kc + 1 < nkc) load_a(kc + 1);
-
-        const float* Ac = (NTAPS == 1) ? As + cur * asz : As;
-        const float* Wc = Ws + cur * WSZ;
-        const int toff = halo + ((NTAPS == 9) ? ((tap / 3) - 1) * g.WP + (tap % 3) - 1 : 0);
-        const float* abase = Ac + (wm * (TM * 32) + li + toff) * AP + 4 * lh;
-        const float* wbase = (WMODE == 0) ? (Wc + (4 * lh) * NT + wn * (TN * 32) + li)
-                                          : (Wc + (wn * (TN * 32) + li) * (KC + 1) + 4 * lh);
-#pragma unroll
-        for (int gk = 0; gk < KC / 8; ++gk) {
-            float4 av[TM];
-            float bv[TN][4];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) av[a] = *(const float4*)(abase + a * 32 * AP + gk * 8);
-#pragma unroll
-            for (int b = 0; b < TN; ++b)
-#pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    bv[b][s] = (WMODE == 0) ? wbase[(gk * 8 + s) * NT + b * 32]
-                                            : wbase[b * 32 * (KC + 1) + gk * 8 + s];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-#pragma unroll
-                for (int a = 0; a < TM; ++a) {
-                    const float as = (s == 0) ? av[a].x : (s == 1) ? av[a].y : (s == 2) ? av[a].z : av[a].w;
-#pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bv[b][s], acc[a][b], 0, 0, 0);
-                }
-            }
-        }
-
-        // write-late: the next step's tiles go into the other buffers (last read one barrier ago)
-        if (more) {
-            store_w(Ws + (cur ^ 1) * WSZ);
-            if (step + 2 < nsteps) load_w(step + 2);
-            if (NTAPS == 1) {
-                store_a(As + (cur ^ 1) * asz, kc + 1);
-                if (kc + 2 < nkc) load_a(kc + 2);
-            } else if (tap == NTAPS - 1) {
-                __syncthreads();                 // every wave is done with this chunk's A tile
-                store_a(As, kc + 1);
-            }
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    // epilogue (tap_epilogue): transpose through LDS, float4 stores.  The staging tiles are dead by now.
-    __syncthreads();
-    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane, tile_m * WM + wm);
-}
-
 // ---- v1: single-buffered W, direct A staging, two barriers per tap, 3 blocks per CU
 template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE, int KCV = 32>
 __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
@@ -349,7 +157,7 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
     for (int step = 0; step < nsteps; step = next_step(step)) {
         const int kc = step / NTAPS, tap = step - kc * NTAPS;
         __syncthreads();
-        if (tap == 0 && !((g.ablate & 1) && kc > 0)) {
+        if (tap == 0) {
             if (NTAPS == 1) {
 #pragma unroll
                 for (int i = 0; i < AREG; ++i) {
@@ -375,9 +183,9 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
                 }
             }
         }
-        if (!((g.ablate & 2) && step > 0)) store_w();
+        store_w();
         __syncthreads();
-        if (next_step(step) < nsteps && !(g.ablate & 2)) {
+        if (next_step(step) < nsteps) {
             load_w(next_step(step));
             if (NTAPS == 1) {
 #pragma unroll
@@ -415,7 +223,6 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
 
     // epilogue (tap_epilogue): transpose through LDS, float4 stores.  The staging tiles are dead by now.
     __syncthreads();
-    if ((g.ablate & 4) && acc[0][0][0] != 123.456f) return;
     tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane, tile_m * WM + wm);
 }
 
@@ -618,287 +425,6 @@ __global__ void arrange_weights_kernel(const float* __restrict__ W, int ntaps, i
     }
 }
 
-// ---- bx6: EXPERIMENTAL split-bf16 contraction (tools/mfma_bf16x.hip).  Every fp32 operand is
-// written as hi + mid + lo bf16 pieces (3 x 8 mantissa bits = the 24 bits of fp32) and a product as SIX
-// v_mfma_f32_32x32x16_bf16 products accumulated in fp32 (hh, hm, mh, mm, hl, lh).  Dropped: mid x low, low x mid, low x low;
-// with 8-bit pieces |mid| <= 2^-8 |x| and |low| <= 2^-17 |x|, i.e. <= 2^-24 |x y| per product in the worst case (typically
-// 2^-28) -- one rounding unit of the fp32 chain it replaces (tests/test_bx6_gpu.py::test_split_bf16_worst_case_dropped_terms):
-// fp32-chain accuracy at 2.6x the matrix-pipe rate.  Structure = v4: the A tile is split once when it is staged
-// (3 x KC bf16 per pixel row), the weights arrive pre-split and transposed ([tap][piece][n][Kp], asr_split_weights) so a
-// lane's B fragment is one 16-byte global load per piece, kept D units ahead in a register ring; two barriers per chunk.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)x;
-    const float r1 = x - (float)h;
-    m = (__bf16)r1;
-    l = (__bf16)(r1 - (float)m);
-}
-
-struct BxArgs { TapGemmArgs g; const __bf16* Ws; int Kp; };
-
-template <int MT, int NT, int WM, int WN, int NTAPS, int D, int KCV, int MINB>
-__global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_bx6(BxArgs args) {
-    const TapGemmArgs& g = args.g;
-    constexpr int KC = KCV;
-    constexpr int APB = 3 * KC * 2 + 16;              // LDS bytes per pixel row: 3 pieces x KC bf16 + pad (13 x 16 B)
-    constexpr int TM = MT / WM / 32, TN = NT / WN / 32;
-    constexpr int KS = KC / 16;                       // MFMA K-steps per chunk
-    constexpr int SB = 4;
-    static_assert(NTAPS == 1 || NTAPS % D == 0, "ring depth must divide the taps");
-    // tap groups fully unrolled where the register budget (2 waves per SIMD) allows: straight-line code lets the
-    // compiler count the ring's outstanding loads exactly (s_waitcnt vmcnt(6..8) instead of 0 at a loop header)
-    constexpr int GU = (MINB >= 3) ? 1 : (NTAPS / D > 0 ? NTAPS / D : 1);
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int halo = g.halo;
-    const int arows = MT + 2 * halo;
-    int* rowa = (int*)smem;
-    int* rowy = rowa + MT;
-    float* tile_lds = smem + 2 * MT;
-    char* As = (char*)tile_lds;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = tid >> 6, wm = wave / WN, wn = wave % WN;
-    const int swz = asr_xcd_swizzle(blockIdx.x, gridDim.x);
-    const int tile_m = swz / g.ntn, tile_n = swz - tile_m * g.ntn;
-    const long p0 = (long)tile_m * MT;
-    const int n0 = tile_n * NT;
-    const int K = g.K, N = g.N, Kp = args.Kp;
-
-    if (tid < MT) {
-        const long p = p0 + tid;
-        int ra = -1, ry = -1;
-        if (p < g.M) {
-            if (g.H == 0) {
-                ra = (int)p; ry = (int)p;
-            } else {
-                const int b = (int)(p / g.HPWP);
-                const int r = (int)(p - (long)b * g.HPWP);
-                const int hh = r / g.WP, ww = r - hh * g.WP;
-                if (hh >= 1 && hh <= g.H && ww >= 1 && ww <= g.Wd) {
-                    ra = (int)p;
-                    ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : (int)p;
-                }
-            }
-        }
-        rowa[tid] = ra; rowy[tid] = ry;
-    }
-
-    floatx16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int nkc = (K + KC - 1) / KC;
-    // ring of D slots, one slot = the B fragments of ONE tap for the KS K-steps of a chunk
-    bf16x8 breg[D][KS][TN][3];
-    const int kst = Kp >> 4, nbt = (N + 31) >> 5;
-    int nbb[TN];                                       // column blocks of this wave (clamped: blocks past N are never stored)
-#pragma unroll
-    for (int b = 0; b < TN; ++b) { nbb[b] = (n0 >> 5) + wn * TN + b; if (nbb[b] >= nbt) nbb[b] = nbt - 1; }
-
-    auto load_b = [&](bf16x8 (&dst)[KS][TN][3], int kc, int tap) {
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int kstep = kc * KS + ks;
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                // branch-free (the split tensor is zero-padded to whole K-steps and column blocks): with conditional
-                // loads the compiler falls back to s_waitcnt vmcnt(0) and the ring stops hiding latency
-#pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
-                    dst[ks][b][pc] = *(const bf16x8*)(args.Ws + (((((long)tap * 3 + pc) * kst + kstep) * nbt + nbb[b]) * 64 + lane) * 8);
-            }
-        }
-    };
-    auto load_a_row = [&](int f, int kc) -> float4 {
-        const int row = f / (KC / 4), c4 = f - row * (KC / 4);
-        const long grow = p0 - halo + row;
-        const int kk = kc * KC + c4 * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (grow >= g.rmin && grow < g.rmax && kk < K) v = *(const float4*)(g.A + grow * g.lda + kk);
-        return v;
-    };
-    auto compute_tap = [&](const bf16x8 (&bb)[KS][TN][3], int tap) {
-        const int toff = halo + tap_row_offset<NTAPS, 0>(tap, g.WP);
-        const char* abase = As + (wm * (TM * 32) + li + toff) * APB + lh * 16;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const bf16x8 ah = *(const bf16x8*)(abase + a * 32 * APB + ks * 32);
-                const bf16x8 am = *(const bf16x8*)(abase + a * 32 * APB + ks * 32 + KC * 2);
-                const bf16x8 al = *(const bf16x8*)(abase + a * 32 * APB + ks * 32 + 2 * KC * 2);
-#pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    floatx16 c = acc[a][b];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bb[ks][b][0], c, 0, 0, 0);      // small terms first
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bb[ks][b][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bb[ks][b][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bb[ks][b][0], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bb[ks][b][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bb[ks][b][0], c, 0, 0, 0);
-                    acc[a][b] = c;
-                }
-            }
-        }
-    };
-
-    auto stage_a = [&](int kc) {
-        __syncthreads();
-        for (int base = 0; base < arows * (KC / 4); base += SB * 256) {
-            float4 t[SB];
-#pragma unroll
-            for (int i = 0; i < SB; ++i) {
-                const int f = base + tid + i * 256;
-                t[i] = (f < arows * (KC / 4)) ? load_a_row(f, kc) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int i = 0; i < SB; ++i) {
-                const int f = base + tid + i * 256;
-                if (f >= arows * (KC / 4)) continue;
-                const int row = f / (KC / 4), c4 = f - row * (KC / 4);
-                bf16x4 ph, pm, pl;
-                const float e[4] = {t[i].x, t[i].y, t[i].z, t[i].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    __bf16 h, m, l;
-                    split3(e[j], h, m, l);
-                    ph[j] = h; pm[j] = m; pl[j] = l;
-                }
-                char* d = As + row * APB + c4 * 8;
-                *(bf16x4*)(d) = ph; *(bf16x4*)(d + KC * 2) = pm; *(bf16x4*)(d + 2 * KC * 2) = pl;
-            }
-        }
-        __syncthreads();
-    };
-
-    if (NTAPS > 1) {
-#pragma unroll
-        for (int d = 0; d < D; ++d) load_b(breg[d], 0, d);
-        for (int kc = 0; kc < nkc; ++kc) {
-            stage_a(kc);
-            // groups of D taps: the slot index is static inside a group, the group loop is not unrolled (registers)
-#pragma unroll GU
-            for (int t0 = 0; t0 < NTAPS; t0 += D) {
-#pragma unroll
-                for (int d = 0; d < D; ++d) {
-                    const int tap = t0 + d;
-                    compute_tap(breg[d], tap);
-                    int ntap = tap + D, nk = kc;
-                    if (ntap >= NTAPS) { ntap -= NTAPS; ++nk; }
-                    if (nk >= nkc) nk = nkc - 1;      // the tail refills are valid reloads that nobody reads
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_b(breg[d], nk, ntap);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-    } else {
-        // one tap: slot d holds chunk kc0 + d, refilled D chunks ahead
-#pragma unroll
-        for (int d = 0; d < D; ++d)
-            if (d < nkc) load_b(breg[d], d, 0);
-        for (int kc0 = 0; kc0 < nkc; kc0 += D) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                const int kc = kc0 + d;
-                if (kc < nkc) {                       // uniform over the workgroup
-                    stage_a(kc);
-                    compute_tap(breg[d], 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    load_b(breg[d], (kc + D < nkc) ? kc + D : nkc - 1, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-        }
-    }
-
-    __syncthreads();
-    tap_epilogue<TM, TN>(g, acc, tile_lds + wave * (32 * 33), rowa, rowy, wm * (TM * 32), n0 + wn * (TN * 32), lane, tile_m * WM + wm);
-}
-
-// W [ntaps][K][N] (HWIO; wmode 0) or its data-gradient view (wmode 1: taps mirrored, K and N swapped) ->
-// Ws bf16 in FRAGMENT ORDER [ntaps][3 pieces][Kp/16 K-steps][ceil(N/32) column blocks][64 lanes][8]: lane = 32 * h + i
-// holds column 32 * block + i, k = 16 * step + 8 * h .. + 7, so that the B operand of one v_mfma_f32_32x32x16_bf16 is ONE
-// contiguous, fully coalesced 1 KB wave load (Kp = K rounded up to 32; k >= K and columns >= N are zero)
-__global__ void split_weights_kernel(const float* __restrict__ W, int ntaps, int K, int N, int ldw, int wmode, int Kp,
-                                     __bf16* __restrict__ out) {
-    // one thread = one lane's 8 contraction indices of one column: 8 row reads (forward view; each coalesced over the 32
-    // columns of a block) or two float4 (data-gradient view), three coalesced 16-byte stores
-    const int NB = (N + 31) >> 5, KST = Kp >> 4;
-    const long per_piece = (long)KST * NB * 512;
-    const long total = (long)ntaps * KST * NB * 64;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int lane = (int)(i & 63);
-        long r = i >> 6;
-        const int nb = (int)(r % NB); r /= NB;
-        const int ks = (int)(r % KST);
-        const int tap = (int)(r / KST);
-        const int n = nb * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8;
-        float e[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = 0.f;
-        if (n < N) {
-            if (wmode == 0) {
-                const float* src = W + ((long)tap * K + k) * ldw + n;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) if (k + j < K) e[j] = src[(long)j * ldw];
-            } else {
-                const float* src = W + ((long)(ntaps - 1 - tap) * N + n) * ldw + k;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) if (k + j < K) e[j] = src[j];
-            }
-        }
-        bf16x8 h, m, l;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { __bf16 a, b, c; split3(e[j], a, b, c); h[j] = a; m[j] = b; l[j] = c; }
-        __bf16* d = out + (long)tap * 3 * per_piece + (i - (long)tap * KST * NB * 64) * 8;
-        *(bf16x8*)d = h; *(bf16x8*)(d + per_piece) = m; *(bf16x8*)(d + 2 * per_piece) = l;
-    }
-}
-
-template <int MT, int NT, int WM, int WN, int NTAPS, int D, int KCV = 32, int MINB = 3>
-int launch_bx6(const TapGemmArgs& a, const __bf16* Ws, int Kp, hipStream_t st) {
-    auto kern = tap_gemm_kernel_bx6<MT, NT, WM, WN, NTAPS, D, KCV, MINB>;
-    const int arows = MT + 2 * a.halo;
-    size_t lds = (size_t)arows * (3 * KCV * 2 + 16) + 2 * MT * sizeof(int);
-    if (lds < kEpilogueLds + 2 * MT * sizeof(int)) lds = kEpilogueLds + 2 * MT * sizeof(int);
-    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    BxArgs b;
-    b.g = a; b.Ws = Ws; b.Kp = Kp;
-    b.g.ntm = asr_cdiv(a.M, MT);
-    b.g.ntn = asr_cdiv(a.N, NT);
-    hipLaunchKernelGGL(kern, dim3(b.g.ntm * b.g.ntn), dim3(256), lds, st, b);
-    ASR_CHECK_LAUNCH("tap_gemm_bx6");
-    ASR_NOTE_KERNEL("tap_gemm_kernel_bx6<%d, %d, %d, %d, %d, %d, %d, %d>", MT, NT, WM, WN, NTAPS, D, KCV, MINB);
-    return ASR_OK;
-}
-
-// Two generations of the main loop are kept because neither wins everywhere (tools/bench_layers.py,
-// MI355X): v1 (single-buffered tiles, two barriers per tap, 3 workgroups per CU) is faster wherever
-// thread-level parallelism hides the staging; v2 (double-buffered W, register-prefetched A, one barrier
-// per tap, 2 workgroups per CU) wins the data-gradients into 32/64 output channels, whose A tiles
-// (wide planes, large halo) are the expensive part.  ASR_TAPGEMM_VARIANT=1|2 forces one for A/B runs.
-inline int tap_gemm_variant(int ntaps, int wmode, int K, int N) {
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("ASR_TAPGEMM_VARIANT"); forced = e ? atoi(e) : 0; }
-    if (forced == 1 || forced == 2) return forced;
-    if (ntaps == 9 && wmode == 1 && N <= 64 && (N > 32 || K >= 64)) return 2;
-    return 1;
-}
-
 template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE, int KCV>
 int launch_v1(const TapGemmArgs& a, hipStream_t st) {
     auto kern = tap_gemm_kernel_v1<MT, NT, WM, WN, NTAPS, WMODE, KCV>;
@@ -922,41 +448,6 @@ int launch_v1(const TapGemmArgs& a, hipStream_t st) {
     return ASR_OK;
 }
 
-template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE>
-int launch_v2(const TapGemmArgs& a, hipStream_t st) {
-    auto kern = tap_gemm_kernel<MT, NT, WM, WN, NTAPS, WMODE>;
-    const int arows = MT + 2 * a.halo;
-    const size_t wfl = ((WMODE == 0) ? KC * NT : NT * (KC + 1) + 3) / 4 * 4;
-    size_t lds = ((size_t)arows * AP * (NTAPS == 1 ? 2 : 1) + 2 * wfl) * sizeof(float) + 2 * MT * sizeof(int);
-    if (lds < kEpilogueLds + 2 * MT * sizeof(int)) lds = kEpilogueLds + 2 * MT * sizeof(int);
-    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    TapGemmArgs g = a;
-    g.ntm = asr_cdiv(a.M, MT);
-    g.ntn = asr_cdiv(a.N, NT);
-    if (a.gate_rows) *a.gate_rows = g.ntm * WM;
-    hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn), dim3(256), lds, st, g);
-    ASR_CHECK_LAUNCH("tap_gemm");
-    ASR_NOTE_KERNEL("tap_gemm_kernel<%d, %d, %d, %d, %d, %d>", MT, NT, WM, WN, NTAPS, WMODE);
-    return ASR_OK;
-}
-
-template <int MT, int NT, int WM, int WN, int NTAPS, int WMODE>
-int launch_cfg(const TapGemmArgs& a, hipStream_t st) {
-    if (tap_gemm_variant(NTAPS, WMODE, a.K, a.N) == 1) return launch_v1<MT, NT, WM, WN, NTAPS, WMODE, 32>(a, st);
-    return launch_v2<MT, NT, WM, WN, NTAPS, WMODE>(a, st);
-}
-
-inline int tap_gemm_experiment() {      // tuning experiments (tools/bench_layers.py): 0 none, 1 NT=64 tiles, 2 KC=16
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("ASR_TG_EXP"); v = e ? atoi(e) : 0; }
-    return v;
-}
-
 template <int NTAPS, int WMODE>
 int launch_n(const TapGemmArgs& a, hipStream_t st) {
     if constexpr (NTAPS == 4) {         // pre-net stride-2 conv on the phase-split plane: 4C -> C and its data-gradient
@@ -965,18 +456,11 @@ int launch_n(const TapGemmArgs& a, hipStream_t st) {
         if (a.N > 32) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
         return launch_v1<256, 32, 4, 1, NTAPS, WMODE, 32>(a, st);
     } else {
-    if constexpr (NTAPS == 1) {
-        const int ex1 = tap_gemm_experiment();
-        if (ex1 == 9 && a.N > 64) return launch_v1<128, 128, 2, 2, NTAPS, WMODE, 16>(a, st);
-        if (ex1 == 10 && a.N > 64) return launch_v1<256, 128, 4, 1, NTAPS, WMODE, 16>(a, st);
-        if (ex1 == 11 && a.N > 64) return launch_v1<256, 128, 4, 1, NTAPS, WMODE, 32>(a, st);
-        if (ex1 == 12 && a.N > 64) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
-    }
     if (NTAPS == 1 && a.N > 32) {
         // a grid of 128x128 tiles that leaves most CUs idle (e.g. the 6400->128 hidden dense of
         // acoustic_model.py: 50 tiles) runs on 64x64 tiles instead
         const long tiles = (long)asr_cdiv(a.M, 128) * asr_cdiv(a.N, 128);
-        if (tiles < 160) return launch_cfg<64, 64, 2, 2, NTAPS, WMODE>(a, st);
+        if (tiles < 160) return launch_v1<64, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
         if constexpr (WMODE == 0) {
             // forward GEMMs whose 128x128 grid is about one round of the chip (tools/bench_layers.py): up to 768 tiles
             // (3 workgroups/CU at KC 32) leave CUs idle -> 128x64 tiles (+7 % on 6400x6400x1536); 769..1024 tiles fit
@@ -990,26 +474,18 @@ int launch_n(const TapGemmArgs& a, hipStream_t st) {
         }
     }
     if (NTAPS == 9) {
-        const int ex = tap_gemm_experiment();
-        if (ex == 1 && a.N > 64) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
-        if (ex == 2 && a.N > 64) return launch_v1<128, 128, 2, 2, NTAPS, WMODE, 16>(a, st);
-        if (ex == 2 && a.N > 32) return launch_v1<256, 64, 4, 1, NTAPS, WMODE, 16>(a, st);
-        if (ex == 3 && a.N > 32 && a.N <= 64) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
-        if (ex == 4 && a.N > 32) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 16>(a, st);
-        if (ex == 0) {
-            // measured on the DFCNN layer shapes (tools/bench_layers.py, profiles/r01b_layer_tiles.txt):
-            // 128x64 tiles (more, smaller workgroups per CU) win up to 128 output channels; a 16-deep
-            // K chunk wins while the A tile (plane width + halo) dominates LDS, 32-deep for K >= 128
-            if (a.N > 32 && a.N <= 64) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 16>(a, st);
-            if (a.N > 64 && a.N <= 128) {
-                if (a.K >= 128) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
-                return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 16>(a, st);
-            }
+        // measured on the DFCNN layer shapes (tools/bench_layers.py, profiles/r01b_layer_tiles.txt):
+        // 128x64 tiles (more, smaller workgroups per CU) win up to 128 output channels; a 16-deep
+        // K chunk wins while the A tile (plane width + halo) dominates LDS, 32-deep for K >= 128
+        if (a.N > 32 && a.N <= 64) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 16>(a, st);
+        if (a.N > 64 && a.N <= 128) {
+            if (a.K >= 128) return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 32>(a, st);
+            return launch_v1<128, 64, 2, 2, NTAPS, WMODE, 16>(a, st);
         }
     }
-    if (a.N > 64) return launch_cfg<128, 128, 2, 2, NTAPS, WMODE>(a, st);
-    if (a.N > 32) return launch_cfg<256, 64, 4, 1, NTAPS, WMODE>(a, st);
-    return launch_cfg<256, 32, 4, 1, NTAPS, WMODE>(a, st);
+    if (a.N > 64) return launch_v1<128, 128, 2, 2, NTAPS, WMODE, 32>(a, st);
+    if (a.N > 32) return launch_v1<256, 64, 4, 1, NTAPS, WMODE, 32>(a, st);
+    return launch_v1<256, 32, 4, 1, NTAPS, WMODE, 32>(a, st);
     }
 }
 
@@ -1043,9 +519,6 @@ static int tap_gemm_impl(const asr_gemm_desc* d, const float* A, const float* W,
     a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
     a.ntm = a.ntn = 0;
     set_gate(a, gs);
-    static int ablate = -1;
-    if (ablate < 0) { const char* e = getenv("ASR_TG_ABLATE"); ablate = e ? atoi(e) : 0; }
-    a.ablate = ablate;
     hipStream_t st = (hipStream_t)stream;
     if (d->ntaps == 9) return d->wmode ? launch_n<9, 1>(a, st) : launch_n<9, 0>(a, st);
     if (d->ntaps == 4) return d->wmode ? launch_n<4, 1>(a, st) : launch_n<4, 0>(a, st);
@@ -1103,7 +576,7 @@ extern "C" int asr_tap_gemm_splitk(const asr_gemm_desc* d, const float* A, const
     a.H = 0; a.Wd = 0; a.WP = 1; a.HPWP = 1; a.halo = 0;
     a.rmin = 0; a.rmax = d->M;
     a.relu = 0; a.accumulate = 0; a.y_unpadded = 0;
-    a.ntm = a.ntn = 0; a.ablate = 0;
+    a.ntm = a.ntn = 0;
     set_gate(a, nullptr);
     a.ksplit = splits; a.split_out = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
@@ -1159,9 +632,9 @@ static int tap_gemm_pw_impl(const asr_gemm_desc* d, const float* A, const float*
     a.halo = (d->ntaps != 1) ? a.WP + 1 : 0;
     a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
     a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
-    a.ntm = a.ntn = 0; a.ablate = 0;
+    a.ntm = a.ntn = 0;
     set_gate(a, gs);
-    { static int nts = -1; if (nts < 0) { const char* e = getenv("ASR_PW_NT"); nts = e ? atoi(e) : 0; } a.nt_store = nts; }
+    a.nt_store = 0;       // streaming stores were measured on the direct kernels: no change
     hipStream_t st = (hipStream_t)stream;
     const int dir = d->wmode ? 1 : 0;       // labels the launch only (distinct kernel symbols per direction)
     // tile choice (tools/bench_pw.py, MI355X): 128x64 workgroup tiles with a 16-deep chunk and a 3-unit ring win on every
@@ -1169,13 +642,7 @@ static int tap_gemm_pw_impl(const asr_gemm_desc* d, const float* A, const float*
     // asr_tap_gemm stays faster (0.86-0.97x here: no tap reuse to pay for the direct weight loads), so the engines use
     // this entry point for ntaps = 9 only -- the 1-tap configurations exist for completeness and tests
     if (d->ntaps == 9) {
-        static int mt = -1;
-        if (mt < 0) { const char* e = getenv("ASR_PW_MT"); mt = e ? atoi(e) : 0; }
         if (d->N > 32) {
-            if (mt == 192) return launch_v5<192, 64, 2, 2, 9, 16, 3, 3>(a, Wf, dir, st);
-            if (mt == 64) return launch_v5<64, 64, 2, 2, 9, 16, 3, 3>(a, Wf, dir, st);
-            if (mt == 256) return launch_v5<256, 64, 2, 2, 9, 16, 3, 2>(a, Wf, dir, st);
-            if (mt == 128) return launch_v5<128, 64, 2, 2, 9, 16, 3, 3>(a, Wf, dir, st);
             // The kernel advances in beats of one tile per CU (tools/exp_tail.py: its duration is ceil(tiles / 256) x the time
             // of one tile, whatever the three co-resident workgroups overlap), so the partial last beat is lost: 2 614 tiles
             // of 128 rows = 10.2 beats cost 11.  Rows per tile are therefore picked per launch, 128 or 192 (2 x 2 waves of
@@ -1235,64 +702,4 @@ extern "C" int asr_tap_gemm_gated(const asr_gemm_desc* d, const float* dZ, const
     m.nseg = 3; m.width[0] = d->N; m.width[1] = d->N; m.width[2] = d->N; m.width[3] = 0;
     m.out[0] = dscale; m.out[1] = dshift; m.out[2] = dbias; m.out[3] = nullptr;
     return asr_reduce::colsum_multi(partials, rows, 3L * d->N, m, partials + (size_t)rows * 3 * d->N, (hipStream_t)stream);
-}
-
-// ---- EXPERIMENTAL split-bf16 path (include/asr_hip.h): weights pre-split by asr_split_weights, then asr_tap_gemm_bx6
-extern "C" size_t asr_split_weights_bytes(int ntaps, int K, int N) {
-    const int Kp = (K + 31) / 32 * 32, Np = (N + 31) / 32 * 32;
-    return (size_t)ntaps * 3 * Np * Kp * 2;
-}
-
-extern "C" int asr_split_weights(const float* W, int ntaps, int K, int N, int ldw, int wmode, void* out, void* stream) {
-    if (!W || !out || (ntaps != 1 && ntaps != 9) || K < 1 || N < 1) return ASR_ERR_BAD_ARG;
-    const int Kp = (K + 31) / 32 * 32;
-    const long total = (long)ntaps * ((N + 31) / 32 * 32) * Kp / 8;
-    long nb = (total + 255) / 256;
-    if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(split_weights_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, W, ntaps, K, N, ldw, wmode, Kp,
-                       (__bf16*)out);
-    ASR_CHECK_LAUNCH("split_weights");
-    return ASR_OK;
-}
-
-extern "C" int asr_tap_gemm_bx6(const asr_gemm_desc* d, const float* A, const void* Wsplit,
-                                const float* bias, const float* scale, const float* shift,
-                                float* out_a, float* out_y, void* stream) {
-    if (!d || !A || !Wsplit || (!out_a && !out_y)) return ASR_ERR_BAD_ARG;
-    if (d->ntaps != 1 && d->ntaps != 9) return ASR_ERR_BAD_ARG;
-    if ((d->K & 3) || (d->N & 3) || (d->lda & 3)) return ASR_ERR_BAD_ARG;
-    if (d->ntaps == 9 && d->H <= 0) return ASR_ERR_BAD_ARG;
-    if (((uintptr_t)A | (uintptr_t)Wsplit) & 15) return ASR_ERR_BAD_ARG;
-    TapGemmArgs a;
-    a.A = A; a.W = nullptr; a.bias = bias; a.scale = scale; a.shift = shift;
-    a.out_a = out_a; a.out_y = out_y;
-    a.M = d->M; a.K = d->K; a.N = d->N; a.lda = d->lda; a.ldw = d->ldw;
-    a.ldo_a = d->ldo_a; a.ldo_y = d->ldo_y;
-    a.H = d->H; a.Wd = d->W; a.WP = d->W + 1; a.HPWP = (d->H + 1) * (d->W + 1);
-    if (d->H > 0 && d->M != d->B * a.HPWP) return ASR_ERR_BAD_ARG;
-    a.halo = (d->ntaps != 1) ? a.WP + 1 : 0;
-    a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
-    a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
-    a.ntm = a.ntn = 0; a.ablate = 0;
-    set_gate(a, nullptr);
-    const int Kp = (d->K + 31) / 32 * 32;
-    hipStream_t st = (hipStream_t)stream;
-    const __bf16* Ws = (const __bf16*)Wsplit;
-    // Tile choice (tools/bench_bx6.py, MI355X): with the matrix pipe 2.6x faster the kernel is bound by operand traffic,
-    // and the per-wave weight fragments (global / L2 loads) dominate it: 128x32 wave tiles (256x64 workgroups, 2 waves
-    // per SIMD, no spills) reach 161-180 fp32-equivalent TFLOP/s where 64x32 wave tiles stop at 140-148 and 128x64
-    // ones spill.  Register-prefetching the A tile (one barrier per chunk) is slower, as for the fp32 kernels.
-    static int cfg = -1;
-    if (cfg < 0) { const char* e = getenv("ASR_BX6_CFG"); cfg = e ? atoi(e) : 0; }
-    if (d->ntaps == 9) {
-        if (d->N > 32) {
-            if (cfg == 2) return launch_bx6<128, 64, 2, 2, 9, 3, 16, 3>(a, Ws, Kp, st);
-            if (cfg == 13 && d->N > 64) return launch_bx6<256, 128, 2, 2, 9, 3, 16, 2>(a, Ws, Kp, st);
-            return launch_bx6<256, 64, 2, 2, 9, 3, 16, 2>(a, Ws, Kp, st);
-        }
-        return launch_bx6<256, 32, 4, 1, 9, 3, 16, 3>(a, Ws, Kp, st);
-    }
-    if (d->N > 32 && cfg != 2) return launch_bx6<256, 64, 2, 2, 1, 2, 32, 2>(a, Ws, Kp, st);
-    if (d->N > 32) return launch_bx6<128, 64, 2, 2, 1, 2>(a, Ws, Kp, st);
-    return launch_bx6<256, 32, 4, 1, 1, 2>(a, Ws, Kp, st);
 }

@@ -23,190 +23,7 @@ struct WgradArgs {
     long rmin, rmax;
     int pch;                                      // pixels per chunk (multiple of PS)
     long slab;                                    // floats per chunk partial = ntaps*K*N
-    int ap, zp;                                   // bx6 only: LDS row pitches (bytes) of the A / dZ piece images
 };
-
-template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS>
-__global__ __launch_bounds__(256) void tap_wgrad_kernel(WgradArgs g) {
-    constexpr int WAVES_P = 4 / WAVES_N;
-    constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32;
-    constexpr int NACC = NTAPS * TKW * TNW;
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int halo = g.halo;
-    const int arows = PS + 2 * halo;
-    const int bufsz = arows * KT + PS * NT;   // one staging buffer: A run [arows][KT] then dZ run [PS][NT]
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = tid >> 6, wn = wave % WAVES_N, wp = wave / WAVES_N;
-    const int chunk = blockIdx.x;
-    const int k0 = blockIdx.y * KT, n0 = blockIdx.z * NT;
-    const long cbeg = (long)chunk * g.pch;
-    const long cend = (cbeg + g.pch < g.M) ? cbeg + g.pch : g.M;
-
-    floatx16 acc[NTAPS][TKW][TNW];
-#pragma unroll
-    for (int t = 0; t < NTAPS; ++t)
-#pragma unroll
-        for (int a = 0; a < TKW; ++a)
-#pragma unroll
-            for (int b = 0; b < TNW; ++b)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][a][b][r] = 0.f;
-
-    // issue-early / write-late staging: the next run of pixels is loaded into registers while the
-    // MFMAs of the current run execute, and written to LDS after the barrier that retires it.
-    constexpr int HALO_MAX = (NTAPS == 9) ? 103 : 0;                     // W + 3 of the widest DFCNN plane (100 + 3)
-    constexpr int AR = ((PS + 2 * HALO_MAX) * (KT / 4) + 255) / 256;     // float4 per thread, A run (+ halo)
-    constexpr int ZR = (PS * (NT / 4) + 255) / 256;                      // float4 per thread, dZ run
-    const int atotal = arows * (KT / 4);
-    float4 areg[AR], zreg[ZR];
-    auto load_a_one = [&](int f, long ps0) -> float4 {
-        const int row = f / (KT / 4), c4 = f - row * (KT / 4);
-        const long grow = ps0 - halo + row;
-        const int kk = k0 + c4 * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (grow >= g.rmin && grow < g.rmax && kk < g.K) v = *(const float4*)(g.A + grow * g.lda + kk);
-        return v;
-    };
-    auto load_tiles = [&](long ps0) {
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int f = tid + i * 256;
-            areg[i] = (f < atotal) ? load_a_one(f, ps0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < ZR; ++i) {
-            const int f = tid + i * 256;
-            const int row = f / (NT / 4), n4 = f - row * (NT / 4);
-            const long grow = ps0 + row;
-            const int nn = n0 + n4 * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (f < PS * (NT / 4) && grow < cend && nn < g.N) v = *(const float4*)(g.Z + grow * g.ldz + nn);
-            zreg[i] = v;
-        }
-    };
-    auto store_tiles = [&](long ps0, float* As) {
-        float* Zs = As + arows * KT;
-#pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            const int f = tid + i * 256;
-            if (f < atotal) { const int row = f / (KT / 4), c4 = f - row * (KT / 4); *(float4*)(As + row * KT + c4 * 4) = areg[i]; }
-        }
-        for (int f = tid + AR * 256; f < atotal; f += 256) {           // planes wider than HALO_MAX: direct
-            const int row = f / (KT / 4), c4 = f - row * (KT / 4);
-            *(float4*)(As + row * KT + c4 * 4) = load_a_one(f, ps0);
-        }
-#pragma unroll
-        for (int i = 0; i < ZR; ++i) {
-            const int f = tid + i * 256;
-            if (f < PS * (NT / 4)) { const int row = f / (NT / 4), n4 = f - row * (NT / 4); *(float4*)(Zs + row * NT + n4 * 4) = zreg[i]; }
-        }
-    };
-
-    // two LDS buffers, one barrier per run: run i+1 is written into the other buffer while
-    // slower waves may still read run i; the barrier at the end of the iteration retires both.
-    load_tiles(cbeg);
-    store_tiles(cbeg, smem);
-    __syncthreads();
-    if (cbeg + PS < cend) load_tiles(cbeg + PS);
-    int cur = 0;
-    for (long ps0 = cbeg; ps0 < cend; ps0 += PS) {
-        const float* As = smem + cur * bufsz;
-        const float* Zs = As + arows * KT;
-        // Software-pipelined operand fetch, unrolled by two with two named register sets: the LDS reads of
-        // the next pixel pair are issued BEFORE the MFMAs of the current pair and consumed after them, so
-        // their latency hides under 9 x 64 MFMA cycles.
-        {
-            float a0[NTAPS][TKW], b0[TNW], a1[NTAPS][TKW], b1[TNW];
-            auto fetch = [&](float (&an)[NTAPS][TKW], float (&bn)[TNW], int r) {
-#pragma unroll
-                for (int b = 0; b < TNW; ++b) bn[b] = Zs[(r + lh) * NT + (wn * TNW + b) * 32 + li];
-#pragma unroll
-                for (int t = 0; t < NTAPS; ++t) {
-                    const int off = (NTAPS == 9) ? ((t / 3) - 1) * g.WP + (t % 3) - 1 : 0;
-#pragma unroll
-                    for (int a = 0; a < TKW; ++a) an[t][a] = As[(r + lh + halo + off) * KT + li + a * 32];
-                }
-            };
-            auto fma_all = [&](const float (&ac)[NTAPS][TKW], const float (&bc)[TNW]) {
-#pragma unroll
-                for (int t = 0; t < NTAPS; ++t)
-#pragma unroll
-                    for (int a = 0; a < TKW; ++a)
-#pragma unroll
-                        for (int b = 0; b < TNW; ++b)
-                            acc[t][a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ac[t][a], bc[b], acc[t][a][b], 0, 0, 0);
-            };
-            constexpr int RS = 2 * WAVES_P;             // pixel-pair stride of this wave (PS / RS is even)
-            static_assert((PS / RS) % 2 == 0, "unroll by two");
-            fetch(a0, b0, 2 * wp);
-            for (int r = 2 * wp; r < PS; r += 2 * RS) {
-                fetch(a1, b1, r + RS);
-                fma_all(a0, b0);
-                if (r + 2 * RS < PS) fetch(a0, b0, r + 2 * RS);
-                fma_all(a1, b1);
-            }
-        }
-        if (ps0 + PS < cend) {
-            store_tiles(ps0 + PS, smem + (cur ^ 1) * bufsz);
-            if (ps0 + 2 * PS < cend) load_tiles(ps0 + 2 * PS);
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    // fold the pixel-split waves of this block through LDS, one tap at a time (keeps the
-    // transfer at 16 registers per lane) and in a fixed order wp = 1, 2, ...
-    if (WAVES_P > 1) {
-        float* red = smem;   // [WAVES_P-1][WAVES_N][TKW*TNW*16][64]
-#pragma unroll
-        for (int t = 0; t < NTAPS; ++t) {
-            __syncthreads();
-            if (wp > 0) {
-                float* dst = red + (((wp - 1) * WAVES_N + wn) * (TKW * TNW * 16)) * 64 + lane;
-#pragma unroll
-                for (int a = 0; a < TKW; ++a)
-#pragma unroll
-                    for (int b = 0; b < TNW; ++b)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            dst[((a * TNW + b) * 16 + r) * 64] = acc[t][a][b][r];
-            }
-            __syncthreads();
-            if (wp == 0) {
-                for (int src = 1; src < WAVES_P; ++src) {
-                    const float* sp = red + (((src - 1) * WAVES_N + wn) * (TKW * TNW * 16)) * 64 + lane;
-#pragma unroll
-                    for (int a = 0; a < TKW; ++a)
-#pragma unroll
-                        for (int b = 0; b < TNW; ++b)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r)
-                                acc[t][a][b][r] += sp[((a * TNW + b) * 16 + r) * 64];
-                }
-            }
-        }
-    }
-    if (wp != 0) return;
-
-    float* out = g.out + (long)chunk * g.slab;
-#pragma unroll
-    for (int t = 0; t < NTAPS; ++t)
-#pragma unroll
-        for (int a = 0; a < TKW; ++a)
-#pragma unroll
-            for (int b = 0; b < TNW; ++b) {
-                const int n = n0 + (wn * TNW + b) * 32 + li;
-                if (n >= g.N) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k = k0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (k < g.K) out[((long)t * g.K + k) * g.N + n] = acc[t][a][b][r];
-                }
-            }
-}
 
 // ---- v1: direct staging, two barriers per run, two blocks per CU
 template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS>
@@ -384,152 +201,6 @@ __global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_v1(WgradArgs g) {
                     if (k < g.K) out[((long)t * g.K + k) * g.N + n] = acc[t][a][b][r];
                 }
             }
-}
-
-// ---- bx6: EXPERIMENTAL split-bf16 weight gradient (forward / data-gradient twin in tap_gemm.hip).
-// The contraction index is the PIXEL, so both MFMA operands need, per lane, 8 consecutive pixels of one channel --
-// a transposed view of the natural [pixel][channel] tiles.  The tiles are staged as they come (split into hi/mid/lo
-// bf16 pieces, channel-contiguous rows) and read with gfx950's transposing ds_read_b64_tr_b16: a 16-lane group fetches
-// a 4-pixel x 16-channel block and every lane receives its channel's 4 pixels.  A tap is a ROW offset of the A image,
-// so the nine taps need no alignment of any kind.  One workgroup = 32 input channels x 128 output channels x 9 taps.
-typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
-typedef short wshort4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void wsplit3(float x, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)x;
-    const float r1 = x - (float)h;
-    m = (__bf16)r1;
-    l = (__bf16)(r1 - (float)m);
-}
-
-// 8 consecutive rows (pixels) of this lane's column, from a [row][column] bf16 image: two transposed 4 x 16 block reads.
-// `p` = address of (first row + (lane&15)>>2, first column of the lane's 16-group + 4*(lane&3)); EXEC must be all ones.
-__device__ __forceinline__ wbf16x8 tr_read8(const char* p, int pitch) {
-    typedef wshort4 __attribute__((address_space(3)))* lptr;
-    const wshort4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p));
-    const wshort4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lptr)(p + 4 * pitch));
-    union { wshort4 s[2]; wbf16x8 v; } u;
-    u.s[0] = a; u.s[1] = b;
-    return u.v;
-}
-
-template <int PS>
-__global__ __launch_bounds__(256, 2) void tap_wgrad_kernel_bx6(WgradArgs g) {
-    constexpr int KT = 32, NT = 128, NTAPS = 9;
-    const int AP = g.ap, ZP = g.zp;       // bytes per row of one piece image (multiples of 8; see the launcher)
-    extern __shared__ __attribute__((aligned(16))) char wsm[];
-    const int halo = g.halo;
-    const int arows = PS + 2 * halo;
-    char* As = wsm;                                               // [3][arows][AP]
-    char* Zs = wsm + (3 * arows * AP + 15) / 16 * 16;             // [3][PS][ZP]
-
-    const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
-    const int lh = lane >> 5, gg = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3, li = lane & 31;
-    const int chunk = blockIdx.x;
-    const int k0 = blockIdx.y * KT, n0 = blockIdx.z * NT;
-    const long cbeg = (long)chunk * g.pch;
-    const long cend = (cbeg + g.pch < g.M) ? cbeg + g.pch : g.M;
-
-    floatx16 acc[NTAPS];
-#pragma unroll
-    for (int t = 0; t < NTAPS; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    // per-lane byte offsets of the transposed block reads (row part is added per step / tap)
-    const int a_col = (8 * lh + q) * AP + (16 * gg + 4 * pp) * 2;
-    const int z_col = (8 * lh + q) * ZP + (wn * 32 + 16 * gg + 4 * pp) * 2;
-
-    for (long ps0 = cbeg; ps0 < cend; ps0 += PS) {
-        __syncthreads();
-        constexpr int SB = 4;
-        for (int base = 0; base < arows * (KT / 4); base += SB * 256) {
-            float4 t[SB];
-#pragma unroll
-            for (int i = 0; i < SB; ++i) {
-                const int f = base + tid + i * 256;
-                const int row = f / (KT / 4), c4 = f - row * (KT / 4);
-                const long grow = ps0 - halo + row;
-                const int kk = k0 + c4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (f < arows * (KT / 4) && grow >= g.rmin && grow < g.rmax && kk < g.K) v = *(const float4*)(g.A + grow * g.lda + kk);
-                t[i] = v;
-            }
-#pragma unroll
-            for (int i = 0; i < SB; ++i) {
-                const int f = base + tid + i * 256;
-                if (f >= arows * (KT / 4)) continue;
-                const int row = f / (KT / 4), c4 = f - row * (KT / 4);
-                wbf16x4 ph, pm, pl;
-                const float e[4] = {t[i].x, t[i].y, t[i].z, t[i].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { __bf16 h, m, l; wsplit3(e[j], h, m, l); ph[j] = h; pm[j] = m; pl[j] = l; }
-                char* d = As + row * AP + c4 * 8;
-                *(wbf16x4*)(d) = ph; *(wbf16x4*)(d + arows * AP) = pm; *(wbf16x4*)(d + 2 * arows * AP) = pl;
-            }
-        }
-        for (int base = 0; base < PS * (NT / 4); base += SB * 256) {
-            float4 t[SB];
-#pragma unroll
-            for (int i = 0; i < SB; ++i) {
-                const int f = base + tid + i * 256;
-                const int row = f / (NT / 4), n4 = f - row * (NT / 4);
-                const long grow = ps0 + row;
-                const int nn = n0 + n4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (f < PS * (NT / 4) && grow < cend && nn < g.N) v = *(const float4*)(g.Z + grow * g.ldz + nn);
-                t[i] = v;
-            }
-#pragma unroll
-            for (int i = 0; i < SB; ++i) {
-                const int f = base + tid + i * 256;
-                if (f >= PS * (NT / 4)) continue;
-                const int row = f / (NT / 4), n4 = f - row * (NT / 4);
-                wbf16x4 ph, pm, pl;
-                const float e[4] = {t[i].x, t[i].y, t[i].z, t[i].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { __bf16 h, m, l; wsplit3(e[j], h, m, l); ph[j] = h; pm[j] = m; pl[j] = l; }
-                char* d = Zs + row * ZP + n4 * 8;
-                *(wbf16x4*)(d) = ph; *(wbf16x4*)(d + PS * ZP) = pm; *(wbf16x4*)(d + 2 * PS * ZP) = pl;
-            }
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int pix = 0; pix < PS; pix += 16) {
-            const char* zb = Zs + pix * ZP + z_col;
-            const wbf16x8 zh = tr_read8(zb, ZP), zm = tr_read8(zb + PS * ZP, ZP), zl = tr_read8(zb + 2 * PS * ZP, ZP);
-#pragma unroll
-            for (int t = 0; t < NTAPS; ++t) {
-                const int off = ((t / 3) - 1) * g.WP + (t % 3) - 1;
-                const char* ab = As + (pix + halo + off) * AP + a_col;
-                const wbf16x8 ah = tr_read8(ab, AP), am = tr_read8(ab + arows * AP, AP), al = tr_read8(ab + 2 * arows * AP, AP);
-                floatx16 c = acc[t];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, zh, c, 0, 0, 0);      // small terms first
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, zl, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, zm, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, zh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, zm, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, zh, c, 0, 0, 0);
-                acc[t] = c;
-                // keep the compiler from hoisting all 27 A fragments of a step ahead of the MFMAs (144 accumulator
-                // registers leave no room for them); the reads of tap t+1 still overlap the queued MFMAs of tap t
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-
-    float* out = g.out + (long)chunk * g.slab;
-    const int n = n0 + wn * 32 + li;
-    if (n < g.N) {
-#pragma unroll
-        for (int t = 0; t < NTAPS; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (k < g.K) out[((long)t * g.K + k) * g.N + n] = acc[t][r];
-            }
-    }
 }
 
 // ---- v3: as v1, but dZ never touches LDS.  A wave only needs its own 32 output channels of dZ, and for a
@@ -949,47 +620,42 @@ Plan make_plan(const asr_gemm_desc* d, int target_blocks = 768, long cap_mb = 64
 
 template <int NTAPS, int TKW, int WAVES_N, int TNW, int PS>
 int launch_wgrad(const WgradArgs& a, const Plan& p, int K, int N, hipStream_t st) {
-    // 3x3: v1 (batched direct staging, 2 workgroups per CU) wins almost everywhere, v2 (register prefetch + LDS
-    // double buffer, 1 workgroup per CU) only for the 64->64 class; dense / 1x1 (no halo): v3 (dZ in registers,
-    // half-length runs) is 10-30 % faster (tools/bench_layers.py).  ASR_WGRAD_VARIANT forces one.  (A v1 with the next
-    // run register-prefetched at 2 workgroups per CU was tried again with pinned, branch-free loads: 144 accumulator +
-    // 56 prefetch registers spill, 66 vs 99 TFLOP/s -- removed.)
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("ASR_WGRAD_VARIANT"); forced = e ? atoi(e) : 0; }
-    const int variant = (NTAPS == 4) ? 1 : (forced >= 1 && forced <= 3) ? forced : (NTAPS == 1 ? 3 : ((WAVES_N == 2 && K >= 64) ? 2 : 1));
+    // The register-staged generation, for what the LDS-DMA kernels below do not take (4-tap phase-split convs, operands
+    // that are not 16-byte aligned, dense outputs of fewer than four tiles): 3x3 / 4-tap on v1 (batched direct staging,
+    // 2 workgroups per CU), dense / 1x1 on v3 (dZ in registers, half-length runs: 10-30 % faster than v1 there).
+    constexpr bool V3 = (NTAPS == 1);
     constexpr int PS3 = PS / 2;          // v3 keeps the run's dZ in registers: half the run length
-    auto kern = (variant == 1) ? tap_wgrad_kernel_v1<NTAPS, TKW, WAVES_N, TNW, PS>
-              : (variant == 3) ? tap_wgrad_kernel_v3<NTAPS, TKW, WAVES_N, TNW, PS3> : tap_wgrad_kernel<NTAPS, TKW, WAVES_N, TNW, PS>;
-    constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32, NACC = NTAPS * TKW * TNW;
-    size_t lds = (variant == 3) ? (size_t)(PS3 + 2 * a.halo) * KT * sizeof(float)
-               : (variant == 1 ? 1 : 2) * ((size_t)(PS + 2 * a.halo) * KT + (size_t)PS * NT) * sizeof(float);
+    constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32;
+    size_t lds = V3 ? (size_t)(PS3 + 2 * a.halo) * KT * sizeof(float)
+                    : ((size_t)(PS + 2 * a.halo) * KT + (size_t)PS * NT) * sizeof(float);
     const size_t red = (size_t)(4 / WAVES_N - 1) * WAVES_N * TKW * TNW * 16 * 64 * sizeof(float);
     if (red > lds) lds = red;
     if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
-    static bool attr_set[4] = {false, false, false, false};
-    if (!attr_set[variant]) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set[variant] = true;
+    const dim3 grid(p.nchunks, asr_cdiv(K, KT), asr_cdiv(N, NT));
+    static bool attr_set = false;
+    if constexpr (V3) {
+        auto kern = tap_wgrad_kernel_v3<NTAPS, TKW, WAVES_N, TNW, PS3>;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+        ASR_NOTE_KERNEL("tap_wgrad_kernel_v3<%d, %d, %d, %d, %d>", NTAPS, TKW, WAVES_N, TNW, PS3);
+    } else {
+        auto kern = tap_wgrad_kernel_v1<NTAPS, TKW, WAVES_N, TNW, PS>;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+        ASR_NOTE_KERNEL("tap_wgrad_kernel_v1<%d, %d, %d, %d, %d>", NTAPS, TKW, WAVES_N, TNW, PS);
     }
-    hipLaunchKernelGGL(kern, dim3(p.nchunks, asr_cdiv(K, KT), asr_cdiv(N, NT)), dim3(256), lds, st, a);
     ASR_CHECK_LAUNCH("tap_wgrad");
-    if (variant == 1) ASR_NOTE_KERNEL("tap_wgrad_kernel_v1<%d, %d, %d, %d, %d>", NTAPS, TKW, WAVES_N, TNW, PS);
-    else if (variant == 3) ASR_NOTE_KERNEL("tap_wgrad_kernel_v3<%d, %d, %d, %d, %d>", NTAPS, TKW, WAVES_N, TNW, PS3);
-    else ASR_NOTE_KERNEL("tap_wgrad_kernel<%d, %d, %d, %d, %d>", NTAPS, TKW, WAVES_N, TNW, PS);
     return ASR_OK;
 }
 
 // v6 (LDS-DMA, two run buffers): run length and workgroups per CU from what fits the 160 KB of LDS -- two workgroups per
 // CU with 32-pixel runs when two double-buffered images fit in 80 KB each, else one with 64- or 32-pixel runs -- and a
 // grid of exactly one round of resident workgroups (512 or 256): every workgroup runs beside the same neighbours from
-// start to end, no partial round.  ASR_WGRAD6_PS / ASR_WGRAD6_BLOCKS override (experiments).
+// start to end, no partial round.
 struct Plan6 { Plan p; int ps, minb; size_t lds; };
 
 template <int KT, int NT>
 Plan6 make_plan6(const asr_gemm_desc* d) {
-    static int ps_force = -1, blocks_force = -1;
-    if (ps_force < 0) { const char* e = getenv("ASR_WGRAD6_PS"); ps_force = e ? atoi(e) : 0; }
-    if (blocks_force < 0) { const char* e = getenv("ASR_WGRAD6_BLOCKS"); blocks_force = e ? atoi(e) : 0; }
     const int halo = (d->ntaps != 1) ? d->W + 2 : 0;
     auto lds_for = [&](int ps) { return (size_t)2 * ((((size_t)(ps + 2 * halo) * KT + 255) & ~(size_t)255) + (size_t)ps * NT) * sizeof(float); };
     Plan6 q;
@@ -1001,20 +667,19 @@ Plan6 make_plan6(const asr_gemm_desc* d) {
     // TFLOP/s) but leave half of every CU's registers and wave slots to the HBM-bound kernels that run beside the weight
     // gradient on the other stream, and halve the partial slab (256 workgroups): whole step -1 % (gpurun_out/r02g/ps.log)
     int ps = (d->ntaps == 1) ? 32 : (NT > 64 ? 64 : (d->W > 64 ? 128 : 64));
-    if (ps_force == 32 || ps_force == 64 || ps_force == 128) ps = ps_force;
     while (ps > 32 && !fits(ps)) ps >>= 1;
     q.ps = ps;
     q.minb = (2 * lds_for(ps) <= 160 * 1024) ? 2 : 1;
     q.lds = lds_for(q.ps);
-    q.p = make_plan(d, blocks_force > 0 ? blocks_force : 256 * q.minb, 128, q.ps);
+    q.p = make_plan(d, 256 * q.minb, 128, q.ps);
     q.p.ktile = KT; q.p.ntile = NT;
-    if (d->ntaps == 1 && blocks_force <= 0) {
+    if (d->ntaps == 1) {
         // Dense layers: the chunk count is picked from the beat model (a CU finishes its workgroups at a fixed aggregate
         // rate, so a grid costs ceil(workgroups / 256) beats of one chunk each) plus the price of summing the slabs:
         //   t(nc) = ceil(tiles * nc / 256) / nc * t_rows + nc * slab traffic
         // e.g. 6400 x 6400 x 1536 (600 tiles): one chunk = 3 beats, two chunks = 5 half-beats (1388 -> 1156 us measured);
         // 32768 x 512 x 6348 (200 tiles): 2 chunks 2266 us, 15 chunks 1894 us; the 16- and 64-tile projection / FFN shapes
-        // keep 512 workgroups (tools/bench_wgrad1.py, ASR_WGRAD6_BLOCKS sweeps)
+        // keep 512 workgroups (tools/bench_wgrad1.py)
         const long tiles = (long)asr_cdiv(d->K, KT) * asr_cdiv(d->N, NT);
         const double slab = (double)d->K * d->N * 4.0;
         const double t_rows = (double)d->M * KT * NT * 2.0 / (0.75 * 157.3e12 / 256);
@@ -1036,22 +701,10 @@ Plan6 make_plan6(const asr_gemm_desc* d) {
     return q;
 }
 
-inline bool v6_enabled() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("ASR_WGRAD_V6"); on = e ? atoi(e) : 1; }
-    return on != 0;
-}
-
-inline bool v6_dense_enabled() {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("ASR_WGRAD_V6_DENSE"); on = e ? atoi(e) : 1; }
-    return on != 0;
-}
-
 template <int NTAPS, int TKW, int WAVES_N, int TNW>
 bool v6_ok(const asr_gemm_desc* d, int ldz) {
     constexpr int KT = TKW * 32, NT = WAVES_N * TNW * 32;
-    if (!v6_enabled() || (d->K & 3) || (d->N & 3) || (d->lda & 3) || (ldz & 3)) return false;
+    if ((d->K & 3) || (d->N & 3) || (d->lda & 3) || (ldz & 3)) return false;
     const Plan6 q = make_plan6<KT, NT>(d);
     const size_t red = (size_t)(4 / WAVES_N - 1) * WAVES_N * TKW * TNW * 16 * 64 * sizeof(float);
     return q.lds <= 160 * 1024 && red <= q.lds;
@@ -1074,8 +727,6 @@ int launch_wgrad6(WgradArgs a, const asr_gemm_desc* d, float* dW, float* partial
         hipLaunchKernelGGL(kern, grid, dim3(256), q.lds, st, a);                                                         \
         ASR_NOTE_KERNEL("tap_wgrad_kernel_v6<%d, %d, %d, %d, %d, %d>", NTAPS, TKW, WAVES_N, TNW, PSV, MB);                \
     } while (0)
-    static int tsplit = -1;
-    if (tsplit < 0) { const char* e = getenv("ASR_WG_SPLIT"); tsplit = e ? atoi(e) : 1; }
     if constexpr (NTAPS == 9) {
 #define ASR_V6S_LAUNCH(PSV)                                                                                               \
         do {                                                                                                             \
@@ -1088,8 +739,8 @@ int launch_wgrad6(WgradArgs a, const asr_gemm_desc* d, float* dW, float* partial
             return ASR_OK;                                                                                               \
         } while (0)
         // one workgroup per CU (minb 1): eight waves instead of four, two per SIMD
-        if (tsplit && q.minb == 1 && q.ps == 64) ASR_V6S_LAUNCH(64);
-        if (tsplit && q.minb == 1 && q.ps == 128) ASR_V6S_LAUNCH(128);
+        if (q.minb == 1 && q.ps == 64) ASR_V6S_LAUNCH(64);
+        if (q.minb == 1 && q.ps == 128) ASR_V6S_LAUNCH(128);
 #undef ASR_V6S_LAUNCH
     }
     if (q.ps == 128) { if (q.minb == 2) ASR_V6_LAUNCH(128, 2); else ASR_V6_LAUNCH(128, 1); }
@@ -1106,7 +757,7 @@ int launch_wgrad6(WgradArgs a, const asr_gemm_desc* d, float* dW, float* partial
 
 extern "C" size_t asr_tap_wgrad_workspace(const asr_gemm_desc* d) {
     if (!d) return 0;
-    const Plan p = make_plan(d), q = make_plan(d, 1024, 128);  // q: the most chunks any variant (bx6 sweeps included) asks for
+    const Plan p = make_plan(d), q = make_plan(d, 1024, 128);  // q: an upper bound on the chunks of any variant
     int nc = p.nchunks > q.nchunks ? p.nchunks : q.nchunks;
     if (d->ntaps == 9) {                                       // the LDS-DMA variant plans its own (shorter) runs
         const int n6 = d->N > 64 ? make_plan6<32, 128>(d).p.nchunks : d->N > 32 ? make_plan6<32, 64>(d).p.nchunks
@@ -1146,7 +797,7 @@ extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float
     else if (d->ntaps == 9 && d->N > 64 && v6_ok<9, 1, 4, 1>(d, ldz)) rc = launch_wgrad6<9, 1, 4, 1>(a, d, dW, partials, st, &p6);
     else if (d->ntaps == 9 && d->N > 32 && d->N <= 64 && v6_ok<9, 1, 2, 1>(d, ldz)) rc = launch_wgrad6<9, 1, 2, 1>(a, d, dW, partials, st, &p6);
     else if (d->ntaps == 9 && d->N <= 32 && v6_ok<9, 1, 1, 1>(d, ldz)) rc = launch_wgrad6<9, 1, 1, 1>(a, d, dW, partials, st, &p6);
-    else if (d->ntaps == 1 && v6_dense_enabled() && (long)asr_cdiv(d->K, 128) * asr_cdiv(d->N, 128) >= 4 && v6_ok<1, 4, 4, 1>(d, ldz)) rc = launch_wgrad6<1, 4, 4, 1>(a, d, dW, partials, st, &p6);
+    else if (d->ntaps == 1 && (long)asr_cdiv(d->K, 128) * asr_cdiv(d->N, 128) >= 4 && v6_ok<1, 4, 4, 1>(d, ldz)) rc = launch_wgrad6<1, 4, 4, 1>(a, d, dW, partials, st, &p6);
     else is6 = false;
     if (is6) {
         if (rc != ASR_OK) return rc;
@@ -1174,58 +825,6 @@ extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float
         const int threads = 64;
         const int blocks = asr_cdiv(asr_cdiv(n, 4), threads);
         hipLaunchKernelGGL(sum_chunks_kernel, dim3(blocks), dim3(threads), 0, st, partials, dW, n, p.nchunks);
-        ASR_CHECK_LAUNCH("sum_chunks");
-    }
-    return ASR_OK;
-}
-
-
-// EXPERIMENTAL split-bf16 weight gradient (3x3 taps, N >= 128 and K >= 32): same contract as asr_tap_wgrad
-extern "C" int asr_tap_wgrad_bx6(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz,
-                                 float* dW, float* partials, void* stream) {
-    if (!d || !A || !dZ || !dW) return ASR_ERR_BAD_ARG;
-    if (d->ntaps != 9 || d->H <= 0 || d->N <= 64) return ASR_ERR_UNSUPPORTED;
-    if ((d->K & 3) || (d->N & 3) || (d->lda & 3) || (ldz & 3)) return ASR_ERR_BAD_ARG;
-    // ktile 32, ntile 128; two workgroups per CU (144 accumulator registers): aim at exactly one round of them.  The run
-    // length PS is 64 pixels while TWO workgroups' tiles fit the 160 KB of LDS, else 48 (planes 33..64 wide: the halo
-    // rows of the A image grow with the plane width) -- dropping to one workgroup per CU costs 40 %.
-    static int tb = 0;
-    if (!tb) { const char* e = getenv("ASR_BX6_WBLOCKS"); tb = e ? atoi(e) : 512; }
-    static int apz = 0, zpz = 0;
-    if (!apz) {
-        apz = 72; zpz = 264;
-        const char* e = getenv("ASR_BX6_PITCH");
-        if (e) { int x = 0, y = 0; if (sscanf(e, "%d,%d", &x, &y) == 2 && x >= 64 && y >= 256 && !(x & 7) && !(y & 7)) { apz = x; zpz = y; } }
-    }
-    auto lds_for = [&](int ps) { return ((size_t)3 * (ps + 2 * (d->W + 2)) * apz + 15) / 16 * 16 + (size_t)3 * ps * zpz; };
-    const int PSsel = (2 * lds_for(64) <= 160 * 1024) ? 64 : 48;
-    const Plan p = make_plan(d, tb, 128, PSsel);
-    if (p.nchunks > 1 && !partials) return ASR_ERR_BAD_ARG;
-    WgradArgs a;
-    a.A = A; a.Z = dZ; a.out = (p.nchunks > 1) ? partials : dW;
-    a.M = d->M; a.K = d->K; a.N = d->N; a.lda = d->lda; a.ldz = ldz;
-    a.WP = d->W + 1;
-    a.halo = a.WP + 1;
-    a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
-    a.pch = p.pch;
-    a.slab = (long)d->ntaps * d->K * d->N;
-    hipStream_t st = (hipStream_t)stream;
-    a.ap = apz; a.zp = zpz;
-    const size_t lds = lds_for(PSsel);
-    if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
-    const dim3 grid(p.nchunks, asr_cdiv(d->K, 32), asr_cdiv(d->N, 128));
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)tap_wgrad_kernel_bx6<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)tap_wgrad_kernel_bx6<48>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    if (PSsel == 64) { hipLaunchKernelGGL(tap_wgrad_kernel_bx6<64>, grid, dim3(256), lds, st, a); ASR_NOTE_KERNEL("tap_wgrad_kernel_bx6<64>"); }
-    else { hipLaunchKernelGGL(tap_wgrad_kernel_bx6<48>, grid, dim3(256), lds, st, a); ASR_NOTE_KERNEL("tap_wgrad_kernel_bx6<48>"); }
-    ASR_CHECK_LAUNCH("tap_wgrad_bx6");
-    if (p.nchunks > 1) {
-        const long n = a.slab;
-        hipLaunchKernelGGL(sum_chunks_kernel, dim3(asr_cdiv(asr_cdiv(n, 4), 64)), dim3(64), 0, st, partials, dW, n, p.nchunks);
         ASR_CHECK_LAUNCH("sum_chunks");
     }
     return ASR_OK;

@@ -15,9 +15,9 @@
 //     of the tiles -- which go through the SAME epilogues as the tap-GEMM kernels (tap_epilogue: bias / ReLU / BN affine /
 //     accumulate / the gated backward prologues) via their row tables; for a pooled cell the 2x2 pool of the BN output is
 //     formed from those four pixels in registers (asr_tap_gemm_wino_pool).
-// Two kernels: wino8_kernel (default; eight waves, the sixteen positions split 8 + 8 over the two waves of a SIMD, persistent
-// workgroups, DMA pieces between the MFMAs) and the first, four-wave wino_kernel (sixteen accumulators per wave, one wave per
-// SIMD; ASR_WINO8=0), kept as the reference form of the same arithmetic.
+// wino8_kernel: eight waves, the sixteen positions split 8 + 8 over the two waves of a SIMD, persistent workgroups, DMA pieces
+// between the MFMAs.  (The first, four-wave form -- sixteen accumulators per wave, one wave per SIMD -- kept the matrix pipe
+// busy 34 % of the time and was removed in round 3.)
 // Planes as everywhere else ([B][H+1][W+1][C], zero borders): patch rows / columns that stick out read the border; an odd
 // plane width needs the fourth patch column of the last tile column zeroed (it would wrap into the next pixel row).
 #include "asr_common.h"
@@ -36,7 +36,6 @@ struct WinoArgs {
     int TH, TW;             // tile rows / columns per image
     long ntiles;            // B * TH * TW
     int wodd;               // plane width is odd
-    int xcd_order;          // eight-wave kernel: items of a round grouped by XCD (ASR_WINO_XCD, default 1)
     float* pool_y;          // eight-wave kernel: pooled BN output plane [B][H/2+1][W/2+1][N] of a fused 2x2 pool, or null
     int pool_mode, H2, W2;  // 1 average, 2 maximum
 };
@@ -78,248 +77,7 @@ __global__ void wino_weights_kernel(const float* __restrict__ W, int K, int N, i
     }
 }
 
-// DMA of one chunk: the raw patches (32 pieces: pixel x quad, 64 tiles each) and the weights (32 pieces of 4 rows x 64 channels);
-// wave w issues pieces w, w + 4, ...
-// Addresses are a wave-uniform pointer (scalar registers, scalar arithmetic) plus a 32-bit per-lane byte offset that never
-// changes: no vector instruction per piece.
-__device__ __forceinline__ void wino_stage(float* __restrict__ raw, float* __restrict__ ub, const char* __restrict__ abase,
-                                           unsigned off_t0, unsigned off_t1, const char* __restrict__ ubase, unsigned off_u,
-                                           int WPl, int lda, long ustride_xi, int N, int kc, int wave) {
-    // raw: piece = pixel * 2 + tile half; a lane fetches quad (lane & 1) of tile half * 32 + lane / 2 -- the two quads of a
-    // pixel are 32 contiguous bytes fetched by neighbouring lanes (one 64-byte request instead of two)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int p = wave + 4 * j;
-        const int px = p >> 1, th = p & 1;
-        const int r = px >> 2, c = px & 3;
-        const char* pb = abase + (((long)r * WPl + c) * lda + kc * WKC) * 4;          // uniform
-        __builtin_amdgcn_global_load_lds((wn_glb_f*)(pb + (th ? off_t1 : off_t0)), (wn_lds_f*)(raw + p * 256), 16, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int p = wave + 4 * j;                  // piece = xi * 2 + (ci >> 2)
-        const int xi = p >> 1, cig = p & 1;
-        const char* pb = ubase + (xi * ustride_xi + (long)(kc * WKC + cig * 4) * N) * 4;   // uniform
-        __builtin_amdgcn_global_load_lds((wn_glb_f*)(pb + off_u), (wn_lds_f*)(ub + p * 256), 16, 0, 0);
-    }
-}
-
-// one chunk of 8 input channels = four batches (channel quad x pair member) of one patch transform + 16 MFMAs.  One wave
-// per SIMD: nothing hides an LDS wait, so the operands of batch b + 1 (its 16 weights, and the raw pixels of the next
-// quad) are requested BEFORE the transform and the MFMAs of batch b.  The transform's adds must NOT be interleaved with
-// the MFMAs (hipcc sinks each add to just before the MFMA that consumes it): on this pipe a vector instruction behind an
-// fp32 MFMA waits for the MFMA to finish and the next MFMA pays again (tools/mfma_valu.hip: 1 MFMA + 4 v_fma = 129
-// cycles, not 64 + 16) -- alternating costs a whole extra MFMA time per MFMA.
-__device__ __forceinline__ void wino_transform(const float2 (&d)[16], int kk, float (&v)[16]) {
-    float t[4][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float d0 = kk ? d[0 + c].y : d[0 + c].x, d1 = kk ? d[4 + c].y : d[4 + c].x;
-        const float d2 = kk ? d[8 + c].y : d[8 + c].x, d3 = kk ? d[12 + c].y : d[12 + c].x;
-        t[0][c] = d0 - d2; t[1][c] = d1 + d2; t[2][c] = d2 - d1; t[3][c] = d1 - d3;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        v[r * 4 + 0] = t[r][0] - t[r][2]; v[r * 4 + 1] = t[r][1] + t[r][2];
-        v[r * 4 + 2] = t[r][2] - t[r][1]; v[r * 4 + 3] = t[r][1] - t[r][3];
-    }
-}
-
-__device__ __forceinline__ void wino_chunk(const float* __restrict__ raw, const float* __restrict__ ub, float* __restrict__ rawn,
-                                           float* __restrict__ ubn, bool prefetch, const char* __restrict__ abase,
-                                           unsigned off_t0, unsigned off_t1, const char* __restrict__ ubase, unsigned off_u,
-                                           int WPl, int lda, long ustride_xi, int N, int kcn, int wave,
-                                           int aoff, int boff, bool wodd, bool zero_c3, floatx16 (&acc)[16]) {
-    auto load_d = [&](float2 (&d)[16], int quad) {
-#pragma unroll
-        for (int px = 0; px < 16; ++px) d[px] = *(const float2*)(raw + (px * WT * 2 + quad) * 4 + aoff);
-    };
-    // channel of this lane in the chunk: 4 quad + 2 half + kk (the pairing of channels into MFMA k-pairs is free)
-    auto load_u = [&](float (&u)[16], int quad, int kk) {
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) u[xi] = ub[(xi * WKC + quad * 4 + kk) * WC + boff];
-    };
-    auto fix_d = [&](float2 (&d)[16]) {
-        if (wodd) {              // uniform: only odd-width planes pay for the selects
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (zero_c3) d[r * 4 + 3] = make_float2(0.f, 0.f);
-        }
-    };
-    auto mfmas = [&](const float (&v)[16], const float (&u)[16]) {
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[xi], u[xi], acc[xi], 0, 0, 0);
-    };
-    float2 d[16];
-    float ua[16], ubb[16], v[16];
-    load_d(d, 0);
-    load_u(ua, 0, 0);
-    if (prefetch) wino_stage(rawn, ubn, abase, off_t0, off_t1, ubase, off_u, WPl, lda, ustride_xi, N, kcn, wave);
-    __builtin_amdgcn_sched_barrier(0);
-    // batch 0
-    load_u(ubb, 0, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    fix_d(d);
-    wino_transform(d, 0, v);
-    __builtin_amdgcn_sched_barrier(0);     // all 32 adds first, then 16 MFMAs back to back (see above)
-    mfmas(v, ua);
-    __builtin_amdgcn_sched_barrier(0);
-    // batch 1: the raw pixels of quad 0 are dead after this transform -- quad 1 is fetched into the same registers
-    load_u(ua, 1, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    wino_transform(d, 1, v);
-    __builtin_amdgcn_sched_barrier(0);
-    load_d(d, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(v, ubb);
-    __builtin_amdgcn_sched_barrier(0);
-    // batch 2
-    load_u(ubb, 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    fix_d(d);
-    wino_transform(d, 0, v);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(v, ua);
-    __builtin_amdgcn_sched_barrier(0);
-    // batch 3
-    wino_transform(d, 1, v);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(v, ubb);
-}
-
-// per-lane DMA offsets of one work item (tile block blk, channel block nb)
-__device__ __forceinline__ void wino_offsets(const WinoArgs& args, long t0, int n0, int lane, unsigned (&off_t)[2], unsigned& off_u) {
-    const TapGemmArgs& g = args.g;
-#pragma unroll
-    for (int th = 0; th < 2; ++th) {
-        // quad (lane & 1) of tiles t0 + lane / 2 and t0 + 32 + lane / 2 (clamped): byte offset of the top-left pixel of the
-        // patch in the plane (planes are < 4 GB)
-        long t = t0 + th * 32 + (lane >> 1);
-        if (t > args.ntiles - 1) t = args.ntiles - 1;
-        const int per = args.TH * args.TW;
-        const int b = (int)(t / per);
-        const int rr = (int)(t - (long)b * per);
-        const int ti = rr / args.TW, tj = rr - ti * args.TW;
-        off_t[th] = (unsigned)((((long)b * g.HPWP + (long)(2 * ti) * g.WP + 2 * tj) * g.lda + (lane & 1) * 4) * 4);
-    }
-    // weights: row lane / 16 of a 4-row piece, column quad lane % 16
-    off_u = (unsigned)(((long)(lane >> 4) * g.N + n0 + (lane & 15) * 4) * 4);
-}
-
-// Persistent workgroups (one per CU): work item = (tile block, channel block), channel blocks of one tile block adjacent.
-// The first chunk of the NEXT item is requested before the epilogue of the current one, so its latency and the epilogue's
-// stores overlap -- with one workgroup per CU nothing else would cover them.
-template <int DIR>
-__global__ __launch_bounds__(256, 1) void wino_kernel(WinoArgs args) {
-    const TapGemmArgs& g = args.g;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    int* rowa = (int*)smem;                          // [2 wave rows][4 pixels][32 tiles]
-    int* rowy = rowa + 256;
-    float* bufs = smem + 512;                        // raw0 | raw1 | u0 | u1
-    float* scratch = bufs + 2 * RAW_F + 2 * U_F;     // epilogue transpose scratch, 4 waves x 32 x 33
-
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int nnb = g.ntn;                           // channel blocks
-    const int nwork = g.ntm * nnb;
-    const char* abase = (const char*)g.A;
-    const char* ubase = (const char*)args.Ut;
-    const long ustride_xi = (long)g.K * g.N;
-    const int aoff = (wm * 32 + li) * 8 + lh * 2;    // this lane's pair: slot (tile, quad) of a pixel row, half lh
-    const int boff = lh * 2 * WC + wn * 32 + li;     // half 1 reads channel + 2
-    const int nkc = g.K / WKC;
-
-    int w = blockIdx.x;
-    if (w >= nwork) return;
-    unsigned off_t[2], off_u;
-    {
-        const int blk = w / nnb, nb = w - blk * nnb;
-        wino_offsets(args, (long)blk * WT, nb * WC, lane, off_t, off_u);
-    }
-    int cur = 0;
-    wino_stage(bufs, bufs + 2 * RAW_F, abase, off_t[0], off_t[1], ubase, off_u, g.WP, g.lda, ustride_xi, g.N, 0, wave);
-
-    for (; w < nwork; w += gridDim.x) {
-        const int blk = w / nnb, nb = w - blk * nnb;
-        const long t0 = (long)blk * WT;
-        const int n0 = nb * WC;
-        // row tables of the epilogue: local row = wm * 128 + pixel * 32 + tile (the previous item's epilogue has finished
-        // with them: it ends with a barrier)
-        {
-            const int tl = tid & 63, pl = tid >> 6;      // 64 tiles x 4 pixels = 256 entries
-            const long t = t0 + tl;
-            int ra = -1, ry = -1;
-            if (t < args.ntiles) {
-                const int per = args.TH * args.TW;
-                const int b = (int)(t / per);
-                const int rr = (int)(t - (long)b * per);
-                const int ti = rr / args.TW, tj = rr - ti * args.TW;
-                const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
-                if (ww <= g.Wd) {
-                    ra = (int)((long)b * g.HPWP + (long)hh * g.WP + ww);
-                    ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : ra;
-                }
-            }
-            const int m = (tl >> 5) * 128 + pl * 32 + (tl & 31);
-            rowa[m] = ra; rowy[m] = ry;
-        }
-        // does this lane's (compute) tile sit in the last tile column of an odd-width plane?
-        bool zero_c3 = false;
-        if (args.wodd) {
-            long t = t0 + wm * 32 + li;
-            if (t > args.ntiles - 1) t = args.ntiles - 1;
-            zero_c3 = (int)(t % args.TW) == args.TW - 1;
-        }
-
-        floatx16 acc[16];
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
-
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // chunk 0 of this item (requested before the previous epilogue) has landed
-        __syncthreads();
-
-        for (int kc = 0; kc < nkc; ++kc) {
-            wino_chunk(bufs + cur * RAW_F, bufs + 2 * RAW_F + cur * U_F, bufs + (cur ^ 1) * RAW_F, bufs + 2 * RAW_F + (cur ^ 1) * U_F,
-                       kc + 1 < nkc, abase, off_t[0], off_t[1], ubase, off_u, g.WP, g.lda, ustride_xi, g.N, kc + 1, wave, aoff, boff,
-                       args.wodd != 0, zero_c3, acc);
-            if (kc + 1 < nkc) {
-                __builtin_amdgcn_s_waitcnt(0x0F70);  // the next chunk has landed
-                __syncthreads();
-                cur ^= 1;
-            }
-        }
-        // every wave has issued its last reads of buffer `cur`; the other buffer is free: the next item's first chunk goes there
-        const int wnext = w + gridDim.x;
-        if (wnext < nwork) {
-            const int blk2 = wnext / nnb, nb2 = wnext - blk2 * nnb;
-            wino_offsets(args, (long)blk2 * WT, nb2 * WC, lane, off_t, off_u);
-            wino_stage(bufs + (cur ^ 1) * RAW_F, bufs + 2 * RAW_F + (cur ^ 1) * U_F, abase, off_t[0], off_t[1], ubase, off_u, g.WP, g.lda,
-                       ustride_xi, g.N, 0, wave);
-        }
-        cur ^= 1;
-
-        // inverse transform, lane-local: register r of the 16 accumulators is one tile.  Two pixel rows of the tiles at a
-        // time (32 live output registers beside the 256 accumulators instead of 64)
-#pragma unroll
-        for (int pair = 0; pair < 2; ++pair) {
-            floatx16 out[2][1];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float sx[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    sx[c] = pair == 0 ? (acc[0 + c][r] + acc[4 + c][r]) + acc[8 + c][r] : (acc[4 + c][r] - acc[8 + c][r]) - acc[12 + c][r];
-                out[0][0][r] = (sx[0] + sx[1]) + sx[2];
-                out[1][0][r] = (sx[1] - sx[2]) - sx[3];
-            }
-            tap_epilogue<2, 1>(g, out, scratch + wave * (32 * 33), rowa, rowy, wm * 128 + pair * 64, n0 + wn * 32, lane, (blk * 2 + wm) * 2 + pair);
-        }
-        __syncthreads();                             // the row tables are rewritten by the next item
-    }
-}
-
-// ---- eight waves per workgroup: the same 64 tiles x 64 channels, the sixteen positions split between the two waves of a
+// ---- eight waves per workgroup: 64 tiles x 64 channels, the sixteen positions split between the two waves of a
 // SIMD (wave xh owns transform columns 2 xh and 2 xh + 1: 8 accumulators = 128 registers), so that two waves cover each
 // other's stalls -- with one wave per SIMD the pipe was busy 34 % of the time.  A wave needs three patch columns (12
 // pixels, 20 adds per 8 MFMAs); the two halves meet once per item: each wave finishes one pixel ROW of the tiles and gets
@@ -495,7 +253,7 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
     const int G = gridDim.x;
     auto item_of = [&](int wl) {
         const int r0 = (wl / G) * G;
-        if ((G & 7) || args.xcd_order == 0 || r0 + G > nwork) return wl;
+        if ((G & 7) || r0 + G > nwork) return wl;
         const int p = wl - r0;
         return r0 + (p & 7) * (G >> 3) + (p >> 3);
     };
@@ -710,8 +468,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     a.halo = a.WP + 1;
     a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
     a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
-    a.ablate = 0;
-    { static int nts = -1; if (nts < 0) { const char* e = getenv("ASR_WINO_NT"); nts = e ? atoi(e) : 1; } a.nt_store = nts; }     // streaming stores: -2..3 % per layer (the planes do not fit L2 anyway)
+    a.nt_store = 1;       // streaming stores: -2..3 % per layer (the planes do not fit L2 anyway)
     a.gate_mode = 0; a.gate_H = a.gate_W = 0; a.gate_a = nullptr; a.gate_dz = nullptr; a.gate_part = nullptr; a.gate_rows = nullptr;
     if (gs) { a.gate_mode = gs->mode; a.gate_H = gs->H; a.gate_W = gs->W; a.gate_a = gs->a; a.gate_dz = gs->dz; a.gate_part = gs->part; a.gate_rows = gs->rows; }
     w.Ut = Ut;
@@ -719,63 +476,31 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     w.ntiles = (long)d->B * w.TH * w.TW;
     w.wodd = d->W & 1;
     w.pool_y = pool_y; w.pool_mode = pool_mode; w.H2 = d->H / 2; w.W2 = d->W / 2;
-    { static int xo = -1; if (xo < 0) { const char* e = getenv("ASR_WINO_XCD"); xo = e ? atoi(e) : 1; } w.xcd_order = xo; }
     const int nblk = asr_cdiv(w.ntiles, WT);
     a.ntm = nblk; a.ntn = d->N / WC;
     if (a.gate_rows) *a.gate_rows = nblk * 4;
-    const size_t lds = (size_t)(512 + 2 * RAW_F + 2 * U_F + 4 * 32 * 33) * sizeof(float);
-    static int ncu = 0;
-    if (!ncu) {
+    const size_t lds8 = (size_t)(576 + 2 * RAW_F + 2 * U_F) * sizeof(float);
+    static_assert(4 * 2048 <= RAW_F && 4 * 2048 <= U_F && 4 * 32 * 33 + 2 * 1024 <= RAW_F && 4 * 32 * 33 + 2 * 1024 <= U_F, "exchange / scratch + pool hand-over must fit in one buffer set");
+    static int ncu8 = 0;
+    if (!ncu8) {
         int dev = 0; hipDeviceProp_t pr;
-        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+        ncu8 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
     }
-    const int nwork = nblk * a.ntn;
-    static int w8 = -1;
-    if (w8 < 0) { const char* e = getenv("ASR_WINO8"); w8 = e ? atoi(e) : 1; }
-    if (w8) {
-        const size_t lds8 = (size_t)(576 + 2 * RAW_F + 2 * U_F) * sizeof(float);
-        static_assert(4 * 2048 <= RAW_F && 4 * 2048 <= U_F && 4 * 32 * 33 + 2 * 1024 <= RAW_F && 4 * 32 * 33 + 2 * 1024 <= U_F, "exchange / scratch + pool hand-over must fit in one buffer set");
-        static int ncu8 = 0;
-        if (!ncu8) {
-            int dev = 0; hipDeviceProp_t pr;
-            ncu8 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
-        }
-        static int pers = -1;
-        if (pers < 0) { const char* e = getenv("ASR_WINO_PERSIST"); pers = e ? atoi(e) : 1; }
-        const int nwork8 = nblk * a.ntn;
-        const int grid8 = (pers && nwork8 > ncu8) ? ncu8 : nwork8;
-        auto q0 = wino8_kernel<0>;
-        auto q1 = wino8_kernel<1>;
-        static bool b0 = false, b1 = false;
-        hipStream_t st8 = (hipStream_t)stream;
-        if (d->wmode) {
-            if (!b1) { (void)hipFuncSetAttribute((const void*)q1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); b1 = true; }
-            hipLaunchKernelGGL(q1, dim3(grid8), dim3(512), lds8, st8, w);
-        } else {
-            if (!b0) { (void)hipFuncSetAttribute((const void*)q0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); b0 = true; }
-            hipLaunchKernelGGL(q0, dim3(grid8), dim3(512), lds8, st8, w);
-        }
-        ASR_CHECK_LAUNCH("tap_gemm_wino8");
-        if (d->wmode) ASR_NOTE_KERNEL("wino8_kernel<1>"); else ASR_NOTE_KERNEL("wino8_kernel<0>");     // one name per call site
-        return ASR_OK;
-    }
-    if (pool_y) return ASR_ERR_UNSUPPORTED;             // the fused pool lives in the eight-wave kernel only
-    static int gmul = -1;
-    if (gmul < 0) { const char* e = getenv("ASR_WINO_GRID"); gmul = e ? atoi(e) : 1; }       // 0: one workgroup per work item
-    const int grid = (gmul <= 0 || nwork < ncu * gmul) ? nwork : ncu * gmul;
-    auto k0 = wino_kernel<0>;
-    auto k1 = wino_kernel<1>;
-    static bool attr0 = false, attr1 = false;
-    hipStream_t st = (hipStream_t)stream;
+    const int nwork8 = nblk * a.ntn;
+    const int grid8 = nwork8 > ncu8 ? ncu8 : nwork8;        // persistent: one workgroup per CU
+    auto q0 = wino8_kernel<0>;
+    auto q1 = wino8_kernel<1>;
+    static bool b0 = false, b1 = false;
+    hipStream_t st8 = (hipStream_t)stream;
     if (d->wmode) {
-        if (!attr1) { (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
-        hipLaunchKernelGGL(k1, dim3(grid), dim3(256), lds, st, w);
+        if (!b1) { (void)hipFuncSetAttribute((const void*)q1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); b1 = true; }
+        hipLaunchKernelGGL(q1, dim3(grid8), dim3(512), lds8, st8, w);
     } else {
-        if (!attr0) { (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr0 = true; }
-        hipLaunchKernelGGL(k0, dim3(grid), dim3(256), lds, st, w);
+        if (!b0) { (void)hipFuncSetAttribute((const void*)q0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); b0 = true; }
+        hipLaunchKernelGGL(q0, dim3(grid8), dim3(512), lds8, st8, w);
     }
-    ASR_CHECK_LAUNCH("tap_gemm_wino");
-    if (d->wmode) ASR_NOTE_KERNEL("wino_kernel<1>"); else ASR_NOTE_KERNEL("wino_kernel<0>");
+    ASR_CHECK_LAUNCH("tap_gemm_wino8");
+    if (d->wmode) ASR_NOTE_KERNEL("wino8_kernel<1>"); else ASR_NOTE_KERNEL("wino8_kernel<0>");     // one name per call site
     return ASR_OK;
 }
 
@@ -794,12 +519,6 @@ extern "C" int asr_pool_fwd(const float* a, int B, int H, int W, int C, const fl
 extern "C" int asr_tap_gemm_wino_pool(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale,
                                       const float* shift, float* out_a, int pool, float* y_pooled, void* stream) {
     if (!d || !out_a || !y_pooled || !scale || !shift || (pool != 1 && pool != 2) || d->ldo_a != d->N) return ASR_ERR_BAD_ARG;
-    static int w8 = -1;
-    if (w8 < 0) { const char* e = getenv("ASR_WINO8"); w8 = e ? atoi(e) : 1; }
-    if (!w8) {                                       // four-wave fallback kernel: two launches
-        const int rc = wino_impl(d, A, Ut, bias, scale, shift, out_a, nullptr, stream, nullptr);
-        return rc != ASR_OK ? rc : asr_pool_fwd(out_a, d->B, d->H, d->W, d->N, scale, shift, pool, y_pooled, stream);
-    }
     return wino_impl(d, A, Ut, bias, scale, shift, out_a, nullptr, stream, nullptr, y_pooled, pool);
 }
 

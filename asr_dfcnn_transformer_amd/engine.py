@@ -152,8 +152,16 @@ def param_layout(g):
 
 class DFCNNEngine:
     def __init__(self, model='m2', vocab=1536, B=32, T=1600, F=200, widths=None, seed=0, device='cuda',
-                 lr=7e-4, decay_steps=5000, min_lr=1e-6, beta1=0.9, beta2=0.999, adam_eps=1e-8):
+                 lr=7e-4, decay_steps=5000, min_lr=1e-6, beta1=0.9, beta2=0.999, adam_eps=1e-8,
+                 dual_stream=None, wino=None, fuse_prologues=True):
+        """``dual_stream`` (default: environment ASR_DUAL_STREAM, else on): weight gradients / decode on a second stream;
+        ``wino`` (default: ASR_WINO, else on): Winograd F(2x2,3x3) for the 3x3 layers it supports instead of the direct
+        tap-GEMM; ``fuse_prologues``: cell backward prologues inside the data-gradient epilogues.  Each of them leaves the
+        results bitwise (streams, fusion) or to rounding (Winograd) unchanged; they exist for A/B measurements and tests."""
         assert T % 8 == 0 and F >= 8
+        self.opt_dual = (os.environ.get('ASR_DUAL_STREAM', '1') == '1') if dual_stream is None else bool(dual_stream)
+        self.opt_wino = (os.environ.get('ASR_WINO', '1') == '1') if wino is None else bool(wino)
+        self.opt_fuse = bool(fuse_prologues)
         self.model, self.V, self.B, self.T, self.F = model, vocab, B, T, F
         self.device = device
         self.g = graph(model, vocab, widths, F)
@@ -310,10 +318,10 @@ class DFCNNEngine:
                 self.wdesc[dst] = ops.gemm_desc(rows, cin, cout, cin, cout, ntaps=1)
                 ws_bytes = max(ws_bytes, ops.tap_wgrad_workspace(self.wdesc[dst]), ops.colsum_workspace(rows, cout))
                 # a deep contraction with few output tiles (6400 -> 128: 200 workgroups of 200 chunk steps) is split eight ways
-                # over the grid (asr_tap_gemm_splitk: 185 -> 124 us with the second pass; ASR_SPLITK=0: off)
+                # over the grid (asr_tap_gemm_splitk: 185 -> 124 us with the second pass)
                 # (decided by the layer's widths only, never by the batch: an utterance alone must give bitwise the logits it
                 # gives inside a batch, tests/test_fullsize_gpu.py)
-                if os.environ.get('ASR_SPLITK', '1') == '1' and cout <= 128 and cin >= 2048 and cin % 256 == 0:
+                if cout <= 128 and cin >= 2048 and cin % 256 == 0:
                     self.splitk[dst] = 8
                     ws_bytes = max(ws_bytes, ops.tap_gemm_splitk_workspace(self.fdesc[dst], 8))
         self.T8 = self.res[self.g[-1][2]][0]
@@ -333,68 +341,40 @@ class DFCNNEngine:
         self.dist = torch.zeros(B, dtype=torch.float32, device=dev)
         self.scalars = torch.zeros(8, dtype=torch.float32, device=dev)     # [0] sum loss, [1] sum dist
         self.ws = torch.zeros(ws_bytes // 4 + 64, dtype=torch.float32, device=dev)
-        # Second stream for the backward pass (ASR_DUAL_STREAM=0 turns it off): the weight-gradient of a cell (MFMA-bound)
-        # runs beside its data-gradient and the NEXT cell's HBM-bound backward prologue -- they only share the
+        # Second stream for the backward pass (dual_stream=False / ASR_DUAL_STREAM=0 turns it off): the weight-gradient of a cell
+        # (MFMA-bound) runs beside its data-gradient and the NEXT cell's HBM-bound backward prologue -- they only share the
         # read-only dZ plane -- so one kernel's last partial round of workgroups is filled by the others and the
         # HBM-bound prologues hide under MFMA work (+6 % M1, +8 % M2 at B = 32).  Per-kernel durations of the
         # overlapped kernels then overlap in any profile.  Results are bitwise the same as with one stream.
-        self.side = torch.cuda.Stream(device=dev) if os.environ.get('ASR_DUAL_STREAM', '1') == '1' else None
-        self.wgrad_first = os.environ.get('ASR_WGRAD_FIRST', '0') == '1'
-        # experiment switch: start a weight-gradient only when its data-gradient has finished.  Before the backward
-        # prologues were fused into the data-gradient epilogues it was worth +1.6 % on the SE graphs (more HBM-bound kernels
-        # between the contractions to run beside), -1 % on acoustic_model.py; with the fusion it loses on both
-        # (gpurun_out/r02b/bench6.txt, r02h): off
-        self.wgrad_after_dgrad = os.environ.get('ASR_WGRAD_AFTER_DGRAD', '0') == '1'
-        if os.environ.get('ASR_SIDE_PRIO'):              # experiment: explicit priority of the side stream
-            self.side = torch.cuda.Stream(device=dev, priority=int(os.environ['ASR_SIDE_PRIO']))
+        # (The data-gradient is enqueued before the weight gradient -- it is on the critical path; starting the weight gradient
+        # first or only after the data-gradient has finished were measured in round 2 and lose on both graphs.)
+        self.side = torch.cuda.Stream(device=dev) if self.opt_dual else None
         self.ws_side = torch.zeros_like(self.ws) if self.side is not None else None
         # with the side stream every geometry gets a second dZ plane, used alternately, so the next cell's (HBM-bound)
         # backward prologue can run while the previous weight-gradient (MFMA-bound) still reads the other one
         self.dz_alt = {geo: Plane(p.B, p.H, p.W, p.C, dev) for geo, p in self.dz_pool.items()} if self.side is not None else {}
         self._decode_done = None
-        # EXPERIMENTAL (ASR_BX6=1): forward and data-gradient of the 3x3 convs on the split-bf16
-        # kernels.  The fp32 weights stay the parameters; their hi/mid/lo bf16 pieces (forward view and mirrored
-        # data-gradient view) are regenerated at the start of every forward pass.
-        self.bx6 = os.environ.get('ASR_BX6', '0') == '1'
-        if self.bx6 and B < 2:
-            # known issue of the EXPERIMENTAL mode: the full-width one-utterance SE-DFCNN step faults in one of
-            # the split-bf16 kernels; the mode is measured and tested at B >= 2 only -- refuse rather than fault
-            raise ValueError('ASR_BX6=1 (experimental split-bf16 convolutions) needs a batch of at least 2 utterances')
-        self.ws_f, self.ws_b = {}, {}
         self._cell_dims = {op[2]: (op[3], op[4]) for op in self.g if op[0] == 'cell'}
-        if self.bx6:
-            for op in self.g:
-                if op[0] == 'cell' and op[1] != 'x' and op[5] == 3:
-                    _, src, dst, cin, cout, k, pool = op
-                    self.ws_f[dst] = torch.zeros(ops.split_weights_bytes(9, cin, cout), dtype=torch.uint8, device=dev)
-                    self.ws_b[dst] = torch.zeros(ops.split_weights_bytes(9, cout, cin), dtype=torch.uint8, device=dev)
         # 3x3 convs (forward and data-gradient) on weights pre-arranged in MFMA fragment order (asr_arrange_weights /
-        # asr_tap_gemm_pw: same fp32 arithmetic, no weight tile in LDS, +6..20 % per layer; ASR_PW=0 = asr_tap_gemm).
+        # asr_tap_gemm_pw: same fp32 arithmetic, no weight tile in LDS, +6..20 % per layer over asr_tap_gemm).
         # Both views are regenerated from the fp32 parameters at the start of every forward pass.
-        self.pw = os.environ.get('ASR_PW', '1') == '1' and not self.bx6
         self.wf_f, self.wf_b = {}, {}
-        if self.pw:
-            for op in self.g:
-                if op[0] == 'cell' and op[1] != 'x' and op[5] == 3:
-                    _, src, dst, cin, cout, k, pool = op
-                    self.wf_f[dst] = torch.zeros(ops._lib.load().asr_arrange_weights_bytes(9, cin, cout) // 4, dtype=torch.float32, device=dev)
-                    self.wf_b[dst] = torch.zeros(ops._lib.load().asr_arrange_weights_bytes(9, cout, cin) // 4, dtype=torch.float32, device=dev)
+        for op in self.g:
+            if op[0] == 'cell' and op[1] != 'x' and op[5] == 3:
+                _, src, dst, cin, cout, k, pool = op
+                self.wf_f[dst] = torch.zeros(ops._lib.load().asr_arrange_weights_bytes(9, cin, cout) // 4, dtype=torch.float32, device=dev)
+                self.wf_b[dst] = torch.zeros(ops._lib.load().asr_arrange_weights_bytes(9, cout, cin) // 4, dtype=torch.float32, device=dev)
         # Winograd F(2x2,3x3) kernels (wino.hip) for the 3x3 convs they support, forward and data-gradient (plain and gated):
-        # 16 instead of 36 multiplies per 2x2 output tile, still fp32; 1.15-1.35x the tap-GEMM per layer.  Forward alone is
-        # step -2.4 % (M1) / -1.7 % (M2); the data-gradients add -1.7 % / -3.2 % with the persistent kernel (its workgroups
-        # take whole CUs, so beside the weight-gradient stream the two kernels take turns rather than share CUs).
-        # ASR_WINO_DIRS=f keeps the data-gradients on the tap-GEMM; ASR_WINO=0 turns all of it off.
-        self.wino = os.environ.get('ASR_WINO', '1') == '1' and self.pw
+        # 16 instead of 36 multiplies per 2x2 output tile, still fp32; 1.3-1.6x the tap-GEMM per layer.  For a pooled cell
+        # the 2x2 pool is computed inside the forward launch.  wino=False / ASR_WINO=0 keeps every layer on the tap-GEMM.
         self.wt_f, self.wt_b = {}, {}
-        self.fuse_pool = os.environ.get('ASR_WINO_POOL', '1') == '1'      # pooled cells: pool inside the Winograd forward launch
-        if self.wino:
-            which = os.environ.get('ASR_WINO_DIRS', 'fb')
+        if self.opt_wino:
             for op in self.g:
                 if op[0] == 'cell' and op[1] != 'x' and op[5] == 3:
                     _, src, dst, cin, cout, k, pool = op
-                    if 'f' in which and ops.winograd_supported(self.fdesc[dst]):
+                    if ops.winograd_supported(self.fdesc[dst]):
                         self.wt_f[dst] = torch.zeros(16 * cin * cout, dtype=torch.float32, device=dev)
-                    if 'b' in which and ops.winograd_supported(self.bdesc[dst]):
+                    if ops.winograd_supported(self.bdesc[dst]):
                         self.wt_b[dst] = torch.zeros(16 * cin * cout, dtype=torch.float32, device=dev)
         self.labels = torch.zeros(B, MAX_LABEL, dtype=torch.int32, device=dev)
         self.label_len = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -427,10 +407,10 @@ class DFCNNEngine:
         gated cell}.  The gradient plane of a cell's output may receive several contributions (an SE block's identity
         branch is the plane itself, other consumers accumulate); the prologue can only run on the sum, i.e. in the LAST
         writer of the backward pass = the FIRST writer in graph order, and only if that writer is a conv cell.  Not fused:
-        cells read by a dense layer (their gradient arrives in the dense layout), the first cell (own kernel), pooled cells
-        with odd plane sizes, and everything in split-bf16 mode."""
+        cells read by a dense layer (their gradient arrives in the dense layout), the first cell (own kernel) and pooled
+        cells with odd plane sizes."""
         self.fuse, self.ws_gate = {}, 0
-        if self.bx6 or os.environ.get('ASR_FUSE_PRE', '1') != '1':
+        if not self.opt_fuse:
             return
         for c in self.g:
             if c[0] != 'cell' or c[1] == 'x' or c[2] in self.dflat:
@@ -505,10 +485,6 @@ class DFCNNEngine:
         assert x.is_contiguous() and tuple(x.shape) == (self.B, self.T, self.F)
         self.x = x
         self.refresh_bn()
-        for dst, buf in self.ws_f.items():
-            cin, cout = self._cell_dims[dst]
-            ops.split_weights(self.p(dst, 'w'), 9, cin, cout, cout, 0, buf)
-            ops.split_weights(self.p(dst, 'w'), 9, cout, cin, cout, 1, self.ws_b[dst])
         # the fragment-order weight copies (two small launches per 3x3 layer, ~20 in all) are not needed before the second
         # cell: they run on the side stream beside the VALU-bound first cell instead of in front of it
         # The forward views first: the second cell waits for them only (they used to sit behind the backward views: 36 us of
@@ -541,9 +517,7 @@ class DFCNNEngine:
                     torch.cuda.current_stream().wait_event(wf_ready)
                     wf_ready = None
                 out_y = None if pool else (self.flat[dst] if dst in self.flat else self.y[dst])
-                if dst in self.ws_f:
-                    ops.tap_gemm_bx6(self.fdesc[dst], self.y[src], self.ws_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], out_y)
-                elif dst in self.wt_f and pool and self.fuse_pool:
+                if dst in self.wt_f and pool:
                     # conv + bias + ReLU -> BN -> 2x2 pool in one launch: a Winograd tile is a pooling window
                     ops.tap_gemm_wino_pool(self.fdesc[dst], self.y[src], self.wt_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], pm, self.y[dst])
                     continue
@@ -728,8 +702,7 @@ class DFCNNEngine:
                         dyv, layout = self._dplane(dst), (1 if pool else 0)
                     ops.cell_bwd_pre(dyv, layout, self.a[dst], sc, sh, pm, dz, self.dscale_of(dst),
                                      self.gview(dst, 'beta'), self.gview(dst, 'b'), self.ws)
-                # split-bf16 weight gradient where it wins (tools/bench_bx6.py): narrow planes (small halo) and >= 128 outputs
-                wgrad = ops.tap_wgrad_bx6 if (self.bx6 and k == 3 and cout >= 128 and W <= 64) else ops.tap_wgrad
+                wgrad = ops.tap_wgrad
                 def run_wgrad():
                     nonlocal side_busy
                     if self.side is None:
@@ -745,10 +718,8 @@ class DFCNNEngine:
                     dz_ready = torch.cuda.Event()
                     dz_ready.record()
                 # The data-gradient is on the critical path (the next cell's prologue waits for it); the weight-gradient
-                # is needed only at the end of backward.  With ASR_WGRAD_FIRST=0 (default) the data-gradient is enqueued
-                # first, so that its workgroups are not locked out by the weight-gradient's one-round grid.
-                if self.wgrad_first:
-                    run_wgrad()
+                # is needed only at the end of backward: the data-gradient is enqueued first, so that its workgroups are not
+                # locked out by the weight-gradient's one-round grid.
                 dx, acc = grad_target(src)
                 d = self.bdesc[dst]
                 d.accumulate = 1 if acc else 0
@@ -765,22 +736,13 @@ class DFCNNEngine:
                                        dx if acc else None, dzt, self.dscale_of(tgt), self.gview(tgt, 'beta'),
                                        self.gview(tgt, 'b'), self.ws)
                     fused_dz[tgt] = dzt
-                elif dst in self.ws_b:
-                    ops.tap_gemm_bx6(d, dz, self.ws_b[dst], None, None, None, None, dx, dgrad=True)
                 elif dst in self.wt_b:
                     ops.tap_gemm_wino(d, dz, self.wt_b[dst], None, None, None, None, dx)
                 elif dst in self.wf_b:
                     ops.tap_gemm_pw(d, dz, self.wf_b[dst], None, None, None, None, dx)
                 else:
                     ops.tap_gemm(d, dz, self.p(dst, 'w'), None, None, None, None, dx)
-                if not self.wgrad_first:
-                    if self.side is not None and self.wgrad_after_dgrad:
-                        # the side stream starts this weight-gradient only when the data-gradient has FINISHED: two MFMA-bound
-                        # kernels that start together also end together and leave the next HBM-bound prologue alone on the
-                        # chip; started late, the weight-gradient runs beside that prologue instead
-                        dz_ready = torch.cuda.Event()
-                        dz_ready.record()
-                    run_wgrad()
+                run_wgrad()
         if side_busy is not None:
             torch.cuda.current_stream().wait_event(side_busy)
         if self._decode_done is not None:

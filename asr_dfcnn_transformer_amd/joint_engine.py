@@ -120,7 +120,6 @@ class _LanguageHalf(_Base):
         if self._rate > 0:
             ops.dropout(cur, self._rate, self._seed_emb)
         ops.colsum(cur, N, T * C, T * C, self.g('pos')[:T * C], self.ws)
-        self._join_side()
         return cur.view(rows, C)
 
 

@@ -12,7 +12,6 @@ distance.  Dropout(0.3) in front of both dense layers (cnn_ctc.py:38,40): `dropo
 mask of asr_dropout (Keras' own random stream cannot be reproduced); 0 = identity, which the parity runs use.
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -68,7 +67,7 @@ class KerasDFCNNEngine:
         self.a, self.y, self.yp, self.stats = {}, {}, {}, {}
         self.dz, self.dplane = {}, {}
         self.fdesc, self.bdesc, self.wdesc = {}, {}, {}
-        self.pw = os.environ.get('ASR_PW', '1') == '1'
+        self.pw = True     # 3x3 convs on weights in MFMA fragment order (asr_tap_gemm_pw)
         self.wf_f, self.wf_b, self._dims = {}, {}, {}
         ws = 1 << 20
         for idx, (n, cp, cout, H, W, pool_after) in enumerate(self.convs):

@@ -46,6 +46,15 @@ class Plane:
     def zero_(self):
         self.buf.zero_()
 
+    def border_abs_max(self):
+        """Largest |value| outside the interior (guards, top border rows, left border columns): must stay exactly 0 for the
+        plane to be a valid SAME-padded conv input (tests)."""
+        g = self.G * self.C
+        v = self.view()
+        m = torch.stack([self.buf[:g].abs().max(), self.buf[g + self.NP * self.C:].abs().max(),
+                         v[:, 0].abs().max(), v[:, :, 0].abs().max()]).max()
+        return float(m)
+
 
 class KernelTimer:
     """Optional HIP-event timing of the contraction kernels, keyed by kernel instantiation
@@ -483,54 +492,6 @@ def pix_ln_bwd(dy, xhat, rstd, gamma, dx, dgamma, dbeta, ws):
 def maxpool_bwd(dy, y, dx):
     """dy: pooled-gradient Plane, y: the pooled tensor's input Plane, dx: Plane like y."""
     check(_lib.load().asr_maxpool_bwd(dy.ptr, y.ptr, y.B, y.H, y.W, y.C, dx.ptr, _stream()), 'asr_maxpool_bwd')
-
-
-# ---------------------------------------------------------------------------- experimental split-bf16 contractions
-def split_weights_bytes(ntaps, K, N):
-    return _lib.load().asr_split_weights_bytes(ntaps, K, N)
-
-
-def split_weights(W, ntaps, K, N, ldw, wmode=0, out=None):
-    """bf16 [ntaps][3][N][Kp] pieces of a weight tensor (see include/asr_hip.h); returns the uint8 buffer."""
-    lib = _lib.load()
-    nbytes = lib.asr_split_weights_bytes(ntaps, K, N)
-    if out is None:
-        out = torch.empty(nbytes, dtype=torch.uint8, device=W.device)
-    check(lib.asr_split_weights(_ptr(W), ntaps, K, N, ldw, wmode, _ptr(out), _stream()), 'asr_split_weights')
-    return out
-
-
-def tap_gemm_bx6(desc, A, Wsplit, bias=None, scale=None, shift=None, out_a=None, out_y=None, dgrad=False):
-    lib = _lib.load()
-    pa = A.ptr if isinstance(A, Plane) else _ptr(A)
-    po_a = out_a.ptr if isinstance(out_a, Plane) else _ptr(out_a)
-    po_y = out_y.ptr if isinstance(out_y, Plane) else _ptr(out_y)
-    _timed(desc, lambda: check(lib.asr_tap_gemm_bx6(C.byref(desc), pa, _ptr(Wsplit), _ptr(bias), _ptr(scale), _ptr(shift), po_a,
-                                                    po_y, _stream()), 'asr_tap_gemm_bx6'),
-           tag=' [dgrad]' if dgrad else '')              # one symbol serves both directions
-
-
-def tap_wgrad_bx6(desc, A, dZ, ldz, dW, partials):
-    lib = _lib.load()
-    pa = A.ptr if isinstance(A, Plane) else _ptr(A)
-    pz = dZ.ptr if isinstance(dZ, Plane) else _ptr(dZ)
-    _timed(desc, lambda: check(lib.asr_tap_wgrad_bx6(C.byref(desc), pa, pz, ldz, _ptr(dW), _ptr(partials), _stream()),
-                               'asr_tap_wgrad_bx6'))
-
-
-def split_rows(X, M, K, ldx, out=None):
-    """bf16 [3][M][Kp] hi / mid / lo planes of a row-major fp32 matrix (asr_split_rows); returns the uint8 buffer."""
-    lib = _lib.load()
-    if out is None:
-        out = torch.empty(lib.asr_split_rows_bytes(M, K), dtype=torch.uint8, device=X.device)
-    check(lib.asr_split_rows(_ptr(X), M, K, ldx, _ptr(out), _stream()), 'asr_split_rows')
-    return out
-
-
-def gemm_bx6s(As, Bs, M, K, N, bias=None, relu=0, accumulate=0, Y=None, ldy=0, Ysplit=None):
-    """Y [M][N] (+)= act(A . B^T + bias) on pre-split operands (asr_gemm_bx6s)."""
-    check(_lib.load().asr_gemm_bx6s(_ptr(As), _ptr(Bs), M, K, N, _ptr(bias), relu, accumulate, _ptr(Y), ldy, _ptr(Ysplit),
-                                    _stream()), 'asr_gemm_bx6s')
 
 
 # ---------------------------------------------------------------------------- fp32 contraction on pre-arranged weights

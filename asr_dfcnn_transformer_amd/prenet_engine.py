@@ -37,7 +37,7 @@ def fwd_flops_per_seq(T, F=320):
 
 
 class PreNetEngine:
-    def __init__(self, B, T, F=320, lr=5e-4, beta2=0.98, seed=0, device='cuda'):
+    def __init__(self, B, T, F=320, lr=5e-4, beta2=0.98, seed=0, device='cuda', dual_stream=None, wino=None):
         assert F == 320, 'the attention kernels are built for 80 frequency bins after the two stride-2 convs (4 x 80 / 4)'
         assert T % 4 == 0 and T >= 4
         self.B, self.T, self.F, self.device = B, T, F, device
@@ -97,39 +97,30 @@ class PreNetEngine:
                  ops.bn_workspace(self.a1), ops.bn_workspace(self.x2), ops.pix_ln_bwd_workspace(self.x2),
                  ops.prenet_conv1_bwd_workspace(B, T, F), ops.colsum_workspace(NP, CH), 4 * (B * CH * H2 + 64), 1 << 20])
         self.ws = z(ws // 4 + 64)
-        # Second stream for the backward pass (ASR_DUAL_STREAM=0 turns it off; see engine.py): the weight- and bias-gradient
-        # of a conv run on it while the main stream goes on with the data-gradient and the next (HBM-bound) BatchNorm /
-        # transpose / LayerNorm backward.  The pre-activation gradient planes alternate between two buffers.
-        self.side = torch.cuda.Stream(device=device) if os.environ.get('ASR_DUAL_STREAM', '1') == '1' else None
+        # Second stream for the backward pass (dual_stream=False / ASR_DUAL_STREAM=0 turns it off; see engine.py): the weight- and
+        # bias-gradient of a conv run on it while the main stream goes on with the data-gradient and the next (HBM-bound)
+        # BatchNorm / transpose / LayerNorm backward.  The pre-activation gradient planes alternate between two buffers.
+        dual = (os.environ.get('ASR_DUAL_STREAM', '1') == '1') if dual_stream is None else bool(dual_stream)
+        self.side = torch.cuda.Stream(device=device) if dual else None
         self.ws_side = z(ws // 4 + 64) if self.side is not None else None
         self.dz_alt = pl() if self.side is not None else None
         self._busy = {}            # id(plane) -> event of the last side-stream reader
         self._flip = False
-        # EXPERIMENTAL (ASR_BX6=1): the six 3x3 stride-1 convs (forward + data-gradient) on the split-bf16 kernels
-        self.bx6 = os.environ.get('ASR_BX6', '0') == '1'
-        self.ws_f, self.ws_b = {}, {}
-        if self.bx6:
-            for k, cin in (('q', CH), ('k', CH), ('v', CH), ('merge', 2 * CH), ('f1', CH), ('f2', CH)):
-                self.ws_f[k] = torch.zeros(ops.split_weights_bytes(9, cin, CH), dtype=torch.uint8, device=device)
-                self.ws_b[k] = torch.zeros(ops.split_weights_bytes(9, CH, cin), dtype=torch.uint8, device=device)
         self._cin = {'q': CH, 'k': CH, 'v': CH, 'merge': 2 * CH, 'f1': CH, 'f2': CH}
-        # default: the same six convs on weights pre-arranged in MFMA fragment order (asr_tap_gemm_pw; ASR_PW=0 turns it off)
+        # the six 3x3 stride-1 convs on weights pre-arranged in MFMA fragment order (asr_tap_gemm_pw) ...
         self.wf_f, self.wf_b = {}, {}
-        if os.environ.get('ASR_PW', '1') == '1' and not self.bx6:
-            nb = ops._lib.load().asr_arrange_weights_bytes
-            for k, cin in self._cin.items():
-                self.wf_f[k] = torch.zeros(nb(9, cin, CH) // 4, dtype=torch.float32, device=device)
-                self.wf_b[k] = torch.zeros(nb(9, CH, cin) // 4, dtype=torch.float32, device=device)
-
-        # the same convs on the Winograd F(2x2,3x3) kernel (wino.hip; see engine.py): forward and data-gradients
-        # (ASR_WINO_DIRS=f: forward only), ASR_WINO=0 turns it off
+        nb = ops._lib.load().asr_arrange_weights_bytes
+        for k, cin in self._cin.items():
+            self.wf_f[k] = torch.zeros(nb(9, cin, CH) // 4, dtype=torch.float32, device=device)
+            self.wf_b[k] = torch.zeros(nb(9, CH, cin) // 4, dtype=torch.float32, device=device)
+        # ... or, where supported, on the Winograd F(2x2,3x3) kernel (wino.hip; see engine.py), forward and data-gradients;
+        # wino=False / ASR_WINO=0 turns it off
         self.wt_f, self.wt_b = {}, {}
-        if os.environ.get('ASR_WINO', '1') == '1' and self.wf_f:
-            which = os.environ.get('ASR_WINO_DIRS', 'fb')
+        if (os.environ.get('ASR_WINO', '1') == '1') if wino is None else bool(wino):
             for k, cin in self._cin.items():
-                if 'f' in which and ops.winograd_supported(self.d_conv[k]):
+                if ops.winograd_supported(self.d_conv[k]):
                     self.wt_f[k] = torch.zeros(16 * cin * CH, dtype=torch.float32, device=device)
-                if 'b' in which and ops.winograd_supported(self.d_dx[k]):
+                if ops.winograd_supported(self.d_dx[k]):
                     self.wt_b[k] = torch.zeros(16 * cin * CH, dtype=torch.float32, device=device)
 
     # ---- parameters
@@ -208,9 +199,7 @@ class PreNetEngine:
         self._last_side = done
 
     def _conv(self, name, src, dst):
-        if name in self.ws_f:
-            ops.tap_gemm_bx6(self.d_conv[name], src, self.ws_f[name], self.p(name + '/b'), None, None, dst, None)
-        elif name in self.wt_f:
+        if name in self.wt_f:
             ops.tap_gemm_wino(self.d_conv[name], src, self.wt_f[name], self.p(name + '/b'), None, None, dst, None)
         elif name in self.wf_f:
             ops.tap_gemm_pw(self.d_conv[name], src, self.wf_f[name], self.p(name + '/b'), None, None, dst, None)
@@ -227,9 +216,7 @@ class PreNetEngine:
             self._wait_readers(dx)                  # dx may be a plane an earlier weight-gradient still reads (ds)
             d = self.d_dx[name]
             d.accumulate = 1 if accumulate else 0
-            if name in self.ws_b:
-                ops.tap_gemm_bx6(d, dz, self.ws_b[name], None, None, None, None, dx, dgrad=True)
-            elif name in self.wt_b:
+            if name in self.wt_b:
                 ops.tap_gemm_wino(d, dz, self.wt_b[name], None, None, None, None, dx)
             elif name in self.wf_b:
                 ops.tap_gemm_pw(d, dz, self.wf_b[name], None, None, None, None, dx)
@@ -242,10 +229,6 @@ class PreNetEngine:
         B, H2, W2 = self.B, self.H2, self.W2
         assert tuple(x.shape) == (B, self.T, self.F) and x.is_contiguous() and x.dtype == torch.float32
         self.x = x
-        for k, buf in self.ws_f.items():
-            cin = self._cin[k]
-            ops.split_weights(self.p(k + '/w'), 9, cin, CH, CH, 0, buf)
-            ops.split_weights(self.p(k + '/w'), 9, CH, cin, CH, 1, self.ws_b[k])
         for k, buf in self.wf_f.items():
             cin = self._cin[k]
             ops.arrange_weights(self.p(k + '/w'), 9, cin, CH, CH, 0, buf)

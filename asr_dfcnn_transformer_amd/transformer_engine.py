@@ -11,7 +11,6 @@ re-uses encoder block i's dense kernels in decoder block i (variable-scope reuse
 Dropout: identity (parity mode).
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -166,77 +165,14 @@ class _Base:
         shared = name_off(self, name) in self._written
         self._written.add(name_off(self, name))
 
-        def launch(ws):
-            if shared:
-                ops.tap_wgrad(d, x, dy, N, self._wtmp[:K * N], ws)
-                ops.axpy(self.g(name), self._wtmp[:K * N], 1.0, True)
-            else:
-                ops.tap_wgrad(d, x, dy, N, self.g(name), ws)
-
-        if self.side is None:
-            launch(self.ws)
-            return
-        ready = torch.cuda.Event()
-        ready.record()                                # dy (and x) are final on the main stream
-        self.side.wait_event(ready)
-        with torch.cuda.stream(self.side):
-            launch(self.ws_side)
-            self._side_dirty = True
-
-    def _wgrad_ld(self, x, dy, rows, K, N, name, ldz):
-        """_wgrad for a dy that is a column block of a wider matrix (row pitch ldz)."""
-        d = ops.gemm_desc(rows, K, N, K, N, ntaps=1)
-        shared = name_off(self, name) in self._written
-        self._written.add(name_off(self, name))
-
-        def launch(ws):
-            if shared:
-                ops.tap_wgrad(d, x, dy, ldz, self._wtmp[:K * N], ws)
-                ops.axpy(self.g(name), self._wtmp[:K * N], 1.0, True)
-            else:
-                ops.tap_wgrad(d, x, dy, ldz, self.g(name), ws)
-
-        if self.side is None:
-            launch(self.ws)
-            return
-        ready = torch.cuda.Event()
-        ready.record()
-        self.side.wait_event(ready)
-        with torch.cuda.stream(self.side):
-            launch(self.ws_side)
-            self._side_dirty = True
-
-    def _begin_block(self):
-        """Backward of one sub-layer starts: take the other scratch set and wait for the weight-gradients that still read it."""
-        if self.side is None:
-            return
-        self._blk ^= 1
-        self.sc = self.sc_sets[self._blk]
-        if self._sc_busy[self._blk] is not None:
-            torch.cuda.current_stream().wait_event(self._sc_busy[self._blk])
-            self._sc_busy[self._blk] = None
-
-    def _end_block(self):
-        if self.side is None or not getattr(self, '_side_dirty', False):
-            return
-        ev = torch.cuda.Event()
-        ev.record(self.side)
-        self._sc_busy[self._blk] = ev
-        self._side_dirty = False
-
-    def _join_side(self):
-        """End of backward: every weight-gradient is in self.grad before the all-reduce / Adam on the main stream."""
-        if self.side is None:
-            return
-        self._end_block()
-        for i, ev in enumerate(self._sc_busy):
-            if ev is not None:
-                torch.cuda.current_stream().wait_event(ev)
-                self._sc_busy[i] = None
+        if shared:
+            ops.tap_wgrad(d, x, dy, N, self._wtmp[:K * N], self.ws)
+            ops.axpy(self.g(name), self._wtmp[:K * N], 1.0, True)
+        else:
+            ops.tap_wgrad(d, x, dy, N, self.g(name), self.ws)
 
     def _bgrad(self, dy, rows, N, name):
         if name_off(self, name) in self._written:
-            # own scratch: _wtmp belongs to the weight-gradients, which may be running on the side stream right now
             ops.colsum(dy, rows, N, N, self._btmp[:N], self.ws)
             ops.axpy(self.g(name), self._btmp[:N], 1.0, True)
         else:
@@ -337,7 +273,6 @@ class _Base:
         """dq_in (+)= dL/d(queries), dk_in (+)= dL/d(keys); dk_in may be dq_in (self-attention)."""
         C, N, Tq, Tk = self.C, st['N'], st['Tq'], st['Tk']
         rq, rk = N * Tq, N * Tk
-        self._begin_block()
         dr, dZ, dA = self.sc['a'][:rq * C], self.sc['b'][:rq * C], self.sc['c'][:rq * C]
         ops.layernorm_bwd(dout, st['xhat'], st['rstd'], self.p(name + '/ln_g'), rq, C, dr, False,
                           self.g(name + '/ln_g'), self.g(name + '/ln_b'), self.ws)
@@ -361,24 +296,15 @@ class _Base:
                           dQ, dK, dV, self.ws, relu_grad=True,      # gradients of the pre-ReLU projections
                           dropout_rate=self._rate, seed=st['seed_att'], ldq=ldq, ldk=ldk)
         W3 = st['W3']
-        if fused3 and self.side is None:
+        if fused3:
             self._wgrad_packed(st['q_in'], dQ, rq, C, [name + '/wq', name + '/wk', name + '/wv'], 3 * C)
             self._dense_dgrad(dQ, rq, C, 3 * C, W3, dq_in, True)              # dx += [dQ | dK | dV] . [wq | wk | wv]^T
-        elif fused3:
-            for nm, dy in (('/wq', dQ), ('/wk', dK), ('/wv', dV)):
-                self._wgrad_ld(st['q_in'], dy, rq, C, C, name + nm, 3 * C)
-            self._dense_dgrad(dQ, rq, C, 3 * C, W3, dq_in, True)
         else:
             self._wgrad(st['q_in'], dQ, rq, C, C, name + '/wq')
             self._dense_dgrad(dQ, rq, C, C, self.p(name + '/wq'), dq_in, True)
-            if self.side is None:
-                self._wgrad_packed(st['k_in'], dK, rk, C, [name + '/wk', name + '/wv'], 2 * C)
-            else:
-                self._wgrad_ld(st['k_in'], dK, rk, C, C, name + '/wk', 2 * C)
-                self._wgrad_ld(st['k_in'], dV, rk, C, C, name + '/wv', 2 * C)
+            self._wgrad_packed(st['k_in'], dK, rk, C, [name + '/wk', name + '/wv'], 2 * C)
             d = ops.gemm_desc(rk, 2 * C, C, 2 * C, 3 * C, 0, C, ntaps=1, wmode=1, accumulate=1 if dk_acc else 0)
             ops.tap_gemm(d, dK, W3.view(-1)[C:], None, None, None, None, dk_in)   # dk_in (+)= [dK | dV] . [wk | wv]^T
-        self._end_block()
 
     def _ffn_alloc(self, rows):
         C = self.C
@@ -399,7 +325,6 @@ class _Base:
 
     def _ffn_bwd(self, name, st, dout, dx, dx_acc):
         C, rows = self.C, st['rows']
-        self._begin_block()
         dr = self.sc['a'][:rows * C]
         dH = self.sc['h'][:rows * 4 * C]
         ops.layernorm_bwd(dout, st['xhat'], st['rstd'], self.p(name + '/ln_g'), rows, C, dr, False,
@@ -417,34 +342,22 @@ class _Base:
         self._bgrad(dH, rows, 4 * C, name + '/b1')
         self._wgrad(st['x'], dH, rows, C, 4 * C, name + '/w1')
         self._dense_dgrad(dH, rows, C, 4 * C, self.p(name + '/w1'), dx, True)
-        self._end_block()
 
     def _alloc_scratch(self, max_rows, max_w, gemms):
         """gemms: (rows, K, N) of every weight-gradient GEMM, to size the split-K slab workspace."""
         C = self.C
-        # Optional second stream for the backward pass (ASR_TR_DUAL_STREAM=1; same idea as engine.py): every weight-gradient
-        # GEMM runs on it, beside the data-gradient GEMMs / attention / LayerNorm backward of the main stream.  The
-        # gradients it reads live in scratch buffers, so there are two scratch sets, used by alternate blocks; a block
-        # waits for the side-stream work of the block that used its set before.  OFF by default: measured 2 % SLOWER on
-        # configs[3] (60.3 vs 59.1 ms) -- here both streams are MFMA-bound GEMMs of exactly one round of workgroups, there
-        # is no HBM-bound prologue to hide as in the DFCNN backward, and the two only take matrix-pipe cycles from each other.
-        self.side = torch.cuda.Stream(device=self.device) if os.environ.get('ASR_TR_DUAL_STREAM', '0') == '1' else None
-        nsets = 2 if self.side is not None else 1
-        self.sc_sets = []
-        for _ in range(nsets):
-            sc = {k: self._t(max_rows * C) for k in 'abcdef'}
-            sc['h'] = self._t(max_rows * 4 * C)
-            sc['qkv'] = self._t(max_rows * 3 * C)            # d[Q | K | V] of a block (see _mha_bwd)
-            self.sc_sets.append(sc)
-        self.sc, self._blk, self._sc_busy = self.sc_sets[0], 0, [None] * nsets
+        # One stream: running the weight-gradient GEMMs on a second stream beside the data-gradient GEMMs was measured 2 % SLOWER
+        # on configs[3] in round 1 (both are MFMA-bound one-round grids, there is no HBM-bound prologue to hide) and removed.
+        self.sc = {k: self._t(max_rows * C) for k in 'abcdef'}
+        self.sc['h'] = self._t(max_rows * 4 * C)
+        self.sc['qkv'] = self._t(max_rows * 3 * C)            # d[Q | K | V] of a block (see _mha_bwd)
         self._wtmp = self._t(max_w)
-        self._btmp = self._t(max(4 * C, self.Vp, 1024))      # bias-gradient scratch of the main stream (_bgrad)
+        self._btmp = self._t(max(4 * C, self.Vp, 1024))      # bias-gradient scratch (_bgrad)
         ws = max(ops.layernorm_bwd_workspace(max_rows, C), ops.colsum_workspace(max_rows, 4 * C),
                  ops.colsum_workspace(max_rows, self.Vp), 4 * (max_rows * self.H + 64), 1 << 20)
         for rows, K, N in list(gemms) + [(max_rows, C, 3 * C), (max_rows, C, 2 * C)]:
             ws = max(ws, ops.tap_wgrad_workspace(ops.gemm_desc(rows, K, N, K, N, ntaps=1)))
         self.ws = self._t(ws // 4 + 64)
-        self.ws_side = self._t(ws // 4 + 64) if self.side is not None else None
 
     # ---- loss head
     def _head_alloc(self, rows):
@@ -578,7 +491,6 @@ class LMEngine(_Base):
         self.seg[2][:len(seg)].copy_(torch.from_numpy(seg), non_blocking=True)
         ops.embed_bwd(cur, self.seg[0], self.seg[1], self.seg[2], len(uniq), C, True, float(C) ** 0.5, self.g('emb'))
         ops.colsum(cur, N, T * C, T * C, self.g('pos')[:T * C], self.ws)
-        self._join_side()
 
 
 class E2EEngine(_Base):
@@ -703,7 +615,6 @@ class E2EEngine(_Base):
             ops.dropout(cur, self._rate, self._seed_emb)
         ops.colsum(cur, N, T * C, T * C, self.g('enc_pe')[:T * C], self.ws)
         if self.vin is None:
-            self._begin_block()
             du = self.sc['b'][:re * C]
             ops.layernorm_bwd(cur, self.u_xhat, self.u_rstd, self.p('in_ln_g'), re, C, du, False, self.g('in_ln_g'),
                               self.g('in_ln_b'), self.ws)
@@ -712,12 +623,10 @@ class E2EEngine(_Base):
             self._bgrad(du, re, C, 'in_b')
             if self.need_dx:
                 self._dense_dgrad(du, re, self.din, C, self.p('in_w'), self.dx_feat, False)
-            self._end_block()
         else:
             perm, uniq, seg = sorted_segments(self._x_host)
             self._seg_upload(perm, uniq, seg)
             ops.embed_bwd(cur, self.seg[0], self.seg[1], self.seg[2], len(uniq), C, True, float(C) ** 0.5, self.g('enc_emb'))
-        self._join_side()
 
     def _seg_upload(self, perm, uniq, seg):
         self.seg[0][:len(perm)].copy_(torch.from_numpy(perm), non_blocking=True)

@@ -27,29 +27,53 @@ import torch.distributed as dist
 FP32_PEAK_TFLOPS = 157.3        # MI355X dense fp32 (vector = matrix), MI355X_MICROARCH.md
 
 
-def kernel_name(key):
-    """KernelTimer keys are the kernel symbols themselves, as libasrhip reports them (asr_last_kernel)."""
-    return key
+# Winograd F(2x2,3x3) kernel (wino.hip): per 8-channel chunk a wave issues 32 v_mfma_f32_32x32x2_f32 (64 cycles each) and the
+# input transform's vector instructions (45 per chunk: 40 v_pk_add_f32 + selects).  On this pipe
+# vector instructions do not hide under the fp32 MFMAs of the SIMD's two waves, they ADD to them (tools/mfma_valu.hip, mode
+# "wino": measured time of the kernel's issue pattern with and without the adds, profiles/r03_mfma_valu.txt), so the bound of
+# the kernel in DIRECT-convolution flops is
+#     peak_effective = 157.3 TFLOP/s x 2.25 (multiplies saved) x t_mfma / (t_mfma + t_transform)
+WINO_MULT_SAVING = 2.25
+WINO_MFMA_TIME_SHARE = 0.85      # t_mfma / (t_mfma + t_transform); see above (replaced by the measured value in profiles/)
 
 
 def kernel_peak(sym):
-    """fp32 MFMA peak, or -- for the experimental split-bf16 kernels, whose fp32-equivalent flop is six bf16 MFMA flops --
-    the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md) divided by 6."""
-    return round(2500.0 / 6.0, 1) if sym.startswith('tap_gemm_kernel_bx6') else FP32_PEAK_TFLOPS
+    """(peak TFLOP/s in the kernel's ALGORITHMIC flops, explanation)."""
+    if sym.startswith('wino'):
+        return (round(FP32_PEAK_TFLOPS * WINO_MULT_SAVING * WINO_MFMA_TIME_SHARE, 1),
+                'Winograd F(2x2,3x3) in fp32: `achieved` counts the flops of the DIRECT 3x3 convolution (SURVEY 8d: 2 x MACs); the '
+                'kernel issues 2.25x fewer MFMA multiplies but pays its input transform in vector instructions that add to the MFMA '
+                'time on this pipe: peak = %.1f x %.2f x %.2f' % (FP32_PEAK_TFLOPS, WINO_MULT_SAVING, WINO_MFMA_TIME_SHARE))
+    return FP32_PEAK_TFLOPS, None
 
 
 def is_forward_symbol(sym):
-    """tap_gemm_kernel[_v1]<MT, NT, WM, WN, NTAPS, WMODE[, KC]>: WMODE 0 = forward (conv / dense), 1 = data-gradient."""
-    if sym.startswith('tap_gemm_kernel_bx6'):          # split-bf16 kernels: one symbol for both directions, tagged by ops
-        return '[dgrad]' not in sym
-    if sym.startswith('wino8_kernel') or sym.startswith('wino_kernel'):      # <DIR>: Winograd F(2x2,3x3) conv (wino.hip)
-        return sym[sym.index('<') + 1:sym.rindex('>')].strip() == '0'
-    if not sym.startswith('tap_gemm_kernel'):
+    """Contraction kernels that only the forward pass launches (they run alone on the main stream even when the backward
+    pass uses two): wino8_kernel<DIR>, tap_gemm_kernel_v5<..., DIR>, tap_gemm_kernel_v1<MT, NT, WM, WN, NTAPS, WMODE[, KC]>,
+    gemm1_kernel<..., DIR> with DIR / WMODE 0."""
+    if '<' not in sym:
         return False
     args = [a.strip() for a in sym[sym.index('<') + 1:sym.rindex('>')].split(',')]
-    if sym.startswith('tap_gemm_kernel_v5'):           # <MT, NT, WM, WN, NTAPS, KC, D, MINB, DIR>
-        return args[8] == '0'
-    return args[5] == '0'
+    if sym.startswith('wino8_kernel'):
+        return args[0] == '0'
+    if sym.startswith('tap_gemm_kernel_v5') or sym.startswith('gemm1_kernel'):
+        return args[-1] == '0'
+    if sym.startswith('tap_gemm_kernel_v1'):
+        return args[5] == '0'
+    return False
+
+
+def roofline_block(dom, r, steps):
+    """The `roofline` object for kernel symbol `dom` from its KernelTimer record r (HIP events on the launch stream)."""
+    peak, why = kernel_peak(dom)
+    out = {'bound': 'mfma', 'achieved': round(r['tflops'], 2), 'peak': peak, 'unit': 'TFLOP/s',
+           'frac': round(r['tflops'] / peak, 4), 'traffic': None, 'kernel': dom,
+           'launches_per_step': r['launches'] // max(1, steps), 'avg_launch_us': round(r['avg_us'], 2),
+           'flop_per_launch': round(r['total_flops'] / r['launches'] / 1e9, 3), 'flop_unit': 'GFLOP'}
+    if why:
+        out['peak_note'] = why
+        out['mfma_pipe_frac'] = round(r['tflops'] / WINO_MULT_SAVING / FP32_PEAK_TFLOPS, 4)
+    return out
 
 
 def pmc_traffic(workload, symbol):
@@ -77,10 +101,11 @@ def attach_traffic(out, workload, dom, default_config):
         out['roofline']['traffic_unit'] = 'bytes/launch (PMC pass: %s)' % src
 
 
-def cpu_baseline(variant, t_pad, vocab, seconds=10.0, budget_s=15.0):
-    """CPU restatement ("port": oracle/torch_ref.py on torch-CPU ops + the numpy fbank oracle)
-    of the identical step, timed on this host's cores on a bounded sample.  Stand-in for the
-    reference's TF-CPU path, which cannot run offline."""
+def cpu_baseline(variant, t_pad, vocab, batch=32, seconds=10.0, budget_s=20.0):
+    """CPU restatement ("port": oracle/torch_ref.py on torch-CPU ops + the numpy fbank oracle) of the identical step at the
+    SAME batch the GPU number is quoted on, timed on this host's cores on a bounded sample: one untimed warm-up
+    step, then timed steps until `budget_s` is used up (at least one).  Stand-in for the reference's TF-CPU path, which
+    cannot run offline."""
     from oracle import dfcnn as odf, fbank as ofb, torch_ref
     try:
         cores = len(os.sched_getaffinity(0))
@@ -88,7 +113,7 @@ def cpu_baseline(variant, t_pad, vocab, seconds=10.0, budget_s=15.0):
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 64))
     torch.set_num_threads(cores)
-    Bc = 2
+    Bc = batch
     g = odf.graph(variant, vocab)
     P = odf.init_params(g, seed=0)
     tP = torch_ref.to_torch_params(P, dtype=torch.float32)
@@ -110,17 +135,19 @@ def cpu_baseline(variant, t_pad, vocab, seconds=10.0, budget_s=15.0):
         torch_ref.train_step(g, tP, torch.from_numpy(x), [125] * Bc, labels)
         torch_ref.adam_tf_(params, [p.grad for p in params], m, v, 7e-4, t)
 
+    tw = time.perf_counter()
     step(1)                                   # warm-up (allocations, oneDNN primitive caches)
+    tw = time.perf_counter() - tw
     n, t0 = 0, time.perf_counter()
     while True:
         step(n + 2)
         n += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or n >= 60:
+        if el + el / n > budget_s or n >= 10:
             break
     return {'value': round(Bc * n / el, 4), 'unit': 'utterances/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d timed steps of batch %d (same model, T_pad %d, 10 s audio, fbank+fwd+CTC+bwd+Adam, '
-                      'torch-CPU fp32 + numpy fbank) after 1 warm-up' % (n, Bc, t_pad)}
+            'sample': '%d timed step(s) of batch %d (same model, T_pad %d, 10 s audio, fbank+fwd+CTC+bwd+Adam, '
+                      'torch-CPU fp32 + numpy fbank) after 1 warm-up step (%.1f s)' % (n, Bc, t_pad, tw)}
 
 
 def run_am_lm(args):
@@ -206,9 +233,7 @@ def run_am_lm(args):
                           'step_frac_of_fp32_peak': round(utt_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
                           'backward_streams': 2 if overlapped else 1, 'dropout_rate': args.dropout,
                           'am_mean_loss': round(am_mean, 4), 'lm_mean_loss': round(lm_mean, 4)},
-               'roofline': {'bound': 'mfma', 'achieved': round(r['tflops'], 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': round(r['tflops'] / FP32_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': kernel_name(dom),
-                            'launches_per_step': r['launches'] // args.steps, 'avg_launch_us': round(r['avg_us'], 2)}}
+               'roofline': roofline_block(dom, r, args.steps)}
         attach_traffic(out, 'am_lm', dom, args.batch == 32 and args.tpad == 1600)
         if args.kernel_table:
             for key, rr in sorted(table.items(), key=lambda kv: -kv[1]['total_ms']):
@@ -246,8 +271,7 @@ def run_lm(args):
             torch.cuda.synchronize(); ops.TIMER = ops.KernelTimer()
         step()
     torch.cuda.synchronize(); table = ops.TIMER.summary(); ops.TIMER = None
-    overlapped = eng.side is not None
-    dom = max([k for k in table if not overlapped or is_forward_symbol(k)], key=lambda k: table[k]['total_ms'])
+    dom = max(table, key=lambda k: table[k]['total_ms'])          # one stream: every kernel runs alone
     ops.TIMER = ops.KernelTimer(only={dom})
     if world > 1:
         dist.barrier()
@@ -276,9 +300,7 @@ def run_lm(args):
                           'step_tflops': round(seq_s / world * fstep / 1e12, 2),
                           'step_frac_of_fp32_peak': round(seq_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
                           'dropout_rate': args.dropout, 'mean_loss': round(eng.fetch()[0], 4)},
-               'roofline': {'bound': 'mfma', 'achieved': round(r['tflops'], 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': round(r['tflops'] / FP32_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': kernel_name(dom),
-                            'launches_per_step': r['launches'] // args.steps, 'avg_launch_us': round(r['avg_us'], 2)}}
+               'roofline': roofline_block(dom, r, args.steps)}
         attach_traffic(out, 'lm', dom, N == 64)
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -334,8 +356,8 @@ def run_transformer(args):
             torch.cuda.synchronize(); ops.TIMER = ops.KernelTimer()
         step()
     torch.cuda.synchronize(); table = ops.TIMER.summary(); ops.TIMER = None
-    # weight-gradients on a second stream: price a kernel that runs alone (forward)
-    overlapped = eng.side is not None or (prenet and pre.side is not None)
+    # the pre-net runs its weight-gradients on a second stream: price a kernel that runs alone (forward) there
+    overlapped = prenet and pre.side is not None
     dom = max([k for k in table if not overlapped or is_forward_symbol(k)], key=lambda k: table[k]['total_ms'])
     ops.TIMER = ops.KernelTimer(only={dom})
     if world > 1:
@@ -375,9 +397,7 @@ def run_transformer(args):
                           'step_frac_of_fp32_peak': round(seq_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
                           'backward_streams': 2 if overlapped else 1, 'dropout_rate': args.dropout,
                           'mean_loss': round(eng.fetch()[0], 4)},
-               'roofline': {'bound': 'mfma', 'achieved': round(r['tflops'], 2), 'peak': FP32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': round(r['tflops'] / FP32_PEAK_TFLOPS, 4), 'traffic': None, 'kernel': kernel_name(dom),
-                            'launches_per_step': r['launches'] // args.steps, 'avg_launch_us': round(r['avg_us'], 2)}}
+               'roofline': roofline_block(dom, r, args.steps)}
         attach_traffic(out, args.workload, dom, N == 64)
         if prenet:
             out['dp_semantics'] = ('per-replica BN: the batch-statistics BatchNorm of the pre-net normalises over the batch of each rank '
@@ -399,17 +419,42 @@ def dp_info():
     return {'ranks': 1, 'dist_backend': None, 'gpus_visible': torch.cuda.device_count()}
 
 
+def visible_gpu_count():
+    """GPUs this job may use, WITHOUT a HIP call in the launcher process (torch.cuda.device_count() can fall through to
+    hipGetDeviceCount, which initialises the runtime in the parent): KFD topology nodes with SIMDs, cut down by the
+    ROCR_ / HIP_ / CUDA_VISIBLE_DEVICES lists.  None when the topology cannot be read (the ranks then fail by themselves
+    with a clear message from torch.cuda.set_device)."""
+    import glob
+    n = 0
+    nodes = glob.glob('/sys/class/kfd/kfd/topology/nodes/*/properties')
+    if not nodes:
+        return None
+    for f in nodes:
+        try:
+            for line in open(f):
+                k, _, v = line.partition(' ')
+                if k == 'simd_count' and int(v) > 0:
+                    n += 1
+        except OSError:
+            return None
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        lst = os.environ.get(var)
+        if lst is not None:
+            n = min(n, len([x for x in lst.split(',') if x.strip() != '']))
+    return n
+
+
 def spawn_ranks(n):
-    """`python bench.py --gpus N` without a launcher: this (parent) process has not touched the GPU -- importing torch
-    does not initialise HIP -- and starts N FRESH child processes of this same script, one rank per GPU, with the
+    """`python bench.py --gpus N` without a launcher: this (parent) process never touches the GPU -- importing torch
+    does not initialise HIP, and the device count comes from sysfs -- and starts N FRESH child processes of this same script, one rank per GPU, with the
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment torch.distributed.run would give them.  Rank 0 inherits
     stdout (its ONE JSON line is the parent's output); the exit code is non-zero if any rank fails, and the surviving
     ranks of a failed job are terminated by PID (no retry)."""
     import socket
     import subprocess
     backend = os.environ.get('ASR_DIST_BACKEND', 'nccl')
-    ndev = torch.cuda.device_count()                 # counting devices does not initialise the GPU
-    if backend == 'nccl' and ndev < n:
+    ndev = visible_gpu_count()                       # from sysfs / the *_VISIBLE_DEVICES lists: this process never calls HIP
+    if backend == 'nccl' and ndev is not None and ndev < n:
         print('bench.py: --gpus %d but only %d GPU(s) visible (RCCL needs one GPU per rank; ASR_DIST_BACKEND=gloo '
               'rehearses more ranks on fewer GPUs)' % (n, ndev), file=sys.stderr)
         return 2
@@ -451,7 +496,6 @@ def main():
     ap.add_argument('--tpad', type=int, default=1600)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dropout', type=float, default=0.2, help='Transformer workloads: dropout_rate (reference default 0.2, model.py:36)')
-    ap.add_argument('--no-experimental', action='store_true', help='skip the extra split-bf16 measurement')
     ap.add_argument('--no-prefetch', action='store_true', help='compute the fbank features in line instead of one step ahead')
     ap.add_argument('--kernel-table', action='store_true', help='also print per-kernel timings to stderr')
     ap.add_argument('--host-input', action='store_true',
@@ -481,13 +525,8 @@ def main():
     dev = 'cuda'
     variant = 'm1' if args.workload == 'dfcnn' else 'm2'
     B, T, F, V = args.batch, args.tpad, 200, 1536
-    def make_engine():
-        e = DFCNNEngine(model=variant, vocab=V, B=B, T=T, F=F, seed=0, device=dev)
-        r = BucketedAllReduce(e.grad, [(e.n_gamma, e.dense_end), (0, e.n_gamma), (e.dense_end, e.grad.numel())])
-        return e, r
-
-    eng, red = make_engine()
-    cur_model = {'eng': eng, 'red': red}          # step() runs whatever engine is installed here
+    eng = DFCNNEngine(model=variant, vocab=V, B=B, T=T, F=F, seed=0, device=dev)
+    red = BucketedAllReduce(eng.grad, [(eng.n_gamma, eng.dense_end), (0, eng.n_gamma), (eng.dense_end, eng.grad.numel())])
     fb = FbankExtractor(nfilt=F, device=dev)
 
     ns = 160000
@@ -520,34 +559,42 @@ def main():
             ev = torch.cuda.Event(); ev.record()
             feat_ready[slot] = ev
 
-    def step():
-        if prefetch:
+    def step(single_stream=False):
+        """One training step.  ``single_stream``: the same step with everything on the main stream (features in line, backward
+        on one stream), so that HIP events around a kernel price that kernel alone -- used outside the timed region only."""
+        pf = prefetch and not single_stream
+        if pf:
             cur = state['i'] & 1
             if feat_ready[cur] is None:
                 produce(cur)                                  # very first step: nothing was prefetched yet
             torch.cuda.current_stream().wait_event(feat_ready[cur])
             feat = feats[cur]
         else:
-            feat = feats[0]
+            feat = feats[-1] if not prefetch else single_feat
             if host_pinned is not None:
                 signal.copy_(host_pinned, non_blocking=True)
             fb.batch(signal, nsamp, T, out=feat)
-        eng, red = cur_model['eng'], cur_model['red']
-        eng.forward(feat)
-        if prefetch:
-            # after the conv stack: the latency-bound fbank fills the chip while the (equally latency-bound) CTC lattice /
-            # decode / small head GEMMs run, and the forward contractions keep the chip to themselves
-            produce(cur ^ 1)
-        eng.set_targets(seq, target)
-        eng.loss_and_decode(defer_decode_join=True)
-        if world > 1:
-            eng.backward(on_dense_grads_ready=lambda: red.launch(0))
-            red.launch(1); red.launch(2)
-            red.wait()
-        else:
-            eng.backward()
-        eng.apply_adam(red.grad_scale)
-        if prefetch:
+        side = eng.side
+        if single_stream:
+            eng.side = None                                   # engine.py reads it per call: forward / loss / backward stay on this stream
+        try:
+            eng.forward(feat)
+            if pf:
+                # after the conv stack: the latency-bound fbank fills the chip while the (equally latency-bound) CTC lattice /
+                # decode / small head GEMMs run, and the forward contractions keep the chip to themselves
+                produce(cur ^ 1)
+            eng.set_targets(seq, target)
+            eng.loss_and_decode(defer_decode_join=True)
+            if world > 1:
+                eng.backward(on_dense_grads_ready=lambda: red.launch(0))
+                red.launch(1); red.launch(2)
+                red.wait()
+            else:
+                eng.backward()
+            eng.apply_adam(red.grad_scale)
+        finally:
+            eng.side = side
+        if pf:
             ev = torch.cuda.Event(); ev.record()
             consumed[cur] = ev
             feat_ready[cur] = None
@@ -557,26 +604,33 @@ def main():
         if world > 1:
             dist.barrier()
 
-    # warm-up; the LAST warm-up step (steady state: code loaded, attributes set) also times every contraction kernel
-    # to find the dominant one
+    single_feat = torch.empty(B, T, F, dtype=torch.float32, device=dev) if prefetch else None
+    # Warm-up: W untimed steps.  One of them (the second to last; with W < 3 an extra step in front of the last) runs on ONE
+    # stream with every contraction kernel between HIP events: its table decides which kernel symbol is the dominant one
+    # (most time in the step, forward or backward) -- with the two-stream backward of the real step, durations of
+    # overlapped kernels no longer price one kernel.
     nwarm = max(1, args.warmup)
-    for i in range(nwarm):
-        if i == nwarm - 1:
+    plan = ['step'] * nwarm
+    if nwarm >= 3:
+        plan[nwarm - 2] = 'single'
+    else:
+        plan.insert(len(plan) - 1, 'single')
+    for kind in plan:
+        if kind == 'single':
             torch.cuda.synchronize()
             ops.TIMER = ops.KernelTimer()
-        step()
+            step(single_stream=True)
+            torch.cuda.synchronize()
+            table = ops.TIMER.summary()
+            ops.TIMER = None
+        else:
+            step()
     torch.cuda.synchronize()
-    table = ops.TIMER.summary()
-    ops.TIMER = None
-    # With the two-stream backward (engine.side) a weight-gradient runs beside the data-gradient and the next cell's
-    # prologue: their durations overlap and no longer price one kernel.  The roofline kernel is then the dominant
-    # contraction that still runs alone -- a forward one (wmode 0 symbols are launched by the forward pass only).
     overlapped = eng.side is not None
-    cands = [k for k in table if not overlapped or is_forward_symbol(k)]
-    dom = max(cands, key=lambda k: table[k]['total_ms'])     # one kernel symbol = one rocprof row
-    dom_keys = {dom}
+    dom = max(table, key=lambda k: table[k]['total_ms'])     # one kernel symbol = one rocprof row
+    dom_alone = (not overlapped) or is_forward_symbol(dom)   # does it run alone in the real (two-stream) step?
 
-    ops.TIMER = ops.KernelTimer(only=dom_keys)
+    ops.TIMER = ops.KernelTimer(only={dom})
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -591,88 +645,66 @@ def main():
         dt = float(t.item())
     mean_loss, label_err = eng.fetch_scalars()
 
-    # The same step on the EXPERIMENTAL split-bf16 conv kernels, reported beside the fp32 number and
-    # never as `value`: a second engine, same protocol (warm-up, barrier, K timed steps, max over ranks).
-    experimental = None
-    if not eng.bx6 and not args.no_experimental:
-        os.environ['ASR_BX6'] = '1'
-        eng2, red2 = make_engine()
-        os.environ['ASR_BX6'] = '0'
-        cur_model['eng'], cur_model['red'] = eng2, red2
-        for _ in range(nwarm):
-            step()
-        barrier(); torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize(); barrier()
-        dt2 = time.perf_counter() - t1
-        if world > 1:
-            t = torch.tensor([dt2], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt2 = float(t.item())
-        experimental = {'conv_arithmetic': 'split-bf16 (hi+mid+lo pieces, six bf16 MFMA products, fp32 accumulate) for the 3x3 conv '
-                                           'forward / data-gradient and the narrow-plane weight-gradients; fp32 MFMA elsewhere',
-                        'value': round(world * B * args.steps / dt2, 3), 'unit': 'utterances/s',
-                        'ms_per_step': round(1e3 * dt2 / args.steps, 3), 'mean_loss': round(eng2.fetch_scalars()[0], 4),
-                        'note': 'same workload, steps and timing protocol; error vs float64 equal to or below the fp32 kernels '
-                                '(tools/bench_bx6.py); parity tests pass in this mode (ASR_BX6=1); not the headline number'}
-        cur_model['eng'], cur_model['red'] = eng, red
+    # Roofline pass (after the timed region, never part of `value`): when the dominant kernel overlaps with others in the real
+    # step, its launch duration is measured in min(K, 5) single-stream steps of the same workload.
+    roof_steps, roof = args.steps, timed[dom]
+    if not dom_alone:
+        roof_steps = min(args.steps, 5)
+        ops.TIMER = ops.KernelTimer(only={dom})
+        for _ in range(roof_steps):
+            step(single_stream=True)
+        torch.cuda.synchronize()
+        roof = ops.TIMER.summary()[dom]
+        ops.TIMER = None
 
     if rank == 0:
-        ms = sum(r['total_ms'] for r in timed.values())
-        fl = sum(r['total_flops'] for r in timed.values())
-        nl = sum(r['launches'] for r in timed.values())
-        achieved = fl / (ms * 1e-3) / 1e12
         utt_s = world * B * args.steps / dt
         fstep = step_flops_per_utt(eng.g, T, F)
+        step_ms = 1e3 * dt / args.steps
         out = {
             'metric': 'utterances/sec (10 s audio, B=32) DFCNN+CTC fwd+bwd',
             'value': round(utt_s, 3), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
+            'warmup': args.warmup, 'ms_per_step': round(step_ms, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
             'config': {'workload': ('plain DFCNN (acoustic_model.py) + CTC' if variant == 'm1' else
                                     'SE-DFCNN (acoustic_model2.py) + CTC') +
                                    ', fbank+fwd+CTC+greedy+bwd+Adam, 10 s/16 kHz audio, T_pad %d, V %d' % (T, V),
                        'global_batch': world * B, 'batch_per_gpu': B, 't_pad': T, 'parallelism': 'dp%d' % world, **dp_info(),
                        'gflop_per_utt_fwd_bwd': round(fstep / 1e9, 3),
-                       'step_tflops': round(utt_s / world * fstep / 1e12, 2),
-                       'step_frac_of_fp32_peak': round(utt_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
+                       'step_algorithmic_tflops': round(utt_s / world * fstep / 1e12, 2),
+                       'step_algorithmic_frac_of_fp32_peak': round(utt_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
+                       'step_flops_note': 'direct-convolution flops (SURVEY 8d); the Winograd layers execute 1/2.25 of their multiplies, '
+                                          'so this is a rate of useful work, not a utilisation of the fp32 pipe',
                        'backward_streams': 2 if overlapped else 1, 'feature_prefetch': prefetch,
                        'host_input': bool(args.host_input),
-                       'conv_arithmetic': ('split-bf16 x6 products, fp32 accumulate (EXPERIMENTAL, ASR_BX6=1) for conv fwd/dgrad; '
-                                           'fp32 MFMA elsewhere') if eng.bx6 else
-                                          ('fp32 MFMA; 3x3 convs %s by Winograd F(2x2,3x3) in fp32 (ASR_WINO=0: direct)' % ('forward + data-gradient' if eng.wt_b else 'forward') if eng.wt_f else 'fp32 MFMA'),
+                       'conv_arithmetic': ('fp32 MFMA; 3x3 convs with N % 64 == 0 by Winograd F(2x2,3x3) in fp32, forward + data-gradient '
+                                           '(ASR_WINO=0: direct)' if eng.wt_f else 'fp32 MFMA, direct convolution'),
                        'mean_loss': round(mean_loss, 4)},
-            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 2), 'peak': kernel_peak(dom), 'unit': 'TFLOP/s',
-                         'frac': round(achieved / kernel_peak(dom), 4), 'traffic': None,
-                         'kernel': kernel_name(dom),
-                         'launches_per_step': nl // args.steps, 'avg_launch_us': round(1e3 * ms / nl, 2),
-                         'flop_per_launch': round(fl / nl / 1e9, 3), 'flop_unit': 'GFLOP',
-                         'share_of_step_time': round(ms / args.steps / (1e3 * dt / args.steps), 3)},
+            'roofline': roofline_block(dom, roof, roof_steps),
         }
-        if overlapped:
-            out['roofline']['note'] = ('backward runs on two streams (weight-gradient beside data-gradient + next prologue), so '
-                                       'backward kernel durations overlap; this is the dominant contraction that runs alone '
-                                       '(forward).  ASR_DUAL_STREAM=0 gives the single-stream step and per-kernel numbers.')
-        if dom.startswith('wino'):
-            out['roofline']['algorithm'] = ('Winograd F(2x2,3x3), fp32: `achieved` counts the ALGORITHMIC flops of the direct 3x3 '
-                                            'convolution (SURVEY 8d: 2 x MACs); the kernel issues 2.25x fewer MFMA multiplies, so '
-                                            'its matrix-pipe utilisation is achieved / 2.25 / peak')
-            out['roofline']['mfma_pipe_frac'] = round(achieved / 2.25 / kernel_peak(dom), 4)
+        rf = out['roofline']
+        rf['share_of_single_stream_step'] = round(table[dom]['total_ms'] / sum(r['total_ms'] for r in table.values()), 3)
+        rf['selection'] = ('kernel symbol with the most time in a single-stream warm-up step (all %d contraction symbols between HIP '
+                           'events on the launch stream)' % len(table))
+        if dom_alone:
+            rf['measured'] = 'HIP events on the launch stream inside the timed region (%d launches); the kernel runs alone there' % roof['launches']
+        else:
+            rf['measured'] = ('HIP events on the launch stream in %d single-stream steps after the timed region (%d launches): in the '
+                              'real step this kernel runs on the second stream beside the data-gradients, where a launch took '
+                              '%.1f us on average (overlapped, not a per-kernel figure)'
+                              % (roof_steps, roof['launches'], timed[dom]['avg_us']))
         # the committed PMC pass was taken on the default configuration only
         tr, src = pmc_traffic(args.workload, dom) if (args.tpad == 1600 and args.batch == 32) else (None, None)
-        out['roofline']['traffic'] = tr
+        rf['traffic'] = tr
         if src:
-            out['roofline']['traffic_unit'] = 'bytes/launch (PMC pass: %s)' % src
+            rf['traffic_unit'] = 'bytes/launch (PMC pass: %s)' % src
         if args.kernel_table:
             for key, r in sorted(table.items(), key=lambda kv: -kv[1]['total_ms']):
-                print('%-48s launches %3d  total %8.3f ms  avg %9.1f us  %7.2f TFLOP/s' %
-                      (key, r['launches'], r['total_ms'], r['avg_us'], r['tflops']), file=sys.stderr)
-        if experimental is not None:
-            out['experimental_split_bf16'] = experimental
+                pk = kernel_peak(key)[0]
+                print('%-56s launches %3d  total %8.3f ms  avg %9.1f us  %7.2f TFLOP/s  %.3f of its bound' %
+                      (key, r['launches'], r['total_ms'], r['avg_us'], r['tflops'], r['tflops'] / pk), file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline(variant, T, V)
+            out['cpu_baseline'] = cpu_baseline(variant, T, V, batch=B)
         print(json.dumps(out), flush=True)
     barrier()
     if world > 1:

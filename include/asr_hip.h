@@ -42,7 +42,7 @@ typedef enum {
 
 int asr_version(void);
 /* Name of the contraction kernel instantiation the calling thread's last asr_tap_gemm / asr_tap_gemm_pw /
- * asr_tap_gemm_bx6 / asr_tap_wgrad / asr_tap_wgrad_bx6 call enqueued, spelled as rocprofv3 --kernel-trace prints it
+ * asr_tap_gemm_wino / asr_tap_wgrad call enqueued, spelled as rocprofv3 --kernel-trace prints it
  * without the namespace (e.g. "tap_gemm_kernel_v5<128, 64, 2, 2, 9, 16, 3, 3, 0>"); "" before the first such call.
  * bench.py keys its HIP-event timings by it, so that `roofline.kernel` always names the row of the rocprof summary
  * the launcher's dispatch rules really picked.  The pointer stays valid for the life of the library. */
@@ -457,34 +457,6 @@ int asr_tap_gemm_gated(const asr_gemm_desc* d, const float* dZ, const float* W, 
                        int pool, int gate_H, int gate_W, const float* gate_a,
                        const float* bn_scale, const float* bn_shift, const float* dy_prev,
                        float* dz_out, float* dscale, float* dshift, float* dbias, float* partials, void* stream);
-
-/* ====================================================================== EXPERIMENTAL: split-bf16 contractions
- * (DESIGN.md section 9).  Same contraction and epilogue as asr_tap_gemm, computed as six v_mfma_f32_32x32x16_bf16
- * products of the hi/mid/lo bf16 pieces of the fp32 operands with fp32 accumulation (fp32-chain accuracy, 2.6x the matrix
- * pipe rate).  The weights are pre-split and transposed once per optimiser step:
- *   asr_split_weights(W, ntaps, K, N, ldw, wmode, out): out = bf16 in MFMA fragment order [ntaps][3][Kp/16][ceil(N/32)]
- *   [64 lanes][8] (lane 32h+i = column 32*block+i, k = 16*step+8h..+7; Kp = K rounded up to 32, zero padded); wmode 1
- *   takes the data-gradient view of a forward tensor (K, N = the GEMM's, i.e. swapped; taps mirrored), after which
- *   asr_tap_gemm_bx6 is called with desc.wmode ignored.  NOT used by the engines / bench unless ASR_BX6=1. */
-size_t asr_split_weights_bytes(int ntaps, int K, int N);
-int asr_split_weights(const float* W, int ntaps, int K, int N, int ldw, int wmode, void* out, void* stream);
-/* split-bf16 weight gradient (3x3 taps, N > 64): same arguments and workspace as asr_tap_wgrad; operands are split at
- * staging time and read transposed from LDS (ds_read_b64_tr_b16). */
-int asr_tap_wgrad_bx6(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz,
-                      float* dW, float* partials, void* stream);
-int asr_tap_gemm_bx6(const asr_gemm_desc* d, const float* A, const void* Wsplit,
-                     const float* bias, const float* scale, const float* shift,
-                     float* out_a, float* out_y, void* stream);
-/* Dense contraction on PRE-SPLIT operands (the Transformer projections / FFN, end2end/transformer.py:117-158,204-231):
- *   asr_split_rows(X [M][K] fp32, row pitch ldx) -> bf16 [3][Kp/32][M][32] (hi, mid, lo planes stored K-chunk-major;
- *   Kp = K rounded up to 32);
- *   asr_gemm_bx6s: Y [M][N] (+)= act(A . B + bias) with A = split planes [3][M][Kp] and B = asr_split_weights(W, 1, K, N, ...)
- *   (wmode 0 for the forward, wmode 1 with K and N swapped for the data-gradient); Ysplit, if given, also receives the
- *   result as split planes [3][Np/32][M][32] for the next GEMM. */
-size_t asr_split_rows_bytes(long M, int K);
-int asr_split_rows(const float* X, long M, int K, int ldx, void* out, void* stream);
-int asr_gemm_bx6s(const void* Asplit, const void* Bsplit, long M, int K, int N, const float* bias, int relu,
-                  int accumulate, float* Y, int ldy, void* Ysplit, void* stream);
 
 #ifdef __cplusplus
 }

@@ -82,10 +82,6 @@ def test_size_helpers_and_argument_checks_without_a_gpu():
     # fragment-order fp32 weights: [taps][ceil(K/8)][ceil(N/32)][64 lanes][4] floats
     assert lib.asr_arrange_weights_bytes(9, 64, 128) == 9 * 8 * 4 * 256 * 4
     assert lib.asr_arrange_weights_bytes(1, 72, 100) == 1 * 9 * 4 * 256 * 4
-    # split-bf16 weights: 3 pieces, K rounded up to 32, N rounded up to 32, 2 bytes
-    assert lib.asr_split_weights_bytes(9, 64, 128) == 9 * 3 * 128 * 64 * 2
-    assert lib.asr_split_weights_bytes(1, 72, 100) == 3 * 128 * 96 * 2
-    assert lib.asr_split_rows_bytes(1000, 72) == 3 * 1000 * 96 * 2
     d = ops.gemm_desc(32 * 201 * 26, 128, 128, 128, 128, ntaps=9, B=32, H=200, W=25)
     ws = lib.asr_tap_wgrad_workspace(C.byref(d))
     assert ws % (9 * 128 * 128 * 4) == 0 and ws >= 2 * 9 * 128 * 128 * 4          # whole partial slabs
@@ -93,7 +89,5 @@ def test_size_helpers_and_argument_checks_without_a_gpu():
     bad = lib.asr_tap_gemm_pw(C.byref(d), null, null, null, null, null, null, null, null)
     assert bad < 0
     assert lib.asr_arrange_weights(null, 9, 64, 128, 128, 0, null, null) < 0
-    assert lib.asr_split_rows(null, 10, 8, 8, null, null) < 0
-    assert lib.asr_gemm_bx6s(null, null, 10, 8, 8, null, 0, 0, null, 8, null, null) < 0
     assert lib.asr_tap_gemm(C.byref(d), null, null, null, null, null, null, null, null) < 0
     assert lib.asr_ctc_loss(null, 8, 2, 9, null, 64, null, null, 8, null, null, null, null, null) < 0

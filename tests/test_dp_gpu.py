@@ -164,27 +164,6 @@ def test_data_generation_drop_rules_and_layouts():
     assert w0.shape[0] == 0 and len(l0) == 0 and p0.shape == (0, 64)
 
 
-def test_tied_transformer_two_stream_backward_is_bitwise_the_single_stream_one(monkeypatch):
-    """ASR_TR_DUAL_STREAM=1 on a tied encoder-decoder (shared tensors receive two weight-gradient contributions through a
-    scratch buffer, bias gradients of shared FFN biases through another): same gradient bits as with one stream."""
-    from asr_dfcnn_transformer_amd.transformer_engine import E2EEngine
-    rng = np.random.default_rng(3)
-    N, T, C, H, blocks, Vin, Vout = 2, 24, 128, 2, 2, 50, 70
-    x = rng.integers(1, Vin, (N, T)); y = rng.integers(3, Vout, (N, T))
-    y_in = np.concatenate([np.ones((N, 1), dtype=np.int64), y[:, :-1]], axis=1)
-    grads = []
-    for mode in ('0', '1', '1'):
-        monkeypatch.setenv('ASR_TR_DUAL_STREAM', mode)
-        e = E2EEngine(vin=Vin, vout=Vout, N=N, T=T, L=T, C=C, heads=H, blocks=blocks, pos_max=64, tie=True, seed=2)
-        assert (e.side is not None) == (mode == '1')
-        for _ in range(2):
-            e.forward(x, y_in, y)
-            e.backward()
-        torch.cuda.synchronize()
-        grads.append(e.grad.clone())
-    assert torch.equal(grads[0], grads[1]) and torch.equal(grads[1], grads[2])
-
-
 def test_composite_checkpoints_round_trip(tmp_path):
     """save_checkpoint / load_checkpoint of the joint AM+LM engine (two parts) and of the speech Transformer shim
     (pre-net + encoder-decoder): every part's variables, Adam slots and global_step come back; a checkpoint of a

@@ -367,6 +367,38 @@ def test_ctc_infeasible_and_full_width(ops):
     report('ctc grad full', g[:, keep], g_ref, 2e-6)
 
 
+def test_ctc_saturated_logits_fall_back_to_the_log_domain(ops):
+    """A collapsed model: softmax saturated on the blank, every label at the eps floor -- log(p + 1e-7) = -16.1 per label
+    emission (acoustic_model2.py:68).  With 64 (or 50) labels the states the likelihood needs sit e^-1000 below the frame's
+    dominant state: the linear-domain lattice of the kernel flushes them to zero in float64; it must notice (tail == 0, or the
+    occupancies of a frame not summing to 1) and redo those utterances in the log domain.  tf.nn.ctc_loss returns a finite
+    loss here, and so does the oracle; before round 3 the kernel returned +inf and NaN gradients.  Utterance 2 (3 labels) and
+    utterance 3 (ordinary random logits) stay on the fast path in the same launch."""
+    rng = np.random.default_rng(21)
+    T, B, V = 200, 4, 1536
+    labels = [list(rng.permutation(np.arange(1, V - 1))[:64]), [int(v) for v in rng.integers(1, 40, 50)], [4, 9, 4],
+              list(rng.integers(1, V - 1, 32))]
+    seq = [200, 200, 200, 125]
+    x, lab, ll, sl, ml = _ctc_inputs(rng, T, B, V, labels, seq)
+    p = np.zeros((T, 3, V)); p[:, :, V - 1] = 1.0
+    x[:, :3] = np.log(p + 1e-7).astype(np.float32)
+    loss_ref, g_ref = octc.ctc_loss_and_grad(x, labels, seq, V - 1)
+    assert np.all(np.isfinite(loss_ref)) and loss_ref[0] > 900 and loss_ref[1] > 650
+    loss = torch.zeros(B, device='cuda')
+    grad = torch.full((T, B, V), 7.0, device='cuda')
+    status = torch.zeros(B, dtype=torch.int32, device='cuda')
+    ws = torch.zeros(ops.ctc_workspace(T, B, ml) // 8 + 8, dtype=torch.float64, device='cuda')
+    ops.ctc_loss(dev(x), T, B, V, dev(lab, torch.int32), ml, dev(ll, torch.int32), dev(sl, torch.int32), V - 1,
+                 loss, grad, status, ws)
+    assert status.cpu().tolist() == [0] * B
+    l, g = loss.cpu().numpy(), grad.cpu().numpy()
+    assert np.all(np.isfinite(l)) and np.all(np.isfinite(g))
+    report('ctc loss saturated', l, loss_ref, 1e-6)
+    report('ctc grad saturated', g, g_ref, 2e-6)
+    # rows of the gradient w.r.t. the logits sum to 0 (softmax minus a distribution) wherever the utterance has frames
+    assert np.abs(g[:125].sum(axis=2)).max() < 1e-4
+
+
 def test_greedy_decode_bit_exact(ops):
     rng = np.random.default_rng(12)
     T, B, V = 60, 6, 1536

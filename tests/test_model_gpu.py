@@ -155,14 +155,11 @@ def test_session_style_model_trains_and_checkpoints(tmp_path):
 
 
 @pytest.mark.parametrize("model,widths", [('m2', (16, 32, 32, 64)), ('m1', (8, 16, 32, 64, 8, 32)), ('m3', (8, 16, 32, 64))])
-def test_stream_and_fusion_modes_give_the_same_bits(model, widths, monkeypatch):
+def test_stream_and_fusion_modes_give_the_same_bits(model, widths):
     """The same step with the backward on one stream or two, and with the backward prologues fused into the data-gradient
     epilogues or run as passes of their own: dZ is the same arithmetic either way, so the weight / bias gradients are
     bitwise equal; the three BN / bias channel sums of fused cells are folded in another (fixed) order -> 1e-6."""
     from asr_dfcnn_transformer_amd.engine import DFCNNEngine
-    import os
-    if os.environ.get('ASR_BX6') == '1':
-        pytest.skip('the opt-in split-bf16 mode runs the backward prologues as passes of their own (no fused form to compare)')
     rng = np.random.default_rng(5)
     B, T, F, V = 2, 64, 24, 20
     x = torch.tensor(rng.standard_normal((B, T, F)).astype(np.float32), device='cuda')
@@ -171,8 +168,8 @@ def test_stream_and_fusion_modes_give_the_same_bits(model, widths, monkeypatch):
     grads = {}
     for dual in ('1', '0'):
         for fuse in ('1', '0'):
-            monkeypatch.setenv('ASR_DUAL_STREAM', dual); monkeypatch.setenv('ASR_FUSE_PRE', fuse)
-            eng = DFCNNEngine(model=model, vocab=V, B=B, T=T, F=F, widths=widths, seed=1)
+            eng = DFCNNEngine(model=model, vocab=V, B=B, T=T, F=F, widths=widths, seed=1, dual_stream=dual == '1',
+                              fuse_prologues=fuse == '1')
             assert bool(eng.fuse) == (fuse == '1') and (eng.side is not None) == (dual == '1')
             for _ in range(2):
                 eng.forward(x); eng.set_targets([8, 8], tgt); eng.loss_and_decode(); eng.backward()

@@ -18,13 +18,12 @@ def main():
     n = 0
     for wl in ('dfcnn', 'se_dfcnn', 'transformer', 'e2e_prenet', 'am_lm', 'lm'):
         nm = NAME.get(wl, wl)
-        for suffix in ('kernel_stats.csv', 'single_stream_kernel_stats.csv', 'split_bf16_kernel_stats.csv', 'pmc_summary.csv',
+        for suffix in ('kernel_stats.csv', 'single_stream_kernel_stats.csv', 'pmc_summary.csv',
                        'traffic.json'):
             f = os.path.join(src, '%s_%s' % (wl, suffix))
             if os.path.exists(f):
                 shutil.copy(f, os.path.join(dst, '%s_%s_%s' % (tag, nm, suffix))); n += 1
-        for log, label in (('bench_%s.log', 'bench_%s_under_rocprof.json'), ('bench1_%s.log', 'bench_%s_single_stream_under_rocprof.json'),
-                           ('benchx_%s.log', 'bench_%s_split_bf16_under_rocprof.json')):
+        for log, label in (('bench_%s.log', 'bench_%s_under_rocprof.json'), ('bench1_%s.log', 'bench_%s_single_stream_under_rocprof.json')):
             f = os.path.join(src, log % wl)
             if not os.path.exists(f):
                 continue
