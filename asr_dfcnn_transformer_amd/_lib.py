@@ -88,6 +88,7 @@ SIGNATURES = {
     'asr_prenet_conv1_bwd': (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P]),
     'asr_bn_workspace': (_Z, [C.POINTER(PixMap)]),
     'asr_bn_stats': (_I, [_P, C.POINTER(PixMap), _F, _P, _P, _P, _P]),
+    'asr_bn_moving': (_I, [_P, _P, _I, _F, _F, _F, _P, _P, _P, _P]),
     'asr_bn_apply': (_I, [_P, C.POINTER(PixMap), _P, _P, _P, _P, _P, C.POINTER(PixMap), _I, _P, C.POINTER(PixMap), _P]),
     'asr_bn_bwd': (_I, [_P, C.POINTER(PixMap), _P, C.POINTER(PixMap), _P, _P, _P, _I, _P, C.POINTER(PixMap), _P, _P, _P, _P]),
     'asr_relu_mask': (_I, [_P, C.POINTER(PixMap), _P, C.POINTER(PixMap), _P, C.POINTER(PixMap), _P]),

@@ -92,9 +92,24 @@ class CNNCTCModel:
                 # reduce_mean over the rows of the (global) batch, acoustic_model2.py:83: under data parallelism every rank
                 # divides by the GLOBAL number of surviving rows, so the summed all-reduce is that mean whatever each
                 # rank's B' is (a rank may even hold 0 rows: it still enters every collective)
-                denom = r.sum_count(n) if (dp and self.train_op in flist) else n
-                e.set_targets(np.asarray(feed_dict[self.logits_length]), np.asarray(tp), n_valid=n,
-                              loss_denom=max(denom, 1))
+                # The host-side target checks (label length, "not enough time for target transition sequence": where TF raises
+                # InvalidArgumentError) run BEFORE the first collective of the step and their verdict rides on it: a bad batch
+                # on one rank stops every rank here, none is left waiting inside a gradient all-reduce.
+                prepared, err = None, None
+                try:
+                    prepared = e.prepare_targets(np.asarray(feed_dict[self.logits_length]), np.asarray(tp), n_valid=n)
+                except ValueError as ex:
+                    err = ex
+                if dp and self.train_op in flist:
+                    try:
+                        denom = r.sum_count(n, ok=err is None)
+                    except RuntimeError:
+                        if err is not None:
+                            raise err
+                        raise
+                elif err is not None:
+                    raise err
+                e.commit_targets(prepared, loss_denom=max(denom, 1))
                 e.loss_and_decode(defer_decode_join=self.train_op in flist)
         if self.train_op in flist:
             if not self.is_training:

@@ -46,6 +46,9 @@ class CNNCTCModel:
                                  dropout_rate=self.dropout_rate if self.is_training else 0.0)
         self.hidden_units = self.engine.lm.C            # = width of h7 (D1), not args.hidden_units
         self.num_heads = self.engine.lm.H
+        import torch.distributed as dist
+        # one process per GPU (am_lm_train.train_model): gradients summed over ranks, Adam averages
+        self.reducers = self.engine.make_reducers() if (dist.is_initialized() and dist.get_world_size() > 1) else None
 
     @property
     def global_step(self):
@@ -71,8 +74,8 @@ class CNNCTCModel:
                           np.asarray(feed_dict[self.target_py_length]), feed_dict.get(self.target_hanzi))
             e.loss_and_decode()
         if train:
-            e.backward()
-            e.apply_adam()
+            e.backward(self.reducers)
+            e.apply_adam(self.reducers[0].grad_scale if self.reducers else 1.0)
         out, scal = [], None
         for f in flist:
             if f == self.am_logits:

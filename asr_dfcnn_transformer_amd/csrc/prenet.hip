@@ -712,6 +712,39 @@ extern "C" int asr_bn_stats(const float* src, const asr_pixmap* m, float eps, fl
     return ASR_OK;
 }
 
+namespace {
+// moving statistics of a Keras BatchNormalization (keras/layers/normalization.py 2.3.1, call(): the batch variance is made
+// unbiased with sample_size / (sample_size - (1 + epsilon)) before K.moving_average_update, which is
+// variable -= (variable - value) * (1 - momentum)), and the inference-mode 1 / sqrt(moving_var + eps)
+__global__ void bn_moving_kernel(const float* __restrict__ mean, const float* __restrict__ rstd, int C, float eps, float count,
+                                 float momentum, float* __restrict__ mov_mean, float* __restrict__ mov_var,
+                                 float* __restrict__ inf_rstd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float mm = mov_mean[c], mv = mov_var[c];
+    if (mean && rstd) {
+        const float r = rstd[c];
+        float var = 1.f / (r * r) - eps;
+        if (var < 0.f) var = 0.f;
+        var *= count / (count - (1.f + eps));
+        mm -= (mm - mean[c]) * (1.f - momentum);
+        mv -= (mv - var) * (1.f - momentum);
+        mov_mean[c] = mm; mov_var[c] = mv;
+    }
+    if (inf_rstd) inf_rstd[c] = 1.f / sqrtf(mv + eps);
+}
+}  // namespace
+
+extern "C" int asr_bn_moving(const float* mean, const float* rstd, int C, float eps, float count, float momentum,
+                             float* mov_mean, float* mov_var, float* inf_rstd, void* stream) {
+    if (!mov_mean || !mov_var || C < 1 || (!!mean != !!rstd) || (!mean && !inf_rstd)) return ASR_ERR_BAD_ARG;
+    if (mean && !(count > 1.f + eps)) return ASR_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bn_moving_kernel, dim3(asr_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, mean, rstd, C, eps, count, momentum,
+                       mov_mean, mov_var, inf_rstd);
+    ASR_CHECK_LAUNCH("bn_moving");
+    return ASR_OK;
+}
+
 extern "C" int asr_bn_apply(const float* src, const asr_pixmap* sm, const float* mean, const float* rstd,
                             const float* gamma, const float* beta, const float* res, const asr_pixmap* rm, int relu,
                             float* dst, const asr_pixmap* dm, void* stream) {

@@ -225,3 +225,9 @@ class DataLoader:
     def am_generator(self):
         for i in range(len(self)):
             yield self[i]
+
+    def end2end_generator(self):
+        """lm_and_am/data_loader.py:257-266: the same six-tuple per batch, as the joint loop's tf.data generator
+        (am_lm_train.py:47-49)."""
+        for i in range(len(self)):
+            yield self[i]

@@ -30,9 +30,32 @@ class Transformer_Model:
         self.tie, self.seed, self.device = tie, seed, device
         self.engine = None
         self.prenet = None
+        self._restore = None          # parts of a checkpoint waiting for their engine (restore_checkpoint)
 
     def build_transformer(self):
         return self
+
+    def restore_checkpoint(self, path):
+        """saver.restore(sess, tf.train.latest_checkpoint(model_path)) of transformerTrain.train (end2end/model.py:81-88).  The
+        engines of this shim are built on the first run() (their shapes come from the first batch), so the checkpoint's parts
+        are kept here and copied into each engine the moment it is created: variables, Adam slots and global_step."""
+        ck = torch.load(path, map_location='cpu', weights_only=True)
+        if ck.get('format') != 2 or '' not in ck['parts']:
+            raise ValueError('%s is not a checkpoint of an encoder-decoder model' % path)
+        self._restore = dict(ck['parts'])
+        for name, e in (('', self.engine), ('prenet', self.prenet)):
+            if e is not None:
+                self._restore_into(name, e)
+
+    def _restore_into(self, name, e):
+        st = (self._restore or {}).pop(name, None)
+        if st is None:
+            return
+        ent = {str(k): (int(v[0]), tuple(int(d) for d in v[1])) for k, v in e.entries.items()}
+        if st['variant'] != str(getattr(e, 'model', type(e).__name__)) or st['entries'] != ent:
+            raise ValueError('checkpoint part %r was written by a different model (%s)' % (name, st['variant']))
+        e.theta.copy_(st['theta']); e.adam_m.copy_(st['adam_m']); e.adam_v.copy_(st['adam_v'])
+        e.global_step = int(st['global_step'])
 
     def _prenet_for(self, T):
         p = self.prenet
@@ -42,6 +65,8 @@ class Transformer_Model:
         if p is not None:
             new.theta.copy_(p.theta); new.adam_m.copy_(p.adam_m); new.adam_v.copy_(p.adam_v)
             new.global_step = p.global_step
+        else:
+            self._restore_into('prenet', new)
         self.prenet = new
         return new
 
@@ -58,6 +83,8 @@ class Transformer_Model:
         if e is not None:
             new.theta.copy_(e.theta); new.adam_m.copy_(e.adam_m); new.adam_v.copy_(e.adam_v)
             new.global_step = e.global_step
+        else:
+            self._restore_into('', new)
         self.engine = new
         return new
 

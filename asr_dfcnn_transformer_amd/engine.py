@@ -563,12 +563,16 @@ class DFCNNEngine:
         With ``target_length`` [B] the labels are the DENSE form of tf.nn.ctc_loss_v2(labels=target_py,
         label_length=target_length) (am_lm_model.py:72): the first target_length ids of each row, zeros kept.
         Raises ValueError where TF raises InvalidArgumentError (no valid CTC alignment)."""
+        self.commit_targets(self.prepare_targets(logits_length, target_py, target_length, n_valid, loss_denom))
+
+    def prepare_targets(self, logits_length, target_py, target_length=None, n_valid=None, loss_denom=None):
+        """The host half of set_targets: every check (and its ValueError) and the label arrays, nothing touches the device or
+        the engine.  A data-parallel caller runs it BEFORE its first collective of the step, so that a rank whose batch cannot
+        be aligned fails together with the others instead of leaving them inside an all-reduce (acoustic_model.run)."""
         tp = np.asarray(target_py)
         nv = self.B if n_valid is None else int(n_valid)
         if not 0 <= nv <= self.B:
             raise ValueError('n_valid %d outside [0, %d]' % (nv, self.B))
-        self.n_valid = nv
-        self.loss_denom = float(loss_denom if loss_denom is not None else max(nv, 1))
         lab = np.zeros((self.B, MAX_LABEL), dtype=np.int32)
         ll = np.zeros(self.B, dtype=np.int32)
         sl = np.zeros(self.B, dtype=np.int32)
@@ -583,6 +587,14 @@ class DFCNNEngine:
                                  'in batch %d' % (len(ids) + rep, sl[b], b))
             lab[b, :len(ids)] = ids
             ll[b] = len(ids)
+        return nv, loss_denom, lab, ll, sl
+
+    def commit_targets(self, prepared, loss_denom=None):
+        nv, denom, lab, ll, sl = prepared
+        if loss_denom is not None:
+            denom = loss_denom
+        self.n_valid = nv
+        self.loss_denom = float(denom if denom is not None else max(nv, 1))
         self.labels.copy_(torch.from_numpy(lab), non_blocking=True)
         self.label_len.copy_(torch.from_numpy(ll), non_blocking=True)
         self.seq_len.copy_(torch.from_numpy(sl), non_blocking=True)

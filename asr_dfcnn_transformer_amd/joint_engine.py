@@ -174,13 +174,29 @@ class AMLMEngine:
     def han_wer(self):
         return float(self.lm.loss_sum.cpu().numpy()[1]) / self.B
 
-    def backward(self):
+    def backward(self, reducers=None):
+        """``reducers`` = (BucketedAllReduce over lm.grad, BucketedAllReduce over am.grad in engine.param_layout's three buckets):
+        under data parallelism the language half's gradients are summed while the acoustic backward runs, the acoustic dense
+        head as soon as it is final, the rest at the end (bench.py --workload am_lm)."""
         dh7 = self.lm.backward()
-        self.am.backward(extra={'h7': dh7})
+        if reducers is None:
+            self.am.backward(extra={'h7': dh7})
+            return
+        red_lm, red_am = reducers
+        red_lm.launch(0)
+        self.am.backward(on_dense_grads_ready=lambda: red_am.launch(0), extra={'h7': dh7})
+        red_am.launch(1); red_am.launch(2)
+        red_lm.wait(); red_am.wait()
 
-    def apply_adam(self):
-        self.lm.apply_adam()
-        return self.am.apply_adam()
+    def make_reducers(self):
+        from .parallel import BucketedAllReduce
+        am, lm = self.am, self.lm
+        return (BucketedAllReduce(lm.grad, [(0, lm.grad.numel())]),
+                BucketedAllReduce(am.grad, [(am.n_gamma, am.dense_end), (0, am.n_gamma), (am.dense_end, am.grad.numel())]))
+
+    def apply_adam(self, gscale=1.0):
+        self.lm.apply_adam(gscale)
+        return self.am.apply_adam(gscale)
 
     def fetch(self):
         """-> (am_mean_loss, lm_mean_loss, mean_loss, label_err of the acoustic half)"""

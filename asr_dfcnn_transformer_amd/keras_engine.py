@@ -20,6 +20,7 @@ from . import ops
 from .ops import Plane
 
 BN_EPS = 1e-3            # keras.layers.BatchNormalization default epsilon
+BN_MOMENTUM = 0.99       # ... and momentum
 K_EPSILON = 1e-7         # keras.backend.epsilon()
 MAX_LABEL = 64
 CELLS = [(32, True), (64, True), (128, True), (128, False), (128, False)]
@@ -50,6 +51,9 @@ class KerasDFCNNEngine:
                 cp = max(cin, 4)
                 add(n + '/w', (3, 3, cin, size), (3, 3, cp, size)); add(n + '/b', (size,))
                 add(n + '/g', (size,)); add(n + '/be', (size,))
+                # moving_mean / moving_variance of the BatchNormalization (non-trainable: their gradient stays 0, so Adam
+                # never moves them; living in theta they are part of every checkpoint like the Keras weights file)
+                add(n + '/mm', (size,)); add(n + '/mv', (size,))
                 self.convs.append((n, cp, size, H, W, pool and j == 'b'))
                 cin = size
             if pool:
@@ -133,15 +137,19 @@ class KerasDFCNNEngine:
             if name.endswith('/w'):
                 fan_in = int(np.prod(shp[:-1]))
                 flat[name] = rng.standard_normal(shp) * math.sqrt(2.0 / fan_in)
-            elif name.endswith('/g'):
+            elif name.endswith('/g') or name.endswith('/mv'):
                 flat[name] = np.ones(shp)
             else:
                 flat[name] = np.zeros(shp)
         self.load_params(flat)
 
     def load_params(self, flat):
+        """flat: {name: ndarray} in logical shapes; moving statistics that are not given start at Keras' initial values
+        (moving_mean 0, moving_variance 1)."""
         host = self.theta.cpu().numpy()
         for name, (off, phys) in self.entries.items():
+            if name not in flat and name.endswith(('/mm', '/mv')):
+                flat = dict(flat); flat[name] = np.zeros(self.logical[name]) if name.endswith('/mm') else np.ones(self.logical[name])
             v = np.asarray(flat[name], dtype=np.float32)
             assert tuple(v.shape) == self.logical[name], (name, v.shape, self.logical[name])
             buf = np.zeros(phys, dtype=np.float32)
@@ -165,9 +173,13 @@ class KerasDFCNNEngine:
         return (self.drop_seed + 1009 * self.global_step + 7919 * site) & 0xFFFFFFFF
 
     def forward(self, x, train=True):
-        """x: [B, T, F] float32 on the device -> time-major log(softmax + 1e-7) logits [T/8, B, vocab]."""
+        """x: [B, T, F] float32 on the device -> time-major log(softmax + 1e-7) logits [T/8, B, vocab].
+        train=True is Keras' learning phase 1 (ctc_model.fit / train_on_batch): BatchNormalization on BATCH moments, the
+        moving statistics take a momentum-0.99 step, Dropout live.  train=False is phase 0 (Model.predict, cnn_ctc.py:82;
+        evaluate): BatchNormalization on the MOVING statistics, Dropout off."""
         assert tuple(x.shape) == (self.B, self.T, self.F)
         self._rate = self.dropout_rate if train else 0.0
+        self._train = bool(train)
         self.x4.interior()[..., 0].copy_(x)
         src = self.x4
         for n, cp, cout, H, W, pool_after in self.convs:
@@ -179,8 +191,13 @@ class KerasDFCNNEngine:
             else:
                 ops.tap_gemm(self.fdesc[n], src, self.p(n + '/w'), self.p(n + '/b'), None, None, self.a[n], None)
             mean, rstd = self.stats[n]
-            ops.bn_stats(self.a[n], BN_EPS, mean, rstd, self.ws)
-            ops.bn_apply(self.a[n], mean, rstd, self.p(n + '/g'), self.p(n + '/be'), self.y[n])
+            if train:
+                ops.bn_stats(self.a[n], BN_EPS, mean, rstd, self.ws)
+                ops.bn_moving(mean, rstd, cout, BN_EPS, self.B * H * W, BN_MOMENTUM, self.p(n + '/mm'), self.p(n + '/mv'))
+                ops.bn_apply(self.a[n], mean, rstd, self.p(n + '/g'), self.p(n + '/be'), self.y[n])
+            else:
+                ops.bn_moving(None, None, cout, BN_EPS, 0, BN_MOMENTUM, self.p(n + '/mm'), self.p(n + '/mv'), rstd)
+                ops.bn_apply(self.a[n], self.p(n + '/mm'), rstd, self.p(n + '/g'), self.p(n + '/be'), self.y[n])
             src = self.y[n]
             if pool_after:
                 ops.pool_fwd(self.y[n], self.ones[:cout], self.zeros[:cout], 2, self.yp[n])

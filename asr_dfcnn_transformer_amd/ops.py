@@ -412,6 +412,12 @@ def bn_stats(src, eps, mean, rstd, ws, **kw):
     check(_lib.load().asr_bn_stats(p, C.byref(m), eps, _ptr(mean), _ptr(rstd), _ptr(ws), _stream()), 'asr_bn_stats')
 
 
+def bn_moving(mean, rstd, C_, eps, count, momentum, mov_mean, mov_var, inf_rstd=None):
+    """One momentum step of a Keras BatchNormalization's moving statistics and / or its inference-mode 1/sqrt(var + eps)."""
+    check(_lib.load().asr_bn_moving(_ptr(mean), _ptr(rstd), C_, eps, float(count), momentum, _ptr(mov_mean), _ptr(mov_var),
+                                    _ptr(inf_rstd), _stream()), 'asr_bn_moving')
+
+
 def bn_apply(src, mean, rstd, gamma, beta, dst, res=None, relu=False, dst_phase_split=False):
     ps, sm = pixmap(src)
     pd, dm = pixmap(dst, phase_split=dst_phase_split)

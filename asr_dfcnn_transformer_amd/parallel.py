@@ -70,15 +70,24 @@ class BucketedAllReduce:
             w.wait()
         self.pending = []
 
-    def sum_count(self, n):
+    def sum_count(self, n, ok=True):
         """Sum of a per-rank integer over the ranks (rows that survived the loader: the denominator of the global
-        mean).  One tiny blocking all-reduce; every rank must call it the same number of times."""
+        mean).  One tiny blocking all-reduce; every rank must call it the same number of times.  ``ok=False`` reports that
+        this rank cannot take the step (its batch failed a host-side check): the same collective carries the flag, and EVERY
+        rank then gets RuntimeError here -- before any gradient all-reduce is entered -- instead of the healthy ranks
+        waiting for the failed one until the RCCL timeout."""
         if self.world == 1:
+            if not ok:
+                raise RuntimeError('this step cannot run (host-side check failed)')
             return int(n)
         dev = self.flat.device if dist.get_backend(self.group) == 'nccl' else 'cpu'
-        t = torch.tensor([int(n)], dtype=torch.int64, device=dev)
+        t = torch.tensor([int(n), 0 if ok else 1], dtype=torch.int64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        return int(t.item())
+        tot, bad = (int(v) for v in t.tolist())
+        if bad:
+            raise RuntimeError('%d rank(s) cannot take this step (host-side target check failed); no rank entered the gradient '
+                               'all-reduce' % bad)
+        return tot
 
     @property
     def grad_scale(self):

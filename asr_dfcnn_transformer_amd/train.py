@@ -197,8 +197,11 @@ def train_transformer(args, loader, model=None, ckpt_dir=None, seed=0):
         torch.cuda.set_device(local)
     model = model or Transformer_Model(args, label_vocab_size=loader.language_vocab_size)
     model.build_transformer()
-    if ckpt_dir and os.path.exists(os.path.join(ckpt_dir, 'final_model.pt')) and model.engine is not None:
-        load_checkpoint(model, os.path.join(ckpt_dir, 'final_model.pt'))
+    if ckpt_dir and os.path.exists(os.path.join(ckpt_dir, 'final_model.pt')):
+        # model.py:81-88: restore the latest checkpoint before the loop.  The shim builds its engines on the first batch, so
+        # the restore is deferred to that moment (Transformer_Model.restore_checkpoint); train_steps restarts at 0 as in the
+        # reference, global_step (the learning-rate schedule) continues
+        model.restore_checkpoint(os.path.join(ckpt_dir, 'final_model.pt'))
     batch_nums = len(loader)
     mine = set(rank_batches(batch_nums, world, rank))
     train_steps, history = 0, []

@@ -85,13 +85,45 @@ _extractors = {}
 
 
 def compute_fbank_from_api(signal, sample_rate, nfilt=200):
-    """Reference signature (util/wav_util.py:22).  ``signal`` is a 1-D array in [-1, 1)."""
-    key = (int(sample_rate), int(nfilt))
+    """Reference signature (util/wav_util.py:22-31).  ``signal`` is a 1-D array (soundfile: float in [-1, 1)).
+    A 2-D ``[channels, n]`` array -- what ``read_wav_data`` returns -- goes through python_speech_features' pre-emphasis as
+    the reference's does: ``numpy.append(signal[0], signal[1:] - 0.97 * signal[:-1])`` on a [1, n] array is the row ITSELF
+    (``signal[1:]`` is empty), i.e. a mono file read that way is NOT pre-emphasised (and keeps its int16 scale, which the
+    per-column standardisation removes again); that append is done here on the host and the device pass runs with
+    pre-emphasis 0."""
+    sig_np = np.asarray(signal)
+    preemph = 0.97
+    if sig_np.ndim == 2:
+        sig_np = np.append(sig_np[0], sig_np[1:] - 0.97 * sig_np[:-1])
+        preemph = 0.0
+    key = (int(sample_rate), int(nfilt), preemph)
     if key not in _extractors:
-        _extractors[key] = FbankExtractor(sample_rate=int(sample_rate), nfilt=int(nfilt))
+        _extractors[key] = FbankExtractor(sample_rate=int(sample_rate), nfilt=int(nfilt), preemph=preemph)
     ex = _extractors[key]
-    sig = torch.as_tensor(np.asarray(signal, dtype=np.float32)).reshape(1, -1).cuda()
+    sig = torch.as_tensor(np.asarray(sig_np, dtype=np.float32)).reshape(1, -1).cuda()
     n = torch.tensor([sig.shape[1]], dtype=torch.int32, device='cuda')
     T = num_frames(sig.shape[1], ex.frame_len, ex.frame_step)
     feat, _ = ex.batch(sig, n, T)
     return feat[0].double().cpu().numpy()
+
+
+def read_wav_data(filename):
+    """util/wav_util.py:34-45: the frames of a 16-bit PCM WAV file as an int16 array ``[channels, n]`` and the frame rate
+    (``np.fromstring`` there; the removed alias of ``np.frombuffer``)."""
+    import wave
+    with wave.open(filename, 'rb') as w:
+        num_frame, num_channel, framerate = w.getnframes(), w.getnchannels(), w.getframerate()
+        str_data = w.readframes(num_frame)
+    wave_data = np.frombuffer(str_data, dtype=np.short).reshape(-1, num_channel).T
+    return wave_data, framerate
+
+
+def compute_fbank_from_file(file, feature_dim=200, sf_flag=False):
+    """util/wav_util.py:13-19: ``sf_flag`` reads the file the way soundfile does (float64 in [-1, 1), 1-D for a mono file;
+    16-bit PCM is decoded with the standard library: data_util.read_wav_pcm16), else through ``read_wav_data``."""
+    if sf_flag:
+        from .data_util import read_wav_pcm16
+        signal, sample_rate = read_wav_pcm16(file)
+    else:
+        signal, sample_rate = read_wav_data(file)
+    return compute_fbank_from_api(signal, sample_rate, nfilt=feature_dim)

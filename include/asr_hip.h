@@ -346,6 +346,13 @@ int asr_prenet_conv1_bwd(const float* x, const float* dz, int B, int T, int F, f
  * OUTPUT of the activation of the conv in front (act 0 none, 1 relu: a > 0, 2 tanh: 1 - a^2); dgamma, dbeta (=). */
 size_t asr_bn_workspace(const asr_pixmap* m);
 int asr_bn_stats(const float* src, const asr_pixmap* m, float eps, float* mean, float* rstd, void* workspace, void* stream);
+/* Moving statistics of keras.layers.BatchNormalization (cnn_ctc.py:106-107 `norm`; Keras 2.3.1 normalization.py call()):
+ * with mean / rstd of the current batch (asr_bn_stats; count = B*H*W samples per channel) the moving mean / variance take one
+ * momentum step -- the batch variance made unbiased by count / (count - (1 + eps)) first, as Keras does --; inf_rstd, if given,
+ * receives 1 / sqrt(moving_var + eps), the factor of the inference-mode normalisation (Model.predict, cnn_ctc.py:82).  With
+ * mean = rstd = NULL only inf_rstd is computed. */
+int asr_bn_moving(const float* mean, const float* rstd, int C, float eps, float count, float momentum,
+                  float* mov_mean, float* mov_var, float* inf_rstd, void* stream);
 int asr_bn_apply(const float* src, const asr_pixmap* sm, const float* mean, const float* rstd, const float* gamma,
                  const float* beta, const float* res, const asr_pixmap* rm, int relu, float* dst, const asr_pixmap* dm,
                  void* stream);

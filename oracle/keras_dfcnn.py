@@ -61,6 +61,22 @@ def batch_norm(x, g, b):
     return g * (x - mu) / torch.sqrt(var + BN_EPS) + b
 
 
+def batch_norm_inference(x, g, b, mov_mean, mov_var):
+    """Keras learning phase 0 (Model.predict, cnn_ctc.py:82): K.batch_normalization on the moving statistics."""
+    return g * (x - mov_mean) / torch.sqrt(mov_var + BN_EPS) + b
+
+
+def moving_update(mov_mean, mov_var, x, momentum=0.99):
+    """One fit() step of a BatchNormalization's moving statistics (Keras 2.3.1 layers/normalization.py, call()): batch mean and
+    the batch variance made unbiased by sample_size / (sample_size - (1 + epsilon)), then
+    K.moving_average_update: variable -= (variable - value) * (1 - momentum)."""
+    mu = x.mean(dim=(0, 1, 2))
+    var = ((x - mu) ** 2).mean(dim=(0, 1, 2))
+    n = float(x.shape[0] * x.shape[1] * x.shape[2])
+    var = var * (n / (n - (1.0 + BN_EPS)))
+    return mov_mean - (mov_mean - mu) * (1 - momentum), mov_var - (mov_var - var) * (1 - momentum)
+
+
 def conv_relu(x, w, b):
     y = F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), b, padding=1)
     return torch.relu(y).permute(0, 2, 3, 1)
@@ -70,13 +86,23 @@ def drop_seed(base, step, site):
     return (int(base) + 1009 * int(step) + 7919 * int(site)) & 0xFFFFFFFF
 
 
-def forward(P, x, cells=CELLS, drop=None):
-    """x [B, T, F] -> softmax outputs y_pred [B, T/8, vocab] (torch, differentiable).  drop = (rate, base_seed, step)."""
+def forward(P, x, cells=CELLS, drop=None, moving=None, collect=None):
+    """x [B, T, F] -> softmax outputs y_pred [B, T/8, vocab] (torch, differentiable).  drop = (rate, base_seed, step).
+    ``moving`` = {layer: (moving_mean, moving_var)}: inference mode (learning phase 0) -- BatchNormalization on those
+    statistics, no dropout.  ``collect`` (a dict): filled with the moving statistics after ONE training step from the values in
+    ``collect`` itself ({layer: (mean, var)}, default 0 / 1)."""
     h = x.unsqueeze(-1)
     for i, (size, pool) in enumerate(cells):
         for j in 'ab':
             n = 'c%d%s' % (i + 1, j)
-            h = batch_norm(conv_relu(h, P[n + '/w'], P[n + '/b']), P[n + '/g'], P[n + '/be'])
+            a = conv_relu(h, P[n + '/w'], P[n + '/b'])
+            if moving is not None:
+                h = batch_norm_inference(a, P[n + '/g'], P[n + '/be'], moving[n][0], moving[n][1])
+                continue
+            if collect is not None:
+                m0, v0 = collect.get(n, (torch.zeros(size, dtype=a.dtype), torch.ones(size, dtype=a.dtype)))
+                collect[n] = tuple(t.detach() for t in moving_update(m0, v0, a.detach()))
+            h = batch_norm(a, P[n + '/g'], P[n + '/be'])
         if pool:
             h = F.max_pool2d(h.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
     B, H, W, C = h.shape

@@ -138,6 +138,15 @@ def test_end2end_training_loop_from_wav_files(tmp_path):
     from asr_dfcnn_transformer_amd.train import load_checkpoint
     load_checkpoint(model, str(tmp_path / 'ck' / 'model_20.pt'))         # composite checkpoint: encoder-decoder + pre-net
     assert model.engine.global_step == 20 and model.prenet.global_step == 20
+    # resume (end2end/model.py:81-88 restores the latest checkpoint before the loop): a second call with the same ckpt_dir and a
+    # FRESH model -- whose engines do not exist before its first batch -- continues from final_model.pt (written at step 20):
+    # global_step and the learning-rate schedule go on, the first losses are those of a trained model, not of a random one
+    args.epochs = 1
+    m2, h2 = tr.train_transformer(args, dl, ckpt_dir=str(tmp_path / 'ck'))
+    assert m2 is not model and len(h2) == 4
+    assert m2.engine.global_step == 20 + 4 and m2.prenet.global_step == 20 + 4
+    assert h2[0][1] == pytest.approx(model.engine.current_learning_rate(20), rel=1e-6)
+    assert np.mean([h[0] for h in h2]) < 0.8 * np.mean([h[0] for h in hist[:4]])
 
 
 def test_speech_test_loop_writes_pred_log(tmp_path):
@@ -165,3 +174,23 @@ def test_speech_test_loop_writes_pred_log(tmp_path):
     from asr_dfcnn_transformer_amd.test_pipeline import AccuracyMeter
     m = AccuracyMeter(); m.update([1, 2, 3], [9, 9, 9, 9, 9, 9, 9]); assert (m.words, m.errors) == (3, 3)
     m.update([1, 2, 3, 4], [1, 2, 4]); assert (m.words, m.errors) == (7, 4)
+
+
+def test_compute_fbank_from_file_both_readers(tmp_path):
+    """util/wav_util.py:13-19,34-45.  sf_flag=True: the soundfile view of the file (float in [-1, 1), 1-D) through
+    compute_fbank_from_api.  sf_flag=False: read_wav_data returns the int16 frames as [1, n], and python_speech_features'
+    pre-emphasis ``append(signal[0], signal[1:] - 0.97 * signal[:-1])`` of a [1, n] array is the row itself -- that path is
+    NOT pre-emphasised (a reference quirk the oracle's logfbank reproduces by the same numpy expression)."""
+    from asr_dfcnn_transformer_amd.wav_util import compute_fbank_from_file, read_wav_data
+    sigs = _write_wavs(str(tmp_path), ['a/one.wav'], seed=3, seconds=(0.7, 0.7))
+    f = str(tmp_path / 'a' / 'one.wav')
+    wd, sr = read_wav_data(f)
+    assert sr == 16000 and wd.dtype == np.int16 and wd.shape == (1, len(sigs['a/one.wav']))
+    assert np.array_equal(wd[0].astype(np.float64) / 32768.0, sigs['a/one.wav'])
+    got_sf = compute_fbank_from_file(f, feature_dim=200, sf_flag=True)
+    ref_sf = ofb.compute_fbank_from_api(sigs['a/one.wav'], 16000, nfilt=200)
+    assert got_sf.shape == ref_sf.shape and np.abs(got_sf - ref_sf).max() <= 2e-6
+    got = compute_fbank_from_file(f, feature_dim=200)
+    ref = ofb.compute_fbank_from_api(wd, 16000, nfilt=200)                  # 2-D in: no pre-emphasis, int16 scale
+    assert got.shape == ref.shape and np.abs(got - ref).max() <= 2e-6
+    assert np.abs(got - got_sf).max() > 1e-2                                # the two readers do give different features

@@ -2,6 +2,8 @@
 8f.2) against oracle/amlm.py on a small configuration: both time-major logit tensors and both losses (1e-3 bar of
 north_star; observed ~1e-5), every gradient of both halves (the acoustic trunk's include the language half's contribution
 through h7), bitwise reproducibility, and one Adam step."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -147,3 +149,43 @@ def test_dense_label_mode_keeps_zeros_and_rejects_infeasible_alignments():
     tp_long = np.zeros((B, 8), dtype=np.int32); tp_long[:, :8] = 1 + np.arange(8)
     with pytest.raises(ValueError):
         eng.set_targets([8, 6, 7], tp_long, [8, 8, 8])           # 8 labels in 6 / 7 frames
+
+
+def test_joint_training_loop_feeds_fetches_evaluates_and_checkpoints(tmp_path):
+    """am_lm_train.train_model (lm_and_am/am_lm_train.py:27-116) on a small synthetic source: every batch of
+    DataLoader.end2end_generator is fed as the six placeholders and [lm_mean_loss, label_err, han_wer, summary, train_op]
+    fetched; a batch that lost a row is skipped (static batch); the dev pass runs without dropout and without updates; the
+    per-epoch and final checkpoints are written; resume=True continues from final_model."""
+    from asr_dfcnn_transformer_amd import am_lm_train
+    from asr_dfcnn_transformer_amd.data_loader import DataLoader, SyntheticSource
+    from asr_dfcnn_transformer_amd.hparams import AmLmHparams, AmDataHparams
+    hp, dhp = AmLmHparams().args, AmDataHparams().args
+    hp.am_batch_size, hp.epochs, hp.feature_dim, hp.feature_max_length = 2, 3, 16, 64
+    hp.num_blocks, hp.dropout_rate, hp.am_lr, hp.position_max_length = 1, 0.1, 2e-3, 8
+    V = 24
+    train = SyntheticSource(8, seconds=0.5, label_len=3, vocab=V, seed=5, faults={3: 'long_label'})     # batch 1 loses a row
+    dev = SyntheticSource(4, seconds=0.5, label_len=3, vocab=V, seed=9)
+    loader = DataLoader(train, dhp, hp)
+    assert [b[0].shape[0] for b in loader.end2end_generator()] == [2, 1, 2, 2]
+    assert all(len(b) == 6 for b in loader.end2end_generator())
+
+    class SmallVocabLoader(DataLoader):                    # the synthetic ids live in a 24-entry vocabulary
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            self.acoustic_vocab_size, self.language_vocab_size = V, 41
+    kw = dict(widths=(4, 8, 16, 4, 128), seed=2)
+    model, hist = am_lm_train.train_model(dhp, hp, train, dev, ckpt_dir=str(tmp_path), loader_cls=SmallVocabLoader, model_kw=kw,
+                                          log_every=100)
+    assert len(hist) == 3 * 3 and model.global_step == 9                   # 4 batches per epoch, one skipped
+    assert all(np.isfinite(h[0]) for h in hist)
+    assert np.mean([h[0] for h in hist[-3:]]) < np.mean([h[0] for h in hist[:3]])
+    files = sorted(os.listdir(tmp_path))
+    assert 'final_model.pt' in files and sum(f.startswith('model_') for f in files) == 3
+    theta = model.engine.am.theta.clone()
+    hp.epochs = 1
+    m2, h2 = am_lm_train.train_model(dhp, hp, train, dev, ckpt_dir=str(tmp_path), loader_cls=SmallVocabLoader, model_kw=kw,
+                                     resume=True, log_every=100)
+    assert m2.global_step > 3 and len(h2) == 3                             # continued from a saved final_model, not from scratch
+    m3, _ = am_lm_train.train_model(dhp, hp, train, None, ckpt_dir=str(tmp_path), loader_cls=SmallVocabLoader, model_kw=kw,
+                                    log_every=100)
+    assert m3.global_step == 3                                             # the reference's `latest = None`: no resume by default

@@ -73,3 +73,73 @@ def test_keras_dfcnn_step_matches_oracle(B, T, rate):
     assert torch.equal(g1, eng.grad)                      # bitwise reproducible
     eng.apply_adam()
     assert eng.global_step == 1
+
+
+def test_moving_statistics_and_predict_match_oracle(tmp_path):
+    """Keras learning phases (cnn_ctc.py:67-83, utils.py:57-66): three train_on_batch steps move the
+    BatchNormalization moving statistics by the Keras 2.3.1 rule (unbiased batch variance, momentum 0.99) -- compared with the
+    oracle's restatement after re-deriving the oracle's parameters from the engine at every step --; then
+    CNNCTCModel.predict (inference-mode BatchNormalization, zero padding to the maximum length, batch replication,
+    decode_ctc = greedy K.ctc_decode over `length` frames) gives exactly the ids the oracle decodes from its inference-mode
+    forward.  save_model / load_model carry the moving statistics."""
+    from asr_dfcnn_transformer_amd.cnn_ctc import CNNCTCModel
+    from oracle import ctc as octc
+
+    class Args:
+        am_lr, is_training, feature_dim, am_batch_size = 2e-3, True, 16, 2
+    rng = np.random.default_rng(4)
+    B, T, F, V, hidden = 2, 64, 16, 12, 16
+    cells = [(8, True), (16, True), (32, True), (32, False), (32, False)]
+    m = CNNCTCModel(Args, V, batch_size=B, feature_max_length=T, cells=cells, hidden=hidden, seed=3, model_dir=str(tmp_path))
+    m.engine.dropout_rate = 0.0
+    names = ok.layer_names(cells)
+    mov = {}
+    for step in range(3):
+        x = rng.standard_normal((B, T, F)).astype(np.float32)
+        labels = np.zeros((B, 8), dtype=np.int64); labels[:, :2] = rng.integers(1, V - 1, (B, 2))
+        P = {k: torch.tensor(v.astype(np.float64)) for k, v in m.engine.params_dict().items() if not k.endswith(('/mm', '/mv'))}
+        ok.forward(P, torch.tensor(x.astype(np.float64)), cells, collect=mov)            # the oracle's moving statistics, one step on
+        loss = m.train_on_batch({'the_inputs': x.reshape(B, T, F, 1), 'the_labels': labels,
+                                 'input_length': np.full((B, 1), T // 8), 'label_length': np.full((B, 1), 2)})
+        assert np.isfinite(loss)
+    got = m.engine.params_dict()
+    for n in names:
+        assert np.abs(got[n + '/mm'] - mov[n][0].numpy()).max() < 1e-5, n
+        assert np.abs(got[n + '/mv'] - mov[n][1].numpy()).max() < 1e-5, n
+    assert m.global_step == 3 and float(np.abs(m.engine.grads_dict()['c1a/mm']).max()) == 0.0
+    # predict: one utterance of 41 frames, length = 41 // 8 + 1 (read_wav.py:48)
+    feat = rng.standard_normal((41, F, 1)).astype(np.float32)
+    length = 41 // 8 + 1
+    for bs in (1, 3):
+        ids = m.predict(feat, length, batch_size=bs)
+        P = {k: torch.tensor(v.astype(np.float64)) for k, v in got.items() if not k.endswith(('/mm', '/mv'))}
+        movt = {n: (torch.tensor(got[n + '/mm'].astype(np.float64)), torch.tensor(got[n + '/mv'].astype(np.float64))) for n in names}
+        xin = np.zeros((1, T, F)); xin[0, :41] = feat[:, :, 0]
+        y = ok.forward(P, torch.tensor(xin), cells, moving=movt).numpy()                 # [1, T/8, V] softmax
+        want, _ = octc.ctc_greedy_decode(np.log(y.transpose(1, 0, 2) + 1e-7), [length])
+        assert list(ids) == list(want[0]), (bs, ids, want)
+        logits = m._engines[bs].logits[:, 0].cpu().numpy()
+        assert np.abs(logits - np.log(y[0] + 1e-7)).max() < 1e-3
+    # the weights file carries everything, moving statistics included
+    m.save_model('keras_am')
+    m2 = CNNCTCModel(Args, V, batch_size=B, feature_max_length=T, cells=cells, hidden=hidden, seed=9, model_dir=str(tmp_path))
+    m2.load_model('keras_am')
+    assert torch.equal(m2.engine.theta, m.engine.theta) and m2.global_step == 3
+    assert list(m2.predict(feat, length)) == list(m.predict(feat, length))
+
+
+def test_decode_ctc_is_greedy_ctc_decode_of_one_utterance():
+    """util/utils.py:57-66 on a hand-made softmax output: repeats merge, blanks split, ties go to the lowest index, frames past
+    input_length are ignored."""
+    from asr_dfcnn_transformer_amd.utils import decode_ctc
+    V = 6
+    path = [2, 2, 5, 2, 3, 3, 5, 5, 1, 4]                  # blank = 5
+    p = np.full((1, len(path), V), 0.02, dtype=np.float32)
+    for t, k in enumerate(path):
+        p[0, t, k] = 0.9
+    p[0, 4, 0] = 0.9                                       # tie between 0 and 3 at t = 4 -> 0
+    assert list(decode_ctc(p, len(path))) == [2, 2, 0, 3, 1, 4]
+    assert list(decode_ctc(p, 4)) == [2, 2]
+    assert list(decode_ctc(p, 0)) == []
+    with pytest.raises(ValueError):
+        decode_ctc(np.concatenate([p, p]), 3)

@@ -221,3 +221,38 @@ def test_training_loop_keeps_ranks_in_step_with_odd_batch_count_and_dropped_rows
             tot = rows[b0] + rows[b1]
             theta -= 0.1 * (4 * (b0 + 1) * rows[b0] + 4 * (b1 + 1) * rows[b1]) / tot
     assert abs(res[0][3][0] - theta) < 1e-12
+
+
+def _bad_step_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from asr_dfcnn_transformer_amd.parallel import init_from_env, BucketedAllReduce
+    init_from_env(backend='gloo')
+    red = BucketedAllReduce(torch.zeros(8), [(0, 8)])
+    first = red.sum_count(3 + rank)                       # a healthy step: the global row count
+    try:
+        red.sum_count(4, ok=(rank != 1))                  # rank 1's batch failed its host-side target check
+        raised = False
+    except RuntimeError:
+        raised = True
+    after = red.sum_count(1)                              # the group is still usable: nobody was left inside a collective
+    q.put((rank, first, raised, after))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_rank_that_cannot_take_the_step_stops_every_rank_before_the_gradient_allreduce():
+    """CNNCTCModel.run validates the targets on the host BEFORE the step's first collective and sends the verdict along with the
+    row count: a bad batch on one rank raises on every rank at that point (no hang until the RCCL timeout)."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_bad_step_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, 7, True, 2), (1, 7, True, 2)]

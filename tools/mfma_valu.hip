@@ -91,6 +91,40 @@ __global__ __launch_bounds__(512) void split_loop(float* out, int iters, float a
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+// The issue pattern of wino8_kernel (wino.hip), eight waves = two per SIMD, every wave the same stream: per "double batch"
+// NP packed adds on aligned register pairs (the input transform: 20 v_pk_add_f32 + a few selects per 16 MFMAs in the kernel),
+// all of them BEFORE sixteen back-to-back v_mfma_f32_32x32x2_f32 on eight accumulators.  time(NP) / time(0) is the factor by
+// which the transform's vector issue stretches the kernel's MFMA time: bench.py prices the Winograd kernels against
+// 157.3 TFLOP/s x 2.25 x time(0) / time(NP).
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <int NP>
+__global__ __launch_bounds__(512) void wino_pattern(float* out, int iters, float a0, float b0) {
+    floatx16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const float a = a0 + threadIdx.x * 1e-6f, b = b0;
+    f2 v[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] = f2{a + i, a - i};
+    const f2 inc = f2{b, -b};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) v[i % 12] = v[i % 12] + (i % 3 == 0 ? inc : v[(i + 5) % 12]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i & 7] = __builtin_amdgcn_mfma_f32_32x32x2f32((i & 8) ? v[i & 7].y : v[i & 7].x, b, acc[i & 7], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i][0] + acc[i][15];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s += v[i].x + v[i].y;
+    out[blockIdx.x * 512 + threadIdx.x] = s;
+}
+
 template <typename F>
 float timeit(F launch) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -125,8 +159,23 @@ void run_split16(float* out, int iters) {
     printf("16x16x4 x2, two waves/SIMD, NV %2d: MFMA-only wave %.3f ms, VALU-only wave %.3f ms, both side by side %.3f ms\n", NV, tm, tv, tb);
 }
 
-int main() {
+template <int NP>
+float run_wino(float* out, int iters, float t0) {
+    const float t = timeit([&] { hipLaunchKernelGGL((wino_pattern<NP>), dim3(256), dim3(512), 0, 0, out, iters, 1.0f, 0.5f); });
+    printf("wino pattern, two waves/SIMD: %2d v_pk_add_f32 + 16 MFMA per iteration: %.3f ms  = %.1f cyc per 16 MFMAs and wave pair at 2.4 GHz;  time(0)/time(NP) = %.3f\n",
+           NP, t, t * 1e-3 * 2.4e9 / iters, t0 > 0 ? t0 / t : 1.0);
+    return t;
+}
+
+int main(int argc, char** argv) {
     float* out; hipMalloc(&out, 512 * 512 * sizeof(float));
+    if (argc > 1 && argv[1][0] == 'w') {
+        const int it = 50000;
+        const float t0 = run_wino<0>(out, it, 0.f);
+        run_wino<8>(out, it, t0); run_wino<16>(out, it, t0); run_wino<20>(out, it, t0); run_wino<23>(out, it, t0); run_wino<24>(out, it, t0);
+        run_wino<32>(out, it, t0);
+        return 0;
+    }
     const int iters = 200000;
     run_mix<0>(out, iters); run_mix<4>(out, iters); run_mix<8>(out, iters); run_mix<12>(out, iters); run_mix<16>(out, iters); run_mix<24>(out, iters); run_mix<32>(out, iters);
     run_split<8>(out, iters); run_split<16>(out, iters); run_split<32>(out, iters);
