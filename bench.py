@@ -34,7 +34,7 @@ FP32_PEAK_TFLOPS = 157.3        # MI355X dense fp32 (vector = matrix), MI355X_MI
 # the kernel in DIRECT-convolution flops is
 #     peak_effective = 157.3 TFLOP/s x 2.25 (multiplies saved) x t_mfma / (t_mfma + t_transform)
 WINO_MULT_SAVING = 2.25
-WINO_MFMA_TIME_SHARE = 0.85      # t_mfma / (t_mfma + t_transform); see above (replaced by the measured value in profiles/)
+WINO_MFMA_TIME_SHARE = 0.91      # t_mfma / (t_mfma + t_transform), measured: profiles/r03_mfma_valu_wino.txt (22.5 packed adds per 16 MFMAs)
 
 
 def kernel_peak(sym):
