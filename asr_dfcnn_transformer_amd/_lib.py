@@ -69,6 +69,8 @@ SIGNATURES = {
     'asr_attention_bwd_p': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint, _P, _P, _P, _P, _P]),
     'asr_copy2d': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     'asr_copy2d_batch': (_I, [_P, _I, _I, _I, _P]),
+    'asr_transpose_batch': (_I, [_P, _I, _I, _P]),
+    'asr_tap_gemm_nt': (_I, [C.POINTER(GemmDesc), _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     'asr_winograd_weights_bytes': (_Z, [_I, _I]),
     'asr_winograd_weights': (_I, [_P, _I, _I, _I, _I, _P, _P]),
     'asr_winograd_supported': (_I, [_P]),

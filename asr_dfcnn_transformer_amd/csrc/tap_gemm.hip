@@ -493,6 +493,12 @@ int launch_n(const TapGemmArgs& a, hipStream_t st) {
 
 struct GateSpec { int mode, H, W; const float* a; float* dz; float* part; int* rows; };
 
+// gemm1.hip: the LDS-DMA "NT" GEMM that takes the large 1-tap data-gradients (dX = dY . W^T: both operands K-contiguous)
+struct Gemm1Gate { int mode, H, W; const float* a; float* dz; float* part; int* rows; };
+bool asr_gemm1_eligible(const asr_gemm_desc* d, const float* A, const float* Bt, int ldb);
+int asr_gemm1_launch(const asr_gemm_desc* d, const float* A, const float* Bt, int ldb, const float* bias, const float* scale,
+                     const float* shift, float* out_a, float* out_y, int dir, void* stream, const Gemm1Gate* gate);
+
 static void set_gate(TapGemmArgs& a, const GateSpec* gs) {
     a.gate_mode = 0; a.gate_H = a.gate_W = 0; a.gate_a = nullptr; a.gate_dz = nullptr; a.gate_part = nullptr; a.gate_rows = nullptr;
     if (gs) { a.gate_mode = gs->mode; a.gate_H = gs->H; a.gate_W = gs->W; a.gate_a = gs->a; a.gate_dz = gs->dz; a.gate_part = gs->part; a.gate_rows = gs->rows; }
@@ -507,6 +513,11 @@ static int tap_gemm_impl(const asr_gemm_desc* d, const float* A, const float* W,
     if (d->ntaps != 1 && d->H <= 0) return ASR_ERR_BAD_ARG;
     if (d->M <= 0 || d->K <= 0 || d->N <= 0) return ASR_ERR_BAD_ARG;
     if (((uintptr_t)A | (uintptr_t)W) & 15) return ASR_ERR_BAD_ARG;
+    if (d->ntaps == 1 && d->wmode == 1 && asr_gemm1_eligible(d, A, W, d->ldw)) {
+        Gemm1Gate gg;
+        if (gs) { gg.mode = gs->mode; gg.H = gs->H; gg.W = gs->W; gg.a = gs->a; gg.dz = gs->dz; gg.part = gs->part; gg.rows = gs->rows; }
+        return asr_gemm1_launch(d, A, W, d->ldw, bias, scale, shift, out_a, out_y, 1, stream, gs ? &gg : nullptr);
+    }
     TapGemmArgs a;
     a.A = A; a.W = W; a.bias = bias; a.scale = scale; a.shift = shift;
     a.out_a = out_a; a.out_y = out_y;

@@ -755,6 +755,10 @@ int launch_wgrad6(WgradArgs a, const asr_gemm_desc* d, float* dW, float* partial
 
 }  // namespace
 
+// gemm1.hip: the dense (1-tap) weight gradient on buffer-form LDS-DMA; this file keeps the chunk plan and the slab sum
+bool asr_wgrad1_eligible(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz);
+int asr_wgrad1_launch(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz, float* out, int pch, int nchunks, void* stream);
+
 extern "C" size_t asr_tap_wgrad_workspace(const asr_gemm_desc* d) {
     if (!d) return 0;
     const Plan p = make_plan(d), q = make_plan(d, 1024, 128);  // q: an upper bound on the chunks of any variant
@@ -764,7 +768,7 @@ extern "C" size_t asr_tap_wgrad_workspace(const asr_gemm_desc* d) {
                                                                                  : make_plan6<32, 32>(d).p.nchunks;
         if (n6 > nc) nc = n6;
     } else if (d->ntaps == 1) {
-        const int n6 = make_plan6<128, 128>(d).p.nchunks;
+        const int n6 = d->N <= 32 ? make_plan6<128, 32>(d).p.nchunks : make_plan6<128, 128>(d).p.nchunks;
         if (n6 > nc) nc = n6;
     }
     if (nc <= 1) return 16;
@@ -792,6 +796,18 @@ extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float
     int rc;
     Plan p6 = p;
     // the LDS-DMA kernels fetch 16 bytes per lane: both operands must be 16-byte aligned (row pitches are checked above)
+    if (d->ntaps == 1 && asr_wgrad1_eligible(d, A, dZ, ldz)) {
+        // dense layers and 1x1 convs: wgrad1_kernel (gemm1.hip), 128 x 128 tiles, or 128 x 32 for outputs of up to 32 channels
+        const Plan6 q = d->N <= 32 ? make_plan6<128, 32>(d) : make_plan6<128, 128>(d);
+        if (q.p.nchunks > 1 && !partials) return ASR_ERR_BAD_ARG;
+        rc = asr_wgrad1_launch(d, A, dZ, ldz, q.p.nchunks > 1 ? partials : dW, q.p.pch, q.p.nchunks, stream);
+        if (rc != ASR_OK) return rc;
+        if (q.p.nchunks > 1) {
+            hipLaunchKernelGGL(sum_chunks_kernel, dim3(asr_cdiv(asr_cdiv(a.slab, 4), 64)), dim3(64), 0, st, partials, dW, a.slab, q.p.nchunks);
+            ASR_CHECK_LAUNCH("sum_chunks");
+        }
+        return ASR_OK;
+    }
     bool is6 = ((((uintptr_t)A) | ((uintptr_t)dZ)) & 15) == 0;
     if (!is6) { /* fall through to the register-staged kernels */ }
     else if (d->ntaps == 9 && d->N > 64 && v6_ok<9, 1, 4, 1>(d, ldz)) rc = launch_wgrad6<9, 1, 4, 1>(a, d, dW, partials, st, &p6);

@@ -126,6 +126,15 @@ def tap_gemm(desc, A, W, bias=None, scale=None, shift=None, out_a=None, out_y=No
         'asr_tap_gemm'))
 
 
+def tap_gemm_nt(desc, A, W, Wt, ldwt, bias=None, scale=None, shift=None, out_a=None, out_y=None):
+    """Dense forward with the kernel W [K][N] AND its transposed copy Wt [N][K] (asr_tap_gemm_nt): the large problems take the
+    LDS-DMA kernel on Wt, the rest asr_tap_gemm on W."""
+    lib = _lib.load()
+    _timed(desc, lambda: check(
+        lib.asr_tap_gemm_nt(C.byref(desc), _ptr(A), _ptr(W), _ptr(Wt), int(ldwt), _ptr(bias), _ptr(scale), _ptr(shift),
+                            _ptr(out_a), _ptr(out_y), _stream()), 'asr_tap_gemm_nt'))
+
+
 def tap_gemm_splitk_workspace(desc, splits):
     return _lib.load().asr_tap_gemm_splitk_workspace(C.byref(desc), int(splits))
 
@@ -334,6 +343,10 @@ class Copy2dBatch:
 
     def run(self, accumulate=False):
         check(_lib.load().asr_copy2d_batch(_ptr(self.table), self.n, self.max_elems, int(accumulate), _stream()), 'asr_copy2d_batch')
+
+    def run_transposed(self):
+        """dst[c][r] = src[r][c] for every item (rows / cols / lds describe src): asr_transpose_batch."""
+        check(_lib.load().asr_transpose_batch(_ptr(self.table), self.n, self.max_elems, _stream()), 'asr_transpose_batch')
 
 
 def dropout(x, rate, seed, y=None):

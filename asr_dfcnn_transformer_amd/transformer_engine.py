@@ -151,8 +151,35 @@ class _Base:
         return torch.zeros(*shape, dtype=dtype, device=self.device)
 
     def _dense(self, x, rows, K, N, w, b, out, relu):
+        """tf.layers.dense forward.  The kernel also exists transposed ([N][K], refreshed once per forward by ONE batched
+        launch, _wt_for): the large GEMMs read both operands K-contiguous through LDS-DMA (asr_tap_gemm_nt, gemm1.hip)."""
         d = ops.gemm_desc(rows, K, N, K, N, 0, N, ntaps=1, relu=1 if relu else 0)
-        ops.tap_gemm(d, x, w, b, None, None, None, out)
+        ops.tap_gemm_nt(d, x, w, self._wt_for([(w, K, N, N)]), K, b, None, None, None, out)
+
+    def _wt_for(self, parts):
+        """The transposed copy of a dense kernel given as column blocks ``parts`` = [(w [K][n_j] tensor, K, n_j, pitch)]:
+        a [sum n_j][K] tensor whose rows are the kernel's columns.  Registered on first use (and transposed at once);
+        afterwards the first request of a forward pass re-transposes EVERY registered kernel in one launch
+        (asr_transpose_batch) -- the parameters may have been stepped, loaded or perturbed since the last forward."""
+        reg = self.__dict__.setdefault('_wt_reg', {})
+        key = tuple((w.data_ptr(), K, n, ld) for w, K, n, ld in parts)
+        if key not in reg:
+            K = parts[0][1]
+            wt = self._t(sum(n for _, _, n, _ in parts) * K)
+            items, row = [], 0
+            for w, _, n, ld in parts:
+                items.append((wt[row * K:], K, w, ld, K, n))
+                row += n
+            ops.Copy2dBatch(items).run_transposed()
+            reg[key] = (wt, items)
+            self._wt_batch = None
+            return wt
+        if self.__dict__.get('_wt_dirty', True):
+            if self.__dict__.get('_wt_batch') is None:
+                self._wt_batch = ops.Copy2dBatch([it for _, items in reg.values() for it in items])
+            self._wt_batch.run_transposed()
+            self._wt_dirty = False
+        return reg[key][0]
 
     def _dense_dgrad(self, dy, rows, K, N, w, dx, accumulate):
         # dx[rows,K] (+)= dy[rows,N] . w[K,N]^T
@@ -210,13 +237,14 @@ class _Base:
         W3 = st['W3']
         self._pack_qkv(name, st)
         Q, K, V, ldq, ldk = self._qkv_views(st, fused3)
+        wq, wk, wv = (self.p('%s/%s' % (name, k)) for k in ('wq', 'wk', 'wv'))
         if fused3:
             d = ops.gemm_desc(rq, C, 3 * C, C, 3 * C, 0, 3 * C, ntaps=1, relu=1)
-            ops.tap_gemm(d, q_in, W3, None, None, None, None, Q)
+            ops.tap_gemm_nt(d, q_in, W3, self._wt_for([(wq, C, C, C), (wk, C, C, C), (wv, C, C, C)]), C, None, None, None, None, Q)
         else:
-            self._dense(q_in, rq, C, C, self.p(name + '/wq'), None, Q, True)
+            self._dense(q_in, rq, C, C, wq, None, Q, True)
             d = ops.gemm_desc(rk, C, 2 * C, C, 3 * C, 0, 2 * C, ntaps=1, relu=1)
-            ops.tap_gemm(d, k_in, W3.view(-1)[C:], None, None, None, None, K)
+            ops.tap_gemm_nt(d, k_in, W3.view(-1)[C:], self._wt_for([(wk, C, C, C), (wv, C, C, C)]), C, None, None, None, None, K)
         rate = self._rate
         kind, blk = self._block_site(name)
         st['seed_att'], st['seed_out'] = self._drop_seed((kind, blk, 'att')), self._drop_seed((kind, blk, 'out'))
@@ -250,8 +278,9 @@ class _Base:
 
     def _begin_forward(self):
         """Start of a forward pass: the packed projection weights are rebuilt from the parameters once (they may have
-        been stepped, loaded or perturbed since the last forward)."""
+        been stepped, loaded or perturbed since the last forward), and so are the transposed kernels (_wt_for)."""
         self._pack_dirty = True
+        self._wt_dirty = True
 
     def _wgrad_packed(self, x, dy, rows, K, names, ldz):
         """[g(names[0]) | g(names[1]) | ...] += x^T dy for weight matrices packed side by side (dy [rows][len(names) * C],

@@ -302,6 +302,10 @@ def run_lm(args):
                           'dropout_rate': args.dropout, 'mean_loss': round(eng.fetch()[0], 4)},
                'roofline': roofline_block(dom, r, args.steps)}
         attach_traffic(out, 'lm', dom, N == 64)
+        if args.kernel_table:
+            for key, rr in sorted(table.items(), key=lambda kv: -kv[1]['total_ms']):
+                print('%-48s launches %3d  total %8.3f ms  avg %9.1f us  %7.2f TFLOP/s' %
+                      (key, rr['launches'], rr['total_ms'], rr['avg_us'], rr['tflops']), file=sys.stderr)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(); dist.destroy_process_group()

@@ -285,6 +285,16 @@ int asr_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int col
  * the largest rows * cols among them (sizes the grid). */
 typedef struct asr_copy2d_item { float* dst; const float* src; int ldd, lds, rows, cols; } asr_copy2d_item;
 int asr_copy2d_batch(const asr_copy2d_item* items_dev, int n_items, int max_elems, int accumulate, void* stream);
+/* Several transposes in one launch: dst[c][r] = src[r][c] for every item (rows / cols / lds describe src, ldd the pitch of dst,
+ * no alignment rule).  The Transformer engines transpose every dense kernel once per step with it, so that the forward GEMMs
+ * read both operands K-contiguous (asr_tap_gemm_nt).  max_elems = the largest rows * cols of the table. */
+int asr_transpose_batch(const asr_copy2d_item* items_dev, int n_items, int max_elems, void* stream);
+/* tf.layers.dense forward (end2end/transformer.py:130-136,211-222; language_model.py:44-52) as asr_tap_gemm with ntaps 1 /
+ * wmode 0, given BOTH the kernel W [K][N] (pitch d->ldw) and its transposed copy Wt [N][K] (pitch ldwt): large problems run on
+ * the LDS-DMA kernel of gemm1.hip, which wants both operands K-contiguous, the others fall through to asr_tap_gemm on W.
+ * Same arithmetic per output element up to the order of the K sum inside 8-wide groups. */
+int asr_tap_gemm_nt(const asr_gemm_desc* d, const float* A, const float* W, const float* Wt, int ldwt,
+                    const float* bias, const float* scale, const float* shift, float* out_a, float* out_y, void* stream);
 /* tf.layers.dropout(x, rate, training=True) (transformer.py:154,226; model.py:290; language_model.py:34):
  *   y[i] = keep(i, seed) ? x[i] / (1 - rate) : 0 with keep(i, seed) = (murmur3_fmix(i * 0x9E3779B1 + seed) >> 8) >= rate * 2^24.
  *   In place is allowed; the same call on the gradient is the backward.  TensorFlow's random stream is not reproduced. */
