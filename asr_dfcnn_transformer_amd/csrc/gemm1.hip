@@ -31,6 +31,14 @@ namespace {
 typedef __attribute__((address_space(3))) float g1_lds_f;
 typedef const __attribute__((address_space(1))) float g1_glb_f;
 
+// The barrier that publishes a DMA'd tile: every wave first waits for ITS OWN pieces (explicitly -- whether hipcc adds the
+// vmcnt(0) to a __syncthreads() by itself depends on what its alias analysis concluded about the LDS-DMA; in one kernel of this
+// family it did not), then the barrier makes all pieces visible to all waves.
+__device__ __forceinline__ void dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 }  // namespace
 
 struct Gemm1Gate { int mode, H, W; const float* a; float* dz; float* part; int* rows; };
@@ -206,14 +214,14 @@ __global__ __launch_bounds__(256, 2) void gemm1_kernel(Gemm1Args args) {
     const int last_plain = ktail ? nkc - 2 : nkc - 1;    // the last chunk that can be fetched without the K-tail test
     int kc = 0;
     for (; kc + 2 <= last_plain; kc += 2) {
-        __syncthreads();
+        dma_barrier();
         g1_chunk<1>(set0, set1, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc);
-        __syncthreads();
+        dma_barrier();
         g1_chunk<1>(set1, set0, rsa, rsb, q, kc + 1, nkc, ktail, arow, brow, xo, acc);
     }
-    if (kc < nkc) { __syncthreads(); g1_chunk<2>(set0, set1, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc); ++kc; }
-    if (kc < nkc) { __syncthreads(); g1_chunk<2>(set1, set0, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc); ++kc; }
-    if (kc < nkc) { __syncthreads(); g1_chunk<2>(set0, set1, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc); ++kc; }
+    if (kc < nkc) { dma_barrier(); g1_chunk<2>(set0, set1, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc); ++kc; }
+    if (kc < nkc) { dma_barrier(); g1_chunk<2>(set1, set0, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc); ++kc; }
+    if (kc < nkc) { dma_barrier(); g1_chunk<2>(set0, set1, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc); ++kc; }
 
     __syncthreads();                                     // the tiles are dead: their space is the epilogue's scratch
     tap_epilogue<2, 2>(g, acc, bufs + wave * (32 * 33), rowa, rowy, wm * 64, n0 + wn * 64, lane, tile_m * 2 + wm);
@@ -334,15 +342,15 @@ __global__ __launch_bounds__(256, 2) void wgrad1_kernel(Wgrad1Args g) {
     const int nfull = (int)((cend - cbeg) >> 5);
     int r = 0;
     for (; r + 2 <= nfull - 1; r += 2) {
-        __syncthreads();
+        dma_barrier();
         w1_run<WM, WN, TKB, TNB, 1>(set0, set1, ra, rz, wave, voa, voz, cbeg + (long)(r + 1) * 32, cend, g.lda, g.ldz, lane, true, aoff, zoff, acc);
-        __syncthreads();
+        dma_barrier();
         w1_run<WM, WN, TKB, TNB, 1>(set1, set0, ra, rz, wave, voa, voz, cbeg + (long)(r + 2) * 32, cend, g.lda, g.ldz, lane, true, aoff, zoff, acc);
     }
-    if (r < nruns) { __syncthreads(); w1_run<WM, WN, TKB, TNB, 2>(set0, set1, ra, rz, wave, voa, voz, cbeg + (long)(r + 1) * 32, cend, g.lda, g.ldz, lane, r + 1 < nruns, aoff, zoff, acc); ++r; }
-    if (r < nruns) { __syncthreads(); w1_run<WM, WN, TKB, TNB, 2>(set1, set0, ra, rz, wave, voa, voz, cbeg + (long)(r + 1) * 32, cend, g.lda, g.ldz, lane, r + 1 < nruns, aoff, zoff, acc); ++r; }
-    if (r < nruns) { __syncthreads(); w1_run<WM, WN, TKB, TNB, 2>(set0, set1, ra, rz, wave, voa, voz, cbeg + (long)(r + 1) * 32, cend, g.lda, g.ldz, lane, r + 1 < nruns, aoff, zoff, acc); ++r; }
-    if (r < nruns) { __syncthreads(); w1_run<WM, WN, TKB, TNB, 2>(set1, set0, ra, rz, wave, voa, voz, cbeg + (long)(r + 1) * 32, cend, g.lda, g.ldz, lane, r + 1 < nruns, aoff, zoff, acc); ++r; }
+    if (r < nruns) { dma_barrier(); w1_run<WM, WN, TKB, TNB, 2>(set0, set1, ra, rz, wave, voa, voz, cbeg + (long)(r + 1) * 32, cend, g.lda, g.ldz, lane, r + 1 < nruns, aoff, zoff, acc); ++r; }
+    if (r < nruns) { dma_barrier(); w1_run<WM, WN, TKB, TNB, 2>(set1, set0, ra, rz, wave, voa, voz, cbeg + (long)(r + 1) * 32, cend, g.lda, g.ldz, lane, r + 1 < nruns, aoff, zoff, acc); ++r; }
+    if (r < nruns) { dma_barrier(); w1_run<WM, WN, TKB, TNB, 2>(set0, set1, ra, rz, wave, voa, voz, cbeg + (long)(r + 1) * 32, cend, g.lda, g.ldz, lane, r + 1 < nruns, aoff, zoff, acc); ++r; }
+    if (r < nruns) { dma_barrier(); w1_run<WM, WN, TKB, TNB, 2>(set1, set0, ra, rz, wave, voa, voz, cbeg + (long)(r + 1) * 32, cend, g.lda, g.ldz, lane, r + 1 < nruns, aoff, zoff, acc); ++r; }
 
     float* out = g.out + (long)blockIdx.x * g.K * g.N;
 #pragma unroll

@@ -1,464 +1,16 @@
 // Transformer pieces of end2end/transformer.py on gfx950:
-//   * fused multi-head attention forward / backward on the fp32 MFMA pipe with the reference's
-//     mask semantics (key mask = zero rows of the per-head K, fill value -2^32+1, optional
-//     lower-triangular mask, query mask applied after the softmax): scores never touch HBM;
+//   * (the fused multi-head attention kernels live in attention.hip);
 //   * (residual add +) LayerNorm forward / backward (eps 1e-8, biased variance);
 //   * embedding gather (+ sqrt(d) scale, zero_pad row, learned position table) and its
 //     deterministic scatter (sorted index lists from the host: no float atomics);
 //   * label-smoothed softmax cross-entropy with the reference's masking (-1 targets count).
 // The projection / FFN / vocabulary GEMMs are the 1-tap tap_gemm / tap_wgrad kernels.
-//
-// Attention layout trick: the score tile is computed TRANSPOSED, S^T = K.Q^T (keys in
-// registers, query on the lane), so the row max / row sum of the online softmax are
-// lane-local (+1 exchange between the two half-waves), and the P tile sits in exactly the
-// register layout the next MFMA needs as its B operand (contraction index = register
-// index): P never moves between lanes or through LDS.
 #include "asr_common.h"
 #include "reduce.h"
+#include "attn_common.h"
 #include <math.h>
 
 namespace {
-
-constexpr float MASK_FILL = -4294967296.0f;     // float32(-2**32 + 1)
-constexpr int DH = 64;                          // head width (hidden_units / num_heads = 512 / 8)
-constexpr int KP = DH + 4;                      // LDS pitch of tiles read with ds_read_b128
-// The fp32 MFMA shares the SIMD's vector issue with every other vector instruction (tools/mfma_valu.hip: an MFMA-only
-// wave and a VALU-only wave on one SIMD take the SUM of their times), so each vector instruction of the softmax costs
-// its full issue time.  The scores are therefore kept in base-2 units (q pre-scaled by log2(e) / sqrt(d)): one v_sub +
-// one v_exp_f32 per element instead of expf's 13 instructions, and the key mask is one compare + select against a per-key
-// bias staged with the tile (a wave-uniform branch around the mask code cost 300 spilled registers instead).
-constexpr float LOG2E = 1.44269504088896340736f;
-constexpr float QSCALE2 = 0.125f * LOG2E;        // 1 / sqrt(64), in base-2 units
-constexpr float FILL2 = MASK_FILL * LOG2E;       // the fill value in the same units
-__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
-
-__device__ __forceinline__ int rowidx(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
-
-// Counter-based dropout mask (tf.layers.dropout, transformer.py:111,154,226; model.py:290): element `idx` of the tensor
-// drawn for `seed` is kept when the top 24 bits of a murmur3-finalised hash reach the threshold rate * 2^24; kept values
-// are scaled by 1 / (1 - rate).  The same function regenerates the mask in the backward pass (nothing is stored) and
-// in oracle/transformer.py.  TensorFlow's own random stream cannot be reproduced; parity is against this generator.
-__device__ __forceinline__ bool drop_keep(uint32_t idx, uint32_t seed, uint32_t thr) {
-    uint32_t h = idx * 0x9E3779B1u + seed;
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return (h >> 8) >= thr;
-}
-
-// stage a [rows x 64] head slice of X[n][t][C] into LDS with pitch KP; rows beyond T are zero.
-// 16 consecutive lanes own one row, so a 16-lane xor-reduction gives per-row statistics: the row sum (stat_mode 0), the
-// sum of magnitudes (1), or the key bias of the row (2): 0 for a real key, the fill value for a key-masked one (zero row
-// sum), -inf for a row past the end -- what a score is replaced by when the bias is not 0.
-__device__ __forceinline__ void stage_tile(float* dst, const float* __restrict__ X, long base_row, int row0, int nrows,
-                                           int T, int C, int hoff, int tid, float scale, float* rowstat, int stat_mode) {
-    for (int f = tid; f < nrows * 16; f += 256) {
-        const int row = f >> 4, c4 = f & 15;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + row < T) v = *(const float4*)(X + (base_row + row0 + row) * C + hoff + c4 * 4);
-        if (rowstat) {
-            float s = (stat_mode != 1) ? (v.x + v.y + v.z + v.w) : (fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w));
-#pragma unroll
-            for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-            if (stat_mode == 2) s = (row0 + row < T) ? (s != 0.f ? 0.f : FILL2) : -INFINITY;
-            if (c4 == 0) rowstat[row] = s;
-        }
-        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-        *(float4*)(dst + row * KP + c4 * 4) = v;
-    }
-}
-
-// write a wave's transposed accumulator tile (rows = d in registers, column = token on the lane)
-// to X[n][tok][hoff + d] through an LDS transpose so the global stores are whole rows.
-// relu_src (optional): the post-ReLU tensor this gradient belongs to; the stored value is masked by (relu_src > 0).
-__device__ __forceinline__ void store_tile_T(float* __restrict__ X, float* scratch, const floatx16 (&acc)[2], float mul_lane,
-                                             long base_row, int tok0, int T, int C, int hoff, int lane,
-                                             const float* __restrict__ relu_src = nullptr) {
-    const int li = lane & 31, lh = lane >> 5;
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) scratch[li * 65 + dt * 32 + rowidx(r, lh)] = acc[dt][r] * mul_lane;
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes are done (wave-private region)
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int row = it * 4 + (lane >> 4), c4 = lane & 15;
-        if (tok0 + row < T) {
-            const float* s = scratch + row * 65 + c4 * 4;
-            float4 o = make_float4(s[0], s[1], s[2], s[3]);
-            if (relu_src) {
-                const float4 h = *(const float4*)(relu_src + (base_row + tok0 + row) * C + hoff + c4 * 4);
-                o.x = h.x > 0.f ? o.x : 0.f; o.y = h.y > 0.f ? o.y : 0.f; o.z = h.z > 0.f ? o.z : 0.f; o.w = h.w > 0.f ? o.w : 0.f;
-            }
-            *(float4*)(X + (base_row + tok0 + row) * C + hoff + c4 * 4) = o;
-        }
-    }
-}
-
-// Workgroup -> (tile, head, sample).  Plain launches use grid (tiles, H, N): the tiles of one (sample, head) run
-// together and share its K/V in L2.  Causal launches use grid (N*H, tiles): their tiles do unequal work (the key
-// range ends at the diagonal), so the longest tiles are dispatched first across all (sample, head) pairs --
-// longest-first keeps the last round full; with the plain order the skipped tiles bought no time at all.
-template <bool CAUSAL>
-__device__ __forceinline__ void attn_block_coords(int H, bool longest_is_last, int& tile, int& head, int& n, int& N) {
-    if (CAUSAL) {
-        head = blockIdx.x % H; n = blockIdx.x / H; N = gridDim.x / H;
-        tile = longest_is_last ? (int)(gridDim.y - 1 - blockIdx.y) : (int)blockIdx.y;
-    } else {
-        tile = blockIdx.x; head = blockIdx.y; n = blockIdx.z; N = gridDim.z;
-    }
-}
-
-// ------------------------------------------------------------------ attention forward
-template <bool CAUSAL, bool DROP>
-__global__ __launch_bounds__(256, CAUSAL ? 2 : 3) void attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                       const float* __restrict__ V, float* __restrict__ O,
-                                                       float* __restrict__ lse, int Tq, int Tk, int C, int H, int ldq, int ldk,
-                                                       uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
-    __shared__ __attribute__((aligned(16))) float kv_lds[2 * 64 * KP];   // also the epilogue's transpose scratch
-    float* Ks = kv_lds;
-    float* Vs = kv_lds + 64 * KP;
-    __shared__ float kstat[64];
-    static_assert(4 * 32 * 65 <= 2 * 64 * KP, "transpose scratch must fit in the K/V tiles");
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
-    int qtile, head, n, Nn;
-    attn_block_coords<CAUSAL>(H, true, qtile, head, n, Nn);
-    const int hoff = head * DH;
-    const int q0 = qtile * 128 + wave * 32, q = q0 + li;
-    const long qbase = (long)n * Tq, kbase = (long)n * Tk;
-
-    float qreg[32];
-    float qabs = 0.f;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < Tq) v = *(const float4*)(Q + (qbase + q) * ldq + hoff + 8 * g + 4 * lh);
-        qabs += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w);
-        qreg[g * 4 + 0] = v.x * QSCALE2; qreg[g * 4 + 1] = v.y * QSCALE2;
-        qreg[g * 4 + 2] = v.z * QSCALE2; qreg[g * 4 + 3] = v.w * QSCALE2;
-    }
-    qabs += __shfl_xor(qabs, 32, 64);
-    const float qmask = (qabs != 0.f) ? 1.f : 0.f;
-
-    floatx16 oacc[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
-
-    const int qlast_blk = qtile * 128 + 127;
-    for (int k0 = 0; k0 < Tk; k0 += 64) {
-        // A tile that lies entirely in the future of every query of this workgroup holds only the fill value:
-        // it contributes exp(fill - max) = 0 to a row that has already met a real score.  It may be skipped only
-        // when that holds for EVERY row (a row whose keys so far were all key-masked must still see it: TF's
-        // softmax is uniform over all fill entries, future ones included).
-        if (CAUSAL && k0 > qlast_blk) {
-            if (__syncthreads_and((q >= Tq) || (m_run > -1.0e9f))) break;
-        }
-        __syncthreads();
-        stage_tile(Ks, K, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, kstat, 2);
-        stage_tile(Vs, V, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, nullptr, 0);
-        __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            // same rule per wave: 32 keys that are future to all 32 queries of this wave (no barrier in this loop)
-            if (CAUSAL && k0 + sub * 32 > q0 + 31 && __all((q >= Tq) || (m_run > -1.0e9f))) continue;
-            floatx16 s;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const float4 kv = *(const float4*)(Ks + (sub * 32 + li) * KP + 8 * g + 4 * lh);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qreg[g * 4 + 0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qreg[g * 4 + 1], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qreg[g * 4 + 2], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qreg[g * 4 + 3], s, 0, 0, 0);
-            }
-            float mt = -INFINITY;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = sub * 32 + rowidx(r, lh);
-                const float kb = kstat[kl];                      // key bias (stage_tile, mode 2)
-                float v = s[r];
-                if (CAUSAL) v = (k0 + kl <= q) ? v : FILL2;
-                v = (kb == 0.f) ? v : kb;
-                s[r] = v;
-                mt = fmaxf(mt, v);
-            }
-            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-            const float m_new = fmaxf(m_run, mt);
-            const float alpha = ex2(m_run - m_new);
-            float lt = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = ex2(s[r] - m_new); lt += s[r]; }
-            lt += __shfl_xor(lt, 32, 64);
-            l_run = l_run * alpha + lt;
-            m_run = m_new;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
-            if (DROP) {            // dropout of the attention weights (transformer.py:111): after the row sum, before P.V
-                const uint32_t base = (uint32_t)(((n * H + head) * Tq + q) * Tk + k0 + sub * 32);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] = drop_keep(base + rowidx(r, lh), drop_seed, drop_thr) ? s[r] * drop_scale : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float* vrow = Vs + (sub * 32 + rowidx(r, lh)) * KP + li;
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], s[r], oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], s[r], oacc[1], 0, 0, 0);
-            }
-        }
-    }
-    __syncthreads();
-    if (q < Tq && lh == 0) {      // kept as (max, log-sum) pair, both in base-2 units: max may be the fill, which would swallow log(l)
-        lse[((long)n * H + head) * Tq + q] = m_run;
-        lse[(long)Nn * H * Tq + ((long)n * H + head) * Tq + q] = log2f(l_run);
-    }
-    store_tile_T(O, Ks + wave * (32 * 65), oacc, qmask / l_run, qbase, q0, Tq, C, hoff, lane);
-}
-
-// delta[n][head][q] = sum_d dO*O  (one 16-lane group per (q, head))
-__global__ void attn_delta_kernel(const float* __restrict__ O, const float* __restrict__ dO, float* __restrict__ delta,
-                                  int N, int Tq, int C, int H) {
-    const long gid = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    const int c4 = threadIdx.x & 15;
-    const long total = (long)N * Tq * H;
-    float s = 0.f;
-    if (gid < total) {
-        const int head = (int)(gid % H);
-        const long row = gid / H;                       // n*Tq + q
-        const float4 a = *(const float4*)(O + row * C + head * DH + c4 * 4);
-        const float4 b = *(const float4*)(dO + row * C + head * DH + c4 * 4);
-        s = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (gid < total && c4 == 0) {
-        const int head = (int)(gid % H);
-        const long row = gid / H;
-        const int n = (int)(row / Tq), q = (int)(row - (long)n * Tq);
-        delta[((long)n * H + head) * Tq + q] = s;
-    }
-}
-
-// ------------------------------------------------------------------ attention backward: dK, dV
-// One wave owns 32 keys (K, V in registers); the block walks the queries in tiles of 64.
-template <bool CAUSAL, bool DROP>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                          const float* __restrict__ V, const float* __restrict__ dO,
-                                                          const float* __restrict__ lse, const float* __restrict__ delta,
-                                                          float* __restrict__ dK, float* __restrict__ dV,
-                                                          int Tq, int Tk, int C, int H, int ldq, int ldk, int relu_grad,
-                                                          uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
-    constexpr int QT = 64;                       // queries staged per barrier round (two 32-row MFMA sub-tiles)
-    __shared__ __attribute__((aligned(16))) float Qs[QT * KP];
-    __shared__ __attribute__((aligned(16))) float Ds[QT * KP];
-    __shared__ float qstat[QT];
-    __shared__ float lse_s[QT], lsl_s[QT], del_s[QT];
-    __shared__ float scratch[4 * 32 * 65];
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
-    int ktile, head, n, Nn;
-    attn_block_coords<CAUSAL>(H, false, ktile, head, n, Nn);      // causal: the first key tile sees every query
-    const int hoff = head * DH;
-    const int k0 = ktile * 128 + wave * 32, key = k0 + li;
-    const long qbase = (long)n * Tq, kbase = (long)n * Tk;
-
-    float kreg[32], vreg[32];
-    float ksum = 0.f;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (key < Tk) {
-            a = *(const float4*)(K + (kbase + key) * ldk + hoff + 8 * g + 4 * lh);
-            b = *(const float4*)(V + (kbase + key) * ldk + hoff + 8 * g + 4 * lh);
-        }
-        ksum += a.x + a.y + a.z + a.w;
-        // K only feeds the score recomputation here: pre-scaled to base-2 units of the scaled scores
-        kreg[g * 4 + 0] = a.x * QSCALE2; kreg[g * 4 + 1] = a.y * QSCALE2; kreg[g * 4 + 2] = a.z * QSCALE2; kreg[g * 4 + 3] = a.w * QSCALE2;
-        vreg[g * 4 + 0] = b.x; vreg[g * 4 + 1] = b.y; vreg[g * 4 + 2] = b.z; vreg[g * 4 + 3] = b.w;
-    }
-    ksum += __shfl_xor(ksum, 32, 64);
-    const bool kkeep = (ksum != 0.f) && (key < Tk);
-    const float kfill = (key < Tk) ? FILL2 : -INFINITY;
-
-    floatx16 dk[2], dv[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
-
-    const int kfirst_blk = ktile * 128;
-    const long lrow = ((long)n * H + head) * Tq;
-    for (int q0 = 0; q0 < Tq; q0 += QT) {
-        if (CAUSAL && q0 + QT - 1 < kfirst_blk) {
-            // every score of this query tile against this key block is future-masked: dS = 0 (no dK), and P is
-            // exp(fill - max) = 0 unless a row's max IS the fill value (all of its keys masked) -- only then dV sees it
-            const int q = q0 + (tid & (QT - 1));
-            const bool degenerate = (q < Tq) && (lse[lrow + q] < -1.0e9f);
-            if (!__syncthreads_or(degenerate)) continue;
-        }
-        __syncthreads();
-        stage_tile(Qs, Q, qbase, q0, QT, Tq, ldq, hoff, tid, 1.f, qstat, 1);
-        if (tid < QT) {
-            const int q = q0 + tid;
-            lse_s[tid] = (q < Tq) ? lse[lrow + q] : INFINITY;
-            lsl_s[tid] = (q < Tq) ? lse[(long)Nn * H * Tq + lrow + q] : 0.f;
-            del_s[tid] = (q < Tq) ? delta[lrow + q] : 0.f;
-        }
-        __syncthreads();
-        // dO' = qmask * dO  (the query mask multiplies the post-softmax matrix)
-        for (int f = tid; f < QT * 16; f += 256) {
-            const int row = f >> 4, c4 = f & 15;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q0 + row < Tq && qstat[row] != 0.f) v = *(const float4*)(dO + (qbase + q0 + row) * C + hoff + c4 * 4);
-            *(float4*)(Ds + row * KP + c4 * 4) = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < QT / 32; ++sub) {
-            const float* Qt = Qs + sub * 32 * KP;
-            const float* Dt = Ds + sub * 32 * KP;
-            const float* lse_t = lse_s + sub * 32; const float* lsl_t = lsl_s + sub * 32; const float* del_t = del_s + sub * 32;
-            // the same rule per wave: these 32 queries all precede this wave's 32 keys (no barrier inside this loop)
-            if (CAUSAL && q0 + sub * 32 + 31 < k0 && !__any(lse_t[li] < -1.0e9f)) continue;
-            floatx16 s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const float4 qv = *(const float4*)(Qt + li * KP + 8 * g + 4 * lh);
-                const float4 dv4 = *(const float4*)(Dt + li * KP + 8 * g + 4 * lh);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.x, kreg[g * 4 + 0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.y, kreg[g * 4 + 1], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.z, kreg[g * 4 + 2], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.w, kreg[g * 4 + 3], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.x, vreg[g * 4 + 0], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.y, vreg[g * 4 + 1], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.z, vreg[g * 4 + 2], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.w, vreg[g * 4 + 3], dp, 0, 0, 0);
-            }
-            // rows of s/dp = queries rowidx(r, lh), column = this lane's key
-            // s <- P (as dV sees it), dp <- dS / 0.125 (the 1 / sqrt(d) is applied when dK is stored)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ql = rowidx(r, lh), q = q0 + sub * 32 + ql;
-                const bool keep = kkeep && (!CAUSAL || key <= q);
-                const float sv = keep ? s[r] : kfill;            // fill value, or -inf (p = 0) for a key past the end
-                const float p = ex2((sv - lse_t[ql]) - lsl_t[ql]);
-                float pd = p, dpe = dp[r];
-                if (DROP) {        // O = (P o M / (1-rate)) V: dV sees the dropped weights, dP arrives through the same mask
-                    const bool dm = drop_keep((uint32_t)(((n * H + head) * Tq + q) * Tk + key), drop_seed, drop_thr);
-                    pd = dm ? p * drop_scale : 0.f;
-                    dpe = dm ? dpe * drop_scale : 0.f;
-                }
-                const float ds = keep ? p * (dpe - del_t[ql]) : 0.f;
-                s[r] = pd; dp[r] = ds;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float* drow = Dt + rowidx(r, lh) * KP + li;
-                const float* qrow = Qt + rowidx(r, lh) * KP + li;
-                dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[0], s[r], dv[0], 0, 0, 0);
-                dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[32], s[r], dv[1], 0, 0, 0);
-                dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[0], dp[r], dk[0], 0, 0, 0);
-                dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[32], dp[r], dk[1], 0, 0, 0);
-            }
-        }
-    }
-    store_tile_T(dK, scratch + wave * (32 * 65), dk, 0.125f, kbase, k0, Tk, ldk, hoff, lane, relu_grad ? K : nullptr);
-    store_tile_T(dV, scratch + wave * (32 * 65), dv, 1.f, kbase, k0, Tk, ldk, hoff, lane, relu_grad ? V : nullptr);
-}
-
-// ------------------------------------------------------------------ attention backward: dQ
-template <bool CAUSAL, bool DROP>
-__global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restrict__ Q, const float* __restrict__ K,
-                                                         const float* __restrict__ V, const float* __restrict__ dO,
-                                                         const float* __restrict__ lse, const float* __restrict__ delta,
-                                                         float* __restrict__ dQ, int Tq, int Tk, int C, int H, int ldq, int ldk, int relu_grad,
-                                                         uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
-    __shared__ __attribute__((aligned(16))) float kv_lds[2 * 64 * KP];   // also the epilogue's transpose scratch
-    float* Ks = kv_lds;
-    float* Vs = kv_lds + 64 * KP;
-    __shared__ float kstat[64];
-    static_assert(4 * 32 * 65 <= 2 * 64 * KP, "transpose scratch must fit in the K/V tiles");
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
-    int qtile, head, n, Nn;
-    attn_block_coords<CAUSAL>(H, true, qtile, head, n, Nn);
-    const int hoff = head * DH;
-    const int q0 = qtile * 128 + wave * 32, q = q0 + li;
-    const long qbase = (long)n * Tq, kbase = (long)n * Tk;
-
-    float qreg[32], doreg[32];
-    float qabs = 0.f;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (q < Tq) {
-            a = *(const float4*)(Q + (qbase + q) * ldq + hoff + 8 * g + 4 * lh);
-            b = *(const float4*)(dO + (qbase + q) * C + hoff + 8 * g + 4 * lh);
-        }
-        qabs += fabsf(a.x) + fabsf(a.y) + fabsf(a.z) + fabsf(a.w);
-        qreg[g * 4 + 0] = a.x * QSCALE2; qreg[g * 4 + 1] = a.y * QSCALE2; qreg[g * 4 + 2] = a.z * QSCALE2; qreg[g * 4 + 3] = a.w * QSCALE2;
-        doreg[g * 4 + 0] = b.x; doreg[g * 4 + 1] = b.y; doreg[g * 4 + 2] = b.z; doreg[g * 4 + 3] = b.w;
-    }
-    qabs += __shfl_xor(qabs, 32, 64);
-    const float qmask = (qabs != 0.f) ? 1.f : 0.f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) doreg[i] *= qmask;
-    const float my_lse = (q < Tq) ? lse[((long)n * H + head) * Tq + q] : INFINITY;
-    const float my_lsl = (q < Tq) ? lse[(long)Nn * H * Tq + ((long)n * H + head) * Tq + q] : 0.f;
-    const float my_del = (q < Tq) ? delta[((long)n * H + head) * Tq + q] : 0.f;
-
-    floatx16 dq[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
-
-    for (int k0 = 0; k0 < Tk; k0 += 64) {
-        if (CAUSAL && k0 > qtile * 128 + 127) break;     // masked scores get no gradient: nothing for dQ there
-        __syncthreads();
-        stage_tile(Ks, K, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, kstat, 2);
-        stage_tile(Vs, V, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, nullptr, 0);
-        __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            if (CAUSAL && k0 + sub * 32 > q0 + 31) continue;       // future to this whole wave: dS = 0
-            floatx16 s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const float4 kv = *(const float4*)(Ks + (sub * 32 + li) * KP + 8 * g + 4 * lh);
-                const float4 vv = *(const float4*)(Vs + (sub * 32 + li) * KP + 8 * g + 4 * lh);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qreg[g * 4 + 0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qreg[g * 4 + 1], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qreg[g * 4 + 2], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qreg[g * 4 + 3], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, doreg[g * 4 + 0], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.y, doreg[g * 4 + 1], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.z, doreg[g * 4 + 2], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.w, doreg[g * 4 + 3], dp, 0, 0, 0);
-            }
-            // dp <- dS / 0.125 (the 1 / sqrt(d) is applied when dQ is stored)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = sub * 32 + rowidx(r, lh);
-                const float kb = kstat[kl];                      // key bias (stage_tile, mode 2)
-                const bool keep = (kb == 0.f) && (!CAUSAL || k0 + kl <= q);
-                float sv = s[r];
-                if (CAUSAL) sv = (k0 + kl <= q) ? sv : FILL2;
-                sv = (kb == 0.f) ? sv : kb;
-                const float p = ex2((sv - my_lse) - my_lsl);
-                float dpe = dp[r];
-                if (DROP) dpe = drop_keep((uint32_t)(((n * H + head) * Tq + q) * Tk + k0 + kl), drop_seed, drop_thr) ? dpe * drop_scale : 0.f;
-                dp[r] = keep ? p * (dpe - my_del) : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float* krow = Ks + (sub * 32 + rowidx(r, lh)) * KP + li;
-                dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[0], dp[r], dq[0], 0, 0, 0);
-                dq[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[32], dp[r], dq[1], 0, 0, 0);
-            }
-        }
-    }
-    __syncthreads();
-    store_tile_T(dQ, Ks + wave * (32 * 65), dq, 0.125f, qbase, q0, Tq, ldq, hoff, lane, relu_grad ? Q : nullptr);
-}
-
 // ------------------------------------------------------------------ (add +) LayerNorm
 // one wave per row; y = gamma * (x - mean) / sqrt(var + eps) + beta with x = a (+ b)
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -831,80 +383,6 @@ inline int grid_for(long total, int threads) {
 }  // namespace
 
 // ===================================================================== C ABI
-static inline uint32_t drop_threshold(float rate) {
-    double t = (double)rate * 16777216.0;
-    if (t < 0) t = 0;
-    if (t > 16777215.0) t = 16777215.0;
-    return (uint32_t)(t + 0.5);
-}
-
-extern "C" int asr_attention_fwd_p(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
-                                   int ldq, int ldk, int causal, float dropout_rate, unsigned int seed, float* O, float* lse,
-                                   void* stream) {
-    if (!Q || !K || !V || !O || !lse || N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
-    if (ldq < C || ldk < C || (ldq & 3) || (ldk & 3)) return ASR_ERR_BAD_ARG;
-    if (dropout_rate < 0.f || dropout_rate >= 1.f || (double)N * H * Tq * Tk >= 4294967296.0) return ASR_ERR_BAD_ARG;
-    dim3 grid(asr_cdiv(Tq, 128), H, N), grid_causal(N * H, asr_cdiv(Tq, 128), 1);      // see attn_block_coords
-    hipStream_t st = (hipStream_t)stream;
-    const uint32_t thr = drop_threshold(dropout_rate);
-    const float sc = 1.0f / (1.0f - dropout_rate);
-    if (dropout_rate > 0.f) {
-        if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true, true>), grid_causal, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, ldq, ldk, thr, seed, sc);
-        else hipLaunchKernelGGL((attn_fwd_kernel<false, true>), grid, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, ldq, ldk, thr, seed, sc);
-    } else {
-        if (causal) hipLaunchKernelGGL((attn_fwd_kernel<true, false>), grid_causal, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, ldq, ldk, thr, seed, sc);
-        else hipLaunchKernelGGL((attn_fwd_kernel<false, false>), grid, dim3(256), 0, st, Q, K, V, O, lse, Tq, Tk, C, H, ldq, ldk, thr, seed, sc);
-    }
-    ASR_CHECK_LAUNCH("attention_fwd");
-    return ASR_OK;
-}
-
-extern "C" int asr_attention_fwd(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
-                                 int causal, float dropout_rate, unsigned int seed, float* O, float* lse, void* stream) {
-    return asr_attention_fwd_p(Q, K, V, N, Tq, Tk, C, H, C, C, causal, dropout_rate, seed, O, lse, stream);
-}
-
-extern "C" int asr_attention_bwd_p(const float* Q, const float* K, const float* V, const float* O, const float* dO,
-                                   const float* lse, int N, int Tq, int Tk, int C, int H, int ldq, int ldk, int causal,
-                                   int relu_grad, float dropout_rate, unsigned int seed,
-                                   float* dQ, float* dK, float* dV, float* delta_ws, void* stream) {
-    if (ldq < C || ldk < C || (ldq & 3) || (ldk & 3)) return ASR_ERR_BAD_ARG;
-    if (!Q || !K || !V || !O || !dO || !lse || !dQ || !dK || !dV || !delta_ws) return ASR_ERR_BAD_ARG;
-    if (N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
-    if (dropout_rate < 0.f || dropout_rate >= 1.f || (double)N * H * Tq * Tk >= 4294967296.0) return ASR_ERR_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const long groups = (long)N * Tq * H;
-    hipLaunchKernelGGL(attn_delta_kernel, dim3(asr_cdiv(groups * 16, 256)), dim3(256), 0, st, O, dO, delta_ws, N, Tq, C, H);
-    dim3 gkv(asr_cdiv(Tk, 128), H, N), gq(asr_cdiv(Tq, 128), H, N);
-    dim3 ckv(N * H, asr_cdiv(Tk, 128), 1), cq(N * H, asr_cdiv(Tq, 128), 1);
-    const float* dl = (const float*)delta_ws;
-    const uint32_t thr = drop_threshold(dropout_rate);
-    const float sc = 1.0f / (1.0f - dropout_rate);
-#define ASR_ATTN_BWD(CA, DR, GKV, GQ)                                                                                          \
-    do {                                                                                                                       \
-        hipLaunchKernelGGL((attn_bwd_kv_kernel<CA, DR>), GKV, dim3(256), 0, st, Q, K, V, dO, lse, dl, dK, dV, Tq, Tk, C, H,    \
-                           ldq, ldk, relu_grad, thr, seed, sc);                                                                          \
-        hipLaunchKernelGGL((attn_bwd_q_kernel<CA, DR>), GQ, dim3(256), 0, st, Q, K, V, dO, lse, dl, dQ, Tq, Tk, C, H,           \
-                           ldq, ldk, relu_grad, thr, seed, sc);                                                                          \
-    } while (0)
-    if (dropout_rate > 0.f) {
-        if (causal) ASR_ATTN_BWD(true, true, ckv, cq); else ASR_ATTN_BWD(false, true, gkv, gq);
-    } else {
-        if (causal) ASR_ATTN_BWD(true, false, ckv, cq); else ASR_ATTN_BWD(false, false, gkv, gq);
-    }
-#undef ASR_ATTN_BWD
-    ASR_CHECK_LAUNCH("attention_bwd");
-    return ASR_OK;
-}
-
-extern "C" int asr_attention_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO,
-                                 const float* lse, int N, int Tq, int Tk, int C, int H, int causal, int relu_grad,
-                                 float dropout_rate, unsigned int seed,
-                                 float* dQ, float* dK, float* dV, float* delta_ws, void* stream) {
-    return asr_attention_bwd_p(Q, K, V, O, dO, lse, N, Tq, Tk, C, H, C, C, causal, relu_grad, dropout_rate, seed, dQ, dK, dV,
-                               delta_ws, stream);
-}
-
 __global__ void copy2d_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds, int rows, int c4n,
                               int accumulate) {
     const long total = (long)rows * c4n;
