@@ -367,6 +367,16 @@ class DFCNNEngine:
         # Winograd F(2x2,3x3) kernels (wino.hip) for the 3x3 convs they support, forward and data-gradient (plain and gated):
         # 16 instead of 36 multiplies per 2x2 output tile, still fp32; 1.3-1.6x the tap-GEMM per layer.  For a pooled cell
         # the 2x2 pool is computed inside the forward launch.  wino=False / ASR_WINO=0 keeps every layer on the tap-GEMM.
+        # dense layers: the kernel transposed ([cout][cin], one batched launch per step), so that the large forward GEMMs read
+        # both operands K-contiguous through LDS-DMA (asr_tap_gemm_nt, gemm1.hip: 6400 x 6400 x 1536 of acoustic_model2.py
+        # 109 -> 125 TFLOP/s); small ones fall through to asr_tap_gemm inside the library
+        self.wT, items = {}, []
+        for op in self.g:
+            if op[0] == 'dense' and op[2] not in self.splitk:
+                _, src, dst, cin, cout, act = op
+                self.wT[dst] = torch.zeros(cout * cin, dtype=torch.float32, device=dev)
+                items.append((self.wT[dst], cin, self.p(dst, 'w'), cout, cin, cout))
+        self._wT_batch = ops.Copy2dBatch(items) if items else None
         self.wt_f, self.wt_b = {}, {}
         if self.opt_wino:
             for op in self.g:
@@ -467,6 +477,8 @@ class DFCNNEngine:
                 ops.winograd_weights(self.p(dst, 'w'), cin, cout, cout, 0, self.wt_f[dst])
             else:
                 ops.arrange_weights(self.p(dst, 'w'), 9, cin, cout, cout, 0, buf)
+        if self._wT_batch is not None:
+            self._wT_batch.run_transposed()
 
     def _backward_weights(self):
         """The same for the data-gradient views (mirrored taps); not needed before the backward pass."""
@@ -541,8 +553,8 @@ class DFCNNEngine:
                     ops.tap_gemm_splitk(self.fdesc[dst], self.flat[src], self.p(dst, 'w'), self.p(dst, 'b'), None, None,
                                         None, self.flat[dst], self.splitk[dst], self.ws)
                 else:
-                    ops.tap_gemm(self.fdesc[dst], self.flat[src], self.p(dst, 'w'), self.p(dst, 'b'), None, None,
-                                 None, self.flat[dst])
+                    ops.tap_gemm_nt(self.fdesc[dst], self.flat[src], self.p(dst, 'w'), self.wT[dst], cin, self.p(dst, 'b'), None, None,
+                                    None, self.flat[dst])
         ops.softmax_log_fwd(self.flat[self.g[-1][2]], self.B, self.T8, self.V, K_EPSILON, self.logits)
         return self.logits
 
