@@ -38,6 +38,12 @@ struct WinoArgs {
     int wodd;               // plane width is odd
     float* pool_y;          // eight-wave kernel: pooled BN output plane [B][H/2+1][W/2+1][N] of a fused 2x2 pool, or null
     int pool_mode, H2, W2;  // 1 average, 2 maximum
+    // column-blocked tile order (wino9_kernel): the tile columns of an image are cut into ncb blocks of 11..15 columns; the tiles
+    // of a block are numbered row-major WITHIN the block and a work item is 64 consecutive tiles of one block
+    int ncb;                // number of column blocks (0: plain order, wino8_kernel)
+    int cb_tj0[8];          // first tile column of the block
+    int cb_w[8];            // tile columns of the block
+    int cb_it0[9];          // first item of the block within an image; cb_it0[ncb] = items per image
 };
 
 constexpr int WT = 64;                      // tiles per workgroup
@@ -87,11 +93,12 @@ __global__ void wino_weights_kernel(const float* __restrict__ W, int K, int N, i
 // chunk -- the pairing of channels into k-pairs is free as long as the weights follow it -- so all four floats are used.
 typedef float wn_f2 __attribute__((ext_vector_type(2)));
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding global access of the wave
-// (vmcnt(0)) -- the next item's DMA and the epilogue's stores, which nothing in the workgroup is waiting for
+// (vmcnt(0)) -- the next item's DMA and the epilogue's stores, which nothing in the workgroup is waiting for.  Written as
+// plain instructions: a release / acquire fence pair on the local address space still makes hipcc emit vmcnt(0) while an
+// LDS-DMA is in flight (it counts the DMA as an LDS write), which is how the tail of wino8_kernel waited for the next item's
+// first chunk until round 3.
 __device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 #ifdef WINO_TRACE
 __device__ long long wino_trace_buf[4 * 8 * 16];          // [item 4][wave 8][stamp 16], workgroup 0 only
@@ -201,6 +208,84 @@ __device__ __forceinline__ void wino8_chunk(const float* __restrict__ raw, const
     mfmas(v, 0, ua, -1);
     __builtin_amdgcn_sched_barrier(0);
     mfmas(v, 1, ubb, -1);
+}
+
+// The item tail shared by wino8_kernel and wino9_kernel: exchange of the column sums between the two halves, the lane-local inverse
+// transform, the fused pool and the epilogues.  rfree / ufree: the raw and the weight buffer set that no DMA is writing (8192
+// floats each).
+template <int XH>
+__device__ __forceinline__ void wino_item_tail(const WinoArgs& args, floatx16 (&acc)[8], float* rfree, float* ufree, const int* rowa,
+                                               const int* rowy, const int* prow, int wave, int lane, int wm, int wn, int n0, int blk,
+                                               float pool_bs, float pool_sc, float pool_sh) {
+    const TapGemmArgs& g = args.g;
+    // own column sums: m(r, j) = acc[r * 2 + j], transform column c = 2 XH + j
+    floatx16 s0[2], s1[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[j][r] = (acc[0 + j][r] + acc[2 + j][r]) + acc[4 + j][r];
+            s1[j][r] = (acc[2 + j][r] - acc[4 + j][r]) - acc[6 + j][r];
+        }
+    // half 0 finishes pixel row 0 and needs s0 of columns 2, 3; half 1 finishes pixel row 1 and needs s1 of columns 0, 1
+    // each wave hands its partner 2 x 16 registers x 64 lanes = 2048 floats: waves 0-3 through the raw set, waves 4-7
+    // through the weight set (8192 floats each)
+    float* xch = (XH == 0 ? rfree : ufree) + (wave & 3) * 2048;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(j * 16 + r) * 64 + lane] = XH == 0 ? s1[j][r] : s0[j][r];
+    lds_barrier();
+    const float* pch = (XH == 0 ? ufree : rfree) + (wave & 3) * 2048;
+    floatx16 out[2][1];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float c0, c1, c2, c3;
+        if (XH == 0) { c0 = s0[0][r]; c1 = s0[1][r]; c2 = pch[(0 * 16 + r) * 64 + lane]; c3 = pch[(1 * 16 + r) * 64 + lane]; }
+        else         { c0 = pch[(0 * 16 + r) * 64 + lane]; c1 = pch[(1 * 16 + r) * 64 + lane]; c2 = s1[0][r]; c3 = s1[1][r]; }
+        out[0][0][r] = (c0 + c1) + c2;
+        out[1][0][r] = (c1 - c2) - c3;
+    }
+    lds_barrier();                               // every wave has read its partner's values: the weight set becomes scratch
+    if (args.pool_y) {
+        // Fused 2x2 pool (a Winograd tile IS a pooling window): this wave holds pixels (XH, 0) and (XH, 1) of its tiles as
+        // out[0] / out[1], lane = output channel.  BN(ReLU(x + bias)) and the row's pair lane-locally, then half 1 hands its
+        // pair to half 0 through LDS (behind the scratch areas) and half 0 stores the pooled pixel: 128-byte rows of 32
+        // channels.  Same arithmetic and association as asr_pool_fwd on the stored activation: bit-identical.
+        const float bs = pool_bs, scv = pool_sc, shv = pool_sh;
+        floatx16 pm;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float x0 = out[0][0][r] + bs, x1 = out[1][0][r] + bs;
+            if (g.relu == 1) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
+            else if (g.relu == 2) { x0 = tanhf(x0); x1 = tanhf(x1); }
+            const float v0 = fmaf(scv, x0, shv), v1 = fmaf(scv, x1, shv);
+            pm[r] = args.pool_mode == 1 ? v0 + v1 : fmaxf(v0, v1);
+        }
+        float* pex = (wave & 2 ? ufree : rfree) + 4 * (32 * 33) + (wave & 1) * 1024;    // pair (wm, wn)
+        if (XH == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pex[r * 64 + lane] = pm[r];
+        }
+        lds_barrier();
+        if (XH == 0) {
+            floatx16 po[1][1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float qv = pex[r * 64 + lane];
+                po[0][0][r] = args.pool_mode == 1 ? 0.25f * (pm[r] + qv) : fmaxf(pm[r], qv);
+            }
+            // stored through the shared epilogue (one 32 x 32 block, float4 rows: 4 store instructions instead of 16 scalar
+            // ones -- the tail is store-issue bound), row table = the pooled rows of this wave's 32 tiles
+            TapGemmArgs gp = g;
+            gp.out_a = args.pool_y; gp.ldo_a = g.N; gp.out_y = nullptr; gp.bias = nullptr; gp.relu = 0; gp.accumulate = 0; gp.gate_mode = 0;
+            float* pscr = (wave < 4 ? rfree : ufree) + (wave & 3) * (32 * 33);
+            tap_epilogue<1, 1>(gp, po, pscr, prow, prow, wm * 32, n0 + wn * 32, lane, 0);
+        }
+    }
+    // transpose scratch (32 x 33 floats per wave): waves 0-3 in the raw set, waves 4-7 in the weight set
+    float* scratch = (wave < 4 ? rfree : ufree) + (wave & 3) * (32 * 33);
+    tap_epilogue<2, 1>(g, out, scratch, rowa, rowy, wm * 128 + XH * 64, n0 + wn * 32, lane, (blk * 2 + wm) * 2 + XH);
 }
 
 // per-lane DMA offsets of one work item of the eight-wave kernel: tile t0 + lane (clamped): byte offset of the top-left pixel
@@ -340,84 +425,324 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
             cur ^= 1;
         }
         WTRACE(3);
-        WTRACE(4);
-        // own column sums: m(r, j) = acc[r * 2 + j], transform column c = 2 XH + j
-        floatx16 s0[2], s1[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s0[j][r] = (acc[0 + j][r] + acc[2 + j][r]) + acc[4 + j][r];
-                s1[j][r] = (acc[2 + j][r] - acc[4 + j][r]) - acc[6 + j][r];
-            }
-        // half 0 finishes pixel row 0 and needs s0 of columns 2, 3; half 1 finishes pixel row 1 and needs s1 of columns 0, 1
-        // each wave hands its partner 2 x 16 registers x 64 lanes = 2048 floats: waves 0-3 through the raw set, waves 4-7
-        // through the weight set of `cur ^ 1` (8192 floats each)
-        float* xbase = bufs + (cur ^ 1) * RAW_F;
-        float* xch = (XH == 0 ? xbase : bufs + 2 * RAW_F + (cur ^ 1) * U_F) + (wave & 3) * 2048;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) xch[(j * 16 + r) * 64 + lane] = XH == 0 ? s1[j][r] : s0[j][r];
-        WTRACE(5);
-        lds_barrier();
-        WTRACE(6);
-        const float* pch = (XH == 0 ? bufs + 2 * RAW_F + (cur ^ 1) * U_F : xbase) + (wave & 3) * 2048;
-        floatx16 out[2][1];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float c0, c1, c2, c3;
-            if (XH == 0) { c0 = s0[0][r]; c1 = s0[1][r]; c2 = pch[(0 * 16 + r) * 64 + lane]; c3 = pch[(1 * 16 + r) * 64 + lane]; }
-            else         { c0 = pch[(0 * 16 + r) * 64 + lane]; c1 = pch[(1 * 16 + r) * 64 + lane]; c2 = s1[0][r]; c3 = s1[1][r]; }
-            out[0][0][r] = (c0 + c1) + c2;
-            out[1][0][r] = (c1 - c2) - c3;
-        }
-        WTRACE(7);
-        lds_barrier();                               // every wave has read its partner's values: the weight set becomes scratch
-        WTRACE(8);
-        if (args.pool_y) {
-            // Fused 2x2 pool (a Winograd tile IS a pooling window): this wave holds pixels (XH, 0) and (XH, 1) of its tiles as
-            // out[0] / out[1], lane = output channel.  BN(ReLU(x + bias)) and the row's pair lane-locally, then half 1 hands its
-            // pair to half 0 through LDS (behind the scratch areas) and half 0 stores the pooled pixel: 128-byte rows of 32
-            // channels.  Same arithmetic and association as asr_pool_fwd on the stored activation: bit-identical.
-            const float bs = pool_bs, scv = pool_sc, shv = pool_sh;
-            floatx16 pm;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x0 = out[0][0][r] + bs, x1 = out[1][0][r] + bs;
-                if (g.relu == 1) { x0 = fmaxf(x0, 0.f); x1 = fmaxf(x1, 0.f); }
-                else if (g.relu == 2) { x0 = tanhf(x0); x1 = tanhf(x1); }
-                const float v0 = fmaf(scv, x0, shv), v1 = fmaf(scv, x1, shv);
-                pm[r] = args.pool_mode == 1 ? v0 + v1 : fmaxf(v0, v1);
-            }
-            float* pex = (wave & 2 ? bufs + 2 * RAW_F + (cur ^ 1) * U_F : xbase) + 4 * (32 * 33) + (wave & 1) * 1024;    // pair (wm, wn)
-            if (XH == 1) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) pex[r * 64 + lane] = pm[r];
-            }
-            lds_barrier();
-            if (XH == 0) {
-                floatx16 po[1][1];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float qv = pex[r * 64 + lane];
-                    po[0][0][r] = args.pool_mode == 1 ? 0.25f * (pm[r] + qv) : fmaxf(pm[r], qv);
-                }
-                // stored through the shared epilogue (one 32 x 32 block, float4 rows: 4 store instructions instead of 16 scalar
-                // ones -- the tail is store-issue bound), row table = the pooled rows of this wave's 32 tiles
-                TapGemmArgs gp = g;
-                gp.out_a = args.pool_y; gp.ldo_a = g.N; gp.out_y = nullptr; gp.bias = nullptr; gp.relu = 0; gp.accumulate = 0; gp.gate_mode = 0;
-                float* pscr = (wave < 4 ? xbase : bufs + 2 * RAW_F + (cur ^ 1) * U_F) + (wave & 3) * (32 * 33);
-                tap_epilogue<1, 1>(gp, po, pscr, prow, prow, wm * 32, n0 + wn * 32, lane, 0);
-            }
-        }
-        // transpose scratch (32 x 33 floats per wave): waves 0-3 in the raw set, waves 4-7 in the weight set of `cur ^ 1`
-        float* scratch = (wave < 4 ? xbase : bufs + 2 * RAW_F + (cur ^ 1) * U_F) + (wave & 3) * (32 * 33);
-        tap_epilogue<2, 1>(g, out, scratch, rowa, rowy, wm * 128 + XH * 64, n0 + wn * 32, lane, (blk * 2 + wm) * 2 + XH);
+        wino_item_tail<XH>(args, acc, bufs + (cur ^ 1) * RAW_F, bufs + 2 * RAW_F + (cur ^ 1) * U_F, rowa, rowy, prow, wave, lane, wm, wn, n0,
+                           blk, pool_bs, pool_sc, pool_sh);
         WTRACE(9);
         lds_barrier();                               // row tables and buffer set `cur ^ 1` are reused by the next item
         WTRACE(10);
     }
+}
+
+// ------------------------------------------------------------------------------------------------ wino9_kernel (round 3)
+// The same computation with the raw patches fetched ONCE.  wino8_kernel fetches the 4 x 4 patch of every tile separately: 16 pixels
+// x 2 quads x 64 tiles = 2048 16-byte slots per 8-channel chunk, every DMA instruction 64 lanes on 64 different 128-byte lines,
+// every pixel four times (the patches of neighbouring tiles overlap by two pixels) -- the ablation in profiles/r03_wino_ablation.txt
+// prices those 32 instructions per chunk at 17-20 % of the kernel.  Here:
+//   * the tile columns of an image are cut into column blocks of w = 11..15 columns and the tiles are numbered row-major WITHIN a
+//     block, so that the 64 consecutive tiles of an item cover <= 7 tile rows x w columns: a region of <= 16 pixel rows x (2 w + 2)
+//     pixel columns holds every patch of the item once;
+//   * the region is fetched for SIXTEEN channels at a time (a "super-chunk" = two 8-channel chunks): a DMA piece is one pixel row
+//     and one column parity -- <= 16 pixels (pixel columns 2 idx + par) x 64 contiguous bytes: 16 lines per instruction instead of
+//     64, and <= 32 pieces per 16 channels instead of 64 per 16: the addresser time of the raw fetch drops about eightfold;
+//   * LDS layout of a piece (64 slots of 16 bytes): [channel quad 0..3][position 0..15]; the pixel idx of row Y sits at position
+//     (idx + rho(Y)) & 15, rho(Y) = ((Y >> 1) w) & 15 -- so that the ds_read_b128 of patch pixel (r, c) by the 32 lanes of a
+//     half-wave (tile l of the block reads idx = tc + (c >> 1) of row 2 tr + r) lands on position (l + (r >> 1) w + (c >> 1)) & 15:
+//     consecutive tiles on consecutive positions, whatever w is -- conflict-free on the instruction's 16-lane service groups;
+//   * columns past the plane's width and rows past the image are sent out of the buffer's range and read zeros (no patch column
+//     to clear for odd widths).
+// The weights arrive as before (per 8-channel chunk), all pieces by buffer-form DMA (scalar row offsets, no vector instruction
+// per piece).  Items do not span column blocks or images: the last item of a block may be partly empty (1-3 % of the tiles).
+#if __HIP_DEVICE_COMPILE__
+struct Wino9Geo { int b, tj0, w, l0, tr0, npieces; };
+
+__device__ __forceinline__ Wino9Geo wino9_geo(const WinoArgs& args, int blk) {
+    Wino9Geo e;
+    const int ipi = args.cb_it0[args.ncb];
+    e.b = blk / ipi;
+    const int rem = blk - e.b * ipi;
+    int cb = 0;
+    while (cb + 1 < args.ncb && rem >= args.cb_it0[cb + 1]) ++cb;
+    e.tj0 = args.cb_tj0[cb]; e.w = args.cb_w[cb];
+    e.l0 = (rem - args.cb_it0[cb]) * WT;
+    e.tr0 = e.l0 / e.w;
+    const int rows = (e.l0 + WT - 1) / e.w - e.tr0 + 1;       // tile rows the item touches (<= 7)
+    e.npieces = 2 * (2 * rows + 2);                           // pixel rows x column parities
+    return e;
+}
+
+template <class R>
+struct Wino9Dma {
+    R ra, ru;
+    unsigned voff[4];        // raw pieces wave + 8 j of a super-chunk
+    unsigned sbase;          // byte offset of the region's first pixel (channel 0)
+    unsigned off_u;
+    int npieces, wave, rowbytes, N;
+    long ustride_xi;
+};
+
+// per-lane offsets of the raw pieces this wave issues (piece p = wave + 8 j: pixel row p >> 1 of the region, parity p & 1)
+template <class R>
+__device__ __forceinline__ void wino9_offsets(const WinoArgs& args, const Wino9Geo& e, int lane, Wino9Dma<R>& q) {
+    const TapGemmArgs& g = args.g;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = q.wave + 8 * j, y = p >> 1, par = p & 1;
+        const int rho = ((e.tr0 + (y >> 1)) * e.w) & 15;
+        const int idx = ((lane & 15) - rho) & 15;
+        const int x = 2 * idx + par;
+        const bool ok = idx <= e.w && 2 * e.tj0 + x < g.WP && 2 * e.tr0 + y <= g.H + 1 && p < e.npieces;
+        q.voff[j] = ok ? (unsigned)((x * g.lda + (lane >> 4) * 4) * 4) : 0xFFFFFFF0u;
+    }
+    q.sbase = (unsigned)((((long)e.b * g.HPWP + (long)(2 * e.tr0) * g.WP + 2 * e.tj0) * g.lda) * 4);
+    q.npieces = e.npieces;
+}
+// per-lane offset inside a weight piece (4 rows of N floats): row lane / 16, column quad lane % 16 of channel block n0
+__device__ __forceinline__ unsigned wino9_u_offset(const WinoArgs& args, int n0, int lane) {
+    return (unsigned)(((long)(lane >> 4) * args.g.N + n0 + (lane & 15) * 4) * 4);
+}
+
+// raw piece jr (0..3) of the super-chunk whose first channel is c16, into raw set `raw`
+template <class R>
+__device__ __forceinline__ void wino9_raw_piece(const Wino9Dma<R>& q, float* __restrict__ raw, int jr, int c16) {
+    // always issued (a piece past the region has every lane out of range: it moves nothing), so that the number of DMA
+    // instructions a wave has in flight is known to the s_waitcnt of the chunk barrier
+    const int p = q.wave + 8 * jr;
+#if defined(WINO_ABL) && (WINO_ABL & 4)
+    return;
+#endif
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(q.ra, (wn_lds_f*)(raw + p * 256), 16, q.voff[jr],
+                                             (int)(q.sbase + (unsigned)((p >> 1) * q.rowbytes + c16 * 4)), 0, 0);
+}
+// weight piece ju (0..3) of chunk kc: piece p = wave + 8 ju = xi * 2 + (ci >> 2)
+template <class R>
+__device__ __forceinline__ void wino9_u_piece(const Wino9Dma<R>& q, float* __restrict__ ub, int ju, int kc) {
+    const int p = q.wave + 8 * ju;
+    const int xi = p >> 1, cig = p & 1;
+#if defined(WINO_ABL) && (WINO_ABL & 8)
+    return;
+#endif
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(q.ru, (wn_lds_f*)(ub + p * 256), 16, q.off_u,
+                                             (int)((xi * q.ustride_xi + (long)(kc * WKC + cig * 4) * q.N) * 4), 0, 0);
+}
+
+// One 8-channel chunk (half hh of its super-chunk) in two phases.  Phase A: the LDS reads of the chunk (12 patch pixels, the
+// weights of all four k-pairs as the registers come free), both input transforms and the first sixteen MFMAs; phase B: the other
+// sixteen MFMAs, from registers only.  (Running the two waves of a SIMD half a chunk apart -- half 1 arriving at the chunk barrier
+// between its phases, so that one of them always has MFMAs in registers behind a barrier -- was tried: 2 % slower, the half that
+// is ahead waits for the other at the item's exchange.)
+// Prefetches sit between the MFMAs of two groups (`slots`): the four weight pieces of chunk `kcn` (into ubn), then -- in the
+// FIRST chunk of a super-chunk -- the four raw pieces of the super-chunk at channel c16n (into rawn): those have the rest of
+// this chunk and the whole next one to arrive (every second super-chunk starts new 128-byte lines, i.e. comes from HBM rather
+// than L2: the in-kernel stamps of wino8_kernel showed exactly those chunks 1.5 us longer).
+struct Wino9Regs { wn_f2 v[8]; float ua[8], ubb[8]; };
+template <class R>
+struct Wino9Pre { bool u, raw; int kcn, c16n; float* rawn; float* ubn; const Wino9Dma<R>* q; };
+
+// eight MFMAs; what = 1: a weight piece, 2: a raw piece behind MFMA 1, 3, 5, 7
+template <class R>
+__device__ __forceinline__ void wino9_group(floatx16 (&acc)[8], const wn_f2 (&v)[8], int h, const float (&u)[8], int what,
+                                            const Wino9Pre<R>& pf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[i].y : v[i].x, u[i], acc[i], 0, 0, 0);
+        if (what && (i & 1)) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (what == 1 && pf.u) wino9_u_piece(*pf.q, pf.ubn, i >> 1, pf.kcn);
+            if (what == 2 && pf.raw) wino9_raw_piece(*pf.q, pf.rawn, i >> 1, pf.c16n);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int XH, class R>
+__device__ __forceinline__ void wino9_phase_a(const float* __restrict__ raw, const float* __restrict__ ub, const Wino9Pre<R>& pf, bool slots,
+                                              int hh, const unsigned (&lb)[4], int boff, floatx16 (&acc)[8], Wino9Regs& rg) {
+    auto load_u = [&](float (&u)[8], int kp) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+#if defined(WINO_ABL) && (WINO_ABL & 2)
+            for (int j = 0; j < 2; ++j) u[r * 2 + j] = __int_as_float(boff + r * 2 + j + kp);
+#else
+            for (int j = 0; j < 2; ++j) u[r * 2 + j] = ub[((r * 4 + 2 * XH + j) * WKC + kp) * WC + boff];
+#endif
+    };
+    float4 d[12];
+    const char* rb = (const char*)raw + hh * 512;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int cc = XH + c;
+#if defined(WINO_ABL) && (WINO_ABL & 1)
+            { const float f = __uint_as_float(lb[(r >> 1) * 2 + (cc >> 1)] + r * 3 + c); d[r * 3 + c] = make_float4(f, f * 2.f, f * 3.f, f * 4.f); }
+#else
+            d[r * 3 + c] = *(const float4*)(rb + lb[(r >> 1) * 2 + (cc >> 1)] + r * 2048 + (cc & 1) * 1024);
+#endif
+        }
+    load_u(rg.ua, 0);
+    load_u(rg.ubb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    wino8_transform<XH>(d, 0, rg.v);
+    __builtin_amdgcn_sched_barrier(0);
+    wino9_group(acc, rg.v, 0, rg.ua, slots ? 1 : 0, pf);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(rg.ua, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    wino9_group(acc, rg.v, 1, rg.ubb, slots ? 2 : 0, pf);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(rg.ubb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    wino8_transform<XH>(d, 1, rg.v);
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <class R>
+__device__ __forceinline__ void wino9_phase_b(const Wino9Pre<R>& pf, bool slots, floatx16 (&acc)[8], const Wino9Regs& rg) {
+    __builtin_amdgcn_sched_barrier(0);
+    wino9_group(acc, rg.v, 0, rg.ua, slots ? 1 : 0, pf);
+    __builtin_amdgcn_sched_barrier(0);
+    wino9_group(acc, rg.v, 1, rg.ubb, slots ? 2 : 0, pf);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int XH>
+__device__ __forceinline__ void wino9_body(const WinoArgs& args, float* smem) {
+    const TapGemmArgs& g = args.g;
+    int* rowa = (int*)smem;                          // [2 wave rows][4 pixels][32 tiles]
+    int* rowy = rowa + 256;
+    int* prow = rowy + 256;                          // [64 tiles]: row of the tile's pooled pixel (fused 2x2 pool), or -1
+    float* bufs = smem + 576;                        // raw0 | raw1 | u0 | u1
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = (wave >> 1) & 1, wn = wave & 1;                       // wave = xh * 4 + wm * 2 + wn
+    const int boff = lh * 4 * WC + wn * 32 + li;     // half 1 contracts channels 4 .. 7 of the chunk
+    const int nkc = g.K / WKC;                       // even (K % 16 == 0), >= 4
+    const int nnb = g.ntn, nwork = g.ntm * nnb;
+
+    int w = blockIdx.x;
+    if (w >= nwork) return;
+    const int G = gridDim.x;
+    auto item_of = [&](int wl) {                     // see wino8_body
+        const int r0 = (wl / G) * G;
+        if ((G & 7) || r0 + G > nwork) return wl;
+        const int p = wl - r0;
+        return r0 + (p & 7) * (G >> 3) + (p >> 3);
+    };
+    auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7FFFFFF0, 0x00020000);
+    auto ru = __builtin_amdgcn_make_buffer_rsrc((void*)args.Ut, 0, 0x7FFFFFF0, 0x00020000);
+    Wino9Dma<decltype(ra)> q;
+    q.ra = ra; q.ru = ru; q.wave = wave; q.rowbytes = g.WP * g.lda * 4; q.N = g.N; q.ustride_xi = (long)g.K * g.N;
+    int rcur = 0, ucur = 0;                          // raw set of the current super-chunk, weight set of the current chunk
+    {
+        const int it = item_of(w);
+        const Wino9Geo e = wino9_geo(args, it / nnb);
+        wino9_offsets(args, e, lane, q);
+        q.off_u = wino9_u_offset(args, (it % nnb) * WC, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { wino9_raw_piece(q, bufs, j, 0); wino9_u_piece(q, bufs + 2 * RAW_F, j, 0); }
+    }
+
+    for (; w < nwork; w += gridDim.x) {
+        const int item = item_of(w);
+        const int blk = item / nnb, nb = item - blk * nnb;
+        const Wino9Geo e = wino9_geo(args, blk);
+        const int n0 = nb * WC;
+        if (tid < 256) {
+            const int tl = tid & 63, pl = tid >> 6;      // 64 tiles x 4 pixels = 256 entries
+            const int l = e.l0 + tl;
+            const int ti = l / e.w, tj = e.tj0 + l - ti * e.w;
+            int ra_ = -1, ry = -1;
+            if (ti < args.TH) {
+                const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
+                if (ww <= g.Wd) {
+                    ra_ = (int)((long)e.b * g.HPWP + (long)hh * g.WP + ww);
+                    ry = g.y_unpadded ? ((e.b * g.H + hh - 1) * g.Wd + ww - 1) : ra_;
+                }
+            }
+            const int m = (tl >> 5) * 128 + pl * 32 + (tl & 31);
+            rowa[m] = ra_; rowy[m] = ry;
+            if (pl == 0) {
+                int pr = -1;
+                if (args.pool_y && ti < args.TH && tj < args.W2 && ti < args.H2) pr = (e.b * (args.H2 + 1) + ti + 1) * (args.W2 + 1) + tj + 1;
+                prow[tl] = pr;
+            }
+        }
+        // LDS byte offsets of this lane's patch pixels inside a raw set: tile l of the block, its row relative to the region
+        unsigned lb[4];
+        {
+            const int l = e.l0 + wm * 32 + li;
+            const int trl = l / e.w - e.tr0;
+            const unsigned fix = (unsigned)(trl * 4096 + lh * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lb[j] = fix + (unsigned)(((l + (j >> 1) * e.w + (j & 1)) & 15) * 16);
+        }
+        const int pool_n = n0 + wn * 32 + li;
+        float pool_bs = 0.f, pool_sc = 1.f, pool_sh = 0.f;
+        if (args.pool_y && pool_n < g.N) {
+            if (g.bias) pool_bs = g.bias[pool_n];
+            if (g.scale) pool_sc = g.scale[pool_n];
+            if (g.shift) pool_sh = g.shift[pool_n];
+        }
+        floatx16 acc[8];
+        Wino9Regs rg;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+        __builtin_amdgcn_s_waitcnt(0x0F70);          // the first super-chunk and chunk 0 of this item have landed
+        __syncthreads();
+        const int wnext = w + gridDim.x;
+        const bool more = wnext < nwork;
+        const int itn = more ? item_of(wnext) : 0;
+        for (int kc = 0; kc < nkc; ++kc) {
+            const int hh = kc & 1;
+            const bool last = kc + 1 == nkc;
+            if (kc == nkc - 2 && more) wino9_offsets(args, wino9_geo(args, itn / nnb), lane, q);      // the raw prefetch now belongs to the next item
+            if (last && more) q.off_u = wino9_u_offset(args, (itn % nnb) * WC, lane);                  // and so does the weight prefetch
+            const bool tail2 = kc >= nkc - 2;
+            Wino9Pre<decltype(ra)> pf;
+            pf.u = last ? more : true; pf.raw = hh == 0 && (tail2 ? more : true);
+            pf.kcn = last ? 0 : kc + 1; pf.c16n = tail2 ? 0 : (kc + 2) * WKC;
+            pf.rawn = bufs + (rcur ^ 1) * RAW_F; pf.ubn = bufs + 2 * RAW_F + (ucur ^ 1) * U_F; pf.q = &q;
+            wino9_phase_a<XH>(bufs + rcur * RAW_F, bufs + 2 * RAW_F + ucur * U_F, pf, true, hh, lb, boff, acc, rg);
+            wino9_phase_b(pf, false, acc, rg);
+            // the weight pieces of the next chunk must have landed; the four raw pieces issued AFTER them in this interval may stay
+            // in flight until the barrier of the super-chunk's second chunk
+            // (the barrier as plain instructions: a fence on the local address space makes hipcc wait for every DMA in flight)
+#if defined(WINO_ABL) && (WINO_ABL & 16)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+            if (last) lds_barrier();
+            else if (pf.raw) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+            ucur ^= 1;
+            rcur ^= hh;
+        }
+#if defined(WINO_ABL) && (WINO_ABL & 32)
+        { float sink = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) sink += acc[i][r];
+          if (sink == 123.456f) rowa[0] = 1; }
+#else
+        wino_item_tail<XH>(args, acc, bufs + (rcur ^ 1) * RAW_F, bufs + 2 * RAW_F + (ucur ^ 1) * U_F, rowa, rowy, prow, wave, lane, wm, wn, n0,
+                           blk, pool_bs, pool_sc, pool_sh);
+#endif
+        lds_barrier();                               // row tables and the free buffer sets are reused by the next item
+    }
+}
+#endif
+
+template <int DIR>
+__global__ __launch_bounds__(512) void wino9_kernel(WinoArgs args) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((threadIdx.x >> 8) == 0) wino9_body<0>(args, smem);
+    else wino9_body<1>(args, smem);
+#endif
 }
 
 template <int DIR>
@@ -476,7 +801,23 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     w.ntiles = (long)d->B * w.TH * w.TW;
     w.wodd = d->W & 1;
     w.pool_y = pool_y; w.pool_mode = pool_mode; w.H2 = d->H / 2; w.W2 = d->W / 2;
-    const int nblk = asr_cdiv(w.ntiles, WT);
+    // column-blocked tile order (wino9_kernel) when the tile columns split into blocks of 11..15 and K is a multiple of 16
+    w.ncb = 0;
+    if (d->K % 16 == 0 && d->K >= 32) {
+        for (int nb = asr_cdiv(w.TW, 15); nb <= 8 && nb * 11 <= w.TW; ++nb) {
+            if (asr_cdiv(w.TW, nb) > 15) continue;
+            w.ncb = nb;
+            int tj = 0, it = 0;
+            for (int c = 0; c < nb; ++c) {
+                const int cw = w.TW / nb + (c < w.TW % nb ? 1 : 0);
+                w.cb_tj0[c] = tj; w.cb_w[c] = cw; w.cb_it0[c] = it;
+                tj += cw; it += asr_cdiv(w.TH * cw, WT);
+            }
+            w.cb_it0[nb] = it;
+            break;
+        }
+    }
+    const int nblk = w.ncb ? d->B * w.cb_it0[w.ncb] : asr_cdiv(w.ntiles, WT);
     a.ntm = nblk; a.ntn = d->N / WC;
     if (a.gate_rows) *a.gate_rows = nblk * 4;
     const size_t lds8 = (size_t)(576 + 2 * RAW_F + 2 * U_F) * sizeof(float);
@@ -488,10 +829,25 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     }
     const int nwork8 = nblk * a.ntn;
     const int grid8 = nwork8 > ncu8 ? ncu8 : nwork8;        // persistent: one workgroup per CU
+    hipStream_t st8 = (hipStream_t)stream;
+    if (w.ncb) {
+        auto p0 = wino9_kernel<0>;
+        auto p1 = wino9_kernel<1>;
+        static bool c0 = false, c1 = false;
+        if (d->wmode) {
+            if (!c1) { (void)hipFuncSetAttribute((const void*)p1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); c1 = true; }
+            hipLaunchKernelGGL(p1, dim3(grid8), dim3(512), lds8, st8, w);
+        } else {
+            if (!c0) { (void)hipFuncSetAttribute((const void*)p0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); c0 = true; }
+            hipLaunchKernelGGL(p0, dim3(grid8), dim3(512), lds8, st8, w);
+        }
+        ASR_CHECK_LAUNCH("tap_gemm_wino9");
+        if (d->wmode) ASR_NOTE_KERNEL("wino9_kernel<1>"); else ASR_NOTE_KERNEL("wino9_kernel<0>");
+        return ASR_OK;
+    }
     auto q0 = wino8_kernel<0>;
     auto q1 = wino8_kernel<1>;
     static bool b0 = false, b1 = false;
-    hipStream_t st8 = (hipStream_t)stream;
     if (d->wmode) {
         if (!b1) { (void)hipFuncSetAttribute((const void*)q1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); b1 = true; }
         hipLaunchKernelGGL(q1, dim3(grid8), dim3(512), lds8, st8, w);

@@ -24,7 +24,12 @@ def conv_ref(x, w, b=None):
     return torch.from_numpy(y).to(x.device)
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 6, 5, 8, 64), (3, 4, 2, 16, 64), (2, 8, 12, 24, 128), (1, 16, 25, 32, 64), (5, 10, 7, 8, 192)])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 6, 5, 8, 64), (3, 4, 2, 16, 64), (2, 8, 12, 24, 128), (1, 16, 25, 32, 64), (5, 10, 7, 8, 192),
+                                            # column-blocked tile order (wino9_kernel: K % 16 == 0, tile columns split into blocks of
+                                            # 11..15): two blocks 13 + 12 with partly filled last items, one block of 14 / 15 / 11
+                                            # columns at odd and even widths, four blocks, many tile rows per block
+                                            (3, 20, 50, 64, 128), (2, 14, 27, 48, 64), (2, 30, 29, 32, 64), (1, 200, 22, 32, 64),
+                                            (2, 12, 100, 32, 64), (1, 6, 200, 32, 64)])
 def test_forward_matches_tap_gemm_and_float64(ops, B, H, W, cin, cout):
     g = torch.Generator(device='cuda').manual_seed(11)
     x = ops.Plane(B, H, W, cin); xi = torch.randn(B, H, W, cin, device='cuda', generator=g); x.set_interior(xi)
@@ -69,7 +74,7 @@ def test_fused_pool_equals_conv_then_pool_bitwise(ops, pool, B, H, W, cin, cout)
     assert y1.interior().abs().sum().item() > 0
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 6, 5, 64, 8), (1, 12, 25, 128, 32), (3, 4, 4, 64, 16)])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 6, 5, 64, 8), (1, 12, 25, 128, 32), (3, 4, 4, 64, 16), (2, 20, 50, 64, 64), (3, 10, 23, 128, 48)])
 def test_data_gradient_view_with_accumulation(ops, B, H, W, cin, cout):
     g = torch.Generator(device='cuda').manual_seed(12)
     w = torch.randn(3, 3, cin, cout, device='cuda', generator=g) * 0.1
