@@ -52,6 +52,11 @@ __device__ __forceinline__ int tap_weight_index(int tap) { return (NTAPS == 9 &&
 // the pixel row in the register, which makes the natural store 4 bytes per lane (two 128-byte rows per wave
 // instruction, 32 instructions per tile and tensor).  Each wave instead transposes its tile through a private
 // 32x33 LDS scratch and stores float4 rows: 4x fewer, 16-byte store instructions (+8 % on the conv kernels).
+// A use of a just-loaded channel constant on EVERY path: a tile whose rows are all outside the plane never reads them, hipcc's
+// wait-count pass then carries "load possibly in flight" to the top of a persistent kernel's next item, where the first write to the
+// same register costs an s_waitcnt vmcnt(0) -- which on this ISA also waits for every store of the epilogue.
+__device__ __forceinline__ void ep_touch(const float4& v) { asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+
 __device__ __forceinline__ float gate_pick(float y0, float y1, float y2, float y3, int k, float dp) {
     int arg = 0; float m = y0;                  // first maximum in row-major window order (TF's max-pool gradient)
     if (y1 > m) { m = y1; arg = 1; }
@@ -96,6 +101,7 @@ __device__ __forceinline__ void tap_epilogue_gated(const TapGemmArgs& g, const f
         const bool ncol = n < g.N;
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ncol) { sc = *(const float4*)(g.scale + n); sh = *(const float4*)(g.shift + n); }
+        ep_touch(sc); ep_touch(sh);
         float s_scale[4] = {0.f, 0.f, 0.f, 0.f}, s_shift[4] = {0.f, 0.f, 0.f, 0.f}, s_bias[4] = {0.f, 0.f, 0.f, 0.f};
         const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
@@ -194,6 +200,7 @@ __device__ __forceinline__ void tap_epilogue(const TapGemmArgs& g, const floatx1
             if (g.scale) sc = *(const float4*)(g.scale + n);
             if (g.shift) sh = *(const float4*)(g.shift + n);
         }
+        ep_touch(bs); ep_touch(sc); ep_touch(sh);
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
 #pragma unroll

@@ -213,10 +213,13 @@ __device__ __forceinline__ void wino8_chunk(const float* __restrict__ raw, const
 // The item tail shared by wino8_kernel and wino9_kernel: exchange of the column sums between the two halves, the lane-local inverse
 // transform, the fused pool and the epilogues.  rfree / ufree: the raw and the weight buffer set that no DMA is writing (8192
 // floats each).
-template <int XH>
+// `before_stores` runs after the exchange and before the first global store of the epilogues (wino9_kernel: the place where the
+// next item's DMA is waited for and its row tables are written).
+struct WinoNoHook { __device__ __forceinline__ void operator()() const {} };
+template <int XH, class Hook = WinoNoHook>
 __device__ __forceinline__ void wino_item_tail(const WinoArgs& args, floatx16 (&acc)[8], float* rfree, float* ufree, const int* rowa,
                                                const int* rowy, const int* prow, int wave, int lane, int wm, int wn, int n0, int blk,
-                                               float pool_bs, float pool_sc, float pool_sh) {
+                                               float pool_bs, float pool_sc, float pool_sh, Hook before_stores = Hook()) {
     const TapGemmArgs& g = args.g;
     // own column sums: m(r, j) = acc[r * 2 + j], transform column c = 2 XH + j
     floatx16 s0[2], s1[2];
@@ -247,6 +250,7 @@ __device__ __forceinline__ void wino_item_tail(const WinoArgs& args, floatx16 (&
         out[1][0][r] = (c1 - c2) - c3;
     }
     lds_barrier();                               // every wave has read its partner's values: the weight set becomes scratch
+    before_stores();
     if (args.pool_y) {
         // Fused 2x2 pool (a Winograd tile IS a pooling window): this wave holds pixels (XH, 0) and (XH, 1) of its tiles as
         // out[0] / out[1], lane = output channel.  BN(ReLU(x + bias)) and the row's pair lane-locally, then half 1 hands its
@@ -605,13 +609,46 @@ __device__ __forceinline__ void wino9_phase_b(const Wino9Pre<R>& pf, bool slots,
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// row tables of one item (threads 0..255: 64 tiles x 4 pixels): plane row of every output pixel for out_a / out_y, and the row of
+// the tile's pooled pixel
+__device__ __forceinline__ void wino9_tables(const WinoArgs& args, const Wino9Geo& e, int tid, int* rowa, int* rowy, int* prow) {
+    const TapGemmArgs& g = args.g;
+    if (tid < 256) {
+        const int tl = tid & 63, pl = tid >> 6;
+        const int l = e.l0 + tl;
+        const int ti = l / e.w, tj = e.tj0 + l - ti * e.w;
+        int ra_ = -1, ry = -1;
+        if (ti < args.TH) {
+            const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
+            if (ww <= g.Wd) {
+                ra_ = (int)((long)e.b * g.HPWP + (long)hh * g.WP + ww);
+                ry = g.y_unpadded ? ((e.b * g.H + hh - 1) * g.Wd + ww - 1) : ra_;
+            }
+        }
+        const int m = (tl >> 5) * 128 + pl * 32 + (tl & 31);
+        rowa[m] = ra_; rowy[m] = ry;
+        if (pl == 0) {
+            int pr = -1;
+            if (args.pool_y && ti < args.TH && tj < args.W2 && ti < args.H2) pr = (e.b * (args.H2 + 1) + ti + 1) * (args.W2 + 1) + tj + 1;
+            prow[tl] = pr;
+        }
+    }
+}
+
+// Item flow: [chunks of item i, the last ones prefetching item i + 1] -> exchange of the halves -> WAIT for the prefetched DMA (no
+// store is in flight at that point, so the wait is for the DMA alone) -> row tables of item i + 1 (second table set) -> epilogue
+// stores of item i -> one LDS-only barrier -> chunks of item i + 1.  Nothing waits for the stores until the first chunk barrier of
+// the next item (vmcnt counts loads and stores together on this ISA), so they drain behind a chunk of MFMA work: every workgroup
+// runs items of the same length from the same start, the stores of all 256 CUs come in one burst, and before this order every
+// wave sat out the burst at the top of the next item.
 template <int XH>
 __device__ __forceinline__ void wino9_body(const WinoArgs& args, float* smem) {
     const TapGemmArgs& g = args.g;
-    int* rowa = (int*)smem;                          // [2 wave rows][4 pixels][32 tiles]
-    int* rowy = rowa + 256;
-    int* prow = rowy + 256;                          // [64 tiles]: row of the tile's pooled pixel (fused 2x2 pool), or -1
-    float* bufs = smem + 576;                        // raw0 | raw1 | u0 | u1
+    int* tables = (int*)smem;                        // two sets of [rowa 256 | rowy 256 | prow 64]
+    float* bufs = smem + 2 * 576;                    // raw0 | raw1 | u0 | u1
+    float* pconst = bufs + 2 * RAW_F + 2 * U_F;      // fused pool: [bias N | scale N | shift N] (read per item without a vector
+                                                     // memory load: a load in the item loop makes hipcc wait for vmcnt(0) -- i.e. for the
+                                                     // previous item's stores -- at the top of every item)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = (wave >> 1) & 1, wn = wave & 1;                       // wave = xh * 4 + wm * 2 + wn
@@ -632,7 +669,7 @@ __device__ __forceinline__ void wino9_body(const WinoArgs& args, float* smem) {
     auto ru = __builtin_amdgcn_make_buffer_rsrc((void*)args.Ut, 0, 0x7FFFFFF0, 0x00020000);
     Wino9Dma<decltype(ra)> q;
     q.ra = ra; q.ru = ru; q.wave = wave; q.rowbytes = g.WP * g.lda * 4; q.N = g.N; q.ustride_xi = (long)g.K * g.N;
-    int rcur = 0, ucur = 0;                          // raw set of the current super-chunk, weight set of the current chunk
+    int rcur = 0, ucur = 0, tcur = 0;                // raw set of the current super-chunk, weight set of the current chunk, table set
     {
         const int it = item_of(w);
         const Wino9Geo e = wino9_geo(args, it / nnb);
@@ -640,6 +677,15 @@ __device__ __forceinline__ void wino9_body(const WinoArgs& args, float* smem) {
         q.off_u = wino9_u_offset(args, (it % nnb) * WC, lane);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { wino9_raw_piece(q, bufs, j, 0); wino9_u_piece(q, bufs + 2 * RAW_F, j, 0); }
+        wino9_tables(args, e, tid, tables, tables + 256, tables + 512);
+        if (args.pool_y)
+            for (int n = tid; n < g.N; n += 512) {
+                pconst[n] = g.bias ? g.bias[n] : 0.f;
+                pconst[g.N + n] = g.scale ? g.scale[n] : 1.f;
+                pconst[2 * g.N + n] = g.shift ? g.shift[n] : 0.f;
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first super-chunk and chunk 0 of the first item
+        lds_barrier();
     }
 
     for (; w < nwork; w += gridDim.x) {
@@ -647,26 +693,9 @@ __device__ __forceinline__ void wino9_body(const WinoArgs& args, float* smem) {
         const int blk = item / nnb, nb = item - blk * nnb;
         const Wino9Geo e = wino9_geo(args, blk);
         const int n0 = nb * WC;
-        if (tid < 256) {
-            const int tl = tid & 63, pl = tid >> 6;      // 64 tiles x 4 pixels = 256 entries
-            const int l = e.l0 + tl;
-            const int ti = l / e.w, tj = e.tj0 + l - ti * e.w;
-            int ra_ = -1, ry = -1;
-            if (ti < args.TH) {
-                const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
-                if (ww <= g.Wd) {
-                    ra_ = (int)((long)e.b * g.HPWP + (long)hh * g.WP + ww);
-                    ry = g.y_unpadded ? ((e.b * g.H + hh - 1) * g.Wd + ww - 1) : ra_;
-                }
-            }
-            const int m = (tl >> 5) * 128 + pl * 32 + (tl & 31);
-            rowa[m] = ra_; rowy[m] = ry;
-            if (pl == 0) {
-                int pr = -1;
-                if (args.pool_y && ti < args.TH && tj < args.W2 && ti < args.H2) pr = (e.b * (args.H2 + 1) + ti + 1) * (args.W2 + 1) + tj + 1;
-                prow[tl] = pr;
-            }
-        }
+        int* rowa = tables + tcur * 576;
+        int* rowy = rowa + 256;
+        int* prow = rowy + 256;
         // LDS byte offsets of this lane's patch pixels inside a raw set: tile l of the block, its row relative to the region
         unsigned lb[4];
         {
@@ -676,13 +705,6 @@ __device__ __forceinline__ void wino9_body(const WinoArgs& args, float* smem) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) lb[j] = fix + (unsigned)(((l + (j >> 1) * e.w + (j & 1)) & 15) * 16);
         }
-        const int pool_n = n0 + wn * 32 + li;
-        float pool_bs = 0.f, pool_sc = 1.f, pool_sh = 0.f;
-        if (args.pool_y && pool_n < g.N) {
-            if (g.bias) pool_bs = g.bias[pool_n];
-            if (g.scale) pool_sc = g.scale[pool_n];
-            if (g.shift) pool_sh = g.shift[pool_n];
-        }
         floatx16 acc[8];
         Wino9Regs rg;
 #pragma unroll
@@ -690,8 +712,6 @@ __device__ __forceinline__ void wino9_body(const WinoArgs& args, float* smem) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-        __builtin_amdgcn_s_waitcnt(0x0F70);          // the first super-chunk and chunk 0 of this item have landed
-        __syncthreads();
         const int wnext = w + gridDim.x;
         const bool more = wnext < nwork;
         const int itn = more ? item_of(wnext) : 0;
@@ -707,7 +727,7 @@ __device__ __forceinline__ void wino9_body(const WinoArgs& args, float* smem) {
             pf.rawn = bufs + (rcur ^ 1) * RAW_F; pf.ubn = bufs + 2 * RAW_F + (ucur ^ 1) * U_F; pf.q = &q;
             wino9_phase_a<XH>(bufs + rcur * RAW_F, bufs + 2 * RAW_F + ucur * U_F, pf, true, hh, lb, boff, acc, rg);
             wino9_phase_b(pf, false, acc, rg);
-            // the weight pieces of the next chunk must have landed; the four raw pieces issued AFTER them in this interval may stay
+            // the weight pieces of the next chunk must have landed; the four raw pieces issued AFTER them in this chunk may stay
             // in flight until the barrier of the super-chunk's second chunk
             // (the barrier as plain instructions: a fence on the local address space makes hipcc wait for every DMA in flight)
 #if defined(WINO_ABL) && (WINO_ABL & 16)
@@ -720,6 +740,15 @@ __device__ __forceinline__ void wino9_body(const WinoArgs& args, float* smem) {
             ucur ^= 1;
             rcur ^= hh;
         }
+        // fused pool: this lane's channel constants (from LDS: not live across the chunk loop, no vector memory load in the loop)
+        const int pool_n = n0 + wn * 32 + li;
+        float pool_bs = 0.f, pool_sc = 1.f, pool_sh = 0.f;
+        if (args.pool_y && pool_n < g.N) { pool_bs = pconst[pool_n]; pool_sc = pconst[g.N + pool_n]; pool_sh = pconst[2 * g.N + pool_n]; }
+        auto before_stores = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next item's first super-chunk / chunk 0
+            if (more) wino9_tables(args, wino9_geo(args, itn / nnb), tid, tables + (tcur ^ 1) * 576, tables + (tcur ^ 1) * 576 + 256,
+                                   tables + (tcur ^ 1) * 576 + 512);
+        };
 #if defined(WINO_ABL) && (WINO_ABL & 32)
         { float sink = 0.f;
 #pragma unroll
@@ -727,11 +756,13 @@ __device__ __forceinline__ void wino9_body(const WinoArgs& args, float* smem) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) sink += acc[i][r];
           if (sink == 123.456f) rowa[0] = 1; }
+        before_stores();
 #else
         wino_item_tail<XH>(args, acc, bufs + (rcur ^ 1) * RAW_F, bufs + 2 * RAW_F + (ucur ^ 1) * U_F, rowa, rowy, prow, wave, lane, wm, wn, n0,
-                           blk, pool_bs, pool_sc, pool_sh);
+                           blk, pool_bs, pool_sc, pool_sh, before_stores);
 #endif
-        lds_barrier();                               // row tables and the free buffer sets are reused by the next item
+        lds_barrier();               // the scratch sets and this item's tables are free, the next item's tables and DMA'd data visible
+        tcur ^= 1;
     }
 }
 #endif
@@ -803,7 +834,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     w.pool_y = pool_y; w.pool_mode = pool_mode; w.H2 = d->H / 2; w.W2 = d->W / 2;
     // column-blocked tile order (wino9_kernel) when the tile columns split into blocks of 11..15 and K is a multiple of 16
     w.ncb = 0;
-    if (d->K % 16 == 0 && d->K >= 32) {
+    if (d->K % 16 == 0 && d->K >= 32 && (!pool_y || d->N <= 2048)) {      // (the pool constants of all N channels sit in LDS)
         for (int nb = asr_cdiv(w.TW, 15); nb <= 8 && nb * 11 <= w.TW; ++nb) {
             if (asr_cdiv(w.TW, nb) > 15) continue;
             w.ncb = nb;
@@ -821,6 +852,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     a.ntm = nblk; a.ntn = d->N / WC;
     if (a.gate_rows) *a.gate_rows = nblk * 4;
     const size_t lds8 = (size_t)(576 + 2 * RAW_F + 2 * U_F) * sizeof(float);
+    const size_t lds9 = lds8 + (576 + (pool_y ? 3 * (size_t)d->N : 0)) * sizeof(float);      // wino9_kernel: two sets of row tables, pool constants
     static_assert(4 * 2048 <= RAW_F && 4 * 2048 <= U_F && 4 * 32 * 33 + 2 * 1024 <= RAW_F && 4 * 32 * 33 + 2 * 1024 <= U_F, "exchange / scratch + pool hand-over must fit in one buffer set");
     static int ncu8 = 0;
     if (!ncu8) {
@@ -835,11 +867,11 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
         auto p1 = wino9_kernel<1>;
         static bool c0 = false, c1 = false;
         if (d->wmode) {
-            if (!c1) { (void)hipFuncSetAttribute((const void*)p1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); c1 = true; }
-            hipLaunchKernelGGL(p1, dim3(grid8), dim3(512), lds8, st8, w);
+            if (!c1) { (void)hipFuncSetAttribute((const void*)p1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); c1 = true; }
+            hipLaunchKernelGGL(p1, dim3(grid8), dim3(512), lds9, st8, w);
         } else {
-            if (!c0) { (void)hipFuncSetAttribute((const void*)p0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); c0 = true; }
-            hipLaunchKernelGGL(p0, dim3(grid8), dim3(512), lds8, st8, w);
+            if (!c0) { (void)hipFuncSetAttribute((const void*)p0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); c0 = true; }
+            hipLaunchKernelGGL(p0, dim3(grid8), dim3(512), lds9, st8, w);
         }
         ASR_CHECK_LAUNCH("tap_gemm_wino9");
         if (d->wmode) ASR_NOTE_KERNEL("wino9_kernel<1>"); else ASR_NOTE_KERNEL("wino9_kernel<0>");
