@@ -759,8 +759,16 @@ int launch_wgrad6(WgradArgs a, const asr_gemm_desc* d, float* dW, float* partial
 bool asr_wgrad1_eligible(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz);
 int asr_wgrad1_launch(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz, float* out, int pch, int nchunks, void* stream);
 
+size_t asr_wino_wgrad_workspace(const asr_gemm_desc* d, int ldz);
+int asr_wino_wgrad_launch(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz, float* dW, float* partials, void* stream);
+
+static size_t direct_wgrad_workspace(const asr_gemm_desc* d);
 extern "C" size_t asr_tap_wgrad_workspace(const asr_gemm_desc* d) {
     if (!d) return 0;
+    const size_t a = direct_wgrad_workspace(d), b = d->ntaps == 9 ? asr_wino_wgrad_workspace(d, d->N) : 0;
+    return a > b ? a : b;
+}
+static size_t direct_wgrad_workspace(const asr_gemm_desc* d) {
     const Plan p = make_plan(d), q = make_plan(d, 1024, 128);  // q: an upper bound on the chunks of any variant
     int nc = p.nchunks > q.nchunks ? p.nchunks : q.nchunks;
     if (d->ntaps == 9) {                                       // the LDS-DMA variant plans its own (shorter) runs
@@ -782,6 +790,12 @@ extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float
     if ((d->K & 3) || (d->N & 3) || (d->lda & 3) || (ldz & 3)) return ASR_ERR_BAD_ARG;
     if (d->ntaps != 1 && d->H <= 0) return ASR_ERR_BAD_ARG;
     if (d->ntaps == 4 && (d->K & 255)) return ASR_ERR_UNSUPPORTED;      // phase blocks of K/4 channels, whole 32-wide k-tiles
+    // 3x3 layers with 32 or a multiple of 64 input channels and a multiple of 64 output channels: Winograd F(3x3, 2x2),
+    // wino_wgrad.hip (16 instead of 36 multiplies per tile and channel pair); ASR_ERR_UNSUPPORTED = not that shape
+    if (d->ntaps == 9 && partials) {
+        const int rw = asr_wino_wgrad_launch(d, A, dZ, ldz, dW, partials, stream);
+        if (rw != ASR_ERR_UNSUPPORTED) return rw;
+    }
     const Plan p = make_plan(d);
     if (p.nchunks > 1 && !partials) return ASR_ERR_BAD_ARG;
     WgradArgs a;

@@ -1,0 +1,390 @@
+// Weight gradient of the 3x3 convolutions by Winograd F(3x3, 2x2) on the fp32 MFMA pipe (round 3): per 2x2 tile of the output
+// gradient, input channel and output channel 16 multiplies instead of 36, still fp32.
+//
+//   dW = A'^T [ sum_tiles (G' dy G'^T) (.) (B^T d B) ] A'        d  = 4x4 input patch of the tile (the forward's patch, wino.hip)
+//                                                                 dy = its 2x2 output-gradient pixels
+//   B^T = the forward's input transform, G' = [[1,0],[1,1],[1,-1],[0,1]] (the halves of G moved into A'),
+//   A'^T = [[1,.5,.5,0],[0,.5,-.5,0],[0,.5,.5,-1]]
+//
+// One GEMM per transform position xi = 0..15 with the TILES as the contraction index:
+//   M_xi[ci][co] = sum_tile V_xi[tile][ci] * Z_xi[tile][co]
+// v_mfma_f32_32x32x2_f32 contracts two tiles per instruction: lane (l % 32, l / 32) supplies the A value of input channel
+// l % 32 and the B value of output channel l % 32 for tile l / 32 of the pair -- so BOTH transforms are lane-local with the
+// channel on the lane and the pixels in registers, and the planes' own [pixel][channel] layout is what LDS holds (rows of
+// 128 / 256 contiguous bytes per pixel: every DMA piece is whole lines, every ds_read_b32 of a half-wave 128 contiguous bytes).
+// There is no per-item tail: a workgroup owns a 64 (or 32) x 64 block of (ci, co) pairs for all sixteen positions -- the whole
+// register file of the CU as in the forward kernel -- walks its share of the tiles and writes its accumulators ONCE, as a partial
+// [16][ci][co]; wino_wgrad_reduce_kernel adds the partials in a fixed order (deterministic) and applies A'^T . A'.
+//
+// Work: the tile columns of an image are cut into blocks of <= 13 columns (as in wino9_kernel); a STAGE is two tile rows of one
+// block = 2 w tiles = w tile pairs.  Its input region (6 pixel rows x (2 w + 2) pixels) and gradient region (4 x 2 w pixels) arrive
+// by buffer-form LDS-DMA in two buffer sets, one barrier per stage; pixels outside the plane are sent out of the buffer's range and
+// read zeros.  Eight waves: wave = xh * 4 + a * 2 + wn; xh owns transform columns 2 xh, 2 xh + 1 (8 accumulators), wn the 32-wide
+// half of the 64 output channels, a the 32-wide half of 64 input channels (CINB = 64) or, for 32 input channels (CINB = 32), every
+// other tile pair (two partials per workgroup).  Two tile pairs are transformed together with packed adds.
+#include "asr_common.h"
+#include <stdint.h>
+
+namespace {
+
+typedef __attribute__((address_space(3))) float ww_lds_f;
+typedef float ww_f2 __attribute__((ext_vector_type(2)));
+
+constexpr int WW_MAXW = 13;          // tile columns of a column block
+constexpr int WW_ZP = 28;            // pixel pitch of a staged gradient row (2 w <= 26)
+
+template <int CINB> struct WwCfg {
+    static constexpr int XP = CINB == 64 ? 28 : 32;             // pixel pitch of a staged input row (2 w + 2 <= 28), whole pieces
+    static constexpr int XPX = 1024 / (CINB * 4);               // pixels per 1 KB piece
+    static constexpr int XPPR = XP / XPX;                       // pieces per input row
+    static constexpr int NXP = 6 * XPPR;                        // input pieces per stage
+    static constexpr int NZP = 4 * (WW_ZP / 4);                 // gradient pieces per stage (4 pixels x 64 channels each)
+    static constexpr int XF = 6 * XP * CINB;                    // floats of the input region
+    static constexpr int ZF = 4 * WW_ZP * 64;
+    static constexpr int SETF = XF + ZF;
+};
+
+struct WwArgs {
+    const float* A; const float* Z; float* part;
+    int K, N, lda, ldz, B, H, Wd, WP, HPWP;
+    int SR;                  // stage rows per image = ceil(TH / 2)
+    int ncb; int cb_tj0[8]; int cb_w[8];
+    int nstages, nsl, nbp, ncob;   // stages in all, slices (workgroups per block pair), block pairs, output-channel blocks (N / 64)
+};
+
+__device__ __forceinline__ void ww_barrier_dma() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void ww_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#if __HIP_DEVICE_COMPILE__
+struct WwStage { int b, row0, tj0, w; };
+
+__device__ __forceinline__ WwStage ww_stage(const WwArgs& a, int g) {
+    WwStage s;
+    const int per = a.SR * a.ncb;
+    s.b = g / per;
+    const int rem = g - s.b * per;
+    const int sr = rem / a.ncb, cb = rem - sr * a.ncb;
+    s.row0 = 4 * sr;                 // first padded pixel row of the input region; the gradient region starts one row lower
+    s.tj0 = a.cb_tj0[cb]; s.w = a.cb_w[cb];
+    return s;
+}
+
+// DMA piece j (pieces wave + 8 j) of stage s into buffer set `set`
+template <int CINB, class R>
+__device__ __forceinline__ void ww_piece(const WwArgs& a, const WwStage& s, R rx, R rz, float* __restrict__ set, int wave, int j, int cin0,
+                                         int co0, unsigned vox, unsigned voz, int pxx, int pxz) {
+    typedef WwCfg<CINB> C;
+    const int p = wave + 8 * j;
+    if (p < C::NXP) {
+        const int r = p / C::XPPR, pc = p - r * C::XPPR;
+        const int row = s.row0 + r, col0 = 2 * s.tj0 + pc * C::XPX;
+        int lim = 2 * s.w + 2 - pc * C::XPX;                      // pixels of this piece inside the region ...
+        const int limp = a.Wd + 1 - col0;                         // ... and inside the plane (columns 0 .. W)
+        if (limp < lim) lim = limp;
+        if (row > a.H) lim = 0;
+        const unsigned v = pxx < lim ? vox : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (ww_lds_f*)(set + p * 256), 16, v,
+                                                 (int)(unsigned)((((long)s.b * a.HPWP + (long)row * a.WP + col0) * a.lda + cin0) * 4), 0, 0);
+    } else if (p < C::NXP + C::NZP) {
+        const int q = p - C::NXP;
+        const int r = q / (WW_ZP / 4), pc = q - r * (WW_ZP / 4);
+        const int row = s.row0 + 1 + r, col0 = 2 * s.tj0 + 1 + pc * 4;
+        int lim = 2 * s.w - pc * 4;
+        const int limp = a.Wd + 1 - col0;
+        if (limp < lim) lim = limp;
+        if (row > a.H) lim = 0;
+        const unsigned v = pxz < lim ? voz : 0xFFFFFFF0u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (ww_lds_f*)(set + C::XF + q * 256), 16, v,
+                                                 (int)(unsigned)((((long)s.b * a.HPWP + (long)row * a.WP + col0) * a.ldz + co0) * 4), 0, 0);
+    }
+}
+
+// input transform of two tile pairs at once: d[r * 3 + c] = patch pixel (r, XH + c), .x / .y the two pairs
+template <int XH>
+__device__ __forceinline__ void ww_transform_x(const ww_f2 (&d)[12], ww_f2 (&v)[8]) {
+    ww_f2 t[4][3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const ww_f2 d0 = d[0 + c], d1 = d[3 + c], d2 = d[6 + c], d3 = d[9 + c];
+        t[0][c] = d0 - d2; t[1][c] = d1 + d2; t[2][c] = d2 - d1; t[3][c] = d1 - d3;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (XH == 0) { v[r * 2 + 0] = t[r][0] - t[r][2]; v[r * 2 + 1] = t[r][1] + t[r][2]; }
+        else         { v[r * 2 + 0] = t[r][1] - t[r][0]; v[r * 2 + 1] = t[r][0] - t[r][2]; }
+    }
+}
+// gradient transform G' y G'^T, transform columns 2 XH and 2 XH + 1: y[a * 2 + b] = pixel (a, b)
+template <int XH>
+__device__ __forceinline__ void ww_transform_z(const ww_f2 (&y)[4], ww_f2 (&z)[8]) {
+    ww_f2 yr[4][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) { yr[0][b] = y[b]; yr[1][b] = y[b] + y[2 + b]; yr[2][b] = y[b] - y[2 + b]; yr[3][b] = y[2 + b]; }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        if (XH == 0) { z[r * 2 + 0] = yr[r][0]; z[r * 2 + 1] = yr[r][0] + yr[r][1]; }
+        else         { z[r * 2 + 0] = yr[r][0] - yr[r][1]; z[r * 2 + 1] = yr[r][1]; }
+    }
+}
+
+// One stage out of (xs, zs); the pieces of the next stage go into `nxt` between the MFMAs.  __restrict__ parameters of an inlined
+// function on purpose: without the alias scopes hipcc orders every LDS read behind the DMA in flight (s_waitcnt vmcnt(0)).
+template <int XH, int CINB, class R>
+__device__ __forceinline__ void ww_compute(const WwArgs& a, const char* __restrict__ xs, const char* __restrict__ zs, float* __restrict__ nxt,
+                                           const WwStage& sn, bool more, R rx, R rz, int w, int wave, int wa, int lh, int xch, int zch,
+                                           int cin0, int co0, unsigned vox, unsigned voz, int pxx, int pxz, floatx16 (&acc)[8]) {
+    typedef WwCfg<CINB> C;
+    constexpr int NJ = (C::NXP + C::NZP + 7) / 8;     // piece rounds per stage
+    // tile pairs of this wave: CINB 64: all of them, two per step; CINB 32: pairs wa, wa + 2, ... (two per step: wa + 4 i, wa + 4 i + 2)
+    const int kp0 = CINB == 64 ? 0 : wa, kstep = CINB == 64 ? 1 : 2;
+    int jn = 0;
+    for (int kp = kp0; kp < w; kp += 2 * kstep) {
+        const bool two = kp + kstep < w;
+        // tile of this lane's half in each pair, its region offsets
+        const int tA = 2 * kp + lh, tB = 2 * (kp + kstep) + lh;
+        const int trA = tA >= w ? 1 : 0, trB = (two && tB >= w) ? 1 : 0;
+        const int tcA = tA - trA * w, tcB = two ? tB - trB * w : 0;
+        const int xa = ((2 * trA) * C::XP + 2 * tcA) * CINB * 4 + xch, xb = ((2 * trB) * C::XP + 2 * tcB) * CINB * 4 + xch;
+        const int za = ((2 * trA) * WW_ZP + 2 * tcA) * 256 + zch, zb = ((2 * trB) * WW_ZP + 2 * tcB) * 256 + zch;
+        ww_f2 d[12], y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int off = (r * C::XP + XH + c) * CINB * 4;
+                d[r * 3 + c] = ww_f2{*(const float*)(xs + xa + off), *(const float*)(xs + xb + off)};
+            }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int off = ((p >> 1) * WW_ZP + (p & 1)) * 256;
+            y[p] = ww_f2{*(const float*)(zs + za + off), *(const float*)(zs + zb + off)};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ww_f2 v[8], z[8];
+        ww_transform_x<XH>(d, v);
+        ww_transform_z<XH>(y, z);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i].x, z[i].x, acc[i], 0, 0, 0);
+            if (i == 3 || i == 7) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && jn < NJ) ww_piece<CINB>(a, sn, rx, rz, nxt, wave, jn, cin0, co0, vox, voz, pxx, pxz);
+                ++jn;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (two) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i].y, z[i].y, acc[i], 0, 0, 0);
+                if (i == 3 || i == 7) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more && jn < NJ) ww_piece<CINB>(a, sn, rx, rz, nxt, wave, jn, cin0, co0, vox, voz, pxx, pxz);
+                    ++jn;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    // pieces the loop had no slot for (narrow blocks)
+    if (more) for (; jn < NJ; ++jn) ww_piece<CINB>(a, sn, rx, rz, nxt, wave, jn, cin0, co0, vox, voz, pxx, pxz);
+}
+
+template <int XH, int CINB>
+__device__ __forceinline__ void ww_body(const WwArgs& a, float* smem) {
+    typedef WwCfg<CINB> C;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wa = (wave >> 1) & 1, wn = wave & 1;
+    // workgroup -> (block pair, slice): workgroups of one slice differ by multiples of 8 (the same XCD: they read the same pixels)
+    const int wg = blockIdx.x;
+    const int sl_lo = wg & 7, rest = wg >> 3;
+    const int bp = rest % a.nbp, sl = (rest / a.nbp) * 8 + sl_lo;
+    if (sl >= a.nsl) return;
+    const int cib = bp / a.ncob, cob = bp - cib * a.ncob;
+    const int cin0 = cib * CINB, co0 = cob * 64;
+
+    auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, 0x7FFFFFF0, 0x00020000);
+    auto rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.Z, 0, 0x7FFFFFF0, 0x00020000);
+    // per-lane part of a piece's offsets: pixel of the piece, 16-byte chunk of the channel block
+    constexpr int LPPX = CINB / 4;
+    const int pxx = lane / LPPX, pxz = lane >> 4;
+    const unsigned vox = (unsigned)((pxx * a.lda + (lane % LPPX) * 4) * 4);
+    const unsigned voz = (unsigned)((pxz * a.ldz + (lane & 15) * 4) * 4);
+    constexpr int NJ = (C::NXP + C::NZP + 7) / 8;
+
+    floatx16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    int g = sl;
+    {
+        const WwStage s = ww_stage(a, g);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) ww_piece<CINB>(a, s, rx, rz, smem, wave, j, cin0, co0, vox, voz, pxx, pxz);
+    }
+    int cur = 0;
+    const int xch = ((CINB == 64 ? wa * 32 : 0) + li) * 4;      // byte offset of this lane's input channel inside a pixel
+    const int zch = (wn * 32 + li) * 4;
+    for (; g < a.nstages; g += a.nsl) {
+        const WwStage s = ww_stage(a, g);
+        const int gn = g + a.nsl;
+        const bool more = gn < a.nstages;
+        WwStage sn = s;
+        if (more) sn = ww_stage(a, gn);
+        ww_barrier_dma();                            // this stage has landed; nobody reads the other set any more
+        const char* xs = (const char*)(smem + cur * C::SETF);
+        ww_compute<XH, CINB>(a, xs, xs + C::XF * 4, smem + (cur ^ 1) * C::SETF, sn, more, rx, rz, s.w, wave, wa, lh, xch, zch, cin0, co0,
+                             vox, voz, pxx, pxz, acc);
+        cur ^= 1;
+    }
+    // partial of this workgroup (CINB 32: one per tile-pair parity): [16][CINB][64]; acc[r * 2 + j] = position r * 4 + 2 XH + j,
+    // register = input channel, lane = output channel
+    const int nth = CINB == 64 ? 1 : 2;
+    float* P = a.part + ((long)(sl * a.nbp + bp) * nth + (CINB == 64 ? 0 : wa)) * 16 * CINB * 64;
+    const int ci0 = CINB == 64 ? wa * 32 : 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int xi = (i >> 1) * 4 + 2 * XH + (i & 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            P[((long)xi * CINB + ci) * 64 + wn * 32 + li] = acc[i][r];
+        }
+    }
+}
+#endif
+
+template <int CINB>
+__global__ __launch_bounds__(512) void wino_wgrad_kernel(WwArgs a) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((threadIdx.x >> 8) == 0) ww_body<0, CINB>(a, smem);
+    else ww_body<1, CINB>(a, smem);
+#endif
+}
+
+// dW[kh][kw][k][n] = A'^T (sum over the partials of M[.][k][n]) A', partials in ascending order
+__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int K, int N, int cinb, int nparts,
+                                         int nbp, int ncob) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)K * N) return;
+    const int k = (int)(i / N), n = (int)(i - (long)k * N);
+    const int cib = k / cinb, ci = k - cib * cinb, cob = n >> 6, co = n & 63;
+    const int bp = cib * ncob + cob;
+    const int nth = cinb == 64 ? 1 : 2;
+    const long pstride = (long)16 * cinb * 64;
+    float m[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) m[x] = 0.f;
+    for (int p = 0; p < nparts; ++p) {
+        for (int t = 0; t < nth; ++t) {
+            const float* q = part + ((long)(p * nbp + bp) * nth + t) * pstride + (long)ci * 64 + co;
+#pragma unroll
+            for (int x = 0; x < 16; ++x) m[x] += q[(long)x * cinb * 64];
+        }
+    }
+    // rows: t[kh][c] = A'^T m[.][c]
+    float t[3][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float m0 = m[0 * 4 + c], m1 = m[1 * 4 + c], m2 = m[2 * 4 + c], m3 = m[3 * 4 + c];
+        t[0][c] = m0 + 0.5f * (m1 + m2);
+        t[1][c] = 0.5f * (m1 - m2);
+        t[2][c] = 0.5f * (m1 + m2) - m3;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const float w0 = t[kh][0] + 0.5f * (t[kh][1] + t[kh][2]);
+        const float w1 = 0.5f * (t[kh][1] - t[kh][2]);
+        const float w2 = 0.5f * (t[kh][1] + t[kh][2]) - t[kh][3];
+        dW[((long)(kh * 3 + 0) * K + k) * N + n] = w0;
+        dW[((long)(kh * 3 + 1) * K + k) * N + n] = w1;
+        dW[((long)(kh * 3 + 2) * K + k) * N + n] = w2;
+    }
+}
+
+struct WwPlan { bool ok; int cinb, ncb, cbw[8], cbt[8], SR, nstages, nbp, ncob, nsl, nparts; size_t ws; };
+
+WwPlan ww_plan(const asr_gemm_desc* d, int ldz) {
+    WwPlan p;
+    p.ok = false; p.ws = 0;
+    if (!d || d->ntaps != 9 || d->wmode != 0 || d->H < 2 || d->W < 2 || (d->H & 1)) return p;
+    if (d->K != 32 && (d->K % 64) != 0) return p;
+    if ((d->N % 64) != 0 || (d->lda & 3) || (ldz & 3) || d->M != d->B * (d->H + 1) * (d->W + 1)) return p;
+    if ((long)d->M * d->lda * 4 >= 0x7FFFFFF0L || (long)d->M * ldz * 4 >= 0x7FFFFFF0L) return p;
+    const int TH = d->H / 2, TW = (d->W + 1) / 2;
+    p.cinb = d->K == 32 ? 32 : 64;
+    p.ncb = asr_cdiv(TW, WW_MAXW);
+    if (p.ncb > 8) return p;
+    int tj = 0;
+    for (int c = 0; c < p.ncb; ++c) {
+        p.cbw[c] = TW / p.ncb + (c < TW % p.ncb ? 1 : 0);
+        p.cbt[c] = tj; tj += p.cbw[c];
+    }
+    p.SR = asr_cdiv(TH, 2);
+    p.nstages = d->B * p.SR * p.ncb;
+    p.ncob = d->N / 64;
+    p.nbp = (d->K / p.cinb) * p.ncob;
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    // enough work per workgroup to amortise the partial it writes: at least 8 stages
+    int nsl = ncu / p.nbp;
+    if (nsl < 1) nsl = 1;
+    if (nsl > p.nstages / 8) nsl = p.nstages / 8;
+    if (nsl < 1) return p;                       // too small a problem: the direct kernels
+    p.nsl = nsl;
+    p.nparts = nsl;
+    p.ws = (size_t)nsl * p.nbp * (p.cinb == 64 ? 1 : 2) * 16 * p.cinb * 64 * sizeof(float);
+    p.ok = true;
+    return p;
+}
+
+}  // namespace
+
+size_t asr_wino_wgrad_workspace(const asr_gemm_desc* d, int ldz) {      // (plain C++ linkage: used by tap_wgrad.hip only)
+    const WwPlan p = ww_plan(d, ldz);
+    return p.ok ? p.ws : 0;
+}
+
+// ASR_OK when the Winograd weight gradient ran; ASR_ERR_UNSUPPORTED when the caller should use the direct kernels
+int asr_wino_wgrad_launch(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz, float* dW, float* partials, void* stream) {
+    const WwPlan p = ww_plan(d, ldz);
+    if (!p.ok || !partials || ((((uintptr_t)A) | ((uintptr_t)dZ) | ((uintptr_t)partials)) & 15)) return ASR_ERR_UNSUPPORTED;
+    WwArgs a;
+    a.A = A; a.Z = dZ; a.part = partials;
+    a.K = d->K; a.N = d->N; a.lda = d->lda; a.ldz = ldz; a.B = d->B; a.H = d->H; a.Wd = d->W; a.WP = d->W + 1; a.HPWP = (d->H + 1) * (d->W + 1);
+    a.SR = p.SR; a.ncb = p.ncb;
+    for (int c = 0; c < 8; ++c) { a.cb_tj0[c] = c < p.ncb ? p.cbt[c] : 0; a.cb_w[c] = c < p.ncb ? p.cbw[c] : 0; }
+    a.nstages = p.nstages; a.nsl = p.nsl; a.nbp = p.nbp; a.ncob = p.ncob;
+    // grid: slices rounded up to whole groups of 8, times block pairs (see ww_body)
+    const int grid = asr_cdiv(p.nsl, 8) * 8 * p.nbp;
+    hipStream_t st = (hipStream_t)stream;
+    if (p.cinb == 64) {
+        const size_t lds = (size_t)2 * WwCfg<64>::SETF * sizeof(float);
+        static bool s64 = false;
+        auto k = wino_wgrad_kernel<64>;
+        if (!s64) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); s64 = true; }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
+        ASR_NOTE_KERNEL("wino_wgrad_kernel<64>");
+    } else {
+        const size_t lds = (size_t)2 * WwCfg<32>::SETF * sizeof(float);
+        static bool s32 = false;
+        auto k = wino_wgrad_kernel<32>;
+        if (!s32) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); s32 = true; }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
+        ASR_NOTE_KERNEL("wino_wgrad_kernel<32>");
+    }
+    ASR_CHECK_LAUNCH("wino_wgrad");
+    const long total = (long)d->K * d->N;
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(asr_cdiv(total, 256)), dim3(256), 0, st, partials, dW, d->K, d->N, p.cinb, p.nparts,
+                       p.nbp, p.ncob);
+    ASR_CHECK_LAUNCH("wino_wgrad_reduce");
+    return ASR_OK;
+}

@@ -130,7 +130,12 @@ def test_conv1x1_forward_and_dgrad(ops):
 
 # ------------------------------------------------------------------ wgrad
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 12, 9, 32, 32), (2, 30, 25, 64, 128), (1, 40, 21, 32, 64),
-                                            (2, 9, 12, 128, 256), (3, 50, 50, 32, 32)])
+                                            (2, 9, 12, 128, 256), (3, 50, 50, 32, 32),
+                                            # Winograd F(3x3, 2x2) weight gradient (wino_wgrad.hip: 32 or 64 k input channels, 64 n
+                                            # output channels, enough stages): two and four column blocks, odd tile-row counts, odd
+                                            # widths, a one-column plane, several block pairs, 32 input channels (tile-pair halves)
+                                            (4, 20, 50, 64, 64), (2, 16, 100, 32, 64), (3, 22, 27, 128, 64), (2, 36, 2, 64, 64),
+                                            (2, 26, 25, 32, 128), (1, 64, 13, 128, 128)])
 def test_conv3x3_wgrad(ops, B, H, W, cin, cout):
     rng = np.random.default_rng(4)
     x = rng.standard_normal((B, H, W, cin)).astype(np.float32)
