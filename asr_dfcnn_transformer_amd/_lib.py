@@ -39,6 +39,7 @@ SIGNATURES = {
     'asr_tap_gemm_gated': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_wgrad_workspace': (_Z, [C.POINTER(GemmDesc)]),
     'asr_tap_wgrad': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _P, _P, _P]),
+    'asr_tap_wgrad_direct': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _P, _P, _P]),
     'asr_cell1_fwd': (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     'asr_cell1_bwd_workspace': (_Z, [_I, _I, _I, _I]),
     'asr_cell1_bwd': (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P]),

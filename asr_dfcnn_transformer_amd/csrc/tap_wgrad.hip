@@ -783,8 +783,19 @@ static size_t direct_wgrad_workspace(const asr_gemm_desc* d) {
     return (size_t)nc * d->ntaps * d->K * d->N * sizeof(float);
 }
 
+static int tap_wgrad_impl(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz, float* dW, float* partials, void* stream,
+                          bool allow_winograd);
 extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz,
                              float* dW, float* partials, void* stream) {
+    return tap_wgrad_impl(d, A, dZ, ldz, dW, partials, stream, true);
+}
+// the direct (36 multiplies per tile) kernels only: the second, independent implementation the Winograd path is tested against
+extern "C" int asr_tap_wgrad_direct(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz,
+                                    float* dW, float* partials, void* stream) {
+    return tap_wgrad_impl(d, A, dZ, ldz, dW, partials, stream, false);
+}
+static int tap_wgrad_impl(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz, float* dW, float* partials, void* stream,
+                          bool allow_winograd) {
     if (!d || !A || !dZ || !dW) return ASR_ERR_BAD_ARG;
     if (d->ntaps != 1 && d->ntaps != 9 && d->ntaps != 4) return ASR_ERR_BAD_ARG;
     if ((d->K & 3) || (d->N & 3) || (d->lda & 3) || (ldz & 3)) return ASR_ERR_BAD_ARG;
@@ -792,7 +803,7 @@ extern "C" int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float
     if (d->ntaps == 4 && (d->K & 255)) return ASR_ERR_UNSUPPORTED;      // phase blocks of K/4 channels, whole 32-wide k-tiles
     // 3x3 layers with 32 or a multiple of 64 input channels and a multiple of 64 output channels: Winograd F(3x3, 2x2),
     // wino_wgrad.hip (16 instead of 36 multiplies per tile and channel pair); ASR_ERR_UNSUPPORTED = not that shape
-    if (d->ntaps == 9 && partials) {
+    if (allow_winograd && d->ntaps == 9 && partials) {
         const int rw = asr_wino_wgrad_launch(d, A, dZ, ldz, dW, partials, stream);
         if (rw != ASR_ERR_UNSUPPORTED) return rw;
     }

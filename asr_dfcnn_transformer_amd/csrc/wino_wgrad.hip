@@ -29,6 +29,7 @@ namespace {
 
 typedef __attribute__((address_space(3))) float ww_lds_f;
 typedef float ww_f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) char ww_lds_c;
 
 constexpr int WW_MAXW = 13;          // tile columns of a column block
 constexpr int WW_ZP = 28;            // pixel pitch of a staged gradient row (2 w <= 26)
@@ -75,6 +76,9 @@ __device__ __forceinline__ void ww_piece(const WwArgs& a, const WwStage& s, R rx
                                          int co0, unsigned vox, unsigned voz, int pxx, int pxz) {
     typedef WwCfg<CINB> C;
     const int p = wave + 8 * j;
+#if defined(WW_ABL) && (WW_ABL & 1)
+    return;
+#endif
     if (p < C::NXP) {
         const int r = p / C::XPPR, pc = p - r * C::XPPR;
         const int row = s.row0 + r, col0 = 2 * s.tj0 + pc * C::XPX;
@@ -129,36 +133,45 @@ __device__ __forceinline__ void ww_transform_z(const ww_f2 (&y)[4], ww_f2 (&z)[8
 
 // One stage out of (xs, zs); the pieces of the next stage go into `nxt` between the MFMAs.  __restrict__ parameters of an inlined
 // function on purpose: without the alias scopes hipcc orders every LDS read behind the DMA in flight (s_waitcnt vmcnt(0)).
+// Tile pairs: the tiles (2 q, 2 q + 1) of ONE tile row (lane half = tile of the pair), q = 0 .. w / 2 - 1, for both rows; for an odd
+// w the last tiles of the two rows make one more pair (lane half = row).  A step handles the pairs q and q + kstep of a row: the
+// second pair's pixels are a CONSTANT 4 kstep pixels further, so both values of a packed register come from one base address
+// (ds_read2st64_b32 loads them as the register pair the packed add wants -- pairing tiles of different rows cost 35 v_mov per
+// step) and the address of a step is one vector add.
 template <int XH, int CINB, class R>
 __device__ __forceinline__ void ww_compute(const WwArgs& a, const char* __restrict__ xs, const char* __restrict__ zs, float* __restrict__ nxt,
-                                           const WwStage& sn, bool more, R rx, R rz, int w, int wave, int wa, int lh, int xch, int zch,
+                                           const WwStage& sn, bool more, R rx, R rz, int w, int parity, int wave, int wa, int lh, int xch, int zch,
                                            int cin0, int co0, unsigned vox, unsigned voz, int pxx, int pxz, floatx16 (&acc)[8]) {
     typedef WwCfg<CINB> C;
     constexpr int NJ = (C::NXP + C::NZP + 7) / 8;     // piece rounds per stage
-    // tile pairs of this wave: CINB 64: all of them, two per step; CINB 32: pairs wa, wa + 2, ... (two per step: wa + 4 i, wa + 4 i + 2)
-    const int kp0 = CINB == 64 ? 0 : wa, kstep = CINB == 64 ? 1 : 2;
+    constexpr int PXB = CINB * 4;                      // bytes of an input pixel
+    constexpr int KSTEP = 1;
     int jn = 0;
-    for (int kp = kp0; kp < w; kp += 2 * kstep) {
-        const bool two = kp + kstep < w;
-        // tile of this lane's half in each pair, its region offsets
-        const int tA = 2 * kp + lh, tB = 2 * (kp + kstep) + lh;
-        const int trA = tA >= w ? 1 : 0, trB = (two && tB >= w) ? 1 : 0;
-        const int tcA = tA - trA * w, tcB = two ? tB - trB * w : 0;
-        const int xa = ((2 * trA) * C::XP + 2 * tcA) * CINB * 4 + xch, xb = ((2 * trB) * C::XP + 2 * tcB) * CINB * 4 + xch;
-        const int za = ((2 * trA) * WW_ZP + 2 * tcA) * 256 + zch, zb = ((2 * trB) * WW_ZP + 2 * tcB) * 256 + zch;
+    auto step = [&](int xa, int za, bool two) {
+        // The two values of a packed register are the same pixel of the two pairs: two ds_read_b32 from ONE address register with
+        // immediate offsets, written as instructions -- left to itself hipcc merges neighbouring offsets into ds_read2st64_b32, whose
+        // register pairs are then (pixel c, pixel c + 1) of one pair, and moves 32 registers per step to re-pair them.
         ww_f2 d[12], y[4];
+#if defined(WW_ABL) && (WW_ABL & 2)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int i = 0; i < 12; ++i) d[i] = ww_f2{__int_as_float(xa + i), __int_as_float(xa + i + 1)};
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int off = (r * C::XP + XH + c) * CINB * 4;
-                d[r * 3 + c] = ww_f2{*(const float*)(xs + xa + off), *(const float*)(xs + xb + off)};
-            }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int off = ((p >> 1) * WW_ZP + (p & 1)) * 256;
-            y[p] = ww_f2{*(const float*)(zs + za + off), *(const float*)(zs + zb + off)};
-        }
+        for (int i = 0; i < 4; ++i) y[i] = ww_f2{__int_as_float(za + i), __int_as_float(za + i + 1)};
+#else
+        const unsigned xad = (unsigned)(uintptr_t)(const ww_lds_c*)(xs + xa), zad = (unsigned)(uintptr_t)(const ww_lds_c*)(zs + za);
+#define WW_LD2(dst, ad, off0, off1) { float lo_, hi_;                                                                   \
+        asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4" : "=&v"(lo_), "=&v"(hi_) : "v"(ad), "i"(off0), "i"(off1)); \
+        dst = ww_f2{lo_, hi_}; }
+#define WW_LDX(r, c) WW_LD2(d[(r) * 3 + (c)], xad, ((r) * C::XP + XH + (c)) * PXB, ((r) * C::XP + XH + (c) + 4 * KSTEP) * PXB)
+#define WW_LDZ(p) WW_LD2(y[p], zad, (((p) >> 1) * WW_ZP + ((p) & 1)) * 256, (((p) >> 1) * WW_ZP + ((p) & 1) + 4 * KSTEP) * 256)
+        WW_LDX(0, 0) WW_LDX(0, 1) WW_LDX(0, 2) WW_LDX(1, 0) WW_LDX(1, 1) WW_LDX(1, 2)
+        WW_LDX(2, 0) WW_LDX(2, 1) WW_LDX(2, 2) WW_LDX(3, 0) WW_LDX(3, 1) WW_LDX(3, 2)
+        WW_LDZ(0) WW_LDZ(1) WW_LDZ(2) WW_LDZ(3)
+#undef WW_LDX
+#undef WW_LDZ
+#undef WW_LD2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
         __builtin_amdgcn_sched_barrier(0);
         ww_f2 v[8], z[8];
         ww_transform_x<XH>(d, v);
@@ -186,7 +199,15 @@ __device__ __forceinline__ void ww_compute(const WwArgs& a, const char* __restri
                 }
             }
         }
-    }
+    };
+    const int np = w >> 1;                             // whole pairs per tile row
+    const int xl = xch + lh * 2 * PXB, zl = zch + lh * 2 * 256;       // this lane's tile of a pair: two pixels further for the upper half
+    // CINB 32: the two wave groups take one tile row each (and the odd pair alternates with the stage parity: sn.row0 / 4)
+    for (int row = (CINB == 64 ? 0 : wa); row < (CINB == 64 ? 2 : wa + 1); ++row)
+        for (int q = 0; q < np; q += 2 * KSTEP)
+            step(xl + row * (2 * C::XP * PXB) + q * (4 * PXB), zl + row * (2 * WW_ZP * 256) + q * (4 * 256), q + KSTEP < np);
+    if ((w & 1) && (CINB == 64 || wa == (parity & 1)))
+        step(xch + lh * (2 * C::XP * PXB) + (w - 1) * 2 * PXB, zch + lh * (2 * WW_ZP * 256) + (w - 1) * 2 * 256, false);
     // pieces the loop had no slot for (narrow blocks)
     if (more) for (; jn < NJ; ++jn) ww_piece<CINB>(a, sn, rx, rz, nxt, wave, jn, cin0, co0, vox, voz, pxx, pxz);
 }
@@ -235,13 +256,17 @@ __device__ __forceinline__ void ww_body(const WwArgs& a, float* smem) {
         const bool more = gn < a.nstages;
         WwStage sn = s;
         if (more) sn = ww_stage(a, gn);
+#if defined(WW_ABL) && (WW_ABL & 4)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
         ww_barrier_dma();                            // this stage has landed; nobody reads the other set any more
+#endif
         const char* xs = (const char*)(smem + cur * C::SETF);
-        ww_compute<XH, CINB>(a, xs, xs + C::XF * 4, smem + (cur ^ 1) * C::SETF, sn, more, rx, rz, s.w, wave, wa, lh, xch, zch, cin0, co0,
+        ww_compute<XH, CINB>(a, xs, xs + C::XF * 4, smem + (cur ^ 1) * C::SETF, sn, more, rx, rz, s.w, s.row0 >> 2, wave, wa, lh, xch, zch, cin0, co0,
                              vox, voz, pxx, pxz, acc);
         cur ^= 1;
     }
-    // partial of this workgroup (CINB 32: one per tile-pair parity): [16][CINB][64]; acc[r * 2 + j] = position r * 4 + 2 XH + j,
+    // partial of this workgroup (CINB 32: one per tile row of the stages): [16][CINB][64]; acc[r * 2 + j] = position r * 4 + 2 XH + j,
     // register = input channel, lane = output channel
     const int nth = CINB == 64 ? 1 : 2;
     float* P = a.part + ((long)(sl * a.nbp + bp) * nth + (CINB == 64 ? 0 : wa)) * 16 * CINB * 64;

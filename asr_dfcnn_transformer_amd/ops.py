@@ -166,12 +166,13 @@ def tap_wgrad_workspace(desc):
     return _lib.load().asr_tap_wgrad_workspace(C.byref(desc))
 
 
-def tap_wgrad(desc, A, dZ, ldz, dW, partials):
+def tap_wgrad(desc, A, dZ, ldz, dW, partials, direct=False):
+    """direct=True: asr_tap_wgrad_direct (never the Winograd kernel)."""
     lib = _lib.load()
     pa = A.ptr if isinstance(A, Plane) else _ptr(A)
     pz = dZ.ptr if isinstance(dZ, Plane) else _ptr(dZ)
-    _timed(desc, lambda: check(
-        lib.asr_tap_wgrad(C.byref(desc), pa, pz, ldz, _ptr(dW), _ptr(partials), _stream()), 'asr_tap_wgrad'))
+    fn = lib.asr_tap_wgrad_direct if direct else lib.asr_tap_wgrad
+    _timed(desc, lambda: check(fn(C.byref(desc), pa, pz, ldz, _ptr(dW), _ptr(partials), _stream()), 'asr_tap_wgrad'))
 
 
 def cell1_fwd(x, w, bias, sc, sh, pool, y):

@@ -124,6 +124,11 @@ int asr_tap_gemm(const asr_gemm_desc* d, const float* A, const float* W,
 size_t asr_tap_wgrad_workspace(const asr_gemm_desc* d);
 int asr_tap_wgrad(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz,
                   float* dW, float* partials, void* stream);
+/* asr_tap_wgrad routes 3x3 layers with 32 or 64 k input channels, 64 n output channels, an even height and enough pixels to the
+ * Winograd F(3x3, 2x2) kernel (csrc/wino_wgrad.hip: 16 instead of 36 multiplies per 2x2 tile and channel pair, fp32, fixed-order
+ * reduction).  asr_tap_wgrad_direct never does: the direct kernels, kept as the independent implementation the tests compare with. */
+int asr_tap_wgrad_direct(const asr_gemm_desc* d, const float* A, const float* dZ, int ldz,
+                         float* dW, float* partials, void* stream);
 
 /* ------------------------------------------------------------------ first cell (Cin = 1)
  * cnn_cell(32, wav_input, pool=True): conv3x3(1->C) + bias + ReLU + frozen BN + 2x2 pool
