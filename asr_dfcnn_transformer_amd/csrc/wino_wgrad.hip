@@ -292,26 +292,43 @@ __global__ __launch_bounds__(512) void wino_wgrad_kernel(WwArgs a) {
 #endif
 }
 
-// dW[kh][kw][k][n] = A'^T (sum over the partials of M[.][k][n]) A', partials in ascending order
-__global__ void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int K, int N, int cinb, int nparts,
-                                         int nbp, int ncob) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)K * N) return;
-    const int k = (int)(i / N), n = (int)(i - (long)k * N);
-    const int cib = k / cinb, ci = k - cib * cinb, cob = n >> 6, co = n & 63;
+// dW[kh][kw][k][n] = A'^T (sum over the partials of M[.][k][n]) A'.  One workgroup per (input channel k, block of 64 output
+// channels): thread (co, g) adds the partials of group g (a contiguous range, ascending) for its sixteen positions -- sixteen
+// independent loads per partial, 128-byte rows per half-wave --, the groups' sums are added in ascending order through LDS: a fixed
+// association, bitwise reproducible.  (The first form -- one thread per (k, n) walking all partials -- took 77 us per launch:
+// 32-512 workgroups of dependent loads for 64 MB.)
+constexpr int WW_RG = 16;            // groups of partials per workgroup
+__global__ __launch_bounds__(64 * WW_RG) void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int K, int N,
+                                                                         int cinb, int nparts, int nbp, int ncob) {
+    __shared__ float red[WW_RG][16][64];
+    const int co = threadIdx.x, g = threadIdx.y;
+    const int k = blockIdx.x / ncob, cob = blockIdx.x - k * ncob;
+    const int cib = k / cinb, ci = k - cib * cinb;
     const int bp = cib * ncob + cob;
     const int nth = cinb == 64 ? 1 : 2;
     const long pstride = (long)16 * cinb * 64;
+    const int PT = nparts * nth;                                  // partial (p, t) has index p * nth + t: (p * nbp + bp) * nth + t in memory
+    const int lo = (int)((long)PT * g / WW_RG), hi = (int)((long)PT * (g + 1) / WW_RG);
     float m[16];
 #pragma unroll
     for (int x = 0; x < 16; ++x) m[x] = 0.f;
-    for (int p = 0; p < nparts; ++p) {
-        for (int t = 0; t < nth; ++t) {
-            const float* q = part + ((long)(p * nbp + bp) * nth + t) * pstride + (long)ci * 64 + co;
+    for (int i = lo; i < hi; ++i) {
+        const int p = i / nth, t = i - p * nth;
+        const float* q = part + ((long)(p * nbp + bp) * nth + t) * pstride + (long)ci * 64 + co;
 #pragma unroll
-            for (int x = 0; x < 16; ++x) m[x] += q[(long)x * cinb * 64];
-        }
+        for (int x = 0; x < 16; ++x) m[x] += q[(long)x * cinb * 64];
     }
+#pragma unroll
+    for (int x = 0; x < 16; ++x) red[g][x][co] = m[x];
+    __syncthreads();
+    if (g != 0) return;
+#pragma unroll
+    for (int x = 0; x < 16; ++x) {
+        float s = red[0][x][co];
+        for (int j = 1; j < WW_RG; ++j) s += red[j][x][co];
+        m[x] = s;
+    }
+    const int n = cob * 64 + co;
     // rows: t[kh][c] = A'^T m[.][c]
     float t[3][4];
 #pragma unroll
@@ -407,8 +424,7 @@ int asr_wino_wgrad_launch(const asr_gemm_desc* d, const float* A, const float* d
         ASR_NOTE_KERNEL("wino_wgrad_kernel<32>");
     }
     ASR_CHECK_LAUNCH("wino_wgrad");
-    const long total = (long)d->K * d->N;
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(asr_cdiv(total, 256)), dim3(256), 0, st, partials, dW, d->K, d->N, p.cinb, p.nparts,
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(d->K * p.ncob), dim3(64, WW_RG), 0, st, partials, dW, d->K, d->N, p.cinb, p.nparts,
                        p.nbp, p.ncob);
     ASR_CHECK_LAUNCH("wino_wgrad_reduce");
     return ASR_OK;
