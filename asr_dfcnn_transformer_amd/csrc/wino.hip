@@ -216,10 +216,12 @@ __device__ __forceinline__ void wino8_chunk(const float* __restrict__ raw, const
 // `before_stores` runs after the exchange and before the first global store of the epilogues (wino9_kernel: the place where the
 // next item's DMA is waited for and its row tables are written).
 struct WinoNoHook { __device__ __forceinline__ void operator()() const {} };
-template <int XH, class Hook = WinoNoHook>
+// NWH = waves per position half (4: the eight-wave kernels, 2: wino10_kernel); ws = this wave's index within its half.
+template <int XH, class Hook = WinoNoHook, int NWH = 4>
 __device__ __forceinline__ void wino_item_tail(const WinoArgs& args, floatx16 (&acc)[8], float* rfree, float* ufree, const int* rowa,
                                                const int* rowy, const int* prow, int wave, int lane, int wm, int wn, int n0, int blk,
                                                float pool_bs, float pool_sc, float pool_sh, Hook before_stores = Hook()) {
+    const int ws = wave & (NWH - 1);
     const TapGemmArgs& g = args.g;
     // own column sums: m(r, j) = acc[r * 2 + j], transform column c = 2 XH + j
     floatx16 s0[2], s1[2];
@@ -233,13 +235,13 @@ __device__ __forceinline__ void wino_item_tail(const WinoArgs& args, floatx16 (&
     // half 0 finishes pixel row 0 and needs s0 of columns 2, 3; half 1 finishes pixel row 1 and needs s1 of columns 0, 1
     // each wave hands its partner 2 x 16 registers x 64 lanes = 2048 floats: waves 0-3 through the raw set, waves 4-7
     // through the weight set (8192 floats each)
-    float* xch = (XH == 0 ? rfree : ufree) + (wave & 3) * 2048;
+    float* xch = (XH == 0 ? rfree : ufree) + ws * 2048;
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) xch[(j * 16 + r) * 64 + lane] = XH == 0 ? s1[j][r] : s0[j][r];
     lds_barrier();
-    const float* pch = (XH == 0 ? ufree : rfree) + (wave & 3) * 2048;
+    const float* pch = (XH == 0 ? ufree : rfree) + ws * 2048;
     floatx16 out[2][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -266,7 +268,8 @@ __device__ __forceinline__ void wino_item_tail(const WinoArgs& args, floatx16 (&
             const float v0 = fmaf(scv, x0, shv), v1 = fmaf(scv, x1, shv);
             pm[r] = args.pool_mode == 1 ? v0 + v1 : fmaxf(v0, v1);
         }
-        float* pex = (wave & 2 ? ufree : rfree) + 4 * (32 * 33) + (wave & 1) * 1024;    // pair (wm, wn)
+        float* pex = NWH == 4 ? (wave & 2 ? ufree : rfree) + 4 * (32 * 33) + (wave & 1) * 1024      // pair (wm, wn)
+                              : rfree + 2 * (32 * 33) + ws * 1024;                                 // pair wm
         if (XH == 1) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) pex[r * 64 + lane] = pm[r];
@@ -283,12 +286,12 @@ __device__ __forceinline__ void wino_item_tail(const WinoArgs& args, floatx16 (&
             // ones -- the tail is store-issue bound), row table = the pooled rows of this wave's 32 tiles
             TapGemmArgs gp = g;
             gp.out_a = args.pool_y; gp.ldo_a = g.N; gp.out_y = nullptr; gp.bias = nullptr; gp.relu = 0; gp.accumulate = 0; gp.gate_mode = 0;
-            float* pscr = (wave < 4 ? rfree : ufree) + (wave & 3) * (32 * 33);
+            float* pscr = (XH == 0 ? rfree : ufree) + ws * (32 * 33);
             tap_epilogue<1, 1>(gp, po, pscr, prow, prow, wm * 32, n0 + wn * 32, lane, 0);
         }
     }
     // transpose scratch (32 x 33 floats per wave): waves 0-3 in the raw set, waves 4-7 in the weight set
-    float* scratch = (wave < 4 ? rfree : ufree) + (wave & 3) * (32 * 33);
+    float* scratch = (XH == 0 ? rfree : ufree) + ws * (32 * 33);
     tap_epilogue<2, 1>(g, out, scratch, rowa, rowy, wm * 128 + XH * 64, n0 + wn * 32, lane, (blk * 2 + wm) * 2 + XH);
 }
 
@@ -776,6 +779,209 @@ __global__ __launch_bounds__(512) void wino9_kernel(WinoArgs args) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ wino10_kernel (round 3)
+// The same computation for 32-wide channel blocks: FOUR waves (wave = xh * 2 + wm: 32 tiles x 32 channels x 8 positions each, the
+// register budget of the eight-wave kernels), 64 tiles x 32 output channels per item, 72 KB of LDS -- TWO workgroups per CU, which
+// share each SIMD's matrix pipe and run out of phase by themselves: while one is behind a barrier or in its item tail the other
+// one computes.  Serves the views with N % 64 == 32 (the 64 -> 32 and 256 -> 32 data-gradients of acoustic_model.py, the 32-channel
+// layers of the SE graphs), which the 64-channel items cannot take.  Raw region as in wino9_kernel but per 8-channel chunk: a
+// piece = one PAIR of pixel rows and one column parity ([row 2][quad 2][position 16] 16-byte slots, both rows share the rotation).
+constexpr int W10_C = 32;                       // output channels per item
+constexpr int W10_RAWF = 4352;                  // floats of a raw set: 16 pieces of 256 (+ the pool hand-over behind the transpose scratch)
+constexpr int W10_UF = 16 * WKC * W10_C;        // floats of a weight set
+
+#if __HIP_DEVICE_COMPILE__
+// raw pieces wave + 4 j of a chunk: row pair p >> 1 of the region, parity p & 1
+template <class R>
+__device__ __forceinline__ void wino10_offsets(const WinoArgs& args, const Wino9Geo& e, int lane, Wino9Dma<R>& q) {
+    const TapGemmArgs& g = args.g;
+    const int np = e.npieces >> 1;                              // (rows + 1) row pairs x 2 parities
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int p = q.wave + 4 * j, m = p >> 1, par = p & 1;
+        const int rowbit = lane >> 5, quad = (lane >> 4) & 1;
+        const int y = 2 * m + rowbit;
+        const int rho = ((e.tr0 + m) * e.w) & 15;
+        const int idx = ((lane & 15) - rho) & 15;
+        const int x = 2 * idx + par;
+        const bool ok = idx <= e.w && 2 * e.tj0 + x < g.WP && 2 * e.tr0 + y <= g.H + 1 && p < np;
+        q.voff[j] = ok ? (unsigned)((((long)rowbit * g.WP + x) * g.lda + quad * 4) * 4) : 0xFFFFFFF0u;
+    }
+    q.sbase = (unsigned)((((long)e.b * g.HPWP + (long)(2 * e.tr0) * g.WP + 2 * e.tj0) * g.lda) * 4);
+    q.npieces = np;
+}
+template <class R>
+__device__ __forceinline__ void wino10_raw_piece(const Wino9Dma<R>& q, float* __restrict__ raw, int j, int kc) {
+    const int p = q.wave + 4 * j;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(q.ra, (wn_lds_f*)(raw + p * 256), 16, q.voff[j],
+                                             (int)(q.sbase + (unsigned)((p >> 1) * 2 * q.rowbytes + kc * WKC * 4)), 0, 0);
+}
+// weight piece xi = wave + 4 j of chunk kc: [8 ci][32 co]
+template <class R>
+__device__ __forceinline__ void wino10_u_piece(const Wino9Dma<R>& q, float* __restrict__ ub, int j, int kc) {
+    const int xi = q.wave + 4 * j;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(q.ru, (wn_lds_f*)(ub + xi * 256), 16, q.off_u,
+                                             (int)((xi * q.ustride_xi + (long)(kc * WKC) * q.N) * 4), 0, 0);
+}
+
+template <int XH, class R>
+__device__ __forceinline__ void wino10_chunk(const float* __restrict__ raw, const float* __restrict__ ub, float* __restrict__ rawn,
+                                             float* __restrict__ ubn, bool pre, const Wino9Dma<R>& q, int kcn, const unsigned (&lb)[4],
+                                             int boff, floatx16 (&acc)[8]) {
+    auto load_u = [&](float (&u)[8], int kp) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) u[r * 2 + j] = ub[((r * 4 + 2 * XH + j) * WKC + kp) * W10_C + boff];
+    };
+    // eight MFMAs; behind MFMA 1, 3, 5, 7 one DMA piece of the next chunk: group 0 the weight pieces, group 1 the raw pieces
+    auto mfmas = [&](const wn_f2 (&v)[8], int h, const float (&u)[8], int group) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[i].y : v[i].x, u[i], acc[i], 0, 0, 0);
+            if (group >= 0 && (i & 1)) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (pre) { if (group == 0) wino10_u_piece(q, ubn, i >> 1, kcn); else wino10_raw_piece(q, rawn, i >> 1, kcn); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+    float4 d[12];
+    float ua[8], ubb[8];
+    wn_f2 v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int cc = XH + c;
+            d[r * 3 + c] = *(const float4*)((const char*)raw + lb[(r >> 1) * 2 + (cc >> 1)] + (r >> 1) * 2048 + (cc & 1) * 1024 + (r & 1) * 512);
+        }
+    load_u(ua, 0);
+    load_u(ubb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    wino8_transform<XH>(d, 0, v);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(v, 0, ua, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(ua, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(v, 1, ubb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(ubb, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    wino8_transform<XH>(d, 1, v);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(v, 0, ua, -1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(v, 1, ubb, -1);
+}
+
+template <int XH>
+__device__ __forceinline__ void wino10_body(const WinoArgs& args, float* smem) {
+    const TapGemmArgs& g = args.g;
+    int* tables = (int*)smem;                        // two sets of [rowa 256 | rowy 256 | prow 64]
+    float* bufs = smem + 2 * 576;                    // raw0 | raw1 | u0 | u1
+    float* pconst = bufs + 2 * W10_RAWF + 2 * W10_UF;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1;                         // wave = xh * 2 + wm
+    const int boff = lh * 4 * W10_C + li;
+    const int nkc = g.K / WKC;
+    const int nnb = g.ntn, nwork = g.ntm * nnb;
+
+    int w = blockIdx.x;
+    if (w >= nwork) return;
+    const int G = gridDim.x;
+    auto item_of = [&](int wl) {                     // see wino8_body
+        const int r0 = (wl / G) * G;
+        if ((G & 7) || r0 + G > nwork) return wl;
+        const int p = wl - r0;
+        return r0 + (p & 7) * (G >> 3) + (p >> 3);
+    };
+    auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7FFFFFF0, 0x00020000);
+    auto ru = __builtin_amdgcn_make_buffer_rsrc((void*)args.Ut, 0, 0x7FFFFFF0, 0x00020000);
+    Wino9Dma<decltype(ra)> q;
+    q.ra = ra; q.ru = ru; q.wave = wave; q.rowbytes = g.WP * g.lda * 4; q.N = g.N; q.ustride_xi = (long)g.K * g.N;
+    auto u_offset = [&](int n0) { return (unsigned)(((long)(lane >> 3) * g.N + n0 + (lane & 7) * 4) * 4); };
+    int cur = 0, tcur = 0;
+    {
+        const int it = item_of(w);
+        const Wino9Geo e = wino9_geo(args, it / nnb);
+        wino10_offsets(args, e, lane, q);
+        q.off_u = u_offset((it % nnb) * W10_C);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { wino10_raw_piece(q, bufs, j, 0); wino10_u_piece(q, bufs + 2 * W10_RAWF, j, 0); }
+        wino9_tables(args, e, tid, tables, tables + 256, tables + 512);
+        if (args.pool_y)
+            for (int n = tid; n < g.N; n += 256) {
+                pconst[n] = g.bias ? g.bias[n] : 0.f;
+                pconst[g.N + n] = g.scale ? g.scale[n] : 1.f;
+                pconst[2 * g.N + n] = g.shift ? g.shift[n] : 0.f;
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+    }
+    for (; w < nwork; w += gridDim.x) {
+        const int item = item_of(w);
+        const int blk = item / nnb, nb = item - blk * nnb;
+        const Wino9Geo e = wino9_geo(args, blk);
+        const int n0 = nb * W10_C;
+        int* rowa = tables + tcur * 576;
+        int* rowy = rowa + 256;
+        int* prow = rowy + 256;
+        unsigned lb[4];
+        {
+            const int l = e.l0 + wm * 32 + li;
+            const int trl = l / e.w - e.tr0;
+            const unsigned fix = (unsigned)(trl * 2048 + lh * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lb[j] = fix + (unsigned)(((l + (j >> 1) * e.w + (j & 1)) & 15) * 16);
+        }
+        floatx16 acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const int wnext = w + gridDim.x;
+        const bool more = wnext < nwork;
+        const int itn = more ? item_of(wnext) : 0;
+        for (int kc = 0; kc < nkc; ++kc) {
+            const bool last = kc + 1 == nkc;
+            if (last && more) {                      // the prefetch now belongs to the next item
+                wino10_offsets(args, wino9_geo(args, itn / nnb), lane, q);
+                q.off_u = u_offset((itn % nnb) * W10_C);
+            }
+            wino10_chunk<XH>(bufs + cur * W10_RAWF, bufs + 2 * W10_RAWF + cur * W10_UF, bufs + (cur ^ 1) * W10_RAWF,
+                             bufs + 2 * W10_RAWF + (cur ^ 1) * W10_UF, last ? more : true, q, last ? 0 : kc + 1, lb, boff, acc);
+            if (last) lds_barrier();
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            cur ^= 1;
+        }
+        const int pool_n = n0 + li;
+        float pool_bs = 0.f, pool_sc = 1.f, pool_sh = 0.f;
+        if (args.pool_y && pool_n < g.N) { pool_bs = pconst[pool_n]; pool_sc = pconst[g.N + pool_n]; pool_sh = pconst[2 * g.N + pool_n]; }
+        auto before_stores = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next item's chunk 0
+            if (more) wino9_tables(args, wino9_geo(args, itn / nnb), tid, tables + (tcur ^ 1) * 576, tables + (tcur ^ 1) * 576 + 256,
+                                   tables + (tcur ^ 1) * 576 + 512);
+        };
+        wino_item_tail<XH, decltype(before_stores), 2>(args, acc, bufs + (cur ^ 1) * W10_RAWF, bufs + 2 * W10_RAWF + (cur ^ 1) * W10_UF, rowa, rowy,
+                                                       prow, wave, lane, wm, 0, n0, blk, pool_bs, pool_sc, pool_sh, before_stores);
+        lds_barrier();
+        tcur ^= 1;
+    }
+}
+#endif
+
+template <int DIR>
+__global__ __launch_bounds__(256, 2) void wino10_kernel(WinoArgs args) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    if ((threadIdx.x >> 7) == 0) wino10_body<0>(args, smem);
+    else wino10_body<1>(args, smem);
+#endif
+}
+
 template <int DIR>
 __global__ __launch_bounds__(512) void wino8_kernel(WinoArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -802,9 +1008,28 @@ extern "C" int asr_winograd_weights(const float* W, int K, int N, int ldw, int w
     return ASR_OK;
 }
 
+// column blocks of 11..15 tile columns (wino9_kernel, wino10_kernel); 0: no such split
+static int wino_column_blocks(int TW, int* tj0, int* cw) {
+    for (int nb = asr_cdiv(TW, 15); nb <= 8 && nb * 11 <= TW; ++nb) {
+        if (asr_cdiv(TW, nb) > 15) continue;
+        int tj = 0;
+        for (int c = 0; c < nb; ++c) {
+            const int w = TW / nb + (c < TW % nb ? 1 : 0);
+            if (tj0) tj0[c] = tj;
+            if (cw) cw[c] = w;
+            tj += w;
+        }
+        return nb;
+    }
+    return 0;
+}
+
 extern "C" int asr_winograd_supported(const asr_gemm_desc* d) {
-    return d && d->ntaps == 9 && d->H > 0 && (d->H & 1) == 0 && d->W >= 2 && (d->K % WKC) == 0 && (d->N % WC) == 0 &&
-           (d->lda & 3) == 0 && d->M == d->B * (d->H + 1) * (d->W + 1);
+    if (!(d && d->ntaps == 9 && d->H > 0 && (d->H & 1) == 0 && d->W >= 2 && (d->K % WKC) == 0 && (d->lda & 3) == 0 &&
+          d->M == d->B * (d->H + 1) * (d->W + 1))) return 0;
+    if ((d->N % WC) == 0) return 1;
+    // 32-wide channel blocks: wino10_kernel only (column-blocked tile order)
+    return (d->N % W10_C) == 0 && d->N <= 2048 && wino_column_blocks((d->W + 1) / 2, nullptr, nullptr) > 0;
 }
 
 struct WinoGate { int mode, H, W; const float* a; float* dz; float* part; int* rows; };
@@ -832,24 +1057,19 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     w.ntiles = (long)d->B * w.TH * w.TW;
     w.wodd = d->W & 1;
     w.pool_y = pool_y; w.pool_mode = pool_mode; w.H2 = d->H / 2; w.W2 = d->W / 2;
-    // column-blocked tile order (wino9_kernel) when the tile columns split into blocks of 11..15 and K is a multiple of 16
+    // column-blocked tile order when the tile columns split into blocks of 11..15: wino9_kernel (K a multiple of 16, 64-wide
+    // channel blocks) or wino10_kernel (32-wide channel blocks: N % 64 == 32)
+    const bool use10 = (d->N % WC) != 0;
     w.ncb = 0;
-    if (d->K % 16 == 0 && d->K >= 32 && (!pool_y || d->N <= 2048)) {      // (the pool constants of all N channels sit in LDS)
-        for (int nb = asr_cdiv(w.TW, 15); nb <= 8 && nb * 11 <= w.TW; ++nb) {
-            if (asr_cdiv(w.TW, nb) > 15) continue;
-            w.ncb = nb;
-            int tj = 0, it = 0;
-            for (int c = 0; c < nb; ++c) {
-                const int cw = w.TW / nb + (c < w.TW % nb ? 1 : 0);
-                w.cb_tj0[c] = tj; w.cb_w[c] = cw; w.cb_it0[c] = it;
-                tj += cw; it += asr_cdiv(w.TH * cw, WT);
-            }
-            w.cb_it0[nb] = it;
-            break;
-        }
+    if (use10 || (d->K % 16 == 0 && d->K >= 32 && (!pool_y || d->N <= 2048))) {      // (the pool constants of all N channels sit in LDS)
+        w.ncb = wino_column_blocks(w.TW, w.cb_tj0, w.cb_w);
+        int it = 0;
+        for (int c = 0; c < w.ncb; ++c) { w.cb_it0[c] = it; it += asr_cdiv(w.TH * w.cb_w[c], WT); }
+        w.cb_it0[w.ncb] = it;
     }
+    if (use10 && !w.ncb) return ASR_ERR_UNSUPPORTED;
     const int nblk = w.ncb ? d->B * w.cb_it0[w.ncb] : asr_cdiv(w.ntiles, WT);
-    a.ntm = nblk; a.ntn = d->N / WC;
+    a.ntm = nblk; a.ntn = use10 ? d->N / W10_C : d->N / WC;
     if (a.gate_rows) *a.gate_rows = nblk * 4;
     const size_t lds8 = (size_t)(576 + 2 * RAW_F + 2 * U_F) * sizeof(float);
     const size_t lds9 = lds8 + (576 + (pool_y ? 3 * (size_t)d->N : 0)) * sizeof(float);      // wino9_kernel: two sets of row tables, pool constants
@@ -862,6 +1082,24 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     const int nwork8 = nblk * a.ntn;
     const int grid8 = nwork8 > ncu8 ? ncu8 : nwork8;        // persistent: one workgroup per CU
     hipStream_t st8 = (hipStream_t)stream;
+    if (use10) {
+        const size_t lds10 = (size_t)(2 * 576 + 2 * W10_RAWF + 2 * W10_UF + (pool_y ? 3 * d->N : 0)) * sizeof(float);
+        static_assert(2 * 2048 <= W10_RAWF && 2 * 2048 <= W10_UF && 2 * 32 * 33 + 2 * 1024 <= W10_RAWF, "exchange / scratch + pool hand-over must fit in one buffer set");
+        const int grid10 = nwork8 > 2 * ncu8 ? 2 * ncu8 : nwork8;     // persistent: two workgroups per CU
+        auto r0 = wino10_kernel<0>;
+        auto r1 = wino10_kernel<1>;
+        static bool e0 = false, e1 = false;
+        if (d->wmode) {
+            if (!e1) { (void)hipFuncSetAttribute((const void*)r1, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); e1 = true; }
+            hipLaunchKernelGGL(r1, dim3(grid10), dim3(256), lds10, st8, w);
+        } else {
+            if (!e0) { (void)hipFuncSetAttribute((const void*)r0, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); e0 = true; }
+            hipLaunchKernelGGL(r0, dim3(grid10), dim3(256), lds10, st8, w);
+        }
+        ASR_CHECK_LAUNCH("tap_gemm_wino10");
+        if (d->wmode) ASR_NOTE_KERNEL("wino10_kernel<1>"); else ASR_NOTE_KERNEL("wino10_kernel<0>");
+        return ASR_OK;
+    }
     if (w.ncb) {
         auto p0 = wino9_kernel<0>;
         auto p1 = wino9_kernel<1>;

@@ -29,7 +29,9 @@ def conv_ref(x, w, b=None):
                                             # 11..15): two blocks 13 + 12 with partly filled last items, one block of 14 / 15 / 11
                                             # columns at odd and even widths, four blocks, many tile rows per block
                                             (3, 20, 50, 64, 128), (2, 14, 27, 48, 64), (2, 30, 29, 32, 64), (1, 200, 22, 32, 64),
-                                            (2, 12, 100, 32, 64), (1, 6, 200, 32, 64)])
+                                            (2, 12, 100, 32, 64), (1, 6, 200, 32, 64),
+                                            # 32-wide channel blocks (wino10_kernel: four waves, two workgroups per CU)
+                                            (2, 20, 50, 64, 32), (1, 16, 25, 32, 32), (3, 14, 27, 24, 96), (2, 200, 22, 8, 32)])
 def test_forward_matches_tap_gemm_and_float64(ops, B, H, W, cin, cout):
     g = torch.Generator(device='cuda').manual_seed(11)
     x = ops.Plane(B, H, W, cin); xi = torch.randn(B, H, W, cin, device='cuda', generator=g); x.set_interior(xi)
@@ -52,7 +54,7 @@ def test_forward_matches_tap_gemm_and_float64(ops, B, H, W, cin, cout):
 
 @pytest.mark.parametrize("pool", [1, 2])
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 6, 5, 8, 64), (3, 4, 2, 16, 64), (2, 8, 12, 24, 128), (1, 16, 26, 32, 64), (2, 40, 100, 32, 64),
-                                            (32, 30, 50, 16, 128)])
+                                            (32, 30, 50, 16, 128), (2, 40, 100, 32, 32), (3, 12, 26, 16, 96)])
 def test_fused_pool_equals_conv_then_pool_bitwise(ops, pool, B, H, W, cin, cout):
     """One launch writes the activation AND its pooled BN output; the pooled plane equals asr_pool_fwd of the stored activation
     bit for bit (average and maximum, odd widths drop the last column as asr_pool_fwd does, several items per workgroup)."""
@@ -74,7 +76,7 @@ def test_fused_pool_equals_conv_then_pool_bitwise(ops, pool, B, H, W, cin, cout)
     assert y1.interior().abs().sum().item() > 0
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 6, 5, 64, 8), (1, 12, 25, 128, 32), (3, 4, 4, 64, 16), (2, 20, 50, 64, 64), (3, 10, 23, 128, 48)])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 6, 5, 64, 8), (1, 12, 25, 128, 32), (3, 4, 4, 64, 16), (2, 20, 50, 64, 64), (3, 10, 23, 128, 48), (2, 20, 50, 32, 64), (1, 40, 25, 96, 256)])
 def test_data_gradient_view_with_accumulation(ops, B, H, W, cin, cout):
     g = torch.Generator(device='cuda').manual_seed(12)
     w = torch.randn(3, 3, cin, cout, device='cuda', generator=g) * 0.1
@@ -87,7 +89,7 @@ def test_data_gradient_view_with_accumulation(ops, B, H, W, cin, cout):
         pytest.skip('N % 64 != 0 for this view')
     ops.tap_gemm(bd, dz, w, None, None, None, None, dx0)
     ops.tap_gemm_wino(bd, dz, ops.winograd_weights(w, cout, cin, cout, 1), None, None, None, None, dx1)
-    assert (dx1.interior() - dx0.interior()).abs().max().item() < 3e-5
+    assert (dx1.interior() - dx0.interior()).abs().max().item() < 3e-5 * max(1.0, dx0.interior().abs().max().item() / 4)
 
 
 def test_unsupported_shapes_are_reported(ops):
