@@ -1057,28 +1057,32 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     w.ntiles = (long)d->B * w.TH * w.TW;
     w.wodd = d->W & 1;
     w.pool_y = pool_y; w.pool_mode = pool_mode; w.H2 = d->H / 2; w.W2 = d->W / 2;
-    // column-blocked tile order when the tile columns split into blocks of 11..15: wino9_kernel (K a multiple of 16, 64-wide
-    // channel blocks) or wino10_kernel (32-wide channel blocks: N % 64 == 32)
-    const bool use10 = (d->N % WC) != 0;
-    w.ncb = 0;
-    if (use10 || (d->K % 16 == 0 && d->K >= 32 && (!pool_y || d->N <= 2048))) {      // (the pool constants of all N channels sit in LDS)
-        w.ncb = wino_column_blocks(w.TW, w.cb_tj0, w.cb_w);
-        int it = 0;
-        for (int c = 0; c < w.ncb; ++c) { w.cb_it0[c] = it; it += asr_cdiv(w.TH * w.cb_w[c], WT); }
-        w.cb_it0[w.ncb] = it;
+    static int ncu8 = 0;
+    if (!ncu8) {
+        int dev = 0; hipDeviceProp_t pr;
+        ncu8 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
     }
+    // Column-blocked tile order when the tile columns split into blocks of 11..15: wino10_kernel (32-wide channel blocks, four waves,
+    // two workgroups per CU) for N % 64 == 32 and for launches of few items per CU -- measured per layer (B = 32): 128 -> 128 / 256
+    // and 32 -> 256 at 200 x 25 (5-10 rounds of 64-channel items) 5-12 % faster than wino9_kernel, 64 -> 128 at 400 x 50 (20 rounds)
+    // equal, 32 -> 64 at 800 x 100 (39 rounds) 2 % slower --; else wino9_kernel (K a multiple of 16, 64-wide channel blocks).
+    w.ncb = wino_column_blocks(w.TW, w.cb_tj0, w.cb_w);
+    int it = 0;
+    for (int c = 0; c < w.ncb; ++c) { w.cb_it0[c] = it; it += asr_cdiv(w.TH * w.cb_w[c], WT); }
+    w.cb_it0[w.ncb] = it;
+    bool use10 = (d->N % WC) != 0;
+    if (!use10 && w.ncb && d->N <= 2048 && (long)d->B * it * (d->N / WC) <= 12L * ncu8) use10 = true;
+#ifdef WINO_FORCE10
+    if (w.ncb && (d->N % W10_C) == 0) use10 = true;
+#endif
     if (use10 && !w.ncb) return ASR_ERR_UNSUPPORTED;
+    if (!use10 && !(d->K % 16 == 0 && d->K >= 32 && (!pool_y || d->N <= 2048))) w.ncb = 0;      // wino8_kernel (plain tile order)
     const int nblk = w.ncb ? d->B * w.cb_it0[w.ncb] : asr_cdiv(w.ntiles, WT);
     a.ntm = nblk; a.ntn = use10 ? d->N / W10_C : d->N / WC;
     if (a.gate_rows) *a.gate_rows = nblk * 4;
     const size_t lds8 = (size_t)(576 + 2 * RAW_F + 2 * U_F) * sizeof(float);
     const size_t lds9 = lds8 + (576 + (pool_y ? 3 * (size_t)d->N : 0)) * sizeof(float);      // wino9_kernel: two sets of row tables, pool constants
     static_assert(4 * 2048 <= RAW_F && 4 * 2048 <= U_F && 4 * 32 * 33 + 2 * 1024 <= RAW_F && 4 * 32 * 33 + 2 * 1024 <= U_F, "exchange / scratch + pool hand-over must fit in one buffer set");
-    static int ncu8 = 0;
-    if (!ncu8) {
-        int dev = 0; hipDeviceProp_t pr;
-        ncu8 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
-    }
     const int nwork8 = nblk * a.ntn;
     const int grid8 = nwork8 > ncu8 ? ncu8 : nwork8;        // persistent: one workgroup per CU
     hipStream_t st8 = (hipStream_t)stream;

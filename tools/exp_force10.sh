@@ -1,0 +1,11 @@
+set -e
+cd /root/repo
+P=asr_dfcnn_transformer_amd
+cp $P/libasrhip.so /tmp/libasrhip_good.so
+objs=$(ls $P/build/*.hip.o | grep -v "/wino.hip.o")
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DWINO_FORCE10 -I include -c $P/csrc/wino.hip -o /tmp/wino_f10.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/libasrhip.so $objs /tmp/wino_f10.o
+python tools/bench_wino.py 2>&1 | grep -v amdgpu.ids | cut -c1-130
+python bench.py --steps 20 --warmup 5 --kernel-table 2>&1 | grep -v amdgpu.ids | cut -c1-200 | head -8
+cp /tmp/libasrhip_good.so $P/libasrhip.so
+python tools/bench_wino.py 2>&1 | grep -v amdgpu.ids | cut -c1-130
