@@ -813,6 +813,9 @@ __device__ __forceinline__ void wino10_offsets(const WinoArgs& args, const Wino9
 template <class R>
 __device__ __forceinline__ void wino10_raw_piece(const Wino9Dma<R>& q, float* __restrict__ raw, int j, int kc) {
     const int p = q.wave + 4 * j;
+#if defined(WINO_ABL) && (WINO_ABL & 4)
+    return;
+#endif
     __builtin_amdgcn_raw_ptr_buffer_load_lds(q.ra, (wn_lds_f*)(raw + p * 256), 16, q.voff[j],
                                              (int)(q.sbase + (unsigned)((p >> 1) * 2 * q.rowbytes + kc * WKC * 4)), 0, 0);
 }
@@ -820,6 +823,9 @@ __device__ __forceinline__ void wino10_raw_piece(const Wino9Dma<R>& q, float* __
 template <class R>
 __device__ __forceinline__ void wino10_u_piece(const Wino9Dma<R>& q, float* __restrict__ ub, int j, int kc) {
     const int xi = q.wave + 4 * j;
+#if defined(WINO_ABL) && (WINO_ABL & 8)
+    return;
+#endif
     __builtin_amdgcn_raw_ptr_buffer_load_lds(q.ru, (wn_lds_f*)(ub + xi * 256), 16, q.off_u,
                                              (int)((xi * q.ustride_xi + (long)(kc * WKC) * q.N) * 4), 0, 0);
 }
@@ -832,7 +838,11 @@ __device__ __forceinline__ void wino10_chunk(const float* __restrict__ raw, cons
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
+#if defined(WINO_ABL) && (WINO_ABL & 2)
+            for (int j = 0; j < 2; ++j) u[r * 2 + j] = __int_as_float(boff + r * 2 + j + kp);
+#else
             for (int j = 0; j < 2; ++j) u[r * 2 + j] = ub[((r * 4 + 2 * XH + j) * WKC + kp) * W10_C + boff];
+#endif
     };
     // eight MFMAs; behind MFMA 1, 3, 5, 7 one DMA piece of the next chunk: group 0 the weight pieces, group 1 the raw pieces
     auto mfmas = [&](const wn_f2 (&v)[8], int h, const float (&u)[8], int group) {
@@ -854,7 +864,11 @@ __device__ __forceinline__ void wino10_chunk(const float* __restrict__ raw, cons
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int cc = XH + c;
+#if defined(WINO_ABL) && (WINO_ABL & 1)
+            { const float f = __uint_as_float(lb[(r >> 1) * 2 + (cc >> 1)] + r * 3 + c); d[r * 3 + c] = make_float4(f, f * 2.f, f * 3.f, f * 4.f); }
+#else
             d[r * 3 + c] = *(const float4*)((const char*)raw + lb[(r >> 1) * 2 + (cc >> 1)] + (r >> 1) * 2048 + (cc & 1) * 1024 + (r & 1) * 512);
+#endif
         }
     load_u(ua, 0);
     load_u(ubb, 1);
@@ -953,8 +967,12 @@ __device__ __forceinline__ void wino10_body(const WinoArgs& args, float* smem) {
             }
             wino10_chunk<XH>(bufs + cur * W10_RAWF, bufs + 2 * W10_RAWF + cur * W10_UF, bufs + (cur ^ 1) * W10_RAWF,
                              bufs + 2 * W10_RAWF + (cur ^ 1) * W10_UF, last ? more : true, q, last ? 0 : kc + 1, lb, boff, acc);
+#if defined(WINO_ABL) && (WINO_ABL & 16)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
             if (last) lds_barrier();
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
             cur ^= 1;
         }
         const int pool_n = n0 + li;
@@ -965,8 +983,18 @@ __device__ __forceinline__ void wino10_body(const WinoArgs& args, float* smem) {
             if (more) wino9_tables(args, wino9_geo(args, itn / nnb), tid, tables + (tcur ^ 1) * 576, tables + (tcur ^ 1) * 576 + 256,
                                    tables + (tcur ^ 1) * 576 + 512);
         };
+#if defined(WINO_ABL) && (WINO_ABL & 32)
+        { float sink = 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) sink += acc[i][r];
+          if (sink == 123.456f) rowa[0] = 1; }
+        before_stores();
+#else
         wino_item_tail<XH, decltype(before_stores), 2>(args, acc, bufs + (cur ^ 1) * W10_RAWF, bufs + 2 * W10_RAWF + (cur ^ 1) * W10_UF, rowa, rowy,
                                                        prow, wave, lane, wm, 0, n0, blk, pool_bs, pool_sc, pool_sh, before_stores);
+#endif
         lds_barrier();
         tcur ^= 1;
     }

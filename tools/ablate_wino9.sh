@@ -9,7 +9,7 @@ P=asr_dfcnn_transformer_amd
 cp $P/libasrhip.so /tmp/libasrhip_good.so
 objs=$(ls $P/build/*.hip.o | grep -v wino.hip.o)
 for m in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DWINO_ABL=$m -c $P/csrc/wino.hip -o /tmp/wino_abl.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DWINO_ABL=$m ${WINO_EXTRA:-} -I include -c $P/csrc/wino.hip -o /tmp/wino_abl.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/libasrhip.so $objs /tmp/wino_abl.o
   echo "== WINO_ABL=$m" >> $out
   ONLY=${ONLY:-c} python tools/bench_wino.py 2>&1 | grep -v amdgpu.ids | cut -c1-110 >> $out
