@@ -32,7 +32,7 @@ def check_grads_fullsize(G, R, tag):
     float64 on a few tensors.  Measured with the independent torch-CPU restatement (tests/torch_transformer_ref.py) run in
     float32: on this container's CPU it differs from float64 by 7.2e-3 on enc5/wo and 4-5e-4 on the LayerNorm gains -- the
     same tensors and sizes as the HIP path -- and on the GPU box's CPU (another BLAS code path) by 2.6e-3 on enc5/wv and
-    1.9e-3 on enc_emb instead (gpurun_out/r02c/dbg2.log).  Logits, loss and predictions keep the 1e-3 / exact bars."""
+    1.9e-3 on enc_emb instead (profiles/r02c_fp32_vs_f64_gradient_conditioning.txt).  Logits, loss and predictions keep the 1e-3 / exact bars."""
     worst, worst2 = 0.0, 0.0
     for k in R:
         r, r2 = rel(G[k], R[k]), rel2(G[k], R[k])
