@@ -92,6 +92,7 @@ __device__ __forceinline__ void attn_block_coords(int H, bool longest_is_last, i
 // bit 2 of r, so that for the OTHER read pattern (ds_read_b32 of row rowidx(reg, half): 32 consecutive floats of one row) f is
 // the compile-time register index.  Rows past the end of a sequence are sent out of the buffer's range and read zeros.
 typedef __attribute__((address_space(3))) float at_lds_f;
+typedef __attribute__((address_space(3))) char at_lds_c;
 
 // The barrier that publishes a DMA'd tile: every wave first waits for ITS OWN pieces, explicitly -- hipcc does not add the
 // vmcnt(0) to this __syncthreads() by itself here (its alias analysis decides the LDS-DMA cannot matter) --, then the barrier
@@ -463,23 +464,103 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
 }
 
 // ------------------------------------------------------------------ attention backward: dQ
-template <bool CAUSAL, bool DROP>
+// Round 3: the K / V tiles arrive like the forward's (buffer-form LDS-DMA, two tile sets, 32-key tiles, one barrier per tile, three
+// workgroups per CU).  Both tiles are stored with the swizzle of at_swz: V is only read as the A operand of dP = V.dO^T
+// (ds_read_b128, row = lane); K also as the A operand of dQ += K^T.dS (ds_read_b32 of 32 consecutive floats of row
+// rowidx(reg, half)): element (R, c) of a swizzled row sits at chunk (c >> 2) ^ f(R), and f(rowidx(r, half)) = r -- so the lane's
+// byte address is its plain one XOR ((r & 7) << 4), the columns li and li + 32 are 128 bytes apart in the order bit 3 of r gives.
+#if __HIP_DEVICE_COMPILE__
+template <bool CAUSAL, bool DROP, int TK, class R>
+__device__ __forceinline__ void attn_bwd_q_tile(const float* __restrict__ Kc, const float* __restrict__ Vc, float* __restrict__ Kn,
+                                                float* __restrict__ Vn, const float* __restrict__ kb, R rk, R rv, bool more,
+                                                const unsigned (&vok)[4], long krow_next, int valid_next, int ldk, int wave, int lane,
+                                                int k0, int q0, int q, const float (&qreg)[32], const float (&doreg)[32],
+                                                floatx16 (&dq)[2], float my_lse, float my_lsl, float my_del, uint32_t drop_base,
+                                                uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
+    const int li = lane & 31, lh = lane >> 5;
+    if (more) {
+        at_tile_dma<true, TK / 16>(rk, Kn, wave, lane, vok, krow_next, valid_next, ldk);
+        at_tile_dma<true, TK / 16>(rv, Vn, wave, lane, vok, krow_next, valid_next, ldk);
+    }
+    const int fk = at_swz(li);
+#pragma unroll
+    for (int sub = 0; sub < TK / 32; ++sub) {
+        if (CAUSAL && k0 + sub * 32 > q0 + 31) continue;       // future to this whole wave: dS = 0
+        floatx16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 kv = *(const float4*)(Kc + (sub * 32 + li) * 64 + (((2 * g + lh) ^ fk) << 2));
+            const float4 vv = *(const float4*)(Vc + (sub * 32 + li) * 64 + (((2 * g + lh) ^ fk) << 2));
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qreg[g * 4 + 0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qreg[g * 4 + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qreg[g * 4 + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qreg[g * 4 + 3], s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, doreg[g * 4 + 0], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.y, doreg[g * 4 + 1], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.z, doreg[g * 4 + 2], dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.w, doreg[g * 4 + 3], dp, 0, 0, 0);
+        }
+        float kbv[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 t = *(const float4*)(kb + k0 + sub * 32 + 8 * j + 4 * lh);
+            kbv[4 * j + 0] = t.x; kbv[4 * j + 1] = t.y; kbv[4 * j + 2] = t.z; kbv[4 * j + 3] = t.w;
+        }
+        // dp <- dS / 0.125 (the 1 / sqrt(d) is applied when dQ is stored)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kl = sub * 32 + rowidx(r, lh);
+            const bool keep = (kbv[r] > 1.0e38f) && (!CAUSAL || k0 + kl <= q);       // +inf: a real key
+            float sv = s[r];
+            if (CAUSAL) sv = (k0 + kl <= q) ? sv : FILL2;
+            sv = fminf(sv, kbv[r]);
+            const float p = ex2((sv - my_lse) - my_lsl);
+            float dpe = dp[r];
+            if (DROP) dpe = drop_keep(drop_base + (uint32_t)(k0 + kl), drop_seed, drop_thr) ? dpe * drop_scale : 0.f;
+            dp[r] = keep ? p * (dpe - my_del) : 0.f;
+        }
+        // (the XOR on the 32-bit LDS address: on a generic pointer it turns the reads into flat loads)
+        const unsigned kx = (unsigned)(uintptr_t)(const at_lds_c*)((const char*)Kc + sub * 32 * 256 + lh * 1024 + li * 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned krow = (kx ^ (unsigned)((r & 7) << 4)) + ((r & 3) + 8 * (r >> 2)) * 256;
+            dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(*(const at_lds_f*)(uintptr_t)(krow + ((r & 8) ? 128 : 0)), dp[r], dq[0], 0, 0, 0);
+            dq[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(*(const at_lds_f*)(uintptr_t)(krow + ((r & 8) ? 0 : 128)), dp[r], dq[1], 0, 0, 0);
+        }
+    }
+}
+#endif
+
+template <bool CAUSAL, bool DROP, int TK>
 __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                          const float* __restrict__ V, const float* __restrict__ dO,
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
                                                          float* __restrict__ dQ, int Tq, int Tk, int C, int H, int ldq, int ldk, int relu_grad,
                                                          uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
-    __shared__ __attribute__((aligned(16))) float kv_lds[2 * 64 * KP];   // also the epilogue's transpose scratch
-    float* Ks = kv_lds;
-    float* Vs = kv_lds + 64 * KP;
-    __shared__ float kstat[64];
-    static_assert(4 * 32 * 65 <= 2 * 64 * KP, "transpose scratch must fit in the K/V tiles");
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) float at_smem[];
+    constexpr int TF = TK * 64;                          // floats of one tile
+    float* tiles = at_smem;                              // [2 sets][K TK x 64 | V TK x 64], later the epilogue's transpose scratch
+    float* kb = at_smem + (4 * TF > 4 * 32 * 65 ? 4 * TF : 4 * 32 * 65);      // [Tk rounded up to 64] key bias (min form)
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int qtile, head, n, Nn;
     attn_block_coords<CAUSAL>(H, true, qtile, head, n, Nn);
     const int hoff = head * DH;
     const int q0 = qtile * 128 + wave * 32, q = q0 + li;
     const long qbase = (long)n * Tq, kbase = (long)n * Tk;
+    int ntiles = (Tk + TK - 1) / TK;
+    if (CAUSAL) { const int lim = (qtile * 128 + 127) / TK + 1; if (lim < ntiles) ntiles = lim; }     // masked scores get no gradient
+
+    auto rk = __builtin_amdgcn_make_buffer_rsrc((void*)K, 0, (int)((((long)Nn * Tk - 1) * ldk + C) * 4), 0x00020000);
+    auto rv = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, (int)((((long)Nn * Tk - 1) * ldk + C) * 4), 0x00020000);
+    unsigned vok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) vok[i] = at_voff<true>(i, wave, lane, ldk, hoff);
+    at_tile_dma<true, TK / 16>(rk, tiles, wave, lane, vok, kbase, Tk, ldk);
+    at_tile_dma<true, TK / 16>(rv, tiles + TF, wave, lane, vok, kbase, Tk, ldk);
 
     float qreg[32], doreg[32];
     float qabs = 0.f;
@@ -501,60 +582,26 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
     const float my_lse = (q < Tq) ? lse[((long)n * H + head) * Tq + q] : INFINITY;
     const float my_lsl = (q < Tq) ? lse[(long)Nn * H * Tq + ((long)n * H + head) * Tq + q] : 0.f;
     const float my_del = (q < Tq) ? delta[((long)n * H + head) * Tq + q] : 0.f;
+    at_row_stats<0>(kb, K, kbase, Tk, (Tk + 63) / 64 * 64, ldk, hoff, tid);
 
     floatx16 dq[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+    const uint32_t drop_base = (uint32_t)(((n * H + head) * Tq + q) * Tk);
 
-    for (int k0 = 0; k0 < Tk; k0 += 64) {
-        if (CAUSAL && k0 > qtile * 128 + 127) break;     // masked scores get no gradient: nothing for dQ there
-        __syncthreads();
-        stage_tile(Ks, K, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, kstat, 2);
-        stage_tile(Vs, V, kbase, k0, 64, Tk, ldk, hoff, tid, 1.f, nullptr, 0);
-        __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            if (CAUSAL && k0 + sub * 32 > q0 + 31) continue;       // future to this whole wave: dS = 0
-            floatx16 s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const float4 kv = *(const float4*)(Ks + (sub * 32 + li) * KP + 8 * g + 4 * lh);
-                const float4 vv = *(const float4*)(Vs + (sub * 32 + li) * KP + 8 * g + 4 * lh);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.x, qreg[g * 4 + 0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.y, qreg[g * 4 + 1], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.z, qreg[g * 4 + 2], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(kv.w, qreg[g * 4 + 3], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.x, doreg[g * 4 + 0], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.y, doreg[g * 4 + 1], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.z, doreg[g * 4 + 2], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vv.w, doreg[g * 4 + 3], dp, 0, 0, 0);
-            }
-            // dp <- dS / 0.125 (the 1 / sqrt(d) is applied when dQ is stored)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = sub * 32 + rowidx(r, lh);
-                const float kb = kstat[kl];                      // key bias (stage_tile, mode 2)
-                const bool keep = (kb == 0.f) && (!CAUSAL || k0 + kl <= q);
-                float sv = s[r];
-                if (CAUSAL) sv = (k0 + kl <= q) ? sv : FILL2;
-                sv = (kb == 0.f) ? sv : kb;
-                const float p = ex2((sv - my_lse) - my_lsl);
-                float dpe = dp[r];
-                if (DROP) dpe = drop_keep((uint32_t)(((n * H + head) * Tq + q) * Tk + k0 + kl), drop_seed, drop_thr) ? dpe * drop_scale : 0.f;
-                dp[r] = keep ? p * (dpe - my_del) : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float* krow = Ks + (sub * 32 + rowidx(r, lh)) * KP + li;
-                dq[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[0], dp[r], dq[0], 0, 0, 0);
-                dq[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[32], dp[r], dq[1], 0, 0, 0);
-            }
-        }
+    for (int j = 0; j < ntiles; ++j) {
+        const int k0 = j * TK;
+        at_dma_barrier();                                // tile j has landed, nobody reads the other set any more
+        float* cur = tiles + (j & 1) * 2 * TF;
+        float* nxt = tiles + ((j + 1) & 1) * 2 * TF;
+        const int vnext = Tk - (k0 + TK);
+        attn_bwd_q_tile<CAUSAL, DROP, TK>(cur, cur + TF, nxt, nxt + TF, kb, rk, rv, j + 1 < ntiles, vok, kbase + k0 + TK,
+                                          vnext < TK ? vnext : TK, ldk, wave, lane, k0, q0, q, qreg, doreg, dq, my_lse, my_lsl, my_del,
+                                          drop_base, drop_thr, drop_seed, drop_scale);
     }
-    __syncthreads();
-    store_tile_T(dQ, Ks + wave * (32 * 65), dq, 0.125f, qbase, q0, Tq, ldq, hoff, lane, relu_grad ? Q : nullptr);
+    at_dma_barrier();
+    store_tile_T(dQ, tiles + wave * (32 * 65), dq, 0.125f, qbase, q0, Tq, ldq, hoff, lane, relu_grad ? Q : nullptr);
+#endif
 }
 
 }  // namespace
@@ -612,11 +659,17 @@ extern "C" int asr_attention_bwd_p(const float* Q, const float* K, const float* 
     const float* dl = (const float*)delta_ws;
     const uint32_t thr = drop_threshold(dropout_rate);
     const float sc = 1.0f / (1.0f - dropout_rate);
+    // dQ kernel: the tile sets (or the epilogue's scratch) + the key bias of every key of a (sample, head); 32-bit buffer offsets
+    const size_t ldsq = (size_t)((4 * 32 * 64 > 4 * 32 * 65 ? 4 * 32 * 64 : 4 * 32 * 65) + asr_cdiv(Tk, 64) * 64) * sizeof(float);
+    if (ldsq > 160 * 1024 || (long)N * Tk * ldk * 4 >= (1L << 31)) return ASR_ERR_UNSUPPORTED;
 #define ASR_ATTN_BWD(CA, DR, GKV, GQ)                                                                                          \
     do {                                                                                                                       \
         hipLaunchKernelGGL((attn_bwd_kv_kernel<CA, DR>), GKV, dim3(256), 0, st, Q, K, V, dO, lse, dl, dK, dV, Tq, Tk, C, H,    \
                            ldq, ldk, relu_grad, thr, seed, sc);                                                                          \
-        hipLaunchKernelGGL((attn_bwd_q_kernel<CA, DR>), GQ, dim3(256), 0, st, Q, K, V, dO, lse, dl, dQ, Tq, Tk, C, H,           \
+        auto kq = attn_bwd_q_kernel<CA, DR, 32>;                                                                               \
+        static size_t have = 0;                                                                                                \
+        if (ldsq > have) { if (hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess) { (void)hipGetLastError(); return ASR_ERR_UNSUPPORTED; } have = ldsq; } \
+        hipLaunchKernelGGL(kq, GQ, dim3(256), ldsq, st, Q, K, V, dO, lse, dl, dQ, Tq, Tk, C, H,                                  \
                            ldq, ldk, relu_grad, thr, seed, sc);                                                                          \
     } while (0)
     if (dropout_rate > 0.f) {
