@@ -126,3 +126,26 @@ def test_fbank_full_length_batch_matches_oracle_and_is_ragged_safe():
         assert np.abs(feat[b, :ref.shape[0]] - ref).max() <= 2e-6
         assert np.all(feat[b, ref.shape[0]:] == 0)
     assert np.all(feat[2] == 0)          # a single frame standardises to zero
+
+
+@pytest.mark.parametrize("H,W,cin,cout", [(800, 100, 32, 64), (400, 50, 64, 128), (200, 25, 128, 128), (200, 25, 128, 256),
+                                          (200, 25, 32, 256)])
+def test_winograd_weight_gradient_equals_direct_at_layer_size(H, W, cin, cout):
+    """asr_tap_wgrad (Winograd F(3x3,2x2), wino_wgrad.hip) against asr_tap_wgrad_direct (the direct eight-wave kernels: an independent
+    implementation) on the plain DFCNN's 3x3 layer shapes at B = 8, plus the properties the training step relies on: bitwise
+    reproducible, and blind to what lies in the partials workspace."""
+    from asr_dfcnn_transformer_amd import ops
+    B = 8
+    g = torch.Generator(device='cuda').manual_seed(31)
+    x = ops.Plane(B, H, W, cin); x.set_interior(torch.randn(B, H, W, cin, device='cuda', generator=g))
+    dz = ops.Plane(B, H, W, cout); dz.set_interior(torch.randn(B, H, W, cout, device='cuda', generator=g))
+    d = ops.gemm_desc(x.NP, cin, cout, cin, cout, ntaps=9, B=B, H=H, W=W)
+    ws = torch.zeros(ops.tap_wgrad_workspace(d) // 4 + 64, device='cuda')
+    dw0, dw1, dw2 = (torch.zeros(9 * cin * cout, device='cuda') for _ in range(3))
+    ops.tap_wgrad(d, x, dz, cout, dw0, ws, direct=True)
+    ops.tap_wgrad(d, x, dz, cout, dw1, ws)
+    ws.fill_(float('nan'))                                   # every partial the reduce reads is written by this launch
+    ops.tap_wgrad(d, x, dz, cout, dw2, ws)
+    scale = dw0.abs().max().item()
+    assert (dw1 - dw0).abs().max().item() < 1e-5 * scale
+    assert torch.equal(dw1, dw2)
