@@ -484,7 +484,7 @@ struct Wino9Dma {
     unsigned sbase;          // byte offset of the region's first pixel (channel 0)
     unsigned off_u;
     int npieces, wave, rowbytes, N;
-    long ustride_xi;
+    unsigned ustride_xi;     // floats between the weight matrices of two positions (16 K N floats < 2^30)
 };
 
 // per-lane offsets of the raw pieces this wave issues (piece p = wave + 8 j: pixel row p >> 1 of the region, parity p & 1)
@@ -529,7 +529,7 @@ __device__ __forceinline__ void wino9_u_piece(const Wino9Dma<R>& q, float* __res
     return;
 #endif
     __builtin_amdgcn_raw_ptr_buffer_load_lds(q.ru, (wn_lds_f*)(ub + p * 256), 16, q.off_u,
-                                             (int)((xi * q.ustride_xi + (long)(kc * WKC + cig * 4) * q.N) * 4), 0, 0);
+                                             (int)((xi * q.ustride_xi + (unsigned)((kc * WKC + cig * 4) * q.N)) * 4u), 0, 0);
 }
 
 // One 8-channel chunk (half hh of its super-chunk) in two phases.  Phase A: the LDS reads of the chunk (12 patch pixels, the
@@ -671,7 +671,7 @@ __device__ __forceinline__ void wino9_body(const WinoArgs& args, float* smem) {
     auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7FFFFFF0, 0x00020000);
     auto ru = __builtin_amdgcn_make_buffer_rsrc((void*)args.Ut, 0, 0x7FFFFFF0, 0x00020000);
     Wino9Dma<decltype(ra)> q;
-    q.ra = ra; q.ru = ru; q.wave = wave; q.rowbytes = g.WP * g.lda * 4; q.N = g.N; q.ustride_xi = (long)g.K * g.N;
+    q.ra = ra; q.ru = ru; q.wave = wave; q.rowbytes = g.WP * g.lda * 4; q.N = g.N; q.ustride_xi = (unsigned)(g.K * g.N);
     int rcur = 0, ucur = 0, tcur = 0;                // raw set of the current super-chunk, weight set of the current chunk, table set
     {
         const int it = item_of(w);
@@ -827,7 +827,7 @@ __device__ __forceinline__ void wino10_u_piece(const Wino9Dma<R>& q, float* __re
     return;
 #endif
     __builtin_amdgcn_raw_ptr_buffer_load_lds(q.ru, (wn_lds_f*)(ub + xi * 256), 16, q.off_u,
-                                             (int)((xi * q.ustride_xi + (long)(kc * WKC) * q.N) * 4), 0, 0);
+                                             (int)((xi * q.ustride_xi + (unsigned)(kc * WKC * q.N)) * 4u), 0, 0);
 }
 
 template <int XH, class R>
@@ -915,7 +915,7 @@ __device__ __forceinline__ void wino10_body(const WinoArgs& args, float* smem) {
     auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7FFFFFF0, 0x00020000);
     auto ru = __builtin_amdgcn_make_buffer_rsrc((void*)args.Ut, 0, 0x7FFFFFF0, 0x00020000);
     Wino9Dma<decltype(ra)> q;
-    q.ra = ra; q.ru = ru; q.wave = wave; q.rowbytes = g.WP * g.lda * 4; q.N = g.N; q.ustride_xi = (long)g.K * g.N;
+    q.ra = ra; q.ru = ru; q.wave = wave; q.rowbytes = g.WP * g.lda * 4; q.N = g.N; q.ustride_xi = (unsigned)(g.K * g.N);
     auto u_offset = [&](int n0) { return (unsigned)(((long)(lane >> 3) * g.N + n0 + (lane & 7) * 4) * 4); };
     int cur = 0, tcur = 0;
     {
