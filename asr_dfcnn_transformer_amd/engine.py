@@ -264,6 +264,7 @@ class DFCNNEngine:
         self.fdesc, self.bdesc, self.wdesc = {}, {}, {}
         ws_bytes = 1 << 20
         self.splitk = {}
+        self.dsplitk = {}
         consumers = {}
         for op in self.g:
             srcs = [op[1]] if op[0] != 'se' else [op[1], op[2]]
@@ -324,6 +325,12 @@ class DFCNNEngine:
                 if cout <= 128 and cin >= 2048 and cin % 256 == 0:
                     self.splitk[dst] = 8
                     ws_bytes = max(ws_bytes, ops.tap_gemm_splitk_workspace(self.fdesc[dst], 8))
+                # the mirror case in the backward pass: the data-gradient of a wide layer over a narrow input (128 -> 1536:
+                # dX [rows][128] = dZ [rows][1536] . W^T is 50 tiles of 128 x 128 with a 1536-deep contraction -- 103 us on 50 CUs)
+                # runs as the same split-K GEMM on the transposed kernel the forward pass keeps anyway (self.wT)
+                if cin <= 128 and cout >= 1024 and cout % 256 == 0 and src != 'x':
+                    self.dsplitk[dst] = ops.gemm_desc(rows, cout, cin, cout, cin, 0, cin, ntaps=1)
+                    ws_bytes = max(ws_bytes, ops.tap_gemm_splitk_workspace(self.dsplitk[dst], 8))
         self.T8 = self.res[self.g[-1][2]][0]
         T8, V = self.T8, self.V
         self.logits = torch.zeros(T8, B, V, dtype=torch.float32, device=dev)      # self.logits of the reference
@@ -686,7 +693,10 @@ class DFCNNEngine:
                 rows = dz.shape[0]
                 ops.tap_wgrad(self.wdesc[dst], self.flat[src], dz, cout, self.gview(dst, 'w'), self.ws)
                 ops.colsum(dz, rows, cout, cout, self.gview(dst, 'b'), self.ws)
-                ops.tap_gemm(self.bdesc[dst], dz, self.p(dst, 'w'), None, None, None, None, self.dflat[src])
+                if dst in self.dsplitk and dst in self.wT:
+                    ops.tap_gemm_splitk(self.dsplitk[dst], dz, self.wT[dst], None, None, None, None, self.dflat[src], 8, self.ws)
+                else:
+                    ops.tap_gemm(self.bdesc[dst], dz, self.p(dst, 'w'), None, None, None, None, self.dflat[src])
                 dense_pending -= 1
                 if dense_pending == 0 and on_dense_grads_ready is not None:
                     on_dense_grads_ready()
