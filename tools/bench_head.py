@@ -1,5 +1,8 @@
+"""The dense-head GEMMs of the DFCNN graphs (6400 rows = 32 utterances x 200 frames) in the three directions, as the library routes
+them (asr_tap_gemm_nt / asr_tap_gemm wmode 1 / asr_tap_wgrad): time and TFLOP/s.  The narrow ones are what the engine runs split-K."""
 import sys, torch
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from asr_dfcnn_transformer_amd import ops
 def timeit(fn, iters=20):
     fn(); fn(); torch.cuda.synchronize()
