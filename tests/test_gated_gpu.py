@@ -63,3 +63,48 @@ def test_gated_data_gradient_equals_gemm_then_prologue(pool, ntaps, acc, B, Hq, 
     ops.tap_gemm_gated(d, dzk, wop, ntaps == 9, pool, a, sc, sh, prev if acc else None, again, dsc2, dsh2, db2, ws2)
     torch.cuda.synchronize()
     assert torch.equal(again.interior(), dz.interior()) and torch.equal(dsc, dsc2) and torch.equal(dsh, dsh2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("pool,acc,B,Hq,Wq,N,K", [
+    (0, 0, 2, 20, 50, 64, 128), (2, 1, 2, 10, 25, 64, 64),          # wino9_kernel / wino10_kernel by the item count, 64-wide blocks
+    (2, 0, 2, 20, 50, 32, 64), (1, 1, 3, 10, 25, 32, 64), (0, 0, 1, 40, 25, 96, 32)])     # wino10_kernel: N % 64 == 32
+def test_gated_winograd_data_gradient_matches_the_direct_one(pool, acc, B, Hq, Wq, N, K):
+    """The same fused prologue behind the Winograd data-gradient kernels (prearranged == 2: wino9_kernel / wino10_kernel) against
+    the direct kernel (prearranged == 1): dZ to rounding (the gate decisions -- ReLU sign, max-pool winner -- come from the stored
+    activations, not from the gradient, so they are identical), channel sums to 1e-4 of their scale, borders untouched,
+    bitwise reproducible."""
+    from asr_dfcnn_transformer_amd import ops
+    from asr_dfcnn_transformer_amd.ops import Plane
+    g = torch.Generator(device='cuda').manual_seed(40 + pool + acc)
+    rnd = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    dzk = Plane(B, Hq, Wq, K); dzk.set_interior(rnd(B, Hq, Wq, K))
+    w = rnd(3, 3, N, K) * 0.1
+    gh, gw = (Hq, Wq) if pool == 0 else (2 * Hq, 2 * Wq)
+    a = Plane(B, gh, gw, N); a.set_interior(torch.relu(rnd(B, gh, gw, N)))
+    sc = 1.0 + 0.2 * rnd(N); sh = 0.1 * rnd(N)
+    prev = Plane(B, Hq, Wq, N)
+    if acc:
+        prev.set_interior(rnd(B, Hq, Wq, N))
+    d = ops.gemm_desc(dzk.NP, K, N, K, K, 0, N, ntaps=9, B=B, H=Hq, W=Wq, wmode=1, accumulate=acc)
+    assert ops.winograd_supported(d)
+    ws = torch.zeros(ops.tap_gemm_gated_workspace(d) // 4 + 64, device='cuda')
+    out = {}
+    for pre, wop in ((1, ops.arrange_weights(w, 9, K, N, K, 1)), (2, ops.winograd_weights(w, K, N, K, 1)), (2, None)):
+        if wop is None:
+            wop = out[2][4]
+        dz = Plane(B, gh, gw, N)
+        sums = [torch.zeros(N, device='cuda') for _ in range(3)]
+        ops.tap_gemm_gated(d, dzk, wop, pre, pool, a, sc, sh, prev if acc else None, dz, sums[0], sums[1], sums[2], ws)
+        torch.cuda.synchronize()
+        if pre in out:                                   # second Winograd run: bitwise reproducible
+            assert torch.equal(dz.interior(), out[pre][0].interior())
+            assert all(torch.equal(x, y) for x, y in zip(sums, out[pre][1:4]))
+        else:
+            out[pre] = (dz, sums[0], sums[1], sums[2], wop)
+    ref, got = out[1], out[2]
+    scale = max(1.0, ref[0].interior().abs().max().item())
+    assert (got[0].interior() - ref[0].interior()).abs().max().item() < 3e-5 * scale
+    assert got[0].border_abs_max() == 0.0
+    for i, name in ((1, 'dscale'), (2, 'dshift'), (3, 'dbias')):
+        err = (got[i].double() - ref[i].double()).abs().max().item()
+        assert err <= 1e-4 * max(1.0, ref[i].abs().max().item()), (name, err)
