@@ -102,6 +102,12 @@ __device__ __forceinline__ void at_dma_barrier() {
     __syncthreads();
 }
 
+// dynamic LDS rounded up to 128 bytes (the launchers allocate 128 bytes more)
+__device__ __forceinline__ float* at_lds_align(float* p) {
+    const unsigned a = (unsigned)(uintptr_t)(at_lds_c*)p;
+    return p + (((128u - (a & 127u)) & 127u) >> 2);
+}
+
 __device__ __forceinline__ int at_swz(int row) { return (row & 3) | (((row >> 3) & 3) << 2); }
 
 // per-lane byte offset of piece index i (pieces wave + 4 i) of a tile whose rows have pitch ld floats; SWZ: see above
@@ -338,7 +344,87 @@ __global__ void attn_delta_kernel(const float* __restrict__ O, const float* __re
 }
 
 // ------------------------------------------------------------------ attention backward: dK, dV
-// One wave owns 32 keys (K, V in registers); the block walks the queries in tiles of 64.
+// One wave owns 32 keys (K, V in registers); the block walks the queries in tiles of 32.  Round 3: the Q and dO tiles arrive like
+// the forward's K / V tiles (buffer-form LDS-DMA, two tile sets, one barrier per tile); both are read as MFMA A operands by row
+// (ds_read_b128, swizzled chunks) AND transposed (dV += dO^T.P, dK += Q^T.dS: ds_read_b32 with the lane's LDS address XOR
+// ((r & 7) << 4), see attn_bwd_q_tile).  The per-query statistics of a whole (sample, head) -- row reference, log2 row sum,
+// delta -- sit in LDS once; the query mask (zero rows of Q) is folded into the reference (+inf: P = 0, hence dS = 0 and no dV --
+// what multiplying dO by the mask gave).
+#if __HIP_DEVICE_COMPILE__
+template <bool CAUSAL, bool DROP, class R>
+__device__ __forceinline__ void attn_bwd_kv_tile(const float* __restrict__ Qc, const float* __restrict__ Dc, float* __restrict__ Qn,
+                                                 float* __restrict__ Dn, const float* __restrict__ lse_a, const float* __restrict__ lsl_a,
+                                                 const float* __restrict__ del_a, R rq, R rd, bool more, const unsigned (&voq)[4],
+                                                 const unsigned (&vod)[4], long qrow_next, int valid_next, int ldq, int ldd, int wave,
+                                                 int lane, int q0, int k0, int key, bool kkeep, float kfill, const float (&kreg)[32],
+                                                 const float (&vreg)[32], floatx16 (&dk)[2], floatx16 (&dv)[2], uint32_t drop_row0,
+                                                 int Tk, uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
+    const int li = lane & 31, lh = lane >> 5;
+    if (more) {
+        at_tile_dma<true, 2>(rq, Qn, wave, lane, voq, qrow_next, valid_next, ldq);
+        at_tile_dma<true, 2>(rd, Dn, wave, lane, vod, qrow_next, valid_next, ldd);
+    }
+    // these 32 queries all precede this wave's 32 keys: dS = 0, and P = exp(fill - max) = 0 unless a row's max IS the fill value
+    if (CAUSAL && q0 + 31 < k0 && !__any(lse_a[q0 + li] < -1.0e9f)) return;
+    const int fq = at_swz(li);
+    floatx16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const float4 qv = *(const float4*)(Qc + li * 64 + (((2 * g + lh) ^ fq) << 2));
+        const float4 dv4 = *(const float4*)(Dc + li * 64 + (((2 * g + lh) ^ fq) << 2));
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.x, kreg[g * 4 + 0], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.y, kreg[g * 4 + 1], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.z, kreg[g * 4 + 2], s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.w, kreg[g * 4 + 3], s, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.x, vreg[g * 4 + 0], dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.y, vreg[g * 4 + 1], dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.z, vreg[g * 4 + 2], dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.w, vreg[g * 4 + 3], dp, 0, 0, 0);
+    }
+    // per-query statistics of this half-wave's 16 queries: rows rowidx(r, lh) = {0-3, 8-11, 16-19, 24-27} + 4 lh
+    float lsv[16], llv[16], dlv[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 t0 = *(const float4*)(lse_a + q0 + 8 * j + 4 * lh);
+        const float4 t1 = *(const float4*)(lsl_a + q0 + 8 * j + 4 * lh);
+        const float4 t2 = *(const float4*)(del_a + q0 + 8 * j + 4 * lh);
+        lsv[4 * j + 0] = t0.x; lsv[4 * j + 1] = t0.y; lsv[4 * j + 2] = t0.z; lsv[4 * j + 3] = t0.w;
+        llv[4 * j + 0] = t1.x; llv[4 * j + 1] = t1.y; llv[4 * j + 2] = t1.z; llv[4 * j + 3] = t1.w;
+        dlv[4 * j + 0] = t2.x; dlv[4 * j + 1] = t2.y; dlv[4 * j + 2] = t2.z; dlv[4 * j + 3] = t2.w;
+    }
+    // rows of s / dp = queries rowidx(r, lh), column = this lane's key
+    // s <- P (as dV sees it), dp <- dS / 0.125 (the 1 / sqrt(d) is applied when dK is stored)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int q = q0 + rowidx(r, lh);
+        const bool keep = kkeep && (!CAUSAL || key <= q);
+        const float sv = keep ? s[r] : kfill;            // fill value, or -inf (p = 0) for a key past the end
+        const float p = ex2((sv - lsv[r]) - llv[r]);
+        float pd = p, dpe = dp[r];
+        if (DROP) {        // O = (P o M / (1-rate)) V: dV sees the dropped weights, dP arrives through the same mask
+            const bool dm = drop_keep(drop_row0 + (uint32_t)rowidx(r, lh) * (uint32_t)Tk, drop_seed, drop_thr);
+            pd = dm ? p * drop_scale : 0.f;
+            dpe = dm ? dpe * drop_scale : 0.f;
+        }
+        const float ds = keep ? p * (dpe - dlv[r]) : 0.f;
+        s[r] = pd; dp[r] = ds;
+    }
+    const unsigned qx = (unsigned)(uintptr_t)(const at_lds_c*)((const char*)Qc + lh * 1024 + li * 4);
+    const unsigned dx = (unsigned)(uintptr_t)(const at_lds_c*)((const char*)Dc + lh * 1024 + li * 4);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const unsigned off = (unsigned)(((r & 3) + 8 * (r >> 2)) * 256), x = (unsigned)((r & 7) << 4);
+        const unsigned a0 = (r & 8) ? 128 : 0, a1 = (r & 8) ? 0 : 128;
+        dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(*(const at_lds_f*)(uintptr_t)((dx ^ x) + off + a0), s[r], dv[0], 0, 0, 0);
+        dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(*(const at_lds_f*)(uintptr_t)((dx ^ x) + off + a1), s[r], dv[1], 0, 0, 0);
+        dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(*(const at_lds_f*)(uintptr_t)((qx ^ x) + off + a0), dp[r], dk[0], 0, 0, 0);
+        dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(*(const at_lds_f*)(uintptr_t)((qx ^ x) + off + a1), dp[r], dk[1], 0, 0, 0);
+    }
+}
+#endif
+
 template <bool CAUSAL, bool DROP>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                           const float* __restrict__ V, const float* __restrict__ dO,
@@ -346,18 +432,55 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
                                                           float* __restrict__ dK, float* __restrict__ dV,
                                                           int Tq, int Tk, int C, int H, int ldq, int ldk, int relu_grad,
                                                           uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
-    constexpr int QT = 64;                       // queries staged per barrier round (two 32-row MFMA sub-tiles)
-    __shared__ __attribute__((aligned(16))) float Qs[QT * KP];
-    __shared__ __attribute__((aligned(16))) float Ds[QT * KP];
-    __shared__ float qstat[QT];
-    __shared__ float lse_s[QT], lsl_s[QT], del_s[QT];
-    __shared__ float scratch[4 * 32 * 65];
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, wave = tid >> 6;
+#if __HIP_DEVICE_COMPILE__
+    constexpr int QT = 32;                       // queries per tile
+    constexpr int TF = QT * 64;
+    extern __shared__ __attribute__((aligned(16))) float at_smem[];
+    // (128-byte aligned by hand: the transposed reads XOR bits 4-6 of the LDS address, and static LDS in front of the dynamic
+    // segment -- __syncthreads_or -- may shift its start)
+    float* tiles = (float*)(at_lds_align(at_smem));                      // [2 sets][Q QT x 64 | dO QT x 64], later the epilogue's transpose scratch
+    const int Tq64 = (Tq + 63) / 64 * 64;
+    float* lse_a = tiles + (4 * TF > 4 * 32 * 65 ? 4 * TF : 4 * 32 * 65);      // [Tq64] each: reference (+inf: masked / past the end),
+    float* lsl_a = lse_a + Tq64;                                                 // log2 row sum, delta
+    float* del_a = lsl_a + Tq64;
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int ktile, head, n, Nn;
     attn_block_coords<CAUSAL>(H, false, ktile, head, n, Nn);      // causal: the first key tile sees every query
     const int hoff = head * DH;
     const int k0 = ktile * 128 + wave * 32, key = k0 + li;
     const long qbase = (long)n * Tq, kbase = (long)n * Tk;
+    const long lrow = ((long)n * H + head) * Tq;
+
+    // query mask (1 / 0) into del_a for the moment, then the three statistics
+    at_row_stats<1>(del_a, Q, qbase, Tq, Tq64, ldq, hoff, tid);
+    __syncthreads();
+    bool degenerate = false;                     // a query before this key block whose visible keys were all masked
+    const int kfirst_blk = ktile * 128;
+    for (int q = tid; q < Tq64; q += 256) {
+        const bool live = q < Tq && del_a[q] != 0.f;
+        const float l0 = q < Tq ? lse[lrow + q] : 0.f;
+        if (CAUSAL && q < Tq && q < kfirst_blk && l0 < -1.0e9f) degenerate = true;
+        lse_a[q] = live ? l0 : INFINITY;
+        lsl_a[q] = q < Tq ? lse[(long)Nn * H * Tq + lrow + q] : 0.f;
+    }
+    __syncthreads();                             // del_a (the mask) has been read by every thread
+    for (int q = tid; q < Tq64; q += 256) del_a[q] = q < Tq ? delta[lrow + q] : 0.f;
+    // causal: query tiles wholly before this key block only matter for such degenerate rows (dV; the common case has none)
+    int j0 = 0;
+    if (CAUSAL) { const bool any = __syncthreads_or(degenerate); if (!any) j0 = kfirst_blk / QT; }
+    const int ntiles = (Tq + QT - 1) / QT;
+
+    auto rq = __builtin_amdgcn_make_buffer_rsrc((void*)Q, 0, (int)((((long)Nn * Tq - 1) * ldq + C) * 4), 0x00020000);
+    auto rd = __builtin_amdgcn_make_buffer_rsrc((void*)dO, 0, (int)((((long)Nn * Tq - 1) * C + C) * 4), 0x00020000);
+    unsigned voq[4], vod[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { voq[i] = at_voff<true>(i, wave, lane, ldq, hoff); vod[i] = at_voff<true>(i, wave, lane, C, hoff); }
+    if (j0 < ntiles) {
+        const int v0 = Tq - j0 * QT;
+        at_tile_dma<true, 2>(rq, tiles, wave, lane, voq, qbase + j0 * QT, v0 < QT ? v0 : QT, ldq);
+        at_tile_dma<true, 2>(rd, tiles + TF, wave, lane, vod, qbase + j0 * QT, v0 < QT ? v0 : QT, C);
+    }
 
     float kreg[32], vreg[32];
     float ksum = 0.f;
@@ -381,86 +504,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
 
-    const int kfirst_blk = ktile * 128;
-    const long lrow = ((long)n * H + head) * Tq;
-    for (int q0 = 0; q0 < Tq; q0 += QT) {
-        if (CAUSAL && q0 + QT - 1 < kfirst_blk) {
-            // every score of this query tile against this key block is future-masked: dS = 0 (no dK), and P is
-            // exp(fill - max) = 0 unless a row's max IS the fill value (all of its keys masked) -- only then dV sees it
-            const int q = q0 + (tid & (QT - 1));
-            const bool degenerate = (q < Tq) && (lse[lrow + q] < -1.0e9f);
-            if (!__syncthreads_or(degenerate)) continue;
-        }
-        __syncthreads();
-        stage_tile(Qs, Q, qbase, q0, QT, Tq, ldq, hoff, tid, 1.f, qstat, 1);
-        if (tid < QT) {
-            const int q = q0 + tid;
-            lse_s[tid] = (q < Tq) ? lse[lrow + q] : INFINITY;
-            lsl_s[tid] = (q < Tq) ? lse[(long)Nn * H * Tq + lrow + q] : 0.f;
-            del_s[tid] = (q < Tq) ? delta[lrow + q] : 0.f;
-        }
-        __syncthreads();
-        // dO' = qmask * dO  (the query mask multiplies the post-softmax matrix)
-        for (int f = tid; f < QT * 16; f += 256) {
-            const int row = f >> 4, c4 = f & 15;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (q0 + row < Tq && qstat[row] != 0.f) v = *(const float4*)(dO + (qbase + q0 + row) * C + hoff + c4 * 4);
-            *(float4*)(Ds + row * KP + c4 * 4) = v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int sub = 0; sub < QT / 32; ++sub) {
-            const float* Qt = Qs + sub * 32 * KP;
-            const float* Dt = Ds + sub * 32 * KP;
-            const float* lse_t = lse_s + sub * 32; const float* lsl_t = lsl_s + sub * 32; const float* del_t = del_s + sub * 32;
-            // the same rule per wave: these 32 queries all precede this wave's 32 keys (no barrier inside this loop)
-            if (CAUSAL && q0 + sub * 32 + 31 < k0 && !__any(lse_t[li] < -1.0e9f)) continue;
-            floatx16 s, dp;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
-#pragma unroll
-            for (int g = 0; g < 8; ++g) {
-                const float4 qv = *(const float4*)(Qt + li * KP + 8 * g + 4 * lh);
-                const float4 dv4 = *(const float4*)(Dt + li * KP + 8 * g + 4 * lh);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.x, kreg[g * 4 + 0], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.y, kreg[g * 4 + 1], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.z, kreg[g * 4 + 2], s, 0, 0, 0);
-                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qv.w, kreg[g * 4 + 3], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.x, vreg[g * 4 + 0], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.y, vreg[g * 4 + 1], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.z, vreg[g * 4 + 2], dp, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_32x32x2f32(dv4.w, vreg[g * 4 + 3], dp, 0, 0, 0);
-            }
-            // rows of s/dp = queries rowidx(r, lh), column = this lane's key
-            // s <- P (as dV sees it), dp <- dS / 0.125 (the 1 / sqrt(d) is applied when dK is stored)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ql = rowidx(r, lh), q = q0 + sub * 32 + ql;
-                const bool keep = kkeep && (!CAUSAL || key <= q);
-                const float sv = keep ? s[r] : kfill;            // fill value, or -inf (p = 0) for a key past the end
-                const float p = ex2((sv - lse_t[ql]) - lsl_t[ql]);
-                float pd = p, dpe = dp[r];
-                if (DROP) {        // O = (P o M / (1-rate)) V: dV sees the dropped weights, dP arrives through the same mask
-                    const bool dm = drop_keep((uint32_t)(((n * H + head) * Tq + q) * Tk + key), drop_seed, drop_thr);
-                    pd = dm ? p * drop_scale : 0.f;
-                    dpe = dm ? dpe * drop_scale : 0.f;
-                }
-                const float ds = keep ? p * (dpe - del_t[ql]) : 0.f;
-                s[r] = pd; dp[r] = ds;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float* drow = Dt + rowidx(r, lh) * KP + li;
-                const float* qrow = Qt + rowidx(r, lh) * KP + li;
-                dv[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[0], s[r], dv[0], 0, 0, 0);
-                dv[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(drow[32], s[r], dv[1], 0, 0, 0);
-                dk[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[0], dp[r], dk[0], 0, 0, 0);
-                dk[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(qrow[32], dp[r], dk[1], 0, 0, 0);
-            }
-        }
+    for (int j = j0; j < ntiles; ++j) {
+        const int q0 = j * QT;
+        at_dma_barrier();                        // tile j has landed (and, the first time, the statistics are complete)
+        float* cur = tiles + ((j - j0) & 1) * 2 * TF;
+        float* nxt = tiles + ((j - j0 + 1) & 1) * 2 * TF;
+        const int vnext = Tq - (q0 + QT);
+        const uint32_t drop_row0 = (uint32_t)(((n * H + head) * Tq + q0) * Tk + key);
+        attn_bwd_kv_tile<CAUSAL, DROP>(cur, cur + TF, nxt, nxt + TF, lse_a, lsl_a, del_a, rq, rd, j + 1 < ntiles, voq, vod,
+                                       qbase + q0 + QT, vnext < QT ? vnext : QT, ldq, C, wave, lane, q0, k0, key, kkeep, kfill, kreg, vreg,
+                                       dk, dv, drop_row0, Tk, drop_thr, drop_seed, drop_scale);
     }
-    store_tile_T(dK, scratch + wave * (32 * 65), dk, 0.125f, kbase, k0, Tk, ldk, hoff, lane, relu_grad ? K : nullptr);
-    store_tile_T(dV, scratch + wave * (32 * 65), dv, 1.f, kbase, k0, Tk, ldk, hoff, lane, relu_grad ? V : nullptr);
+    at_dma_barrier();
+    store_tile_T(dK, tiles + wave * (32 * 65), dk, 0.125f, kbase, k0, Tk, ldk, hoff, lane, relu_grad ? K : nullptr);
+    store_tile_T(dV, tiles + wave * (32 * 65), dv, 1.f, kbase, k0, Tk, ldk, hoff, lane, relu_grad ? V : nullptr);
+#endif
 }
 
 // ------------------------------------------------------------------ attention backward: dQ
@@ -542,8 +600,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) float at_smem[];
     constexpr int TF = TK * 64;                          // floats of one tile
-    float* tiles = at_smem;                              // [2 sets][K TK x 64 | V TK x 64], later the epilogue's transpose scratch
-    float* kb = at_smem + (4 * TF > 4 * 32 * 65 ? 4 * TF : 4 * 32 * 65);      // [Tk rounded up to 64] key bias (min form)
+    float* tiles = at_lds_align(at_smem);                // [2 sets][K TK x 64 | V TK x 64], later the epilogue's transpose scratch (128-byte aligned: the XOR reads)
+    float* kb = tiles + (4 * TF > 4 * 32 * 65 ? 4 * TF : 4 * 32 * 65);      // [Tk rounded up to 64] key bias (min form)
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int qtile, head, n, Nn;
@@ -660,11 +718,17 @@ extern "C" int asr_attention_bwd_p(const float* Q, const float* K, const float* 
     const uint32_t thr = drop_threshold(dropout_rate);
     const float sc = 1.0f / (1.0f - dropout_rate);
     // dQ kernel: the tile sets (or the epilogue's scratch) + the key bias of every key of a (sample, head); 32-bit buffer offsets
-    const size_t ldsq = (size_t)((4 * 32 * 64 > 4 * 32 * 65 ? 4 * 32 * 64 : 4 * 32 * 65) + asr_cdiv(Tk, 64) * 64) * sizeof(float);
+    const size_t ldsq = (size_t)((4 * 32 * 64 > 4 * 32 * 65 ? 4 * 32 * 64 : 4 * 32 * 65) + asr_cdiv(Tk, 64) * 64 + 32) * sizeof(float);
     if (ldsq > 160 * 1024 || (long)N * Tk * ldk * 4 >= (1L << 31)) return ASR_ERR_UNSUPPORTED;
+    // dK / dV kernel: the Q / dO tile sets (or the scratch) + three statistics per query of a (sample, head)
+    const size_t ldskv = (size_t)((4 * 32 * 64 > 4 * 32 * 65 ? 4 * 32 * 64 : 4 * 32 * 65) + 3 * asr_cdiv(Tq, 64) * 64 + 32) * sizeof(float);
+    if (ldskv > 160 * 1024 || (long)N * Tq * ldq * 4 >= (1L << 31) || (long)N * Tq * C * 4 >= (1L << 31)) return ASR_ERR_UNSUPPORTED;
 #define ASR_ATTN_BWD(CA, DR, GKV, GQ)                                                                                          \
     do {                                                                                                                       \
-        hipLaunchKernelGGL((attn_bwd_kv_kernel<CA, DR>), GKV, dim3(256), 0, st, Q, K, V, dO, lse, dl, dK, dV, Tq, Tk, C, H,    \
+        auto kkv = attn_bwd_kv_kernel<CA, DR>;                                                                                 \
+        static size_t havekv = 0;                                                                                              \
+        if (ldskv > havekv) { if (hipFuncSetAttribute((const void*)kkv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldskv) != hipSuccess) { (void)hipGetLastError(); return ASR_ERR_UNSUPPORTED; } havekv = ldskv; } \
+        hipLaunchKernelGGL(kkv, GKV, dim3(256), ldskv, st, Q, K, V, dO, lse, dl, dK, dV, Tq, Tk, C, H,                          \
                            ldq, ldk, relu_grad, thr, seed, sc);                                                                          \
         auto kq = attn_bwd_q_kernel<CA, DR, 32>;                                                                               \
         static size_t have = 0;                                                                                                \
