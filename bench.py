@@ -694,7 +694,7 @@ def main():
             rf['measured'] = 'HIP events on the launch stream inside the timed region (%d launches); the kernel runs alone there' % roof['launches']
         else:
             rf['measured'] = ('HIP events on the launch stream in %d single-stream steps after the timed region (%d launches): in the '
-                              'real step this kernel runs on the second stream beside the data-gradients, where a launch took '
+                              'real step this kernel overlaps the kernels of the other backward stream (data-gradients on the main stream, weight gradients on the second), where a launch took '
                               '%.1f us on average (overlapped, not a per-kernel figure)'
                               % (roof_steps, roof['launches'], timed[dom]['avg_us']))
         # the committed PMC pass was taken on the default configuration only
