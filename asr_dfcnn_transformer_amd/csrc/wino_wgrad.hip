@@ -54,7 +54,6 @@ struct WwArgs {
 };
 
 __device__ __forceinline__ void ww_barrier_dma() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-__device__ __forceinline__ void ww_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #if __HIP_DEVICE_COMPILE__
 struct WwStage { int b, row0, tj0, w; };
