@@ -31,6 +31,11 @@ typedef __attribute__((address_space(3))) float ww_lds_f;
 typedef float ww_f2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) char ww_lds_c;
 
+#ifndef WW_SLOT
+// where a DMA piece of the next stage goes between the eight MFMAs of a tile pair: two per pair (measured: four per pair -3 %,
+// three -4 %, one -3..-5 %)
+#define WW_SLOT(i) ((i) == 3 || (i) == 7)
+#endif
 constexpr int WW_MAXW = 13;          // tile columns of a column block
 constexpr int WW_ZP = 28;            // pixel pitch of a staged gradient row (2 w <= 26)
 
@@ -179,7 +184,7 @@ __device__ __forceinline__ void ww_compute(const WwArgs& a, const char* __restri
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i].x, z[i].x, acc[i], 0, 0, 0);
-            if (i == 3 || i == 7) {
+            if (WW_SLOT(i)) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (more && jn < NJ) ww_piece<CINB>(a, sn, rx, rz, nxt, wave, jn, cin0, co0, vox, voz, pxx, pxz);
                 ++jn;
@@ -190,7 +195,7 @@ __device__ __forceinline__ void ww_compute(const WwArgs& a, const char* __restri
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i].y, z[i].y, acc[i], 0, 0, 0);
-                if (i == 3 || i == 7) {
+                if (WW_SLOT(i)) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (more && jn < NJ) ww_piece<CINB>(a, sn, rx, rz, nxt, wave, jn, cin0, co0, vox, voz, pxx, pxz);
                     ++jn;
