@@ -11,6 +11,8 @@ SHAPES = [('c2 800x100 32->64', 800, 100, 32, 64), ('c2_1 400x50 64->64', 400, 5
           ('c4 200x25 128->128', 200, 25, 128, 128), ('c6 200x25 128->256', 200, 25, 128, 256), ('c5 200x25 32->256', 200, 25, 32, 256)]
 if os.environ.get('ONLY'):
     SHAPES = [s for s in SHAPES if s[0].startswith(os.environ['ONLY'])]
+if os.environ.get('SHAPE'):                      # SHAPE=H,W,cin,cout[;H,W,cin,cout...]  (batch from B)
+    SHAPES = [('%sx%s %s->%s' % tuple(t.split(',')),) + tuple(int(v) for v in t.split(',')) for t in os.environ['SHAPE'].split(';')]
 
 
 def timeit(fn, iters=10):
