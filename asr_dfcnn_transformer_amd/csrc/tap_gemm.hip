@@ -683,9 +683,15 @@ extern "C" int asr_tap_gemm_wino_gated_launch(const asr_gemm_desc* d, const floa
                                               float* dz_out, float* partials, int* rows, void* stream);      // wino.hip
 
 // Data-gradient GEMM whose epilogue IS the backward prologue of the cell in front (tap_epilogue_gated).
+extern "C" int asr_winograd_gate_rows(const asr_gemm_desc* d);                                              // wino.hip
+static int gated_partial_rows(const asr_gemm_desc* d) {
+    int rows = asr_cdiv(d->M, 32) + 4;                        // every direct launch configuration has >= 32 tile rows per wave row (+ the ragged last tile)
+    const int wr = asr_winograd_gate_rows(d);                 // the Winograd kernels: 4 per tile block (more on planes of few tile rows)
+    return wr > rows ? wr : rows;
+}
 extern "C" size_t asr_tap_gemm_gated_workspace(const asr_gemm_desc* d) {
     if (!d) return 0;
-    const int rows = asr_cdiv(d->M, 32) + 4;                  // every launch configuration has >= 32 tile rows per wave row (+ the ragged last tile)
+    const int rows = gated_partial_rows(d);
     return ((size_t)rows * 3 * d->N + asr_reduce::colsum_tmp_floats(rows, 3 * d->N)) * sizeof(float);
 }
 
@@ -708,7 +714,7 @@ extern "C" int asr_tap_gemm_gated(const asr_gemm_desc* d, const float* dZ, const
                  : prearranged ? tap_gemm_pw_impl(d, dZ, W, nullptr, bn_scale, bn_shift, nullptr, (float*)dy_prev, stream, &gs)
                                : tap_gemm_impl(d, dZ, W, nullptr, bn_scale, bn_shift, nullptr, (float*)dy_prev, stream, &gs);
     if (rc != ASR_OK) return rc;
-    if (rows <= 0 || rows > asr_cdiv(d->M, 32) + 4) return ASR_ERR_UNSUPPORTED;
+    if (rows <= 0 || rows > gated_partial_rows(d)) return ASR_ERR_UNSUPPORTED;
     asr_reduce::Multi m;
     m.nseg = 3; m.width[0] = d->N; m.width[1] = d->N; m.width[2] = d->N; m.width[3] = 0;
     m.out[0] = dscale; m.out[1] = dshift; m.out[2] = dbias; m.out[3] = nullptr;

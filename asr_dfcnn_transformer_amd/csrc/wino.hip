@@ -373,7 +373,7 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
                 const int rr = (int)(t - (long)b * per);
                 const int ti = rr / args.TW, tj = rr - ti * args.TW;
                 const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
-                if (ww <= g.Wd) {
+                if (ww <= g.Wd && hh <= g.H) {
                     ra = (int)((long)b * g.HPWP + (long)hh * g.WP + ww);
                     ry = g.y_unpadded ? ((b * g.H + hh - 1) * g.Wd + ww - 1) : ra;
                 }
@@ -623,7 +623,7 @@ __device__ __forceinline__ void wino9_tables(const WinoArgs& args, const Wino9Ge
         int ra_ = -1, ry = -1;
         if (ti < args.TH) {
             const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
-            if (ww <= g.Wd) {
+            if (ww <= g.Wd && hh <= g.H) {
                 ra_ = (int)((long)e.b * g.HPWP + (long)hh * g.WP + ww);
                 ry = g.y_unpadded ? ((e.b * g.H + hh - 1) * g.Wd + ww - 1) : ra_;
             }
@@ -1052,15 +1052,36 @@ static int wino_column_blocks(int TW, int* tj0, int* cw) {
     return 0;
 }
 
+// An odd plane height is one half-filled last tile row: its second pixel row is the zero border under the image (rows beyond it
+// are sent out of range / never enter a stored pixel) and the row tables carry no entry for it, as for the last column of an
+// odd width.  The input plane is read through 32-bit offsets (buffer-form DMA with num_records 0x7FFFFFF0 in wino9 / wino10 --
+// offsets past it read zeros by design --, 32-bit lane offsets in wino8): planes of 2 GiB or more are refused here and stay
+// on the direct kernels (asr_tap_gemm_pw), which address with 64 bits.
 extern "C" int asr_winograd_supported(const asr_gemm_desc* d) {
-    if (!(d && d->ntaps == 9 && d->H > 0 && (d->H & 1) == 0 && d->W >= 2 && (d->K % WKC) == 0 && (d->lda & 3) == 0 &&
+    if (!(d && d->ntaps == 9 && d->H > 0 && d->W >= 2 && (d->K % WKC) == 0 && (d->lda & 3) == 0 &&
           d->M == d->B * (d->H + 1) * (d->W + 1))) return 0;
+    if ((long)d->M * d->lda * 4 >= 0x7FFFFFF0L || (long)16 * d->K * d->N * 4 >= 0x7FFFFFF0L) return 0;
     if ((d->N % WC) == 0) return 1;
     // 32-wide channel blocks: wino10_kernel only (column-blocked tile order)
     return (d->N % W10_C) == 0 && d->N <= 2048 && wino_column_blocks((d->W + 1) / 2, nullptr, nullptr) > 0;
 }
 
 struct WinoGate { int mode, H, W; const float* a; float* dz; float* part; int* rows; };
+
+// Tile-block count of a launch (work items along the pixel axis): B x items per image in the column-blocked order, else
+// ceil(tiles / 64).  A gated launch writes 4 partial rows per tile block (asr_tap_gemm_gated_workspace sizes its buffer with it:
+// planes of a few tile rows have mostly empty items, so this can exceed the direct kernels' M / 32 rows).
+static int wino_tile_blocks(const asr_gemm_desc* d) {
+    const int TH = (d->H + 1) / 2, TW = (d->W + 1) / 2;
+    int cw[8], tj0[8];
+    const int ncb = wino_column_blocks(TW, tj0, cw);
+    if (!ncb) return asr_cdiv((long)d->B * TH * TW, WT);
+    int it = 0;
+    for (int c = 0; c < ncb; ++c) it += asr_cdiv(TH * cw[c], WT);
+    const int blocked = d->B * it, plain = asr_cdiv((long)d->B * TH * TW, WT);
+    return blocked > plain ? blocked : plain;            // (wino8_kernel's plain order is the fallback of a blocked geometry)
+}
+extern "C" int asr_winograd_gate_rows(const asr_gemm_desc* d) { return asr_winograd_supported(d) ? 4 * wino_tile_blocks(d) : 0; }
 
 static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale, const float* shift,
                      float* out_a, float* out_y, void* stream, const WinoGate* gs, float* pool_y = nullptr, int pool_mode = 0) {
@@ -1081,7 +1102,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     a.gate_mode = 0; a.gate_H = a.gate_W = 0; a.gate_a = nullptr; a.gate_dz = nullptr; a.gate_part = nullptr; a.gate_rows = nullptr;
     if (gs) { a.gate_mode = gs->mode; a.gate_H = gs->H; a.gate_W = gs->W; a.gate_a = gs->a; a.gate_dz = gs->dz; a.gate_part = gs->part; a.gate_rows = gs->rows; }
     w.Ut = Ut;
-    w.TH = d->H / 2; w.TW = (d->W + 1) / 2;
+    w.TH = (d->H + 1) / 2; w.TW = (d->W + 1) / 2;
     w.ntiles = (long)d->B * w.TH * w.TW;
     w.wodd = d->W & 1;
     w.pool_y = pool_y; w.pool_mode = pool_mode; w.H2 = d->H / 2; w.W2 = d->W / 2;

@@ -358,11 +358,13 @@ struct WwPlan { bool ok; int cinb, ncb, cbw[8], cbt[8], SR, nstages, nbp, ncob, 
 WwPlan ww_plan(const asr_gemm_desc* d, int ldz) {
     WwPlan p;
     p.ok = false; p.ws = 0;
-    if (!d || d->ntaps != 9 || d->wmode != 0 || d->H < 2 || d->W < 2 || (d->H & 1)) return p;
+    // (an odd height is a half-filled last tile row: the gradient row under the image is the zero border, rows past it are sent
+    // out of range -- ww_piece's `row > a.H` -- so the phantom pixels contribute exact zeros)
+    if (!d || d->ntaps != 9 || d->wmode != 0 || d->H < 2 || d->W < 2) return p;
     if (d->K != 32 && (d->K % 64) != 0) return p;
     if ((d->N % 64) != 0 || (d->lda & 3) || (ldz & 3) || d->M != d->B * (d->H + 1) * (d->W + 1)) return p;
     if ((long)d->M * d->lda * 4 >= 0x7FFFFFF0L || (long)d->M * ldz * 4 >= 0x7FFFFFF0L) return p;
-    const int TH = d->H / 2, TW = (d->W + 1) / 2;
+    const int TH = (d->H + 1) / 2, TW = (d->W + 1) / 2;
     p.cinb = d->K == 32 ? 32 : 64;
     p.ncb = asr_cdiv(TW, WW_MAXW);
     if (p.ncb > 8) return p;

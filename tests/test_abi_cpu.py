@@ -91,3 +91,41 @@ def test_size_helpers_and_argument_checks_without_a_gpu():
     assert lib.asr_arrange_weights(null, 9, 64, 128, 128, 0, null, null) < 0
     assert lib.asr_tap_gemm(C.byref(d), null, null, null, null, null, null, null, null) < 0
     assert lib.asr_ctc_loss(null, 8, 2, 9, null, 64, null, null, 8, null, null, null, null, null) < 0
+
+
+def test_winograd_predicate_odd_heights_and_the_2_gib_bound():
+    """asr_winograd_supported (csrc/wino.hip) is a pure function of the descriptor: odd plane heights are Winograd shapes since
+    round 4 (T_pad 1000 -> 125 x 25 planes), and an input plane of 2 GiB or more is refused -- wino9 / wino10 read it through
+    buffer-form DMA with num_records 0x7FFFFFF0 and 32-bit offsets, where an out-of-range read returns zeros without an error;
+    such layers stay on the direct kernels (64-bit addressing).  The 1600 x 200 x 32 plane of the full-size model crosses the
+    bound between B = 52 and B = 53."""
+    from asr_dfcnn_transformer_amd import ops
+
+    def desc(B, H, W, K, N, wmode=0):
+        return ops.gemm_desc(B * (H + 1) * (W + 1), K, N, K, N if wmode == 0 else K, N, N, ntaps=9, B=B, H=H, W=W, wmode=wmode)
+
+    assert ops.winograd_supported(desc(32, 200, 25, 128, 128))
+    assert ops.winograd_supported(desc(32, 125, 25, 128, 128))                     # odd height
+    assert ops.winograd_supported(desc(32, 125, 25, 256, 32, wmode=1))             # ... on the 32-wide channel blocks too
+    assert ops.winograd_supported(desc(2, 7, 5, 8, 64)) and ops.winograd_supported(desc(2, 1, 25, 32, 64))
+    assert not ops.winograd_supported(desc(2, 7, 5, 12, 64))                       # K % 8
+    assert not ops.winograd_supported(desc(2, 7, 5, 8, 48))                        # N % 32
+    assert 52 * 1601 * 201 * 32 * 4 < 0x7FFFFFF0 <= 53 * 1601 * 201 * 32 * 4
+    assert ops.winograd_supported(desc(52, 1600, 200, 32, 64))
+    assert not ops.winograd_supported(desc(53, 1600, 200, 32, 64))                 # 2 GiB input plane
+    assert 103 * 801 * 101 * 64 * 4 < 0x7FFFFFF0 <= 104 * 801 * 101 * 64 * 4
+    assert not ops.winograd_supported(desc(104, 800, 100, 64, 128))                # [B][801][101][64] at B = 104
+    assert ops.winograd_supported(desc(103, 800, 100, 64, 128))
+    # the weight-gradient route has the same bound (ww_plan): the Winograd workspace is only counted below it
+    import ctypes as C
+    from asr_dfcnn_transformer_amd import _lib
+    lib = _lib.load()
+    small, big = desc(52, 1600, 200, 32, 64), desc(53, 1600, 200, 32, 64)
+    assert lib.asr_tap_wgrad_workspace(C.byref(small)) > 0 and lib.asr_tap_wgrad_workspace(C.byref(big)) > 0
+    # a gated Winograd launch writes 4 partial rows per tile block; planes of few tile rows have mostly empty blocks, and the
+    # workspace helper must cover them (it used to assume the direct kernels' M / 32 rows)
+    for B, H, W in ((8, 2, 25), (8, 1, 25), (4, 125, 25), (32, 200, 25)):
+        d = desc(B, H, W, 64, 64, wmode=1)
+        TH, TW = (H + 1) // 2, (W + 1) // 2
+        blocks = B * -(-TH * TW // 64)
+        assert lib.asr_tap_gemm_gated_workspace(C.byref(d)) >= 4 * blocks * 3 * 64 * 4

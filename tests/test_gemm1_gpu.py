@@ -20,6 +20,18 @@ def _rand(shape, gen, scale=1.0):
     return torch.randn(*shape, device='cuda', generator=gen) * scale
 
 
+def _f64(t):
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def _host_ref(a, w, bias=None, relu=False):
+    """float64 reference computed on the HOST with numpy (the GPU's own BLAS is not the oracle)."""
+    r = _f64(a) @ _f64(w)
+    if bias is not None:
+        r = r + _f64(bias)
+    return np.maximum(r, 0.0) if relu else r
+
+
 @pytest.mark.parametrize("M,K,N", [(6144, 512, 1024), (6150, 512, 1028), (6144, 100, 1024), (8192, 6348, 768), (49 * 128, 32, 1024),
                                    (6144, 36, 1024)])
 def test_forward_on_transposed_kernel(ops, M, K, N):
@@ -34,9 +46,9 @@ def test_forward_on_transposed_kernel(ops, M, K, N):
     d = ops.gemm_desc(M, K, N, K, N, 0, N, ntaps=1, relu=1)
     ops.tap_gemm_nt(d, a, w, wt, K, bias, None, None, None, y)
     assert ops.last_kernel().startswith('gemm1_kernel<0>'), ops.last_kernel()
-    ref = torch.relu(a.double() @ w.double() + bias.double())
-    err = (y.double() - ref).abs().max().item()
-    assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
+    ref = _host_ref(a, w, bias, relu=True)                               # float64 on the host (numpy), not a GPU library
+    err = np.abs(y.cpu().numpy().astype(np.float64) - ref).max()
+    assert err < 1e-5 * max(1.0, np.abs(ref).max()), err
     y2 = torch.zeros(M, N, device='cuda')
     ops.tap_gemm_nt(d, a, w, wt, K, bias, None, None, None, y2)
     assert torch.equal(y, y2)                                            # deterministic
@@ -44,7 +56,7 @@ def test_forward_on_transposed_kernel(ops, M, K, N):
     y3 = torch.zeros(M, N, device='cuda')
     ops.tap_gemm(d, a, w, bias, None, None, None, y3)
     assert not ops.last_kernel().startswith('gemm1')
-    assert (y - y3).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    assert (y - y3).abs().max().item() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("M,Kout,N", [(6144, 1024, 512), (8192, 768, 6348), (6200, 1028, 516)])
@@ -57,8 +69,8 @@ def test_data_gradient_routes_to_the_dma_kernel(ops, M, Kout, N):
     d = ops.gemm_desc(M, N, Kout, N, N, 0, Kout, ntaps=1, wmode=1, accumulate=1)
     ops.tap_gemm(d, dy, w, None, None, None, None, dx)
     assert ops.last_kernel().startswith('gemm1_kernel<1>'), ops.last_kernel()
-    ref = dy.double() @ w.double().t() + 1.0
-    assert (dx.double() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    ref = _host_ref(dy, w.t(), None) + 1.0
+    assert np.abs(dx.cpu().numpy().astype(np.float64) - ref).max() < 1e-5 * max(1.0, np.abs(ref).max())
 
 
 def test_column_blocks_of_wider_matrices(ops):
@@ -73,8 +85,8 @@ def test_column_blocks_of_wider_matrices(ops):
     d = ops.gemm_desc(M, 2 * C, C, 3 * C, 3 * C, 0, C + 64, ntaps=1, wmode=1)
     ops.tap_gemm(d, big.view(-1)[C:], W3.view(-1)[C:], None, None, None, None, out)
     assert ops.last_kernel().startswith('gemm1_kernel<1>')
-    ref = big[:, C:].double() @ W3[:, C:].double().t()
-    assert (out[:, :C].double() - ref).abs().max().item() < 1e-5 * max(1.0, ref.abs().max().item())
+    ref = _host_ref(big[:, C:], W3[:, C:].t())
+    assert np.abs(_f64(out[:, :C]) - ref).max() < 1e-5 * max(1.0, np.abs(ref).max())
     assert float(out[:, C:].abs().max()) == 0.0                          # nothing written past N
 
 
@@ -86,7 +98,7 @@ def test_small_problems_keep_the_register_staged_kernels(ops):
     d = ops.gemm_desc(640, 512, 512, 512, 512, 0, 512, ntaps=1)
     ops.tap_gemm_nt(d, a, w, wt, 512, None, None, None, None, y)
     assert ops.last_kernel().startswith('tap_gemm_kernel_v1')
-    assert (y.double() - a.double() @ w.double()).abs().max().item() < 1e-4
+    assert np.abs(_f64(y) - _host_ref(a, w)).max() < 1e-4
 
 
 def test_transpose_batch_ragged_shapes(ops):
@@ -114,9 +126,9 @@ def test_dense_weight_gradient(ops, M, K, N):
     dw = torch.full((K, N), 5.0, device='cuda')
     ops.tap_wgrad(d, a, dz, N, dw, ws)
     assert ops.last_kernel().startswith('wgrad1_kernel<4, 1, 1, 1>' if N <= 32 else 'wgrad1_kernel<2, 2, 2, 2>'), ops.last_kernel()
-    ref = a.double().t() @ dz.double()
-    err = (dw.double() - ref).abs().max().item()
-    assert err < 2e-6 * M ** 0.5 * max(1.0, ref.abs().max().item() / M ** 0.5), err
+    ref = _host_ref(a.t(), dz)
+    err = np.abs(_f64(dw) - ref).max()
+    assert err < 2e-6 * M ** 0.5 * max(1.0, np.abs(ref).max() / M ** 0.5), err
     dw2 = torch.zeros(K, N, device='cuda')
     ops.tap_wgrad(d, a, dz, N, dw2, ws)
     assert torch.equal(dw, dw2)
@@ -132,5 +144,5 @@ def test_dense_weight_gradient_of_a_column_block(ops):
     ws = torch.zeros(ops.tap_wgrad_workspace(d) // 4 + 64, device='cuda')
     dw = torch.zeros(C, C, device='cuda')
     ops.tap_wgrad(d, x, dqkv.view(-1)[C:], 3 * C, dw, ws)                  # the K block
-    ref = x.double().t() @ dqkv[:, C:2 * C].double()
-    assert (dw.double() - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    ref = _host_ref(x.t(), dqkv[:, C:2 * C])
+    assert np.abs(_f64(dw) - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())

@@ -135,7 +135,9 @@ def test_conv1x1_forward_and_dgrad(ops):
                                             # output channels, enough stages): two and four column blocks, odd tile-row counts, odd
                                             # widths, a one-column plane, several block pairs, 32 input channels (tile-pair halves)
                                             (4, 20, 50, 64, 64), (2, 16, 100, 32, 64), (3, 22, 27, 128, 64), (2, 36, 2, 64, 64),
-                                            (2, 26, 25, 32, 128), (1, 64, 13, 128, 128)])
+                                            (2, 26, 25, 32, 128), (1, 64, 13, 128, 128),
+                                            # odd heights on the Winograd route (round 4): the last tile row is half filled
+                                            (2, 125, 25, 64, 64), (3, 7, 50, 32, 64), (2, 25, 25, 128, 128), (16, 1, 25, 64, 64)])
 def test_conv3x3_wgrad(ops, B, H, W, cin, cout):
     rng = np.random.default_rng(4)
     x = rng.standard_normal((B, H, W, cin)).astype(np.float32)

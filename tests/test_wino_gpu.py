@@ -31,7 +31,11 @@ def conv_ref(x, w, b=None):
                                             (3, 20, 50, 64, 128), (2, 14, 27, 48, 64), (2, 30, 29, 32, 64), (1, 200, 22, 32, 64),
                                             (2, 12, 100, 32, 64), (1, 6, 200, 32, 64),
                                             # 32-wide channel blocks (wino10_kernel: four waves, two workgroups per CU)
-                                            (2, 20, 50, 64, 32), (1, 16, 25, 32, 32), (3, 14, 27, 24, 96), (2, 200, 22, 8, 32)])
+                                            (2, 20, 50, 64, 32), (1, 16, 25, 32, 32), (3, 14, 27, 24, 96), (2, 200, 22, 8, 32),
+                                            # odd plane heights (round 4; T_pad 1000 gives 125 x 25 planes): a half-filled last tile
+                                            # row on every kernel generation -- wino8 (plain order), wino9 / wino10 (column blocks)
+                                            (2, 7, 5, 8, 64), (1, 125, 25, 32, 64), (2, 25, 50, 64, 128), (1, 125, 25, 32, 32), (3, 7, 27, 16, 96),
+                                            (2, 1, 25, 32, 64), (4, 125, 25, 128, 128)])
 def test_forward_matches_tap_gemm_and_float64(ops, B, H, W, cin, cout):
     g = torch.Generator(device='cuda').manual_seed(11)
     x = ops.Plane(B, H, W, cin); xi = torch.randn(B, H, W, cin, device='cuda', generator=g); x.set_interior(xi)
@@ -76,7 +80,8 @@ def test_fused_pool_equals_conv_then_pool_bitwise(ops, pool, B, H, W, cin, cout)
     assert y1.interior().abs().sum().item() > 0
 
 
-@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 6, 5, 64, 8), (1, 12, 25, 128, 32), (3, 4, 4, 64, 16), (2, 20, 50, 64, 64), (3, 10, 23, 128, 48), (2, 20, 50, 32, 64), (1, 40, 25, 96, 256)])
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 6, 5, 64, 8), (1, 12, 25, 128, 32), (3, 4, 4, 64, 16), (2, 20, 50, 64, 64), (3, 10, 23, 128, 48), (2, 20, 50, 32, 64), (1, 40, 25, 96, 256),
+                                            (1, 125, 25, 64, 128), (2, 7, 5, 8, 64), (2, 25, 23, 32, 128), (3, 125, 25, 128, 128)])
 def test_data_gradient_view_with_accumulation(ops, B, H, W, cin, cout):
     g = torch.Generator(device='cuda').manual_seed(12)
     w = torch.randn(3, 3, cin, cout, device='cuda', generator=g) * 0.1
@@ -86,15 +91,19 @@ def test_data_gradient_view_with_accumulation(ops, B, H, W, cin, cout):
     dx0.set_interior(prev); dx1.set_interior(prev)
     bd = ops.gemm_desc(dz.NP, cout, cin, cout, cout, 0, cin, ntaps=9, B=B, H=H, W=W, wmode=1, accumulate=1)
     if not ops.winograd_supported(bd):
-        pytest.skip('N % 64 != 0 for this view')
+        pytest.skip('this view is not a Winograd shape (channel counts not multiples of 8 / 32, or no column blocks for N % 64 == 32)')
     ops.tap_gemm(bd, dz, w, None, None, None, None, dx0)
     ops.tap_gemm_wino(bd, dz, ops.winograd_weights(w, cout, cin, cout, 1), None, None, None, None, dx1)
     assert (dx1.interior() - dx0.interior()).abs().max().item() < 3e-5 * max(1.0, dx0.interior().abs().max().item() / 4)
 
 
 def test_unsupported_shapes_are_reported(ops):
-    d = ops.gemm_desc(2 * 6 * 7, 8, 32, 8, 32, 32, 0, ntaps=9, B=2, H=5, W=6)      # odd height, N % 64 != 0
+    d = ops.gemm_desc(2 * 6 * 7, 8, 32, 8, 32, 32, 0, ntaps=9, B=2, H=5, W=6)      # N % 64 == 32 with too few tile columns for a column block
     assert not ops.winograd_supported(d)
+    d = ops.gemm_desc(2 * 6 * 7, 12, 64, 12, 64, 64, 0, ntaps=9, B=2, H=5, W=6)     # K % 8 != 0
+    assert not ops.winograd_supported(d)
+    d = ops.gemm_desc(2 * 6 * 7, 8, 64, 8, 64, 64, 0, ntaps=9, B=2, H=5, W=6)       # odd height: supported since round 4
+    assert ops.winograd_supported(d)
 
 
 def test_engine_opt_in_gives_the_same_step(ops):
