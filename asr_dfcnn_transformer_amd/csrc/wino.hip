@@ -1010,6 +1010,380 @@ __global__ __launch_bounds__(256, 2) void wino10_kernel(WinoArgs args) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ wino11_kernel (round 4)
+// The same computation with a wave owning ONE ROW of the 4 x 4 transform (4 positions, 64 accumulator registers): EIGHT waves of
+// 128 registers per workgroup (wave = row * 2 + wm: 32 tiles x 32 channels x 4 positions each), 64 tiles x 32 output channels per
+// item as in wino10_kernel, two workgroups per CU -- FOUR waves per SIMD instead of two.  What that buys on this pipe, where a
+// vector instruction of any wave of a SIMD costs matrix time:
+//   * row r of V = B^T d B needs two pixel rows of the patch (0: rows 0, 2; 1 and 2: rows 1, 2; 3: rows 1, 3) and all four columns:
+//     8 ds_read_b128 and 16 v_pk_add_f32 per 16 MFMAs (wino10_kernel: 12 reads and 40 packed adds per 32, i.e. 20 per 16);
+//   * four instruction streams per SIMD: an LDS wait, a chunk barrier or an item tail of one wave leaves three others (two of
+//     them of the other workgroup) to feed the matrix pipe -- with two streams the pipe idled whenever both were held;
+//   * the item tail is light: the column combination (M A) is lane-local, the row combination (A^T .) is ONE exchange through LDS
+//     in which wave r receives the register quarter 4 r .. 4 r + 3 of all four rows -- i.e. all four pixels of eight tiles -- so
+//     the fused 2 x 2 pool is lane-local as well and every wave runs the shared epilogue on ONE 32 x 32 block (pixel-major row table).
+// DMA pieces, LDS layouts, column-blocked tile order and item flow as in wino10_kernel (two raw and two weight pieces per wave and
+// chunk).  The chunk loop is unrolled by two so that both buffer sets are immediate offsets of per-lane base registers (no address
+// arithmetic in the loop); an odd chunk count (K % 16 == 8) takes the variant with run-time set offsets.
+// The argument block is read through the kernarg segment pointer, re-derived ("laundered") in front of every item tail and of the
+// next-item set-up: hipcc otherwise keeps the ~100 argument dwords of the epilogues live in scalar registers across the chunk loop
+// and spills them to vector-register lanes (wino10_kernel: 117 scalar spills, four waterfall loops per chunk around DMA pieces
+// whose offsets ended up in vector registers).
+// Which kernel runs is decided by the layer's widths and plane geometry alone -- never by the batch or the CU count -- so an
+// utterance gives the same bits alone and inside a batch (tests/test_fullsize_gpu.py).
+constexpr int W11_SETF = 4224;                  // floats of a raw / weight set: 16 pieces of 256, padded so that four 32 x 33 transpose scratches fit
+constexpr int W11_TABF = 768;                   // ints of a table set: rowa 256 | rowy 256 | prow 256
+constexpr int W11_RAW0 = 2 * W11_TABF * 4;      // byte offsets of the four sets in the dynamic LDS segment
+constexpr int W11_U0 = W11_RAW0 + 2 * W11_SETF * 4;
+
+#if __HIP_DEVICE_COMPILE__
+typedef const __attribute__((address_space(4))) WinoArgs* wino_kernarg_p;
+// the launch's argument block, through a pointer the optimiser cannot connect with earlier loads (s_load_dword on demand)
+__device__ __forceinline__ const WinoArgs& wino_args_fresh() {
+    wino_kernarg_p p = (wino_kernarg_p)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *(const WinoArgs*)p;
+}
+
+struct W11Dma {
+    unsigned voff[2];        // raw pieces wave + 8 j
+    unsigned off_u;          // per-lane offset inside a weight piece
+    unsigned sbase;          // byte offset of the region's first pixel (channel 0)          (scalar)
+    unsigned pairbytes;      // bytes of two pixel rows of the plane                         (scalar)
+    unsigned xibytes;        // bytes between the weight matrices of two positions           (scalar)
+    unsigned chunkbytes;     // bytes of 8 input-channel rows of a weight matrix             (scalar)
+    int wave;
+};
+
+// per-lane offsets of the raw pieces this wave issues (piece p = wave + 8 j: row pair p >> 1 of the region, column parity p & 1;
+// lane = [row of the pair][channel quad][position]); positions past the block / plane and rows past the image read zeros
+__device__ __forceinline__ void wino11_offsets(const WinoArgs& args, const Wino9Geo& e, int lane, W11Dma& q) {
+    const TapGemmArgs& g = args.g;
+    const int np = e.npieces >> 1;                              // (rows + 1) row pairs x 2 parities
+    const int rowbit = lane >> 5, quad = (lane >> 4) & 1;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int p = q.wave + 8 * j, m = p >> 1, par = p & 1;
+        const int y = 2 * m + rowbit;
+        const int rho = ((e.tr0 + m) * e.w) & 15;
+        const int idx = ((lane & 15) - rho) & 15;
+        const int x = 2 * idx + par;
+        const bool ok = idx <= e.w && 2 * e.tj0 + x < g.WP && 2 * e.tr0 + y <= g.H + 1 && p < np;
+        q.voff[j] = ok ? (unsigned)(((rowbit * g.WP + x) * g.lda + quad * 4) * 4) : 0xFFFFFFF0u;
+    }
+    q.sbase = (unsigned)((((long)e.b * g.HPWP + (long)(2 * e.tr0) * g.WP + 2 * e.tj0) * g.lda) * 4);
+}
+template <class R>
+__device__ __forceinline__ void wino11_raw_piece(const W11Dma& q, R ra, int lds_set, int j, int kc) {
+    const int p = q.wave + 8 * j;
+#if defined(W11_ABL) && (W11_ABL & 4)
+    return;
+#endif
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (wn_lds_f*)(uintptr_t)(unsigned)(lds_set + p * 1024), 16, q.voff[j],
+                                             (int)(q.sbase + (unsigned)(p >> 1) * q.pairbytes + (unsigned)kc * (WKC * 4)), 0, 0);
+}
+// weight piece xi = wave + 8 j of chunk kc: [8 ci][32 co]
+template <class R>
+__device__ __forceinline__ void wino11_u_piece(const W11Dma& q, R ru, int lds_set, int j, int kc) {
+    const int xi = q.wave + 8 * j;
+#if defined(W11_ABL) && (W11_ABL & 8)
+    return;
+#endif
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (wn_lds_f*)(uintptr_t)(unsigned)(lds_set + xi * 1024), 16, q.off_u,
+                                             (int)((unsigned)xi * q.xibytes + (unsigned)kc * q.chunkbytes), 0, 0);
+}
+
+// One 8-channel chunk of transform row RR out of buffer set `cur` (CUR 0 / 1: compile-time, all LDS addresses are immediates of the
+// per-lane bases lb / ubase; CUR 2: run-time `cur`): 8 patch reads, 16 weight values (the second half requested behind the first
+// transform: 8 registers at a time), 16 packed adds, 16 MFMAs (k-pair major); behind the four MFMAs of a k-pair one DMA piece of
+// the next chunk into the other set (weights first: they are read first).
+template <int RR, int CUR, class R>
+__device__ __forceinline__ void wino11_chunk(const char* __restrict__ lds, int lds0, int cur, bool pre, const W11Dma& q, R ra, R ru, int kcn,
+                                             const unsigned (&lb)[4], unsigned ubase, floatx16 (&acc)[4]) {
+    constexpr int RA = RR == 0 ? 0 : 1, RB = RR == 3 ? 3 : 2;           // the two patch rows this transform row combines
+    const int setoff = (CUR == 2 ? cur : CUR) * (W11_SETF * 4);
+    const int nxtoff = (CUR == 2 ? cur ^ 1 : CUR ^ 1) * (W11_SETF * 4);
+    float4 da[4], db[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#if defined(W11_ABL) && (W11_ABL & 1)
+        { const float f = __uint_as_float(lb[c] + setoff); da[c] = make_float4(f, f * 2.f, f * 3.f, f * 4.f); db[c] = make_float4(f * 5.f, f * 6.f, f * 7.f, f * 8.f); }
+#else
+        da[c] = *(const float4*)(lds + lb[(RA >> 1) * 2 + (c >> 1)] + setoff + (RA >> 1) * 2048 + (c & 1) * 1024 + (RA & 1) * 512);
+        db[c] = *(const float4*)(lds + lb[(RB >> 1) * 2 + (c >> 1)] + setoff + (RB >> 1) * 2048 + (c & 1) * 1024 + (RB & 1) * 512);
+#endif
+    }
+    float u[4][4];
+    auto load_u = [&](int kp0) {
+#pragma unroll
+        for (int kp = kp0; kp < kp0 + 2; ++kp)
+#pragma unroll
+#if defined(W11_ABL) && (W11_ABL & 2)
+            for (int c = 0; c < 4; ++c) u[c][kp] = __uint_as_float(ubase + setoff + c * 4 + kp);
+#else
+            for (int c = 0; c < 4; ++c) u[c][kp] = *(const float*)(lds + ubase + setoff + ((RR * 4 + c) * WKC + kp) * (W10_C * 4));
+#endif
+    };
+    load_u(0);
+    __builtin_amdgcn_sched_barrier(0);
+    wn_f2 v[4];
+    auto transform = [&](int h) {          // row RR of B^T d for k-pairs 2 h, 2 h + 1 (one packed add each), then V = t B
+        wn_f2 t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const wn_f2 a = h == 0 ? wn_f2{da[c].x, da[c].y} : wn_f2{da[c].z, da[c].w};
+            const wn_f2 b = h == 0 ? wn_f2{db[c].x, db[c].y} : wn_f2{db[c].z, db[c].w};
+            t[c] = RR == 1 ? a + b : RR == 2 ? b - a : a - b;
+        }
+        v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+    };
+    auto mfmas = [&](int kp, int piece) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32((kp & 1) ? v[c].y : v[c].x, u[c][kp], acc[c], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (pre) {
+            if (piece < 2) wino11_u_piece(q, ru, lds0 + W11_U0 + nxtoff, piece, kcn);
+            else wino11_raw_piece(q, ra, lds0 + W11_RAW0 + nxtoff, piece - 2, kcn);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    transform(0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_u(2);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(0, 0);
+    mfmas(1, 1);
+    transform(1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(2, 2);
+    mfmas(3, 3);
+}
+
+// row tables of one item (threads 0..255: 64 tiles x 4 pixels).  Wave (row r, half wm) finishes tiles wm * 32 + 8 r .. + 7 with
+// all four pixels: its 32 x 32 epilogue block has row p * 8 + t' = pixel p of tile t' (the MFMA register q = 4 p + i holds tile
+// i + 4 lh, tap_epilogue's own register-to-row rule).  prow: rows 0..7 of a wave's block = the pooled pixel of its tiles, else -1.
+__device__ __forceinline__ void wino11_tables(const WinoArgs& args, const Wino9Geo& e, int tid, int* rowa, int* rowy, int* prow) {
+    const TapGemmArgs& g = args.g;
+    if (tid < 256) {
+        const int tl = tid & 63, pl = tid >> 6;
+        const int l = e.l0 + tl;
+        const int ti = l / e.w, tj = e.tj0 + l - ti * e.w;
+        int ra_ = -1, ry = -1;
+        if (ti < args.TH) {
+            const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
+            if (ww <= g.Wd && hh <= g.H) {
+                ra_ = (int)((long)e.b * g.HPWP + (long)hh * g.WP + ww);
+                ry = g.y_unpadded ? ((e.b * g.H + hh - 1) * g.Wd + ww - 1) : ra_;
+            }
+        }
+        const int wv = (tl >> 5) + 2 * ((tl & 31) >> 3);             // wave = row * 2 + wm
+        const int m = wv * 32 + pl * 8 + (tl & 7);
+        rowa[m] = ra_; rowy[m] = ry;
+        int pr = -1;
+        if (pl == 0 && args.pool_y && ti < args.TH && tj < args.W2 && ti < args.H2) pr = (e.b * (args.H2 + 1) + ti + 1) * (args.W2 + 1) + tj + 1;
+        prow[m] = pr;                                                // rows 8..31 of a block (pl > 0): -1
+    }
+}
+
+template <int RR>
+__device__ __forceinline__ void wino11_body(float* smem) {
+    const char* lds = (const char*)smem;
+    int* tables = (int*)smem;                        // two sets of [rowa 256 | rowy 256 | prow 256]
+    float* bufs = smem + 2 * W11_TABF;               // raw0 | raw1 | u0 | u1
+    float* pconst = bufs + 4 * W11_SETF;             // fused pool: [bias N | scale N | shift N]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // = RR * 2 + wm
+    const int wm = wave & 1;
+    const unsigned ubase = (unsigned)(W11_U0 + (lh * 4 * W10_C + li) * 4);      // half 1 contracts channels 4 .. 7 of the chunk
+    const int lds0 = (int)(unsigned)(uintptr_t)(wn_lds_f*)smem;          // LDS address of the dynamic segment (DMA destinations are absolute)
+    int nkc, nnb, nwork;
+    W11Dma q;
+    q.wave = wave;
+    int w = blockIdx.x;
+    const int G = gridDim.x;
+    auto item_of = [&](int wl) {                     // see wino8_body
+        const int r0 = (wl / G) * G;
+        if ((G & 7) || r0 + G > nwork) return wl;
+        const int p = wl - r0;
+        return r0 + (p & 7) * (G >> 3) + (p >> 3);
+    };
+    {
+        const WinoArgs& args = wino_args_fresh();
+        const TapGemmArgs& g = args.g;
+        nkc = g.K / WKC; nnb = g.ntn; nwork = g.ntm * nnb;
+        if (w >= nwork) return;
+        q.pairbytes = (unsigned)(2 * g.WP * g.lda * 4); q.xibytes = (unsigned)(g.K * g.N) * 4u; q.chunkbytes = (unsigned)(WKC * g.N) * 4u;
+    }
+    // the two buffer resources: plane and transformed weights (4 scalar registers each, live across the kernel)
+    const WinoArgs& args0 = wino_args_fresh();
+    auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)args0.g.A, 0, 0x7FFFFFF0, 0x00020000);
+    auto ru = __builtin_amdgcn_make_buffer_rsrc((void*)args0.Ut, 0, 0x7FFFFFF0, 0x00020000);
+    int tcur = 0, cur = 0;
+    {
+        const WinoArgs& args = wino_args_fresh();
+        const TapGemmArgs& g = args.g;
+        const int it = item_of(w);
+        const Wino9Geo e = wino9_geo(args, it / nnb);
+        wino11_offsets(args, e, lane, q);
+        q.off_u = (unsigned)(((lane >> 3) * g.N + (it % nnb) * W10_C + (lane & 7) * 4) * 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { wino11_raw_piece(q, ra, lds0 + W11_RAW0, j, 0); wino11_u_piece(q, ru, lds0 + W11_U0, j, 0); }
+        wino11_tables(args, e, tid, tables, tables + 256, tables + 512);
+        if (args.pool_y)
+            for (int n = tid; n < g.N; n += 512) {
+                pconst[n] = g.bias ? g.bias[n] : 0.f;
+                pconst[g.N + n] = g.scale ? g.scale[n] : 1.f;
+                pconst[2 * g.N + n] = g.shift ? g.shift[n] : 0.f;
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+    }
+    for (; w < nwork; w += G) {
+        const int item = item_of(w);
+        const int blk = item / nnb, nb = item - blk * nnb;
+        const int n0 = nb * W10_C;
+        const int wnext = w + G;
+        const bool more = wnext < nwork;
+        const int itn = more ? item_of(wnext) : 0;
+        unsigned lb[4];
+        {
+            const WinoArgs& args = wino_args_fresh();
+            const Wino9Geo e = wino9_geo(args, blk);
+            const int l = e.l0 + wm * 32 + li;
+            const int trl = l / e.w - e.tr0;
+            const unsigned fix = (unsigned)(W11_RAW0 + trl * 2048 + lh * 256);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) lb[j] = fix + (unsigned)(((l + (j >> 1) * e.w + (j & 1)) & 15) * 16);
+        }
+        floatx16 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        // the last chunk's prefetch belongs to the next item: its offsets replace this item's in front of that chunk
+        auto next_item_offsets = [&]() {
+            if (!more) return;
+            const WinoArgs& args = wino_args_fresh();
+            wino11_offsets(args, wino9_geo(args, itn / nnb), lane, q);
+            q.off_u = (unsigned)(((lane >> 3) * args.g.N + (itn % nnb) * W10_C + (lane & 7) * 4) * 4);
+        };
+        if ((nkc & 1) == 0 && cur == 0) {
+            for (int kc = 0; kc < nkc; kc += 2) {
+                wino11_chunk<RR, 0>(lds, lds0, 0, true, q, ra, ru, kc + 1, lb, ubase, acc);
+#if defined(W11_ABL) && (W11_ABL & 16)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+                const bool last = kc + 2 == nkc;
+                if (last) next_item_offsets();
+                wino11_chunk<RR, 1>(lds, lds0, 1, last ? more : true, q, ra, ru, last ? 0 : kc + 2, lb, ubase, acc);
+#if defined(W11_ABL) && (W11_ABL & 16)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#else
+                if (last) lds_barrier();
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+            }
+        } else {
+            for (int kc = 0; kc < nkc; ++kc) {
+                const bool last = kc + 1 == nkc;
+                if (last) next_item_offsets();
+                wino11_chunk<RR, 2>(lds, lds0, cur, last ? more : true, q, ra, ru, last ? 0 : kc + 1, lb, ubase, acc);
+                if (last) lds_barrier();
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                cur ^= 1;
+            }
+        }
+#if defined(W11_ABL) && (W11_ABL & 32)
+        { float sink = 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) sink += acc[i][r];
+          if (sink == 123.456f) tables[0] = 1;
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          lds_barrier(); tcur ^= 1; continue; }
+#endif
+        // ---- item tail: set `cur` is being filled for the next item, set cur ^ 1 is free
+        float* rfree = bufs + (cur ^ 1) * W11_SETF;
+        float* ufree = bufs + (2 + (cur ^ 1)) * W11_SETF;
+        float* xch = wm == 0 ? rfree : ufree;        // the four row waves of a tile half meet in one set (4096 floats per phase)
+        floatx16 out[1][1];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            // column combination (M A)[RR][j], lane-local
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pj = j == 0 ? (acc[0][r] + acc[1][r]) + acc[2][r] : (acc[1][r] - acc[2][r]) - acc[3][r];
+                xch[(RR * 16 + r) * 64 + lane] = pj;
+            }
+            lds_barrier();
+            // row combination for this wave's register quarter: Y[i][j] = sum_r A^T[i][r] (M A)[r][j]
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float p0 = xch[(0 * 16 + 4 * RR + i) * 64 + lane], p1 = xch[(1 * 16 + 4 * RR + i) * 64 + lane];
+                const float p2 = xch[(2 * 16 + 4 * RR + i) * 64 + lane], p3 = xch[(3 * 16 + 4 * RR + i) * 64 + lane];
+                out[0][0][4 * (0 * 2 + j) + i] = (p0 + p1) + p2;
+                out[0][0][4 * (1 * 2 + j) + i] = (p1 - p2) - p3;
+            }
+            lds_barrier();                           // the set is rewritten (phase 1) / becomes transpose scratch
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the next item's chunk 0 (no store is in flight yet)
+        const WinoArgs& args = wino_args_fresh();
+        const TapGemmArgs& g = args.g;
+        int* rowa = tables + tcur * W11_TABF;
+        int* rowy = rowa + 256;
+        int* prow = rowy + 256;
+        if (more) wino11_tables(args, wino9_geo(args, itn / nnb), tid, tables + (tcur ^ 1) * W11_TABF, tables + (tcur ^ 1) * W11_TABF + 256,
+                                tables + (tcur ^ 1) * W11_TABF + 512);
+        float* scratch = (wave < 4 ? rfree : ufree) + (wave & 3) * (32 * 33);
+        if (args.pool_y) {
+            // fused 2 x 2 pool: register 4 p + i = pixel p of tile i + 4 lh -- the window is lane-local.  Same arithmetic and
+            // association as asr_pool_fwd on the stored activation (bit-identical): BN(ReLU(x + bias)), row pairs, then the rows.
+            const int pool_n = n0 + li;
+            float bs = 0.f, scv = 1.f, shv = 0.f;
+            if (pool_n < g.N) { bs = pconst[pool_n]; scv = pconst[g.N + pool_n]; shv = pconst[2 * g.N + pool_n]; }
+            floatx16 po[1][1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) po[0][0][r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float vv[4];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float x = out[0][0][4 * p + i] + bs;
+                    if (g.relu == 1) x = fmaxf(x, 0.f);
+                    else if (g.relu == 2) x = tanhf(x);
+                    vv[p] = fmaf(scv, x, shv);
+                }
+                po[0][0][i] = args.pool_mode == 1 ? 0.25f * ((vv[0] + vv[1]) + (vv[2] + vv[3])) : fmaxf(fmaxf(vv[0], vv[1]), fmaxf(vv[2], vv[3]));
+            }
+            TapGemmArgs gp = g;
+            gp.out_a = args.pool_y; gp.ldo_a = g.N; gp.out_y = nullptr; gp.bias = nullptr; gp.relu = 0; gp.accumulate = 0; gp.gate_mode = 0;
+            tap_epilogue<1, 1>(gp, po, scratch, prow, prow, wave * 32, n0, lane, 0);
+        }
+        tap_epilogue<1, 1>(g, out, scratch, rowa, rowy, wave * 32, n0, lane, blk * 8 + wave);
+        lds_barrier();                               // scratch sets and this item's tables are free; the next item's tables and data visible
+        tcur ^= 1;
+    }
+}
+#endif
+
+template <int DIR>
+__global__ __launch_bounds__(512, 4) void wino11_kernel(WinoArgs args) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    switch (threadIdx.x >> 7) {
+        case 0: wino11_body<0>(smem); break;
+        case 1: wino11_body<1>(smem); break;
+        case 2: wino11_body<2>(smem); break;
+        default: wino11_body<3>(smem); break;
+    }
+#endif
+}
+
 template <int DIR>
 __global__ __launch_bounds__(512) void wino8_kernel(WinoArgs args) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1067,9 +1441,11 @@ extern "C" int asr_winograd_supported(const asr_gemm_desc* d) {
 }
 
 struct WinoGate { int mode, H, W; const float* a; float* dz; float* part; int* rows; };
+static int g_wino_gen = 11;          // DEVELOPMENT ONLY (asr_debug_wino_gen): 10 keeps the round-3 kernels for A/B timing in one process
+extern "C" void asr_debug_wino_gen(int gen) { g_wino_gen = gen; }
 
 // Tile-block count of a launch (work items along the pixel axis): B x items per image in the column-blocked order, else
-// ceil(tiles / 64).  A gated launch writes 4 partial rows per tile block (asr_tap_gemm_gated_workspace sizes its buffer with it:
+// ceil(tiles / 64).  A gated launch writes up to 8 partial rows per tile block (asr_tap_gemm_gated_workspace sizes its buffer with it:
 // planes of a few tile rows have mostly empty items, so this can exceed the direct kernels' M / 32 rows).
 static int wino_tile_blocks(const asr_gemm_desc* d) {
     const int TH = (d->H + 1) / 2, TW = (d->W + 1) / 2;
@@ -1081,7 +1457,7 @@ static int wino_tile_blocks(const asr_gemm_desc* d) {
     const int blocked = d->B * it, plain = asr_cdiv((long)d->B * TH * TW, WT);
     return blocked > plain ? blocked : plain;            // (wino8_kernel's plain order is the fallback of a blocked geometry)
 }
-extern "C" int asr_winograd_gate_rows(const asr_gemm_desc* d) { return asr_winograd_supported(d) ? 4 * wino_tile_blocks(d) : 0; }
+extern "C" int asr_winograd_gate_rows(const asr_gemm_desc* d) { return asr_winograd_supported(d) ? 8 * wino_tile_blocks(d) : 0; }      // wino11_kernel: one per wave
 
 static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale, const float* shift,
                      float* out_a, float* out_y, void* stream, const WinoGate* gs, float* pool_y = nullptr, int pool_mode = 0) {
@@ -1119,6 +1495,31 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     int it = 0;
     for (int c = 0; c < w.ncb; ++c) { w.cb_it0[c] = it; it += asr_cdiv(w.TH * w.cb_w[c], WT); }
     w.cb_it0[w.ncb] = it;
+    // wino11_kernel (eight waves of 128 registers, one transform row per wave, two workgroups per CU) takes every column-blocked shape
+    // with 32-wide channel blocks; the choice depends on widths and plane geometry only.
+    const bool use11 = g_wino_gen >= 11 && w.ncb > 0 && (d->N % W10_C) == 0 && d->N <= 2048 && (!pool_y || d->N <= 640);
+    if (use11) {
+        const int nblk11 = d->B * w.cb_it0[w.ncb];
+        a.ntm = nblk11; a.ntn = d->N / W10_C;
+        if (a.gate_rows) *a.gate_rows = nblk11 * 8;
+        const long nwork11 = (long)nblk11 * a.ntn;
+        const int grid11 = nwork11 > 2L * ncu8 ? 2 * ncu8 : (int)nwork11;     // persistent: two workgroups per CU
+        const size_t lds11 = (size_t)(2 * W11_TABF + 4 * W11_SETF + (pool_y ? 3 * d->N : 0)) * sizeof(float);
+        static_assert(4096 <= W11_SETF && 4 * 32 * 33 <= W11_SETF, "exchange phase / four transpose scratches must fit in one buffer set");
+        auto k0 = wino11_kernel<0>;
+        auto k1 = wino11_kernel<1>;
+        static bool f0 = false, f1 = false;
+        if (d->wmode) {
+            if (!f1) { (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); f1 = true; }
+            hipLaunchKernelGGL(k1, dim3(grid11), dim3(512), lds11, (hipStream_t)stream, w);
+        } else {
+            if (!f0) { (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); f0 = true; }
+            hipLaunchKernelGGL(k0, dim3(grid11), dim3(512), lds11, (hipStream_t)stream, w);
+        }
+        ASR_CHECK_LAUNCH("tap_gemm_wino11");
+        if (d->wmode) ASR_NOTE_KERNEL("wino11_kernel<1>"); else ASR_NOTE_KERNEL("wino11_kernel<0>");
+        return ASR_OK;
+    }
     bool use10 = (d->N % WC) != 0;
     if (!use10 && w.ncb && d->N <= 2048 && (long)d->B * it * (d->N / WC) <= 12L * ncu8) use10 = true;
 #ifdef WINO_FORCE10

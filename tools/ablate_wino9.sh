@@ -7,6 +7,7 @@ cd "$(dirname "$0")/.."
 out=$1; shift
 P=asr_dfcnn_transformer_amd
 cp $P/libasrhip.so /tmp/libasrhip_good.so
+trap 'cp /tmp/libasrhip_good.so $P/libasrhip.so' EXIT      # the good library comes back even when a compile or a bench fails partway
 objs=$(ls $P/build/*.hip.o | grep -v wino.hip.o)
 for m in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DWINO_ABL=$m ${WINO_EXTRA:-} -I include -c $P/csrc/wino.hip -o /tmp/wino_abl.o

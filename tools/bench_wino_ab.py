@@ -1,0 +1,99 @@
+"""A/B timing of the Winograd forward / data-gradient launches of the plain DFCNN step (acoustic_model.py, B = 32, T_pad 1600)
+exactly as the engine issues them -- forward with the fused 2x2 pool where the cell is pooled, data-gradients with the fused
+backward prologue (asr_tap_gemm_gated) where the engine fuses one -- for the kernel generations the development switch
+asr_debug_wino_gen selects (10: wino9 / wino10 of round 3, 11: wino11_kernel), in one process on one box.
+usage: python tools/bench_wino_ab.py [gens ...]     env B, TPAD"""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from asr_dfcnn_transformer_amd import ops, _lib
+from asr_dfcnn_transformer_amd.ops import Plane
+
+B = int(os.environ.get('B', 32))
+TP = int(os.environ.get('TPAD', 1600))
+lib = _lib.load()
+setgen = lib.asr_debug_wino_gen
+setgen.argtypes = [C.c_int]
+setgen.restype = None
+gens = [int(a) for a in sys.argv[1:]] or [10, 11]
+
+
+def timeit(fn, iters=20):
+    fn(); fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+g = torch.Generator(device='cuda').manual_seed(0)
+rnd = lambda *s: torch.randn(*s, device='cuda', generator=g)
+H8, W8 = TP // 8, 25
+# (name, H, W, cin, cout, pool of the cell: 0 none / 2 max)
+FWD = [('c2 32->64', TP // 2, 100, 32, 64, 2), ('c3 64->128', TP // 4, 50, 64, 128, 2), ('c4 128->128', H8, W8, 128, 128, 0),
+       ('c5a 128->256', H8, W8, 128, 256, 0), ('c5 32->256', H8, W8, 32, 256, 0)]
+# data-gradients: (name, H, W, K = cout of the cell, N = cin, gate: None or (pool of the cell in front, its channel count = N))
+BWD = [('h5 256->32', H8, W8, 256, 32, (0,)), ('h5a 256->128', H8, W8, 256, 128, (0,)), ('h4 128->128', H8, W8, 128, 128, (2,)),
+       ('h3 128->64', TP // 4, 50, 128, 64, (2,)), ('h2 64->32', TP // 2, 100, 64, 32, None)]
+tot = {gen: 0.0 for gen in gens}
+print('B = %d, T_pad = %d; us per launch (TFLOP/s in direct-conv flops)' % (B, TP))
+for name, H, W, cin, cout, pool in FWD:
+    x = Plane(B, H, W, cin); x.set_interior(rnd(B, H, W, cin))
+    w = rnd(3, 3, cin, cout) * (2.0 / (9 * cin)) ** 0.5
+    bias = rnd(cout) * 0.1; sc = 1 + 0.2 * rnd(cout); sh = 0.1 * rnd(cout)
+    a = Plane(B, H, W, cout)
+    y = Plane(B, H // 2, W // 2, cout) if pool else Plane(B, H, W, cout)
+    d = ops.gemm_desc(x.NP, cin, cout, cin, cout, cout, 0 if pool else cout, ntaps=9, B=B, H=H, W=W, relu=1)
+    wt = ops.winograd_weights(w, cin, cout, cout, 0)
+    fl = 2.0 * B * H * W * 9 * cin * cout
+    row, ref = [], None
+    for gen in gens:
+        setgen(gen)
+        fn = (lambda: ops.tap_gemm_wino_pool(d, x, wt, bias, sc, sh, a, pool, y)) if pool else (lambda: ops.tap_gemm_wino(d, x, wt, bias, sc, sh, a, y))
+        t = timeit(fn)
+        tot[gen] += t
+        cur = (a.buf.clone(), y.buf.clone())
+        diff = 0.0 if ref is None else max((cur[0] - ref[0]).abs().max().item(), (cur[1] - ref[1]).abs().max().item())
+        ref = ref or cur
+        row.append('gen %d %-18s %7.1f us (%5.1f)  d %.1e' % (gen, ops.last_kernel()[:18], t, fl / t / 1e6, diff))
+    print('fwd   %-14s %dx%d  ' % (name, H, W) + ' | '.join(row), flush=True)
+    del x, a, y
+for name, H, W, K, N, gate in BWD:
+    dz = Plane(B, H, W, K); dz.set_interior(rnd(B, H, W, K))
+    w = rnd(3, 3, N, K) * 0.05
+    bd = ops.gemm_desc(dz.NP, K, N, K, K, 0, N, ntaps=9, B=B, H=H, W=W, wmode=1)
+    wt = ops.winograd_weights(w, K, N, K, 1)
+    fl = 2.0 * B * H * W * 9 * K * N
+    row, ref = [], None
+    if gate is None:
+        dx = Plane(B, H, W, N)
+        for gen in gens:
+            setgen(gen)
+            t = timeit(lambda: ops.tap_gemm_wino(bd, dz, wt, None, None, None, None, dx))
+            tot[gen] += t
+            cur = dx.buf.clone()
+            diff = 0.0 if ref is None else (cur - ref).abs().max().item()
+            ref = cur if ref is None else ref
+            row.append('gen %d %-18s %7.1f us (%5.1f)  d %.1e' % (gen, ops.last_kernel()[:18], t, fl / t / 1e6, diff))
+    else:
+        pool = gate[0]
+        gh, gw = (H, W) if pool == 0 else (2 * H, 2 * W)
+        act = Plane(B, gh, gw, N); act.set_interior(torch.relu(rnd(B, gh, gw, N)))
+        sc = 1 + 0.2 * rnd(N); sh = 0.1 * rnd(N)
+        dzo = Plane(B, gh, gw, N)
+        sums = [torch.zeros(N, device='cuda') for _ in range(3)]
+        ws = torch.zeros(ops.tap_gemm_gated_workspace(bd) // 4 + 64, device='cuda')
+        for gen in gens:
+            setgen(gen)
+            t = timeit(lambda: ops.tap_gemm_gated(bd, dz, wt, 2, pool, act, sc, sh, None, dzo, sums[0], sums[1], sums[2], ws))
+            tot[gen] += t
+            cur = (dzo.buf.clone(), torch.stack(sums).clone())
+            diff = 0.0 if ref is None else max((cur[0] - ref[0]).abs().max().item(), ((cur[1] - ref[1]).abs().max() / ref[1].abs().max()).item())
+            ref = ref or cur
+            row.append('gen %d %-18s %7.1f us (%5.1f)  d %.1e' % (gen, ops.last_kernel()[:18], t, fl / t / 1e6, diff))
+    print('dgrad %-14s %dx%d  ' % (name, H, W) + ' | '.join(row), flush=True)
+print('sum of the ten launches: ' + ', '.join('gen %d %.1f us' % (gen, tot[gen]) for gen in gens))

@@ -5,6 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 P=asr_dfcnn_transformer_amd
 cp $P/libasrhip.so /tmp/libasrhip_good.so
+trap 'cp /tmp/libasrhip_good.so $P/libasrhip.so' EXIT      # the good library comes back even when a compile or a bench fails partway
 objs=$(ls $P/build/*.hip.o | grep -v "/wino.hip.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DWINO_FORCE10 -I include -c $P/csrc/wino.hip -o /tmp/wino_f10.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/libasrhip.so $objs /tmp/wino_f10.o
