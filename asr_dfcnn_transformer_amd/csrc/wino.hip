@@ -53,7 +53,7 @@ constexpr int RAW_F = 16 * 2 * WT * 4;      // floats of one raw buffer   ([pixe
 constexpr int U_F = 16 * WKC * WC;          // floats of one weight buffer ([xi][ci][co])
 
 // U = G g G^T for every (k, n): g(kh, kw) = W[kh][kw][k][n] (forward) or W[2-kh][2-kw][n][k] (data-gradient view)
-__global__ void wino_weights_kernel(const float* __restrict__ W, int K, int N, int ldw, int wmode, float* __restrict__ out) {
+__global__ void wino_weights_kernel(const float* __restrict__ W, int K, int N, int ldw, int wmode, float* __restrict__ out, float* __restrict__ out2) {
     const long total = (long)K * N;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int k = (int)(i / N), n = (int)(i - (long)k * N);
@@ -79,6 +79,14 @@ __global__ void wino_weights_kernel(const float* __restrict__ W, int K, int N, i
             out[((long)(r * 4 + 1) * K + k) * N + n] = u1;
             out[((long)(r * 4 + 2) * K + k) * N + n] = u2;
             out[((long)(r * 4 + 3) * K + k) * N + n] = u3;
+            if (out2) {
+                // second layout (wino11_kernel): [K / 8][xi 16][N / 32][k-pair pair][lane half][co 32][2]; channel kc * 8 + 4 lh + kp of
+                // a chunk is the k-pair kp of lane half lh (the MFMA contracts channels kp and 4 + kp of the chunk together)
+                const int kc = k >> 3, lhh = (k >> 2) & 1, kp = k & 3;
+                const long base = (((long)kc * 16 + r * 4) * (N >> 5) + (n >> 5)) * 256 + (kp >> 1) * 128 + lhh * 64 + (n & 31) * 2 + (kp & 1);
+                const long xs = (long)(N >> 5) * 256;
+                out2[base] = u0; out2[base + xs] = u1; out2[base + 2 * xs] = u2; out2[base + 3 * xs] = u3;
+            }
         }
     }
 }
@@ -1018,23 +1026,39 @@ __global__ __launch_bounds__(256, 2) void wino10_kernel(WinoArgs args) {
 //   * row r of V = B^T d B needs two pixel rows of the patch (0: rows 0, 2; 1 and 2: rows 1, 2; 3: rows 1, 3) and all four columns:
 //     8 ds_read_b128 and 16 v_pk_add_f32 per 16 MFMAs (wino10_kernel: 12 reads and 40 packed adds per 32, i.e. 20 per 16);
 //   * four instruction streams per SIMD: an LDS wait, a chunk barrier or an item tail of one wave leaves three others (two of
-//     them of the other workgroup) to feed the matrix pipe -- with two streams the pipe idled whenever both were held;
+//     them of the other workgroup) to feed the matrix pipe;
 //   * the item tail is light: the column combination (M A) is lane-local, the row combination (A^T .) is ONE exchange through LDS
 //     in which wave r receives the register quarter 4 r .. 4 r + 3 of all four rows -- i.e. all four pixels of eight tiles -- so
-//     the fused 2 x 2 pool is lane-local as well and every wave runs the shared epilogue on ONE 32 x 32 block (pixel-major row table).
-// DMA pieces, LDS layouts, column-blocked tile order and item flow as in wino10_kernel (two raw and two weight pieces per wave and
-// chunk).  The chunk loop is unrolled by two so that both buffer sets are immediate offsets of per-lane base registers (no address
-// arithmetic in the loop); an odd chunk count (K % 16 == 8) takes the variant with run-time set offsets.
-// The argument block is read through the kernarg segment pointer, re-derived ("laundered") in front of every item tail and of the
-// next-item set-up: hipcc otherwise keeps the ~100 argument dwords of the epilogues live in scalar registers across the chunk loop
-// and spills them to vector-register lanes (wino10_kernel: 117 scalar spills, four waterfall loops per chunk around DMA pieces
-// whose offsets ended up in vector registers).
+//     the fused 2 x 2 pool is lane-local as well and every wave finishes ONE 32 x 32 block (pixel-major row table).
+// Raw pieces, column-blocked tile order and item flow as in wino10_kernel.  The weights come from the SECOND layout asr_winograd_weights
+// writes ([K / 8][xi 16][N / 32][k-pair pair 2][lane half 2][co 32][2]): a weight piece is 1 KB of contiguous memory and a lane
+// reads the two k-pairs of a position with one conflict-free ds_read_b64 at a 16-bit immediate of ONE base register.
+// The chunk loop is unrolled by two so that both buffer sets are immediate offsets of per-lane base registers (no address
+// arithmetic in the loop); an odd chunk count (K % 16 == 8) takes the variant with run-time set offsets.  Only the chunk loop is
+// instantiated per transform row; set-up, tail and epilogues exist once.
+// The argument block is read through the kernarg segment pointer, re-derived ("laundered") where a phase starts: hipcc otherwise
+// keeps the ~100 argument dwords of the epilogues live in scalar registers across the chunk loop and spills them to vector-register
+// lanes (wino10_kernel: 117 scalar spills, four waterfall loops per chunk around DMA pieces whose offsets ended up in vector
+// registers).  A spill is worse than its instruction here: a scratch reload is a vector-memory load, and the s_waitcnt vmcnt(0) in
+// front of its use also waits for every DMA piece and every epilogue store in flight.
 // Which kernel runs is decided by the layer's widths and plane geometry alone -- never by the batch or the CU count -- so an
 // utterance gives the same bits alone and inside a batch (tests/test_fullsize_gpu.py).
+#ifdef W11_TRACE
+__device__ long long w11_trace_buf[8 * 8 * 16];           // [item 8][wave 8][stamp 16], workgroup W11_TRACE_WG only (development)
+#ifndef W11_TRACE_WG
+#define W11_TRACE_WG 0
+#endif
+#define W11T(k) do { if (blockIdx.x == W11_TRACE_WG && titem >= 0 && titem < 8 && lane == 0) w11_trace_buf[(titem * 8 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W11T(k) do { } while (0)
+#endif
 constexpr int W11_SETF = 4224;                  // floats of a raw / weight set: 16 pieces of 256, padded so that four 32 x 33 transpose scratches fit
 constexpr int W11_TABF = 768;                   // ints of a table set: rowa 256 | rowy 256 | prow 256
 constexpr int W11_RAW0 = 2 * W11_TABF * 4;      // byte offsets of the four sets in the dynamic LDS segment
 constexpr int W11_U0 = W11_RAW0 + 2 * W11_SETF * 4;
+// epilogue instantiations (see wino11_body)
+constexpr int W11_EPI_GENERIC = 0, W11_EPI_FWD = 1, W11_EPI_POOLMAX = 2, W11_EPI_POOLAVG = 3, W11_EPI_DGRAD = 4, W11_EPI_DGRAD_ACC = 5,
+              W11_EPI_GATE1 = 6, W11_EPI_GATE2 = 7, W11_EPI_GATE3 = 8;
 
 #if __HIP_DEVICE_COMPILE__
 typedef const __attribute__((address_space(4))) WinoArgs* wino_kernarg_p;
@@ -1046,12 +1070,13 @@ __device__ __forceinline__ const WinoArgs& wino_args_fresh() {
 }
 
 struct W11Dma {
-    unsigned voff[2];        // raw pieces wave + 8 j
-    unsigned off_u;          // per-lane offset inside a weight piece
-    unsigned sbase;          // byte offset of the region's first pixel (channel 0)          (scalar)
-    unsigned pairbytes;      // bytes of two pixel rows of the plane                         (scalar)
-    unsigned xibytes;        // bytes between the weight matrices of two positions           (scalar)
-    unsigned chunkbytes;     // bytes of 8 input-channel rows of a weight matrix             (scalar)
+    unsigned voff[2];        // raw pieces wave + 8 j (per lane)
+    unsigned l16;            // lane * 16: a weight piece is contiguous
+    unsigned sbase;          // byte offset of the region's first pixel (channel 0)                    (scalar)
+    unsigned pairbytes;      // bytes of two pixel rows of the plane                                   (scalar)
+    unsigned ubytes;         // byte offset of chunk 0 of this item's channel block in the weights      (scalar)
+    unsigned xibytes;        // bytes between two positions of a chunk: (N / 32) KB                     (scalar)
+    unsigned chunkbytes;     // bytes of a chunk of the weights: 16 positions                           (scalar)
     int wave;
 };
 
@@ -1076,28 +1101,23 @@ __device__ __forceinline__ void wino11_offsets(const WinoArgs& args, const Wino9
 template <class R>
 __device__ __forceinline__ void wino11_raw_piece(const W11Dma& q, R ra, int lds_set, int j, int kc) {
     const int p = q.wave + 8 * j;
-#if defined(W11_ABL) && (W11_ABL & 4)
-    return;
-#endif
     __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (wn_lds_f*)(uintptr_t)(unsigned)(lds_set + p * 1024), 16, q.voff[j],
                                              (int)(q.sbase + (unsigned)(p >> 1) * q.pairbytes + (unsigned)kc * (WKC * 4)), 0, 0);
 }
-// weight piece xi = wave + 8 j of chunk kc: [8 ci][32 co]
+// weight piece xi = wave + 8 j of chunk kc: [k-pair pair 2][lane half 2][32 co][2], contiguous in memory
 template <class R>
 __device__ __forceinline__ void wino11_u_piece(const W11Dma& q, R ru, int lds_set, int j, int kc) {
     const int xi = q.wave + 8 * j;
-#if defined(W11_ABL) && (W11_ABL & 8)
-    return;
-#endif
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (wn_lds_f*)(uintptr_t)(unsigned)(lds_set + xi * 1024), 16, q.off_u,
-                                             (int)((unsigned)xi * q.xibytes + (unsigned)kc * q.chunkbytes), 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, (wn_lds_f*)(uintptr_t)(unsigned)(lds_set + xi * 1024), 16, q.l16,
+                                             (int)(q.ubytes + (unsigned)kc * q.chunkbytes + (unsigned)xi * q.xibytes), 0, 0);
 }
 
 // One 8-channel chunk of transform row RR out of buffer set `cur` (CUR 0 / 1: compile-time, all LDS addresses are immediates of the
-// per-lane bases lb / ubase; CUR 2: run-time `cur`): 8 patch reads, 16 weight values (the second half requested behind the first
-// transform: 8 registers at a time), 16 packed adds, 16 MFMAs (k-pair major); behind the four MFMAs of a k-pair one DMA piece of
-// the next chunk into the other set (weights first: they are read first).
-template <int RR, int CUR, class R>
+// per-lane bases lb / ubase; CUR 2: run-time `cur`): 8 patch reads, 8 weight reads (two k-pairs each; the second four requested
+// behind the first transform: 8 registers at a time), 16 packed adds, 16 MFMAs (k-pair major); behind the four MFMAs of a k-pair
+// one DMA piece of the next chunk into the other set (weights first: they are read first).  FIRST: the accumulators start from
+// the MFMA's zero operand (no 64 register moves per item).
+template <int RR, int CUR, bool FIRST, class R>
 __device__ __forceinline__ void wino11_chunk(const char* __restrict__ lds, int lds0, int cur, bool pre, const W11Dma& q, R ra, R ru, int kcn,
                                              const unsigned (&lb)[4], unsigned ubase, floatx16 (&acc)[4]) {
     constexpr int RA = RR == 0 ? 0 : 1, RB = RR == 3 ? 3 : 2;           // the two patch rows this transform row combines
@@ -1106,41 +1126,34 @@ __device__ __forceinline__ void wino11_chunk(const char* __restrict__ lds, int l
     float4 da[4], db[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-#if defined(W11_ABL) && (W11_ABL & 1)
-        { const float f = __uint_as_float(lb[c] + setoff); da[c] = make_float4(f, f * 2.f, f * 3.f, f * 4.f); db[c] = make_float4(f * 5.f, f * 6.f, f * 7.f, f * 8.f); }
-#else
         da[c] = *(const float4*)(lds + lb[(RA >> 1) * 2 + (c >> 1)] + setoff + (RA >> 1) * 2048 + (c & 1) * 1024 + (RA & 1) * 512);
         db[c] = *(const float4*)(lds + lb[(RB >> 1) * 2 + (c >> 1)] + setoff + (RB >> 1) * 2048 + (c & 1) * 1024 + (RB & 1) * 512);
-#endif
     }
-    float u[4][4];
-    auto load_u = [&](int kp0) {
+    wn_f2 u[4][2];
+    auto load_u = [&](int kpp) {
 #pragma unroll
-        for (int kp = kp0; kp < kp0 + 2; ++kp)
-#pragma unroll
-#if defined(W11_ABL) && (W11_ABL & 2)
-            for (int c = 0; c < 4; ++c) u[c][kp] = __uint_as_float(ubase + setoff + c * 4 + kp);
-#else
-            for (int c = 0; c < 4; ++c) u[c][kp] = *(const float*)(lds + ubase + setoff + ((RR * 4 + c) * WKC + kp) * (W10_C * 4));
-#endif
+        for (int c = 0; c < 4; ++c) u[c][kpp] = *(const wn_f2*)(lds + ubase + setoff + (RR * 4 + c) * 1024 + kpp * 512);
     };
     load_u(0);
     __builtin_amdgcn_sched_barrier(0);
-    wn_f2 v[4];
-    auto transform = [&](int h) {          // row RR of B^T d for k-pairs 2 h, 2 h + 1 (one packed add each), then V = t B
-        wn_f2 t[4];
+    // stage 1, both k-pair halves at once: t = row RR of B^T d (the sixteen patch registers of the second row are free afterwards --
+    // the chunk's peak is 40 registers beside the 64 accumulators); stage 2 per half: V = t B
+    wn_f2 t[4][2];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const wn_f2 a = h == 0 ? wn_f2{da[c].x, da[c].y} : wn_f2{da[c].z, da[c].w};
-            const wn_f2 b = h == 0 ? wn_f2{db[c].x, db[c].y} : wn_f2{db[c].z, db[c].w};
-            t[c] = RR == 1 ? a + b : RR == 2 ? b - a : a - b;
-        }
-        v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
-    };
+    for (int c = 0; c < 4; ++c) {
+        const wn_f2 a0 = {da[c].x, da[c].y}, a1 = {da[c].z, da[c].w}, b0 = {db[c].x, db[c].y}, b1 = {db[c].z, db[c].w};
+        t[c][0] = RR == 1 ? a0 + b0 : RR == 2 ? b0 - a0 : a0 - b0;
+        t[c][1] = RR == 1 ? a1 + b1 : RR == 2 ? b1 - a1 : a1 - b1;
+    }
+    wn_f2 v[4];
+    auto transform = [&](int h) { v[0] = t[0][h] - t[2][h]; v[1] = t[1][h] + t[2][h]; v[2] = t[2][h] - t[1][h]; v[3] = t[1][h] - t[3][h]; };
     auto mfmas = [&](int kp, int piece) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32((kp & 1) ? v[c].y : v[c].x, u[c][kp], acc[c], 0, 0, 0);
+        for (int c = 0; c < 4; ++c) {
+            const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32((kp & 1) ? v[c].y : v[c].x, (kp & 1) ? u[c][kp >> 1].y : u[c][kp >> 1].x,
+                                                          (FIRST && kp == 0) ? zero : acc[c], 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (pre) {
             if (piece < 2) wino11_u_piece(q, ru, lds0 + W11_U0 + nxtoff, piece, kcn);
@@ -1150,7 +1163,7 @@ __device__ __forceinline__ void wino11_chunk(const char* __restrict__ lds, int l
     };
     transform(0);
     __builtin_amdgcn_sched_barrier(0);
-    load_u(2);
+    load_u(1);
     __builtin_amdgcn_sched_barrier(0);
     mfmas(0, 0);
     mfmas(1, 1);
@@ -1160,9 +1173,40 @@ __device__ __forceinline__ void wino11_chunk(const char* __restrict__ lds, int l
     mfmas(3, 3);
 }
 
+// the chunk loop of one item for transform row RR -- the only code instantiated per row.  The last chunk requests nothing: the
+// next item's first chunk is requested at the top of the item tail (shared code), where its offsets are computed.
+template <int RR, class R>
+__device__ __forceinline__ void wino11_item_chunks(const char* lds, int lds0, int nkc, int& cur, const W11Dma& q, R ra, R ru,
+                                                   const unsigned (&lb)[4], unsigned ubase, floatx16 (&acc)[4]) {
+    if ((nkc & 1) == 0 && cur == 0) {
+        wino11_chunk<RR, 0, true>(lds, lds0, 0, true, q, ra, ru, 1, lb, ubase, acc);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        for (int kc = 2; kc < nkc; kc += 2) {
+            wino11_chunk<RR, 1, false>(lds, lds0, 1, true, q, ra, ru, kc, lb, ubase, acc);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            wino11_chunk<RR, 0, false>(lds, lds0, 0, true, q, ra, ru, kc + 1, lb, ubase, acc);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        wino11_chunk<RR, 1, false>(lds, lds0, 1, false, q, ra, ru, 0, lb, ubase, acc);
+        lds_barrier();
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int kc = 0; kc < nkc; ++kc) {
+            const bool last = kc + 1 == nkc;
+            wino11_chunk<RR, 2, false>(lds, lds0, cur, !last, q, ra, ru, kc + 1, lb, ubase, acc);
+            if (last) lds_barrier();
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            cur ^= 1;
+        }
+    }
+}
+
 // row tables of one item (threads 0..255: 64 tiles x 4 pixels).  Wave (row r, half wm) finishes tiles wm * 32 + 8 r .. + 7 with
 // all four pixels: its 32 x 32 epilogue block has row p * 8 + t' = pixel p of tile t' (the MFMA register q = 4 p + i holds tile
-// i + 4 lh, tap_epilogue's own register-to-row rule).  prow: rows 0..7 of a wave's block = the pooled pixel of its tiles, else -1.
+// i + 4 lh, the epilogues' register-to-row rule).  prow: rows 0..7 of a wave's block = the pooled pixel of its tiles, else -1.
 __device__ __forceinline__ void wino11_tables(const WinoArgs& args, const Wino9Geo& e, int tid, int* rowa, int* rowy, int* prow) {
     const TapGemmArgs& g = args.g;
     if (tid < 256) {
@@ -1177,6 +1221,11 @@ __device__ __forceinline__ void wino11_tables(const WinoArgs& args, const Wino9G
                 ry = g.y_unpadded ? ((e.b * g.H + hh - 1) * g.Wd + ww - 1) : ra_;
             }
         }
+        // gated launches with a pooled cell in front: rowy = the full-resolution row of window position 0 of this output pixel
+        if (g.gate_mode >= 2 && ra_ >= 0) {
+            const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
+            ry = (e.b * (g.gate_H + 1) + 2 * hh - 1) * (g.gate_W + 1) + 2 * ww - 1;
+        }
         const int wv = (tl >> 5) + 2 * ((tl & 31) >> 3);             // wave = row * 2 + wm
         const int m = wv * 32 + pl * 8 + (tl & 7);
         rowa[m] = ra_; rowy[m] = ry;
@@ -1186,47 +1235,230 @@ __device__ __forceinline__ void wino11_tables(const WinoArgs& args, const Wino9G
     }
 }
 
-template <int RR>
+// ---- epilogues of one 32 x 32 block per wave.  The launcher picks the kernel instantiation EPI from the descriptor, so that what
+// an epilogue does is known at compile time: with the options as run-time flags (tap_epilogue: ReLU / tanh, out_a, out_y, accumulate,
+// pool mode, gate mode, each tested per ROW inside the unrolled loops) the item tail was a chain of ~100 scalar branches, and a taken
+// branch costs a wave its instruction buffer -- in-kernel stamps: 50-60 cycles per tail instruction, tails as long as the whole
+// chunk loop at K = 32.
+//   EPI 0  generic: tap_epilogue on the run-time flags (tanh, unusual output combinations)
+//   EPI 1  forward, ReLU, out_a and out_y            EPI 2 / 3  forward of a pooled cell: ReLU, out_a, fused max / average pool
+//   EPI 4  data-gradient: out_y (no bias, no affine)  EPI 5  ... accumulating
+//   EPI 6 / 7 / 8  gated data-gradient (fused backward prologue of the cell in front: no pool / average / max), accumulate at run time
+typedef unsigned int w11_u4 __attribute__((ext_vector_type(4)));
+constexpr unsigned W11_OOR = 0xFFFFFFF0u;        // a buffer offset past num_records: the load returns zeros, the store is dropped
+
+// Output / gate planes go through buffer resources with 32-bit byte offsets (wino_impl refuses planes of 4 GiB or 2^24 rows and
+// more): an address is one 24-bit multiply-add, and a row outside the plane is an out-of-range offset instead of a branch.
+template <class R>
+__device__ __forceinline__ float4 w11_load4(R r, unsigned off) {
+    const w11_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+template <class R>
+__device__ __forceinline__ void w11_store4_nt(R r, unsigned off, float x, float y, float z, float w) {
+    __builtin_amdgcn_raw_buffer_store_b128(w11_u4{__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), __float_as_uint(w)}, r, off, 0, 2);
+}
+
+// the block through the per-wave 32 x 33 transpose scratch: afterwards lane (rsub = lane >> 3, c4 = lane & 7) reads row it * 8 + rsub,
+// channels 4 c4 .. 4 c4 + 3 -- tile rsub of the wave, pixel it (wino11_tables)
+__device__ __forceinline__ void wino11_transpose(const floatx16& blk, float* scratch, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) scratch[((r & 3) + 8 * (r >> 2) + 4 * lh) * 33 + li] = blk[r];
+}
+
+// plain epilogue: v = act(x + bias) -> out_a; y = scale v + shift (+ previous) -> out_y.  The lane's channel constants are handed in:
+// requested at the top of the item tail, they arrive behind the exchange.  pa / py: bytes per row of the two outputs, n4: byte
+// offset of the lane's channel quad (W11_OOR beyond N).
+template <bool RELU, bool HAS_A, bool HAS_Y, bool ACC, class R>
+__device__ __forceinline__ void wino11_epilogue_plain(R rA, R rY, unsigned pa, unsigned py, const floatx16& blk, float* scratch, const int* rowa,
+                                                      const int* rowy, unsigned n4, const float4& bs, const float4& sc, const float4& sh, int lane) {
+    const int c4 = lane & 7, rsub = lane >> 3;
+    wino11_transpose(blk, scratch, lane);
+    unsigned oa[4], oy[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int ra = rowa[it * 8 + rsub];
+        const bool ok = ra >= 0 && n4 != W11_OOR;
+        oa[it] = ok ? __umul24((unsigned)ra, pa) + n4 : W11_OOR;
+        if (HAS_Y) { const int ry = rowy[it * 8 + rsub]; oy[it] = ok ? __umul24((unsigned)ry, py) + n4 : W11_OOR; }
+    }
+    float4 prev[4];
+    if (HAS_Y && ACC) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) prev[it] = w11_load4(rY, oy[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const float* sp = scratch + (it * 8 + rsub) * 33 + c4 * 4;
+        float4 v = make_float4(sp[0] + bs.x, sp[1] + bs.y, sp[2] + bs.z, sp[3] + bs.w);
+        if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (HAS_A) w11_store4_nt(rA, oa[it], v.x, v.y, v.z, v.w);
+        if (HAS_Y) {
+            float4 y = make_float4(sc.x * v.x + sh.x, sc.y * v.y + sh.y, sc.z * v.z + sh.z, sc.w * v.w + sh.w);
+            if (ACC) { y.x += prev[it].x; y.y += prev[it].y; y.z += prev[it].z; y.w += prev[it].w; }
+            w11_store4_nt(rY, oy[it], y.x, y.y, y.z, y.w);
+        }
+    }
+}
+
+// gated epilogue (GM 1 no pool, 2 average, 3 max): tap_epilogue_gated's arithmetic in its order -- per output pixel and channel quad
+// g_k = the gradient routed to pre-pool position k, dZ_k = g_k scale where a_k > 0, the three channel sums -- with every load of a
+// pixel pair requested before its arithmetic (the shared form waits for four dependent round trips per block) and the full-resolution
+// row of window position 0 taken from the row table (rowf = rowy: wino11_tables writes it for the gated launches, no divisions here).
+// rGA / rGD: gate activations and dZ (C channels per pixel), rY: dL/dy of the cell in front (accumulate), py its row bytes.
+template <int GM, class R>
+__device__ __forceinline__ void wino11_epilogue_gated(R rGA, R rGD, R rY, bool accumulate, unsigned py, unsigned c4b, unsigned wpf4, float* gate_part, int C,
+                                                      const floatx16& blk, float* scratch, const int* rowa, const int* rowf,
+                                                      int n, unsigned n4, const float4& sc, const float4& sh, int lane, int part_row) {
+    const int c4 = lane & 7, rsub = lane >> 3;
+    wino11_transpose(blk, scratch, lane);
+    float s_scale[4] = {0.f, 0.f, 0.f, 0.f}, s_shift[4] = {0.f, 0.f, 0.f, 0.f}, s_bias[4] = {0.f, 0.f, 0.f, 0.f};
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+    constexpr int NK = GM == 1 ? 1 : 4;
+    // One pixel per trip of a ROLLED loop: unrolled, hipcc interleaves the four pixels (and vectorises across them), holds 100 values
+    // more than the 128-register budget has and parks them in scratch -- whose reloads wait for every store in flight.  The other
+    // three waves of the SIMD cover the round trip of a pixel's loads.
+#pragma nounroll
+    for (int p = 0; p < 4; ++p) {
+        const int row = p * 8 + rsub;
+        const int ra = rowa[row];
+        const bool ok = ra >= 0 && n4 != W11_OOR;
+        const unsigned pf = GM == 1 ? (unsigned)ra : (unsigned)rowf[row];
+        const unsigned o0 = ok ? __umul24(pf, c4b) + n4 : W11_OOR;          // c4b: bytes of a gate pixel (4 C)
+        unsigned off[NK];
+        off[0] = o0;
+        if (GM != 1) { off[1] = ok ? o0 + c4b : W11_OOR; off[2] = ok ? o0 + wpf4 : W11_OOR; off[3] = ok ? o0 + wpf4 + c4b : W11_OOR; }
+        float4 a4[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) a4[k] = w11_load4(rGA, off[k]);
+        const float4 prev = accumulate ? w11_load4(rY, ok ? __umul24((unsigned)ra, py) + n4 : W11_OOR) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* sp = scratch + row * 33 + c4 * 4;
+        // a row outside the plane: its activations read as zeros and its value is dropped (v = 0: no contribution to the sums)
+        const float r0 = sp[0], r1 = sp[1], r2 = sp[2], r3 = sp[3];          // (read unconditionally: a load under a select becomes a branch)
+        const float v[4] = {ok ? r0 + prev.x : 0.f, ok ? r1 + prev.y : 0.f, ok ? r2 + prev.z : 0.f, ok ? r3 + prev.w : 0.f};
+        float av[NK][4];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) { av[k][0] = a4[k].x; av[k][1] = a4[k].y; av[k][2] = a4[k].z; av[k][3] = a4[k].w; }
+        if (GM == 1) {
+            float d[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s_shift[e] += v[e];
+                s_scale[e] = fmaf(v[e], av[0][e], s_scale[e]);
+                d[e] = av[0][e] > 0.f ? v[e] * scv[e] : 0.f;
+                s_bias[e] += d[e];
+            }
+            w11_store4_nt(rGD, off[0], d[0], d[1], d[2], d[3]);
+        } else {
+            int arg[4];
+            if (GM == 3) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {          // first maximum of scale a + shift in row-major window order (gate_pick)
+                    const float y0 = fmaf(scv[e], av[0][e], shv[e]), y1 = fmaf(scv[e], av[1][e], shv[e]);
+                    const float y2 = fmaf(scv[e], av[2][e], shv[e]), y3 = fmaf(scv[e], av[3][e], shv[e]);
+                    int ag = 0; float m = y0;
+                    if (y1 > m) { m = y1; ag = 1; }
+                    if (y2 > m) { m = y2; ag = 2; }
+                    if (y3 > m) { m = y3; ag = 3; }
+                    arg[e] = ag;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gk = GM == 2 ? 0.25f * v[e] : (arg[e] == k ? v[e] : 0.f);
+                    s_shift[e] += gk;
+                    s_scale[e] = fmaf(gk, av[k][e], s_scale[e]);
+                    d[e] = av[k][e] > 0.f ? gk * scv[e] : 0.f;
+                    s_bias[e] += d[e];
+                }
+                w11_store4_nt(rGD, off[k], d[0], d[1], d[2], d[3]);
+            }
+        }
+    }
+    // rows of this wave: lanes with equal c4 differ in bits 3..5 of the lane id; fixed shuffle order
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            s_scale[e] += __shfl_xor(s_scale[e], o, 64);
+            s_shift[e] += __shfl_xor(s_shift[e], o, 64);
+            s_bias[e] += __shfl_xor(s_bias[e], o, 64);
+        }
+    }
+    if (rsub == 0 && n4 != W11_OOR) {
+        float* pr = gate_part + (long)part_row * 3 * C + n;
+        *(float4*)(pr) = make_float4(s_scale[0], s_scale[1], s_scale[2], s_scale[3]);
+        *(float4*)(pr + C) = make_float4(s_shift[0], s_shift[1], s_shift[2], s_shift[3]);
+        *(float4*)(pr + 2 * C) = make_float4(s_bias[0], s_bias[1], s_bias[2], s_bias[3]);
+    }
+}
+
+template <int EPI>
 __device__ __forceinline__ void wino11_body(float* smem) {
+    constexpr bool GATED = EPI >= W11_EPI_GATE1, POOLED = EPI == W11_EPI_POOLMAX || EPI == W11_EPI_POOLAVG;
     const char* lds = (const char*)smem;
     int* tables = (int*)smem;                        // two sets of [rowa 256 | rowy 256 | prow 256]
     float* bufs = smem + 2 * W11_TABF;               // raw0 | raw1 | u0 | u1
     float* pconst = bufs + 4 * W11_SETF;             // fused pool: [bias N | scale N | shift N]
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // = RR * 2 + wm
-    const int wm = wave & 1;
-    const unsigned ubase = (unsigned)(W11_U0 + (lh * 4 * W10_C + li) * 4);      // half 1 contracts channels 4 .. 7 of the chunk
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // = row * 2 + wm
+    const int wm = wave & 1, rr = wave >> 1;
+    unsigned ubase = (unsigned)(W11_U0 + lh * 256 + li * 8);             // [k-pair pair][lane half][co][2]: half 1 contracts channels 4 .. 7
+    asm volatile("" : "+v"(ubase));                  // opaque: the set and position offsets stay 16-bit immediates of this base
     const int lds0 = (int)(unsigned)(uintptr_t)(wn_lds_f*)smem;          // LDS address of the dynamic segment (DMA destinations are absolute)
-    int nkc, nnb, nwork;
+    int nkc, nnb;
     W11Dma q;
     q.wave = wave;
-    int w = blockIdx.x;
-    const int G = gridDim.x;
-    auto item_of = [&](int wl) {                     // see wino8_body
-        const int r0 = (wl / G) * G;
-        if ((G & 7) || r0 + G > nwork) return wl;
-        const int p = wl - r0;
-        return r0 + (p & 7) * (G >> 3) + (p >> 3);
+    q.l16 = (unsigned)lane * 16u;
+    // Work: the two workgroups of a CU (w and w + G / 2 under the observed round-robin placement: speed only) share a CONTIGUOUS range
+    // of items (an item = tile block x 32-channel block, the channel blocks of a tile block adjacent) and split it in the middle:
+    // the CUs are balanced to one item, and consecutive items of a workgroup mostly share the tile block, so that everything which
+    // depends on it alone -- region geometry, the lanes' patch offsets, DMA offsets, the row tables -- is set up once per tile block.
+    // The ranges of the CUs of one XCD (w % 8) are adjacent: neighbouring tile blocks go through one L2.
+    int it, it_end;
+    {
+        const WinoArgs& args = wino_args_fresh();
+        const TapGemmArgs& g = args.g;
+        nkc = g.K / WKC; nnb = g.ntn;
+        const long nwork = (long)g.ntm * nnb;
+        const int G = gridDim.x, w = blockIdx.x;
+        if ((G & 1) == 0) {
+            const int P = G >> 1, p = w % P, half = w / P;
+            const int r = (P & 7) ? p : (p & 7) * (P >> 3) + (p >> 3);
+            const int lo = (int)(nwork * r / P), hi = (int)(nwork * (r + 1) / P), mid = lo + (hi - lo + 1) / 2;
+            it = half ? mid : lo; it_end = half ? hi : mid;
+        } else {
+            it = (int)(nwork * w / G); it_end = (int)(nwork * (w + 1) / G);
+        }
+        if (it >= it_end) return;
+        q.pairbytes = (unsigned)(2 * g.WP * g.lda * 4);
+        q.xibytes = (unsigned)nnb * 1024u; q.chunkbytes = 16u * (unsigned)nnb * 1024u;
+    }
+    // the two buffer resources: plane and transformed weights (second layout: 16 K N floats into the buffer)
+    const WinoArgs& args0 = wino_args_fresh();
+    auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)args0.g.A, 0, 0x7FFFFFF0, 0x00020000);
+    auto ru = __builtin_amdgcn_make_buffer_rsrc((void*)(args0.Ut + (size_t)16 * args0.g.K * args0.g.N), 0, 0x7FFFFFF0, 0x00020000);
+    int tcur = 0, cur = 0;
+    unsigned lb[4];
+    // per-lane LDS offsets of the patch pixels of a tile block (tile l of the block, its row relative to the region)
+    auto patch_offsets = [&](const Wino9Geo& e) {
+        const int l = e.l0 + wm * 32 + li;
+        const int trl = l / e.w - e.tr0;
+        const unsigned fix = (unsigned)(W11_RAW0 + trl * 2048 + lh * 256);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { lb[j] = fix + (unsigned)(((l + (j >> 1) * e.w + (j & 1)) & 15) * 16); asm volatile("" : "+v"(lb[j])); }
     };
     {
         const WinoArgs& args = wino_args_fresh();
         const TapGemmArgs& g = args.g;
-        nkc = g.K / WKC; nnb = g.ntn; nwork = g.ntm * nnb;
-        if (w >= nwork) return;
-        q.pairbytes = (unsigned)(2 * g.WP * g.lda * 4); q.xibytes = (unsigned)(g.K * g.N) * 4u; q.chunkbytes = (unsigned)(WKC * g.N) * 4u;
-    }
-    // the two buffer resources: plane and transformed weights (4 scalar registers each, live across the kernel)
-    const WinoArgs& args0 = wino_args_fresh();
-    auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)args0.g.A, 0, 0x7FFFFFF0, 0x00020000);
-    auto ru = __builtin_amdgcn_make_buffer_rsrc((void*)args0.Ut, 0, 0x7FFFFFF0, 0x00020000);
-    int tcur = 0, cur = 0;
-    {
-        const WinoArgs& args = wino_args_fresh();
-        const TapGemmArgs& g = args.g;
-        const int it = item_of(w);
         const Wino9Geo e = wino9_geo(args, it / nnb);
         wino11_offsets(args, e, lane, q);
-        q.off_u = (unsigned)(((lane >> 3) * g.N + (it % nnb) * W10_C + (lane & 7) * 4) * 4);
+        patch_offsets(e);
+        q.ubytes = (unsigned)(it % nnb) * 1024u;
 #pragma unroll
         for (int j = 0; j < 2; ++j) { wino11_raw_piece(q, ra, lds0 + W11_RAW0, j, 0); wino11_u_piece(q, ru, lds0 + W11_U0, j, 0); }
         wino11_tables(args, e, tid, tables, tables + 256, tables + 512);
@@ -1239,150 +1471,185 @@ __device__ __forceinline__ void wino11_body(float* smem) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
     }
-    for (; w < nwork; w += G) {
-        const int item = item_of(w);
-        const int blk = item / nnb, nb = item - blk * nnb;
+    int titem = -2;
+    for (; it < it_end; ++it) {
+        ++titem;
+        W11T(0);
+        const int blk = it / nnb, nb = it - blk * nnb;
         const int n0 = nb * W10_C;
-        const int wnext = w + G;
-        const bool more = wnext < nwork;
-        const int itn = more ? item_of(wnext) : 0;
-        unsigned lb[4];
-        {
-            const WinoArgs& args = wino_args_fresh();
-            const Wino9Geo e = wino9_geo(args, blk);
-            const int l = e.l0 + wm * 32 + li;
-            const int trl = l / e.w - e.tr0;
-            const unsigned fix = (unsigned)(W11_RAW0 + trl * 2048 + lh * 256);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) lb[j] = fix + (unsigned)(((l + (j >> 1) * e.w + (j & 1)) & 15) * 16);
-        }
+        const bool more = it + 1 < it_end;
+        const bool newblk = more && nb + 1 == nnb;   // the next item starts a new tile block
         floatx16 acc[4];
+        switch (rr) {
+            case 0: wino11_item_chunks<0>(lds, lds0, nkc, cur, q, ra, ru, lb, ubase, acc); break;
+            case 1: wino11_item_chunks<1>(lds, lds0, nkc, cur, q, ra, ru, lb, ubase, acc); break;
+            case 2: wino11_item_chunks<2>(lds, lds0, nkc, cur, q, ra, ru, lb, ubase, acc); break;
+            default: wino11_item_chunks<3>(lds, lds0, nkc, cur, q, ra, ru, lb, ubase, acc); break;
+        }
+        W11T(1);
+        // ---- item tail.  The set the last chunk read (cur ^ 1) is free: exchange area, then transpose scratch; the other one (cur)
+        // receives chunk 0 of the next item, requested FIRST so that it travels behind the whole tail.
+        // (The lane id is re-derived here: what the tail computes from it -- scratch and table addresses -- must not be hoisted out of
+        // the item loop, where it would live across the chunk loop's full register budget and come back as scratch reloads, each with
+        // an s_waitcnt vmcnt(0) that also waits for the stores in flight.)
+        int lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        asm volatile("" : "+v"(lane_t));
+        const int lane = lane_t, li = lane & 31, lh = lane >> 5;
+        if (more) {
+            if (newblk) {
+                const WinoArgs& args = wino_args_fresh();
+                wino11_offsets(args, wino9_geo(args, blk + 1), lane, q);
+                q.ubytes = 0;
+            } else q.ubytes += 1024u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        // the last chunk's prefetch belongs to the next item: its offsets replace this item's in front of that chunk
-        auto next_item_offsets = [&]() {
-            if (!more) return;
+            for (int j = 0; j < 2; ++j) { wino11_raw_piece(q, ra, lds0 + W11_RAW0 + cur * (W11_SETF * 4), j, 0); wino11_u_piece(q, ru, lds0 + W11_U0 + cur * (W11_SETF * 4), j, 0); }
+        }
+        // this lane's channel constants for the epilogue (channels n0 + 4 c4 ..): requested now, used behind the exchange
+        const int ne = n0 + (lane & 7) * 4;
+        float4 cbs = make_float4(0.f, 0.f, 0.f, 0.f), csc = make_float4(1.f, 1.f, 1.f, 1.f), csh = cbs;
+        bool ncol;
+        if (EPI != W11_EPI_GENERIC) {
             const WinoArgs& args = wino_args_fresh();
-            wino11_offsets(args, wino9_geo(args, itn / nnb), lane, q);
-            q.off_u = (unsigned)(((lane >> 3) * args.g.N + (itn % nnb) * W10_C + (lane & 7) * 4) * 4);
-        };
-        if ((nkc & 1) == 0 && cur == 0) {
-            for (int kc = 0; kc < nkc; kc += 2) {
-                wino11_chunk<RR, 0>(lds, lds0, 0, true, q, ra, ru, kc + 1, lb, ubase, acc);
-#if defined(W11_ABL) && (W11_ABL & 16)
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-                const bool last = kc + 2 == nkc;
-                if (last) next_item_offsets();
-                wino11_chunk<RR, 1>(lds, lds0, 1, last ? more : true, q, ra, ru, last ? 0 : kc + 2, lb, ubase, acc);
-#if defined(W11_ABL) && (W11_ABL & 16)
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-                if (last) lds_barrier();
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-            }
-        } else {
-            for (int kc = 0; kc < nkc; ++kc) {
-                const bool last = kc + 1 == nkc;
-                if (last) next_item_offsets();
-                wino11_chunk<RR, 2>(lds, lds0, cur, last ? more : true, q, ra, ru, last ? 0 : kc + 1, lb, ubase, acc);
-                if (last) lds_barrier();
-                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                cur ^= 1;
+            const TapGemmArgs& g = args.g;
+            ncol = ne < g.N;
+            if (ncol) {
+                if (EPI == W11_EPI_FWD || POOLED) cbs = *(const float4*)(g.bias + ne);
+                if (EPI == W11_EPI_FWD || GATED) { csc = *(const float4*)(g.scale + ne); csh = *(const float4*)(g.shift + ne); }
             }
         }
-#if defined(W11_ABL) && (W11_ABL & 32)
-        { float sink = 0.f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) sink += acc[i][r];
-          if (sink == 123.456f) tables[0] = 1;
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          lds_barrier(); tcur ^= 1; continue; }
-#endif
-        // ---- item tail: set `cur` is being filled for the next item, set cur ^ 1 is free
         float* rfree = bufs + (cur ^ 1) * W11_SETF;
         float* ufree = bufs + (2 + (cur ^ 1)) * W11_SETF;
         float* xch = wm == 0 ? rfree : ufree;        // the four row waves of a tile half meet in one set (4096 floats per phase)
         floatx16 out[1][1];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            // column combination (M A)[RR][j], lane-local
+            // column combination (M A)[row][j], lane-local, two registers per packed add
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pj = j == 0 ? (acc[0][r] + acc[1][r]) + acc[2][r] : (acc[1][r] - acc[2][r]) - acc[3][r];
-                xch[(RR * 16 + r) * 64 + lane] = pj;
+            for (int r = 0; r < 16; r += 2) {
+                const wn_f2 a0 = {acc[0][r], acc[0][r + 1]}, a1 = {acc[1][r], acc[1][r + 1]}, a2 = {acc[2][r], acc[2][r + 1]}, a3 = {acc[3][r], acc[3][r + 1]};
+                const wn_f2 pj = j == 0 ? (a0 + a1) + a2 : (a1 - a2) - a3;
+                xch[(rr * 16 + r) * 64 + lane] = pj.x;
+                xch[(rr * 16 + r + 1) * 64 + lane] = pj.y;
             }
+            if (j == 0) W11T(2);
             lds_barrier();
+            if (j == 0) W11T(3);
             // row combination for this wave's register quarter: Y[i][j] = sum_r A^T[i][r] (M A)[r][j]
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float p0 = xch[(0 * 16 + 4 * RR + i) * 64 + lane], p1 = xch[(1 * 16 + 4 * RR + i) * 64 + lane];
-                const float p2 = xch[(2 * 16 + 4 * RR + i) * 64 + lane], p3 = xch[(3 * 16 + 4 * RR + i) * 64 + lane];
-                out[0][0][4 * (0 * 2 + j) + i] = (p0 + p1) + p2;
-                out[0][0][4 * (1 * 2 + j) + i] = (p1 - p2) - p3;
+            for (int i = 0; i < 4; i += 2) {
+                const wn_f2 p0 = {xch[(0 * 16 + 4 * rr + i) * 64 + lane], xch[(0 * 16 + 4 * rr + i + 1) * 64 + lane]};
+                const wn_f2 p1 = {xch[(1 * 16 + 4 * rr + i) * 64 + lane], xch[(1 * 16 + 4 * rr + i + 1) * 64 + lane]};
+                const wn_f2 p2 = {xch[(2 * 16 + 4 * rr + i) * 64 + lane], xch[(2 * 16 + 4 * rr + i + 1) * 64 + lane]};
+                const wn_f2 p3 = {xch[(3 * 16 + 4 * rr + i) * 64 + lane], xch[(3 * 16 + 4 * rr + i + 1) * 64 + lane]};
+                const wn_f2 y0 = (p0 + p1) + p2, y1 = (p1 - p2) - p3;
+                out[0][0][4 * (0 * 2 + j) + i] = y0.x; out[0][0][4 * (0 * 2 + j) + i + 1] = y0.y;
+                out[0][0][4 * (1 * 2 + j) + i] = y1.x; out[0][0][4 * (1 * 2 + j) + i + 1] = y1.y;
             }
             lds_barrier();                           // the set is rewritten (phase 1) / becomes transpose scratch
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's pieces of the next item's chunk 0 (no store is in flight yet)
+        W11T(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the next item's chunk 0 and the channel constants (no store is in flight yet)
+        W11T(5);
         const WinoArgs& args = wino_args_fresh();
         const TapGemmArgs& g = args.g;
         int* rowa = tables + tcur * W11_TABF;
         int* rowy = rowa + 256;
         int* prow = rowy + 256;
-        if (more) wino11_tables(args, wino9_geo(args, itn / nnb), tid, tables + (tcur ^ 1) * W11_TABF, tables + (tcur ^ 1) * W11_TABF + 256,
-                                tables + (tcur ^ 1) * W11_TABF + 512);
-        float* scratch = (wave < 4 ? rfree : ufree) + (wave & 3) * (32 * 33);
-        if (args.pool_y) {
-            // fused 2 x 2 pool: register 4 p + i = pixel p of tile i + 4 lh -- the window is lane-local.  Same arithmetic and
-            // association as asr_pool_fwd on the stored activation (bit-identical): BN(ReLU(x + bias)), row pairs, then the rows.
-            const int pool_n = n0 + li;
-            float bs = 0.f, scv = 1.f, shv = 0.f;
-            if (pool_n < g.N) { bs = pconst[pool_n]; scv = pconst[g.N + pool_n]; shv = pconst[2 * g.N + pool_n]; }
-            floatx16 po[1][1];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) po[0][0][r] = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float vv[4];
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    float x = out[0][0][4 * p + i] + bs;
-                    if (g.relu == 1) x = fmaxf(x, 0.f);
-                    else if (g.relu == 2) x = tanhf(x);
-                    vv[p] = fmaf(scv, x, shv);
-                }
-                po[0][0][i] = args.pool_mode == 1 ? 0.25f * ((vv[0] + vv[1]) + (vv[2] + vv[3])) : fmaxf(fmaxf(vv[0], vv[1]), fmaxf(vv[2], vv[3]));
-            }
-            TapGemmArgs gp = g;
-            gp.out_a = args.pool_y; gp.ldo_a = g.N; gp.out_y = nullptr; gp.bias = nullptr; gp.relu = 0; gp.accumulate = 0; gp.gate_mode = 0;
-            tap_epilogue<1, 1>(gp, po, scratch, prow, prow, wave * 32, n0, lane, 0);
+        if (newblk) {                                // the next tile block: its patch offsets and (second table set) its row tables
+            const Wino9Geo en = wino9_geo(args, blk + 1);
+            patch_offsets(en);
+            wino11_tables(args, en, tid, tables + (tcur ^ 1) * W11_TABF, tables + (tcur ^ 1) * W11_TABF + 256, tables + (tcur ^ 1) * W11_TABF + 512);
         }
-        tap_epilogue<1, 1>(g, out, scratch, rowa, rowy, wave * 32, n0, lane, blk * 8 + wave);
+        W11T(6);
+        float* scratch = (wave < 4 ? rfree : ufree) + (wave & 3) * (32 * 33);
+        const int* ra_w = rowa + wave * 32;
+        const int* ry_w = rowy + wave * 32;
+        if (EPI == W11_EPI_GENERIC) {
+            if (args.pool_y) {
+                // fused 2 x 2 pool, run-time options (see the specialised form below)
+                const int pool_n = n0 + li;
+                const bool pcol = pool_n < g.N;
+                float bs = 0.f, scv = 1.f, shv = 0.f;
+                if (pcol) { bs = pconst[pool_n]; scv = pconst[g.N + pool_n]; shv = pconst[2 * g.N + pool_n]; }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float vv[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) {
+                        float x = out[0][0][4 * p + i] + bs;
+                        if (g.relu == 1) x = fmaxf(x, 0.f);
+                        else if (g.relu == 2) x = tanhf(x);
+                        vv[p] = fmaf(scv, x, shv);
+                    }
+                    const float pv = args.pool_mode == 1 ? 0.25f * ((vv[0] + vv[1]) + (vv[2] + vv[3])) : fmaxf(fmaxf(vv[0], vv[1]), fmaxf(vv[2], vv[3]));
+                    const int pr = prow[wave * 32 + i + 4 * lh];
+                    if (pr >= 0 && pcol) __builtin_nontemporal_store(pv, args.pool_y + (long)pr * g.N + pool_n);
+                }
+            }
+            W11T(7);
+            tap_epilogue<1, 1>(g, out, scratch, rowa, rowy, wave * 32, n0, lane, blk * 8 + wave);
+        } else {
+            // everything the specialised epilogues need from the argument block, loaded once
+            const int N = g.N;
+            const unsigned n4 = ncol ? (unsigned)ne * 4u : W11_OOR;
+            const unsigned pa = (unsigned)g.ldo_a * 4u, py = (unsigned)g.ldo_y * 4u;
+            auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)(POOLED || EPI == W11_EPI_FWD ? g.out_a : g.out_y), 0, 0xFFFFFFF0, 0x00020000);
+            auto rY = __builtin_amdgcn_make_buffer_rsrc((void*)g.out_y, 0, 0xFFFFFFF0, 0x00020000);
+            if (POOLED) {
+                // fused 2 x 2 pool: register 4 p + i = pixel p of tile i + 4 lh -- the window is lane-local.  Same arithmetic and
+                // association as asr_pool_fwd on the stored activation (bit-identical): BN(ReLU(x + bias)), row pairs, then the rows.
+                // Stored straight from the registers: a half-wave writes the 128 bytes of one pooled pixel's 32 channels.
+                auto rP = __builtin_amdgcn_make_buffer_rsrc((void*)args.pool_y, 0, 0xFFFFFFF0, 0x00020000);
+                const int pool_n = n0 + li;
+                const bool pcol = pool_n < N;
+                float bs = 0.f, scv = 1.f, shv = 0.f;
+                if (pcol) { bs = pconst[pool_n]; scv = pconst[N + pool_n]; shv = pconst[2 * N + pool_n]; }
+                unsigned po[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int pr = prow[wave * 32 + i + 4 * lh];
+                    po[i] = (pr >= 0 && pcol) ? __umul24((unsigned)pr, (unsigned)N * 4u) + (unsigned)pool_n * 4u : W11_OOR;
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float vv[4];
+#pragma unroll
+                    for (int p = 0; p < 4; ++p) vv[p] = fmaf(scv, fmaxf(out[0][0][4 * p + i] + bs, 0.f), shv);
+                    const float pv = EPI == W11_EPI_POOLAVG ? 0.25f * ((vv[0] + vv[1]) + (vv[2] + vv[3])) : fmaxf(fmaxf(vv[0], vv[1]), fmaxf(vv[2], vv[3]));
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pv), rP, po[i], 0, 2);
+                }
+            }
+            W11T(7);
+            if (EPI == W11_EPI_FWD) wino11_epilogue_plain<true, true, true, false>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
+            else if (POOLED) wino11_epilogue_plain<true, true, false, false>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
+            else if (EPI == W11_EPI_DGRAD) wino11_epilogue_plain<false, false, true, false>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
+            else if (EPI == W11_EPI_DGRAD_ACC) wino11_epilogue_plain<false, false, true, true>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
+            else {
+                auto rGA = __builtin_amdgcn_make_buffer_rsrc((void*)g.gate_a, 0, 0xFFFFFFF0, 0x00020000);
+                auto rGD = __builtin_amdgcn_make_buffer_rsrc((void*)g.gate_dz, 0, 0xFFFFFFF0, 0x00020000);
+                const unsigned c4b = (unsigned)N * 4u, wpf4 = (unsigned)(g.gate_W + 1) * c4b;
+                const bool accu = g.accumulate != 0;
+                float* gpart = g.gate_part;
+                constexpr int GM = EPI == W11_EPI_GATE1 ? 1 : EPI == W11_EPI_GATE2 ? 2 : 3;
+                wino11_epilogue_gated<GM>(rGA, rGD, rY, accu, py, c4b, wpf4, gpart, N, out[0][0], scratch, ra_w, ry_w, ne, n4, csc, csh, lane, blk * 8 + wave);
+            }
+        }
+        W11T(8);
         lds_barrier();                               // scratch sets and this item's tables are free; the next item's tables and data visible
-        tcur ^= 1;
+        W11T(11);
+        if (newblk) tcur ^= 1;
     }
 }
 #endif
 
-template <int DIR>
+template <int DIR, int EPI>
 __global__ __launch_bounds__(512, 4) void wino11_kernel(WinoArgs args) {
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    switch (threadIdx.x >> 7) {
-        case 0: wino11_body<0>(smem); break;
-        case 1: wino11_body<1>(smem); break;
-        case 2: wino11_body<2>(smem); break;
-        default: wino11_body<3>(smem); break;
-    }
+    wino11_body<EPI>(smem);
 #endif
 }
+
 
 template <int DIR>
 __global__ __launch_bounds__(512) void wino8_kernel(WinoArgs args) {
@@ -1393,19 +1660,26 @@ __global__ __launch_bounds__(512) void wino8_kernel(WinoArgs args) {
 
 }  // namespace
 
+#ifdef W11_TRACE
+extern "C" int asr_w11_trace_dump(long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(w11_trace_buf), sizeof(long long) * 8 * 8 * 16) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef WINO_TRACE
 extern "C" int asr_wino_trace_dump(long long* host) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(wino_trace_buf), sizeof(long long) * 4 * 8 * 16) == hipSuccess ? 0 : 1;
 }
 #endif
 
-extern "C" size_t asr_winograd_weights_bytes(int K, int N) { return (size_t)16 * K * N * sizeof(float); }
+// two layouts side by side: [16][K][N] (wino8_kernel) and, 16 K N floats further, the chunk-major one of wino11_kernel
+extern "C" size_t asr_winograd_weights_bytes(int K, int N) { return (size_t)2 * 16 * K * N * sizeof(float); }
 
 extern "C" int asr_winograd_weights(const float* W, int K, int N, int ldw, int wmode, float* out, void* stream) {
     if (!W || !out || K < 1 || N < 1 || ldw < 1) return ASR_ERR_BAD_ARG;
     long nb = ((long)K * N + 255) / 256;
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(wino_weights_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, W, K, N, ldw, wmode, out);
+    float* out2 = ((K & 7) == 0 && (N & 31) == 0) ? out + (size_t)16 * K * N : nullptr;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((int)nb), dim3(256), 0, (hipStream_t)stream, W, K, N, ldw, wmode, out, out2);
     ASR_CHECK_LAUNCH("winograd_weights");
     return ASR_OK;
 }
@@ -1475,6 +1749,9 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
     a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
     a.nt_store = 1;       // streaming stores: -2..3 % per layer (the planes do not fit L2 anyway)
+#if defined(W11_ABL) && (W11_ABL & 256)
+    a.nt_store = 0;
+#endif
     a.gate_mode = 0; a.gate_H = a.gate_W = 0; a.gate_a = nullptr; a.gate_dz = nullptr; a.gate_part = nullptr; a.gate_rows = nullptr;
     if (gs) { a.gate_mode = gs->mode; a.gate_H = gs->H; a.gate_W = gs->W; a.gate_a = gs->a; a.gate_dz = gs->dz; a.gate_part = gs->part; a.gate_rows = gs->rows; }
     w.Ut = Ut;
@@ -1506,18 +1783,25 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
         const int grid11 = nwork11 > 2L * ncu8 ? 2 * ncu8 : (int)nwork11;     // persistent: two workgroups per CU
         const size_t lds11 = (size_t)(2 * W11_TABF + 4 * W11_SETF + (pool_y ? 3 * d->N : 0)) * sizeof(float);
         static_assert(4096 <= W11_SETF && 4 * 32 * 33 <= W11_SETF, "exchange phase / four transpose scratches must fit in one buffer set");
-        auto k0 = wino11_kernel<0>;
-        auto k1 = wino11_kernel<1>;
-        static bool f0 = false, f1 = false;
-        if (d->wmode) {
-            if (!f1) { (void)hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); f1 = true; }
-            hipLaunchKernelGGL(k1, dim3(grid11), dim3(512), lds11, (hipStream_t)stream, w);
-        } else {
-            if (!f0) { (void)hipFuncSetAttribute((const void*)k0, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); f0 = true; }
-            hipLaunchKernelGGL(k0, dim3(grid11), dim3(512), lds11, (hipStream_t)stream, w);
-        }
+        // the epilogue instantiation (wino11_body): decided by the descriptor
+        int epi = W11_EPI_GENERIC;
+        const bool aff = scale && shift;
+        if (gs) epi = gs->mode == 1 ? W11_EPI_GATE1 : gs->mode == 2 ? W11_EPI_GATE2 : W11_EPI_GATE3;
+        else if (!d->wmode && d->relu == 1 && bias && aff && out_a && pool_y) epi = pool_mode == 2 ? W11_EPI_POOLMAX : W11_EPI_POOLAVG;
+        else if (!d->wmode && d->relu == 1 && bias && aff && out_a && out_y && !d->accumulate && !pool_y) epi = W11_EPI_FWD;
+        else if (d->wmode && d->relu == 0 && !bias && !scale && !shift && !out_a && out_y && !pool_y) epi = d->accumulate ? W11_EPI_DGRAD_ACC : W11_EPI_DGRAD;
+        typedef void (*w11_fn)(WinoArgs);
+        static const w11_fn fns[9] = {nullptr, wino11_kernel<0, 1>, wino11_kernel<0, 2>, wino11_kernel<0, 3>, wino11_kernel<1, 4>, wino11_kernel<1, 5>,
+                                      wino11_kernel<1, 6>, wino11_kernel<1, 7>, wino11_kernel<1, 8>};
+        const w11_fn fn = epi ? fns[epi] : (d->wmode ? (w11_fn)wino11_kernel<1, 0> : (w11_fn)wino11_kernel<0, 0>);
+        static bool attr[10] = {false, false, false, false, false, false, false, false, false, false};
+        const int slot = epi ? epi : (d->wmode ? 9 : 0);
+        if (!attr[slot]) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr[slot] = true; }
+        hipLaunchKernelGGL(fn, dim3(grid11), dim3(512), lds11, (hipStream_t)stream, w);
         ASR_CHECK_LAUNCH("tap_gemm_wino11");
-        if (d->wmode) ASR_NOTE_KERNEL("wino11_kernel<1>"); else ASR_NOTE_KERNEL("wino11_kernel<0>");
+        static const char* const names[10] = {"wino11_kernel<0, 0>", "wino11_kernel<0, 1>", "wino11_kernel<0, 2>", "wino11_kernel<0, 3>", "wino11_kernel<1, 4>",
+                                              "wino11_kernel<1, 5>", "wino11_kernel<1, 6>", "wino11_kernel<1, 7>", "wino11_kernel<1, 8>", "wino11_kernel<1, 0>"};
+        asr_set_last_kernel(names[slot]);
         return ASR_OK;
     }
     bool use10 = (d->N % WC) != 0;

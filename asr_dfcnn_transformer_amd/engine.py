@@ -390,9 +390,9 @@ class DFCNNEngine:
                 if op[0] == 'cell' and op[1] != 'x' and op[5] == 3:
                     _, src, dst, cin, cout, k, pool = op
                     if ops.winograd_supported(self.fdesc[dst]):
-                        self.wt_f[dst] = torch.zeros(16 * cin * cout, dtype=torch.float32, device=dev)
+                        self.wt_f[dst] = torch.zeros(ops.winograd_weights_floats(cin, cout), dtype=torch.float32, device=dev)
                     if ops.winograd_supported(self.bdesc[dst]):
-                        self.wt_b[dst] = torch.zeros(16 * cin * cout, dtype=torch.float32, device=dev)
+                        self.wt_b[dst] = torch.zeros(ops.winograd_weights_floats(cin, cout), dtype=torch.float32, device=dev)
         self.labels = torch.zeros(B, MAX_LABEL, dtype=torch.int32, device=dev)
         self.label_len = torch.zeros(B, dtype=torch.int32, device=dev)
         self.seq_len = torch.zeros(B, dtype=torch.int32, device=dev)

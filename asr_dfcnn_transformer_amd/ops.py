@@ -524,6 +524,11 @@ def arrange_weights(W, ntaps, K, N, ldw, wmode=0, out=None):
     return out
 
 
+def winograd_weights_floats(K, N):
+    """floats of the buffer asr_winograd_weights fills (two layouts side by side, asr_winograd_weights_bytes)"""
+    return _lib.load().asr_winograd_weights_bytes(K, N) // 4
+
+
 def winograd_weights(W, K, N, ldw, wmode=0, out=None):
     """U = G g G^T of a 3x3 layer, [16][K][N] (asr_winograd_weights)."""
     lib = _lib.load()

@@ -119,9 +119,9 @@ class PreNetEngine:
         if (os.environ.get('ASR_WINO', '1') == '1') if wino is None else bool(wino):
             for k, cin in self._cin.items():
                 if ops.winograd_supported(self.d_conv[k]):
-                    self.wt_f[k] = torch.zeros(16 * cin * CH, dtype=torch.float32, device=device)
+                    self.wt_f[k] = torch.zeros(ops.winograd_weights_floats(cin, CH), dtype=torch.float32, device=device)
                 if ops.winograd_supported(self.d_dx[k]):
-                    self.wt_b[k] = torch.zeros(16 * cin * CH, dtype=torch.float32, device=device)
+                    self.wt_b[k] = torch.zeros(ops.winograd_weights_floats(cin, CH), dtype=torch.float32, device=device)
 
     # ---- parameters
     def p(self, name, buf=None):
