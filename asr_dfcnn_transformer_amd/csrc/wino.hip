@@ -38,7 +38,7 @@ struct WinoArgs {
     int wodd;               // plane width is odd
     float* pool_y;          // eight-wave kernel: pooled BN output plane [B][H/2+1][W/2+1][N] of a fused 2x2 pool, or null
     int pool_mode, H2, W2;  // 1 average, 2 maximum
-    // column-blocked tile order (wino9_kernel): the tile columns of an image are cut into ncb blocks of 11..15 columns; the tiles
+    // column-blocked tile order (wino11_kernel): the tile columns of an image are cut into ncb blocks of 11..15 columns; the tiles
     // of a block are numbered row-major WITHIN the block and a work item is 64 consecutive tiles of one block
     int ncb;                // number of column blocks (0: plain order, wino8_kernel)
     int cb_tj0[8];          // first tile column of the block
@@ -218,13 +218,12 @@ __device__ __forceinline__ void wino8_chunk(const float* __restrict__ raw, const
     mfmas(v, 1, ubb, -1);
 }
 
-// The item tail shared by wino8_kernel and wino9_kernel: exchange of the column sums between the two halves, the lane-local inverse
+// The item tail of wino8_kernel: exchange of the column sums between the two halves, the lane-local inverse
 // transform, the fused pool and the epilogues.  rfree / ufree: the raw and the weight buffer set that no DMA is writing (8192
 // floats each).
-// `before_stores` runs after the exchange and before the first global store of the epilogues (wino9_kernel: the place where the
-// next item's DMA is waited for and its row tables are written).
+// `before_stores` runs after the exchange and before the first global store of the epilogues.
 struct WinoNoHook { __device__ __forceinline__ void operator()() const {} };
-// NWH = waves per position half (4: the eight-wave kernels, 2: wino10_kernel); ws = this wave's index within its half.
+// NWH = waves per position half (4); ws = this wave's index within its half.
 template <int XH, class Hook = WinoNoHook, int NWH = 4>
 __device__ __forceinline__ void wino_item_tail(const WinoArgs& args, floatx16 (&acc)[8], float* rfree, float* ufree, const int* rowa,
                                                const int* rowy, const int* prow, int wave, int lane, int wm, int wn, int n0, int blk,
@@ -448,30 +447,23 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------ wino9_kernel (round 3)
-// The same computation with the raw patches fetched ONCE.  wino8_kernel fetches the 4 x 4 patch of every tile separately: 16 pixels
-// x 2 quads x 64 tiles = 2048 16-byte slots per 8-channel chunk, every DMA instruction 64 lanes on 64 different 128-byte lines,
-// every pixel four times (the patches of neighbouring tiles overlap by two pixels) -- the ablation in profiles/r03_wino_ablation.txt
-// prices those 32 instructions per chunk at 17-20 % of the kernel.  Here:
-//   * the tile columns of an image are cut into column blocks of w = 11..15 columns and the tiles are numbered row-major WITHIN a
-//     block, so that the 64 consecutive tiles of an item cover <= 7 tile rows x w columns: a region of <= 16 pixel rows x (2 w + 2)
-//     pixel columns holds every patch of the item once;
-//   * the region is fetched for SIXTEEN channels at a time (a "super-chunk" = two 8-channel chunks): a DMA piece is one pixel row
-//     and one column parity -- <= 16 pixels (pixel columns 2 idx + par) x 64 contiguous bytes: 16 lines per instruction instead of
-//     64, and <= 32 pieces per 16 channels instead of 64 per 16: the addresser time of the raw fetch drops about eightfold;
-//   * LDS layout of a piece (64 slots of 16 bytes): [channel quad 0..3][position 0..15]; the pixel idx of row Y sits at position
-//     (idx + rho(Y)) & 15, rho(Y) = ((Y >> 1) w) & 15 -- so that the ds_read_b128 of patch pixel (r, c) by the 32 lanes of a
-//     half-wave (tile l of the block reads idx = tc + (c >> 1) of row 2 tr + r) lands on position (l + (r >> 1) w + (c >> 1)) & 15:
+// ------------------------------------------------------------------------------------------------ column-blocked tile order
+// The tile columns of an image are cut into column blocks of w = 11..15 columns and the tiles are numbered row-major WITHIN a block,
+// so that the 64 consecutive tiles of an item cover <= 7 tile rows x w columns: a region of <= 16 pixel rows x (2 w + 2) pixel
+// columns holds every patch of the item once (round 3: wino9_kernel / wino10_kernel, superseded by wino11_kernel in round 4, which
+// keeps their raw-region fetch):
+//   * a DMA piece is one PAIR of pixel rows and one column parity -- <= 16 pixels (columns 2 idx + par) x 2 rows x two 16-byte channel
+//     quads: [row 2][quad 2][position 16] 16-byte slots;
+//   * the pixel idx of row pair m sits at position (idx + rho(m)) & 15, rho(m) = ((tr0 + m) w) & 15 -- so that the ds_read_b128 of
+//     patch pixel (r, c) by the 32 lanes of a half-wave (tile l of the block) lands on position (l + (r >> 1) w + (c >> 1)) & 15:
 //     consecutive tiles on consecutive positions, whatever w is -- conflict-free on the instruction's 16-lane service groups;
-//   * columns past the plane's width and rows past the image are sent out of the buffer's range and read zeros (no patch column
-//     to clear for odd widths).
-// The weights arrive as before (per 8-channel chunk), all pieces by buffer-form DMA (scalar row offsets, no vector instruction
-// per piece).  Items do not span column blocks or images: the last item of a block may be partly empty (1-3 % of the tiles).
+//   * columns past the plane's width and rows past the image are sent out of the buffer's range and read zeros.
+// Items do not span column blocks or images: the last item of a block may be partly empty (1-3 % of the tiles).
 #if __HIP_DEVICE_COMPILE__
-struct Wino9Geo { int b, tj0, w, l0, tr0, npieces; };
+struct WinoGeo { int b, tj0, w, l0, tr0, npieces; };
 
-__device__ __forceinline__ Wino9Geo wino9_geo(const WinoArgs& args, int blk) {
-    Wino9Geo e;
+__device__ __forceinline__ WinoGeo wino_geo(const WinoArgs& args, int blk) {
+    WinoGeo e;
     const int ipi = args.cb_it0[args.ncb];
     e.b = blk / ipi;
     const int rem = blk - e.b * ipi;
@@ -484,553 +476,21 @@ __device__ __forceinline__ Wino9Geo wino9_geo(const WinoArgs& args, int blk) {
     e.npieces = 2 * (2 * rows + 2);                           // pixel rows x column parities
     return e;
 }
-
-template <class R>
-struct Wino9Dma {
-    R ra, ru;
-    unsigned voff[4];        // raw pieces wave + 8 j of a super-chunk
-    unsigned sbase;          // byte offset of the region's first pixel (channel 0)
-    unsigned off_u;
-    int npieces, wave, rowbytes, N;
-    unsigned ustride_xi;     // floats between the weight matrices of two positions (16 K N floats < 2^30)
-};
-
-// per-lane offsets of the raw pieces this wave issues (piece p = wave + 8 j: pixel row p >> 1 of the region, parity p & 1)
-template <class R>
-__device__ __forceinline__ void wino9_offsets(const WinoArgs& args, const Wino9Geo& e, int lane, Wino9Dma<R>& q) {
-    const TapGemmArgs& g = args.g;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = q.wave + 8 * j, y = p >> 1, par = p & 1;
-        const int rho = ((e.tr0 + (y >> 1)) * e.w) & 15;
-        const int idx = ((lane & 15) - rho) & 15;
-        const int x = 2 * idx + par;
-        const bool ok = idx <= e.w && 2 * e.tj0 + x < g.WP && 2 * e.tr0 + y <= g.H + 1 && p < e.npieces;
-        q.voff[j] = ok ? (unsigned)((x * g.lda + (lane >> 4) * 4) * 4) : 0xFFFFFFF0u;
-    }
-    q.sbase = (unsigned)((((long)e.b * g.HPWP + (long)(2 * e.tr0) * g.WP + 2 * e.tj0) * g.lda) * 4);
-    q.npieces = e.npieces;
-}
-// per-lane offset inside a weight piece (4 rows of N floats): row lane / 16, column quad lane % 16 of channel block n0
-__device__ __forceinline__ unsigned wino9_u_offset(const WinoArgs& args, int n0, int lane) {
-    return (unsigned)(((long)(lane >> 4) * args.g.N + n0 + (lane & 15) * 4) * 4);
-}
-
-// raw piece jr (0..3) of the super-chunk whose first channel is c16, into raw set `raw`
-template <class R>
-__device__ __forceinline__ void wino9_raw_piece(const Wino9Dma<R>& q, float* __restrict__ raw, int jr, int c16) {
-    // always issued (a piece past the region has every lane out of range: it moves nothing), so that the number of DMA
-    // instructions a wave has in flight is known to the s_waitcnt of the chunk barrier
-    const int p = q.wave + 8 * jr;
-#if defined(WINO_ABL) && (WINO_ABL & 4)
-    return;
 #endif
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(q.ra, (wn_lds_f*)(raw + p * 256), 16, q.voff[jr],
-                                             (int)(q.sbase + (unsigned)((p >> 1) * q.rowbytes + c16 * 4)), 0, 0);
-}
-// weight piece ju (0..3) of chunk kc: piece p = wave + 8 ju = xi * 2 + (ci >> 2)
-template <class R>
-__device__ __forceinline__ void wino9_u_piece(const Wino9Dma<R>& q, float* __restrict__ ub, int ju, int kc) {
-    const int p = q.wave + 8 * ju;
-    const int xi = p >> 1, cig = p & 1;
-#if defined(WINO_ABL) && (WINO_ABL & 8)
-    return;
-#endif
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(q.ru, (wn_lds_f*)(ub + p * 256), 16, q.off_u,
-                                             (int)((xi * q.ustride_xi + (unsigned)((kc * WKC + cig * 4) * q.N)) * 4u), 0, 0);
-}
-
-// One 8-channel chunk (half hh of its super-chunk) in two phases.  Phase A: the LDS reads of the chunk (12 patch pixels, the
-// weights of all four k-pairs as the registers come free), both input transforms and the first sixteen MFMAs; phase B: the other
-// sixteen MFMAs, from registers only.  (Running the two waves of a SIMD half a chunk apart -- half 1 arriving at the chunk barrier
-// between its phases, so that one of them always has MFMAs in registers behind a barrier -- was tried: 2 % slower, the half that
-// is ahead waits for the other at the item's exchange.)
-// Prefetches sit between the MFMAs of two groups (`slots`): the four weight pieces of chunk `kcn` (into ubn), then -- in the
-// FIRST chunk of a super-chunk -- the four raw pieces of the super-chunk at channel c16n (into rawn): those have the rest of
-// this chunk and the whole next one to arrive (every second super-chunk starts new 128-byte lines, i.e. comes from HBM rather
-// than L2: the in-kernel stamps of wino8_kernel showed exactly those chunks 1.5 us longer).
-struct Wino9Regs { wn_f2 v[8]; float ua[8], ubb[8]; };
-template <class R>
-struct Wino9Pre { bool u, raw; int kcn, c16n; float* rawn; float* ubn; const Wino9Dma<R>* q; };
-
-// eight MFMAs; what = 1: a weight piece, 2: a raw piece behind MFMA 1, 3, 5, 7
-template <class R>
-__device__ __forceinline__ void wino9_group(floatx16 (&acc)[8], const wn_f2 (&v)[8], int h, const float (&u)[8], int what,
-                                            const Wino9Pre<R>& pf) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[i].y : v[i].x, u[i], acc[i], 0, 0, 0);
-        if (what && (i & 1)) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (what == 1 && pf.u) wino9_u_piece(*pf.q, pf.ubn, i >> 1, pf.kcn);
-            if (what == 2 && pf.raw) wino9_raw_piece(*pf.q, pf.rawn, i >> 1, pf.c16n);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
-template <int XH, class R>
-__device__ __forceinline__ void wino9_phase_a(const float* __restrict__ raw, const float* __restrict__ ub, const Wino9Pre<R>& pf, bool slots,
-                                              int hh, const unsigned (&lb)[4], int boff, floatx16 (&acc)[8], Wino9Regs& rg) {
-    auto load_u = [&](float (&u)[8], int kp) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-#if defined(WINO_ABL) && (WINO_ABL & 2)
-            for (int j = 0; j < 2; ++j) u[r * 2 + j] = __int_as_float(boff + r * 2 + j + kp);
-#else
-            for (int j = 0; j < 2; ++j) u[r * 2 + j] = ub[((r * 4 + 2 * XH + j) * WKC + kp) * WC + boff];
-#endif
-    };
-    float4 d[12];
-    const char* rb = (const char*)raw + hh * 512;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int cc = XH + c;
-#if defined(WINO_ABL) && (WINO_ABL & 1)
-            { const float f = __uint_as_float(lb[(r >> 1) * 2 + (cc >> 1)] + r * 3 + c); d[r * 3 + c] = make_float4(f, f * 2.f, f * 3.f, f * 4.f); }
-#else
-            d[r * 3 + c] = *(const float4*)(rb + lb[(r >> 1) * 2 + (cc >> 1)] + r * 2048 + (cc & 1) * 1024);
-#endif
-        }
-    load_u(rg.ua, 0);
-    load_u(rg.ubb, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    wino8_transform<XH>(d, 0, rg.v);
-    __builtin_amdgcn_sched_barrier(0);
-    wino9_group(acc, rg.v, 0, rg.ua, slots ? 1 : 0, pf);
-    __builtin_amdgcn_sched_barrier(0);
-    load_u(rg.ua, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    wino9_group(acc, rg.v, 1, rg.ubb, slots ? 2 : 0, pf);
-    __builtin_amdgcn_sched_barrier(0);
-    load_u(rg.ubb, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    wino8_transform<XH>(d, 1, rg.v);
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <class R>
-__device__ __forceinline__ void wino9_phase_b(const Wino9Pre<R>& pf, bool slots, floatx16 (&acc)[8], const Wino9Regs& rg) {
-    __builtin_amdgcn_sched_barrier(0);
-    wino9_group(acc, rg.v, 0, rg.ua, slots ? 1 : 0, pf);
-    __builtin_amdgcn_sched_barrier(0);
-    wino9_group(acc, rg.v, 1, rg.ubb, slots ? 2 : 0, pf);
-    __builtin_amdgcn_sched_barrier(0);
-}
-
-// row tables of one item (threads 0..255: 64 tiles x 4 pixels): plane row of every output pixel for out_a / out_y, and the row of
-// the tile's pooled pixel
-__device__ __forceinline__ void wino9_tables(const WinoArgs& args, const Wino9Geo& e, int tid, int* rowa, int* rowy, int* prow) {
-    const TapGemmArgs& g = args.g;
-    if (tid < 256) {
-        const int tl = tid & 63, pl = tid >> 6;
-        const int l = e.l0 + tl;
-        const int ti = l / e.w, tj = e.tj0 + l - ti * e.w;
-        int ra_ = -1, ry = -1;
-        if (ti < args.TH) {
-            const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
-            if (ww <= g.Wd && hh <= g.H) {
-                ra_ = (int)((long)e.b * g.HPWP + (long)hh * g.WP + ww);
-                ry = g.y_unpadded ? ((e.b * g.H + hh - 1) * g.Wd + ww - 1) : ra_;
-            }
-        }
-        const int m = (tl >> 5) * 128 + pl * 32 + (tl & 31);
-        rowa[m] = ra_; rowy[m] = ry;
-        if (pl == 0) {
-            int pr = -1;
-            if (args.pool_y && ti < args.TH && tj < args.W2 && ti < args.H2) pr = (e.b * (args.H2 + 1) + ti + 1) * (args.W2 + 1) + tj + 1;
-            prow[tl] = pr;
-        }
-    }
-}
-
-// Item flow: [chunks of item i, the last ones prefetching item i + 1] -> exchange of the halves -> WAIT for the prefetched DMA (no
-// store is in flight at that point, so the wait is for the DMA alone) -> row tables of item i + 1 (second table set) -> epilogue
-// stores of item i -> one LDS-only barrier -> chunks of item i + 1.  Nothing waits for the stores until the first chunk barrier of
-// the next item (vmcnt counts loads and stores together on this ISA), so they drain behind a chunk of MFMA work: every workgroup
-// runs items of the same length from the same start, the stores of all 256 CUs come in one burst, and before this order every
-// wave sat out the burst at the top of the next item.
-template <int XH>
-__device__ __forceinline__ void wino9_body(const WinoArgs& args, float* smem) {
-    const TapGemmArgs& g = args.g;
-    int* tables = (int*)smem;                        // two sets of [rowa 256 | rowy 256 | prow 64]
-    float* bufs = smem + 2 * 576;                    // raw0 | raw1 | u0 | u1
-    float* pconst = bufs + 2 * RAW_F + 2 * U_F;      // fused pool: [bias N | scale N | shift N] (read per item without a vector
-                                                     // memory load: a load in the item loop makes hipcc wait for vmcnt(0) -- i.e. for the
-                                                     // previous item's stores -- at the top of every item)
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = (wave >> 1) & 1, wn = wave & 1;                       // wave = xh * 4 + wm * 2 + wn
-    const int boff = lh * 4 * WC + wn * 32 + li;     // half 1 contracts channels 4 .. 7 of the chunk
-    const int nkc = g.K / WKC;                       // even (K % 16 == 0), >= 4
-    const int nnb = g.ntn, nwork = g.ntm * nnb;
-
-    int w = blockIdx.x;
-    if (w >= nwork) return;
-    const int G = gridDim.x;
-    auto item_of = [&](int wl) {                     // see wino8_body
-        const int r0 = (wl / G) * G;
-        if ((G & 7) || r0 + G > nwork) return wl;
-        const int p = wl - r0;
-        return r0 + (p & 7) * (G >> 3) + (p >> 3);
-    };
-    auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7FFFFFF0, 0x00020000);
-    auto ru = __builtin_amdgcn_make_buffer_rsrc((void*)args.Ut, 0, 0x7FFFFFF0, 0x00020000);
-    Wino9Dma<decltype(ra)> q;
-    q.ra = ra; q.ru = ru; q.wave = wave; q.rowbytes = g.WP * g.lda * 4; q.N = g.N; q.ustride_xi = (unsigned)(g.K * g.N);
-    int rcur = 0, ucur = 0, tcur = 0;                // raw set of the current super-chunk, weight set of the current chunk, table set
-    {
-        const int it = item_of(w);
-        const Wino9Geo e = wino9_geo(args, it / nnb);
-        wino9_offsets(args, e, lane, q);
-        q.off_u = wino9_u_offset(args, (it % nnb) * WC, lane);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { wino9_raw_piece(q, bufs, j, 0); wino9_u_piece(q, bufs + 2 * RAW_F, j, 0); }
-        wino9_tables(args, e, tid, tables, tables + 256, tables + 512);
-        if (args.pool_y)
-            for (int n = tid; n < g.N; n += 512) {
-                pconst[n] = g.bias ? g.bias[n] : 0.f;
-                pconst[g.N + n] = g.scale ? g.scale[n] : 1.f;
-                pconst[2 * g.N + n] = g.shift ? g.shift[n] : 0.f;
-            }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the first super-chunk and chunk 0 of the first item
-        lds_barrier();
-    }
-
-    for (; w < nwork; w += gridDim.x) {
-        const int item = item_of(w);
-        const int blk = item / nnb, nb = item - blk * nnb;
-        const Wino9Geo e = wino9_geo(args, blk);
-        const int n0 = nb * WC;
-        int* rowa = tables + tcur * 576;
-        int* rowy = rowa + 256;
-        int* prow = rowy + 256;
-        // LDS byte offsets of this lane's patch pixels inside a raw set: tile l of the block, its row relative to the region
-        unsigned lb[4];
-        {
-            const int l = e.l0 + wm * 32 + li;
-            const int trl = l / e.w - e.tr0;
-            const unsigned fix = (unsigned)(trl * 4096 + lh * 256);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) lb[j] = fix + (unsigned)(((l + (j >> 1) * e.w + (j & 1)) & 15) * 16);
-        }
-        floatx16 acc[8];
-        Wino9Regs rg;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-        const int wnext = w + gridDim.x;
-        const bool more = wnext < nwork;
-        const int itn = more ? item_of(wnext) : 0;
-        for (int kc = 0; kc < nkc; ++kc) {
-            const int hh = kc & 1;
-            const bool last = kc + 1 == nkc;
-            if (kc == nkc - 2 && more) wino9_offsets(args, wino9_geo(args, itn / nnb), lane, q);      // the raw prefetch now belongs to the next item
-            if (last && more) q.off_u = wino9_u_offset(args, (itn % nnb) * WC, lane);                  // and so does the weight prefetch
-            const bool tail2 = kc >= nkc - 2;
-            Wino9Pre<decltype(ra)> pf;
-            pf.u = last ? more : true; pf.raw = hh == 0 && (tail2 ? more : true);
-            pf.kcn = last ? 0 : kc + 1; pf.c16n = tail2 ? 0 : (kc + 2) * WKC;
-            pf.rawn = bufs + (rcur ^ 1) * RAW_F; pf.ubn = bufs + 2 * RAW_F + (ucur ^ 1) * U_F; pf.q = &q;
-            wino9_phase_a<XH>(bufs + rcur * RAW_F, bufs + 2 * RAW_F + ucur * U_F, pf, true, hh, lb, boff, acc, rg);
-            wino9_phase_b(pf, false, acc, rg);
-            // the weight pieces of the next chunk must have landed; the four raw pieces issued AFTER them in this chunk may stay
-            // in flight until the barrier of the super-chunk's second chunk
-            // (the barrier as plain instructions: a fence on the local address space makes hipcc wait for every DMA in flight)
-#if defined(WINO_ABL) && (WINO_ABL & 16)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-            if (last) lds_barrier();
-            else if (pf.raw) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-            ucur ^= 1;
-            rcur ^= hh;
-        }
-        // fused pool: this lane's channel constants (from LDS: not live across the chunk loop, no vector memory load in the loop)
-        const int pool_n = n0 + wn * 32 + li;
-        float pool_bs = 0.f, pool_sc = 1.f, pool_sh = 0.f;
-        if (args.pool_y && pool_n < g.N) { pool_bs = pconst[pool_n]; pool_sc = pconst[g.N + pool_n]; pool_sh = pconst[2 * g.N + pool_n]; }
-        auto before_stores = [&]() {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next item's first super-chunk / chunk 0
-            if (more) wino9_tables(args, wino9_geo(args, itn / nnb), tid, tables + (tcur ^ 1) * 576, tables + (tcur ^ 1) * 576 + 256,
-                                   tables + (tcur ^ 1) * 576 + 512);
-        };
-#if defined(WINO_ABL) && (WINO_ABL & 32)
-        { float sink = 0.f;
-#pragma unroll
-          for (int i = 0; i < 8; ++i)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) sink += acc[i][r];
-          if (sink == 123.456f) rowa[0] = 1; }
-        before_stores();
-#else
-        wino_item_tail<XH>(args, acc, bufs + (rcur ^ 1) * RAW_F, bufs + 2 * RAW_F + (ucur ^ 1) * U_F, rowa, rowy, prow, wave, lane, wm, wn, n0,
-                           blk, pool_bs, pool_sc, pool_sh, before_stores);
-#endif
-        lds_barrier();               // the scratch sets and this item's tables are free, the next item's tables and DMA'd data visible
-        tcur ^= 1;
-    }
-}
-#endif
-
-template <int DIR>
-__global__ __launch_bounds__(512) void wino9_kernel(WinoArgs args) {
-#if __HIP_DEVICE_COMPILE__
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((threadIdx.x >> 8) == 0) wino9_body<0>(args, smem);
-    else wino9_body<1>(args, smem);
-#endif
-}
-
-// ------------------------------------------------------------------------------------------------ wino10_kernel (round 3)
-// The same computation for 32-wide channel blocks: FOUR waves (wave = xh * 2 + wm: 32 tiles x 32 channels x 8 positions each, the
-// register budget of the eight-wave kernels), 64 tiles x 32 output channels per item, 72 KB of LDS -- TWO workgroups per CU, which
-// share each SIMD's matrix pipe and run out of phase by themselves: while one is behind a barrier or in its item tail the other
-// one computes.  Serves the views with N % 64 == 32 (the 64 -> 32 and 256 -> 32 data-gradients of acoustic_model.py, the 32-channel
-// layers of the SE graphs), which the 64-channel items cannot take.  Raw region as in wino9_kernel but per 8-channel chunk: a
-// piece = one PAIR of pixel rows and one column parity ([row 2][quad 2][position 16] 16-byte slots, both rows share the rotation).
-constexpr int W10_C = 32;                       // output channels per item
-constexpr int W10_RAWF = 4352;                  // floats of a raw set: 16 pieces of 256 (+ the pool hand-over behind the transpose scratch)
-constexpr int W10_UF = 16 * WKC * W10_C;        // floats of a weight set
-
-#if __HIP_DEVICE_COMPILE__
-// raw pieces wave + 4 j of a chunk: row pair p >> 1 of the region, parity p & 1
-template <class R>
-__device__ __forceinline__ void wino10_offsets(const WinoArgs& args, const Wino9Geo& e, int lane, Wino9Dma<R>& q) {
-    const TapGemmArgs& g = args.g;
-    const int np = e.npieces >> 1;                              // (rows + 1) row pairs x 2 parities
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int p = q.wave + 4 * j, m = p >> 1, par = p & 1;
-        const int rowbit = lane >> 5, quad = (lane >> 4) & 1;
-        const int y = 2 * m + rowbit;
-        const int rho = ((e.tr0 + m) * e.w) & 15;
-        const int idx = ((lane & 15) - rho) & 15;
-        const int x = 2 * idx + par;
-        const bool ok = idx <= e.w && 2 * e.tj0 + x < g.WP && 2 * e.tr0 + y <= g.H + 1 && p < np;
-        q.voff[j] = ok ? (unsigned)((((long)rowbit * g.WP + x) * g.lda + quad * 4) * 4) : 0xFFFFFFF0u;
-    }
-    q.sbase = (unsigned)((((long)e.b * g.HPWP + (long)(2 * e.tr0) * g.WP + 2 * e.tj0) * g.lda) * 4);
-    q.npieces = np;
-}
-template <class R>
-__device__ __forceinline__ void wino10_raw_piece(const Wino9Dma<R>& q, float* __restrict__ raw, int j, int kc) {
-    const int p = q.wave + 4 * j;
-#if defined(WINO_ABL) && (WINO_ABL & 4)
-    return;
-#endif
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(q.ra, (wn_lds_f*)(raw + p * 256), 16, q.voff[j],
-                                             (int)(q.sbase + (unsigned)((p >> 1) * 2 * q.rowbytes + kc * WKC * 4)), 0, 0);
-}
-// weight piece xi = wave + 4 j of chunk kc: [8 ci][32 co]
-template <class R>
-__device__ __forceinline__ void wino10_u_piece(const Wino9Dma<R>& q, float* __restrict__ ub, int j, int kc) {
-    const int xi = q.wave + 4 * j;
-#if defined(WINO_ABL) && (WINO_ABL & 8)
-    return;
-#endif
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(q.ru, (wn_lds_f*)(ub + xi * 256), 16, q.off_u,
-                                             (int)((xi * q.ustride_xi + (unsigned)(kc * WKC * q.N)) * 4u), 0, 0);
-}
-
-template <int XH, class R>
-__device__ __forceinline__ void wino10_chunk(const float* __restrict__ raw, const float* __restrict__ ub, float* __restrict__ rawn,
-                                             float* __restrict__ ubn, bool pre, const Wino9Dma<R>& q, int kcn, const unsigned (&lb)[4],
-                                             int boff, floatx16 (&acc)[8]) {
-    auto load_u = [&](float (&u)[8], int kp) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-#if defined(WINO_ABL) && (WINO_ABL & 2)
-            for (int j = 0; j < 2; ++j) u[r * 2 + j] = __int_as_float(boff + r * 2 + j + kp);
-#else
-            for (int j = 0; j < 2; ++j) u[r * 2 + j] = ub[((r * 4 + 2 * XH + j) * WKC + kp) * W10_C + boff];
-#endif
-    };
-    // eight MFMAs; behind MFMA 1, 3, 5, 7 one DMA piece of the next chunk: group 0 the weight pieces, group 1 the raw pieces
-    auto mfmas = [&](const wn_f2 (&v)[8], int h, const float (&u)[8], int group) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(h ? v[i].y : v[i].x, u[i], acc[i], 0, 0, 0);
-            if (group >= 0 && (i & 1)) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (pre) { if (group == 0) wino10_u_piece(q, ubn, i >> 1, kcn); else wino10_raw_piece(q, rawn, i >> 1, kcn); }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    float4 d[12];
-    float ua[8], ubb[8];
-    wn_f2 v[8];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int cc = XH + c;
-#if defined(WINO_ABL) && (WINO_ABL & 1)
-            { const float f = __uint_as_float(lb[(r >> 1) * 2 + (cc >> 1)] + r * 3 + c); d[r * 3 + c] = make_float4(f, f * 2.f, f * 3.f, f * 4.f); }
-#else
-            d[r * 3 + c] = *(const float4*)((const char*)raw + lb[(r >> 1) * 2 + (cc >> 1)] + (r >> 1) * 2048 + (cc & 1) * 1024 + (r & 1) * 512);
-#endif
-        }
-    load_u(ua, 0);
-    load_u(ubb, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    wino8_transform<XH>(d, 0, v);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(v, 0, ua, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    load_u(ua, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(v, 1, ubb, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    load_u(ubb, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    wino8_transform<XH>(d, 1, v);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(v, 0, ua, -1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(v, 1, ubb, -1);
-}
-
-template <int XH>
-__device__ __forceinline__ void wino10_body(const WinoArgs& args, float* smem) {
-    const TapGemmArgs& g = args.g;
-    int* tables = (int*)smem;                        // two sets of [rowa 256 | rowy 256 | prow 64]
-    float* bufs = smem + 2 * 576;                    // raw0 | raw1 | u0 | u1
-    float* pconst = bufs + 2 * W10_RAWF + 2 * W10_UF;
-    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1;                         // wave = xh * 2 + wm
-    const int boff = lh * 4 * W10_C + li;
-    const int nkc = g.K / WKC;
-    const int nnb = g.ntn, nwork = g.ntm * nnb;
-
-    int w = blockIdx.x;
-    if (w >= nwork) return;
-    const int G = gridDim.x;
-    auto item_of = [&](int wl) {                     // see wino8_body
-        const int r0 = (wl / G) * G;
-        if ((G & 7) || r0 + G > nwork) return wl;
-        const int p = wl - r0;
-        return r0 + (p & 7) * (G >> 3) + (p >> 3);
-    };
-    auto ra = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7FFFFFF0, 0x00020000);
-    auto ru = __builtin_amdgcn_make_buffer_rsrc((void*)args.Ut, 0, 0x7FFFFFF0, 0x00020000);
-    Wino9Dma<decltype(ra)> q;
-    q.ra = ra; q.ru = ru; q.wave = wave; q.rowbytes = g.WP * g.lda * 4; q.N = g.N; q.ustride_xi = (unsigned)(g.K * g.N);
-    auto u_offset = [&](int n0) { return (unsigned)(((long)(lane >> 3) * g.N + n0 + (lane & 7) * 4) * 4); };
-    int cur = 0, tcur = 0;
-    {
-        const int it = item_of(w);
-        const Wino9Geo e = wino9_geo(args, it / nnb);
-        wino10_offsets(args, e, lane, q);
-        q.off_u = u_offset((it % nnb) * W10_C);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { wino10_raw_piece(q, bufs, j, 0); wino10_u_piece(q, bufs + 2 * W10_RAWF, j, 0); }
-        wino9_tables(args, e, tid, tables, tables + 256, tables + 512);
-        if (args.pool_y)
-            for (int n = tid; n < g.N; n += 256) {
-                pconst[n] = g.bias ? g.bias[n] : 0.f;
-                pconst[g.N + n] = g.scale ? g.scale[n] : 1.f;
-                pconst[2 * g.N + n] = g.shift ? g.shift[n] : 0.f;
-            }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        lds_barrier();
-    }
-    for (; w < nwork; w += gridDim.x) {
-        const int item = item_of(w);
-        const int blk = item / nnb, nb = item - blk * nnb;
-        const Wino9Geo e = wino9_geo(args, blk);
-        const int n0 = nb * W10_C;
-        int* rowa = tables + tcur * 576;
-        int* rowy = rowa + 256;
-        int* prow = rowy + 256;
-        unsigned lb[4];
-        {
-            const int l = e.l0 + wm * 32 + li;
-            const int trl = l / e.w - e.tr0;
-            const unsigned fix = (unsigned)(trl * 2048 + lh * 256);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) lb[j] = fix + (unsigned)(((l + (j >> 1) * e.w + (j & 1)) & 15) * 16);
-        }
-        floatx16 acc[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-        const int wnext = w + gridDim.x;
-        const bool more = wnext < nwork;
-        const int itn = more ? item_of(wnext) : 0;
-        for (int kc = 0; kc < nkc; ++kc) {
-            const bool last = kc + 1 == nkc;
-            if (last && more) {                      // the prefetch now belongs to the next item
-                wino10_offsets(args, wino9_geo(args, itn / nnb), lane, q);
-                q.off_u = u_offset((itn % nnb) * W10_C);
-            }
-            wino10_chunk<XH>(bufs + cur * W10_RAWF, bufs + 2 * W10_RAWF + cur * W10_UF, bufs + (cur ^ 1) * W10_RAWF,
-                             bufs + 2 * W10_RAWF + (cur ^ 1) * W10_UF, last ? more : true, q, last ? 0 : kc + 1, lb, boff, acc);
-#if defined(WINO_ABL) && (WINO_ABL & 16)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
-            if (last) lds_barrier();
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-            cur ^= 1;
-        }
-        const int pool_n = n0 + li;
-        float pool_bs = 0.f, pool_sc = 1.f, pool_sh = 0.f;
-        if (args.pool_y && pool_n < g.N) { pool_bs = pconst[pool_n]; pool_sc = pconst[g.N + pool_n]; pool_sh = pconst[2 * g.N + pool_n]; }
-        auto before_stores = [&]() {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next item's chunk 0
-            if (more) wino9_tables(args, wino9_geo(args, itn / nnb), tid, tables + (tcur ^ 1) * 576, tables + (tcur ^ 1) * 576 + 256,
-                                   tables + (tcur ^ 1) * 576 + 512);
-        };
-#if defined(WINO_ABL) && (WINO_ABL & 32)
-        { float sink = 0.f;
-#pragma unroll
-          for (int i = 0; i < 8; ++i)
-#pragma unroll
-              for (int r = 0; r < 16; ++r) sink += acc[i][r];
-          if (sink == 123.456f) rowa[0] = 1; }
-        before_stores();
-#else
-        wino_item_tail<XH, decltype(before_stores), 2>(args, acc, bufs + (cur ^ 1) * W10_RAWF, bufs + 2 * W10_RAWF + (cur ^ 1) * W10_UF, rowa, rowy,
-                                                       prow, wave, lane, wm, 0, n0, blk, pool_bs, pool_sc, pool_sh, before_stores);
-#endif
-        lds_barrier();
-        tcur ^= 1;
-    }
-}
-#endif
-
-template <int DIR>
-__global__ __launch_bounds__(256, 2) void wino10_kernel(WinoArgs args) {
-#if __HIP_DEVICE_COMPILE__
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((threadIdx.x >> 7) == 0) wino10_body<0>(args, smem);
-    else wino10_body<1>(args, smem);
-#endif
-}
 
 // ------------------------------------------------------------------------------------------------ wino11_kernel (round 4)
 // The same computation with a wave owning ONE ROW of the 4 x 4 transform (4 positions, 64 accumulator registers): EIGHT waves of
 // 128 registers per workgroup (wave = row * 2 + wm: 32 tiles x 32 channels x 4 positions each), 64 tiles x 32 output channels per
-// item as in wino10_kernel, two workgroups per CU -- FOUR waves per SIMD instead of two.  What that buys on this pipe, where a
+// item, two workgroups per CU -- FOUR waves per SIMD (round 3's wino10_kernel: the same item on four waves of 256 registers).  What that buys on this pipe, where a
 // vector instruction of any wave of a SIMD costs matrix time:
 //   * row r of V = B^T d B needs two pixel rows of the patch (0: rows 0, 2; 1 and 2: rows 1, 2; 3: rows 1, 3) and all four columns:
-//     8 ds_read_b128 and 16 v_pk_add_f32 per 16 MFMAs (wino10_kernel: 12 reads and 40 packed adds per 32, i.e. 20 per 16);
+//     8 ds_read_b128 and 16 v_pk_add_f32 per 16 MFMAs (a wave with two transform columns: 12 reads and 40 packed adds per 32, i.e. 20 per 16);
 //   * four instruction streams per SIMD: an LDS wait, a chunk barrier or an item tail of one wave leaves three others (two of
 //     them of the other workgroup) to feed the matrix pipe;
 //   * the item tail is light: the column combination (M A) is lane-local, the row combination (A^T .) is ONE exchange through LDS
 //     in which wave r receives the register quarter 4 r .. 4 r + 3 of all four rows -- i.e. all four pixels of eight tiles -- so
 //     the fused 2 x 2 pool is lane-local as well and every wave finishes ONE 32 x 32 block (pixel-major row table).
-// Raw pieces, column-blocked tile order and item flow as in wino10_kernel.  The weights come from the SECOND layout asr_winograd_weights
+// Raw pieces and tile order: the section above.  The weights come from the SECOND layout asr_winograd_weights
 // writes ([K / 8][xi 16][N / 32][k-pair pair 2][lane half 2][co 32][2]): a weight piece is 1 KB of contiguous memory and a lane
 // reads the two k-pairs of a position with one conflict-free ds_read_b64 at a 16-bit immediate of ONE base register.
 // The chunk loop is unrolled by two so that both buffer sets are immediate offsets of per-lane base registers (no address
@@ -1038,8 +498,8 @@ __global__ __launch_bounds__(256, 2) void wino10_kernel(WinoArgs args) {
 // instantiated per transform row; set-up, tail and epilogues exist once.
 // The argument block is read through the kernarg segment pointer, re-derived ("laundered") where a phase starts: hipcc otherwise
 // keeps the ~100 argument dwords of the epilogues live in scalar registers across the chunk loop and spills them to vector-register
-// lanes (wino10_kernel: 117 scalar spills, four waterfall loops per chunk around DMA pieces whose offsets ended up in vector
-// registers).  A spill is worse than its instruction here: a scratch reload is a vector-memory load, and the s_waitcnt vmcnt(0) in
+// lanes (round 3's wino10_kernel: 117 scalar spills, four waterfall loops per chunk around DMA pieces whose offsets ended up in
+// vector registers).  A spill is worse than its instruction here: a scratch reload is a vector-memory load, and the s_waitcnt vmcnt(0) in
 // front of its use also waits for every DMA piece and every epilogue store in flight.
 // Which kernel runs is decided by the layer's widths and plane geometry alone -- never by the batch or the CU count -- so an
 // utterance gives the same bits alone and inside a batch (tests/test_fullsize_gpu.py).
@@ -1052,6 +512,7 @@ __device__ long long w11_trace_buf[8 * 8 * 16];           // [item 8][wave 8][st
 #else
 #define W11T(k) do { } while (0)
 #endif
+constexpr int W11_C = 32;                       // output channels per item
 constexpr int W11_SETF = 4224;                  // floats of a raw / weight set: 16 pieces of 256, padded so that four 32 x 33 transpose scratches fit
 constexpr int W11_TABF = 768;                   // ints of a table set: rowa 256 | rowy 256 | prow 256
 constexpr int W11_RAW0 = 2 * W11_TABF * 4;      // byte offsets of the four sets in the dynamic LDS segment
@@ -1082,7 +543,7 @@ struct W11Dma {
 
 // per-lane offsets of the raw pieces this wave issues (piece p = wave + 8 j: row pair p >> 1 of the region, column parity p & 1;
 // lane = [row of the pair][channel quad][position]); positions past the block / plane and rows past the image read zeros
-__device__ __forceinline__ void wino11_offsets(const WinoArgs& args, const Wino9Geo& e, int lane, W11Dma& q) {
+__device__ __forceinline__ void wino11_offsets(const WinoArgs& args, const WinoGeo& e, int lane, W11Dma& q) {
     const TapGemmArgs& g = args.g;
     const int np = e.npieces >> 1;                              // (rows + 1) row pairs x 2 parities
     const int rowbit = lane >> 5, quad = (lane >> 4) & 1;
@@ -1207,7 +668,7 @@ __device__ __forceinline__ void wino11_item_chunks(const char* lds, int lds0, in
 // row tables of one item (threads 0..255: 64 tiles x 4 pixels).  Wave (row r, half wm) finishes tiles wm * 32 + 8 r .. + 7 with
 // all four pixels: its 32 x 32 epilogue block has row p * 8 + t' = pixel p of tile t' (the MFMA register q = 4 p + i holds tile
 // i + 4 lh, the epilogues' register-to-row rule).  prow: rows 0..7 of a wave's block = the pooled pixel of its tiles, else -1.
-__device__ __forceinline__ void wino11_tables(const WinoArgs& args, const Wino9Geo& e, int tid, int* rowa, int* rowy, int* prow) {
+__device__ __forceinline__ void wino11_tables(const WinoArgs& args, const WinoGeo& e, int tid, int* rowa, int* rowy, int* prow) {
     const TapGemmArgs& g = args.g;
     if (tid < 256) {
         const int tl = tid & 63, pl = tid >> 6;
@@ -1445,7 +906,7 @@ __device__ __forceinline__ void wino11_body(float* smem) {
     int tcur = 0, cur = 0;
     unsigned lb[4];
     // per-lane LDS offsets of the patch pixels of a tile block (tile l of the block, its row relative to the region)
-    auto patch_offsets = [&](const Wino9Geo& e) {
+    auto patch_offsets = [&](const WinoGeo& e) {
         const int l = e.l0 + wm * 32 + li;
         const int trl = l / e.w - e.tr0;
         const unsigned fix = (unsigned)(W11_RAW0 + trl * 2048 + lh * 256);
@@ -1455,7 +916,7 @@ __device__ __forceinline__ void wino11_body(float* smem) {
     {
         const WinoArgs& args = wino_args_fresh();
         const TapGemmArgs& g = args.g;
-        const Wino9Geo e = wino9_geo(args, it / nnb);
+        const WinoGeo e = wino_geo(args, it / nnb);
         wino11_offsets(args, e, lane, q);
         patch_offsets(e);
         q.ubytes = (unsigned)(it % nnb) * 1024u;
@@ -1475,8 +936,11 @@ __device__ __forceinline__ void wino11_body(float* smem) {
     for (; it < it_end; ++it) {
         ++titem;
         W11T(0);
+#ifdef W11_TRACE
+        if (blockIdx.x == W11_TRACE_WG && titem >= 0 && titem < 8 && lane == 0) w11_trace_buf[(titem * 8 + wave) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
+#endif
         const int blk = it / nnb, nb = it - blk * nnb;
-        const int n0 = nb * W10_C;
+        const int n0 = nb * W11_C;
         const bool more = it + 1 < it_end;
         const bool newblk = more && nb + 1 == nnb;   // the next item starts a new tile block
         floatx16 acc[4];
@@ -1498,7 +962,7 @@ __device__ __forceinline__ void wino11_body(float* smem) {
         if (more) {
             if (newblk) {
                 const WinoArgs& args = wino_args_fresh();
-                wino11_offsets(args, wino9_geo(args, blk + 1), lane, q);
+                wino11_offsets(args, wino_geo(args, blk + 1), lane, q);
                 q.ubytes = 0;
             } else q.ubytes += 1024u;
 #pragma unroll
@@ -1556,7 +1020,7 @@ __device__ __forceinline__ void wino11_body(float* smem) {
         int* rowy = rowa + 256;
         int* prow = rowy + 256;
         if (newblk) {                                // the next tile block: its patch offsets and (second table set) its row tables
-            const Wino9Geo en = wino9_geo(args, blk + 1);
+            const WinoGeo en = wino_geo(args, blk + 1);
             patch_offsets(en);
             wino11_tables(args, en, tid, tables + (tcur ^ 1) * W11_TABF, tables + (tcur ^ 1) * W11_TABF + 256, tables + (tcur ^ 1) * W11_TABF + 512);
         }
@@ -1684,7 +1148,7 @@ extern "C" int asr_winograd_weights(const float* W, int K, int N, int ldw, int w
     return ASR_OK;
 }
 
-// column blocks of 11..15 tile columns (wino9_kernel, wino10_kernel); 0: no such split
+// column blocks of 11..15 tile columns (wino11_kernel); 0: no such split
 static int wino_column_blocks(int TW, int* tj0, int* cw) {
     for (int nb = asr_cdiv(TW, 15); nb <= 8 && nb * 11 <= TW; ++nb) {
         if (asr_cdiv(TW, nb) > 15) continue;
@@ -1700,23 +1164,33 @@ static int wino_column_blocks(int TW, int* tj0, int* cw) {
     return 0;
 }
 
+// wino11_kernel takes a shape when its tile columns split into column blocks, N is a multiple of 32 and every plane it touches fits
+// its 32-bit addressing: outputs and gate planes go through buffer resources with 24-bit row x 24-bit pitch offsets (< 4 GiB,
+// < 2^24 rows).  A function of the descriptor's widths and geometry only (plus the launch's output pitches).
+static bool wino11_takes(const asr_gemm_desc* d, bool pooled, int gate_mode) {
+    if ((d->N % W11_C) != 0 || d->N > 2048 || wino_column_blocks((d->W + 1) / 2, nullptr, nullptr) == 0) return false;
+    if (pooled && d->N > 640) return false;                                  // the pool's channel constants live in LDS (3 N floats)
+    const long rows = d->M, grows = gate_mode >= 2 ? (long)d->B * (2 * d->H + 1) * (2 * d->W + 1) : rows;
+    const long pitch = d->ldo_a > d->ldo_y ? d->ldo_a : d->ldo_y;
+    if (grows >= (1L << 24) || pitch * 4 >= (1L << 24) || (long)d->N * 4 >= (1L << 24)) return false;
+    if (rows * (pitch > d->N ? pitch : d->N) * 4 >= 0xFFFFFFF0L || grows * d->N * 4 >= 0xFFFFFFF0L) return false;
+    return true;
+}
+
 // An odd plane height is one half-filled last tile row: its second pixel row is the zero border under the image (rows beyond it
 // are sent out of range / never enter a stored pixel) and the row tables carry no entry for it, as for the last column of an
-// odd width.  The input plane is read through 32-bit offsets (buffer-form DMA with num_records 0x7FFFFFF0 in wino9 / wino10 --
-// offsets past it read zeros by design --, 32-bit lane offsets in wino8): planes of 2 GiB or more are refused here and stay
+// odd width.  The input plane is read through 32-bit offsets (buffer-form DMA with num_records 0x7FFFFFF0 in wino11_kernel --
+// offsets past it read zeros by design --, 32-bit lane offsets in wino8_kernel): planes of 2 GiB or more are refused here and stay
 // on the direct kernels (asr_tap_gemm_pw), which address with 64 bits.
 extern "C" int asr_winograd_supported(const asr_gemm_desc* d) {
     if (!(d && d->ntaps == 9 && d->H > 0 && d->W >= 2 && (d->K % WKC) == 0 && (d->lda & 3) == 0 &&
           d->M == d->B * (d->H + 1) * (d->W + 1))) return 0;
     if ((long)d->M * d->lda * 4 >= 0x7FFFFFF0L || (long)16 * d->K * d->N * 4 >= 0x7FFFFFF0L) return 0;
-    if ((d->N % WC) == 0) return 1;
-    // 32-wide channel blocks: wino10_kernel only (column-blocked tile order)
-    return (d->N % W10_C) == 0 && d->N <= 2048 && wino_column_blocks((d->W + 1) / 2, nullptr, nullptr) > 0;
+    if ((d->N % WC) == 0) return 1;                     // wino8_kernel (or wino11_kernel)
+    return wino11_takes(d, false, 3) ? 1 : 0;           // 32-wide channel blocks: wino11_kernel only (any epilogue the ABI can ask for)
 }
 
 struct WinoGate { int mode, H, W; const float* a; float* dz; float* part; int* rows; };
-static int g_wino_gen = 11;          // DEVELOPMENT ONLY (asr_debug_wino_gen): 10 keeps the round-3 kernels for A/B timing in one process
-extern "C" void asr_debug_wino_gen(int gen) { g_wino_gen = gen; }
 
 // Tile-block count of a launch (work items along the pixel axis): B x items per image in the column-blocked order, else
 // ceil(tiles / 64).  A gated launch writes up to 8 partial rows per tile block (asr_tap_gemm_gated_workspace sizes its buffer with it:
@@ -1749,9 +1223,6 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     a.rmin = -(long)a.halo; a.rmax = (long)d->M + a.halo;
     a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->y_unpadded;
     a.nt_store = 1;       // streaming stores: -2..3 % per layer (the planes do not fit L2 anyway)
-#if defined(W11_ABL) && (W11_ABL & 256)
-    a.nt_store = 0;
-#endif
     a.gate_mode = 0; a.gate_H = a.gate_W = 0; a.gate_a = nullptr; a.gate_dz = nullptr; a.gate_part = nullptr; a.gate_rows = nullptr;
     if (gs) { a.gate_mode = gs->mode; a.gate_H = gs->H; a.gate_W = gs->W; a.gate_a = gs->a; a.gate_dz = gs->dz; a.gate_part = gs->part; a.gate_rows = gs->rows; }
     w.Ut = Ut;
@@ -1764,20 +1235,16 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
         int dev = 0; hipDeviceProp_t pr;
         ncu8 = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
     }
-    // Column-blocked tile order when the tile columns split into blocks of 11..15: wino10_kernel (32-wide channel blocks, four waves,
-    // two workgroups per CU) for N % 64 == 32 and for launches of few items per CU -- measured per layer (B = 32): 128 -> 128 / 256
-    // and 32 -> 256 at 200 x 25 (5-10 rounds of 64-channel items) 5-12 % faster than wino9_kernel, 64 -> 128 at 400 x 50 (20 rounds)
-    // equal, 32 -> 64 at 800 x 100 (39 rounds) 2 % slower --; else wino9_kernel (K a multiple of 16, 64-wide channel blocks).
     w.ncb = wino_column_blocks(w.TW, w.cb_tj0, w.cb_w);
     int it = 0;
     for (int c = 0; c < w.ncb; ++c) { w.cb_it0[c] = it; it += asr_cdiv(w.TH * w.cb_w[c], WT); }
     w.cb_it0[w.ncb] = it;
+    hipStream_t st = (hipStream_t)stream;
     // wino11_kernel (eight waves of 128 registers, one transform row per wave, two workgroups per CU) takes every column-blocked shape
-    // with 32-wide channel blocks; the choice depends on widths and plane geometry only.
-    const bool use11 = g_wino_gen >= 11 && w.ncb > 0 && (d->N % W10_C) == 0 && d->N <= 2048 && (!pool_y || d->N <= 640);
-    if (use11) {
+    // with 32-wide channel blocks; the choice depends on widths and plane geometry only, never on the batch or the CU count.
+    if (wino11_takes(d, pool_y != nullptr, a.gate_mode)) {
         const int nblk11 = d->B * w.cb_it0[w.ncb];
-        a.ntm = nblk11; a.ntn = d->N / W10_C;
+        a.ntm = nblk11; a.ntn = d->N / W11_C;
         if (a.gate_rows) *a.gate_rows = nblk11 * 8;
         const long nwork11 = (long)nblk11 * a.ntn;
         const int grid11 = nwork11 > 2L * ncu8 ? 2 * ncu8 : (int)nwork11;     // persistent: two workgroups per CU
@@ -1797,71 +1264,32 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
         static bool attr[10] = {false, false, false, false, false, false, false, false, false, false};
         const int slot = epi ? epi : (d->wmode ? 9 : 0);
         if (!attr[slot]) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr[slot] = true; }
-        hipLaunchKernelGGL(fn, dim3(grid11), dim3(512), lds11, (hipStream_t)stream, w);
+        hipLaunchKernelGGL(fn, dim3(grid11), dim3(512), lds11, st, w);
         ASR_CHECK_LAUNCH("tap_gemm_wino11");
         static const char* const names[10] = {"wino11_kernel<0, 0>", "wino11_kernel<0, 1>", "wino11_kernel<0, 2>", "wino11_kernel<0, 3>", "wino11_kernel<1, 4>",
                                               "wino11_kernel<1, 5>", "wino11_kernel<1, 6>", "wino11_kernel<1, 7>", "wino11_kernel<1, 8>", "wino11_kernel<1, 0>"};
         asr_set_last_kernel(names[slot]);
         return ASR_OK;
     }
-    bool use10 = (d->N % WC) != 0;
-    if (!use10 && w.ncb && d->N <= 2048 && (long)d->B * it * (d->N / WC) <= 12L * ncu8) use10 = true;
-#ifdef WINO_FORCE10
-    if (w.ncb && (d->N % W10_C) == 0) use10 = true;
-#endif
-    if (use10 && !w.ncb) return ASR_ERR_UNSUPPORTED;
-    if (!use10 && !(d->K % 16 == 0 && d->K >= 32 && (!pool_y || d->N <= 2048))) w.ncb = 0;      // wino8_kernel (plain tile order)
-    const int nblk = w.ncb ? d->B * w.cb_it0[w.ncb] : asr_cdiv(w.ntiles, WT);
-    a.ntm = nblk; a.ntn = use10 ? d->N / W10_C : d->N / WC;
+    // wino8_kernel: 64 x 64 items in the plain tile order (planes whose tile columns do not split into column blocks, N % 64 == 0)
+    if ((d->N % WC) != 0) return ASR_ERR_UNSUPPORTED;
+    w.ncb = 0;
+    const int nblk = asr_cdiv(w.ntiles, WT);
+    a.ntm = nblk; a.ntn = d->N / WC;
     if (a.gate_rows) *a.gate_rows = nblk * 4;
     const size_t lds8 = (size_t)(576 + 2 * RAW_F + 2 * U_F) * sizeof(float);
-    const size_t lds9 = lds8 + (576 + (pool_y ? 3 * (size_t)d->N : 0)) * sizeof(float);      // wino9_kernel: two sets of row tables, pool constants
     static_assert(4 * 2048 <= RAW_F && 4 * 2048 <= U_F && 4 * 32 * 33 + 2 * 1024 <= RAW_F && 4 * 32 * 33 + 2 * 1024 <= U_F, "exchange / scratch + pool hand-over must fit in one buffer set");
     const int nwork8 = nblk * a.ntn;
     const int grid8 = nwork8 > ncu8 ? ncu8 : nwork8;        // persistent: one workgroup per CU
-    hipStream_t st8 = (hipStream_t)stream;
-    if (use10) {
-        const size_t lds10 = (size_t)(2 * 576 + 2 * W10_RAWF + 2 * W10_UF + (pool_y ? 3 * d->N : 0)) * sizeof(float);
-        static_assert(2 * 2048 <= W10_RAWF && 2 * 2048 <= W10_UF && 2 * 32 * 33 + 2 * 1024 <= W10_RAWF, "exchange / scratch + pool hand-over must fit in one buffer set");
-        const int grid10 = nwork8 > 2 * ncu8 ? 2 * ncu8 : nwork8;     // persistent: two workgroups per CU
-        auto r0 = wino10_kernel<0>;
-        auto r1 = wino10_kernel<1>;
-        static bool e0 = false, e1 = false;
-        if (d->wmode) {
-            if (!e1) { (void)hipFuncSetAttribute((const void*)r1, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); e1 = true; }
-            hipLaunchKernelGGL(r1, dim3(grid10), dim3(256), lds10, st8, w);
-        } else {
-            if (!e0) { (void)hipFuncSetAttribute((const void*)r0, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); e0 = true; }
-            hipLaunchKernelGGL(r0, dim3(grid10), dim3(256), lds10, st8, w);
-        }
-        ASR_CHECK_LAUNCH("tap_gemm_wino10");
-        if (d->wmode) ASR_NOTE_KERNEL("wino10_kernel<1>"); else ASR_NOTE_KERNEL("wino10_kernel<0>");
-        return ASR_OK;
-    }
-    if (w.ncb) {
-        auto p0 = wino9_kernel<0>;
-        auto p1 = wino9_kernel<1>;
-        static bool c0 = false, c1 = false;
-        if (d->wmode) {
-            if (!c1) { (void)hipFuncSetAttribute((const void*)p1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); c1 = true; }
-            hipLaunchKernelGGL(p1, dim3(grid8), dim3(512), lds9, st8, w);
-        } else {
-            if (!c0) { (void)hipFuncSetAttribute((const void*)p0, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); c0 = true; }
-            hipLaunchKernelGGL(p0, dim3(grid8), dim3(512), lds9, st8, w);
-        }
-        ASR_CHECK_LAUNCH("tap_gemm_wino9");
-        if (d->wmode) ASR_NOTE_KERNEL("wino9_kernel<1>"); else ASR_NOTE_KERNEL("wino9_kernel<0>");
-        return ASR_OK;
-    }
     auto q0 = wino8_kernel<0>;
     auto q1 = wino8_kernel<1>;
     static bool b0 = false, b1 = false;
     if (d->wmode) {
         if (!b1) { (void)hipFuncSetAttribute((const void*)q1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); b1 = true; }
-        hipLaunchKernelGGL(q1, dim3(grid8), dim3(512), lds8, st8, w);
+        hipLaunchKernelGGL(q1, dim3(grid8), dim3(512), lds8, st, w);
     } else {
         if (!b0) { (void)hipFuncSetAttribute((const void*)q0, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8); b0 = true; }
-        hipLaunchKernelGGL(q0, dim3(grid8), dim3(512), lds8, st8, w);
+        hipLaunchKernelGGL(q0, dim3(grid8), dim3(512), lds8, st, w);
     }
     ASR_CHECK_LAUNCH("tap_gemm_wino8");
     if (d->wmode) ASR_NOTE_KERNEL("wino8_kernel<1>"); else ASR_NOTE_KERNEL("wino8_kernel<0>");     // one name per call site

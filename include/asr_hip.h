@@ -443,15 +443,19 @@ int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const float* Warrang
  * The 3x3 convolution of asr_tap_gemm (ntaps 9; forward, or data-gradient view with wmode 1) with 16 instead of 36
  * multiplies per 2x2 output tile, input and output channel -- still fp32, results agree with asr_tap_gemm to rounding
  * (tests/test_wino_gpu.py).  Weights are transformed once per optimiser step:
- *   asr_winograd_weights(W HWIO [3][3][Cin][Cout] with pitch ldw, K, N, ldw, wmode, out [16][K][N])
+ *   asr_winograd_weights(W HWIO [3][3][Cin][Cout] with pitch ldw, K, N, ldw, wmode, out)
  *     wmode 0: K = Cin, N = Cout;  wmode 1: the data-gradient view, K = Cout, N = Cin, taps mirrored (as asr_arrange_weights)
- * asr_winograd_supported(d): ntaps 9, even plane height, K % 8 == 0, and N % 64 == 0 -- or (round 3) N % 32 == 0 on planes whose
+ *     out (asr_winograd_weights_bytes(K, N) bytes, round 4: two layouts side by side): [16][K][N], and 16 K N floats further
+ *     the chunk-major form [K / 8][16][N / 32][2][2][32][2] (written when K % 8 == 0 and N % 32 == 0) whose 1 KB blocks wino11_kernel
+ *     copies into LDS as they lie.
+ * asr_winograd_supported(d): ntaps 9, K % 8 == 0, input plane below 2 GiB, and N % 64 == 0 -- or N % 32 == 0 on planes whose
  *   (W + 1) / 2 tile columns split into blocks of 11..15 (the 25-, 50-, 100-wide planes of the models: yes) -- otherwise use
- *   asr_tap_gemm[_pw].
- * asr_tap_gemm_wino: same contract and epilogue options as asr_tap_gemm_pw.  Three kernels behind it (csrc/wino.hip), chosen from
- * the descriptor: wino10_kernel (64 tiles x 32 channels per item, four waves, two workgroups per CU: N % 64 == 32, and launches
- * of <= 12 items per CU), wino9_kernel (64 x 64, eight waves, every input pixel fetched once: K % 16 == 0), wino8_kernel
- * (64 x 64, plain tile order: every other supported shape).  All three: identical arithmetic per output element. */
+ *   asr_tap_gemm[_pw].  Odd plane heights are supported since round 4 (T_pad 1000: 125 x 25 planes).
+ * asr_tap_gemm_wino: same contract and epilogue options as asr_tap_gemm_pw.  Two kernels behind it (csrc/wino.hip), chosen from
+ * the descriptor's widths and plane geometry alone (never the batch or the device): wino11_kernel (round 4: 64 tiles x 32
+ * channels per item, eight waves of 128 registers -- one transform row each --, two workgroups per CU, the epilogue fixed per
+ * kernel instantiation) for every shape whose tile columns split into column blocks; wino8_kernel (64 x 64 items, plain tile
+ * order) for the rest.  Identical arithmetic per output element up to the order of the inverse transform's additions. */
 size_t asr_winograd_weights_bytes(int K, int N);
 int asr_winograd_weights(const float* W, int K, int N, int ldw, int wmode, float* out, void* stream);
 int asr_winograd_supported(const asr_gemm_desc* d);

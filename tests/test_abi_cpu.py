@@ -95,7 +95,7 @@ def test_size_helpers_and_argument_checks_without_a_gpu():
 
 def test_winograd_predicate_odd_heights_and_the_2_gib_bound():
     """asr_winograd_supported (csrc/wino.hip) is a pure function of the descriptor: odd plane heights are Winograd shapes since
-    round 4 (T_pad 1000 -> 125 x 25 planes), and an input plane of 2 GiB or more is refused -- wino9 / wino10 read it through
+    round 4 (T_pad 1000 -> 125 x 25 planes), and an input plane of 2 GiB or more is refused -- wino11_kernel reads it through
     buffer-form DMA with num_records 0x7FFFFFF0 and 32-bit offsets, where an out-of-range read returns zeros without an error;
     such layers stay on the direct kernels (64-bit addressing).  The 1600 x 200 x 32 plane of the full-size model crosses the
     bound between B = 52 and B = 53."""

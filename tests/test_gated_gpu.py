@@ -66,11 +66,11 @@ def test_gated_data_gradient_equals_gemm_then_prologue(pool, ntaps, acc, B, Hq, 
 
 
 @pytest.mark.parametrize("pool,acc,B,Hq,Wq,N,K", [
-    (0, 0, 2, 20, 50, 64, 128), (2, 1, 2, 10, 25, 64, 64),          # wino9_kernel / wino10_kernel by the item count, 64-wide blocks
-    (2, 0, 2, 20, 50, 32, 64), (1, 1, 3, 10, 25, 32, 64), (0, 0, 1, 40, 25, 96, 32),      # wino10_kernel: N % 64 == 32
+    (0, 0, 2, 20, 50, 64, 128), (2, 1, 2, 10, 25, 64, 64),          # wino11_kernel, N % 64 == 0
+    (2, 0, 2, 20, 50, 32, 64), (1, 1, 3, 10, 25, 32, 64), (0, 0, 1, 40, 25, 96, 32),      # wino11_kernel: N % 64 == 32
     (2, 0, 2, 125, 25, 128, 128), (0, 1, 1, 25, 25, 64, 64), (1, 0, 2, 7, 25, 32, 64)])    # odd heights (round 4)
 def test_gated_winograd_data_gradient_matches_the_direct_one(pool, acc, B, Hq, Wq, N, K):
-    """The same fused prologue behind the Winograd data-gradient kernels (prearranged == 2: wino9_kernel / wino10_kernel) against
+    """The same fused prologue behind the Winograd data-gradient kernels (prearranged == 2: wino11_kernel's gated epilogues) against
     the direct kernel (prearranged == 1): dZ to rounding (the gate decisions -- ReLU sign, max-pool winner -- come from the stored
     activations, not from the gradient, so they are identical), channel sums to 1e-4 of their scale, borders untouched,
     bitwise reproducible."""

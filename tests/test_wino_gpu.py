@@ -25,15 +25,15 @@ def conv_ref(x, w, b=None):
 
 
 @pytest.mark.parametrize("B,H,W,cin,cout", [(2, 6, 5, 8, 64), (3, 4, 2, 16, 64), (2, 8, 12, 24, 128), (1, 16, 25, 32, 64), (5, 10, 7, 8, 192),
-                                            # column-blocked tile order (wino9_kernel: K % 16 == 0, tile columns split into blocks of
+                                            # column-blocked tile order (wino11_kernel: tile columns split into blocks of
                                             # 11..15): two blocks 13 + 12 with partly filled last items, one block of 14 / 15 / 11
                                             # columns at odd and even widths, four blocks, many tile rows per block
                                             (3, 20, 50, 64, 128), (2, 14, 27, 48, 64), (2, 30, 29, 32, 64), (1, 200, 22, 32, 64),
                                             (2, 12, 100, 32, 64), (1, 6, 200, 32, 64),
-                                            # 32-wide channel blocks (wino10_kernel: four waves, two workgroups per CU)
+                                            # channel counts that are odd multiples of 32 (wino11_kernel only)
                                             (2, 20, 50, 64, 32), (1, 16, 25, 32, 32), (3, 14, 27, 24, 96), (2, 200, 22, 8, 32),
                                             # odd plane heights (round 4; T_pad 1000 gives 125 x 25 planes): a half-filled last tile
-                                            # row on every kernel generation -- wino8 (plain order), wino9 / wino10 (column blocks)
+                                            # row on both kernels -- wino8 (plain order), wino11 (column blocks)
                                             (2, 7, 5, 8, 64), (1, 125, 25, 32, 64), (2, 25, 50, 64, 128), (1, 125, 25, 32, 32), (3, 7, 27, 16, 96),
                                             (2, 1, 25, 32, 64), (4, 125, 25, 128, 128)])
 def test_forward_matches_tap_gemm_and_float64(ops, B, H, W, cin, cout):

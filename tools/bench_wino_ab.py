@@ -1,8 +1,8 @@
-"""A/B timing of the Winograd forward / data-gradient launches of the plain DFCNN step (acoustic_model.py, B = 32, T_pad 1600)
+"""Timing of the ten Winograd forward / data-gradient launches of the plain DFCNN step (acoustic_model.py, B = 32, T_pad 1600)
 exactly as the engine issues them -- forward with the fused 2x2 pool where the cell is pooled, data-gradients with the fused
-backward prologue (asr_tap_gemm_gated) where the engine fuses one -- for the kernel generations the development switch
-asr_debug_wino_gen selects (10: wino9 / wino10 of round 3, 11: wino11_kernel), in one process on one box.
-usage: python tools/bench_wino_ab.py [gens ...]     env B, TPAD"""
+backward prologue (asr_tap_gemm_gated) where the engine fuses one.  (Round 4 used it with a development switch to time
+wino11_kernel against round 3's wino9 / wino10 in one process: 4575 -> 3778 us for the ten launches, profiles/r04_wino11_ab.txt.)
+usage: python tools/bench_wino_ab.py     env B, TPAD"""
 import ctypes as C
 import os
 import sys
@@ -14,10 +14,8 @@ from asr_dfcnn_transformer_amd.ops import Plane
 B = int(os.environ.get('B', 32))
 TP = int(os.environ.get('TPAD', 1600))
 lib = _lib.load()
-setgen = lib.asr_debug_wino_gen
-setgen.argtypes = [C.c_int]
-setgen.restype = None
-gens = [int(a) for a in sys.argv[1:]] or [10, 11]
+setgen = lambda gen: None
+gens = [11]
 
 
 def timeit(fn, iters=20):

@@ -25,6 +25,9 @@ def dump(title):
     assert lib.asr_w11_trace_dump(buf.ctypes.data_as(C.c_void_p)) == 0
     t = buf.reshape(8, 8, 16)
     print(title + ': cycles (shader clock) since the item start; stamps ' + ' '.join('%5d' % k for k in ORDER[1:]))
+    r0, r1 = t[1, 0], t[6, 0]
+    if r1[12] > r0[12]:
+        print('  in-kernel clock (items 1..6, wave 0): %.0f MHz' % ((r1[0] - r0[0]) / (r1[12] - r0[12]) * 100.0))
     for item in (2, 3, 4):
         for wave in (0, 3, 7):
             r = t[item, wave]
