@@ -44,6 +44,8 @@ struct WinoArgs {
     int cb_tj0[8];          // first tile column of the block
     int cb_w[8];            // tile columns of the block
     int cb_it0[9];          // first item of the block within an image; cb_it0[ncb] = items per image
+    float inv_ipi;          // 1 / items per image and 1 / cb_w: the kernel's index divisions are a convert, a multiply-add and a convert
+    float cb_invw[8];       // (exact for the index ranges here: floor((x + 0.5) / d) = floor(x / d), x < 2^22)
 };
 
 constexpr int WT = 64;                      // tiles per workgroup
@@ -460,19 +462,22 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
 //   * columns past the plane's width and rows past the image are sent out of the buffer's range and read zeros.
 // Items do not span column blocks or images: the last item of a block may be partly empty (1-3 % of the tiles).
 #if __HIP_DEVICE_COMPILE__
-struct WinoGeo { int b, tj0, w, l0, tr0, npieces; };
+struct WinoGeo { int b, tj0, w, l0, tr0, npieces; float invw; };
+
+__device__ __forceinline__ int wino_fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }      // floor(x / d) for 0 <= x < 2^22
 
 __device__ __forceinline__ WinoGeo wino_geo(const WinoArgs& args, int blk) {
     WinoGeo e;
     const int ipi = args.cb_it0[args.ncb];
-    e.b = blk / ipi;
+    e.b = wino_fdiv(blk, args.inv_ipi);
     const int rem = blk - e.b * ipi;
     int cb = 0;
-    while (cb + 1 < args.ncb && rem >= args.cb_it0[cb + 1]) ++cb;
-    e.tj0 = args.cb_tj0[cb]; e.w = args.cb_w[cb];
+#pragma unroll
+    for (int c = 1; c < 8; ++c) cb += (c < args.ncb && rem >= args.cb_it0[c]) ? 1 : 0;      // blocks are in ascending item order
+    e.tj0 = args.cb_tj0[cb]; e.w = args.cb_w[cb]; e.invw = args.cb_invw[cb];
     e.l0 = (rem - args.cb_it0[cb]) * WT;
-    e.tr0 = e.l0 / e.w;
-    const int rows = (e.l0 + WT - 1) / e.w - e.tr0 + 1;       // tile rows the item touches (<= 7)
+    e.tr0 = wino_fdiv(e.l0, e.invw);
+    const int rows = wino_fdiv(e.l0 + WT - 1, e.invw) - e.tr0 + 1;       // tile rows the item touches (<= 7)
     e.npieces = 2 * (2 * rows + 2);                           // pixel rows x column parities
     return e;
 }
@@ -673,7 +678,7 @@ __device__ __forceinline__ void wino11_tables(const WinoArgs& args, const WinoGe
     if (tid < 256) {
         const int tl = tid & 63, pl = tid >> 6;
         const int l = e.l0 + tl;
-        const int ti = l / e.w, tj = e.tj0 + l - ti * e.w;
+        const int ti = wino_fdiv(l, e.invw), tj = e.tj0 + l - ti * e.w;
         int ra_ = -1, ry = -1;
         if (ti < args.TH) {
             const int hh = 2 * ti + 1 + (pl >> 1), ww = 2 * tj + 1 + (pl & 1);
@@ -908,7 +913,7 @@ __device__ __forceinline__ void wino11_body(float* smem) {
     // per-lane LDS offsets of the patch pixels of a tile block (tile l of the block, its row relative to the region)
     auto patch_offsets = [&](const WinoGeo& e) {
         const int l = e.l0 + wm * 32 + li;
-        const int trl = l / e.w - e.tr0;
+        const int trl = wino_fdiv(l, e.invw) - e.tr0;
         const unsigned fix = (unsigned)(W11_RAW0 + trl * 2048 + lh * 256);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { lb[j] = fix + (unsigned)(((l + (j >> 1) * e.w + (j & 1)) & 15) * 16); asm volatile("" : "+v"(lb[j])); }
@@ -959,10 +964,12 @@ __device__ __forceinline__ void wino11_body(float* smem) {
         int lane_t = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         asm volatile("" : "+v"(lane_t));
         const int lane = lane_t, li = lane & 31, lh = lane >> 5;
+        WinoGeo en;                                  // the next tile block (where the next item starts one)
         if (more) {
             if (newblk) {
                 const WinoArgs& args = wino_args_fresh();
-                wino11_offsets(args, wino_geo(args, blk + 1), lane, q);
+                en = wino_geo(args, blk + 1);
+                wino11_offsets(args, en, lane, q);
                 q.ubytes = 0;
             } else q.ubytes += 1024u;
 #pragma unroll
@@ -1020,7 +1027,6 @@ __device__ __forceinline__ void wino11_body(float* smem) {
         int* rowy = rowa + 256;
         int* prow = rowy + 256;
         if (newblk) {                                // the next tile block: its patch offsets and (second table set) its row tables
-            const WinoGeo en = wino_geo(args, blk + 1);
             patch_offsets(en);
             wino11_tables(args, en, tid, tables + (tcur ^ 1) * W11_TABF, tables + (tcur ^ 1) * W11_TABF + 256, tables + (tcur ^ 1) * W11_TABF + 512);
         }
@@ -1239,6 +1245,8 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     int it = 0;
     for (int c = 0; c < w.ncb; ++c) { w.cb_it0[c] = it; it += asr_cdiv(w.TH * w.cb_w[c], WT); }
     w.cb_it0[w.ncb] = it;
+    w.inv_ipi = it > 0 ? 1.0f / (float)it : 0.f;
+    for (int c = 0; c < 8; ++c) w.cb_invw[c] = c < w.ncb ? 1.0f / (float)w.cb_w[c] : 0.f;
     hipStream_t st = (hipStream_t)stream;
     // wino11_kernel (eight waves of 128 registers, one transform row per wave, two workgroups per CU) takes every column-blocked shape
     // with 32-wide channel blocks; the choice depends on widths and plane geometry only, never on the batch or the CU count.
