@@ -12,16 +12,17 @@
 // l % 32 and the B value of output channel l % 32 for tile l / 32 of the pair -- so BOTH transforms are lane-local with the
 // channel on the lane and the pixels in registers, and the planes' own [pixel][channel] layout is what LDS holds (rows of
 // 128 / 256 contiguous bytes per pixel: every DMA piece is whole lines, every ds_read_b32 of a half-wave 128 contiguous bytes).
-// There is no per-item tail: a workgroup owns a 64 (or 32) x 64 block of (ci, co) pairs for all sixteen positions -- the whole
-// register file of the CU as in the forward kernel -- walks its share of the tiles and writes its accumulators ONCE, as a partial
+// There is no per-item tail: a workgroup owns a 64 (or 32) x 64 block of (ci, co) pairs for all sixteen positions -- half the
+// register file of the CU -- walks its share of the tiles and writes its accumulators ONCE, as a partial
 // [16][ci][co]; wino_wgrad_reduce_kernel adds the partials in a fixed order (deterministic) and applies A'^T . A'.
 //
-// Work: the tile columns of an image are cut into blocks of <= 13 columns (as in wino9_kernel); a STAGE is two tile rows of one
-// block = 2 w tiles = w tile pairs.  Its input region (6 pixel rows x (2 w + 2) pixels) and gradient region (4 x 2 w pixels) arrive
-// by buffer-form LDS-DMA in two buffer sets, one barrier per stage; pixels outside the plane are sent out of the buffer's range and
-// read zeros.  Eight waves: wave = xh * 4 + a * 2 + wn; xh owns transform columns 2 xh, 2 xh + 1 (8 accumulators), wn the 32-wide
-// half of the 64 output channels, a the 32-wide half of 64 input channels (CINB = 64) or, for 32 input channels (CINB = 32), every
-// other tile pair (two partials per workgroup).  Two tile pairs are transformed together with packed adds.
+// Work: the tile columns of an image are cut into blocks of <= 13 columns; a STAGE is two tile rows of one block = 2 w tiles = w
+// tile pairs.  Its input region (6 pixel rows x (2 w + 2) pixels) and gradient region (4 x 2 w pixels) arrive by buffer-form LDS-DMA
+// in two buffer sets, one barrier per stage; pixels outside the plane are sent out of the buffer's range and read zeros.  Sixteen
+// waves (round 4; round 3: eight, two transform columns each): wave = row * 4 + a * 2 + wn; `row` the transform row it owns (4
+// accumulators), wn the 32-wide half of the 64 output channels, a the 32-wide half of 64 input channels (CINB = 64) or, for 32
+// input channels (CINB = 32), every other tile row (two partials per workgroup).  Two tile pairs are transformed together with
+// packed adds.
 #include "asr_common.h"
 #include <stdint.h>
 
@@ -107,120 +108,87 @@ __device__ __forceinline__ void ww_piece(const WwArgs& a, const WwStage& s, R rx
     }
 }
 
-// input transform of two tile pairs at once: d[r * 3 + c] = patch pixel (r, XH + c), .x / .y the two pairs
-template <int XH>
-__device__ __forceinline__ void ww_transform_x(const ww_f2 (&d)[12], ww_f2 (&v)[8]) {
-    ww_f2 t[4][3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const ww_f2 d0 = d[0 + c], d1 = d[3 + c], d2 = d[6 + c], d3 = d[9 + c];
-        t[0][c] = d0 - d2; t[1][c] = d1 + d2; t[2][c] = d2 - d1; t[3][c] = d1 - d3;
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (XH == 0) { v[r * 2 + 0] = t[r][0] - t[r][2]; v[r * 2 + 1] = t[r][1] + t[r][2]; }
-        else         { v[r * 2 + 0] = t[r][1] - t[r][0]; v[r * 2 + 1] = t[r][0] - t[r][2]; }
-    }
-}
-// gradient transform G' y G'^T, transform columns 2 XH and 2 XH + 1: y[a * 2 + b] = pixel (a, b)
-template <int XH>
-__device__ __forceinline__ void ww_transform_z(const ww_f2 (&y)[4], ww_f2 (&z)[8]) {
-    ww_f2 yr[4][2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) { yr[0][b] = y[b]; yr[1][b] = y[b] + y[2 + b]; yr[2][b] = y[b] - y[2 + b]; yr[3][b] = y[2 + b]; }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        if (XH == 0) { z[r * 2 + 0] = yr[r][0]; z[r * 2 + 1] = yr[r][0] + yr[r][1]; }
-        else         { z[r * 2 + 0] = yr[r][0] - yr[r][1]; z[r * 2 + 1] = yr[r][1]; }
-    }
-}
+#endif
 
-// One stage out of (xs, zs); the pieces of the next stage go into `nxt` between the MFMAs.  __restrict__ parameters of an inlined
-// function on purpose: without the alias scopes hipcc orders every LDS read behind the DMA in flight (s_waitcnt vmcnt(0)).
-// Tile pairs: the tiles (2 q, 2 q + 1) of ONE tile row (lane half = tile of the pair), q = 0 .. w / 2 - 1, for both rows; for an odd
-// w the last tiles of the two rows make one more pair (lane half = row).  A step handles the pairs q and q + kstep of a row: the
-// second pair's pixels are a CONSTANT 4 kstep pixels further, so both values of a packed register come from one base address
-// (ds_read2st64_b32 loads them as the register pair the packed add wants -- pairing tiles of different rows cost 35 v_mov per
-// step) and the address of a step is one vector add.
-template <int XH, int CINB, class R>
-__device__ __forceinline__ void ww_compute(const WwArgs& a, const char* __restrict__ xs, const char* __restrict__ zs, float* __restrict__ nxt,
-                                           const WwStage& sn, bool more, R rx, R rz, int w, int parity, int wave, int wa, int lh, int xch, int zch,
-                                           int cin0, int co0, unsigned vox, unsigned voz, int pxx, int pxz, floatx16 (&acc)[8]) {
+// ------------------------------------------------------------------------------------------------ sixteen-wave form (round 4)
+// The same work with a wave owning ONE ROW of the 4 x 4 transform (4 accumulators = 64 registers): sixteen waves of 128 registers,
+// wave = row * 4 + a * 2 + wn -- FOUR waves per SIMD instead of two, as in wino11_kernel (wino.hip) and for the same reasons: row r
+// of V = B^T d B needs two pixel rows of the patch (0: rows 0, 2; 1, 2: rows 1, 2; 3: rows 1, 3) and all four columns -- 8 packed
+// adds per tile-pair pair instead of 20 for a column pair --, row r of Z = G' y G'^T needs one or both gradient rows (2-4 packed
+// adds instead of 8), and four instruction streams per SIMD cover each other's LDS round trips and the stage barrier.
+#if __HIP_DEVICE_COMPILE__
+template <int RR, int CINB, class R>
+__device__ __forceinline__ void ww4_compute(const WwArgs& a, const char* __restrict__ xs, const char* __restrict__ zs, float* __restrict__ nxt,
+                                            const WwStage& sn, bool more, R rx, R rz, int w, int parity, int wave, int wa, int lh, int xch, int zch,
+                                            int cin0, int co0, unsigned vox, unsigned voz, int pxx, int pxz, floatx16 (&acc)[4]) {
     typedef WwCfg<CINB> C;
-    constexpr int NJ = (C::NXP + C::NZP + 7) / 8;     // piece rounds per stage
+    constexpr int NJ = (C::NXP + C::NZP + 15) / 16;    // piece rounds per stage (pieces wave + 16 j)
     constexpr int PXB = CINB * 4;                      // bytes of an input pixel
-    constexpr int KSTEP = 1;
+    constexpr int RA = RR == 0 ? 0 : 1, RB = RR == 3 ? 3 : 2;           // the two patch rows this transform row combines
     int jn = 0;
+    auto piece = [&]() {
+        if (more && jn < NJ) {
+            const int p = wave + 16 * jn;
+            // (ww_piece numbers pieces wave + 8 j: hand it the equivalent (wave', j') of piece p)
+            ww_piece<CINB>(a, sn, rx, rz, nxt, p & 7, p >> 3, cin0, co0, vox, voz, pxx, pxz);
+        }
+        ++jn;
+    };
     auto step = [&](int xa, int za, bool two) {
-        // The two values of a packed register are the same pixel of the two pairs: two ds_read_b32 from ONE address register with
-        // immediate offsets, written as instructions -- left to itself hipcc merges neighbouring offsets into ds_read2st64_b32, whose
-        // register pairs are then (pixel c, pixel c + 1) of one pair, and moves 32 registers per step to re-pair them.
-        ww_f2 d[12], y[4];
-#if defined(WW_ABL) && (WW_ABL & 2)
-#pragma unroll
-        for (int i = 0; i < 12; ++i) d[i] = ww_f2{__int_as_float(xa + i), __int_as_float(xa + i + 1)};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = ww_f2{__int_as_float(za + i), __int_as_float(za + i + 1)};
-#else
+        // the two values of a packed register are the same pixel of the two tile pairs (one address register, two immediates)
+        ww_f2 da[4], db[4], y0[2], y1[2];
         const unsigned xad = (unsigned)(uintptr_t)(const ww_lds_c*)(xs + xa), zad = (unsigned)(uintptr_t)(const ww_lds_c*)(zs + za);
 #define WW_LD2(dst, ad, off0, off1) { float lo_, hi_;                                                                   \
         asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4" : "=&v"(lo_), "=&v"(hi_) : "v"(ad), "i"(off0), "i"(off1)); \
         dst = ww_f2{lo_, hi_}; }
-#define WW_LDX(r, c) WW_LD2(d[(r) * 3 + (c)], xad, ((r) * C::XP + XH + (c)) * PXB, ((r) * C::XP + XH + (c) + 4 * KSTEP) * PXB)
-#define WW_LDZ(p) WW_LD2(y[p], zad, (((p) >> 1) * WW_ZP + ((p) & 1)) * 256, (((p) >> 1) * WW_ZP + ((p) & 1) + 4 * KSTEP) * 256)
-        WW_LDX(0, 0) WW_LDX(0, 1) WW_LDX(0, 2) WW_LDX(1, 0) WW_LDX(1, 1) WW_LDX(1, 2)
-        WW_LDX(2, 0) WW_LDX(2, 1) WW_LDX(2, 2) WW_LDX(3, 0) WW_LDX(3, 1) WW_LDX(3, 2)
-        WW_LDZ(0) WW_LDZ(1) WW_LDZ(2) WW_LDZ(3)
+#define WW_LDX(dst, r, c) WW_LD2(dst, xad, ((r) * C::XP + (c)) * PXB, ((r) * C::XP + (c) + 4) * PXB)
+#define WW_LDZ(dst, p) WW_LD2(dst, zad, (((p) >> 1) * WW_ZP + ((p) & 1)) * 256, (((p) >> 1) * WW_ZP + ((p) & 1) + 4) * 256)
+        WW_LDX(da[0], RA, 0) WW_LDX(da[1], RA, 1) WW_LDX(da[2], RA, 2) WW_LDX(da[3], RA, 3)
+        WW_LDX(db[0], RB, 0) WW_LDX(db[1], RB, 1) WW_LDX(db[2], RB, 2) WW_LDX(db[3], RB, 3)
+        if (RR != 3) { WW_LDZ(y0[0], 0) WW_LDZ(y0[1], 1) }
+        if (RR != 0) { WW_LDZ(y1[0], 2) WW_LDZ(y1[1], 3) }
 #undef WW_LDX
 #undef WW_LDZ
 #undef WW_LD2
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
         __builtin_amdgcn_sched_barrier(0);
-        ww_f2 v[8], z[8];
-        ww_transform_x<XH>(d, v);
-        ww_transform_z<XH>(y, z);
+        ww_f2 t[4], v[4], yr[2], z[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[c] = RR == 1 ? da[c] + db[c] : RR == 2 ? db[c] - da[c] : da[c] - db[c];
+        v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) yr[b] = RR == 0 ? y0[b] : RR == 1 ? y0[b] + y1[b] : RR == 2 ? y0[b] - y1[b] : y1[b];
+        z[0] = yr[0]; z[1] = yr[0] + yr[1]; z[2] = yr[0] - yr[1]; z[3] = yr[1];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i].x, z[i].x, acc[i], 0, 0, 0);
-            if (WW_SLOT(i)) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (more && jn < NJ) ww_piece<CINB>(a, sn, rx, rz, nxt, wave, jn, cin0, co0, vox, voz, pxx, pxz);
-                ++jn;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
+        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i].x, z[i].x, acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        piece();
+        __builtin_amdgcn_sched_barrier(0);
         if (two) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i].y, z[i].y, acc[i], 0, 0, 0);
-                if (WW_SLOT(i)) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (more && jn < NJ) ww_piece<CINB>(a, sn, rx, rz, nxt, wave, jn, cin0, co0, vox, voz, pxx, pxz);
-                    ++jn;
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[i].y, z[i].y, acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            piece();
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
     const int np = w >> 1;                             // whole pairs per tile row
     const int xl = xch + lh * 2 * PXB, zl = zch + lh * 2 * 256;       // this lane's tile of a pair: two pixels further for the upper half
-    // CINB 32: the two wave groups take one tile row each (and the odd pair alternates with the stage parity: sn.row0 / 4)
     for (int row = (CINB == 64 ? 0 : wa); row < (CINB == 64 ? 2 : wa + 1); ++row)
-        for (int q = 0; q < np; q += 2 * KSTEP)
-            step(xl + row * (2 * C::XP * PXB) + q * (4 * PXB), zl + row * (2 * WW_ZP * 256) + q * (4 * 256), q + KSTEP < np);
+        for (int q = 0; q < np; q += 2)
+            step(xl + row * (2 * C::XP * PXB) + q * (4 * PXB), zl + row * (2 * WW_ZP * 256) + q * (4 * 256), q + 1 < np);
     if ((w & 1) && (CINB == 64 || wa == (parity & 1)))
         step(xch + lh * (2 * C::XP * PXB) + (w - 1) * 2 * PXB, zch + lh * (2 * WW_ZP * 256) + (w - 1) * 2 * 256, false);
     // pieces the loop had no slot for (narrow blocks)
-    if (more) for (; jn < NJ; ++jn) ww_piece<CINB>(a, sn, rx, rz, nxt, wave, jn, cin0, co0, vox, voz, pxx, pxz);
+    while (more && jn < NJ) piece();
 }
 
-template <int XH, int CINB>
-__device__ __forceinline__ void ww_body(const WwArgs& a, float* smem) {
+template <int RR, int CINB>
+__device__ __forceinline__ void ww4_body(const WwArgs& a, float* smem) {
     typedef WwCfg<CINB> C;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // = RR * 4 + a * 2 + wn
     const int wa = (wave >> 1) & 1, wn = wave & 1;
     // workgroup -> (block pair, slice): workgroups of one slice differ by multiples of 8 (the same XCD: they read the same pixels)
     const int wg = blockIdx.x;
@@ -232,16 +200,15 @@ __device__ __forceinline__ void ww_body(const WwArgs& a, float* smem) {
 
     auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, 0x7FFFFFF0, 0x00020000);
     auto rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.Z, 0, 0x7FFFFFF0, 0x00020000);
-    // per-lane part of a piece's offsets: pixel of the piece, 16-byte chunk of the channel block
     constexpr int LPPX = CINB / 4;
     const int pxx = lane / LPPX, pxz = lane >> 4;
     const unsigned vox = (unsigned)((pxx * a.lda + (lane % LPPX) * 4) * 4);
     const unsigned voz = (unsigned)((pxz * a.ldz + (lane & 15) * 4) * 4);
-    constexpr int NJ = (C::NXP + C::NZP + 7) / 8;
+    constexpr int NJ = (C::NXP + C::NZP + 15) / 16;
 
-    floatx16 acc[8];
+    floatx16 acc[4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
@@ -249,7 +216,7 @@ __device__ __forceinline__ void ww_body(const WwArgs& a, float* smem) {
     {
         const WwStage s = ww_stage(a, g);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) ww_piece<CINB>(a, s, rx, rz, smem, wave, j, cin0, co0, vox, voz, pxx, pxz);
+        for (int j = 0; j < NJ; ++j) { const int p = wave + 16 * j; ww_piece<CINB>(a, s, rx, rz, smem, p & 7, p >> 3, cin0, co0, vox, voz, pxx, pxz); }
     }
     int cur = 0;
     const int xch = ((CINB == 64 ? wa * 32 : 0) + li) * 4;      // byte offset of this lane's input channel inside a pixel
@@ -260,24 +227,20 @@ __device__ __forceinline__ void ww_body(const WwArgs& a, float* smem) {
         const bool more = gn < a.nstages;
         WwStage sn = s;
         if (more) sn = ww_stage(a, gn);
-#if defined(WW_ABL) && (WW_ABL & 4)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#else
         ww_barrier_dma();                            // this stage has landed; nobody reads the other set any more
-#endif
         const char* xs = (const char*)(smem + cur * C::SETF);
-        ww_compute<XH, CINB>(a, xs, xs + C::XF * 4, smem + (cur ^ 1) * C::SETF, sn, more, rx, rz, s.w, s.row0 >> 2, wave, wa, lh, xch, zch, cin0, co0,
-                             vox, voz, pxx, pxz, acc);
+        ww4_compute<RR, CINB>(a, xs, xs + C::XF * 4, smem + (cur ^ 1) * C::SETF, sn, more, rx, rz, s.w, s.row0 >> 2, wave, wa, lh, xch, zch, cin0, co0,
+                              vox, voz, pxx, pxz, acc);
         cur ^= 1;
     }
-    // partial of this workgroup (CINB 32: one per tile row of the stages): [16][CINB][64]; acc[r * 2 + j] = position r * 4 + 2 XH + j,
+    // partial of this workgroup (CINB 32: one per tile row of the stages): [16][CINB][64]; acc[c] = position RR * 4 + c,
     // register = input channel, lane = output channel
     const int nth = CINB == 64 ? 1 : 2;
     float* P = a.part + ((long)(sl * a.nbp + bp) * nth + (CINB == 64 ? 0 : wa)) * 16 * CINB * 64;
     const int ci0 = CINB == 64 ? wa * 32 : 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int xi = (i >> 1) * 4 + 2 * XH + (i & 1);
+    for (int i = 0; i < 4; ++i) {
+        const int xi = RR * 4 + i;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -288,11 +251,15 @@ __device__ __forceinline__ void ww_body(const WwArgs& a, float* smem) {
 #endif
 
 template <int CINB>
-__global__ __launch_bounds__(512) void wino_wgrad_kernel(WwArgs a) {
+__global__ __launch_bounds__(1024, 4) void wino_wgrad4_kernel(WwArgs a) {
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    if ((threadIdx.x >> 8) == 0) ww_body<0, CINB>(a, smem);
-    else ww_body<1, CINB>(a, smem);
+    switch (threadIdx.x >> 8) {
+        case 0: ww4_body<0, CINB>(a, smem); break;
+        case 1: ww4_body<1, CINB>(a, smem); break;
+        case 2: ww4_body<2, CINB>(a, smem); break;
+        default: ww4_body<3, CINB>(a, smem); break;
+    }
 #endif
 }
 
@@ -416,18 +383,18 @@ int asr_wino_wgrad_launch(const asr_gemm_desc* d, const float* A, const float* d
     hipStream_t st = (hipStream_t)stream;
     if (p.cinb == 64) {
         const size_t lds = (size_t)2 * WwCfg<64>::SETF * sizeof(float);
-        static bool s64 = false;
-        auto k = wino_wgrad_kernel<64>;
-        if (!s64) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); s64 = true; }
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
-        ASR_NOTE_KERNEL("wino_wgrad_kernel<64>");
+        static bool t64 = false;
+        auto k = wino_wgrad4_kernel<64>;
+        if (!t64) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); t64 = true; }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(1024), lds, st, a);
+        ASR_NOTE_KERNEL("wino_wgrad4_kernel<64>");
     } else {
         const size_t lds = (size_t)2 * WwCfg<32>::SETF * sizeof(float);
-        static bool s32 = false;
-        auto k = wino_wgrad_kernel<32>;
-        if (!s32) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); s32 = true; }
-        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, st, a);
-        ASR_NOTE_KERNEL("wino_wgrad_kernel<32>");
+        static bool t32 = false;
+        auto k = wino_wgrad4_kernel<32>;
+        if (!t32) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); t32 = true; }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(1024), lds, st, a);
+        ASR_NOTE_KERNEL("wino_wgrad4_kernel<32>");
     }
     ASR_CHECK_LAUNCH("wino_wgrad");
     hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(d->K * p.ncob), dim3(64, WW_RG), 0, st, partials, dW, d->K, d->N, p.cinb, p.nparts,
