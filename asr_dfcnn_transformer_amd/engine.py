@@ -355,7 +355,7 @@ class DFCNNEngine:
         # overlapped kernels then overlap in any profile.  Results are bitwise the same as with one stream.
         # (The data-gradient is enqueued before the weight gradient -- it is on the critical path; starting the weight gradient
         # first or only after the data-gradient has finished were measured in round 2 and lose on both graphs.)
-        self.side = torch.cuda.Stream(device=dev) if self.opt_dual else None
+        self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get('ASR_SIDE_PRIORITY', '0'))) if self.opt_dual else None
         self.ws_side = torch.zeros_like(self.ws) if self.side is not None else None
         # with the side stream every geometry gets a second dZ plane, used alternately, so the next cell's (HBM-bound)
         # backward prologue can run while the previous weight-gradient (MFMA-bound) still reads the other one
