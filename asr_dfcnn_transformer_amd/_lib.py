@@ -85,6 +85,7 @@ SIGNATURES = {
     'asr_layernorm_bwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P]),
     'asr_embed_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P]),
     'asr_embed_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P]),
+    'asr_embed_bwd_ids': (_I, [_P, _P, _I, _I, _I, _I, _F, _P, _P]),
     'asr_smoothed_ce': (_I, [_P, _I, _P, _I, _I, _F, _I, _F, _P, _P, _P, _P, _P]),
     'asr_prenet_conv1_fwd': (_I, [_P, _P, _P, _I, _I, _I, _P, _P]),
     'asr_prenet_conv1_bwd_workspace': (_Z, [_I, _I, _I]),

@@ -208,11 +208,10 @@ __device__ __forceinline__ void attn_fwd_tile(const float* __restrict__ Kc, cons
         for (int r = 0; r < 16; ++r) {
             float v = s[r];
             if (CAUSAL) v = (k0 + sub * 32 + rowidx(r, lh) <= q) ? v : FILL2;
-            v = fminf(v, kbv[r]);                        // +inf: a real key; the fill value: key-masked; -inf: past the end
-            s[r] = v;
-            mt = fmaxf(mt, v);
+            s[r] = vmin(v, kbv[r]);                      // +inf: a real key; the fill value: key-masked; -inf: past the end
+            if (r & 1) mt = vmax3(mt, s[r - 1], s[r]);
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        mt = vmax(mt, __shfl_xor(mt, 32, 64));
         // Online softmax with a LAZY reference: the running reference m_run only moves when a score exceeds it by more than 2^8
         // (probabilities then stay <= 256: exact in fp32 range), so the rescaling of the 32 output accumulators -- vector
         // instructions that add to the MFMA time on this pipe -- runs for a few tiles per row instead of for every tile.  Any
@@ -573,7 +572,7 @@ __device__ __forceinline__ void attn_bwd_q_tile(const float* __restrict__ Kc, co
             const bool keep = (kbv[r] > 1.0e38f) && (!CAUSAL || k0 + kl <= q);       // +inf: a real key
             float sv = s[r];
             if (CAUSAL) sv = (k0 + kl <= q) ? sv : FILL2;
-            sv = fminf(sv, kbv[r]);
+            sv = vmin(sv, kbv[r]);
             const float p = ex2((sv - my_lse) - my_lsl);
             float dpe = dp[r];
             if (DROP) dpe = drop_keep(drop_base + (uint32_t)(k0 + kl), drop_seed, drop_thr) ? dpe * drop_scale : 0.f;

@@ -17,6 +17,12 @@ constexpr float LOG2E = 1.44269504088896340736f;
 constexpr float QSCALE2 = 0.125f * LOG2E;        // 1 / sqrt(64), in base-2 units
 constexpr float FILL2 = MASK_FILL * LOG2E;       // the fill value in the same units
 __device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+// min / max as the bare instructions: fminf / fmaxf on an MFMA result come with a canonicalising v_max_f32 x, x each (IEEE mode),
+// one more vector instruction per score in kernels where every vector instruction adds to the MFMA time.  No operand is a NaN
+// here (scores are finite, the key bias is +-inf or the fill value).
+__device__ __forceinline__ float vmin(float a, float b) { float d; asm("v_min_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float vmax(float a, float b) { float d; asm("v_max_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
 
 __device__ __forceinline__ int rowidx(int r, int lh) { return (r & 3) + 8 * (r >> 2) + 4 * lh; }
 

@@ -85,17 +85,19 @@ __device__ __forceinline__ void g1_piece(R ra, R rb, const G1Dma& q, int kc, int
 // one) -- only the last three chunks of a tile run this form; the steady-state loop body has no branch.  `set` / `nset` are
 // __restrict__ parameters of an inlined function on purpose: without the alias scopes hipcc orders every LDS read behind the
 // DMA in flight (s_waitcnt vmcnt(0) in front of each k-group) and nothing overlaps.
-template <int MODE, class R>
+// NB = 32-column blocks per wave: 2 (128 x 128 tile) or 1 (128 x 64 tile, whose B tile is 8 pieces: slots 6 and 7 of a chunk's
+// eight DMA slots stay empty).
+template <int MODE, int NB, class R>
 __device__ __forceinline__ void g1_chunk(const float* __restrict__ set, float* __restrict__ nset, R ra, R rb, const G1Dma& q, int kc, int nkc,
-                                         bool ktail, int arow, int brow, const int (&xo)[4], floatx16 (&acc)[2][2]) {
+                                         bool ktail, int arow, int brow, const int (&xo)[4], floatx16 (&acc)[2][NB]) {
     const bool more = MODE == 1 || kc + 1 < nkc;
     const bool tail = MODE == 2 && ktail && kc + 2 == nkc;
-    float4 av[2][2], bv[2][2];
+    float4 av[2][2], bv[2][NB];
     auto load_frag = [&](int slot, int gk) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) av[slot][a] = *(const float4*)(set + arow + a * 32 * G1_KC + xo[gk]);
 #pragma unroll
-        for (int b = 0; b < 2; ++b) bv[slot][b] = *(const float4*)(set + brow + b * 32 * G1_KC + xo[gk]);
+        for (int b = 0; b < NB; ++b) bv[slot][b] = *(const float4*)(set + brow + b * 32 * G1_KC + xo[gk]);
     };
     load_frag(0, 0);
 #pragma unroll
@@ -108,14 +110,14 @@ __device__ __forceinline__ void g1_chunk(const float* __restrict__ set, float* _
             for (int a = 0; a < 2; ++a) {
                 const float as = s == 0 ? av[cs][a].x : s == 1 ? av[cs][a].y : s == 2 ? av[cs][a].z : av[cs][a].w;
 #pragma unroll
-                for (int b = 0; b < 2; ++b) {
+                for (int b = 0; b < NB; ++b) {
                     const float bs = s == 0 ? bv[cs][b].x : s == 1 ? bv[cs][b].y : s == 2 ? bv[cs][b].z : bv[cs][b].w;
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(as, bs, acc[a][b], 0, 0, 0);
                 }
             }
             if (s == 0 || s == 2) {
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) {
+                if (more && gk * 2 + (s >> 1) < 4 + 2 * NB) {
                     if (tail) g1_piece<true>(ra, rb, q, kc + 1, gk * 2 + (s >> 1), nset);
                     else g1_piece<false>(ra, rb, q, kc + 1, gk * 2 + (s >> 1), nset);
                 }
@@ -128,23 +130,27 @@ __device__ __forceinline__ void g1_chunk(const float* __restrict__ set, float* _
 #endif
 
 // DIR (0 forward, 1 data-gradient) changes no code: it gives the two uses distinct symbols in a profile.
-template <int DIR>
-__global__ __launch_bounds__(256, 2) void gemm1_kernel(Gemm1Args args) {
+// NB = 2: 128 x 128 tile, two workgroups per CU.  NB = 1: 128 x 64 tile (waves 2 x 2 of 64 x 32), 49 KB of LDS, three
+// workgroups per CU -- for the problems whose 128 x 128 grid is not a whole number of rounds over 512 slots (the launcher's
+// rule); every output element sums its K products in the same order in both, so the choice changes no bit.
+template <int DIR, int NB>
+__global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void gemm1_kernel(Gemm1Args args) {
 #if __HIP_DEVICE_COMPILE__
     const TapGemmArgs& g = args.g;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* rowa = (int*)smem;                              // [128] output row of out_a (or -1), [128] of out_y
     int* rowy = rowa + 128;
     float* bufs = smem + 256;                            // A0 | B0 | A1 | B1, later the epilogue's transpose scratch
+    constexpr int SETF = G1_TILE_F + NB * 64 * G1_KC;    // floats of one buffer set: A tile | B tile
     float* set0 = bufs;
-    float* set1 = bufs + 2 * G1_TILE_F;
+    float* set1 = bufs + SETF;
 
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int swz = asr_xcd_swizzle(blockIdx.x, gridDim.x);
     const int tile_m = swz / g.ntn, tile_n = swz - tile_m * g.ntn;
-    const int m0 = tile_m * 128, n0 = tile_n * 128;
+    const int m0 = tile_m * 128, n0 = tile_n * (64 * NB);
     const int K = g.K;
 
     if (tid < 128) {
@@ -179,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm1_kernel(Gemm1Args args) {
     for (int i = 0; i < 4; ++i) {
         const int r = 8 * (wave + 4 * i) + (lane >> 3);
         int ra = m0 + r; if (ra > g.M - 1) ra = g.M - 1;
-        int rb = n0 + r; if (rb > g.N - 1) rb = g.N - 1;
+        int rb = n0 + r; if (rb > g.N - 1) rb = g.N - 1;                 // (NB = 1: only i < 2 is used)
         q.offa[i] = (unsigned)(((long)ra * g.lda + q.dchunk * 4) * 4);
         q.offb[i] = (unsigned)(((long)rb * args.ldb + q.dchunk * 4) * 4);
     }
@@ -191,22 +197,22 @@ __global__ __launch_bounds__(256, 2) void gemm1_kernel(Gemm1Args args) {
     int xo[4];
 #pragma unroll
     for (int gk = 0; gk < 4; ++gk) xo[gk] = ((2 * gk + lh) ^ ((li >> 1) & 7)) * 4;
-    const int arow = (wm * 64 + li) * G1_KC, brow = G1_TILE_F + (wn * 64 + li) * G1_KC;
+    const int arow = (wm * 64 + li) * G1_KC, brow = G1_TILE_F + (wn * (32 * NB) + li) * G1_KC;
 
-    floatx16 acc[2][2];
+    floatx16 acc[2][NB];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     if (ktail && nkc == 1) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g1_piece<true>(rsa, rsb, q, 0, j, set0);
+        for (int j = 0; j < 4 + 2 * NB; ++j) g1_piece<true>(rsa, rsb, q, 0, j, set0);
     } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) g1_piece<false>(rsa, rsb, q, 0, j, set0);
+        for (int j = 0; j < 4 + 2 * NB; ++j) g1_piece<false>(rsa, rsb, q, 0, j, set0);
     }
 
     // a barrier per chunk: behind it chunk kc has landed (every wave waited for its own pieces: __syncthreads is also
@@ -215,16 +221,16 @@ __global__ __launch_bounds__(256, 2) void gemm1_kernel(Gemm1Args args) {
     int kc = 0;
     for (; kc + 2 <= last_plain; kc += 2) {
         dma_barrier();
-        g1_chunk<1>(set0, set1, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc);
+        g1_chunk<1, NB>(set0, set1, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc);
         dma_barrier();
-        g1_chunk<1>(set1, set0, rsa, rsb, q, kc + 1, nkc, ktail, arow, brow, xo, acc);
+        g1_chunk<1, NB>(set1, set0, rsa, rsb, q, kc + 1, nkc, ktail, arow, brow, xo, acc);
     }
-    if (kc < nkc) { dma_barrier(); g1_chunk<2>(set0, set1, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc); ++kc; }
-    if (kc < nkc) { dma_barrier(); g1_chunk<2>(set1, set0, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc); ++kc; }
-    if (kc < nkc) { dma_barrier(); g1_chunk<2>(set0, set1, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc); ++kc; }
+    if (kc < nkc) { dma_barrier(); g1_chunk<2, NB>(set0, set1, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc); ++kc; }
+    if (kc < nkc) { dma_barrier(); g1_chunk<2, NB>(set1, set0, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc); ++kc; }
+    if (kc < nkc) { dma_barrier(); g1_chunk<2, NB>(set0, set1, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc); ++kc; }
 
     __syncthreads();                                     // the tiles are dead: their space is the epilogue's scratch
-    tap_epilogue<2, 2>(g, acc, bufs + wave * (32 * 33), rowa, rowy, wm * 64, n0 + wn * 64, lane, tile_m * 2 + wm);
+    tap_epilogue<2, NB>(g, acc, bufs + wave * (32 * 33), rowa, rowy, wm * 64, n0 + wn * (32 * NB), lane, tile_m * 2 + wm);
 #endif
 }
 
@@ -404,6 +410,16 @@ bool asr_gemm1_eligible(const asr_gemm_desc* d, const float* A, const float* Bt,
     return (long)asr_cdiv(d->M, 128) * asr_cdiv(d->N, 128) >= 48;
 }
 
+// 32-column blocks per wave (tile width / 64): see gemm1_kernel.  A function of the problem's shape alone: the 128 x 128 tile
+// when its grid fills whole rounds of the chip's 512 workgroup slots (>= 0.96 of the last one), else the 128 x 64 tile, whose
+// grid is twice as fine and runs three to a CU (tools/bench_gemm1_tiles.py, profiles/r04_gemm1_tiles.txt: 6400 x 512 -> 1536,
+// 600 tiles: 90 -> 111 TFLOP/s; 6400 x 3200 -> 256, 100 tiles: 52 -> 102; 32768-row problems: unchanged, they keep 128 x 128).
+static int gemm1_blocks(int M, int N) {
+    const long tiles = (long)asr_cdiv(M, 128) * asr_cdiv(N, 128);
+    const long rounds = (tiles + 511) / 512;
+    return tiles * 100 >= rounds * 512 * 96 ? 2 : 1;
+}
+
 // gate: the fused backward prologue of asr_tap_gemm_gated (tap_epilogue_gated), or null
 int asr_gemm1_launch(const asr_gemm_desc* d, const float* A, const float* Bt, int ldb, const float* bias, const float* scale,
                      const float* shift, float* out_a, float* out_y, int dir, void* stream, const Gemm1Gate* gate) {
@@ -417,25 +433,23 @@ int asr_gemm1_launch(const asr_gemm_desc* d, const float* A, const float* Bt, in
     a.relu = d->relu; a.accumulate = d->accumulate; a.y_unpadded = d->H > 0 ? d->y_unpadded : 0;
     a.gate_mode = 0; a.gate_H = a.gate_W = 0; a.gate_a = nullptr; a.gate_dz = nullptr; a.gate_part = nullptr; a.gate_rows = nullptr;
     a.nt_store = 0;
-    a.ntm = asr_cdiv(d->M, 128); a.ntn = asr_cdiv(d->N, 128);
+    const int nb = gemm1_blocks(d->M, d->N);
+    a.ntm = asr_cdiv(d->M, 128); a.ntn = asr_cdiv(d->N, 64 * nb);
     if (gate) {
         a.gate_mode = gate->mode; a.gate_H = gate->H; a.gate_W = gate->W; a.gate_a = gate->a; a.gate_dz = gate->dz; a.gate_part = gate->part;
         if (gate->rows) *gate->rows = a.ntm * 2;           // one partial row per (tile row, wave row)
     }
     ga.Bt = Bt; ga.ldb = ldb;
-    const size_t lds = (size_t)(256 + 4 * G1_TILE_F) * sizeof(float);
-    static_assert(4 * 32 * 33 <= 4 * G1_TILE_F, "epilogue scratch fits the tile buffers");
-    static bool attr0 = false, attr1 = false;
-    hipStream_t st = (hipStream_t)stream;
-    if (dir) {
-        if (!attr1) { (void)hipFuncSetAttribute((const void*)gemm1_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
-        hipLaunchKernelGGL(gemm1_kernel<1>, dim3(a.ntm * a.ntn), dim3(256), lds, st, ga);
-        ASR_NOTE_KERNEL("gemm1_kernel<1>");
-    } else {
-        if (!attr0) { (void)hipFuncSetAttribute((const void*)gemm1_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr0 = true; }
-        hipLaunchKernelGGL(gemm1_kernel<0>, dim3(a.ntm * a.ntn), dim3(256), lds, st, ga);
-        ASR_NOTE_KERNEL("gemm1_kernel<0>");
-    }
+    const size_t lds = (size_t)(256 + 2 * (G1_TILE_F + nb * 64 * G1_KC)) * sizeof(float);
+    static_assert(4 * 32 * 33 <= 2 * (G1_TILE_F + 64 * G1_KC), "epilogue scratch fits the tile buffers");
+    typedef void (*kern_t)(Gemm1Args);
+    static const kern_t kerns[4] = {gemm1_kernel<0, 1>, gemm1_kernel<0, 2>, gemm1_kernel<1, 1>, gemm1_kernel<1, 2>};
+    static const char* const names[4] = {"gemm1_kernel<0, 1>", "gemm1_kernel<0, 2>", "gemm1_kernel<1, 1>", "gemm1_kernel<1, 2>"};
+    static bool attr[4] = {false, false, false, false};
+    const int ki = (dir ? 2 : 0) + (nb - 1);
+    if (!attr[ki]) { (void)hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[ki] = true; }
+    hipLaunchKernelGGL(kerns[ki], dim3(a.ntm * a.ntn), dim3(256), lds, (hipStream_t)stream, ga);
+    asr_set_last_kernel(names[ki]);
     ASR_CHECK_LAUNCH("gemm1");
     return ASR_OK;
 }

@@ -83,19 +83,21 @@ __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const float* __rest
     }
 }
 
-constexpr int kLnRows = 64;     // rows per block in the backward (block partials for dgamma/dbeta)
+// rows per block in the backward (block partials for dgamma / dbeta): 64, or 16 when that leaves fewer than 512 blocks (the
+// language model's 6400 rows were 100 blocks of sixteen rows per wave on 256 CUs: 27 us for 39 MB of traffic)
+static inline int ln_rows_per_block(int rows) { return rows >= 64 * 512 ? 64 : 16; }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma;  partials[blk][2][C] = sum dy*xhat, sum dy
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                      int rows, int C, float* __restrict__ dx, int accumulate,
-                                                     float* __restrict__ partials) {
+                                                     float* __restrict__ partials, int rpb) {
     extern __shared__ float sm[];        // [4 waves][2][C]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* mine = sm + wave * 2 * C;
     for (int c = lane; c < 2 * C; c += 64) mine[c] = 0.f;
-    const int r0 = blockIdx.x * kLnRows;
-    for (int rr = wave; rr < kLnRows; rr += 4) {
+    const int r0 = blockIdx.x * rpb;
+    for (int rr = wave; rr < rpb; rr += 4) {
         const int row = r0 + rr;
         if (row >= rows) break;
         const float* pdy = dy + (long)row * C;
@@ -127,7 +129,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                          int rows, int C, float* __restrict__ dx, int accumulate,
-                                                         float* __restrict__ partials) {
+                                                         float* __restrict__ partials, int rpb) {
     extern __shared__ float sm[];        // [4 waves][2][C]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n4 = C >> 2;
@@ -138,8 +140,8 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* __restrict
         g4[i] = (q < n4) ? *(const float4*)(gamma + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         ag[i] = make_float4(0.f, 0.f, 0.f, 0.f); ab[i] = ag[i];
     }
-    const int r0 = blockIdx.x * kLnRows;
-    for (int rr = wave; rr < kLnRows; rr += 4) {
+    const int r0 = blockIdx.x * rpb;
+    for (int rr = wave; rr < rpb; rr += 4) {
         const int row = r0 + rr;
         if (row >= rows) break;
         const float* pdy = dy + (long)row * C;
@@ -217,6 +219,48 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(const float* __restrict_
         float s = 0.f;
         for (int j = beg; j < end; ++j) s += dout[(long)perm[j] * C + c];
         dtable[(long)id * C + c] = (zero_pad && id == 0) ? 0.f : s * scale;
+    }
+}
+
+// The same sums with no host-side sort: one wave per table row v scans the id array 64 positions at a time (a ballot of
+// ids[p] == v) and adds the matching rows of dout in ascending position -- the order of a stable sort by id, so the bits are
+// those of embed_bwd_kernel.  V * rows / 64 wave iterations over an L2-resident array: microseconds for the models' tables
+// (1536 x 6400, 6348 x 32768), against an argsort + unique on the host and three uploads per step.
+__global__ __launch_bounds__(256) void embed_bwd_ids_kernel(const float* __restrict__ dout, const int32_t* __restrict__ ids, int rows,
+                                                            int V, int C, int zero_pad, float scale, float* __restrict__ dtable) {
+    const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= V) return;
+    const int lane = threadIdx.x & 63;
+    const int n4 = C >> 2;                       // float4 columns: lane owns lane, lane + 64, ... (C <= 1024)
+    float4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool any = false;
+    for (int p0 = 0; p0 < rows; p0 += 64) {
+        const int p = p0 + lane;
+        unsigned long long m = __ballot(p < rows && ids[p] == v);
+        any |= m != 0;
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            const float* src = dout + (long)(p0 + j) * C;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = lane + i * 64;
+                if (q < n4) {
+                    const float4 t = *(const float4*)(src + q * 4);
+                    acc[i].x += t.x; acc[i].y += t.y; acc[i].z += t.z; acc[i].w += t.w;
+                }
+            }
+        }
+    }
+    if (!any) return;                            // an id that does not occur: its row is not written
+    const bool zero = zero_pad && v == 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = lane + i * 64;
+        if (q < n4) *(float4*)(dtable + (long)v * C + q * 4) = zero ? make_float4(0.f, 0.f, 0.f, 0.f)
+                                                                     : make_float4(acc[i].x * scale, acc[i].y * scale, acc[i].z * scale, acc[i].w * scale);
     }
 }
 
@@ -454,7 +498,7 @@ extern "C" int asr_add_layernorm_fwd(const float* a, const float* b, const float
 }
 
 extern "C" size_t asr_layernorm_bwd_workspace(int rows, int C) {
-    const size_t nblk = (size_t)asr_cdiv(rows, kLnRows);
+    const size_t nblk = (size_t)asr_cdiv(rows, ln_rows_per_block(rows));
     return (nblk * 2 * C + asr_reduce::colsum_tmp_floats((int)nblk, 2 * C) + 16) * sizeof(float);
 }
 
@@ -463,13 +507,14 @@ extern "C" int asr_layernorm_bwd(const float* dy, const float* xhat, const float
     if (!dy || !xhat || !rstd || !gamma || !dx || !dgamma || !dbeta || !partials || rows < 1 || C < 1) return ASR_ERR_BAD_ARG;
     if ((size_t)8 * C * sizeof(float) > 64 * 1024) return ASR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int nblk = asr_cdiv(rows, kLnRows);
+    const int rpb = ln_rows_per_block(rows);
+    const int nblk = asr_cdiv(rows, rpb);
     const size_t lds = (size_t)8 * C * sizeof(float);
     const bool vec = (C & 3) == 0 && ((((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)dx | (uintptr_t)gamma)) & 15) == 0;
-    if (vec && C <= 256) hipLaunchKernelGGL(ln_bwd_vec_kernel<1>, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials);
-    else if (vec && C <= 512) hipLaunchKernelGGL(ln_bwd_vec_kernel<2>, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials);
-    else if (vec && C <= 2048) hipLaunchKernelGGL(ln_bwd_vec_kernel<8>, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials);
-    else hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials);
+    if (vec && C <= 256) hipLaunchKernelGGL(ln_bwd_vec_kernel<1>, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials, rpb);
+    else if (vec && C <= 512) hipLaunchKernelGGL(ln_bwd_vec_kernel<2>, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials, rpb);
+    else if (vec && C <= 2048) hipLaunchKernelGGL(ln_bwd_vec_kernel<8>, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials, rpb);
+    else hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials, rpb);
     ASR_CHECK_LAUNCH("layernorm_bwd");
     float* tmp = partials + (size_t)nblk * 2 * C;
     asr_reduce::Multi m;
@@ -492,6 +537,15 @@ extern "C" int asr_embed_bwd(const float* dout, const int32_t* perm, const int32
     if (n_uniq == 0) return ASR_OK;
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(n_uniq), dim3(256), 0, (hipStream_t)stream, dout, perm, uniq, seg, C, zero_pad, scale, dtable);
     ASR_CHECK_LAUNCH("embed_bwd");
+    return ASR_OK;
+}
+
+extern "C" int asr_embed_bwd_ids(const float* dout, const int32_t* ids, int rows, int V, int C, int zero_pad, float scale,
+                                 float* dtable, void* stream) {
+    if (!dout || !ids || !dtable || rows < 1 || V < 1 || C < 4) return ASR_ERR_BAD_ARG;
+    if ((C & 3) || C > 1024 || (((uintptr_t)dout | (uintptr_t)dtable) & 15)) return ASR_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(embed_bwd_ids_kernel, dim3(asr_cdiv(V, 4)), dim3(256), 0, (hipStream_t)stream, dout, ids, rows, V, C, zero_pad, scale, dtable);
+    ASR_CHECK_LAUNCH("embed_bwd_ids");
     return ASR_OK;
 }
 

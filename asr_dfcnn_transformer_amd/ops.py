@@ -376,6 +376,11 @@ def embed_fwd(table, ids, pos, N, T, Cc, zero_pad, scale, out):
                                     _stream()), 'asr_embed_fwd')
 
 
+def embed_bwd_ids(dout, ids, rows, V, Cc, zero_pad, scale, dtable):
+    check(_lib.load().asr_embed_bwd_ids(_ptr(dout), _ptr(ids), rows, V, Cc, int(zero_pad), scale, _ptr(dtable), _stream()),
+          'asr_embed_bwd_ids')
+
+
 def embed_bwd(dout, perm, uniq, seg, n_uniq, Cc, zero_pad, scale, dtable):
     check(_lib.load().asr_embed_bwd(_ptr(dout), _ptr(perm), _ptr(uniq), _ptr(seg), n_uniq, Cc, int(zero_pad), scale,
                                     _ptr(dtable), _stream()), 'asr_embed_bwd')

@@ -22,7 +22,8 @@ SMOOTH_EPS = 0.1
 
 
 def sorted_segments(ids):
-    """Positions sorted by id (stable) + segment table, for the deterministic embedding scatter."""
+    """Positions sorted by id (stable) + segment table: the inputs of asr_embed_bwd (the engines use asr_embed_bwd_ids, which
+    needs neither; kept for callers that hold a sorted index already, and for the test that the two forms give the same bits)."""
     flat = np.asarray(ids).reshape(-1)
     perm = np.argsort(flat, kind='stable').astype(np.int32)
     sv = flat[perm]
@@ -485,7 +486,6 @@ class LMEngine(_Base):
         self.ffn = self._ffn_alloc(rows)
         self._head_alloc(rows)
         self.dstream = [self._t(rows * C), self._t(rows * C)]
-        self.seg = [self._t(rows, dtype=torch.int32), self._t(rows, dtype=torch.int32), self._t(rows + 1, dtype=torch.int32)]
         self._alloc_scratch(rows, max(C * self.Vp, 4 * C * C),
                             [(rows, C, C), (rows, C, 4 * C), (rows, 4 * C, C), (rows, C, self.Vp)])
 
@@ -535,9 +535,8 @@ class LMEngine(_Base):
             cur, nxt = nxt, cur
         if self._rate > 0:
             ops.dropout(cur, self._rate, self._seed_emb)
-        perm, uniq, seg = sorted_segments(self._x_host)
-        self._upload('seg0', self.seg[0], perm); self._upload('seg1', self.seg[1], uniq); self._upload('seg2', self.seg[2], seg)
-        ops.embed_bwd(cur, self.seg[0], self.seg[1], self.seg[2], len(uniq), C, True, float(C) ** 0.5, self.g('emb'))
+        # (the ids are still on the device from the forward pass: no host-side sort, nothing to upload)
+        ops.embed_bwd_ids(cur, self.ids, rows, self.vin, C, True, float(C) ** 0.5, self.g('emb'))
         ops.colsum(cur, N, T * C, T * C, self.g('pos')[:T * C], self.ws)
 
 
@@ -579,7 +578,6 @@ class E2EEngine(_Base):
         mr = max(re, rd)
         self.dstream = [self._t(mr * C), self._t(mr * C)]
         self.dmem = self._t(re * C)
-        self.seg = [self._t(mr, dtype=torch.int32), self._t(mr, dtype=torch.int32), self._t(mr + 1, dtype=torch.int32)]
         self.dx_feat = self._t(re, din) if self.need_dx else None
         self._alloc_scratch(mr, max(C * self.Vp, 4 * C * C, din * C),
                             [(r, C, C) for r in (re, rd)] + [(r, C, 4 * C) for r in (re, rd)] +
@@ -649,9 +647,7 @@ class E2EEngine(_Base):
             self._mha_bwd('dec%d' % i, self.dec[i], cur, nxt, False, self.dmem, not first)
             first = False
             cur, nxt = nxt, cur
-        perm, uniq, seg = sorted_segments(self._y_host)
-        self._seg_upload(perm, uniq, seg)
-        ops.embed_bwd(cur, self.seg[0], self.seg[1], self.seg[2], len(uniq), C, False, 1.0, self.g('dec_input'))
+        ops.embed_bwd_ids(cur, self.y_ids, rd, self.logical['dec_input'][0], C, False, 1.0, self.g('dec_input'))
         ops.colsum(cur, N, L * C, L * C, self.g('dec_pe')[:L * C], self.ws)
         e0, e1 = self.dstream[0][:re * C], self.dstream[1][:re * C]
         self._ffn_bwd('enc_ffn', self.enc_ffn, self.dmem, e0, False)
@@ -672,9 +668,4 @@ class E2EEngine(_Base):
             if self.need_dx:
                 self._dense_dgrad(du, re, self.din, C, self.p('in_w'), self.dx_feat, False)
         else:
-            perm, uniq, seg = sorted_segments(self._x_host)
-            self._seg_upload(perm, uniq, seg)
-            ops.embed_bwd(cur, self.seg[0], self.seg[1], self.seg[2], len(uniq), C, True, float(C) ** 0.5, self.g('enc_emb'))
-
-    def _seg_upload(self, perm, uniq, seg):
-        self._upload('seg0', self.seg[0], perm); self._upload('seg1', self.seg[1], uniq); self._upload('seg2', self.seg[2], seg)
+            ops.embed_bwd_ids(cur, self.x_ids, re, self.vin, C, True, float(C) ** 0.5, self.g('enc_emb'))

@@ -50,13 +50,15 @@ def kernel_peak(sym):
 def is_forward_symbol(sym):
     """Contraction kernels that only the forward pass launches (they run alone on the main stream even when the backward
     pass uses two): wino11_kernel<DIR, EPI> / wino8_kernel<DIR>, tap_gemm_kernel_v5<..., DIR>, tap_gemm_kernel_v1<MT, NT, WM, WN, NTAPS, WMODE[, KC]>,
-    gemm1_kernel<..., DIR> with DIR / WMODE 0."""
+    gemm1_kernel<DIR, NB> with DIR / WMODE 0."""
     if '<' not in sym:
         return False
     args = [a.strip() for a in sym[sym.index('<') + 1:sym.rindex('>')].split(',')]
     if sym.startswith('wino8_kernel') or sym.startswith('wino11_kernel'):
         return args[0] == '0'
-    if sym.startswith('tap_gemm_kernel_v5') or sym.startswith('gemm1_kernel'):
+    if sym.startswith('gemm1_kernel'):
+        return args[0] == '0'
+    if sym.startswith('tap_gemm_kernel_v5'):
         return args[-1] == '0'
     if sym.startswith('tap_gemm_kernel_v1'):
         return args[5] == '0'

@@ -324,6 +324,12 @@ int asr_embed_fwd(const float* table, const int32_t* ids, const float* pos, int 
                   int zero_pad, float scale, float* out, void* stream);
 int asr_embed_bwd(const float* dout, const int32_t* perm, const int32_t* uniq, const int32_t* seg, int n_uniq,
                   int C, int zero_pad, float scale, float* dtable, void* stream);
+/* The same gradient straight from the fed ids [rows] (no host-side sort, nothing to upload): a wave per table row v < V adds the
+ * rows of dout whose id is v in ascending position -- the order of the stable sort above, hence the same bits.  Ids outside
+ * [0, V) contribute nothing; rows of the table whose id does not occur are not written.  C % 4 == 0, C <= 1024, 16-byte
+ * aligned dout / dtable, else ASR_ERR_UNSUPPORTED.  (tf.gradients of tf.nn.embedding_lookup, transformer.py:30-55.) */
+int asr_embed_bwd_ids(const float* dout, const int32_t* ids, int rows, int V, int C, int zero_pad, float scale,
+                      float* dtable, void* stream);
 
 /* K16 label_smoothing(one_hot(y)) + softmax_cross_entropy_with_logits_v2 + istarget masking
  * (end2end/model.py:342-356, language_model.py:55-67).  logits [rows][ld] (ld >= V, pad columns ignored),

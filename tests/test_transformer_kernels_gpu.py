@@ -110,6 +110,36 @@ def test_embedding_fwd_bwd(ops):
     ops.embed_bwd(dev(dout), dev(perm, torch.int32), dev(uniq, torch.int32), dev(seg, torch.int32), len(uniq), C, True,
                   C ** 0.5, g)
     report('embed bwd', g.cpu().numpy(), gref, 2e-6)
+    # the same gradient straight from the ids (no sort): the same bits, absent ids untouched
+    g2 = torch.full((V, C), 7.0, device='cuda')
+    ops.embed_bwd_ids(dev(dout), dev(ids, torch.int32), N * T, V, C, True, C ** 0.5, g2)
+    present = np.zeros(V, dtype=bool); present[np.unique(ids)] = True
+    assert torch.equal(g2[torch.from_numpy(present).cuda()], g[torch.from_numpy(present).cuda()])
+    assert float((g2[torch.from_numpy(~present).cuda()] - 7.0).abs().max()) == 0.0 if (~present).any() else True
+
+
+def test_embed_bwd_from_ids_at_model_size(ops):
+    """asr_embed_bwd_ids at the language model's size (6400 positions, 1536 ids, C 512) and with out-of-range ids: against the
+    float64 oracle and bit-for-bit against the sorted-segment kernel."""
+    from asr_dfcnn_transformer_amd.transformer_engine import sorted_segments
+    rng = np.random.default_rng(12)
+    rows, V, C = 6400, 1536, 512
+    ids = rng.integers(0, V, rows).astype(np.int32)
+    ids[rng.integers(0, rows, 200)] = rng.integers(0, 40, 200)          # a few heavily used ids
+    dout = rng.standard_normal((rows, C)).astype(np.float32)
+    gref = otr.embedding_bwd((V, C), ids.reshape(1, -1), dout.astype(np.float64).reshape(1, rows, C), True, True)
+    perm, uniq, seg = sorted_segments(ids)
+    g1, g2 = torch.zeros(V, C, device='cuda'), torch.zeros(V, C, device='cuda')
+    ops.embed_bwd(dev(dout), dev(perm, torch.int32), dev(uniq, torch.int32), dev(seg, torch.int32), len(uniq), C, True, C ** 0.5, g1)
+    ops.embed_bwd_ids(dev(dout), dev(ids, torch.int32), rows, V, C, True, C ** 0.5, g2)
+    assert torch.equal(g1, g2)
+    report('embed bwd from ids', g2.cpu().numpy(), gref, 2e-6)
+    bad = ids.copy(); bad[:5] = [-1, V, V + 7, 2 ** 30, -(2 ** 31)]
+    g3 = torch.zeros(V, C, device='cuda')
+    ops.embed_bwd_ids(dev(dout), dev(bad, torch.int32), rows, V, C, True, C ** 0.5, g3)
+    keep = np.ones(rows, dtype=bool); keep[:5] = False
+    gref3 = otr.embedding_bwd((V, C), ids[keep].reshape(1, -1), dout[keep].astype(np.float64).reshape(1, -1, C), True, True)
+    report('embed bwd, ids out of range ignored', g3.cpu().numpy(), gref3, 2e-6)
 
 
 @pytest.mark.parametrize("rows,V", [(12, 13), (64, 6345), (7, 6347), (5, 7001)])     # 7001: wider than the register kernel
