@@ -42,7 +42,8 @@ template <int NV>
 __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              int rows, int C, float eps, float* __restrict__ y,
-                                                             float* __restrict__ xhat, float* __restrict__ rstd) {
+                                                             float* __restrict__ xhat, float* __restrict__ rstd,
+                                                             uint32_t dthr, uint32_t dseed, float dscale) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63, n4 = C >> 2;
@@ -56,6 +57,13 @@ __global__ __launch_bounds__(256) void add_ln_fwd_vec_kernel(const float* __rest
         v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (q < n4) {
             v[i] = *(const float4*)(pa + q * 4);
+            if (dthr) {        // asr_add_layernorm_fwd_dropout: a is dropped with asr_dropout's mask (element row * C + col) first
+                const uint32_t e = (uint32_t)row * (uint32_t)C + (uint32_t)(q * 4);
+                v[i].x = drop_keep(e, dseed, dthr) ? v[i].x * dscale : 0.f;
+                v[i].y = drop_keep(e + 1, dseed, dthr) ? v[i].y * dscale : 0.f;
+                v[i].z = drop_keep(e + 2, dseed, dthr) ? v[i].z * dscale : 0.f;
+                v[i].w = drop_keep(e + 3, dseed, dthr) ? v[i].w * dscale : 0.f;
+            }
             if (pb) { const float4 w = *(const float4*)(pb + q * 4); v[i].x += w.x; v[i].y += w.y; v[i].z += w.z; v[i].w += w.w; }
         }
         s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
@@ -125,11 +133,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 // The same pass with float4 loads, the row kept in registers (one read of dy / xhat) and the dgamma / dbeta partial
 // sums of a wave in registers instead of read-modify-write LDS traffic (120 -> ~45 us at 32768 x 512).
 // A lane owns float4 columns lane + 64*i, i < NV (C <= 1024*NV/4... i.e. C <= 256*NV).
+// Fused consumers of dx (asr_layernorm_bwd_fused): dx2 (+)= dx is the residual fan-in that used to be an axpy of its own, dz =
+// (z > 0) ? dx * zscale : 0 the backward of the Dense(relu) [+ in-place dropout] that produced the normalised sum's other
+// operand; dx itself is optional then.  One read of dy / xhat instead of writing dx and reading it back twice.
+struct LnBwdExtra { float* dx2; int acc2; const float* z; float zscale; float* dz; uint32_t dthr, dseed; };
+
 template <int NV>
 __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ xhat,
                                                          const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                          int rows, int C, float* __restrict__ dx, int accumulate,
-                                                         float* __restrict__ partials, int rpb) {
+                                                         float* __restrict__ partials, int rpb, LnBwdExtra ex) {
     extern __shared__ float sm[];        // [4 waves][2][C]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n4 = C >> 2;
@@ -164,11 +177,30 @@ __global__ __launch_bounds__(256) void ln_bwd_vec_kernel(const float* __restrict
         for (int i = 0; i < NV; ++i) {
             const int q = lane + i * 64;
             if (q >= n4) continue;
-            float4 v = make_float4(rs * (d[i].x * g4[i].x - s1 - xh[i].x * s2), rs * (d[i].y * g4[i].y - s1 - xh[i].y * s2),
-                                   rs * (d[i].z * g4[i].z - s1 - xh[i].z * s2), rs * (d[i].w * g4[i].w - s1 - xh[i].w * s2));
-            float* o = dx + (long)row * C + q * 4;
-            if (accumulate) { const float4 p = *(const float4*)o; v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
-            *(float4*)o = v;
+            const float4 v0 = make_float4(rs * (d[i].x * g4[i].x - s1 - xh[i].x * s2), rs * (d[i].y * g4[i].y - s1 - xh[i].y * s2),
+                                          rs * (d[i].z * g4[i].z - s1 - xh[i].z * s2), rs * (d[i].w * g4[i].w - s1 - xh[i].w * s2));
+            const long off = (long)row * C + q * 4;
+            if (dx) {
+                float4 v = v0;
+                if (accumulate) { const float4 p = *(const float4*)(dx + off); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+                *(float4*)(dx + off) = v;
+            }
+            if (ex.dx2) {
+                float4 v = v0;
+                if (ex.acc2) { const float4 p = *(const float4*)(ex.dx2 + off); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+                *(float4*)(ex.dx2 + off) = v;
+            }
+            if (ex.dz) {
+                float4 a = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (ex.z) a = *(const float4*)(ex.z + off);
+                if (ex.dthr) {
+                    const uint32_t e = (uint32_t)off;
+                    a.x = drop_keep(e, ex.dseed, ex.dthr) ? a.x : 0.f; a.y = drop_keep(e + 1, ex.dseed, ex.dthr) ? a.y : 0.f;
+                    a.z = drop_keep(e + 2, ex.dseed, ex.dthr) ? a.z : 0.f; a.w = drop_keep(e + 3, ex.dseed, ex.dthr) ? a.w : 0.f;
+                }
+                *(float4*)(ex.dz + off) = make_float4(a.x > 0.f ? v0.x * ex.zscale : 0.f, a.y > 0.f ? v0.y * ex.zscale : 0.f,
+                                                      a.z > 0.f ? v0.z * ex.zscale : 0.f, a.w > 0.f ? v0.w * ex.zscale : 0.f);
+            }
             ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
             ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
         }
@@ -482,19 +514,32 @@ extern "C" int asr_dropout(const float* x, size_t n, float rate, unsigned int se
     return ASR_OK;
 }
 
-extern "C" int asr_add_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, int rows, int C,
-                                     float eps, float* y, float* xhat, float* rstd, void* stream) {
-    if (!a || !gamma || !beta || !y || !xhat || !rstd || rows < 1 || C < 1) return ASR_ERR_BAD_ARG;
+static int add_ln_launch(const float* a, const float* b, const float* gamma, const float* beta, int rows, int C, float eps, float* y,
+                         float* xhat, float* rstd, uint32_t dthr, uint32_t dseed, float dscale, hipStream_t st) {
     const bool vec = (C & 3) == 0 &&
         ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)y | (uintptr_t)xhat)) & 15) == 0;
     const dim3 grid(asr_cdiv(rows, 4));
-    hipStream_t st = (hipStream_t)stream;
-    if (vec && C <= 256) hipLaunchKernelGGL(add_ln_fwd_vec_kernel<1>, grid, dim3(256), 0, st, a, b, gamma, beta, rows, C, eps, y, xhat, rstd);
-    else if (vec && C <= 512) hipLaunchKernelGGL(add_ln_fwd_vec_kernel<2>, grid, dim3(256), 0, st, a, b, gamma, beta, rows, C, eps, y, xhat, rstd);
-    else if (vec && C <= 2048) hipLaunchKernelGGL(add_ln_fwd_vec_kernel<8>, grid, dim3(256), 0, st, a, b, gamma, beta, rows, C, eps, y, xhat, rstd);
+    if (vec && C <= 256) hipLaunchKernelGGL(add_ln_fwd_vec_kernel<1>, grid, dim3(256), 0, st, a, b, gamma, beta, rows, C, eps, y, xhat, rstd, dthr, dseed, dscale);
+    else if (vec && C <= 512) hipLaunchKernelGGL(add_ln_fwd_vec_kernel<2>, grid, dim3(256), 0, st, a, b, gamma, beta, rows, C, eps, y, xhat, rstd, dthr, dseed, dscale);
+    else if (vec && C <= 2048) hipLaunchKernelGGL(add_ln_fwd_vec_kernel<8>, grid, dim3(256), 0, st, a, b, gamma, beta, rows, C, eps, y, xhat, rstd, dthr, dseed, dscale);
+    else if (dthr) return ASR_ERR_UNSUPPORTED;
     else hipLaunchKernelGGL(add_ln_fwd_kernel, grid, dim3(256), 0, st, a, b, gamma, beta, rows, C, eps, y, xhat, rstd);
     ASR_CHECK_LAUNCH("add_layernorm_fwd");
     return ASR_OK;
+}
+
+extern "C" int asr_add_layernorm_fwd(const float* a, const float* b, const float* gamma, const float* beta, int rows, int C,
+                                     float eps, float* y, float* xhat, float* rstd, void* stream) {
+    if (!a || !gamma || !beta || !y || !xhat || !rstd || rows < 1 || C < 1) return ASR_ERR_BAD_ARG;
+    return add_ln_launch(a, b, gamma, beta, rows, C, eps, y, xhat, rstd, 0u, 0u, 1.f, (hipStream_t)stream);
+}
+
+extern "C" int asr_add_layernorm_fwd_dropout(const float* a, const float* b, const float* gamma, const float* beta, int rows, int C,
+                                             float eps, float rate, unsigned seed, float* y, float* xhat, float* rstd, void* stream) {
+    if (!a || !gamma || !beta || !y || !xhat || !rstd || rows < 1 || C < 1 || rate < 0.f || rate >= 1.f) return ASR_ERR_BAD_ARG;
+    if ((unsigned long long)rows * (unsigned long long)C >= 4294967296ull) return ASR_ERR_BAD_ARG;
+    const uint32_t thr = drop_threshold(rate);
+    return add_ln_launch(a, b, gamma, beta, rows, C, eps, y, xhat, rstd, thr, (uint32_t)seed, thr ? 1.0f / (1.0f - rate) : 1.f, (hipStream_t)stream);
 }
 
 extern "C" size_t asr_layernorm_bwd_workspace(int rows, int C) {
@@ -502,18 +547,19 @@ extern "C" size_t asr_layernorm_bwd_workspace(int rows, int C) {
     return (nblk * 2 * C + asr_reduce::colsum_tmp_floats((int)nblk, 2 * C) + 16) * sizeof(float);
 }
 
-extern "C" int asr_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int C,
-                                 float* dx, int accumulate, float* dgamma, float* dbeta, float* partials, void* stream) {
-    if (!dy || !xhat || !rstd || !gamma || !dx || !dgamma || !dbeta || !partials || rows < 1 || C < 1) return ASR_ERR_BAD_ARG;
+static int ln_bwd_launch(const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int C, float* dx,
+                         int accumulate, float* dgamma, float* dbeta, float* partials, const LnBwdExtra& ex, hipStream_t st) {
     if ((size_t)8 * C * sizeof(float) > 64 * 1024) return ASR_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
     const int rpb = ln_rows_per_block(rows);
     const int nblk = asr_cdiv(rows, rpb);
     const size_t lds = (size_t)8 * C * sizeof(float);
-    const bool vec = (C & 3) == 0 && ((((uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)dx | (uintptr_t)gamma)) & 15) == 0;
-    if (vec && C <= 256) hipLaunchKernelGGL(ln_bwd_vec_kernel<1>, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials, rpb);
-    else if (vec && C <= 512) hipLaunchKernelGGL(ln_bwd_vec_kernel<2>, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials, rpb);
-    else if (vec && C <= 2048) hipLaunchKernelGGL(ln_bwd_vec_kernel<8>, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials, rpb);
+    uintptr_t al = (uintptr_t)dy | (uintptr_t)xhat | (uintptr_t)dx | (uintptr_t)gamma | (uintptr_t)ex.dx2 | (uintptr_t)ex.z | (uintptr_t)ex.dz;
+    const bool vec = (C & 3) == 0 && (al & 15) == 0;
+    const bool fused = ex.dx2 || ex.dz;
+    if (vec && C <= 256) hipLaunchKernelGGL(ln_bwd_vec_kernel<1>, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials, rpb, ex);
+    else if (vec && C <= 512) hipLaunchKernelGGL(ln_bwd_vec_kernel<2>, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials, rpb, ex);
+    else if (vec && C <= 2048) hipLaunchKernelGGL(ln_bwd_vec_kernel<8>, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials, rpb, ex);
+    else if (fused) return ASR_ERR_UNSUPPORTED;
     else hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials, rpb);
     ASR_CHECK_LAUNCH("layernorm_bwd");
     float* tmp = partials + (size_t)nblk * 2 * C;
@@ -521,6 +567,24 @@ extern "C" int asr_layernorm_bwd(const float* dy, const float* xhat, const float
     m.nseg = 2; m.width[0] = C; m.width[1] = C; m.width[2] = 0; m.width[3] = 0;
     m.out[0] = dgamma; m.out[1] = dbeta; m.out[2] = nullptr; m.out[3] = nullptr;
     return asr_reduce::colsum_multi(partials, nblk, 2 * C, m, tmp, st);
+}
+
+extern "C" int asr_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int C,
+                                 float* dx, int accumulate, float* dgamma, float* dbeta, float* partials, void* stream) {
+    if (!dy || !xhat || !rstd || !gamma || !dx || !dgamma || !dbeta || !partials || rows < 1 || C < 1) return ASR_ERR_BAD_ARG;
+    LnBwdExtra ex; ex.dx2 = nullptr; ex.acc2 = 0; ex.z = nullptr; ex.zscale = 0.f; ex.dz = nullptr; ex.dthr = 0; ex.dseed = 0;
+    return ln_bwd_launch(dy, xhat, rstd, gamma, rows, C, dx, accumulate, dgamma, dbeta, partials, ex, (hipStream_t)stream);
+}
+
+extern "C" int asr_layernorm_bwd_fused(const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int C,
+                                       float* dx, float* dx2, int accumulate2, const float* z, float drop_rate, unsigned drop_seed,
+                                       float zscale, float* dz, float* dgamma, float* dbeta, float* partials, void* stream) {
+    if (!dy || !xhat || !rstd || !gamma || !dgamma || !dbeta || !partials || rows < 1 || C < 1) return ASR_ERR_BAD_ARG;
+    if ((!dx && !dx2 && !dz) || drop_rate < 0.f || drop_rate >= 1.f) return ASR_ERR_BAD_ARG;
+    if ((unsigned long long)rows * (unsigned long long)C >= 4294967296ull) return ASR_ERR_BAD_ARG;
+    LnBwdExtra ex; ex.dx2 = dx2; ex.acc2 = accumulate2; ex.z = z; ex.zscale = zscale; ex.dz = dz;
+    ex.dthr = drop_threshold(drop_rate); ex.dseed = (uint32_t)drop_seed;
+    return ln_bwd_launch(dy, xhat, rstd, gamma, rows, C, dx, 0, dgamma, dbeta, partials, ex, (hipStream_t)stream);
 }
 
 extern "C" int asr_embed_fwd(const float* table, const int32_t* ids, const float* pos, int N, int T, int C,

@@ -376,6 +376,22 @@ def embed_fwd(table, ids, pos, N, T, Cc, zero_pad, scale, out):
                                     _stream()), 'asr_embed_fwd')
 
 
+def layernorm_bwd_fused(dy, xhat, rstd, gamma, rows, Cc, dx, dx2, accumulate2, z, zscale, dz, dgamma, dbeta, partials,
+                        drop_rate=0.0, drop_seed=0):
+    """asr_layernorm_bwd with its consumers fused: dx (or None), dx2 (+)= dx (or None), dz = mask ? dx * zscale : 0 (or None),
+    mask = (z > 0 if z is given) and (asr_dropout's keep(element, drop_seed) if drop_rate > 0)."""
+    check(_lib.load().asr_layernorm_bwd_fused(_ptr(dy), _ptr(xhat), _ptr(rstd), _ptr(gamma), rows, Cc, _ptr(dx), _ptr(dx2),
+                                              int(accumulate2), _ptr(z), float(drop_rate), int(drop_seed) & 0xffffffff, float(zscale),
+                                              _ptr(dz), _ptr(dgamma), _ptr(dbeta), _ptr(partials), _stream()), 'asr_layernorm_bwd_fused')
+
+
+def add_layernorm_fwd_dropout(a, b, gamma, beta, rows, Cc, eps, rate, seed, y, xhat, rstd):
+    """add_layernorm_fwd(dropout(a, rate, seed), b) in one pass; a is left as it is."""
+    check(_lib.load().asr_add_layernorm_fwd_dropout(_ptr(a), _ptr(b), _ptr(gamma), _ptr(beta), rows, Cc, eps, float(rate),
+                                                    int(seed) & 0xffffffff, _ptr(y), _ptr(xhat), _ptr(rstd), _stream()),
+          'asr_add_layernorm_fwd_dropout')
+
+
 def embed_bwd_ids(dout, ids, rows, V, Cc, zero_pad, scale, dtable):
     check(_lib.load().asr_embed_bwd_ids(_ptr(dout), _ptr(ids), rows, V, Cc, int(zero_pad), scale, _ptr(dtable), _stream()),
           'asr_embed_bwd_ids')

@@ -272,10 +272,9 @@ class _Base:
         st['seed_att'], st['seed_out'] = self._drop_seed((kind, blk, 'att')), self._drop_seed((kind, blk, 'out'))
         ops.attention_fwd(Q, K, V, N, Tq, Tk, C, self.H, causal, st['A'], st['lse'], rate, st['seed_att'], ldq=ldq, ldk=ldk)
         self._dense(st['A'], N * Tq, C, C, self.p(name + '/wo'), None, st['Z'], True)
-        if rate > 0:
-            ops.dropout(st['Z'], rate, st['seed_out'])          # in place: Z > 0 now also means "kept"
-        ops.add_layernorm_fwd(st['Z'], q_in, self.p(name + '/ln_g'), self.p(name + '/ln_b'), N * Tq, C, LN_EPS,
-                              st['out'], st['xhat'], st['rstd'])
+        # dropout(Z) + residual + LayerNorm in one pass; Z itself stays undropped, the backward regenerates the mask
+        ops.add_layernorm_fwd_dropout(st['Z'], q_in, self.p(name + '/ln_g'), self.p(name + '/ln_b'), N * Tq, C, LN_EPS,
+                                      rate, st['seed_out'], st['out'], st['xhat'], st['rstd'])
         return st['out']
 
     def _pack_qkv(self, name, st):
@@ -324,15 +323,12 @@ class _Base:
         """dq_in (+)= dL/d(queries), dk_in (+)= dL/d(keys); dk_in may be dq_in (self-attention)."""
         C, N, Tq, Tk = self.C, st['N'], st['Tq'], st['Tk']
         rq, rk = N * Tq, N * Tk
-        dr, dZ, dA = self.sc['a'][:rq * C], self.sc['b'][:rq * C], self.sc['c'][:rq * C]
-        ops.layernorm_bwd(dout, st['xhat'], st['rstd'], self.p(name + '/ln_g'), rq, C, dr, False,
-                          self.g(name + '/ln_g'), self.g(name + '/ln_b'), self.ws)
-        ops.axpy(dq_in, dr, 1.0, dq_acc)
-        if self._rate > 0:
-            # Z was dropped out in place: Z > 0 means active AND kept, the dropout backward is its 1 / (1 - rate) factor
-            ops.relu_bwd_scaled(dr, st['Z'], 1.0 / (1.0 - self._rate), dZ)
-        else:
-            ops.relu_bwd(dr, st['Z'], dZ)
+        dZ, dA = self.sc['b'][:rq * C], self.sc['c'][:rq * C]
+        # one pass: LayerNorm backward, dq_in (+)= its result (the residual branch) and dZ = the dropout + Dense(relu) backward
+        # of it (mask = kept by the generator AND Z > 0, factor 1 / (1 - rate))
+        ops.layernorm_bwd_fused(dout, st['xhat'], st['rstd'], self.p(name + '/ln_g'), rq, C, None, dq_in, dq_acc, st['Z'],
+                                1.0 / (1.0 - self._rate) if self._rate > 0 else 1.0, dZ,
+                                self.g(name + '/ln_g'), self.g(name + '/ln_b'), self.ws, self._rate, st['seed_out'])
         self._wgrad(st['A'], dZ, rq, C, C, name + '/wo')
         self._dense_dgrad(dZ, rq, C, C, self.p(name + '/wo'), dA, False)
         fused3 = st['fused3']
@@ -368,24 +364,18 @@ class _Base:
         self._dense(x, rows, C, 4 * C, self.p(name + '/w1'), self.p(name + '/b1'), st['H'], True)
         self._dense(st['H'], rows, 4 * C, C, self.p(name + '/w2'), self.p(name + '/b2'), st['Y'], False)
         st['seed'] = self._drop_seed(name)
-        if self._rate > 0:
-            ops.dropout(st['Y'], self._rate, st['seed'])
-        ops.add_layernorm_fwd(st['Y'], x, self.p(name + '/ln_g'), self.p(name + '/ln_b'), rows, C, LN_EPS,
-                              st['out'], st['xhat'], st['rstd'])
+        ops.add_layernorm_fwd_dropout(st['Y'], x, self.p(name + '/ln_g'), self.p(name + '/ln_b'), rows, C, LN_EPS,
+                                      self._rate, st['seed'], st['out'], st['xhat'], st['rstd'])
         return st['out']
 
     def _ffn_bwd(self, name, st, dout, dx, dx_acc):
         C, rows = self.C, st['rows']
-        dr = self.sc['a'][:rows * C]
+        dY = self.sc['b'][:rows * C]
         dH = self.sc['h'][:rows * 4 * C]
-        ops.layernorm_bwd(dout, st['xhat'], st['rstd'], self.p(name + '/ln_g'), rows, C, dr, False,
-                          self.g(name + '/ln_g'), self.g(name + '/ln_b'), self.ws)
-        ops.axpy(dx, dr, 1.0, dx_acc)
-        if self._rate > 0:                        # gradient of the dropped branch; the residual keeps dr itself
-            dY = self.sc['b'][:rows * C]
-            ops.dropout(dr, self._rate, st['seed'], dY)
-        else:
-            dY = dr
+        # one pass: dx (+)= the LayerNorm input gradient (the residual branch), dY = the same through the dropout of the FFN output
+        ops.layernorm_bwd_fused(dout, st['xhat'], st['rstd'], self.p(name + '/ln_g'), rows, C, None, dx, dx_acc, None,
+                                1.0 / (1.0 - self._rate) if self._rate > 0 else 1.0, dY,
+                                self.g(name + '/ln_g'), self.g(name + '/ln_b'), self.ws, self._rate, st['seed'])
         self._bgrad(dY, rows, C, name + '/b2')
         self._wgrad(st['H'], dY, rows, 4 * C, C, name + '/w2')
         self._dense_dgrad(dY, rows, 4 * C, C, self.p(name + '/w2'), dH, False)

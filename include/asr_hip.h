@@ -314,6 +314,22 @@ int asr_add_layernorm_fwd(const float* a, const float* b, const float* gamma, co
 size_t asr_layernorm_bwd_workspace(int rows, int C);
 int asr_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int C,
                       float* dx, int accumulate, float* dgamma, float* dbeta, float* partials, void* stream);
+/* The same pass with the consumers of dx fused in (the residual sub-layers of transformer.py:139-158, 211-232 in reverse):
+ *   dx  (may be NULL)  = the LayerNorm input gradient itself,
+ *   dx2 (may be NULL) (+)= dx            -- the residual branch's fan-in (accumulate2: add to what dx2 holds),
+ *   dz  (may be NULL)  = m ? dx * zscale : 0 -- the gradient of the sum's OTHER operand in front of what produced it: m =
+ *       (z > 0 when z is given: Dense(relu), asr_relu_bwd) AND (asr_dropout's keep(row * C + col, drop_seed) when drop_rate > 0:
+ *       the operand was dropped by asr_add_layernorm_fwd_dropout); zscale is the caller's 1 / (1 - rate) (or 1).
+ * Every value is the one the separate calls (asr_layernorm_bwd, asr_axpy alpha 1, asr_relu_bwd / asr_dropout) produce, bit for
+ * bit.  At least one output; C % 4 == 0, C <= 2048 and 16-byte aligned pointers, else ASR_ERR_UNSUPPORTED. */
+int asr_layernorm_bwd_fused(const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int C,
+                            float* dx, float* dx2, int accumulate2, const float* z, float drop_rate, unsigned drop_seed,
+                            float zscale, float* dz, float* dgamma, float* dbeta, float* partials, void* stream);
+/* asr_add_layernorm_fwd on (asr_dropout(a, rate, seed), b) without the pass over a: a is read once and stays as it is (the
+ * backward regenerates the mask: asr_layernorm_bwd_fused).  Same bits as the two calls.  rows * C < 2^32; C % 4 == 0, C <= 2048,
+ * 16-byte aligned pointers, else ASR_ERR_UNSUPPORTED. */
+int asr_add_layernorm_fwd_dropout(const float* a, const float* b, const float* gamma, const float* beta, int rows, int C,
+                                  float eps, float rate, unsigned seed, float* y, float* xhat, float* rstd, void* stream);
 
 /* K12 embedding (transformer.py:30-55): out[n][t] = scale * table[ids[n][t]] (row 0 reads as zeros
  * when zero_pad) + pos[t] (either table or pos may be NULL).  Backward is a deterministic

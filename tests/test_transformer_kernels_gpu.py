@@ -89,6 +89,37 @@ def test_add_layernorm(ops, rows, C, with_b):
     report('ln dbeta', db.cpu().numpy(), dbr, 2e-5)
     ops.layernorm_bwd(dev(dy), xh, rs, dev(g), rows, C, dx, True, dg, db, ws)
     report('ln dx accumulate', dx.cpu().numpy(), 2 * dxr, 2e-5)
+    if C % 4 == 0:
+        # the fused form (residual fan-in + Dense(relu)/dropout backward in the same pass) against the separate calls: same bits
+        z = np.maximum(rng.standard_normal((rows, C)), 0).astype(np.float32)
+        res = rng.standard_normal((rows, C)).astype(np.float32)
+        dx1 = torch.zeros(rows, C, device='cuda')
+        ops.layernorm_bwd(dev(dy), xh, rs, dev(g), rows, C, dx1, False, dg, db, ws)
+        want2 = dev(res); ops.axpy(want2, dx1, 1.0, True)
+        wantz = torch.zeros(rows, C, device='cuda'); ops.relu_bwd_scaled(dx1, dev(z), 1.25, wantz)
+        dg1, db1 = dg.clone(), db.clone()
+        got, got2, gotz = torch.zeros(rows, C, device='cuda'), dev(res), torch.full((rows, C), 3.0, device='cuda')
+        ops.layernorm_bwd_fused(dev(dy), xh, rs, dev(g), rows, C, got, got2, True, dev(z), 1.25, gotz, dg, db, ws)
+        assert torch.equal(got, dx1) and torch.equal(got2, want2) and torch.equal(gotz, wantz)
+        assert torch.equal(dg, dg1) and torch.equal(db, db1)
+        # ... and with the generator's mask on top (the operand was dropped by add_layernorm_fwd_dropout)
+        wantd = wantz.clone(); ops.dropout(wantd, 0.2, 77)                       # mask o relu mask, factor 1.25 * 1.25
+        ops.layernorm_bwd_fused(dev(dy), xh, rs, dev(g), rows, C, None, None, False, dev(z), 1.25 * 1.25, gotz, dg, db, ws, 0.2, 77)
+        keep = wantd != 0
+        assert float((gotz - wantd).abs().max()) <= 1e-6 * float(wantd.abs().max())
+        assert torch.equal(gotz == 0, wantd == 0)
+        # forward: add_layernorm(dropout(a), b) in one pass = the two calls, a untouched
+        a_d = dev(a); a_keep = a_d.clone()
+        ops.dropout(a_d, 0.2, 77)
+        y1, xh1, rs1 = torch.zeros(rows, C, device='cuda'), torch.zeros(rows, C, device='cuda'), torch.zeros(rows, device='cuda')
+        ops.add_layernorm_fwd(a_d, dev(b) if with_b else None, dev(g), dev(be), rows, C, 1e-8, y1, xh1, rs1)
+        y2, xh2, rs2 = torch.zeros(rows, C, device='cuda'), torch.zeros(rows, C, device='cuda'), torch.zeros(rows, device='cuda')
+        ops.add_layernorm_fwd_dropout(a_keep, dev(b) if with_b else None, dev(g), dev(be), rows, C, 1e-8, 0.2, 77, y2, xh2, rs2)
+        assert torch.equal(y1, y2) and torch.equal(xh1, xh2) and torch.equal(rs1, rs2)
+        assert torch.equal(a_keep, dev(a))
+        got2b = torch.full((rows, C), 9.0, device='cuda')
+        ops.layernorm_bwd_fused(dev(dy), xh, rs, dev(g), rows, C, None, got2b, False, None, 0.0, None, dg, db, ws)
+        assert torch.equal(got2b, dx1)
 
 
 def test_embedding_fwd_bwd(ops):
