@@ -407,6 +407,9 @@ bool asr_gemm1_eligible(const asr_gemm_desc* d, const float* A, const float* Bt,
     // Small grids too: with one workgroup on a CU the register-staged kernels expose a global-memory round trip per chunk
     // (6400 x 512 x 512, 200 tiles: 102 us = 33 TFLOP/s on tap_gemm_kernel_v1), the DMA of the next chunk hides it.  Only
     // problems of a few dozen tiles keep the 64 x 64 tiles of tap_gemm_kernel_v1 (more workgroups than 128 x 128 tiles give).
+    // (This rule and gemm1_blocks() look at the row count, i.e. at the batch.  What keeps "an utterance gives the same bits alone
+    // and inside a batch" true is that gemm1_kernel with either tile and tap_gemm_kernel_v1 add the K products of an output element
+    // in the same order: tests/test_gemm1_gpu.py::test_the_tile_choice_changes_no_bit holds all three to torch.equal.)
     return (long)asr_cdiv(d->M, 128) * asr_cdiv(d->N, 128) >= 48;
 }
 

@@ -110,12 +110,6 @@ typedef float wn_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
-#ifdef WINO_TRACE
-__device__ long long wino_trace_buf[4 * 8 * 16];          // [item 4][wave 8][stamp 16], workgroup 0 only
-#define WTRACE(k) do { if (blockIdx.x == 0 && titem < 4 && lane == 0) wino_trace_buf[(titem * 8 + wave) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define WTRACE(k) do { } while (0)
-#endif
 // two k-pairs at a time: components (x, y) or (z, w) of the float4s are aligned register pairs, so the 20 adds of a batch
 // become 20 packed adds for TWO batches (v_pk_add_f32) -- on this pipe every vector instruction costs matrix time
 template <int XH>
@@ -364,10 +358,7 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
     int cur = 0;
     wino8_stage(q, bufs, bufs + 2 * RAW_F, 0);
 
-    int titem = -1;
     for (; w < nwork; w += gridDim.x) {
-        ++titem;
-        WTRACE(0);
         const int item = item_of(w);
         const int blk = item / nnb, nb = item - blk * nnb;
         const long t0 = (long)blk * WT;
@@ -421,10 +412,8 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-        WTRACE(1);
         __builtin_amdgcn_s_waitcnt(0x0F70);          // chunk 0 of this item (requested before the previous epilogue) has landed
         __syncthreads();
-        WTRACE(2);
         // the last chunk of an item requests chunk 0 of the NEXT item instead of a next chunk (same places between the MFMAs):
         // after it one set is being filled for the next item, the other is free for the exchange and the epilogue
         const int wnext = w + gridDim.x;
@@ -437,15 +426,11 @@ __device__ __forceinline__ void wino8_body(const WinoArgs& args, float* smem) {
                             last ? wnext < nwork : true, q, last ? 0 : kc + 1, aoff, boff, args.wodd != 0, zero_c3, acc);
             if (!last) { __builtin_amdgcn_s_waitcnt(0x0F70); __syncthreads(); }
             else lds_barrier();
-            if (kc < 5) WTRACE(11 + kc);
             cur ^= 1;
         }
-        WTRACE(3);
         wino_item_tail<XH>(args, acc, bufs + (cur ^ 1) * RAW_F, bufs + 2 * RAW_F + (cur ^ 1) * U_F, rowa, rowy, prow, wave, lane, wm, wn, n0,
                            blk, pool_bs, pool_sc, pool_sh);
-        WTRACE(9);
         lds_barrier();                               // row tables and buffer set `cur ^ 1` are reused by the next item
-        WTRACE(10);
     }
 }
 
@@ -1133,11 +1118,6 @@ __global__ __launch_bounds__(512) void wino8_kernel(WinoArgs args) {
 #ifdef W11_TRACE
 extern "C" int asr_w11_trace_dump(long long* host) {
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(w11_trace_buf), sizeof(long long) * 8 * 8 * 16) == hipSuccess ? 0 : 1;
-}
-#endif
-#ifdef WINO_TRACE
-extern "C" int asr_wino_trace_dump(long long* host) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(wino_trace_buf), sizeof(long long) * 4 * 8 * 16) == hipSuccess ? 0 : 1;
 }
 #endif
 

@@ -321,7 +321,13 @@ class DFCNNEngine:
                 # a deep contraction with few output tiles (6400 -> 128: 200 workgroups of 200 chunk steps) is split eight ways
                 # over the grid (asr_tap_gemm_splitk: 185 -> 124 us with the second pass)
                 # (decided by the layer's widths only, never by the batch: an utterance alone must give bitwise the logits it
-                # gives inside a batch, tests/test_fullsize_gpu.py)
+                # gives inside a batch, tests/test_fullsize_gpu.py.  The invariant behind that test, rule by rule: (1) Winograd vs
+                # direct 3x3 kernels and the Winograd kernel itself: widths and plane geometry only (asr_winograd_supported,
+                # wino11_takes); (2) gemm1_kernel vs tap_gemm_kernel_v1 and gemm1's 128 x 64 / 128 x 128 tile DO look at the row count,
+                # but all three sum an output element's K products in the same order -- bitwise equal on the same rows,
+                # tests/test_gemm1_gpu.py::test_the_tile_choice_changes_no_bit; (3) split-K, here: widths only; (4) the chunk plans
+                # of the weight-gradient kernels depend on batch and CU count, but weight gradients are sums over the batch
+                # anyway and never enter this property)
                 if cout <= 128 and cin >= 2048 and cin % 256 == 0:
                     self.splitk[dst] = 8
                     ws_bytes = max(ws_bytes, ops.tap_gemm_splitk_workspace(self.fdesc[dst], 8))

@@ -236,6 +236,10 @@ class KerasDFCNNEngine:
         ops.colsum(self.loss, B, 1, 1, self.scalars[0:1], self.ws)
 
     def backward(self):
+        if not getattr(self, '_train', True):
+            # an inference forward left the MOVING rstd beside the batch mean of an earlier step in self.stats: the BatchNormalization
+            # backward would mix the two without an error
+            raise RuntimeError('backward() needs a training forward (forward(x, train=True)); the last forward was an inference pass')
         B, T8, V, rows = self.B, self.T8, self.V, self.B * self.T8
         ops.softmax_log_bwd(self.logits, self.ctc_grad, B, T8, V, K_EPSILON, 1.0 / B, self.dd)
         ops.tap_wgrad(self.w2, self.h7, self.dd, V, self.g('d2/w'), self.ws)

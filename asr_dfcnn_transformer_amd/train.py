@@ -60,14 +60,40 @@ def load_checkpoint(model, path):
     parts = _parts(model)
     if ck.get('format') != 2 or set(ck['parts']) != set(parts):
         raise ValueError('checkpoint %s holds parts %s, the model has %s' % (path, sorted(ck.get('parts', {})), sorted(parts)))
+    plans = {}
     for name, e in parts.items():
         st, mine = ck['parts'][name], _state(e)
-        if st['variant'] != mine['variant'] or st['entries'] != mine['entries']:
+        if st['variant'] != mine['variant']:
             raise ValueError('checkpoint %s was written by a different model (%s)' % (path, st['variant']))
+        plans[name] = None if st['entries'] == mine['entries'] else _migration(st['entries'], mine['entries'], path)
     for name, e in parts.items():
         st = ck['parts'][name]
-        e.theta.copy_(st['theta']); e.adam_m.copy_(st['adam_m']); e.adam_v.copy_(st['adam_v'])
+        if plans[name] is None:
+            e.theta.copy_(st['theta']); e.adam_m.copy_(st['adam_m']); e.adam_v.copy_(st['adam_v'])
+        else:
+            for buf, key in ((e.theta, 'theta'), (e.adam_m, 'adam_m'), (e.adam_v, 'adam_v')):
+                host = torch.zeros(buf.numel(), dtype=torch.float32)
+                for dst, src, n, fill in plans[name]:
+                    host[dst:dst + n] = st[key][src:src + n] if src >= 0 else (fill if key == 'theta' else 0.0)
+                buf.copy_(host)
         e.global_step = int(st['global_step'])
+
+
+def _migration(old, new, path):
+    """Copy plan [(dst offset, src offset or -1, floats, fill)] from a checkpoint whose parameter table lacks entries this build
+    added to an existing variant: the Keras DFCNN's BatchNormalization moving statistics ('<layer>/mm', '<layer>/mv', round 3),
+    which start at Keras' initial values (moving_mean 0, moving_variance 1; zero Adam slots -- the optimiser never moves them).
+    Anything else that differs is a different model."""
+    import numpy as np
+    missing = [k for k in new if k not in old]
+    if any(k not in new for k in old) or not all(k.endswith(('/mm', '/mv')) for k in missing) or \
+            any(tuple(old[k][1]) != tuple(new[k][1]) for k in old):
+        raise ValueError('checkpoint %s was written by a different model (parameter tables differ)' % path)
+    plan = []
+    for k, (off, shape) in new.items():
+        n = int(np.prod(shape))
+        plan.append((int(off), int(old[k][0]) if k in old else -1, n, 1.0 if k.endswith('/mv') else 0.0))
+    return plan
 
 
 def rank_batches(batch_nums, world, rank):

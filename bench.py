@@ -103,7 +103,7 @@ def attach_traffic(out, workload, dom, default_config):
         out['roofline']['traffic_unit'] = 'bytes/launch (PMC pass: %s)' % src
 
 
-def cpu_baseline(variant, t_pad, vocab, batch=32, seconds=10.0, budget_s=20.0):
+def cpu_baseline(variant, t_pad, vocab, batch=32, seconds=10.0, budget_s=30.0):
     """CPU restatement ("port": oracle/torch_ref.py on torch-CPU ops + the numpy fbank oracle) of the identical step at the
     SAME batch the GPU number is quoted on, timed on this host's cores on a bounded sample: one untimed warm-up
     step, then timed steps until `budget_s` is used up (at least one).  Stand-in for the reference's TF-CPU path, which

@@ -74,6 +74,41 @@ def test_data_gradient_routes_to_the_dma_kernel(ops, M, Kout, N):
     assert np.abs(dx.cpu().numpy().astype(np.float64) - ref).max() < 1e-5 * max(1.0, np.abs(ref).max())
 
 
+def test_the_tile_choice_changes_no_bit(ops):
+    """gemm1_blocks() picks the 128 x 64 or the 128 x 128 tile from the grid, i.e. from the row count as well: the same rows must
+    give the same bits in a 6144-row problem (128 x 64 tile) and in an 8192-row one (128 x 128) -- an utterance alone or inside
+    a batch (the invariant engine.py states for its routing rules)."""
+    g = torch.Generator(device='cuda').manual_seed(21)
+    K, N = 512, 1024
+    a = _rand((8192, K), g)
+    w = _rand((K, N), g, (1.0 / K) ** 0.5)
+    wt = w.t().contiguous()
+    bias = _rand((N,), g, 0.1)
+    ys = []
+    for M, kern in ((8192, 'gemm1_kernel<0, 2>'), (6144, 'gemm1_kernel<0, 1>')):
+        y = torch.zeros(M, N, device='cuda')
+        ops.tap_gemm_nt(ops.gemm_desc(M, K, N, K, N, 0, N, ntaps=1, relu=1), a[:M], w, wt, K, bias, None, None, None, y)
+        assert ops.last_kernel() == kern, ops.last_kernel()
+        ys.append(y)
+    assert torch.equal(ys[0][:6144], ys[1])
+    # ... and in a problem small enough for the register-staged kernel (gemm1 needs >= 48 tiles of 128 x 128): both kernels sum
+    # the K products of an output element in the same order
+    y = torch.zeros(640, N, device='cuda')
+    ops.tap_gemm_nt(ops.gemm_desc(640, K, N, K, N, 0, N, ntaps=1, relu=1), a[:640], w, wt, K, bias, None, None, None, y)
+    assert ops.last_kernel().startswith('tap_gemm_kernel_v1'), ops.last_kernel()
+    assert torch.equal(ys[0][:640], y)
+    # data-gradient form
+    dy = _rand((8192, N), g)
+    dxs = []
+    for M, kern in ((8192, 'gemm1_kernel<1, 2>'), (6144, 'gemm1_kernel<1, 1>')):
+        dx = torch.zeros(M, 1024, device='cuda')
+        wk = _rand((1024, N), torch.Generator(device='cuda').manual_seed(22), 0.03)
+        ops.tap_gemm(ops.gemm_desc(M, N, 1024, N, N, 0, 1024, ntaps=1, wmode=1), dy[:M], wk, None, None, None, None, dx)
+        assert ops.last_kernel() == kern, ops.last_kernel()
+        dxs.append(dx)
+    assert torch.equal(dxs[0][:6144], dxs[1])
+
+
 def test_column_blocks_of_wider_matrices(ops):
     """[dK | dV] . [wk | wv]^T of an encoder-decoder attention block (transformer_engine._mha_bwd): the activations are a
     2C-wide column block of a [rows][3C] buffer... here: A = columns C.. of a [M][3C] matrix (pitch 3C), W = columns C.. of the

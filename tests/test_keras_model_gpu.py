@@ -128,6 +128,60 @@ def test_moving_statistics_and_predict_match_oracle(tmp_path):
     assert list(m2.predict(feat, length)) == list(m.predict(feat, length))
 
 
+def test_old_checkpoints_load_and_backward_refuses_an_inference_forward(tmp_path):
+    """A Keras-DFCNN checkpoint written before the moving statistics joined the parameter table ('<layer>/mm', '/mv') still
+    loads: they start at Keras' initial values.  And backward() after forward(train=False) raises instead of mixing the moving
+    rstd with an old batch mean."""
+    from asr_dfcnn_transformer_amd.keras_engine import KerasDFCNNEngine
+    from asr_dfcnn_transformer_amd.train import save_checkpoint, load_checkpoint, _state
+    F, V, hidden, B, T = 16, 12, 16, 2, 32
+    cells = [(8, True), (16, True), (32, True), (32, False), (32, False)]
+    mk = lambda: KerasDFCNNEngine(vocab=V, B=B, T=T, F=F, cells=cells, hidden=hidden, dropout_rate=0.0, drop_seed=5)
+    a = mk()
+    a.load_params({k: np.asarray(v, np.float32) for k, v in ok.init_params(V, F, cells, hidden, seed=4).items()})
+    a.adam_m.normal_(); a.adam_v.uniform_(); a.global_step = 7
+    st = _state(a)
+    # rewrite the state as the older build laid it out: the same entries without the moving statistics, packed in order
+    old_entries, chunks, off = {}, {k: [] for k in ('theta', 'adam_m', 'adam_v')}, 0
+    for name, (o, shape) in st['entries'].items():
+        if name.endswith(('/mm', '/mv')):
+            continue
+        n = (int(np.prod(shape)) + 3) // 4 * 4
+        old_entries[name] = (off, shape)
+        for k in chunks:
+            chunks[k].append(st[k][o:o + n])
+        off += n
+    old = dict(st, entries=old_entries, **{k: torch.cat(v) for k, v in chunks.items()})
+    torch.save({'format': 2, 'parts': {'': old}}, str(tmp_path / 'old.pt'))
+    b = mk()
+    load_checkpoint(b, str(tmp_path / 'old.pt'))
+    pa, pb = a.params_dict(), b.params_dict()
+    for k in pa:
+        if k.endswith('/mm'):
+            assert np.all(pb[k] == 0.0)
+        elif k.endswith('/mv'):
+            assert np.all(pb[k] == 1.0)
+        else:
+            assert np.array_equal(pa[k], pb[k]), k
+    assert b.global_step == 7
+    ga, gb = a.grads_dict(a.adam_v), b.grads_dict(b.adam_v)
+    assert all(np.array_equal(ga[k], gb[k]) for k in ga if not k.endswith(('/mm', '/mv')))
+    assert all(np.all(gb[k] == 0.0) for k in gb if k.endswith(('/mm', '/mv')))
+    # a checkpoint that lacks anything else is still another model
+    bad = dict(old, entries={k: v for k, v in old_entries.items() if k != 'd2/b'})
+    torch.save({'format': 2, 'parts': {'': bad}}, str(tmp_path / 'bad.pt'))
+    with pytest.raises(ValueError):
+        load_checkpoint(mk(), str(tmp_path / 'bad.pt'))
+    # current-format round trip is untouched
+    save_checkpoint(a, str(tmp_path / 'new.pt'))
+    c = mk(); load_checkpoint(c, str(tmp_path / 'new.pt'))
+    assert torch.equal(a.theta, c.theta)
+    x = torch.randn(B, T, F, device='cuda')
+    b.forward(x, train=False)
+    with pytest.raises(RuntimeError):
+        b.backward()
+
+
 def test_decode_ctc_is_greedy_ctc_decode_of_one_utterance():
     """util/utils.py:57-66 on a hand-made softmax output: repeats merge, blanks split, ties go to the lowest index, frames past
     input_length are ignored."""

@@ -33,15 +33,6 @@ for name, H, W, cin, cout in SHAPES:
     dw0, dw1 = torch.zeros(9 * cin * cout, device='cuda'), torch.zeros(9 * cin * cout, device='cuda')
     t0 = timeit(lambda: ops.tap_wgrad(d, x, dz, cout, dw0, ws, direct=True))
     t1 = timeit(lambda: ops.tap_wgrad(d, x, dz, cout, dw1, ws))
-    if os.environ.get('WWGEN'):                  # development: time another kernel generation too (asr_debug_ww_gen)
-        import ctypes
-        from asr_dfcnn_transformer_amd import _lib
-        fn = _lib.load().asr_debug_ww_gen; fn.argtypes = [ctypes.c_int]; fn.restype = None
-        fn(int(os.environ['WWGEN']))
-        dw2 = torch.zeros_like(dw1)
-        t2 = timeit(lambda: ops.tap_wgrad(d, x, dz, cout, dw2, ws))
-        print('    gen %s: %7.1f us (%s), max|diff| to the default / max %.2e' % (os.environ['WWGEN'], 1e3 * t2, ops.last_kernel(), (dw2 - dw1).abs().max().item() / dw1.abs().max().item()))
-        fn(4)
     fl = 2.0 * B * H * W * 9 * cin * cout
     err = (dw0 - dw1).abs().max().item() / dw0.abs().max().item()
     print('%-22s wgrad direct %7.1f us %6.1f TF | winograd %7.1f us %6.1f TF-equivalent (x%.2f) | max|diff| / max %.2e'
