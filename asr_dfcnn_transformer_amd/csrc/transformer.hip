@@ -268,20 +268,25 @@ __global__ __launch_bounds__(256) void embed_bwd_ids_kernel(const float* __restr
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     bool any = false;
-    for (int p0 = 0; p0 < rows; p0 += 64) {
-        const int p = p0 + lane;
-        unsigned long long m = __ballot(p < rows && ids[p] == v);
-        any |= m != 0;
-        while (m) {
-            const int j = __builtin_ctzll(m);
-            m &= m - 1;
-            const float* src = dout + (long)(p0 + j) * C;
+    for (int p0 = 0; p0 < rows; p0 += 256) {              // four independent id loads in flight: the scan is load-latency bound
+        int idv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int q = lane + i * 64;
-                if (q < n4) {
-                    const float4 t = *(const float4*)(src + q * 4);
-                    acc[i].x += t.x; acc[i].y += t.y; acc[i].z += t.z; acc[i].w += t.w;
+        for (int u = 0; u < 4; ++u) { const int p = p0 + u * 64 + lane; idv[u] = p < rows ? ids[p] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            unsigned long long m = __ballot(idv[u] == v);
+            any |= m != 0;
+            while (m) {
+                const int j = __builtin_ctzll(m);
+                m &= m - 1;
+                const float* src = dout + (long)(p0 + u * 64 + j) * C;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int q = lane + i * 64;
+                    if (q < n4) {
+                        const float4 t = *(const float4*)(src + q * 4);
+                        acc[i].x += t.x; acc[i].y += t.y; acc[i].z += t.z; acc[i].w += t.w;
+                    }
                 }
             }
         }

@@ -22,8 +22,8 @@ SMOOTH_EPS = 0.1
 
 
 def sorted_segments(ids):
-    """Positions sorted by id (stable) + segment table: the inputs of asr_embed_bwd (the engines use asr_embed_bwd_ids, which
-    needs neither; kept for callers that hold a sorted index already, and for the test that the two forms give the same bits)."""
+    """Positions sorted by id (stable) + segment table: the inputs of asr_embed_bwd (_Base._embed_bwd says when the engines use it
+    and when asr_embed_bwd_ids, which needs neither)."""
     flat = np.asarray(ids).reshape(-1)
     perm = np.argsort(flat, kind='stable').astype(np.int32)
     sv = flat[perm]
@@ -150,6 +150,21 @@ class _Base:
     # ---- low-level helpers
     def _t(self, *shape, dtype=torch.float32):
         return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def _embed_bwd(self, dout, ids_dev, ids_host, rows, V, zero_pad, scale, dtable):
+        """Gradient of an embedding table.  Small tables x few positions (the language model: 1536 x 6400) straight from the ids
+        on the device (asr_embed_bwd_ids: a wave per table row scans the ids -- V * rows / 64 wave iterations, ~10 us there, no
+        host work); the large ones (6348 x 32768: 200 us of scanning) keep the host-side stable sort + asr_embed_bwd, whose
+        uploads ride a GPU-bound step.  Both give the same bits."""
+        C = self.C
+        if V * rows <= (1 << 25):
+            ops.embed_bwd_ids(dout, ids_dev, rows, V, C, zero_pad, scale, dtable)
+            return
+        perm, uniq, seg = sorted_segments(ids_host)
+        if not hasattr(self, '_seg') or self._seg[0].numel() < rows:
+            self._seg = [self._t(rows, dtype=torch.int32), self._t(rows, dtype=torch.int32), self._t(rows + 1, dtype=torch.int32)]
+        self._upload('seg0', self._seg[0], perm); self._upload('seg1', self._seg[1], uniq); self._upload('seg2', self._seg[2], seg)
+        ops.embed_bwd(dout, self._seg[0], self._seg[1], self._seg[2], len(uniq), C, zero_pad, scale, dtable)
 
     def _upload(self, key, dst, arr):
         """dst[:len] <- int32 host array through a PINNED staging buffer owned by the engine (two per site, alternating, each
@@ -525,8 +540,7 @@ class LMEngine(_Base):
             cur, nxt = nxt, cur
         if self._rate > 0:
             ops.dropout(cur, self._rate, self._seed_emb)
-        # (the ids are still on the device from the forward pass: no host-side sort, nothing to upload)
-        ops.embed_bwd_ids(cur, self.ids, rows, self.vin, C, True, float(C) ** 0.5, self.g('emb'))
+        self._embed_bwd(cur, self.ids, self._x_host, rows, self.vin, True, float(C) ** 0.5, self.g('emb'))
         ops.colsum(cur, N, T * C, T * C, self.g('pos')[:T * C], self.ws)
 
 
@@ -637,7 +651,7 @@ class E2EEngine(_Base):
             self._mha_bwd('dec%d' % i, self.dec[i], cur, nxt, False, self.dmem, not first)
             first = False
             cur, nxt = nxt, cur
-        ops.embed_bwd_ids(cur, self.y_ids, rd, self.logical['dec_input'][0], C, False, 1.0, self.g('dec_input'))
+        self._embed_bwd(cur, self.y_ids, self._y_host, rd, self.logical['dec_input'][0], False, 1.0, self.g('dec_input'))
         ops.colsum(cur, N, L * C, L * C, self.g('dec_pe')[:L * C], self.ws)
         e0, e1 = self.dstream[0][:re * C], self.dstream[1][:re * C]
         self._ffn_bwd('enc_ffn', self.enc_ffn, self.dmem, e0, False)
@@ -658,4 +672,4 @@ class E2EEngine(_Base):
             if self.need_dx:
                 self._dense_dgrad(du, re, self.din, C, self.p('in_w'), self.dx_feat, False)
         else:
-            ops.embed_bwd_ids(cur, self.x_ids, re, self.vin, C, True, float(C) ** 0.5, self.g('enc_emb'))
+            self._embed_bwd(cur, self.x_ids, self._x_host, re, self.vin, True, float(C) ** 0.5, self.g('enc_emb'))

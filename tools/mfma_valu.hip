@@ -125,6 +125,40 @@ __global__ __launch_bounds__(512) void wino_pattern(float* out, int iters, float
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
+// Round 4: the same question for a wave that owns ONE ROW of the transform.  wino11_kernel: NM = 16 MFMAs on 4 accumulators, 16
+// v_pk_add_f32, four waves per SIMD (1024 threads).  A would-be F(4x4,3x3) kernel: NM = 24 MFMAs on 6 accumulators, ~72 v_pk_fma_f32
+// (B^T of F(4x4) has the constants 4, 5, 2: multiply-adds, not adds), three waves per SIMD (768 threads, 96 accumulator registers).
+template <int NP, int NM, int NACC, int THREADS, bool FMA>
+__global__ __launch_bounds__(THREADS) void row_pattern(float* out, int iters, float a0, float b0) {
+    floatx16 acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    const float a = a0 + threadIdx.x * 1e-6f, b = b0;
+    f2 v[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) v[i] = f2{a + i, a - i};
+    const f2 inc = f2{b, -b};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (FMA) v[i % 12] = __builtin_elementwise_fma(v[(i + 5) % 12], inc, v[i % 12]);
+            else v[i % 12] = v[i % 12] + (i % 3 == 0 ? inc : v[(i + 5) % 12]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NM; ++i) acc[i % NACC] = __builtin_amdgcn_mfma_f32_32x32x2f32((i & 8) ? v[i % 12].y : v[i % 12].x, b, acc[i % NACC], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][15];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s += v[i].x + v[i].y;
+    out[blockIdx.x * THREADS + threadIdx.x] = s;
+}
+
 template <typename F>
 float timeit(F launch) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -167,8 +201,25 @@ float run_wino(float* out, int iters, float t0) {
     return t;
 }
 
+template <int NP, int NM, int NACC, int THREADS, bool FMA>
+float run_row(float* out, int iters, float t0, const char* what) {
+    const float t = timeit([&] { hipLaunchKernelGGL((row_pattern<NP, NM, NACC, THREADS, FMA>), dim3(256), dim3(THREADS), 0, 0, out, iters, 1.0f, 0.5f); });
+    printf("%s, %d waves/SIMD: %2d %s + %d MFMA per iteration: %.3f ms;  time(0)/time(NP) = %.3f\n", what, THREADS / 256, NP,
+           FMA ? "v_pk_fma_f32" : "v_pk_add_f32", NM, t, t0 > 0 ? t0 / t : 1.0);
+    return t;
+}
+
 int main(int argc, char** argv) {
-    float* out; hipMalloc(&out, 512 * 512 * sizeof(float));
+    float* out; hipMalloc(&out, 1024 * 1024 * sizeof(float));
+    if (argc > 1 && argv[1][0] == 'r') {
+        const int it = 30000;
+        float t0 = run_row<0, 16, 4, 1024, false>(out, it, 0.f, "wino11 row pattern");
+        run_row<16, 16, 4, 1024, false>(out, it, t0, "wino11 row pattern"); run_row<24, 16, 4, 1024, false>(out, it, t0, "wino11 row pattern");
+        t0 = run_row<0, 24, 6, 768, true>(out, it, 0.f, "F(4x4) row pattern");
+        run_row<48, 24, 6, 768, true>(out, it, t0, "F(4x4) row pattern"); run_row<72, 24, 6, 768, true>(out, it, t0, "F(4x4) row pattern");
+        run_row<96, 24, 6, 768, true>(out, it, t0, "F(4x4) row pattern");
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 'w') {
         const int it = 50000;
         const float t0 = run_wino<0>(out, it, 0.f);
