@@ -547,8 +547,12 @@ extern "C" int asr_add_layernorm_fwd_dropout(const float* a, const float* b, con
     return add_ln_launch(a, b, gamma, beta, rows, C, eps, y, xhat, rstd, thr, (uint32_t)seed, thr ? 1.0f / (1.0f - rate) : 1.f, (hipStream_t)stream);
 }
 
+// Callers size ONE workspace for their largest row count and use it for smaller problems too, so the size must not shrink
+// where the rows-per-block rule switches (a 32767-row problem has four times the blocks of a 32768-row one): the result covers
+// every row count <= rows.
 extern "C" size_t asr_layernorm_bwd_workspace(int rows, int C) {
-    const size_t nblk = (size_t)asr_cdiv(rows, ln_rows_per_block(rows));
+    size_t nblk = (size_t)asr_cdiv(rows, ln_rows_per_block(rows));
+    if (rows >= 64 * 512) { const size_t below = (size_t)asr_cdiv(64 * 512 - 1, ln_rows_per_block(64 * 512 - 1)); if (below > nblk) nblk = below; }
     return (nblk * 2 * C + asr_reduce::colsum_tmp_floats((int)nblk, 2 * C) + 16) * sizeof(float);
 }
 

@@ -129,3 +129,13 @@ def test_winograd_predicate_odd_heights_and_the_2_gib_bound():
         TH, TW = (H + 1) // 2, (W + 1) // 2
         blocks = B * -(-TH * TW // 64)
         assert lib.asr_tap_gemm_gated_workspace(C.byref(d)) >= 4 * blocks * 3 * 64 * 4
+
+
+def test_layernorm_backward_workspace_covers_every_smaller_row_count():
+    """The engines size ONE workspace for their largest row count and reuse it for smaller problems; the rows-per-block rule of
+    asr_layernorm_bwd switches at 32768 rows (16 rows per block below: more blocks), so the size must never shrink as rows grow."""
+    from asr_dfcnn_transformer_amd import _lib
+    lib = _lib.load()
+    sizes = [lib.asr_layernorm_bwd_workspace(r, 512) for r in (1, 100, 6400, 20000, 32767, 32768, 40000, 65536, 200000)]
+    assert all(a <= b for a, b in zip(sizes, sizes[1:])), sizes
+    assert sizes[4] >= 2048 * 2 * 512 * 4                     # 32767 rows = 2048 blocks of [2][512] partials
