@@ -36,6 +36,10 @@ SIGNATURES = {
     'asr_arrange_weights': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'asr_tap_gemm_pw': (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_gemm_gated_workspace': (_Z, [C.POINTER(GemmDesc)]),
+    'asr_poolmax_index_bytes': (_Z, [_I, _I, _I, _I]),
+    'asr_winograd_poolmax_supported': (_I, [_P, _P]),
+    'asr_tap_gemm_wino_poolmax': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'asr_tap_gemm_gated_poolmax': (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_gemm_gated': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_wgrad_workspace': (_Z, [C.POINTER(GemmDesc)]),
     'asr_tap_wgrad': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _P, _P, _P]),

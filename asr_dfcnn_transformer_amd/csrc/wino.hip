@@ -38,6 +38,11 @@ struct WinoArgs {
     int wodd;               // plane width is odd
     float* pool_y;          // eight-wave kernel: pooled BN output plane [B][H/2+1][W/2+1][N] of a fused 2x2 pool, or null
     int pool_mode, H2, W2;  // 1 average, 2 maximum
+    // compact maximum pool (wino11_kernel): instead of the pre-pool activation plane, the activation AT the maximum of each window
+    // (pooled geometry) and the window position of that maximum, two bit planes of 32 channels per pooled pixel:
+    // idx[(pixel * (N / 32) + channel block) * 2 + bit] -- all the maximum-pool backward needs (asr_tap_gemm_gated_poolmax)
+    float* pool_amax;
+    unsigned* pool_idx;     // forward: written; gated launch of mode 4: read (g.gate_a = the amax plane)
     // column-blocked tile order (wino11_kernel): the tile columns of an image are cut into ncb blocks of 11..15 columns; the tiles
     // of a block are numbered row-major WITHIN the block and a work item is 64 consecutive tiles of one block
     int ncb;                // number of column blocks (0: plain order, wino8_kernel)
@@ -509,7 +514,7 @@ constexpr int W11_RAW0 = 2 * W11_TABF * 4;      // byte offsets of the four sets
 constexpr int W11_U0 = W11_RAW0 + 2 * W11_SETF * 4;
 // epilogue instantiations (see wino11_body)
 constexpr int W11_EPI_GENERIC = 0, W11_EPI_FWD = 1, W11_EPI_POOLMAX = 2, W11_EPI_POOLAVG = 3, W11_EPI_DGRAD = 4, W11_EPI_DGRAD_ACC = 5,
-              W11_EPI_GATE1 = 6, W11_EPI_GATE2 = 7, W11_EPI_GATE3 = 8;
+              W11_EPI_GATE1 = 6, W11_EPI_GATE2 = 7, W11_EPI_GATE3 = 8, W11_EPI_POOLMAXC = 9, W11_EPI_GATE4 = 10;
 
 #if __HIP_DEVICE_COMPILE__
 typedef const __attribute__((address_space(4))) WinoArgs* wino_kernarg_p;
@@ -758,15 +763,19 @@ __device__ __forceinline__ void wino11_epilogue_plain(R rA, R rY, unsigned pa, u
 // pixel pair requested before its arithmetic (the shared form waits for four dependent round trips per block) and the full-resolution
 // row of window position 0 taken from the row table (rowf = rowy: wino11_tables writes it for the gated launches, no divisions here).
 // rGA / rGD: gate activations and dZ (C channels per pixel), rY: dL/dy of the cell in front (accumulate), py its row bytes.
+// GM 4 = the maximum pool in its compact form (asr_tap_gemm_gated_poolmax): rGA is the plane of the activations AT the window maxima
+// (pooled geometry = this launch's output pixels), rGI the two bit planes with the position of each maximum; one float4 + 8 bytes per
+// pixel and channel quad instead of four float4.  Every sum receives the terms GM 3 gives it, in the same order (the three positions
+// that are not the maximum contribute exact zeros there too): the same bits.
 template <int GM, class R>
-__device__ __forceinline__ void wino11_epilogue_gated(R rGA, R rGD, R rY, bool accumulate, unsigned py, unsigned c4b, unsigned wpf4, float* gate_part, int C,
+__device__ __forceinline__ void wino11_epilogue_gated(R rGA, R rGD, R rY, R rGI, bool accumulate, unsigned py, unsigned c4b, unsigned wpf4, float* gate_part, int C,
                                                       const floatx16& blk, float* scratch, const int* rowa, const int* rowf,
                                                       int n, unsigned n4, const float4& sc, const float4& sh, int lane, int part_row) {
     const int c4 = lane & 7, rsub = lane >> 3;
     wino11_transpose(blk, scratch, lane);
     float s_scale[4] = {0.f, 0.f, 0.f, 0.f}, s_shift[4] = {0.f, 0.f, 0.f, 0.f}, s_bias[4] = {0.f, 0.f, 0.f, 0.f};
     const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-    constexpr int NK = GM == 1 ? 1 : 4;
+    constexpr int NK = (GM == 1 || GM == 4) ? 1 : 4;
     // One pixel per trip of a ROLLED loop: unrolled, hipcc interleaves the four pixels (and vectorises across them), holds 100 values
     // more than the 128-register budget has and parks them in scratch -- whose reloads wait for every store in flight.  The other
     // three waves of the SIMD cover the round trip of a pixel's loads.
@@ -777,12 +786,20 @@ __device__ __forceinline__ void wino11_epilogue_gated(R rGA, R rGD, R rY, bool a
         const bool ok = ra >= 0 && n4 != W11_OOR;
         const unsigned pf = GM == 1 ? (unsigned)ra : (unsigned)rowf[row];
         const unsigned o0 = ok ? __umul24(pf, c4b) + n4 : W11_OOR;          // c4b: bytes of a gate pixel (4 C)
-        unsigned off[NK];
+        unsigned off[GM == 1 ? 1 : 4];
         off[0] = o0;
         if (GM != 1) { off[1] = ok ? o0 + c4b : W11_OOR; off[2] = ok ? o0 + wpf4 : W11_OOR; off[3] = ok ? o0 + wpf4 + c4b : W11_OOR; }
         float4 a4[NK];
+        unsigned iw0 = 0, iw1 = 0;
+        if (GM == 4) {
+            a4[0] = w11_load4(rGA, ok ? __umul24((unsigned)ra, c4b) + n4 : W11_OOR);
+            const unsigned io = ok ? __umul24((unsigned)ra, (unsigned)(C >> 5) * 8u) + (unsigned)(n >> 5) * 8u : W11_OOR;
+            iw0 = __builtin_amdgcn_raw_buffer_load_b32(rGI, io, 0, 0);
+            iw1 = __builtin_amdgcn_raw_buffer_load_b32(rGI, io == W11_OOR ? W11_OOR : io + 4u, 0, 0);
+        } else {
 #pragma unroll
-        for (int k = 0; k < NK; ++k) a4[k] = w11_load4(rGA, off[k]);
+            for (int k = 0; k < NK; ++k) a4[k] = w11_load4(rGA, off[k]);
+        }
         const float4 prev = accumulate ? w11_load4(rY, ok ? __umul24((unsigned)ra, py) + n4 : W11_OOR) : make_float4(0.f, 0.f, 0.f, 0.f);
         const float* sp = scratch + row * 33 + c4 * 4;
         // a row outside the plane: its activations read as zeros and its value is dropped (v = 0: no contribution to the sums)
@@ -801,6 +818,23 @@ __device__ __forceinline__ void wino11_epilogue_gated(R rGA, R rGD, R rY, bool a
                 s_bias[e] += d[e];
             }
             w11_store4_nt(rGD, off[0], d[0], d[1], d[2], d[3]);
+        } else if (GM == 4) {
+            const int cb = n & 31;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ag = (int)((iw0 >> (cb + e)) & 1u) | (int)(((iw1 >> (cb + e)) & 1u) << 1);
+                    const bool here = ag == k;
+                    const float gk = here ? v[e] : 0.f;
+                    s_shift[e] += gk;
+                    s_scale[e] = fmaf(gk, here ? av[0][e] : 0.f, s_scale[e]);
+                    d[e] = (here && av[0][e] > 0.f) ? gk * scv[e] : 0.f;
+                    s_bias[e] += d[e];
+                }
+                w11_store4_nt(rGD, off[k], d[0], d[1], d[2], d[3]);
+            }
         } else {
             int arg[4];
             if (GM == 3) {
@@ -850,7 +884,8 @@ __device__ __forceinline__ void wino11_epilogue_gated(R rGA, R rGD, R rY, bool a
 
 template <int EPI>
 __device__ __forceinline__ void wino11_body(float* smem) {
-    constexpr bool GATED = EPI >= W11_EPI_GATE1, POOLED = EPI == W11_EPI_POOLMAX || EPI == W11_EPI_POOLAVG;
+    constexpr bool GATED = (EPI >= W11_EPI_GATE1 && EPI <= W11_EPI_GATE3) || EPI == W11_EPI_GATE4;
+    constexpr bool POOLED = EPI == W11_EPI_POOLMAX || EPI == W11_EPI_POOLAVG || EPI == W11_EPI_POOLMAXC;
     const char* lds = (const char*)smem;
     int* tables = (int*)smem;                        // two sets of [rowa 256 | rowy 256 | prow 256]
     float* bufs = smem + 2 * W11_TABF;               // raw0 | raw1 | u0 | u1
@@ -1065,17 +1100,49 @@ __device__ __forceinline__ void wino11_body(float* smem) {
                     const int pr = prow[wave * 32 + i + 4 * lh];
                     po[i] = (pr >= 0 && pcol) ? __umul24((unsigned)pr, (unsigned)N * 4u) + (unsigned)pool_n * 4u : W11_OOR;
                 }
+                if (EPI == W11_EPI_POOLMAXC) {
+                    // Compact form: the pre-pool activation plane is not written at all.  Per window: the pooled value, the activation
+                    // AT the first maximum (row-major window order, asr_cell_bwd_pre's rule) and its position -- two ballots per tile
+                    // slot give the bit planes of 32 channels x 2 tiles, stored by lane 0 of each half-wave.
+                    auto rPA = __builtin_amdgcn_make_buffer_rsrc((void*)args.pool_amax, 0, 0xFFFFFFF0, 0x00020000);
+                    auto rPI = __builtin_amdgcn_make_buffer_rsrc((void*)args.pool_idx, 0, 0xFFFFFFF0, 0x00020000);
+                    const unsigned nb8 = (unsigned)(N >> 5) * 8u, cb8 = (unsigned)(n0 >> 5) * 8u;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float vv[4];
+                    for (int i = 0; i < 4; ++i) {
+                        // (scalars and selects on purpose: written with arrays, hipcc turns "the activation at the arg-max" into an indexed
+                        //  load from a private array in scratch -- a store and a dependent load per window, behind every store in flight)
+                        const float x0 = fmaxf(out[0][0][i] + bs, 0.f), x1 = fmaxf(out[0][0][4 + i] + bs, 0.f);
+                        const float x2 = fmaxf(out[0][0][8 + i] + bs, 0.f), x3 = fmaxf(out[0][0][12 + i] + bs, 0.f);
+                        const float v0 = fmaf(scv, x0, shv), v1 = fmaf(scv, x1, shv), v2 = fmaf(scv, x2, shv), v3 = fmaf(scv, x3, shv);
+                        float m = v0, am = x0; int ag = 0;
+                        const bool c1 = v1 > m; m = c1 ? v1 : m; am = c1 ? x1 : am; ag = c1 ? 1 : ag;
+                        asm volatile("" : "+v"(am), "+v"(ag));
+                        const bool c2 = v2 > m; m = c2 ? v2 : m; am = c2 ? x2 : am; ag = c2 ? 2 : ag;
+                        asm volatile("" : "+v"(am), "+v"(ag));
+                        const bool c3 = v3 > m; m = c3 ? v3 : m; am = c3 ? x3 : am; ag = c3 ? 3 : ag;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rP, po[i], 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(am), rPA, po[i], 0, 2);
+                        const unsigned long long b0 = __ballot(ag & 1), b1 = __ballot(ag >> 1);
+                        const unsigned w0 = lh ? (unsigned)(b0 >> 32) : (unsigned)b0, w1 = lh ? (unsigned)(b1 >> 32) : (unsigned)b1;
+                        const int pr = prow[wave * 32 + i + 4 * lh];
+                        const unsigned io = (pr >= 0 && li == 0) ? __umul24((unsigned)pr, nb8) + cb8 : W11_OOR;
+                        __builtin_amdgcn_raw_buffer_store_b32(w0, rPI, io, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(w1, rPI, io == W11_OOR ? W11_OOR : io + 4u, 0, 0);
+                    }
+                } else {
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) vv[p] = fmaf(scv, fmaxf(out[0][0][4 * p + i] + bs, 0.f), shv);
-                    const float pv = EPI == W11_EPI_POOLAVG ? 0.25f * ((vv[0] + vv[1]) + (vv[2] + vv[3])) : fmaxf(fmaxf(vv[0], vv[1]), fmaxf(vv[2], vv[3]));
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pv), rP, po[i], 0, 2);
+                    for (int i = 0; i < 4; ++i) {
+                        float vv[4];
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) vv[p] = fmaf(scv, fmaxf(out[0][0][4 * p + i] + bs, 0.f), shv);
+                        const float pv = EPI == W11_EPI_POOLAVG ? 0.25f * ((vv[0] + vv[1]) + (vv[2] + vv[3])) : fmaxf(fmaxf(vv[0], vv[1]), fmaxf(vv[2], vv[3]));
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pv), rP, po[i], 0, 2);
+                    }
                 }
             }
             W11T(7);
             if (EPI == W11_EPI_FWD) wino11_epilogue_plain<true, true, true, false>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
+            else if (EPI == W11_EPI_POOLMAXC) { }            // nothing else to store: no activation plane in the compact form
             else if (POOLED) wino11_epilogue_plain<true, true, false, false>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
             else if (EPI == W11_EPI_DGRAD) wino11_epilogue_plain<false, false, true, false>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
             else if (EPI == W11_EPI_DGRAD_ACC) wino11_epilogue_plain<false, false, true, true>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
@@ -1085,8 +1152,9 @@ __device__ __forceinline__ void wino11_body(float* smem) {
                 const unsigned c4b = (unsigned)N * 4u, wpf4 = (unsigned)(g.gate_W + 1) * c4b;
                 const bool accu = g.accumulate != 0;
                 float* gpart = g.gate_part;
-                constexpr int GM = EPI == W11_EPI_GATE1 ? 1 : EPI == W11_EPI_GATE2 ? 2 : 3;
-                wino11_epilogue_gated<GM>(rGA, rGD, rY, accu, py, c4b, wpf4, gpart, N, out[0][0], scratch, ra_w, ry_w, ne, n4, csc, csh, lane, blk * 8 + wave);
+                constexpr int GM = EPI == W11_EPI_GATE1 ? 1 : EPI == W11_EPI_GATE2 ? 2 : EPI == W11_EPI_GATE3 ? 3 : 4;
+                auto rGI = __builtin_amdgcn_make_buffer_rsrc((void*)args.pool_idx, 0, 0xFFFFFFF0, 0x00020000);
+                wino11_epilogue_gated<GM>(rGA, rGD, rY, rGI, accu, py, c4b, wpf4, gpart, N, out[0][0], scratch, ra_w, ry_w, ne, n4, csc, csh, lane, blk * 8 + wave);
             }
         }
         W11T(8);
@@ -1194,8 +1262,9 @@ static int wino_tile_blocks(const asr_gemm_desc* d) {
 extern "C" int asr_winograd_gate_rows(const asr_gemm_desc* d) { return asr_winograd_supported(d) ? 8 * wino_tile_blocks(d) : 0; }      // wino11_kernel: one per wave
 
 static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale, const float* shift,
-                     float* out_a, float* out_y, void* stream, const WinoGate* gs, float* pool_y = nullptr, int pool_mode = 0) {
-    if (!d || !A || !Ut || (!out_a && !out_y && !gs)) return ASR_ERR_BAD_ARG;
+                     float* out_a, float* out_y, void* stream, const WinoGate* gs, float* pool_y = nullptr, int pool_mode = 0,
+                     float* pool_amax = nullptr, unsigned* pool_idx = nullptr) {
+    if (!d || !A || !Ut || (!out_a && !out_y && !gs && !pool_amax)) return ASR_ERR_BAD_ARG;
     if (!asr_winograd_supported(d)) return ASR_ERR_UNSUPPORTED;
     if ((((uintptr_t)A) | ((uintptr_t)Ut)) & 15) return ASR_ERR_BAD_ARG;
     WinoArgs w;
@@ -1216,6 +1285,8 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     w.ntiles = (long)d->B * w.TH * w.TW;
     w.wodd = d->W & 1;
     w.pool_y = pool_y; w.pool_mode = pool_mode; w.H2 = d->H / 2; w.W2 = d->W / 2;
+    w.pool_amax = pool_amax; w.pool_idx = pool_idx;
+    const bool compact = pool_amax != nullptr || (gs && gs->mode == 4);
     static int ncu8 = 0;
     if (!ncu8) {
         int dev = 0; hipDeviceProp_t pr;
@@ -1241,26 +1312,28 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
         // the epilogue instantiation (wino11_body): decided by the descriptor
         int epi = W11_EPI_GENERIC;
         const bool aff = scale && shift;
-        if (gs) epi = gs->mode == 1 ? W11_EPI_GATE1 : gs->mode == 2 ? W11_EPI_GATE2 : W11_EPI_GATE3;
+        if (gs) epi = gs->mode == 1 ? W11_EPI_GATE1 : gs->mode == 2 ? W11_EPI_GATE2 : gs->mode == 3 ? W11_EPI_GATE3 : W11_EPI_GATE4;
+        else if (pool_amax) { if (d->wmode || d->relu != 1 || !bias || !aff || !pool_y || !pool_idx || pool_mode != 2) return ASR_ERR_BAD_ARG; epi = W11_EPI_POOLMAXC; }
         else if (!d->wmode && d->relu == 1 && bias && aff && out_a && pool_y) epi = pool_mode == 2 ? W11_EPI_POOLMAX : W11_EPI_POOLAVG;
         else if (!d->wmode && d->relu == 1 && bias && aff && out_a && out_y && !d->accumulate && !pool_y) epi = W11_EPI_FWD;
         else if (d->wmode && d->relu == 0 && !bias && !scale && !shift && !out_a && out_y && !pool_y) epi = d->accumulate ? W11_EPI_DGRAD_ACC : W11_EPI_DGRAD;
         typedef void (*w11_fn)(WinoArgs);
-        static const w11_fn fns[9] = {nullptr, wino11_kernel<0, 1>, wino11_kernel<0, 2>, wino11_kernel<0, 3>, wino11_kernel<1, 4>, wino11_kernel<1, 5>,
-                                      wino11_kernel<1, 6>, wino11_kernel<1, 7>, wino11_kernel<1, 8>};
+        static const w11_fn fns[11] = {nullptr, wino11_kernel<0, 1>, wino11_kernel<0, 2>, wino11_kernel<0, 3>, wino11_kernel<1, 4>, wino11_kernel<1, 5>,
+                                       wino11_kernel<1, 6>, wino11_kernel<1, 7>, wino11_kernel<1, 8>, wino11_kernel<0, 9>, wino11_kernel<1, 10>};
         const w11_fn fn = epi ? fns[epi] : (d->wmode ? (w11_fn)wino11_kernel<1, 0> : (w11_fn)wino11_kernel<0, 0>);
-        static bool attr[10] = {false, false, false, false, false, false, false, false, false, false};
-        const int slot = epi ? epi : (d->wmode ? 9 : 0);
+        static bool attr[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
+        const int slot = epi ? epi : (d->wmode ? 11 : 0);
         if (!attr[slot]) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr[slot] = true; }
         hipLaunchKernelGGL(fn, dim3(grid11), dim3(512), lds11, st, w);
         ASR_CHECK_LAUNCH("tap_gemm_wino11");
-        static const char* const names[10] = {"wino11_kernel<0, 0>", "wino11_kernel<0, 1>", "wino11_kernel<0, 2>", "wino11_kernel<0, 3>", "wino11_kernel<1, 4>",
-                                              "wino11_kernel<1, 5>", "wino11_kernel<1, 6>", "wino11_kernel<1, 7>", "wino11_kernel<1, 8>", "wino11_kernel<1, 0>"};
+        static const char* const names[12] = {"wino11_kernel<0, 0>", "wino11_kernel<0, 1>", "wino11_kernel<0, 2>", "wino11_kernel<0, 3>", "wino11_kernel<1, 4>",
+                                              "wino11_kernel<1, 5>", "wino11_kernel<1, 6>", "wino11_kernel<1, 7>", "wino11_kernel<1, 8>", "wino11_kernel<0, 9>",
+                                              "wino11_kernel<1, 10>", "wino11_kernel<1, 0>"};
         asr_set_last_kernel(names[slot]);
         return ASR_OK;
     }
     // wino8_kernel: 64 x 64 items in the plain tile order (planes whose tile columns do not split into column blocks, N % 64 == 0)
-    if ((d->N % WC) != 0) return ASR_ERR_UNSUPPORTED;
+    if ((d->N % WC) != 0 || compact) return ASR_ERR_UNSUPPORTED;
     w.ncb = 0;
     const int nblk = asr_cdiv(w.ntiles, WT);
     a.ntm = nblk; a.ntn = d->N / WC;
@@ -1303,6 +1376,51 @@ extern "C" int asr_tap_gemm_wino_pool(const asr_gemm_desc* d, const float* A, co
 }
 
 // Launch of the gated data-gradient (asr_tap_gemm_gated with prearranged == 2; the caller folds the partial rows)
+// ---- the maximum pool in its compact form (round 4): the forward launch of a max-pooled cell writes, instead of the pre-pool
+// activation plane (4 x the pooled size, read back once by the backward pass), the pooled output, the activation AT each window's
+// maximum and the maximum's position (2 bits); the gated data-gradient that completes the cell's output gradient reads those.
+extern "C" size_t asr_poolmax_index_bytes(int B, int H2, int W2, int N) {
+    if (B < 1 || H2 < 1 || W2 < 1 || N < 32 || (N & 31)) return 0;
+    return (size_t)B * (H2 + 1) * (W2 + 1) * (N >> 5) * 2 * sizeof(unsigned);
+}
+
+// fwd: the pooled cell's forward descriptor (its pre-pool plane H x W); bwd: the data-gradient descriptor whose OUTPUT is the cell's
+// pooled plane (H / 2 x W / 2, N = the cell's channels).  Widths and geometry only.
+extern "C" int asr_winograd_poolmax_supported(const asr_gemm_desc* fwd, const asr_gemm_desc* bwd) {
+    if (!fwd || !bwd || fwd->wmode != 0 || bwd->wmode != 1) return 0;
+    if ((fwd->H & 1) || (fwd->W & 1) || bwd->H != fwd->H / 2 || bwd->W != fwd->W / 2 || bwd->N != fwd->N || bwd->B != fwd->B) return 0;
+    if (!asr_winograd_supported(fwd) || !asr_winograd_supported(bwd)) return 0;
+    return wino11_takes(fwd, true, 0) && wino11_takes(bwd, false, 4) ? 1 : 0;
+}
+
+extern "C" int asr_tap_gemm_wino_poolmax(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale,
+                                         const float* shift, float* y_pooled, float* a_max, unsigned* index, void* stream) {
+    if (!d || !A || !Ut || !bias || !scale || !shift || !y_pooled || !a_max || !index) return ASR_ERR_BAD_ARG;
+    if ((d->H & 1) || (d->W & 1) || !asr_winograd_supported(d) || !wino11_takes(d, true, 0)) return ASR_ERR_UNSUPPORTED;
+    return wino_impl(d, A, Ut, bias, scale, shift, nullptr, nullptr, stream, nullptr, y_pooled, 2, a_max, index);
+}
+
+extern "C" size_t asr_tap_gemm_gated_workspace(const asr_gemm_desc* d);
+
+extern "C" int asr_tap_gemm_gated_poolmax(const asr_gemm_desc* d, const float* dZ, const float* Ut, int gate_H, int gate_W, const float* a_max,
+                                          const unsigned* index, const float* bn_scale, const float* bn_shift, const float* dy_prev,
+                                          float* dz_out, float* dscale, float* dshift, float* dbias, float* partials, void* stream) {
+    if (!d || !dZ || !Ut || !a_max || !index || !bn_scale || !bn_shift || !dz_out || !dscale || !dshift || !dbias || !partials) return ASR_ERR_BAD_ARG;
+    if (d->wmode != 1 || d->relu != 0 || d->y_unpadded || d->H <= 0 || d->ldo_y != d->N || (d->accumulate && !dy_prev)) return ASR_ERR_BAD_ARG;
+    if (gate_H != 2 * d->H || gate_W != 2 * d->W) return ASR_ERR_BAD_ARG;
+    if (!asr_winograd_supported(d) || !wino11_takes(d, false, 4)) return ASR_ERR_UNSUPPORTED;
+    int rows = 0;
+    WinoGate gs;
+    gs.mode = 4; gs.H = gate_H; gs.W = gate_W; gs.a = a_max; gs.dz = dz_out; gs.part = partials; gs.rows = &rows;
+    const int rc = wino_impl(d, dZ, Ut, nullptr, bn_scale, bn_shift, nullptr, (float*)dy_prev, stream, &gs, nullptr, 0, nullptr, (unsigned*)index);
+    if (rc != ASR_OK) return rc;
+    if (rows <= 0 || (size_t)rows * 3 * d->N * sizeof(float) > asr_tap_gemm_gated_workspace(d)) return ASR_ERR_UNSUPPORTED;
+    asr_reduce::Multi m;
+    m.nseg = 3; m.width[0] = d->N; m.width[1] = d->N; m.width[2] = d->N; m.width[3] = 0;
+    m.out[0] = dscale; m.out[1] = dshift; m.out[2] = dbias; m.out[3] = nullptr;
+    return asr_reduce::colsum_multi(partials, rows, 3L * d->N, m, partials + (size_t)rows * 3 * d->N, (hipStream_t)stream);
+}
+
 extern "C" int asr_tap_gemm_wino_gated_launch(const asr_gemm_desc* d, const float* dZ, const float* Ut, int mode, int gate_H, int gate_W,
                                               const float* gate_a, const float* scale, const float* shift, float* dy_prev,
                                               float* dz_out, float* partials, int* rows, void* stream) {

@@ -416,6 +416,16 @@ class DFCNNEngine:
                 self._dplane(op[2])
                 self._dplane(op[3])
         self._plan_fused_prologues()
+        # Max-pooled cells whose forward conv and whose gated data-gradient both run on the Winograd kernel keep no pre-pool
+        # activation plane: the forward writes the activation at each window's maximum + its position, the backward reads those
+        # (asr_tap_gemm_wino_poolmax / asr_tap_gemm_gated_poolmax: a quarter of the traffic, the same bits).  Widths and geometry only.
+        self.compact = {}
+        for writer, tgt in (self.fuse.items() if os.environ.get('ASR_POOLMAX', '1') != '0' else ()):
+            top = next(o for o in self.g if o[0] == 'cell' and o[2] == tgt)
+            if top[6] == 'max' and tgt in self.wt_f and writer in self.wt_b and ops.poolmax_supported(self.fdesc[tgt], self.bdesc[writer]):
+                Ho, Wo, cout = self.res[tgt]
+                self.compact[tgt] = (Plane(B, Ho, Wo, cout, dev), ops.poolmax_index(B, Ho, Wo, cout, dev))
+                del self.a[tgt]
         if self.fuse and not self.dz_alt:
             # a fused data-gradient reads dZ of its own cell while its epilogue writes dZ of the cell in front: two planes
             # per geometry are needed on one stream as well (the two cells may share a geometry)
@@ -542,6 +552,9 @@ class DFCNNEngine:
                     torch.cuda.current_stream().wait_event(wf_ready)
                     wf_ready = None
                 out_y = None if pool else (self.flat[dst] if dst in self.flat else self.y[dst])
+                if dst in self.compact:
+                    ops.tap_gemm_wino_poolmax(self.fdesc[dst], self.y[src], self.wt_f[dst], self.p(dst, 'b'), sc, sh, self.y[dst], *self.compact[dst])
+                    continue
                 if dst in self.wt_f and pool:
                     # conv + bias + ReLU -> BN -> 2x2 pool in one launch: a Winograd tile is a pooling window
                     ops.tap_gemm_wino_pool(self.fdesc[dst], self.y[src], self.wt_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], pm, self.y[dst])
@@ -770,11 +783,16 @@ class DFCNNEngine:
                     top = next(o for o in self.g if o[0] == 'cell' and o[2] == tgt)
                     Hf, Wf, _ = self.res[top[1]]
                     dzt = acquire_dz((Hf, Wf, top[4]))
-                    ops.tap_gemm_gated(d, dz, self.wt_b[dst] if dst in self.wt_b else self.wf_b[dst] if dst in self.wf_b else self.p(dst, 'w'),
-                                       2 if dst in self.wt_b else 1 if dst in self.wf_b else 0,
-                                       {None: 0, 'avg': 1, 'max': 2}[top[6]], self.a[tgt], self.scale_of(tgt), self.p(tgt, 'beta'),
-                                       dx if acc else None, dzt, self.dscale_of(tgt), self.gview(tgt, 'beta'),
-                                       self.gview(tgt, 'b'), self.ws)
+                    if tgt in self.compact:
+                        ops.tap_gemm_gated_poolmax(d, dz, self.wt_b[dst], Hf, Wf, *self.compact[tgt], self.scale_of(tgt), self.p(tgt, 'beta'),
+                                                   dx if acc else None, dzt, self.dscale_of(tgt), self.gview(tgt, 'beta'),
+                                                   self.gview(tgt, 'b'), self.ws)
+                    else:
+                        ops.tap_gemm_gated(d, dz, self.wt_b[dst] if dst in self.wt_b else self.wf_b[dst] if dst in self.wf_b else self.p(dst, 'w'),
+                                           2 if dst in self.wt_b else 1 if dst in self.wf_b else 0,
+                                           {None: 0, 'avg': 1, 'max': 2}[top[6]], self.a[tgt], self.scale_of(tgt), self.p(tgt, 'beta'),
+                                           dx if acc else None, dzt, self.dscale_of(tgt), self.gview(tgt, 'beta'),
+                                           self.gview(tgt, 'b'), self.ws)
                     fused_dz[tgt] = dzt
                 elif dst in self.wt_b:
                     ops.tap_gemm_wino(d, dz, self.wt_b[dst], None, None, None, None, dx)

@@ -162,6 +162,37 @@ def tap_gemm_gated(desc, dZ, W, prearranged, pool, gate_a, bn_scale, bn_shift, d
                                _ptr(partials), _stream()), 'asr_tap_gemm_gated'))
 
 
+def poolmax_supported(fwd_desc, bwd_desc):
+    return bool(_lib.load().asr_winograd_poolmax_supported(C.byref(fwd_desc), C.byref(bwd_desc)))
+
+
+def poolmax_index(B, H2, W2, N, device='cuda'):
+    """the position planes of asr_tap_gemm_wino_poolmax (uint32 words, held in an int32 tensor)"""
+    n = _lib.load().asr_poolmax_index_bytes(B, H2, W2, N)
+    assert n > 0
+    return torch.zeros(n // 4, dtype=torch.int32, device=device)
+
+
+def tap_gemm_wino_poolmax(desc, A, Wt, bias, scale, shift, y_pooled, a_max, index):
+    """Forward conv of a MAX-pooled cell in the compact form (asr_tap_gemm_wino_poolmax): no activation plane; y_pooled, the
+    activation at each window's maximum (a_max, a Plane of the pooled geometry) and its position (index)."""
+    lib = _lib.load()
+    pa = A.ptr if isinstance(A, Plane) else _ptr(A)
+    _timed(desc, lambda: check(lib.asr_tap_gemm_wino_poolmax(C.byref(desc), pa, _ptr(Wt), _ptr(bias), _ptr(scale), _ptr(shift),
+                                                             y_pooled.ptr, a_max.ptr, _ptr(index), _stream()), 'asr_tap_gemm_wino_poolmax'))
+
+
+def tap_gemm_gated_poolmax(desc, dZ, Wt, gate_H, gate_W, a_max, index, bn_scale, bn_shift, dy_prev, dz_out, dscale, dshift, dbias, partials):
+    """asr_tap_gemm_gated for a max-pooled cell in the compact form: (a_max, index) in place of the activation plane."""
+    lib = _lib.load()
+    pz = dZ.ptr if isinstance(dZ, Plane) else _ptr(dZ)
+    pp = dy_prev.ptr if isinstance(dy_prev, Plane) else _ptr(dy_prev)
+    _timed(desc, lambda: check(
+        lib.asr_tap_gemm_gated_poolmax(C.byref(desc), pz, _ptr(Wt), int(gate_H), int(gate_W), a_max.ptr, _ptr(index), _ptr(bn_scale),
+                                       _ptr(bn_shift), pp, dz_out.ptr, _ptr(dscale), _ptr(dshift), _ptr(dbias), _ptr(partials), _stream()),
+        'asr_tap_gemm_gated_poolmax'))
+
+
 def tap_wgrad_workspace(desc):
     return _lib.load().asr_tap_wgrad_workspace(C.byref(desc))
 

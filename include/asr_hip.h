@@ -512,6 +512,25 @@ int asr_tap_gemm_gated(const asr_gemm_desc* d, const float* dZ, const float* W, 
                        const float* bn_scale, const float* bn_shift, const float* dy_prev,
                        float* dz_out, float* dscale, float* dshift, float* dbias, float* partials, void* stream);
 
+/* ------------------------------------------------------------------ maximum pool, compact form (round 4)
+ * A max-pooled cell (acoustic_model.py:120-130: conv + bias + ReLU -> BN -> max_pooling2d 2x2) whose forward conv AND the
+ * data-gradient that completes its output gradient both run on the Winograd kernel needs no pre-pool activation plane: the forward
+ * launch writes the pooled output, the activation AT each window's maximum (a_max, pooled geometry [B][H/2+1][W/2+1][N]) and the
+ * maximum's window position (index: two bit planes of 32 channels per pooled pixel, asr_poolmax_index_bytes); the gated data-gradient
+ * reads those two instead of four activation pixels per window.  A quarter of the activation traffic in both directions, and bit for bit
+ * the values of asr_tap_gemm_wino_pool + asr_tap_gemm_gated(pool = 2) (first maximum of bn_scale * a + bn_shift in row-major window
+ * order; the positions that are not the maximum contribute exact zeros to the channel sums in both forms).
+ *   asr_winograd_poolmax_supported(fwd, bwd): fwd = the cell's forward descriptor (pre-pool plane H x W, both even), bwd = the
+ *   data-gradient descriptor whose output is the cell's pooled plane; a function of widths and geometry only. */
+size_t asr_poolmax_index_bytes(int B, int H2, int W2, int N);
+int asr_winograd_poolmax_supported(const asr_gemm_desc* fwd, const asr_gemm_desc* bwd);
+int asr_tap_gemm_wino_poolmax(const asr_gemm_desc* d, const float* A, const float* Wt, const float* bias, const float* bn_scale,
+                              const float* bn_shift, float* y_pooled, float* a_max, unsigned* index, void* stream);
+/* as asr_tap_gemm_gated(prearranged = 2, pool = 2) with (a_max, index) in place of gate_a; gate_H / gate_W = the pre-pool plane */
+int asr_tap_gemm_gated_poolmax(const asr_gemm_desc* d, const float* dZ, const float* Wt, int gate_H, int gate_W, const float* a_max,
+                               const unsigned* index, const float* bn_scale, const float* bn_shift, const float* dy_prev,
+                               float* dz_out, float* dscale, float* dshift, float* dbias, float* partials, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,3 +109,77 @@ def test_gated_winograd_data_gradient_matches_the_direct_one(pool, acc, B, Hq, W
     for i, name in ((1, 'dscale'), (2, 'dshift'), (3, 'dbias')):
         err = (got[i].double() - ref[i].double()).abs().max().item()
         assert err <= 1e-4 * max(1.0, ref[i].abs().max().item()), (name, err)
+
+
+@pytest.mark.parametrize("B,H,W,cin,N,K2,acc", [(2, 16, 50, 32, 64, 64, 0), (1, 40, 100, 32, 64, 128, 1), (2, 8, 52, 64, 128, 32, 0)])
+def test_poolmax_compact_form_gives_the_bits_of_the_activation_plane_form(B, H, W, cin, N, K2, acc):
+    """A max-pooled cell in the compact form (asr_tap_gemm_wino_poolmax / asr_tap_gemm_gated_poolmax: activation at each window's
+    maximum + its 2-bit position instead of the pre-pool activation plane) against the form it replaces (asr_tap_gemm_wino_pool /
+    asr_tap_gemm_gated with pool = 2): pooled output, dZ and the three channel sums bit for bit; negative BN scales (arg-max of the BN
+    output = arg-min of the activation) and windows of equal values (ReLU zeros: the FIRST position takes the gradient) included."""
+    from asr_dfcnn_transformer_amd import ops
+    from asr_dfcnn_transformer_amd.ops import Plane
+    g = torch.Generator(device='cuda').manual_seed(B + H + W + N)
+    rnd = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    x = Plane(B, H, W, cin); x.set_interior(rnd(B, H, W, cin))
+    w = rnd(3, 3, cin, N) * (2.0 / (9 * cin)) ** 0.5
+    bias = rnd(N) * 0.1 - 0.3                        # plenty of ReLU zeros
+    sc = 1.0 + 0.2 * rnd(N); sh = 0.1 * rnd(N)
+    sc[0] = -0.5; sc[N - 1] = -1.25
+    fd = ops.gemm_desc(x.NP, cin, N, cin, N, N, 0, ntaps=9, B=B, H=H, W=W, relu=1)
+    H2, W2 = H // 2, W // 2
+    w2 = rnd(3, 3, N, K2) * 0.05
+    dzk = Plane(B, H2, W2, K2); dzk.set_interior(rnd(B, H2, W2, K2))
+    bd = ops.gemm_desc(dzk.NP, K2, N, K2, K2, 0, N, ntaps=9, B=B, H=H2, W=W2, wmode=1, accumulate=acc)
+    assert ops.poolmax_supported(fd, bd)
+    wt = ops.winograd_weights(w, cin, N, N, 0)
+    wtb = ops.winograd_weights(w2, K2, N, K2, 1)
+    # the form with the activation plane
+    a, y1 = Plane(B, H, W, N), Plane(B, H2, W2, N)
+    ops.tap_gemm_wino_pool(fd, x, wt, bias, sc, sh, a, 2, y1)
+    assert ops.last_kernel() == 'wino11_kernel<0, 2>'
+    prev = Plane(B, H2, W2, N)
+    if acc:
+        prev.set_interior(rnd(B, H2, W2, N))
+    ws = torch.zeros(ops.tap_gemm_gated_workspace(bd) // 4 + 64, device='cuda')
+    dz1 = Plane(B, H, W, N)
+    s1 = [torch.zeros(N, device='cuda') for _ in range(3)]
+    ops.tap_gemm_gated(bd, dzk, wtb, 2, 2, a, sc, sh, prev if acc else None, dz1, s1[0], s1[1], s1[2], ws)
+    assert ops.last_kernel() == 'wino11_kernel<1, 8>'
+    # the compact form
+    y2, amax = Plane(B, H2, W2, N), Plane(B, H2, W2, N)
+    idx = ops.poolmax_index(B, H2, W2, N)
+    ops.tap_gemm_wino_poolmax(fd, x, wt, bias, sc, sh, y2, amax, idx)
+    assert ops.last_kernel() == 'wino11_kernel<0, 9>'
+    assert torch.equal(y1.buf, y2.buf)
+    # a_max / index against the activation plane: first maximum of sc * a + sh in row-major window order
+    av = a.interior().reshape(B, H2, 2, W2, 2, N).permute(0, 1, 3, 2, 4, 5).reshape(B, H2, W2, 4, N)
+    bn = av * sc + sh                                  # (same fma? the comparison below is on positions: recompute exactly)
+    bn = torch.addcmul(sh.expand_as(av), av, sc.expand_as(av))
+    pos = torch.zeros(B, H2, W2, N, dtype=torch.long, device='cuda'); best = bn[..., 0, :].clone()
+    for k in (1, 2, 3):
+        better = bn[..., k, :] > best
+        pos = torch.where(better, torch.full_like(pos, k), pos); best = torch.where(better, bn[..., k, :], best)
+    want_amax = torch.gather(av, 3, pos.unsqueeze(3)).squeeze(3)
+    # (torch's addcmul may round differently from the kernel's fma in a near-tie: compare where the margin is clear, the bits of dZ and
+    #  of the sums below are the real check)
+    srt = bn.sort(dim=3, descending=True).values
+    clear = (srt[..., 0, :] - srt[..., 1, :]).abs() > 1e-5
+    assert torch.equal(amax.interior()[clear], want_amax[clear])
+    words = idx.view(B, H2 + 1, W2 + 1, N // 32, 2)[:, 1:, 1:]
+    shifts = torch.arange(32, device='cuda', dtype=torch.int32)
+    bits0 = ((words[..., 0].unsqueeze(-1) >> shifts) & 1).reshape(B, H2, W2, N)
+    bits1 = ((words[..., 1].unsqueeze(-1) >> shifts) & 1).reshape(B, H2, W2, N)
+    got_pos = (bits0 + 2 * bits1).long()
+    assert torch.equal(got_pos[clear], pos[clear])
+    dz2 = Plane(B, H, W, N)
+    dz2.buf.fill_(7.0)
+    dz2.view()[:, 0].zero_(); dz2.view()[:, :, 0].zero_(); dz2.buf[:dz2.G * N].zero_(); dz2.buf[-dz2.G * N:].zero_()
+    s2 = [torch.zeros(N, device='cuda') for _ in range(3)]
+    ops.tap_gemm_gated_poolmax(bd, dzk, wtb, H, W, amax, idx, sc, sh, prev if acc else None, dz2, s2[0], s2[1], s2[2], ws)
+    assert ops.last_kernel() == 'wino11_kernel<1, 10>'
+    torch.cuda.synchronize()
+    assert torch.equal(dz1.interior(), dz2.interior())
+    assert float(dz2.view()[:, 0].abs().max()) == 0 and float(dz2.view()[:, :, 0].abs().max()) == 0
+    for u, v in zip(s1, s2):
+        assert torch.equal(u, v)
