@@ -1048,7 +1048,8 @@ __device__ __forceinline__ void wino11_body(float* smem) {
         int* prow = rowy + 256;
         if (newblk) {                                // the next tile block: its patch offsets and (second table set) its row tables
             patch_offsets(en);
-            wino11_tables(args, en, tid, tables + (tcur ^ 1) * W11_TABF, tables + (tcur ^ 1) * W11_TABF + 256, tables + (tcur ^ 1) * W11_TABF + 512);
+            // (the thread index from the re-derived lane id: `tid` itself would live across the chunk loop and come back from scratch)
+            wino11_tables(args, en, wave * 64 + lane, tables + (tcur ^ 1) * W11_TABF, tables + (tcur ^ 1) * W11_TABF + 256, tables + (tcur ^ 1) * W11_TABF + 512);
         }
         W11T(6);
         float* scratch = (wave < 4 ? rfree : ufree) + (wave & 3) * (32 * 33);
