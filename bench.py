@@ -641,6 +641,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_enq = time.perf_counter() - t0                 # host side only: how far ahead of the GPU the enqueue runs (config.host_enqueue_ms_per_step)
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     timed = ops.TIMER.summary()
@@ -676,7 +677,7 @@ def main():
                                     'SE-DFCNN (acoustic_model2.py) + CTC') +
                                    ', fbank+fwd+CTC+greedy+bwd+Adam, 10 s/16 kHz audio, T_pad %d, V %d' % (T, V),
                        'global_batch': world * B, 'batch_per_gpu': B, 't_pad': T, 'parallelism': 'dp%d' % world, **dp_info(),
-                       'gflop_per_utt_fwd_bwd': round(fstep / 1e9, 3),
+                       'gflop_per_utt_fwd_bwd': round(fstep / 1e9, 3), 'host_enqueue_ms_per_step': round(1e3 * t_enq / args.steps, 3),
                        'step_algorithmic_tflops': round(utt_s / world * fstep / 1e12, 2),
                        'step_algorithmic_frac_of_fp32_peak': round(utt_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
                        'step_flops_note': 'direct-convolution flops (SURVEY 8d); the Winograd layers execute 1/2.25 of their multiplies, '
