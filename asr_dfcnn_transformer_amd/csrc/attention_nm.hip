@@ -206,6 +206,10 @@ __global__ __launch_bounds__(256, 2) void nm_bwd_kv_kernel(const float* __restri
 
     for (int q0 = 0; q0 < Tq; q0 += 32) {
         __syncthreads();
+        // (the thread index re-derived per trip: the staging addresses hipcc hoists out of this loop otherwise live across its 250
+        //  registers of accumulators and operands and come back as twelve scratch reloads per trip, each behind an s_waitcnt vmcnt(0))
+        int tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(tid));
         stage<DH>(Qs, Q, qbase, q0, 32, Tq, C, hoff, tid);
         stage<DH>(Ds, dO, qbase, q0, 32, Tq, C, hoff, tid);
         if (tid < 32) {
