@@ -88,6 +88,8 @@ SIGNATURES = {
     'asr_layernorm_bwd_workspace': (_Z, [_I, _I]),
     'asr_layernorm_bwd': (_I, [_P, _P, _P, _P, _I, _I, _P, _I, _P, _P, _P, _P]),
     'asr_layernorm_bwd_fused': (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _F, C.c_uint, _F, _P, _P, _P, _P, _P]),
+    'asr_layernorm_bwd_blocks': (_I, [_I]),
+    'asr_colsum_multi_batch': (_I, [_P, _I, _I, _P]),
     'asr_add_layernorm_fwd_dropout': (_I, [_P, _P, _P, _P, _I, _I, _F, _F, C.c_uint, _P, _P, _P, _P]),
     'asr_embed_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P]),
     'asr_embed_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P, _P]),

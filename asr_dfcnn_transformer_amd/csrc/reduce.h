@@ -149,4 +149,61 @@ inline int colsum_multi(const float* x, int rows, long ldx, const Multi& m, floa
     return ASR_OK;
 }
 
+
+// ---- several of those reductions in TWO launches (asr_colsum_multi_batch): the producers leave their block partials where they
+// are, the caller lists them in a device table and reduces all of them at the end of the backward pass (gradients of affine
+// parameters are needed by the optimiser only).  Per item exactly the arithmetic of colsum_multi: level 1 folds rows_per_split
+// rows per split (four chains in fixed order; one row per split when rows <= kSplits, i.e. a copy), level 2 the splits.
+struct BatchItem {
+    const float* x; float* tmp;          // partials [rows][ld]; tmp: kSplits * cols floats
+    int rows, ld, nseg;
+    int width[4];
+    float* out[4];
+};
+
+static __global__ void colsum_batch_kernel(const BatchItem* __restrict__ items, int level) {
+    const BatchItem it = items[blockIdx.z];
+    int cols = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) cols += i < it.nseg ? it.width[i] : 0;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const int rps = it.rows > kSplits ? (it.rows + kSplits - 1) / kSplits : 1;
+    const int ns = (it.rows + rps - 1) / rps;
+    const float* x; long ldx; int r0, r1;
+    if (level == 1) {
+        if ((int)blockIdx.y >= ns) return;
+        x = it.x; ldx = it.ld; r0 = blockIdx.y * rps; r1 = r0 + rps < it.rows ? r0 + rps : it.rows;
+    } else {
+        x = it.tmp; ldx = cols; r0 = 0; r1 = ns;
+    }
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {
+        s0 += x[(long)r * ldx + c];
+        s1 += x[(long)(r + 1) * ldx + c];
+        s2 += x[(long)(r + 2) * ldx + c];
+        s3 += x[(long)(r + 3) * ldx + c];
+    }
+    for (; r < r1; ++r) s0 += x[(long)r * ldx + c];
+    const float v = (s0 + s1) + (s2 + s3);
+    if (level == 1) { it.tmp[(long)blockIdx.y * cols + c] = v; return; }
+    int cc = c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < it.nseg) {
+            if (cc < it.width[i]) { it.out[i][cc] = v; return; }
+            cc -= it.width[i];
+        }
+    }
+}
+
+inline int colsum_multi_batch(const BatchItem* items_dev, int n_items, int max_cols, hipStream_t st) {
+    const int gx = asr_cdiv(max_cols, 256);
+    hipLaunchKernelGGL(colsum_batch_kernel, dim3(gx, kSplits, n_items), dim3(256), 0, st, items_dev, 1);
+    hipLaunchKernelGGL(colsum_batch_kernel, dim3(gx, 1, n_items), dim3(256), 0, st, items_dev, 2);
+    ASR_CHECK_LAUNCH("colsum_multi_batch");
+    return ASR_OK;
+}
+
 }  // namespace asr_reduce

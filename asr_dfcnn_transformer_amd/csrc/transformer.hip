@@ -571,6 +571,7 @@ static int ln_bwd_launch(const float* dy, const float* xhat, const float* rstd, 
     else if (fused) return ASR_ERR_UNSUPPORTED;
     else hipLaunchKernelGGL(ln_bwd_kernel, dim3(nblk), dim3(256), lds, st, dy, xhat, rstd, gamma, rows, C, dx, accumulate, partials, rpb);
     ASR_CHECK_LAUNCH("layernorm_bwd");
+    if (!dgamma) return ASR_OK;          // deferred: the block partials [nblk][2 C] stay in `partials` for asr_colsum_multi_batch
     float* tmp = partials + (size_t)nblk * 2 * C;
     asr_reduce::Multi m;
     m.nseg = 2; m.width[0] = C; m.width[1] = C; m.width[2] = 0; m.width[3] = 0;
@@ -588,12 +589,21 @@ extern "C" int asr_layernorm_bwd(const float* dy, const float* xhat, const float
 extern "C" int asr_layernorm_bwd_fused(const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int C,
                                        float* dx, float* dx2, int accumulate2, const float* z, float drop_rate, unsigned drop_seed,
                                        float zscale, float* dz, float* dgamma, float* dbeta, float* partials, void* stream) {
-    if (!dy || !xhat || !rstd || !gamma || !dgamma || !dbeta || !partials || rows < 1 || C < 1) return ASR_ERR_BAD_ARG;
+    if (!dy || !xhat || !rstd || !gamma || (!dgamma != !dbeta) || !partials || rows < 1 || C < 1) return ASR_ERR_BAD_ARG;
     if ((!dx && !dx2 && !dz) || drop_rate < 0.f || drop_rate >= 1.f) return ASR_ERR_BAD_ARG;
     if ((unsigned long long)rows * (unsigned long long)C >= 4294967296ull) return ASR_ERR_BAD_ARG;
     LnBwdExtra ex; ex.dx2 = dx2; ex.acc2 = accumulate2; ex.z = z; ex.zscale = zscale; ex.dz = dz;
     ex.dthr = drop_threshold(drop_rate); ex.dseed = (uint32_t)drop_seed;
     return ln_bwd_launch(dy, xhat, rstd, gamma, rows, C, dx, 0, dgamma, dbeta, partials, ex, (hipStream_t)stream);
+}
+
+extern "C" int asr_layernorm_bwd_blocks(int rows) { return rows < 1 ? 0 : asr_cdiv(rows, ln_rows_per_block(rows)); }
+
+static_assert(sizeof(asr_reduce_item) == sizeof(asr_reduce::BatchItem), "asr_reduce_item is the kernel's table entry");
+
+extern "C" int asr_colsum_multi_batch(const asr_reduce_item* items_dev, int n_items, int max_cols, void* stream) {
+    if (!items_dev || n_items < 1 || n_items > 65535 || max_cols < 1) return ASR_ERR_BAD_ARG;
+    return asr_reduce::colsum_multi_batch((const asr_reduce::BatchItem*)items_dev, n_items, max_cols, (hipStream_t)stream);
 }
 
 extern "C" int asr_embed_fwd(const float* table, const int32_t* ids, const float* pos, int N, int T, int C,

@@ -120,6 +120,7 @@ class _LanguageHalf(_Base):
         if self._rate > 0:
             ops.dropout(cur, self._rate, self._seed_emb)
         ops.colsum(cur, N, T * C, T * C, self.g('pos')[:T * C], self.ws)
+        self._ln_reduce()
         return cur.view(rows, C)
 
 

@@ -381,6 +381,36 @@ class Copy2dBatch:
         check(_lib.load().asr_transpose_batch(_ptr(self.table), self.n, self.max_elems, _stream()), 'asr_transpose_batch')
 
 
+class ReduceBatch:
+    """Deferred column reductions run as one asr_colsum_multi_batch (two launches).  ``items``: (partials tensor, rows, ld,
+    [(width, out tensor), ...] with up to four segments); scratch is owned here; the tensors must keep their storage."""
+
+    def __init__(self, items):
+        import struct
+        assert items
+        dev = items[0][0].device
+        self._keep, raw, self.max_cols = [], b'', 0
+        for part, rows, ld, segs in items:
+            assert 1 <= len(segs) <= 4
+            cols = sum(w for w, _ in segs)
+            tmp = torch.zeros(64 * cols, dtype=torch.float32, device=dev)
+            self._keep.append((part, tmp, [o for _, o in segs]))
+            widths = [w for w, _ in segs] + [0] * (4 - len(segs))
+            outs = [(_ptr(o).value or 0) for _, o in segs] + [0] * (4 - len(segs))
+            raw += struct.pack('<QQiii4i4xQQQQ', _ptr(part).value or 0, _ptr(tmp).value or 0, rows, ld, len(segs), *widths, *outs)
+            self.max_cols = max(self.max_cols, cols)
+        assert len(raw) == 80 * len(items)
+        self.n = len(items)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+
+    def run(self):
+        check(_lib.load().asr_colsum_multi_batch(_ptr(self.table), self.n, self.max_cols, _stream()), 'asr_colsum_multi_batch')
+
+
+def layernorm_bwd_blocks(rows):
+    return _lib.load().asr_layernorm_bwd_blocks(rows)
+
+
 def dropout(x, rate, seed, y=None):
     """y = keep(i, seed) ? x / (1 - rate) : 0 (in place when y is None); the same call on a gradient is the backward."""
     y = x if y is None else y

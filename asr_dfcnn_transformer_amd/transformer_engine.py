@@ -151,6 +151,27 @@ class _Base:
     def _t(self, *shape, dtype=torch.float32):
         return torch.zeros(*shape, dtype=dtype, device=self.device)
 
+    def _ln_part(self, name, rows):
+        """The block-partial buffer of LayerNorm site ``name``: its backward leaves the partial sums of dgamma / dbeta there
+        (asr_layernorm_bwd_fused with NULL outputs) and _ln_reduce folds the partials of ALL sites of a step in one batched reduction
+        (two launches instead of two per LayerNorm; the optimiser is the only reader of those gradients)."""
+        reg = self.__dict__.setdefault('_ln_sites', {})
+        if name not in reg:
+            nblk = ops.layernorm_bwd_blocks(rows)
+            reg[name] = (self._t(nblk * 2 * self.C), nblk)
+            self._ln_batch = None
+        return reg[name][0]
+
+    def _ln_reduce(self):
+        reg = self.__dict__.get('_ln_sites')
+        if not reg:
+            return
+        if self.__dict__.get('_ln_batch') is None:
+            C = self.C
+            self._ln_batch = ops.ReduceBatch([(part, nblk, 2 * C, [(C, self.g(n + '/ln_g')), (C, self.g(n + '/ln_b'))])
+                                              for n, (part, nblk) in reg.items()])
+        self._ln_batch.run()
+
     def _embed_bwd(self, dout, ids_dev, ids_host, rows, V, zero_pad, scale, dtable):
         """Gradient of an embedding table.  Small tables x few positions (the language model: 1536 x 6400) straight from the ids
         on the device (asr_embed_bwd_ids: a wave per table row scans the ids -- V * rows / 64 wave iterations, ~10 us there, no
@@ -343,7 +364,7 @@ class _Base:
         # of it (mask = kept by the generator AND Z > 0, factor 1 / (1 - rate))
         ops.layernorm_bwd_fused(dout, st['xhat'], st['rstd'], self.p(name + '/ln_g'), rq, C, None, dq_in, dq_acc, st['Z'],
                                 1.0 / (1.0 - self._rate) if self._rate > 0 else 1.0, dZ,
-                                self.g(name + '/ln_g'), self.g(name + '/ln_b'), self.ws, self._rate, st['seed_out'])
+                                None, None, self._ln_part(name, rq), self._rate, st['seed_out'])
         self._wgrad(st['A'], dZ, rq, C, C, name + '/wo')
         self._dense_dgrad(dZ, rq, C, C, self.p(name + '/wo'), dA, False)
         fused3 = st['fused3']
@@ -390,7 +411,7 @@ class _Base:
         # one pass: dx (+)= the LayerNorm input gradient (the residual branch), dY = the same through the dropout of the FFN output
         ops.layernorm_bwd_fused(dout, st['xhat'], st['rstd'], self.p(name + '/ln_g'), rows, C, None, dx, dx_acc, None,
                                 1.0 / (1.0 - self._rate) if self._rate > 0 else 1.0, dY,
-                                self.g(name + '/ln_g'), self.g(name + '/ln_b'), self.ws, self._rate, st['seed'])
+                                None, None, self._ln_part(name, rows), self._rate, st['seed'])
         self._bgrad(dY, rows, C, name + '/b2')
         self._wgrad(st['H'], dY, rows, 4 * C, C, name + '/w2')
         self._dense_dgrad(dY, rows, 4 * C, C, self.p(name + '/w2'), dH, False)
@@ -542,6 +563,7 @@ class LMEngine(_Base):
             ops.dropout(cur, self._rate, self._seed_emb)
         self._embed_bwd(cur, self.ids, self._x_host, rows, self.vin, True, float(C) ** 0.5, self.g('emb'))
         ops.colsum(cur, N, T * C, T * C, self.g('pos')[:T * C], self.ws)
+        self._ln_reduce()
 
 
 class E2EEngine(_Base):
@@ -673,3 +695,4 @@ class E2EEngine(_Base):
                 self._dense_dgrad(du, re, self.din, C, self.p('in_w'), self.dx_feat, False)
         else:
             self._embed_bwd(cur, self.x_ids, self._x_host, re, self.vin, True, float(C) ** 0.5, self.g('enc_emb'))
+        self._ln_reduce()

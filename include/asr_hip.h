@@ -325,6 +325,16 @@ int asr_layernorm_bwd(const float* dy, const float* xhat, const float* rstd, con
 int asr_layernorm_bwd_fused(const float* dy, const float* xhat, const float* rstd, const float* gamma, int rows, int C,
                             float* dx, float* dx2, int accumulate2, const float* z, float drop_rate, unsigned drop_seed,
                             float zscale, float* dz, float* dgamma, float* dbeta, float* partials, void* stream);
+/* Deferred form: with dgamma == dbeta == NULL the block partials of the two sums stay in `partials`
+ * ([asr_layernorm_bwd_blocks(rows)][2 C] floats: sum dy * xhat | sum dy) and the caller reduces them later -- the gradients of
+ * affine parameters are needed by the optimiser only, so a backward pass can leave all of them to ONE asr_colsum_multi_batch. */
+int asr_layernorm_bwd_blocks(int rows);
+/* Several fixed-order column reductions in two launches.  items_dev: n_items entries in DEVICE memory; entry = a [rows][ld] matrix of
+ * partial rows whose first sum(width) columns form nseg <= 4 consecutive segments that go to out[0 .. nseg-1]; tmp = 64 * sum(width)
+ * floats of scratch per entry.  Per entry the arithmetic and summation order of the reductions the producers run themselves
+ * (two levels: at most 64 splits of consecutive rows, four chains each): the same bits.  max_cols = the largest sum(width). */
+typedef struct asr_reduce_item { const float* partials; float* tmp; int rows, ld, nseg; int width[4]; float* out[4]; } asr_reduce_item;
+int asr_colsum_multi_batch(const asr_reduce_item* items_dev, int n_items, int max_cols, void* stream);
 /* asr_add_layernorm_fwd on (asr_dropout(a, rate, seed), b) without the pass over a: a is read once and stays as it is (the
  * backward regenerates the mask: asr_layernorm_bwd_fused).  Same bits as the two calls.  rows * C < 2^32; C % 4 == 0, C <= 2048,
  * 16-byte aligned pointers, else ASR_ERR_UNSUPPORTED. */
