@@ -55,6 +55,8 @@ SIGNATURES = {
     'asr_se_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_se_bwd_workspace': (_Z, [_I, _I, _I, _I, _I]),
     'asr_se_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'asr_se_bwd_cell_workspace': (_Z, [_I, _I, _I, _I, _I]),
+    'asr_se_bwd_cell': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_axpy': (_I, [_P, _P, _Z, _F, _I, _P]),
     'asr_softmax_log_fwd': (_I, [_P, _I, _I, _I, _F, _P, _P]),
     'asr_softmax_log_bwd': (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P]),

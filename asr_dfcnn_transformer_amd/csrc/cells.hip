@@ -433,12 +433,19 @@ __global__ __launch_bounds__(256) void se_bwd_mlp_kernel(const float* __restrict
 inline int se_apply_ppb(long NP) { return NP >= (4L << 20) ? 1024 : (NP >= (1L << 20) ? 512 : 128); }
 
 // dxt = dout*e + dsb; dx = dxt*sc (+ dout when add_dout); channel sums dshift = sum dxt, dscale = sum dxt*x
+// FUSE (asr_se_bwd_cell): x is the BN output of a conv cell that nothing else reads, so dx is that cell's complete output gradient
+// and its backward prologue (cell_bwd_pre_kernel<0>: BN and ReLU backward + the cell's three channel sums) runs here on the value
+// in the register -- dx is not written and read back: four planes of traffic instead of six.  Same blocks, slots and order as the
+// two kernels it replaces: dZ and every partial sum bit for bit.
+template <bool FUSE>
 __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const float* __restrict__ dout, const float* __restrict__ x,
                                                            int B, int H, int W, int C, const float* __restrict__ sc,
                                                            const float* __restrict__ e, const float* __restrict__ dsb,
                                                            int add_dout, float* __restrict__ dx,
-                                                           float* __restrict__ partials, int PPB) {
-    __shared__ float red[256 * 8];
+                                                           float* __restrict__ partials, int PPB,
+                                                           const float* __restrict__ cell_a, const float* __restrict__ cell_sc,
+                                                           float* __restrict__ cell_dz, float* __restrict__ cell_partials) {
+    __shared__ float red[256 * (FUSE ? 20 : 8)];
     const int C4 = C >> 2;
     const int tid = threadIdx.x;
     const int cg = tid % C4, slot = tid / C4, nslots = 256 / C4;
@@ -448,6 +455,8 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const float* __restri
     const long pend = (pbeg + PPB < NP) ? pbeg + PPB : NP;
     const float4 s = ld4(sc + cg * 4);
     float4 s_shift = f4(0.f), s_scale = f4(0.f);
+    float4 cs = f4(0.f), c_shift = f4(0.f), c_scale = f4(0.f), c_bias = f4(0.f);
+    if (FUSE) cs = ld4(cell_sc + cg * 4);
     for (long p = pbeg + slot; p < pend; p += nslots) {
         int b, hh, ww;
         if (!interior(p, HPWP, WP, H, W, b, hh, ww)) continue;
@@ -458,18 +467,44 @@ __global__ __launch_bounds__(256) void se_bwd_apply_kernel(const float* __restri
         s_scale = fma4(dxt, xv, s_scale);
         float4 d = mul4(dxt, s);
         if (add_dout) d = add4(d, g);
-        st4(dx + p * C + cg * 4, d);
+        if (!FUSE) {
+            st4(dx + p * C + cg * 4, d);
+        } else {                                         // cell_bwd_pre_kernel<0> on d = dL/dy of the cell
+            const float4 av = ld4(cell_a + p * C + cg * 4);
+            c_shift = add4(c_shift, d);
+            c_scale = fma4(d, av, c_scale);
+            float4 dd = mul4(d, cs);
+            dd.x = av.x > 0.f ? dd.x : 0.f; dd.y = av.y > 0.f ? dd.y : 0.f;
+            dd.z = av.z > 0.f ? dd.z : 0.f; dd.w = av.w > 0.f ? dd.w : 0.f;
+            c_bias = add4(c_bias, dd);
+            st4(cell_dz + p * C + cg * 4, dd);
+        }
     }
-    float* mine = red + tid * 8;
+    constexpr int RW = FUSE ? 20 : 8;
+    float* mine = red + tid * RW;
     mine[0] = s_scale.x; mine[1] = s_scale.y; mine[2] = s_scale.z; mine[3] = s_scale.w;
     mine[4] = s_shift.x; mine[5] = s_shift.y; mine[6] = s_shift.z; mine[7] = s_shift.w;
+    if (FUSE) {
+        mine[8] = c_scale.x; mine[9] = c_scale.y; mine[10] = c_scale.z; mine[11] = c_scale.w;
+        mine[12] = c_shift.x; mine[13] = c_shift.y; mine[14] = c_shift.z; mine[15] = c_shift.w;
+        mine[16] = c_bias.x; mine[17] = c_bias.y; mine[18] = c_bias.z; mine[19] = c_bias.w;
+    }
     __syncthreads();
     float* out = partials + (long)blockIdx.x * 2 * C;
     for (int i = tid; i < 2 * C; i += 256) {
         const int which = i / C, c = i - which * C;
         float sum = 0.f;
-        for (int sl = 0; sl < nslots; ++sl) sum += red[(sl * C4 + (c >> 2)) * 8 + which * 4 + (c & 3)];
+        for (int sl = 0; sl < nslots; ++sl) sum += red[(sl * C4 + (c >> 2)) * RW + which * 4 + (c & 3)];
         out[i] = sum;
+    }
+    if (FUSE) {
+        float* outc = cell_partials + (long)blockIdx.x * 3 * C;
+        for (int i = tid; i < 3 * C; i += 256) {
+            const int which = i / C, c = i - which * C;
+            float sum = 0.f;
+            for (int sl = 0; sl < nslots; ++sl) sum += red[(sl * C4 + (c >> 2)) * RW + 8 + which * 4 + (c & 3)];
+            outc[i] = sum;
+        }
     }
 }
 
@@ -641,11 +676,13 @@ extern "C" int asr_se_fwd(const float* main_in, const float* x, int B, int H, in
     return ASR_OK;
 }
 
-extern "C" int asr_se_bwd(const float* dout, const float* x, int B, int H, int W, int C, int hid,
-                          const float* bn_scale, const float* bn_shift, const float* w1, const float* w2,
-                          const float* state, int add_dout, float* dx, float* dscale, float* dshift,
-                          float* dw1, float* db1, float* dw2, float* db2, float* partials, void* stream) {
-    if (!dout || !x || !bn_scale || !bn_shift || !w1 || !w2 || !state || !dx || !dscale || !dshift || !dw1 ||
+struct SeCell { const float* a; const float* scale; float* dz; float* dscale; float* dshift; float* dbias; };
+
+static int se_bwd_impl(const float* dout, const float* x, int B, int H, int W, int C, int hid,
+                       const float* bn_scale, const float* bn_shift, const float* w1, const float* w2,
+                       const float* state, int add_dout, float* dx, float* dscale, float* dshift,
+                       float* dw1, float* db1, float* dw2, float* db2, float* partials, void* stream, const SeCell* cell) {
+    if (!dout || !x || !bn_scale || !bn_shift || !w1 || !w2 || !state || (!dx && !cell) || !dscale || !dshift || !dw1 ||
         !db1 || !dw2 || !db2 || !partials)
         return ASR_ERR_BAD_ARG;
     if (!chan_ok(C) || hid < 1 || hid > 1024) return ASR_ERR_BAD_ARG;
@@ -671,7 +708,13 @@ extern "C" int asr_se_bwd(const float* dout, const float* x, int B, int H, int W
         m.out[0] = dw1; m.out[1] = db1; m.out[2] = dw2; m.out[3] = db2;
         if ((rc = asr_reduce::colsum_multi(mlp_out, B, (long)per, m, tmp, st))) return rc;
     }
-    hipLaunchKernelGGL(se_bwd_apply_kernel, dim3(nblk), dim3(256), 0, st, dout, x, B, H, W, C, bn_scale, st_e, (const float*)dsb, add_dout, dx, part_apply, appb);
+    float* part_cell = tmp + asr_reduce::colsum_tmp_floats(nblk, 2 * C) + 64;      // asr_se_bwd_cell_workspace: [nblk][3 C] + its scratch behind the rest
+    if (cell)
+        hipLaunchKernelGGL(se_bwd_apply_kernel<true>, dim3(nblk), dim3(256), 0, st, dout, x, B, H, W, C, bn_scale, st_e, (const float*)dsb, add_dout, dx,
+                           part_apply, appb, cell->a, cell->scale, cell->dz, part_cell);
+    else
+        hipLaunchKernelGGL(se_bwd_apply_kernel<false>, dim3(nblk), dim3(256), 0, st, dout, x, B, H, W, C, bn_scale, st_e, (const float*)dsb, add_dout, dx,
+                           part_apply, appb, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr);
     ASR_CHECK_LAUNCH("se_bwd_apply");
     {
         asr_reduce::Multi m;
@@ -679,7 +722,41 @@ extern "C" int asr_se_bwd(const float* dout, const float* x, int B, int H, int W
         m.out[0] = dscale; m.out[1] = dshift; m.out[2] = nullptr; m.out[3] = nullptr;
         if ((rc = asr_reduce::colsum_multi(part_apply, nblk, 2 * C, m, tmp, st))) return rc;
     }
+    if (cell) {                                          // the reduction asr_cell_bwd_pre runs on the same block partials
+        asr_reduce::Multi m;
+        m.nseg = 3; m.width[0] = C; m.width[1] = C; m.width[2] = C; m.width[3] = 0;
+        m.out[0] = cell->dscale; m.out[1] = cell->dshift; m.out[2] = cell->dbias; m.out[3] = nullptr;
+        if ((rc = asr_reduce::colsum_multi(part_cell, nblk, 3 * C, m, part_cell + (size_t)nblk * 3 * C, st))) return rc;
+    }
     return ASR_OK;
+}
+
+extern "C" int asr_se_bwd(const float* dout, const float* x, int B, int H, int W, int C, int hid,
+                          const float* bn_scale, const float* bn_shift, const float* w1, const float* w2,
+                          const float* state, int add_dout, float* dx, float* dscale, float* dshift,
+                          float* dw1, float* db1, float* dw2, float* db2, float* partials, void* stream) {
+    if (!dx) return ASR_ERR_BAD_ARG;
+    return se_bwd_impl(dout, x, B, H, W, C, hid, bn_scale, bn_shift, w1, w2, state, add_dout, dx, dscale, dshift, dw1, db1, dw2, db2,
+                       partials, stream, nullptr);
+}
+
+extern "C" size_t asr_se_bwd_cell_workspace(int B, int H, int W, int C, int hid) {
+    const long NP = (long)B * (H + 1) * (W + 1);
+    const size_t nblk = (size_t)asr_cdiv(NP, se_apply_ppb(NP));
+    return asr_se_bwd_workspace(B, H, W, C, hid) + (nblk * 3 * C + asr_reduce::colsum_tmp_floats((int)nblk, 3 * C) + 64) * sizeof(float);
+}
+
+extern "C" int asr_se_bwd_cell(const float* dout, const float* x, int B, int H, int W, int C, int hid,
+                               const float* bn_scale, const float* bn_shift, const float* w1, const float* w2,
+                               const float* state, int add_dout, float* dscale, float* dshift,
+                               float* dw1, float* db1, float* dw2, float* db2,
+                               const float* cell_a, const float* cell_scale, float* cell_dz, float* cell_dscale, float* cell_dshift,
+                               float* cell_dbias, float* partials, void* stream) {
+    if (!cell_a || !cell_scale || !cell_dz || !cell_dscale || !cell_dshift || !cell_dbias) return ASR_ERR_BAD_ARG;
+    static_assert(sizeof(float) == 4, "");
+    SeCell c; c.a = cell_a; c.scale = cell_scale; c.dz = cell_dz; c.dscale = cell_dscale; c.dshift = cell_dshift; c.dbias = cell_dbias;
+    return se_bwd_impl(dout, x, B, H, W, C, hid, bn_scale, bn_shift, w1, w2, state, add_dout, nullptr, dscale, dshift, dw1, db1, dw2, db2,
+                       partials, stream, &c);
 }
 
 extern "C" int asr_axpy(float* dst, const float* src, size_t n, float alpha, int accumulate, void* stream) {

@@ -305,7 +305,8 @@ class DFCNNEngine:
                 self.res[dst] = (H, W, Cc)
                 self.y[dst] = Plane(B, H, W, Cc, dev)
                 self.se_state[dst] = torch.zeros(ops.se_state_floats(B, Cc, hid), dtype=torch.float32, device=dev)
-                ws_bytes = max(ws_bytes, ops.se_fwd_workspace(B, H, W, Cc), ops.se_bwd_workspace(B, H, W, Cc, hid))
+                ws_bytes = max(ws_bytes, ops.se_fwd_workspace(B, H, W, Cc), ops.se_bwd_workspace(B, H, W, Cc, hid),
+                               ops.se_bwd_cell_workspace(B, H, W, Cc, hid) + 4 * 4096)
             elif op[0] == 'dense':
                 _, src, dst, cin, cout, act = op
                 H = self.res[src][0]
@@ -419,6 +420,18 @@ class DFCNNEngine:
         # Max-pooled cells whose forward conv and whose gated data-gradient both run on the Winograd kernel keep no pre-pool
         # activation plane: the forward writes the activation at each window's maximum + its position, the backward reads those
         # (asr_tap_gemm_wino_poolmax / asr_tap_gemm_gated_poolmax: a quarter of the traffic, the same bits).  Widths and geometry only.
+        # SE blocks whose branch is a non-pooled conv cell that nothing else reads (acoustic_model2: cell -> squeeze-excitation): the SE
+        # backward's last pass also runs that cell's BN / ReLU backward (asr_se_bwd_cell) -- no dL/dy plane, no asr_cell_bwd_pre pass
+        self.se_cell = {}
+        if self.opt_fuse and os.environ.get('ASR_SE_FUSE', '1') != '0':
+            for op in self.g:
+                if op[0] != 'se':
+                    continue
+                br = op[2]
+                cell = next((c for c in self.g if c[0] == 'cell' and c[2] == br), None)
+                if cell is not None and cell[1] != 'x' and cell[6] is None and br not in self.dflat and br not in self.fuse.values() \
+                        and self.consumers.get(br, []) == [op]:
+                    self.se_cell[op[3]] = cell
         self.compact = {}
         for writer, tgt in (self.fuse.items() if os.environ.get('ASR_POOLMAX', '1') != '0' else ()):
             top = next(o for o in self.g if o[0] == 'cell' and o[2] == tgt)
@@ -730,6 +743,17 @@ class DFCNNEngine:
                 same = (main == br)
                 dx, acc = grad_target(br)
                 assert not acc
+                if dst in self.se_cell:
+                    # the branch cell's backward prologue in the same pass: its dZ plane and channel sums, no dL/dy plane
+                    cell = self.se_cell[dst]
+                    Hc, Wc, _ = self.res[cell[1]]
+                    dzt = acquire_dz((Hc, Wc, cell[4]))
+                    ops.se_bwd_cell(dout, self.y[br], hid, sc, sh, self.p(dst, 'w1'), self.p(dst, 'w2'), self.se_state[dst],
+                                    1 if same else 0, dsc, dsh, self.gview(dst, 'w1'), self.gview(dst, 'b1'),
+                                    self.gview(dst, 'w2'), self.gview(dst, 'b2'), self.a[br], self.scale_of(br), dzt,
+                                    self.dscale_of(br), self.gview(br, 'beta'), self.gview(br, 'b'), self.ws[:-2048])
+                    fused_dz[br] = dzt
+                    continue
                 ops.se_bwd(dout, self.y[br], hid, sc, sh, self.p(dst, 'w1'), self.p(dst, 'w2'), self.se_state[dst],
                            1 if same else 0, dx, dsc, dsh, self.gview(dst, 'w1'), self.gview(dst, 'b1'),
                            self.gview(dst, 'w2'), self.gview(dst, 'b2'), self.ws[:-2048])

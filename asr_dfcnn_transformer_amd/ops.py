@@ -262,6 +262,19 @@ def se_bwd(dout, x, hid, sc, sh, w1, w2, state, add_dout, dx, dscale, dshift, dw
                                  _ptr(dw2), _ptr(db2), _ptr(partials), _stream()), 'asr_se_bwd')
 
 
+def se_bwd_cell_workspace(B, H, W, Cc, hid):
+    return _lib.load().asr_se_bwd_cell_workspace(B, H, W, Cc, hid)
+
+
+def se_bwd_cell(dout, x, hid, sc, sh, w1, w2, state, add_dout, dscale, dshift, dw1, db1, dw2, db2, cell_a, cell_scale, cell_dz,
+                cell_dscale, cell_dshift, cell_dbias, partials):
+    """asr_se_bwd with the backward prologue of the conv cell that produced x fused in (asr_se_bwd_cell): no dx plane."""
+    check(_lib.load().asr_se_bwd_cell(dout.ptr, x.ptr, x.B, x.H, x.W, x.C, hid, _ptr(sc), _ptr(sh), _ptr(w1), _ptr(w2),
+                                      _ptr(state), add_dout, _ptr(dscale), _ptr(dshift), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2),
+                                      cell_a.ptr, _ptr(cell_scale), cell_dz.ptr, _ptr(cell_dscale), _ptr(cell_dshift), _ptr(cell_dbias),
+                                      _ptr(partials), _stream()), 'asr_se_bwd_cell')
+
+
 def axpy(dst, src, alpha=1.0, accumulate=False):
     check(_lib.load().asr_axpy(_ptr(dst), _ptr(src), dst.numel(), alpha, int(accumulate), _stream()), 'asr_axpy')
 

@@ -186,6 +186,19 @@ int asr_se_bwd(const float* dout, const float* x, int B, int H, int W, int C, in
                const float* bn_scale, const float* bn_shift, const float* w1, const float* w2,
                const float* state, int add_dout, float* dx, float* dscale, float* dshift,
                float* dw1, float* db1, float* dw2, float* db2, float* partials, void* stream);
+/* The same with the backward prologue of the conv cell that produced x fused in (round 4): when x is the BN output of a cell that
+ * nothing else reads (acoustic_model2.py:41,107-148: cell -> squeeze_excitation_layer), dx is that cell's complete output gradient, and
+ * instead of writing it and running asr_cell_bwd_pre(pool 0) over it, the same pass applies the cell's BN and ReLU backward:
+ * cell_dz (padded plane like x) = dL/d(conv + bias), cell_dscale / cell_dshift / cell_dbias [C] = its three channel sums; cell_a = the
+ * cell's post-ReLU pre-BN activations, cell_scale its BN scale.  dx is not produced.  Blocks, slots and summation order are those of
+ * the two calls it replaces: the same bits.  partials: asr_se_bwd_cell_workspace bytes. */
+size_t asr_se_bwd_cell_workspace(int B, int H, int W, int C, int hid);
+int asr_se_bwd_cell(const float* dout, const float* x, int B, int H, int W, int C, int hid,
+                    const float* bn_scale, const float* bn_shift, const float* w1, const float* w2,
+                    const float* state, int add_dout, float* dscale, float* dshift,
+                    float* dw1, float* db1, float* dw2, float* db2,
+                    const float* cell_a, const float* cell_scale, float* cell_dz, float* cell_dscale, float* cell_dshift,
+                    float* cell_dbias, float* partials, void* stream);
 /* dst (+)= src over the interior of a padded plane (residual gradient fan-in). */
 int asr_axpy(float* dst, const float* src, size_t n, float alpha, int accumulate, void* stream);
 

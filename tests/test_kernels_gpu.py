@@ -305,6 +305,28 @@ def test_se_fwd_bwd(ops, B, H, W, C, hid):
     report('se db1', db1.cpu().numpy(), g['b1'], 5e-5)
     report('se dw2', dw2.cpu().numpy().reshape(hid, C), g['w2'], 5e-5)
     report('se db2', db2.cpu().numpy(), g['b2'], 5e-5)
+    # asr_se_bwd_cell: the same with the backward prologue of the conv cell that produced x (a = its activations, x = BN(a)) fused in,
+    # against asr_se_bwd + asr_cell_bwd_pre(pool 0) on the dx plane: dZ and every sum bit for bit, with and without add_dout
+    a_np = np.maximum(rng.standard_normal((B, H, W, C)), 0).astype(np.float32)
+    ap = to_plane(ops, a_np)
+    csc, csh = dev(1 + 0.2 * rng.standard_normal(C)), dev(0.1 * rng.standard_normal(C))
+    for add in (0, 1):
+        ops.se_bwd(dop, xp, hid, sc, sh, w1, w2, state, add, dx, dsc, dsh, dw1, db1, dw2, db2, wsb)
+        dz1 = ops.Plane(B, H, W, C)
+        c1 = [torch.zeros(C, device='cuda') for _ in range(3)]
+        wsp = torch.zeros(ops.cell_bwd_pre_workspace(B, H, W, C) // 4 + 64, device='cuda')
+        ops.cell_bwd_pre(dx, 0, ap, csc, csh, 0, dz1, c1[0], c1[1], c1[2], wsp)
+        want = [t.clone() for t in (dsc, dsh, dw1, db1, dw2, db2)]
+        got = [torch.zeros_like(t) for t in want]
+        dz2 = ops.Plane(B, H, W, C)
+        c2 = [torch.zeros(C, device='cuda') for _ in range(3)]
+        wsc = torch.zeros(ops.se_bwd_cell_workspace(B, H, W, C, hid) // 4 + 4, device='cuda')
+        ops.se_bwd_cell(dop, xp, hid, sc, sh, w1, w2, state, add, got[0], got[1], got[2], got[3], got[4], got[5],
+                        ap, csc, dz2, c2[0], c2[1], c2[2], wsc)
+        assert torch.equal(dz1.buf, dz2.buf)
+        check_border_zero(dz2)
+        for u, v in zip(c1 + want, c2 + got):
+            assert torch.equal(u, v)
 
 
 # ------------------------------------------------------------------ head
