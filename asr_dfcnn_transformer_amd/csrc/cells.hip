@@ -299,31 +299,54 @@ __global__ __launch_bounds__(256) void cell_bwd_pre_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ squeeze-excitation
-constexpr int kSePPB = 512;
+// pixels of one image per se_reduce workgroup: enough workgroups to keep an HBM-bound pass fed on the small planes
+// (200 x 25: 41 x B instead of 11 x B), a function of the plane geometry only
+inline int se_ppb(int H, int W) {
+    const long hpwp = (long)(H + 1) * (W + 1);
+    return hpwp >= 40000 ? 512 : (hpwp >= 12000 ? 256 : 128);
+}
 
-// partial[b][split][C] = sum over a pixel range of image b of x (MODE 0) or dout*(sc*x+sh) (MODE 1)
+// partial[b][split][C] = sum over a pixel range of image b of x (MODE 0) or dout*(sc*x+sh) (MODE 1).
+// Four independent loads per lane and trip, all unconditional (a border / out-of-range pixel reads a clamped address and its
+// term is dropped by a select): with one load in flight per lane the small planes ran at 2.8 TB/s.
 template <int MODE>
 __global__ __launch_bounds__(256) void se_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dout,
-                                                        int H, int W, int C, const float* __restrict__ sc,
+                                                        int H, int W, int C, int ppb, const float* __restrict__ sc,
                                                         const float* __restrict__ sh, float* __restrict__ partials) {
     __shared__ float red[256 * 4];
     const int C4 = C >> 2;
     const int tid = threadIdx.x;
     const int cg = tid % C4, slot = tid / C4, nslots = 256 / C4;
     const int WP = W + 1, HPWP = (H + 1) * WP;
+    const float invwp = 1.0f / (float)WP;
     const int b = blockIdx.y;
     const long base = (long)b * HPWP;
-    const int pbeg = blockIdx.x * kSePPB;
-    const int pend = (pbeg + kSePPB < HPWP) ? pbeg + kSePPB : HPWP;
+    const int pbeg = blockIdx.x * ppb;
+    const int pend = (pbeg + ppb < HPWP) ? pbeg + ppb : HPWP;
     float4 acc = f4(0.f);
     float4 s = f4(1.f), h = f4(0.f);
     if (MODE == 1) { s = ld4(sc + cg * 4); h = ld4(sh + cg * 4); }
-    for (int r = pbeg + slot; r < pend; r += nslots) {
-        const int hh = r / WP, ww = r - hh * WP;
-        if (hh < 1 || hh > H || ww < 1 || ww > W) continue;
-        const float4 xv = ld4(x + (base + r) * C + cg * 4);
-        if (MODE == 0) acc = add4(acc, xv);
-        else acc = fma4(ld4(dout + (base + r) * C + cg * 4), fma4(s, xv, h), acc);
+    constexpr int U = 4;
+    for (int r0 = pbeg + slot; r0 < pend; r0 += U * nslots) {
+        float4 xv[U], gv[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + u * nslots;
+            const int rc = r < pend ? r : pend - 1;
+            // row of the pixel: (rc + 0.5) / WP is at least 0.5 / WP away from an integer, float error is ~1e-4 of that
+            const int hh = (int)(((float)rc + 0.5f) * invwp), ww = rc - hh * WP;
+            ok[u] = r < pend && hh >= 1 && ww >= 1;                 // hh <= H and ww <= W hold for every pixel of an image
+            xv[u] = ld4(x + (base + rc) * C + cg * 4);
+            if (MODE == 1) gv[u] = ld4(dout + (base + rc) * C + cg * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float4 t;
+            if (MODE == 0) t = add4(acc, xv[u]);
+            else t = fma4(gv[u], fma4(s, xv[u], h), acc);
+            acc.x = ok[u] ? t.x : acc.x; acc.y = ok[u] ? t.y : acc.y; acc.z = ok[u] ? t.z : acc.z; acc.w = ok[u] ? t.w : acc.w;
+        }
     }
     float* mine = red + tid * 4;
     mine[0] = acc.x; mine[1] = acc.y; mine[2] = acc.z; mine[3] = acc.w;
@@ -336,6 +359,75 @@ __global__ __launch_bounds__(256) void se_reduce_kernel(const float* __restrict_
     }
 }
 
+// fold of the split partials of image b, all 256 threads: thread (g, c) adds partials g, g + G, ... of channel c (G = 256 / C
+// groups, four loads in flight), the groups are then added in the order g = 0 .. G-1 -- a fixed order, bitwise reproducible.
+// Result in dst[C] (LDS); scratch [256] floats.  Ends with a barrier.
+__device__ __forceinline__ void se_fold_partials(const float* __restrict__ part, int nsplit, int C, float* scratch, float* dst) {
+    const int tid = threadIdx.x;
+    if (C <= 256) {
+        const int G = 256 / C, c = tid % C, g = tid / C;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (g < G) {
+            int k = g;
+            for (; k + 3 * G < nsplit; k += 4 * G) {
+                const float v0 = part[(long)k * C + c], v1 = part[(long)(k + G) * C + c];
+                const float v2 = part[(long)(k + 2 * G) * C + c], v3 = part[(long)(k + 3 * G) * C + c];
+                a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+            }
+            for (; k < nsplit; k += G) a0 += part[(long)k * C + c];
+            scratch[g * C + c] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        if (tid < C) {
+            float sum = 0.f;
+            for (int gg = 0; gg < G; ++gg) sum += scratch[gg * C + tid];
+            dst[tid] = sum;
+        }
+    } else {
+        for (int c = tid; c < C; c += 256) {
+            float sum = 0.f;
+            for (int k = 0; k < nsplit; ++k) sum += part[(long)k * C + c];
+            dst[c] = sum;
+        }
+    }
+    __syncthreads();
+}
+
+// out[j] = sum_c in[c] * Wm[c * ldr + j * ldc]  for j < nout, contraction over nin, all 256 threads: thread (g, j) takes the
+// terms c = g, g + G, ...; groups folded in fixed order.  scratch [256]; result via the callback on threads j < nout after
+// the barrier.  (nout <= 256; otherwise one thread per output walks the whole contraction.)
+template <class F>
+__device__ __forceinline__ void se_matvec(const float* in, const float* __restrict__ Wm, int nin, int nout, long ldr, long ldc,
+                                          float* scratch, F&& done) {
+    const int tid = threadIdx.x;
+    if (nout <= 256) {
+        const int G = 256 / nout, j = tid % nout, g = tid / nout;
+        if (g < G) {
+            float a0 = 0.f, a1 = 0.f;
+            int c = g;
+            for (; c + G < nin; c += 2 * G) {
+                a0 = fmaf(in[c], Wm[(long)c * ldr + (long)j * ldc], a0);
+                a1 = fmaf(in[c + G], Wm[(long)(c + G) * ldr + (long)j * ldc], a1);
+            }
+            if (c < nin) a0 = fmaf(in[c], Wm[(long)c * ldr + (long)j * ldc], a0);
+            scratch[g * nout + j] = a0 + a1;
+        }
+        __syncthreads();
+        if (tid < nout) {
+            float sum = 0.f;
+            for (int gg = 0; gg < G; ++gg) sum += scratch[gg * nout + tid];
+            done(tid, sum);
+        }
+    } else {
+        for (int j = tid; j < nout; j += 256) {
+            float sum = 0.f;
+            for (int c = 0; c < nin; ++c) sum = fmaf(in[c], Wm[(long)c * ldr + (long)j * ldc], sum);
+            done(j, sum);
+        }
+    }
+    __syncthreads();
+}
+
 // one block per image: fold the split partials, run the 2-layer excitation MLP
 __global__ __launch_bounds__(256) void se_excite_kernel(const float* __restrict__ partials, int nsplit, int H, int W,
                                                         int C, int hid, const float* __restrict__ sc,
@@ -346,27 +438,22 @@ __global__ __launch_bounds__(256) void se_excite_kernel(const float* __restrict_
     extern __shared__ float sm[];
     float* s = sm;            // [C]
     float* r = sm + C;        // [hid]
+    float* scratch = r + hid; // [256]
     const int b = blockIdx.x, tid = threadIdx.x;
     const float inv = 1.f / (float)(H * W);
+    se_fold_partials(partials + (long)b * nsplit * C, nsplit, C, scratch, s);
     for (int c = tid; c < C; c += 256) {
-        float sum = 0.f;
-        for (int k = 0; k < nsplit; ++k) sum += partials[((long)b * nsplit + k) * C + c];
-        const float v = fmaf(sc[c], sum * inv, sh[c]);
+        const float v = fmaf(sc[c], s[c] * inv, sh[c]);
         s[c] = v; st_s[(long)b * C + c] = v;
     }
     __syncthreads();
-    for (int j = tid; j < hid; j += 256) {
-        float u = b1[j];
-        for (int c = 0; c < C; ++c) u = fmaf(s[c], w1[(long)c * hid + j], u);
-        u = fmaxf(u, 0.f);
+    se_matvec(s, w1, C, hid, hid, 1, scratch, [&](int j, float sum) {
+        const float u = fmaxf(sum + b1[j], 0.f);
         r[j] = u; st_r[(long)b * hid + j] = u;
-    }
-    __syncthreads();
-    for (int c = tid; c < C; c += 256) {
-        float v = b2[c];
-        for (int j = 0; j < hid; ++j) v = fmaf(r[j], w2[(long)j * C + c], v);
-        st_e[(long)b * C + c] = 1.f / (1.f + expf(-v));
-    }
+    });
+    se_matvec(r, w2, hid, C, C, 1, scratch, [&](int c, float sum) {
+        st_e[(long)b * C + c] = 1.f / (1.f + expf(-(sum + b2[c])));
+    });
 }
 
 __global__ void se_apply_kernel(const float* __restrict__ main_in, const float* __restrict__ x, int B, int H, int W,
@@ -394,26 +481,23 @@ __global__ __launch_bounds__(256) void se_bwd_mlp_kernel(const float* __restrict
     extern __shared__ float sm[];
     float* dv = sm;            // [C]
     float* du = sm + C;        // [hid]
+    float* scratch = du + hid; // [256]
     const int b = blockIdx.x, tid = threadIdx.x;
     const long per = (long)C * hid + hid + (long)hid * C + C;
     float* o = out_b + (long)b * per;
     float* o_dw1 = o; float* o_db1 = o + (long)C * hid; float* o_dw2 = o_db1 + hid; float* o_db2 = o_dw2 + (long)hid * C;
+    se_fold_partials(partials + (long)b * nsplit * C, nsplit, C, scratch, dv);
     for (int c = tid; c < C; c += 256) {
-        float de = 0.f;
-        for (int k = 0; k < nsplit; ++k) de += partials[((long)b * nsplit + k) * C + c];
         const float e = st_e[(long)b * C + c];
-        const float v = de * e * (1.f - e);
+        const float v = dv[c] * e * (1.f - e);
         dv[c] = v; o_db2[c] = v;
     }
     __syncthreads();
-    for (int j = tid; j < hid; j += 256) {
-        float dr = 0.f;
-        for (int c = 0; c < C; ++c) dr = fmaf(dv[c], w2[(long)j * C + c], dr);
+    se_matvec(dv, w2, C, hid, 1, C, scratch, [&](int j, float dr) {
         const float rj = st_r[(long)b * hid + j];
         const float u = rj > 0.f ? dr : 0.f;
         du[j] = u; o_db1[j] = u;
-    }
-    __syncthreads();
+    });
     for (int i = tid; i < hid * C; i += 256) {
         const int j = i / C, c = i - j * C;
         o_dw2[i] = st_r[(long)b * hid + j] * dv[c];
@@ -423,11 +507,7 @@ __global__ __launch_bounds__(256) void se_bwd_mlp_kernel(const float* __restrict
         o_dw1[i] = st_s[(long)b * C + c] * du[j];
     }
     const float inv = 1.f / (float)(H * W);
-    for (int c = tid; c < C; c += 256) {
-        float ds = 0.f;
-        for (int j = 0; j < hid; ++j) ds = fmaf(du[j], w1[(long)c * hid + j], ds);
-        dsb[(long)b * C + c] = ds * inv;
-    }
+    se_matvec(du, w1, hid, C, 1, hid, scratch, [&](int c, float ds) { dsb[(long)b * C + c] = ds * inv; });
 }
 
 inline int se_apply_ppb(long NP) { return NP >= (4L << 20) ? 1024 : (NP >= (1L << 20) ? 512 : 128); }
@@ -643,7 +723,7 @@ extern "C" int asr_cell_bwd_pre(const float* dy, int dy_layout, const float* a, 
 
 extern "C" size_t asr_se_state_floats(int B, int C, int hid) { return (size_t)B * (2 * C + hid); }
 
-static inline int se_nsplit(int H, int W) { return asr_cdiv((long)(H + 1) * (W + 1), kSePPB); }
+static inline int se_nsplit(int H, int W) { return asr_cdiv((long)(H + 1) * (W + 1), se_ppb(H, W)); }
 
 extern "C" size_t asr_se_fwd_workspace(int B, int H, int W, int C) {
     return ((size_t)B * se_nsplit(H, W) * C + 64) * sizeof(float);
@@ -668,8 +748,8 @@ extern "C" int asr_se_fwd(const float* main_in, const float* x, int B, int H, in
     hipStream_t st = (hipStream_t)stream;
     const int ns = se_nsplit(H, W);
     float* st_s = state; float* st_r = st_s + (size_t)B * C; float* st_e = st_r + (size_t)B * hid;
-    hipLaunchKernelGGL(se_reduce_kernel<0>, dim3(ns, B), dim3(256), 0, st, x, (const float*)nullptr, H, W, C, bn_scale, bn_shift, partials);
-    hipLaunchKernelGGL(se_excite_kernel, dim3(B), dim3(256), (size_t)(C + hid) * sizeof(float), st, (const float*)partials, ns, H, W, C, hid, bn_scale, bn_shift, w1, b1, w2, b2, st_s, st_r, st_e);
+    hipLaunchKernelGGL(se_reduce_kernel<0>, dim3(ns, B), dim3(256), 0, st, x, (const float*)nullptr, H, W, C, se_ppb(H, W), bn_scale, bn_shift, partials);
+    hipLaunchKernelGGL(se_excite_kernel, dim3(B), dim3(256), (size_t)(C + hid + 256) * sizeof(float), st, (const float*)partials, ns, H, W, C, hid, bn_scale, bn_shift, w1, b1, w2, b2, st_s, st_r, st_e);
     const long total = (long)B * (H + 1) * (W + 1) * (C / 4);
     hipLaunchKernelGGL(se_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, main_in, x, B, H, W, C, bn_scale, bn_shift, (const float*)st_e, out);
     ASR_CHECK_LAUNCH("se_fwd");
@@ -698,8 +778,8 @@ static int se_bwd_impl(const float* dout, const float* x, int B, int H, int W, i
     float* part_apply = dsb + (size_t)B * C;
     float* tmp = part_apply + (size_t)nblk * 2 * C;
     const float* st_s = state; const float* st_r = st_s + (size_t)B * C; const float* st_e = st_r + (size_t)B * hid;
-    hipLaunchKernelGGL(se_reduce_kernel<1>, dim3(ns, B), dim3(256), 0, st, x, dout, H, W, C, bn_scale, bn_shift, part_red);
-    hipLaunchKernelGGL(se_bwd_mlp_kernel, dim3(B), dim3(256), (size_t)(C + hid) * sizeof(float), st, (const float*)part_red, ns, H, W, C, hid, w1, w2, st_s, st_r, st_e, mlp_out, dsb);
+    hipLaunchKernelGGL(se_reduce_kernel<1>, dim3(ns, B), dim3(256), 0, st, x, dout, H, W, C, se_ppb(H, W), bn_scale, bn_shift, part_red);
+    hipLaunchKernelGGL(se_bwd_mlp_kernel, dim3(B), dim3(256), (size_t)(C + hid + 256) * sizeof(float), st, (const float*)part_red, ns, H, W, C, hid, w1, w2, st_s, st_r, st_e, mlp_out, dsb);
     ASR_CHECK_LAUNCH("se_bwd_mlp");
     int rc;
     {
