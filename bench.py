@@ -162,7 +162,8 @@ def run_am_lm(args):
     from asr_dfcnn_transformer_amd.engine import step_flops_per_utt
     from asr_dfcnn_transformer_amd.wav_util import FbankExtractor
     rank, world, local = init_from_env()
-    local = int(os.environ.get('ASR_BENCH_DEVICE', local))     # a priming child runs on its parent's GPU
+    if 'ASR_BENCH_DEVICE' in os.environ:                        # a priming child runs on its parent's GPU
+        local = int(os.environ['ASR_BENCH_DEVICE']) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     B, T, F, VP, VH, blocks = args.batch, args.tpad, 200, 1536, 6345, 12
     eng = AMLMEngine(v_pinyin=VP, v_hanzi=VH, B=B, T=T, F=F, blocks=blocks, pos_max=T // 8, dropout_rate=args.dropout,
@@ -255,7 +256,8 @@ def run_lm(args):
     from asr_dfcnn_transformer_amd.parallel import init_from_env, BucketedAllReduce
     from asr_dfcnn_transformer_amd.transformer_engine import LMEngine
     rank, world, local = init_from_env()
-    local = int(os.environ.get('ASR_BENCH_DEVICE', local))     # a priming child runs on its parent's GPU
+    if 'ASR_BENCH_DEVICE' in os.environ:                        # a priming child runs on its parent's GPU
+        local = int(os.environ['ASR_BENCH_DEVICE']) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     N, T, C, H, blocks, Vin, Vout = (args.batch if args.batch != 32 else 64), 100, 512, 8, 12, 1536, 6345
     eng = LMEngine(vin=Vin, vout=Vout, N=N, T=T, C=C, heads=H, blocks=blocks, pos_max=100, dropout_rate=args.dropout, drop_seed=rank)
@@ -325,7 +327,8 @@ def run_transformer(args):
     from asr_dfcnn_transformer_amd.transformer_engine import E2EEngine
     from asr_dfcnn_transformer_amd.prenet_engine import PreNetEngine, fwd_flops_per_seq
     rank, world, local = init_from_env()
-    local = int(os.environ.get('ASR_BENCH_DEVICE', local))     # a priming child runs on its parent's GPU
+    if 'ASR_BENCH_DEVICE' in os.environ:                        # a priming child runs on its parent's GPU
+        local = int(os.environ['ASR_BENCH_DEVICE']) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     prenet = args.workload == 'e2e_prenet'
     N, T, C, H, blocks, Vin, Vout = args.batch if args.batch != 32 else 64, 512, 512, 8, 6, 1536, 6347
@@ -588,7 +591,8 @@ def main():
     from asr_dfcnn_transformer_amd.wav_util import FbankExtractor
 
     rank, world, local = init_from_env()
-    local = int(os.environ.get('ASR_BENCH_DEVICE', local))     # a priming child runs on its parent's GPU
+    if 'ASR_BENCH_DEVICE' in os.environ:                        # a priming child runs on its parent's GPU
+        local = int(os.environ['ASR_BENCH_DEVICE']) % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = 'cuda'
     variant = 'm1' if args.workload == 'dfcnn' else 'm2'
