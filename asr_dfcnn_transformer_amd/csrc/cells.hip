@@ -299,54 +299,35 @@ __global__ __launch_bounds__(256) void cell_bwd_pre_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------ squeeze-excitation
-// pixels of one image per se_reduce workgroup: enough workgroups to keep an HBM-bound pass fed on the small planes
-// (200 x 25: 41 x B instead of 11 x B), a function of the plane geometry only
-inline int se_ppb(int H, int W) {
-    const long hpwp = (long)(H + 1) * (W + 1);
-    return hpwp >= 40000 ? 512 : (hpwp >= 12000 ? 256 : 128);
-}
+// One 16-byte load in flight per lane and 512 pixels per workgroup ON PURPOSE: a form with four unconditional loads per trip and
+// plane-sized pixel ranges runs the small planes at 5 instead of 2.8 TB/s alone (se_reduce<0> 45 -> 31 us per launch), but in the
+// two-stream step, beside the weight-gradient kernels of the other stream, it made the SE-DFCNN step 0.15 ms SLOWER (same box,
+// three rounds: 14.43 -> 14.59 ms) -- the trickle hides under the matrix kernels, the burst does not.
+constexpr int kSePPB = 512;
 
-// partial[b][split][C] = sum over a pixel range of image b of x (MODE 0) or dout*(sc*x+sh) (MODE 1).
-// Four independent loads per lane and trip, all unconditional (a border / out-of-range pixel reads a clamped address and its
-// term is dropped by a select): with one load in flight per lane the small planes ran at 2.8 TB/s.
+// partial[b][split][C] = sum over a pixel range of image b of x (MODE 0) or dout*(sc*x+sh) (MODE 1)
 template <int MODE>
 __global__ __launch_bounds__(256) void se_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dout,
-                                                        int H, int W, int C, int ppb, const float* __restrict__ sc,
+                                                        int H, int W, int C, const float* __restrict__ sc,
                                                         const float* __restrict__ sh, float* __restrict__ partials) {
     __shared__ float red[256 * 4];
     const int C4 = C >> 2;
     const int tid = threadIdx.x;
     const int cg = tid % C4, slot = tid / C4, nslots = 256 / C4;
     const int WP = W + 1, HPWP = (H + 1) * WP;
-    const float invwp = 1.0f / (float)WP;
     const int b = blockIdx.y;
     const long base = (long)b * HPWP;
-    const int pbeg = blockIdx.x * ppb;
-    const int pend = (pbeg + ppb < HPWP) ? pbeg + ppb : HPWP;
+    const int pbeg = blockIdx.x * kSePPB;
+    const int pend = (pbeg + kSePPB < HPWP) ? pbeg + kSePPB : HPWP;
     float4 acc = f4(0.f);
     float4 s = f4(1.f), h = f4(0.f);
     if (MODE == 1) { s = ld4(sc + cg * 4); h = ld4(sh + cg * 4); }
-    constexpr int U = 4;
-    for (int r0 = pbeg + slot; r0 < pend; r0 += U * nslots) {
-        float4 xv[U], gv[U];
-        bool ok[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int r = r0 + u * nslots;
-            const int rc = r < pend ? r : pend - 1;
-            // row of the pixel: (rc + 0.5) / WP is at least 0.5 / WP away from an integer, float error is ~1e-4 of that
-            const int hh = (int)(((float)rc + 0.5f) * invwp), ww = rc - hh * WP;
-            ok[u] = r < pend && hh >= 1 && ww >= 1;                 // hh <= H and ww <= W hold for every pixel of an image
-            xv[u] = ld4(x + (base + rc) * C + cg * 4);
-            if (MODE == 1) gv[u] = ld4(dout + (base + rc) * C + cg * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            float4 t;
-            if (MODE == 0) t = add4(acc, xv[u]);
-            else t = fma4(gv[u], fma4(s, xv[u], h), acc);
-            acc.x = ok[u] ? t.x : acc.x; acc.y = ok[u] ? t.y : acc.y; acc.z = ok[u] ? t.z : acc.z; acc.w = ok[u] ? t.w : acc.w;
-        }
+    for (int r = pbeg + slot; r < pend; r += nslots) {
+        const int hh = r / WP, ww = r - hh * WP;
+        if (hh < 1 || hh > H || ww < 1 || ww > W) continue;
+        const float4 xv = ld4(x + (base + r) * C + cg * 4);
+        if (MODE == 0) acc = add4(acc, xv);
+        else acc = fma4(ld4(dout + (base + r) * C + cg * 4), fma4(s, xv, h), acc);
     }
     float* mine = red + tid * 4;
     mine[0] = acc.x; mine[1] = acc.y; mine[2] = acc.z; mine[3] = acc.w;
@@ -723,7 +704,7 @@ extern "C" int asr_cell_bwd_pre(const float* dy, int dy_layout, const float* a, 
 
 extern "C" size_t asr_se_state_floats(int B, int C, int hid) { return (size_t)B * (2 * C + hid); }
 
-static inline int se_nsplit(int H, int W) { return asr_cdiv((long)(H + 1) * (W + 1), se_ppb(H, W)); }
+static inline int se_nsplit(int H, int W) { return asr_cdiv((long)(H + 1) * (W + 1), kSePPB); }
 
 extern "C" size_t asr_se_fwd_workspace(int B, int H, int W, int C) {
     return ((size_t)B * se_nsplit(H, W) * C + 64) * sizeof(float);
@@ -748,7 +729,7 @@ extern "C" int asr_se_fwd(const float* main_in, const float* x, int B, int H, in
     hipStream_t st = (hipStream_t)stream;
     const int ns = se_nsplit(H, W);
     float* st_s = state; float* st_r = st_s + (size_t)B * C; float* st_e = st_r + (size_t)B * hid;
-    hipLaunchKernelGGL(se_reduce_kernel<0>, dim3(ns, B), dim3(256), 0, st, x, (const float*)nullptr, H, W, C, se_ppb(H, W), bn_scale, bn_shift, partials);
+    hipLaunchKernelGGL(se_reduce_kernel<0>, dim3(ns, B), dim3(256), 0, st, x, (const float*)nullptr, H, W, C, bn_scale, bn_shift, partials);
     hipLaunchKernelGGL(se_excite_kernel, dim3(B), dim3(256), (size_t)(C + hid + 256) * sizeof(float), st, (const float*)partials, ns, H, W, C, hid, bn_scale, bn_shift, w1, b1, w2, b2, st_s, st_r, st_e);
     const long total = (long)B * (H + 1) * (W + 1) * (C / 4);
     hipLaunchKernelGGL(se_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, main_in, x, B, H, W, C, bn_scale, bn_shift, (const float*)st_e, out);
@@ -778,7 +759,7 @@ static int se_bwd_impl(const float* dout, const float* x, int B, int H, int W, i
     float* part_apply = dsb + (size_t)B * C;
     float* tmp = part_apply + (size_t)nblk * 2 * C;
     const float* st_s = state; const float* st_r = st_s + (size_t)B * C; const float* st_e = st_r + (size_t)B * hid;
-    hipLaunchKernelGGL(se_reduce_kernel<1>, dim3(ns, B), dim3(256), 0, st, x, dout, H, W, C, se_ppb(H, W), bn_scale, bn_shift, part_red);
+    hipLaunchKernelGGL(se_reduce_kernel<1>, dim3(ns, B), dim3(256), 0, st, x, dout, H, W, C, bn_scale, bn_shift, part_red);
     hipLaunchKernelGGL(se_bwd_mlp_kernel, dim3(B), dim3(256), (size_t)(C + hid + 256) * sizeof(float), st, (const float*)part_red, ns, H, W, C, hid, w1, w2, st_s, st_r, st_e, mlp_out, dsb);
     ASR_CHECK_LAUNCH("se_bwd_mlp");
     int rc;
