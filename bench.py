@@ -565,6 +565,9 @@ def main():
     ap.add_argument('--host-input', action='store_true',
                     help='DFCNN workloads: hand every batch over as a (pinned) HOST buffer, i.e. put the PCIe copy of the raw '
                          'audio inside the timed region (DESIGN.md section 6; never the reported headline)')
+    ap.add_argument('--inference', action='store_true',
+                    help='DFCNN workloads: time fbank + forward + greedy decode only (the predict / speech_test path: cnn_ctc.py:67-83, '
+                         'lm_and_am/test.py:44-61); a separate metric, never the headline')
     ap.add_argument('--prime-steps', type=int, default=40,
                     help='untimed steps of the same workload in a child process before this one touches the GPU (0: none); '
                          'see prime_gpu()')
@@ -655,15 +658,18 @@ def main():
                 # after the conv stack: the latency-bound fbank fills the chip while the (equally latency-bound) CTC lattice /
                 # decode / small head GEMMs run, and the forward contractions keep the chip to themselves
                 produce(cur ^ 1)
-            eng.set_targets(seq, target)
-            eng.loss_and_decode(defer_decode_join=True)
-            if world > 1:
-                eng.backward(on_dense_grads_ready=lambda: red.launch(0))
-                red.launch(1); red.launch(2)
-                red.wait()
+            if args.inference:
+                ops.ctc_greedy(eng.logits, eng.T8, B, V, eng.seq_len, V - 1, eng.dec_ids, eng.dec_len, eng.neg_sum, eng.dec_ws)
             else:
-                eng.backward()
-            eng.apply_adam(red.grad_scale)
+                eng.set_targets(seq, target)
+                eng.loss_and_decode(defer_decode_join=True)
+                if world > 1:
+                    eng.backward(on_dense_grads_ready=lambda: red.launch(0))
+                    red.launch(1); red.launch(2)
+                    red.wait()
+                else:
+                    eng.backward()
+                eng.apply_adam(red.grad_scale)
         finally:
             eng.side = side
         if pf:
@@ -677,6 +683,8 @@ def main():
             dist.barrier()
 
     single_feat = torch.empty(B, T, F, dtype=torch.float32, device=dev) if prefetch else None
+    if args.inference:
+        eng.set_targets(seq, target)                 # the sequence lengths the decoder reads
     # Warm-up: W untimed steps.  One of them (the second to last; with W < 3 an extra step in front of the last) runs on ONE
     # stream with every contraction kernel between HIP events: its table decides which kernel symbol is the dominant one
     # (most time in the step, forward or backward) -- with the two-stream backward of the real step, durations of
@@ -716,7 +724,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    mean_loss, label_err = eng.fetch_scalars()
+    mean_loss, label_err = (0.0, 0.0) if args.inference else eng.fetch_scalars()
 
     # Roofline pass (after the timed region, never part of `value`): when the dominant kernel overlaps with others in the real
     # step, its launch duration is measured in min(K, 5) single-stream steps of the same workload.
@@ -732,18 +740,19 @@ def main():
 
     if rank == 0:
         utt_s = world * B * args.steps / dt
-        fstep = step_flops_per_utt(eng.g, T, F)
+        fstep = fwd_flops_per_utt(eng.g, T, F)[0] if args.inference else step_flops_per_utt(eng.g, T, F)
         step_ms = 1e3 * dt / args.steps
         out = {
-            'metric': 'utterances/sec (10 s audio, B=32) DFCNN+CTC fwd+bwd',
+            'metric': ('utterances/sec (10 s audio, B=32) DFCNN forward + greedy decode (inference; not the headline metric)' if args.inference
+                       else 'utterances/sec (10 s audio, B=32) DFCNN+CTC fwd+bwd'),
             'value': round(utt_s, 3), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(step_ms, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
             'config': {'workload': ('plain DFCNN (acoustic_model.py) + CTC' if variant == 'm1' else
                                     'SE-DFCNN (acoustic_model2.py) + CTC') +
-                                   ', fbank+fwd+CTC+greedy+bwd+Adam, 10 s/16 kHz audio, T_pad %d, V %d' % (T, V),
+                                   (', fbank+fwd+greedy decode' if args.inference else ', fbank+fwd+CTC+greedy+bwd+Adam') + ', 10 s/16 kHz audio, T_pad %d, V %d' % (T, V),
                        'global_batch': world * B, 'batch_per_gpu': B, 't_pad': T, 'parallelism': 'dp%d' % world, **dp_info(),
-                       'gflop_per_utt_fwd_bwd': round(fstep / 1e9, 3), 'host_enqueue_ms_per_step': round(1e3 * t_enq / args.steps, 3),
+                       ('gflop_per_utt_fwd' if args.inference else 'gflop_per_utt_fwd_bwd'): round(fstep / 1e9, 3), 'host_enqueue_ms_per_step': round(1e3 * t_enq / args.steps, 3),
                        'step_algorithmic_tflops': round(utt_s / world * fstep / 1e12, 2),
                        'step_algorithmic_frac_of_fp32_peak': round(utt_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
                        'step_flops_note': 'direct-convolution flops (SURVEY 8d); the Winograd layers execute 1/2.25 of their multiplies, '
