@@ -743,7 +743,7 @@ def main():
         fstep = fwd_flops_per_utt(eng.g, T, F)[0] if args.inference else step_flops_per_utt(eng.g, T, F)
         step_ms = 1e3 * dt / args.steps
         out = {
-            'metric': ('utterances/sec (10 s audio, B=32) DFCNN forward + greedy decode (inference; not the headline metric)' if args.inference
+            'metric': ('utterances/sec (10 s audio, B=%d) DFCNN forward + greedy decode (inference; not the headline metric)' % B if args.inference
                        else 'utterances/sec (10 s audio, B=32) DFCNN+CTC fwd+bwd'),
             'value': round(utt_s, 3), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(step_ms, 3), 'higher_is_better': True,
