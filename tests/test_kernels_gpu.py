@@ -267,7 +267,10 @@ def test_pool_and_cell_bwd_pre(ops, pool, B, H, W, C):
 
 
 # ------------------------------------------------------------------ SE
-@pytest.mark.parametrize("B,H,W,C,hid", [(2, 10, 8, 32, 32), (3, 50, 45, 64, 32), (2, 20, 25, 128, 64)])
+# (2, 200, 101, 16, 12): 40 split partials over sixteen thread groups, a hidden width that does not divide 256;
+# (1, 9, 7, 512, 300): more channels / hidden units than threads (the one-thread-per-output paths of se_fold_partials / se_matvec)
+@pytest.mark.parametrize("B,H,W,C,hid", [(2, 10, 8, 32, 32), (3, 50, 45, 64, 32), (2, 20, 25, 128, 64), (2, 200, 101, 16, 12),
+                                         (1, 9, 7, 512, 300)])
 def test_se_fwd_bwd(ops, B, H, W, C, hid):
     rng = np.random.default_rng(8)
     x = rng.standard_normal((B, H, W, C)).astype(np.float32)
