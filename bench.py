@@ -532,7 +532,7 @@ def prime_gpu(steps):
     cmd = [sys.executable, os.path.abspath(__file__)] + argv + ['--gpus', '1', '--steps', str(steps), '--warmup', '3',
                                                                 '--prime-steps', '0', '--no-cpu-baseline']
     try:
-        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=180)
         if r.returncode != 0:
             print('bench.py: priming child exited with %d (ignored)' % r.returncode, file=sys.stderr)
             return None
