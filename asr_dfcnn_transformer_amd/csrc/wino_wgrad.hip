@@ -57,6 +57,7 @@ struct WwArgs {
     int SR;                  // stage rows per image = ceil(TH / 2)
     int ncb; int cb_tj0[8]; int cb_w[8];
     int nstages, nsl, nbp, ncob;   // stages in all, slices (workgroups per block pair), block pairs, output-channel blocks (N / 64)
+    float inv_per, inv_ncb;        // 1 / (SR * ncb), 1 / ncb: the stage index divisions are a convert, a multiply-add and a convert
 };
 
 __device__ __forceinline__ void ww_barrier_dma() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -66,10 +67,12 @@ struct WwStage { int b, row0, tj0, w; };
 
 __device__ __forceinline__ WwStage ww_stage(const WwArgs& a, int g) {
     WwStage s;
+    // (exact for g < 2^22: floor((x + 0.5) / d) = floor(x / d); every wave of the workgroup pays this once per stage, in lock-step
+    // behind the stage barrier -- two integer divisions here were ~70 vector instructions of idle matrix pipe per stage)
     const int per = a.SR * a.ncb;
-    s.b = g / per;
+    s.b = (int)(((float)g + 0.5f) * a.inv_per);
     const int rem = g - s.b * per;
-    const int sr = rem / a.ncb, cb = rem - sr * a.ncb;
+    const int sr = (int)(((float)rem + 0.5f) * a.inv_ncb), cb = rem - sr * a.ncb;
     s.row0 = 4 * sr;                 // first padded pixel row of the input region; the gradient region starts one row lower
     s.tj0 = a.cb_tj0[cb]; s.w = a.cb_w[cb];
     return s;
@@ -93,7 +96,7 @@ __device__ __forceinline__ void ww_piece(const WwArgs& a, const WwStage& s, R rx
         if (row > a.H) lim = 0;
         const unsigned v = pxx < lim ? vox : 0xFFFFFFF0u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (ww_lds_f*)(set + p * 256), 16, v,
-                                                 (int)(unsigned)((((long)s.b * a.HPWP + (long)row * a.WP + col0) * a.lda + cin0) * 4), 0, 0);
+                                                 (int)((((unsigned)(s.b * a.HPWP + row * a.WP + col0)) * (unsigned)a.lda + (unsigned)cin0) * 4u), 0, 0);
     } else if (p < C::NXP + C::NZP) {
         const int q = p - C::NXP;
         const int r = q / (WW_ZP / 4), pc = q - r * (WW_ZP / 4);
@@ -104,7 +107,7 @@ __device__ __forceinline__ void ww_piece(const WwArgs& a, const WwStage& s, R rx
         if (row > a.H) lim = 0;
         const unsigned v = pxz < lim ? voz : 0xFFFFFFF0u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rz, (ww_lds_f*)(set + C::XF + q * 256), 16, v,
-                                                 (int)(unsigned)((((long)s.b * a.HPWP + (long)row * a.WP + col0) * a.ldz + co0) * 4), 0, 0);
+                                                 (int)((((unsigned)(s.b * a.HPWP + row * a.WP + col0)) * (unsigned)a.ldz + (unsigned)co0) * 4u), 0, 0);
     }
 }
 
@@ -214,15 +217,15 @@ __device__ __forceinline__ void ww4_body(const WwArgs& a, float* smem) {
 
     int g = sl;
     {
-        const WwStage s = ww_stage(a, g);
+        const WwStage s0 = ww_stage(a, g);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { const int p = wave + 16 * j; ww_piece<CINB>(a, s, rx, rz, smem, p & 7, p >> 3, cin0, co0, vox, voz, pxx, pxz); }
+        for (int j = 0; j < NJ; ++j) { const int p = wave + 16 * j; ww_piece<CINB>(a, s0, rx, rz, smem, p & 7, p >> 3, cin0, co0, vox, voz, pxx, pxz); }
     }
     int cur = 0;
     const int xch = ((CINB == 64 ? wa * 32 : 0) + li) * 4;      // byte offset of this lane's input channel inside a pixel
     const int zch = (wn * 32 + li) * 4;
+    WwStage s = ww_stage(a, g);
     for (; g < a.nstages; g += a.nsl) {
-        const WwStage s = ww_stage(a, g);
         const int gn = g + a.nsl;
         const bool more = gn < a.nstages;
         WwStage sn = s;
@@ -232,6 +235,7 @@ __device__ __forceinline__ void ww4_body(const WwArgs& a, float* smem) {
         ww4_compute<RR, CINB>(a, xs, xs + C::XF * 4, smem + (cur ^ 1) * C::SETF, sn, more, rx, rz, s.w, s.row0 >> 2, wave, wa, lh, xch, zch, cin0, co0,
                               vox, voz, pxx, pxz, acc);
         cur ^= 1;
+        s = sn;
     }
     // partial of this workgroup (CINB 32: one per tile row of the stages): [16][CINB][64]; acc[c] = position RR * 4 + c,
     // register = input channel, lane = output channel
@@ -342,6 +346,7 @@ WwPlan ww_plan(const asr_gemm_desc* d, int ldz) {
     }
     p.SR = asr_cdiv(TH, 2);
     p.nstages = d->B * p.SR * p.ncb;
+    if ((long)d->B * p.SR * p.ncb >= (1L << 22)) return p;      // ww_stage's index divisions are exact below 2^22
     p.ncob = d->N / 64;
     p.nbp = (d->K / p.cinb) * p.ncob;
     static int ncu = 0;
@@ -378,6 +383,7 @@ int asr_wino_wgrad_launch(const asr_gemm_desc* d, const float* A, const float* d
     a.SR = p.SR; a.ncb = p.ncb;
     for (int c = 0; c < 8; ++c) { a.cb_tj0[c] = c < p.ncb ? p.cbt[c] : 0; a.cb_w[c] = c < p.ncb ? p.cbw[c] : 0; }
     a.nstages = p.nstages; a.nsl = p.nsl; a.nbp = p.nbp; a.ncob = p.ncob;
+    a.inv_per = 1.0f / (float)(p.SR * p.ncb); a.inv_ncb = 1.0f / (float)p.ncb;
     // grid: slices rounded up to whole groups of 8, times block pairs (see ww_body)
     const int grid = asr_cdiv(p.nsl, 8) * 8 * p.nbp;
     hipStream_t st = (hipStream_t)stream;
