@@ -958,13 +958,15 @@ __device__ __forceinline__ void wino11_body(float* smem) {
         lds_barrier();
     }
     int titem = -2;
+    // (tile block, channel block) of the item, stepped along: a division by the run-time nnb at the top of every item was ~40
+    // instructions that all eight waves executed in lock-step behind the tail's last barrier
+    int blk = it / nnb, nb = it - blk * nnb;
     for (; it < it_end; ++it) {
         ++titem;
         W11T(0);
 #ifdef W11_TRACE
         if (blockIdx.x == W11_TRACE_WG && titem >= 0 && titem < 8 && lane == 0) w11_trace_buf[(titem * 8 + wave) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
 #endif
-        const int blk = it / nnb, nb = it - blk * nnb;
         const int n0 = nb * W11_C;
         const bool more = it + 1 < it_end;
         const bool newblk = more && nb + 1 == nnb;   // the next item starts a new tile block
@@ -1162,6 +1164,7 @@ __device__ __forceinline__ void wino11_body(float* smem) {
         lds_barrier();                               // scratch sets and this item's tables are free; the next item's tables and data visible
         W11T(11);
         if (newblk) tcur ^= 1;
+        if (++nb == nnb) { nb = 0; ++blk; }
     }
 }
 #endif
