@@ -178,11 +178,31 @@ __device__ __forceinline__ void ww4_compute(const WwArgs& a, const char* __restr
     };
     const int np = w >> 1;                             // whole pairs per tile row
     const int xl = xch + lh * 2 * PXB, zl = zch + lh * 2 * 256;       // this lane's tile of a pair: two pixels further for the upper half
+    // Wave priority falls as the wave advances through its stage (3 for the first quarter of its steps ... 0 for the last): the four
+    // waves of a SIMD then take turns at the matrix pipe instead of finishing one after the other.  In-kernel stamps (s_memtime at the
+    // stage barrier and around the steps, 64 -> 128 at 400 x 50): the arbiter serves the oldest wave first -- wave 0 was through a stage
+    // after 8 400 cycles and waited 9 200 at the barrier, wave 15 needed 17 100 -- and the last wave of a SIMD, alone, cannot keep the
+    // pipe busy; with the falling priority every wave takes 16 000-16 400.
+    const int odd = ((w & 1) && (CINB == 64 || wa == (parity & 1))) ? 1 : 0;
+    const int nst = (CINB == 64 ? 2 : 1) * ((np + 1) >> 1) + odd;
+    const int t1 = (nst + 3) >> 2, t2 = (nst + 1) >> 1, t3 = (3 * nst + 3) >> 2;
+    int kst = 0;
+    auto prio = [&]() {
+        if (kst < t1) __builtin_amdgcn_s_setprio(3);
+        else if (kst < t2) __builtin_amdgcn_s_setprio(2);
+        else if (kst < t3) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        ++kst;
+    };
     for (int row = (CINB == 64 ? 0 : wa); row < (CINB == 64 ? 2 : wa + 1); ++row)
-        for (int q = 0; q < np; q += 2)
+        for (int q = 0; q < np; q += 2) {
+            prio();
             step(xl + row * (2 * C::XP * PXB) + q * (4 * PXB), zl + row * (2 * WW_ZP * 256) + q * (4 * 256), q + 1 < np);
-    if ((w & 1) && (CINB == 64 || wa == (parity & 1)))
+        }
+    if (odd) {
+        prio();
         step(xch + lh * (2 * C::XP * PXB) + (w - 1) * 2 * PXB, zch + lh * (2 * WW_ZP * 256) + (w - 1) * 2 * 256, false);
+    }
     // pieces the loop had no slot for (narrow blocks)
     while (more && jn < NJ) piece();
 }
