@@ -971,6 +971,7 @@ __device__ __forceinline__ void wino11_body(float* smem) {
         const bool more = it + 1 < it_end;
         const bool newblk = more && nb + 1 == nnb;   // the next item starts a new tile block
         floatx16 acc[4];
+        __builtin_amdgcn_s_setprio(0);
         switch (rr) {
             case 0: wino11_item_chunks<0>(lds, lds0, nkc, cur, q, ra, ru, lb, ubase, acc); break;
             case 1: wino11_item_chunks<1>(lds, lds0, nkc, cur, q, ra, ru, lb, ubase, acc); break;
@@ -978,6 +979,10 @@ __device__ __forceinline__ void wino11_body(float* smem) {
             default: wino11_item_chunks<3>(lds, lds0, nkc, cur, q, ra, ru, lb, ubase, acc); break;
         }
         W11T(1);
+        // the tail above the chunk phase of the other workgroup's waves on this SIMD (s_setprio 2 here, 0 in the chunk loop): the tail is
+        // the workgroup's critical path -- nothing of it overlaps its own matrix work -- while the other workgroup's MFMAs wait a few
+        // instructions at most (plain DFCNN step -0.3 % on two boxes, the reverse assignment: no change)
+        __builtin_amdgcn_s_setprio(2);
         // ---- item tail.  The set the last chunk read (cur ^ 1) is free: exchange area, then transpose scratch; the other one (cur)
         // receives chunk 0 of the next item, requested FIRST so that it travels behind the whole tail.
         // (The lane id is re-derived here: what the tail computes from it -- scratch and table addresses -- must not be hoisted out of
