@@ -58,6 +58,7 @@ struct WwArgs {
     int ncb; int cb_tj0[8]; int cb_w[8];
     int nstages, nsl, nbp, ncob;   // stages in all, slices (workgroups per block pair), block pairs, output-channel blocks (N / 64)
     float inv_per, inv_ncb;        // 1 / (SR * ncb), 1 / ncb: the stage index divisions are a convert, a multiply-add and a convert
+    int cb_base, cb_rem;           // column block c is cb_base + (c < cb_rem) tile columns wide (cb_w / cb_tj0 without a table look-up)
 };
 
 __device__ __forceinline__ void ww_barrier_dma() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -74,7 +75,9 @@ __device__ __forceinline__ WwStage ww_stage(const WwArgs& a, int g) {
     const int rem = g - s.b * per;
     const int sr = (int)(((float)rem + 0.5f) * a.inv_ncb), cb = rem - sr * a.ncb;
     s.row0 = 4 * sr;                 // first padded pixel row of the input region; the gradient region starts one row lower
-    s.tj0 = a.cb_tj0[cb]; s.w = a.cb_w[cb];
+    // (from the two numbers the blocks are cut by, not from the tables: an indexed scalar load here sat on every wave's way to the barrier)
+    s.w = a.cb_base + (cb < a.cb_rem ? 1 : 0);
+    s.tj0 = cb * a.cb_base + (cb < a.cb_rem ? cb : a.cb_rem);
     return s;
 }
 
@@ -404,6 +407,7 @@ int asr_wino_wgrad_launch(const asr_gemm_desc* d, const float* A, const float* d
     for (int c = 0; c < 8; ++c) { a.cb_tj0[c] = c < p.ncb ? p.cbt[c] : 0; a.cb_w[c] = c < p.ncb ? p.cbw[c] : 0; }
     a.nstages = p.nstages; a.nsl = p.nsl; a.nbp = p.nbp; a.ncob = p.ncob;
     a.inv_per = 1.0f / (float)(p.SR * p.ncb); a.inv_ncb = 1.0f / (float)p.ncb;
+    a.cb_base = ((d->W + 1) / 2) / p.ncb; a.cb_rem = ((d->W + 1) / 2) % p.ncb;
     // grid: slices rounded up to whole groups of 8, times block pairs (see ww_body)
     const int grid = asr_cdiv(p.nsl, 8) * 8 * p.nbp;
     hipStream_t st = (hipStream_t)stream;
