@@ -79,7 +79,7 @@ SIGNATURES = {
     'asr_transpose_batch': (_I, [_P, _I, _I, _P]),
     'asr_tap_gemm_nt': (_I, [C.POINTER(GemmDesc), _P, _P, _P, _I, _P, _P, _P, _P, _P, _P]),
     'asr_winograd_weights_bytes': (_Z, [_I, _I]),
-    'asr_winograd_weights': (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    'asr_winograd_weights2': (_I, [_P, _I, _I, _I, _I, _P, _Z, _P]),
     'asr_winograd_supported': (_I, [_P]),
     'asr_tap_gemm_wino': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_gemm_wino_pool': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),

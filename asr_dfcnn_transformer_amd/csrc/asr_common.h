@@ -8,6 +8,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 #define ASR_WAVE 64
+// cross-file helpers that are NOT part of the C ABI (include/asr_hip.h): kept out of the dynamic symbol table
+#define ASR_INTERNAL __attribute__((visibility("hidden")))
 
 void asr_set_error(const char* what, hipError_t e);
 // name of the contraction kernel instantiation a launcher has just enqueued (asr_last_kernel(), include/asr_hip.h)

@@ -678,12 +678,12 @@ extern "C" int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const flo
     return tap_gemm_pw_impl(d, A, Wf, bias, scale, shift, out_a, out_y, stream, nullptr);
 }
 
-extern "C" int asr_tap_gemm_wino_gated_launch(const asr_gemm_desc* d, const float* dZ, const float* Ut, int mode, int gate_H, int gate_W,
+extern "C" ASR_INTERNAL int asr_tap_gemm_wino_gated_launch(const asr_gemm_desc* d, const float* dZ, const float* Ut, int mode, int gate_H, int gate_W,
                                               const float* gate_a, const float* scale, const float* shift, float* dy_prev,
                                               float* dz_out, float* partials, int* rows, void* stream);      // wino.hip
 
 // Data-gradient GEMM whose epilogue IS the backward prologue of the cell in front (tap_epilogue_gated).
-extern "C" int asr_winograd_gate_rows(const asr_gemm_desc* d);                                              // wino.hip
+extern "C" ASR_INTERNAL int asr_winograd_gate_rows(const asr_gemm_desc* d);                                              // wino.hip
 static int gated_partial_rows(const asr_gemm_desc* d) {
     int rows = asr_cdiv(d->M, 32) + 4;                        // every direct launch configuration has >= 32 tile rows per wave row (+ the ragged last tile)
     const int wr = asr_winograd_gate_rows(d);                 // the Winograd kernels: 4 per tile block (more on planes of few tile rows)

@@ -6,7 +6,7 @@
 //                                                        instead of 36; still fp32
 //
 // One GEMM per transform position xi = 0..15:  M_xi[tile][co] = sum_ci V_xi[tile][ci] * U_xi[ci][co].
-//   * U = G g G^T is prepared once per optimiser step (asr_winograd_weights: [16][K][N], forward or data-gradient view);
+//   * U = G g G^T is prepared once per optimiser step (asr_winograd_weights2: [16][K][N], forward or data-gradient view);
 //   * a work item is 64 consecutive tiles x 64 output channels, the input channels come in chunks of 8: the raw 4x4 patches of
 //     the tiles and the 16 weight matrices ([xi][ci 8][co 64]) arrive by LDS-DMA in two buffer sets, one barrier per chunk;
 //   * the lanes transform their own patch (B^T d B) and V goes straight into the MFMAs as the A operand -- the transformed
@@ -485,7 +485,7 @@ __device__ __forceinline__ WinoGeo wino_geo(const WinoArgs& args, int blk) {
 //   * the item tail is light: the column combination (M A) is lane-local, the row combination (A^T .) is ONE exchange through LDS
 //     in which wave r receives the register quarter 4 r .. 4 r + 3 of all four rows -- i.e. all four pixels of eight tiles -- so
 //     the fused 2 x 2 pool is lane-local as well and every wave finishes ONE 32 x 32 block (pixel-major row table).
-// Raw pieces and tile order: the section above.  The weights come from the SECOND layout asr_winograd_weights
+// Raw pieces and tile order: the section above.  The weights come from the SECOND layout asr_winograd_weights2
 // writes ([K / 8][xi 16][N / 32][k-pair pair 2][lane half 2][co 32][2]): a weight piece is 1 KB of contiguous memory and a lane
 // reads the two k-pairs of a position with one conflict-free ds_read_b64 at a 16-bit immediate of ONE base register.
 // The chunk loop is unrolled by two so that both buffer sets are immediate offsets of per-lane base registers (no address
@@ -498,14 +498,13 @@ __device__ __forceinline__ WinoGeo wino_geo(const WinoArgs& args, int blk) {
 // front of its use also waits for every DMA piece and every epilogue store in flight.
 // Which kernel runs is decided by the layer's widths and plane geometry alone -- never by the batch or the CU count -- so an
 // utterance gives the same bits alone and inside a batch (tests/test_fullsize_gpu.py).
-#ifdef W11_TRACE
-__device__ long long w11_trace_buf[8 * 8 * 16];           // [item 8][wave 8][stamp 16], workgroup W11_TRACE_WG only (development)
-#ifndef W11_TRACE_WG
-#define W11_TRACE_WG 0
+#ifdef ASR_DEV_HOOKS                 // development builds only (tools/trace_wino11.sh); the product build never defines it
+#include "dev_hooks.h"
 #endif
-#define W11T(k) do { if (blockIdx.x == W11_TRACE_WG && titem >= 0 && titem < 8 && lane == 0) w11_trace_buf[(titem * 8 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
+#ifndef W11T                         // phase stamps: nothing in the product
 #define W11T(k) do { } while (0)
+#define W11T_REALTIME(k) do { } while (0)
+#define W11_TRACE_DUMP
 #endif
 constexpr int W11_C = 32;                       // output channels per item
 constexpr int W11_SETF = 4224;                  // floats of a raw / weight set: 16 pieces of 256, padded so that four 32 x 33 transpose scratches fit
@@ -964,9 +963,7 @@ __device__ __forceinline__ void wino11_body(float* smem) {
     for (; it < it_end; ++it) {
         ++titem;
         W11T(0);
-#ifdef W11_TRACE
-        if (blockIdx.x == W11_TRACE_WG && titem >= 0 && titem < 8 && lane == 0) w11_trace_buf[(titem * 8 + wave) * 16 + 12] = __builtin_amdgcn_s_memrealtime();
-#endif
+        W11T_REALTIME(12);
         const int n0 = nb * W11_C;
         const bool more = it + 1 < it_end;
         const bool newblk = more && nb + 1 == nnb;   // the next item starts a new tile block
@@ -1192,17 +1189,15 @@ __global__ __launch_bounds__(512) void wino8_kernel(WinoArgs args) {
 
 }  // namespace
 
-#ifdef W11_TRACE
-extern "C" int asr_w11_trace_dump(long long* host) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(w11_trace_buf), sizeof(long long) * 8 * 8 * 16) == hipSuccess ? 0 : 1;
-}
-#endif
+W11_TRACE_DUMP
 
 // two layouts side by side: [16][K][N] (wino8_kernel) and, 16 K N floats further, the chunk-major one of wino11_kernel
 extern "C" size_t asr_winograd_weights_bytes(int K, int N) { return (size_t)2 * 16 * K * N * sizeof(float); }
 
-extern "C" int asr_winograd_weights(const float* W, int K, int N, int ldw, int wmode, float* out, void* stream) {
-    if (!W || !out || K < 1 || N < 1 || ldw < 1) return ASR_ERR_BAD_ARG;
+// (round 5: `asr_winograd_weights2` with the size of `out` -- round 4 doubled what the entry point writes under its old name;
+// a caller that still allocates 16 K N floats now gets ASR_ERR_BAD_ARG, and one built against the old name fails to link)
+extern "C" int asr_winograd_weights2(const float* W, int K, int N, int ldw, int wmode, float* out, size_t out_bytes, void* stream) {
+    if (!W || !out || K < 1 || N < 1 || ldw < 1 || out_bytes < asr_winograd_weights_bytes(K, N)) return ASR_ERR_BAD_ARG;
     long nb = ((long)K * N + 255) / 256;
     if (nb > 4096) nb = 4096;
     float* out2 = ((K & 7) == 0 && (N & 31) == 0) ? out + (size_t)16 * K * N : nullptr;
@@ -1268,7 +1263,7 @@ static int wino_tile_blocks(const asr_gemm_desc* d) {
     const int blocked = d->B * it, plain = asr_cdiv((long)d->B * TH * TW, WT);
     return blocked > plain ? blocked : plain;            // (wino8_kernel's plain order is the fallback of a blocked geometry)
 }
-extern "C" int asr_winograd_gate_rows(const asr_gemm_desc* d) { return asr_winograd_supported(d) ? 8 * wino_tile_blocks(d) : 0; }      // wino11_kernel: one per wave
+extern "C" ASR_INTERNAL int asr_winograd_gate_rows(const asr_gemm_desc* d) { return asr_winograd_supported(d) ? 8 * wino_tile_blocks(d) : 0; }      // wino11_kernel: one per wave
 
 static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale, const float* shift,
                      float* out_a, float* out_y, void* stream, const WinoGate* gs, float* pool_y = nullptr, int pool_mode = 0,
@@ -1430,7 +1425,7 @@ extern "C" int asr_tap_gemm_gated_poolmax(const asr_gemm_desc* d, const float* d
     return asr_reduce::colsum_multi(partials, rows, 3L * d->N, m, partials + (size_t)rows * 3 * d->N, (hipStream_t)stream);
 }
 
-extern "C" int asr_tap_gemm_wino_gated_launch(const asr_gemm_desc* d, const float* dZ, const float* Ut, int mode, int gate_H, int gate_W,
+extern "C" ASR_INTERNAL int asr_tap_gemm_wino_gated_launch(const asr_gemm_desc* d, const float* dZ, const float* Ut, int mode, int gate_H, int gate_W,
                                               const float* gate_a, const float* scale, const float* shift, float* dy_prev,
                                               float* dz_out, float* partials, int* rows, void* stream) {
     WinoGate gs;

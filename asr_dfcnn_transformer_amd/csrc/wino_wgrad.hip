@@ -32,6 +32,9 @@ typedef __attribute__((address_space(3))) float ww_lds_f;
 typedef float ww_f2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) char ww_lds_c;
 
+#ifdef ASR_DEV_HOOKS                 // development builds only (tools/ablate_wino_wgrad.sh); the product build never defines it
+#include "dev_hooks.h"
+#endif
 #ifndef WW_SLOT
 // where a DMA piece of the next stage goes between the eight MFMAs of a tile pair: two per pair (measured: four per pair -3 %,
 // three -4 %, one -3..-5 %)
@@ -87,7 +90,7 @@ __device__ __forceinline__ void ww_piece(const WwArgs& a, const WwStage& s, R rx
                                          int co0, unsigned vox, unsigned voz, int pxx, int pxz) {
     typedef WwCfg<CINB> C;
     const int p = wave + 8 * j;
-#if defined(WW_ABL) && (WW_ABL & 1)
+#ifdef WW_NO_DMA
     return;
 #endif
     if (p < C::NXP) {

@@ -10,7 +10,6 @@ Graphs follow the reference model files:
 Every cell is conv -> +bias -> ReLU -> frozen-affine BN -> [pool].
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -153,15 +152,17 @@ def param_layout(g):
 class DFCNNEngine:
     def __init__(self, model='m2', vocab=1536, B=32, T=1600, F=200, widths=None, seed=0, device='cuda',
                  lr=7e-4, decay_steps=5000, min_lr=1e-6, beta1=0.9, beta2=0.999, adam_eps=1e-8,
-                 dual_stream=None, wino=None, fuse_prologues=True):
-        """``dual_stream`` (default: environment ASR_DUAL_STREAM, else on): weight gradients / decode on a second stream;
-        ``wino`` (default: ASR_WINO, else on): Winograd F(2x2,3x3) for the 3x3 layers it supports instead of the direct
-        tap-GEMM; ``fuse_prologues``: cell backward prologues inside the data-gradient epilogues.  Each of them leaves the
-        results bitwise (streams, fusion) or to rounding (Winograd) unchanged; they exist for A/B measurements and tests."""
+                 dual_stream=True, wino=True, fuse_prologues=True, fuse_se=True, compact_pool=True, side_priority=0):
+        """Options (constructor arguments only -- nothing here reads the environment; `options()` reports them):
+        ``dual_stream``: weight gradients / decode on a second stream (``side_priority``: its HIP stream priority);
+        ``wino``: Winograd F(2x2,3x3) / F(3x3,2x2) for the 3x3 layers the kernels support instead of the direct tap-GEMM;
+        ``fuse_prologues``: cell backward prologues inside the data-gradient epilogues; ``fuse_se``: an SE block's backward also
+        runs its branch cell's BN / ReLU backward (asr_se_bwd_cell); ``compact_pool``: max-pooled cells keep the activation at each
+        window's maximum + its position instead of the pre-pool plane.  Each of them leaves the results bitwise (streams, fusions,
+        compact form) or to rounding (Winograd) unchanged; they exist for A/B measurements and tests."""
         assert T % 8 == 0 and F >= 8
-        self.opt_dual = (os.environ.get('ASR_DUAL_STREAM', '1') == '1') if dual_stream is None else bool(dual_stream)
-        self.opt_wino = (os.environ.get('ASR_WINO', '1') == '1') if wino is None else bool(wino)
-        self.opt_fuse = bool(fuse_prologues)
+        self.opt_dual, self.opt_wino, self.opt_fuse = bool(dual_stream), bool(wino), bool(fuse_prologues)
+        self.opt_fuse_se, self.opt_compact, self.side_priority = bool(fuse_se), bool(compact_pool), int(side_priority)
         self.model, self.V, self.B, self.T, self.F = model, vocab, B, T, F
         self.device = device
         self.g = graph(model, vocab, widths, F)
@@ -355,14 +356,14 @@ class DFCNNEngine:
         self.dist = torch.zeros(B, dtype=torch.float32, device=dev)
         self.scalars = torch.zeros(8, dtype=torch.float32, device=dev)     # [0] sum loss, [1] sum dist
         self.ws = torch.zeros(ws_bytes // 4 + 64, dtype=torch.float32, device=dev)
-        # Second stream for the backward pass (dual_stream=False / ASR_DUAL_STREAM=0 turns it off): the weight-gradient of a cell
+        # Second stream for the backward pass (dual_stream=False turns it off): the weight-gradient of a cell
         # (MFMA-bound) runs beside its data-gradient and the NEXT cell's HBM-bound backward prologue -- they only share the
         # read-only dZ plane -- so one kernel's last partial round of workgroups is filled by the others and the
         # HBM-bound prologues hide under MFMA work (+6 % M1, +8 % M2 at B = 32).  Per-kernel durations of the
         # overlapped kernels then overlap in any profile.  Results are bitwise the same as with one stream.
         # (The data-gradient is enqueued before the weight gradient -- it is on the critical path; starting the weight gradient
         # first or only after the data-gradient has finished were measured in round 2 and lose on both graphs.)
-        self.side = torch.cuda.Stream(device=dev, priority=int(os.environ.get('ASR_SIDE_PRIORITY', '0'))) if self.opt_dual else None
+        self.side = torch.cuda.Stream(device=dev, priority=self.side_priority) if self.opt_dual else None
         self.ws_side = torch.zeros_like(self.ws) if self.side is not None else None
         # with the side stream every geometry gets a second dZ plane, used alternately, so the next cell's (HBM-bound)
         # backward prologue can run while the previous weight-gradient (MFMA-bound) still reads the other one
@@ -380,7 +381,7 @@ class DFCNNEngine:
                 self.wf_b[dst] = torch.zeros(ops._lib.load().asr_arrange_weights_bytes(9, cout, cin) // 4, dtype=torch.float32, device=dev)
         # Winograd F(2x2,3x3) kernels (wino.hip) for the 3x3 convs they support, forward and data-gradient (plain and gated):
         # 16 instead of 36 multiplies per 2x2 output tile, still fp32; 1.3-1.6x the tap-GEMM per layer.  For a pooled cell
-        # the 2x2 pool is computed inside the forward launch.  wino=False / ASR_WINO=0 keeps every layer on the tap-GEMM.
+        # the 2x2 pool is computed inside the forward launch.  wino=False keeps every layer on the tap-GEMM.
         # dense layers: the kernel transposed ([cout][cin], one batched launch per step), so that the large forward GEMMs read
         # both operands K-contiguous through LDS-DMA (asr_tap_gemm_nt, gemm1.hip: 6400 x 6400 x 1536 of acoustic_model2.py
         # 109 -> 125 TFLOP/s); small ones fall through to asr_tap_gemm inside the library
@@ -423,7 +424,7 @@ class DFCNNEngine:
         # SE blocks whose branch is a non-pooled conv cell that nothing else reads (acoustic_model2: cell -> squeeze-excitation): the SE
         # backward's last pass also runs that cell's BN / ReLU backward (asr_se_bwd_cell) -- no dL/dy plane, no asr_cell_bwd_pre pass
         self.se_cell = {}
-        if self.opt_fuse and os.environ.get('ASR_SE_FUSE', '1') != '0':
+        if self.opt_fuse and self.opt_fuse_se:
             for op in self.g:
                 if op[0] != 'se':
                     continue
@@ -433,7 +434,7 @@ class DFCNNEngine:
                         and self.consumers.get(br, []) == [op]:
                     self.se_cell[op[3]] = cell
         self.compact = {}
-        for writer, tgt in (self.fuse.items() if os.environ.get('ASR_POOLMAX', '1') != '0' else ()):
+        for writer, tgt in (self.fuse.items() if self.opt_compact else ()):
             top = next(o for o in self.g if o[0] == 'cell' and o[2] == tgt)
             if top[6] == 'max' and tgt in self.wt_f and writer in self.wt_b and ops.poolmax_supported(self.fdesc[tgt], self.bdesc[writer]):
                 Ho, Wo, cout = self.res[tgt]
@@ -446,6 +447,14 @@ class DFCNNEngine:
         if self.ws_gate > self.ws.numel() * 4:
             self.ws = torch.zeros(self.ws_gate // 4 + 64, dtype=torch.float32, device=dev)
             self.ws_side = torch.zeros_like(self.ws) if self.side is not None else None
+
+    def options(self):
+        """The switches this engine was built with and what they resolved to on this graph (bench.py puts it in its JSON line)."""
+        return {'dual_stream': self.opt_dual, 'wino': self.opt_wino, 'fuse_prologues': self.opt_fuse, 'fuse_se': self.opt_fuse_se,
+                'compact_pool': self.opt_compact, 'side_priority': self.side_priority,
+                'winograd_layers_fwd': sorted(self.wt_f), 'winograd_layers_dgrad': sorted(self.wt_b),
+                'fused_prologues': len(self.fuse), 'se_blocks_fused_with_cell_backward': len(self.se_cell),
+                'compact_max_pool_cells': sorted(self.compact)}
 
     def _plan_fused_prologues(self):
         """Cells whose backward prologue (pool -> BN -> ReLU backward + the three channel sums, asr_cell_bwd_pre) moves into

@@ -129,10 +129,11 @@ class AMLMEngine:
     apply_adam.  ``hidden`` (= hidden_units = the width of h7) must be heads * 64."""
 
     def __init__(self, v_pinyin=1536, v_hanzi=6345, B=8, T=1600, F=200, widths=None, heads=2, blocks=6, pos_max=200,
-                 lr=7e-4, seed=0, device='cuda', dropout_rate=0.0, drop_seed=0):
+                 lr=7e-4, seed=0, device='cuda', dropout_rate=0.0, drop_seed=0, am_options=None):
+        """``am_options``: A/B switches handed to the acoustic half's DFCNNEngine (dual_stream, wino, ...)."""
         self.B, self.T8 = B, T // 8
         self.am = DFCNNEngine(model='amlm', vocab=v_pinyin, B=B, T=T, F=F, widths=widths, seed=seed, device=device,
-                              lr=lr, decay_steps=5000, min_lr=lr)                         # constant lr (:134)
+                              lr=lr, decay_steps=5000, min_lr=lr, **(am_options or {}))   # constant lr (:134)
         hid = self.am.flat['h7'].shape[1]
         heads = heads or hid // 64
         assert hid == 64 * heads, 'h7 (%d wide) is the language half\'s hidden_units: heads must be %d' % (hid, hid // 64)

@@ -620,16 +620,16 @@ def arrange_weights(W, ntaps, K, N, ldw, wmode=0, out=None):
 
 
 def winograd_weights_floats(K, N):
-    """floats of the buffer asr_winograd_weights fills (two layouts side by side, asr_winograd_weights_bytes)"""
+    """floats of the buffer asr_winograd_weights2 fills (two layouts side by side, asr_winograd_weights_bytes)"""
     return _lib.load().asr_winograd_weights_bytes(K, N) // 4
 
 
 def winograd_weights(W, K, N, ldw, wmode=0, out=None):
-    """U = G g G^T of a 3x3 layer, [16][K][N] (asr_winograd_weights)."""
+    """U = G g G^T of a 3x3 layer: [16][K][N] and, 16 K N floats further, wino11_kernel's chunk-major layout (asr_winograd_weights2)."""
     lib = _lib.load()
     if out is None:
         out = torch.empty(lib.asr_winograd_weights_bytes(K, N) // 4, dtype=torch.float32, device=W.device)
-    check(lib.asr_winograd_weights(_ptr(W), K, N, ldw, wmode, _ptr(out), _stream()), 'asr_winograd_weights')
+    check(lib.asr_winograd_weights2(_ptr(W), K, N, ldw, wmode, _ptr(out), out.numel() * 4, _stream()), 'asr_winograd_weights2')
     return out
 
 

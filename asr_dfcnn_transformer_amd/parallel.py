@@ -25,6 +25,12 @@ def init_from_env(backend=None):
         if backend is None:
             backend = os.environ.get('ASR_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if backend == 'nccl':
+            # RCCL needs one GPU per rank: say so in one line instead of `invalid device ordinal` under a launcher traceback
+            ndev = torch.cuda.device_count()
+            if local >= ndev:
+                raise SystemExit('asr_dfcnn_transformer_amd.parallel: rank %d (LOCAL_RANK %d) of %d has no GPU of its own: %d GPU(s) '
+                                 'visible (backend nccl = RCCL needs one per rank; ASR_DIST_BACKEND=gloo rehearses more ranks than '
+                                 'GPUs)' % (rank, local, world, ndev))
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     if torch.cuda.is_available() and torch.cuda.device_count() > 0:
@@ -48,7 +54,11 @@ class BucketedAllReduce:
     [(lo, hi), ...], each launched asynchronously as soon as the caller says its range is
     final (``launch(i)``); ``wait()`` joins them before the optimiser reads the buffer."""
 
-    def __init__(self, flat_grad, ranges, group=None):
+    def __init__(self, flat_grad, ranges, group=None, always_collective=False):
+        """``always_collective``: enter the collective even in a group of ONE rank (the default skips it there).  With backend
+        nccl that is a real RCCL all-reduce on c10d's collective stream -- library load, communicator, stream ordering
+        against the engine's main / side streams -- whose result must be the input bit for bit (tests/test_rccl_gpu.py)."""
+        self.always = bool(always_collective) and dist.is_initialized()
         self.flat = flat_grad
         self.ranges = [(int(lo), int(hi)) for lo, hi in ranges]
         self.group = group
@@ -61,7 +71,7 @@ class BucketedAllReduce:
 
     def launch(self, i):
         lo, hi = self.ranges[i]
-        if self.world == 1 or hi <= lo:
+        if (self.world == 1 and not self.always) or hi <= lo:
             return
         self.pending.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 

@@ -11,7 +11,6 @@ Buffers follow DESIGN.md 2: padded planes [B][H+1][W+1][C] for everything a 3x3 
 "phase split" plane for the input of the 64->64 stride-2 conv, [B][T'][64][80] for the attention operands.
 """
 import math
-import os
 
 import numpy as np
 import torch
@@ -37,7 +36,7 @@ def fwd_flops_per_seq(T, F=320):
 
 
 class PreNetEngine:
-    def __init__(self, B, T, F=320, lr=5e-4, beta2=0.98, seed=0, device='cuda', dual_stream=None, wino=None):
+    def __init__(self, B, T, F=320, lr=5e-4, beta2=0.98, seed=0, device='cuda', dual_stream=True, wino=True):
         assert F == 320, 'the attention kernels are built for 80 frequency bins after the two stride-2 convs (4 x 80 / 4)'
         assert T % 4 == 0 and T >= 4
         self.B, self.T, self.F, self.device = B, T, F, device
@@ -97,10 +96,10 @@ class PreNetEngine:
                  ops.bn_workspace(self.a1), ops.bn_workspace(self.x2), ops.pix_ln_bwd_workspace(self.x2),
                  ops.prenet_conv1_bwd_workspace(B, T, F), ops.colsum_workspace(NP, CH), 4 * (B * CH * H2 + 64), 1 << 20])
         self.ws = z(ws // 4 + 64)
-        # Second stream for the backward pass (dual_stream=False / ASR_DUAL_STREAM=0 turns it off; see engine.py): the weight- and
+        # Second stream for the backward pass (dual_stream=False turns it off; see engine.py): the weight- and
         # bias-gradient of a conv run on it while the main stream goes on with the data-gradient and the next (HBM-bound)
         # BatchNorm / transpose / LayerNorm backward.  The pre-activation gradient planes alternate between two buffers.
-        dual = (os.environ.get('ASR_DUAL_STREAM', '1') == '1') if dual_stream is None else bool(dual_stream)
+        dual = bool(dual_stream)
         self.side = torch.cuda.Stream(device=device) if dual else None
         self.ws_side = z(ws // 4 + 64) if self.side is not None else None
         self.dz_alt = pl() if self.side is not None else None
@@ -114,9 +113,9 @@ class PreNetEngine:
             self.wf_f[k] = torch.zeros(nb(9, cin, CH) // 4, dtype=torch.float32, device=device)
             self.wf_b[k] = torch.zeros(nb(9, CH, cin) // 4, dtype=torch.float32, device=device)
         # ... or, where supported, on the Winograd F(2x2,3x3) kernel (wino.hip; see engine.py), forward and data-gradients;
-        # wino=False / ASR_WINO=0 turns it off
+        # wino=False turns it off
         self.wt_f, self.wt_b = {}, {}
-        if (os.environ.get('ASR_WINO', '1') == '1') if wino is None else bool(wino):
+        if wino:
             for k, cin in self._cin.items():
                 if ops.winograd_supported(self.d_conv[k]):
                     self.wt_f[k] = torch.zeros(ops.winograd_weights_floats(cin, CH), dtype=torch.float32, device=device)

@@ -27,24 +27,25 @@ import torch.distributed as dist
 FP32_PEAK_TFLOPS = 157.3        # MI355X dense fp32 (vector = matrix), MI355X_MICROARCH.md
 
 
-# Winograd F(2x2,3x3) kernel (wino.hip): per 8-channel chunk a wave issues 32 v_mfma_f32_32x32x2_f32 (64 cycles each) and the
-# input transform's vector instructions (45 per chunk: 40 v_pk_add_f32 + selects).  On this pipe
-# vector instructions do not hide under the fp32 MFMAs of the SIMD's two waves, they ADD to them (tools/mfma_valu.hip, mode
-# "wino": measured time of the kernel's issue pattern with and without the adds, profiles/r03_mfma_valu.txt), so the bound of
-# the kernel in DIRECT-convolution flops is
-#     peak_effective = 157.3 TFLOP/s x 2.25 (multiplies saved) x t_mfma / (t_mfma + t_transform)
+# Winograd kernels (wino.hip F(2x2,3x3) forward / data-gradient, wino_wgrad.hip F(3x3,2x2) weight gradient): 16 instead of 36
+# multiplies per 2x2 tile and channel pair.  SURVEY 8d counts a conv layer in the flops of the DIRECT convolution; a Winograd
+# kernel EXECUTES 1/2.25 of them on the fp32 matrix pipe.  The roofline of such a kernel is priced in executed flops against
+# the plain fp32 MFMA peak (round 5): `achieved` = direct-conv flops / 2.25 / duration, `peak` = 157.3,
+# `frac` = achieved / peak -- what PMC's SQ_VALU_MFMA_BUSY_CYCLES shows as pipe occupancy, to within the clock (157.3 TFLOP/s
+# assumes 2.4 GHz, the chip runs these kernels at 2.2-2.35).  The direct-conv rate (the rate of useful work, which can exceed
+# 157.3) stays in the line as `achieved_direct`.  Rounds 3-4 priced these kernels against 157.3 x 2.25 x 0.91 (0.91 = the
+# measured MFMA time share of the FORWARD kernel's issue pattern); that factor was never measured for the weight gradient.
 WINO_MULT_SAVING = 2.25
-WINO_MFMA_TIME_SHARE = 0.91      # t_mfma / (t_mfma + t_transform), measured: profiles/r03_mfma_valu_wino.txt (22.5 packed adds per 16 MFMAs)
 
 
 def kernel_peak(sym):
-    """(peak TFLOP/s in the kernel's ALGORITHMIC flops, explanation)."""
+    """(peak TFLOP/s, executed flops per algorithmic flop, explanation or None)."""
     if sym.startswith('wino'):
-        return (round(FP32_PEAK_TFLOPS * WINO_MULT_SAVING * WINO_MFMA_TIME_SHARE, 1),
-                'Winograd F(2x2,3x3) in fp32: `achieved` counts the flops of the DIRECT 3x3 convolution (SURVEY 8d: 2 x MACs); the '
-                'kernel issues 2.25x fewer MFMA multiplies but pays its input transform in vector instructions that add to the MFMA '
-                'time on this pipe: peak = %.1f x %.2f x %.2f' % (FP32_PEAK_TFLOPS, WINO_MULT_SAVING, WINO_MFMA_TIME_SHARE))
-    return FP32_PEAK_TFLOPS, None
+        return (FP32_PEAK_TFLOPS, 1.0 / WINO_MULT_SAVING,
+                'Winograd in fp32 (F(2x2,3x3) forward / data-gradient, F(3x3,2x2) weight gradient): the kernel executes 1/2.25 of the '
+                'multiplies of the direct 3x3 convolution; `achieved` / `frac` count the EXECUTED flops against the fp32 MFMA peak, '
+                '`achieved_direct` is the rate in direct-convolution flops (SURVEY 8d: 2 x MACs)')
+    return FP32_PEAK_TFLOPS, 1.0, None
 
 
 def is_forward_symbol(sym):
@@ -67,14 +68,16 @@ def is_forward_symbol(sym):
 
 def roofline_block(dom, r, steps):
     """The `roofline` object for kernel symbol `dom` from its KernelTimer record r (HIP events on the launch stream)."""
-    peak, why = kernel_peak(dom)
-    out = {'bound': 'mfma', 'achieved': round(r['tflops'], 2), 'peak': peak, 'unit': 'TFLOP/s',
-           'frac': round(r['tflops'] / peak, 4), 'traffic': None, 'kernel': dom,
+    peak, executed, why = kernel_peak(dom)
+    ach = r['tflops'] * executed
+    out = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+           'frac': round(ach / peak, 4), 'traffic': None, 'kernel': dom,
            'launches_per_step': r['launches'] // max(1, steps), 'avg_launch_us': round(r['avg_us'], 2),
-           'flop_per_launch': round(r['total_flops'] / r['launches'] / 1e9, 3), 'flop_unit': 'GFLOP'}
+           'flop_per_launch': round(r['total_flops'] * executed / r['launches'] / 1e9, 3), 'flop_unit': 'GFLOP (executed)'}
     if why:
         out['peak_note'] = why
-        out['mfma_pipe_frac'] = round(r['tflops'] / WINO_MULT_SAVING / FP32_PEAK_TFLOPS, 4)
+        out['achieved_direct'] = round(r['tflops'], 2)
+        out['flop_per_launch_direct'] = round(r['total_flops'] / r['launches'] / 1e9, 3)
     return out
 
 
@@ -167,7 +170,7 @@ def run_am_lm(args):
     torch.cuda.set_device(local)
     B, T, F, VP, VH, blocks = args.batch, args.tpad, 200, 1536, 6345, 12
     eng = AMLMEngine(v_pinyin=VP, v_hanzi=VH, B=B, T=T, F=F, blocks=blocks, pos_max=T // 8, dropout_rate=args.dropout,
-                     drop_seed=rank)
+                     drop_seed=rank, am_options=engine_kwargs(args))
     am, lm = eng.am, eng.lm
     red_am = BucketedAllReduce(am.grad, [(am.n_gamma, am.dense_end), (0, am.n_gamma), (am.dense_end, am.grad.numel())])
     red_lm = BucketedAllReduce(lm.grad, [(0, lm.grad.numel())])
@@ -334,7 +337,7 @@ def run_transformer(args):
     N, T, C, H, blocks, Vin, Vout = args.batch if args.batch != 32 else 64, 512, 512, 8, 6, 1536, 6347
     rng = np.random.default_rng(7 + rank)
     if prenet:
-        pre = PreNetEngine(N, 4 * T, 320)
+        pre = PreNetEngine(N, 4 * T, 320, dual_stream=not args.single_stream, wino=not args.no_wino)
         eng = E2EEngine(din=5120, vout=Vout, N=N, T=T, L=T, C=C, heads=H, blocks=blocks, pos_max=600, tie=True, need_dx=True,
                         dropout_rate=args.dropout, drop_seed=rank)
         gen = torch.Generator(device='cuda').manual_seed(7 + rank)
@@ -421,6 +424,12 @@ def run_transformer(args):
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(); dist.destroy_process_group()
+
+
+def engine_kwargs(args):
+    """The A/B switches of DFCNNEngine as command-line flags (the engine itself reads no environment variable)."""
+    return dict(dual_stream=not args.single_stream, wino=not args.no_wino, compact_pool=not args.no_compact_pool,
+                fuse_se=not args.no_fuse_se, side_priority=args.side_priority)
 
 
 def dp_info():
@@ -512,7 +521,11 @@ def prime_gpu(steps):
     code).  So before this process touches the GPU it runs the same workload for `steps` untimed steps in a CHILD process on
     the same GPU and lets it exit: warm-up in process form.  The timed region below is unchanged (W warm-up steps, then
     exactly K timed ones, in this process).  Returns the child's own ms/step (the "first process" figure of this box) or
-    None.  Never under a profiler, never from a process that has already initialised HIP (this runs before any HIP call)."""
+    None.  Never under a profiler, never from a process that has already initialised HIP (this runs before any HIP call),
+    never with more than one rank, and OFF by default (--prime-steps 0: the driver's own record of round 4 showed no
+    first-process effect, child 6.495 ms against 6.513 ms).  The child's exit code and the tail of its stderr go into the JSON
+    line (config.prime_child_rc / prime_child_error); a child that hung or died from a signal raises PrimeChildDied and
+    bench.py exits non-zero WITHOUT measuring -- only a clean non-zero Python exit is ignorable."""
     import subprocess
     env = {k: v for k, v in os.environ.items()
            if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'GROUP_RANK', 'ROLE_RANK', 'ROLE_WORLD_SIZE',
@@ -531,23 +544,53 @@ def prime_gpu(steps):
         argv.append(a)
     cmd = [sys.executable, os.path.abspath(__file__)] + argv + ['--gpus', '1', '--steps', str(steps), '--warmup', '3',
                                                                 '--prime-steps', '0', '--no-cpu-baseline']
+    PRIME['rc'], PRIME['error'] = None, None
     try:
-        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=180)
-        if r.returncode != 0:
-            print('bench.py: priming child exited with %d (ignored)' % r.returncode, file=sys.stderr)
-            return None
+        r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+    except subprocess.TimeoutExpired as e:
+        # the child was killed at its limit with the GPU in use: a hang is evidence, not noise -- no measurement on top of it
+        PRIME['rc'], PRIME['error'] = 'timeout', _tail(e.stderr)
+        raise PrimeChildDied('priming child hung (killed after %d s); stderr tail:\n%s' % (180, PRIME['error']))
+    except OSError as e:                         # could not be started at all: nothing ran on the GPU
+        PRIME['rc'], PRIME['error'] = 'not started', repr(e)
+        print('bench.py: priming child could not be started: %r (ignored)' % (e,), file=sys.stderr)
+        return None
+    PRIME['rc'] = r.returncode
+    if r.returncode < 0:
+        # death by signal (a GPU fault aborts the process): stop here so that the cause is found from THIS failure
+        PRIME['error'] = _tail(r.stderr)
+        raise PrimeChildDied('priming child died from signal %d; stderr tail:\n%s' % (-r.returncode, PRIME['error']))
+    if r.returncode != 0:
+        # a clean Python exit (bad flag, import error): the prime is a courtesy, the measurement goes ahead and carries the text
+        PRIME['error'] = _tail(r.stderr)
+        print('bench.py: priming child exited with %d (ignored); stderr tail:\n%s' % (r.returncode, PRIME['error']), file=sys.stderr)
+        return None
+    try:
         return json.loads(r.stdout.decode().strip().splitlines()[-1]).get('ms_per_step')
-    except Exception as e:                       # the prime is a courtesy: the measurement goes ahead without it
-        print('bench.py: priming child failed: %r (ignored)' % (e,), file=sys.stderr)
+    except (ValueError, IndexError) as e:
+        PRIME['error'] = 'no JSON line: %r' % (e,)
         return None
 
 
-PRIME = {'ms_per_step': None, 'steps': 0}
+class PrimeChildDied(RuntimeError):
+    """The priming child hung or died from a signal on the GPU the measurement would use."""
+
+
+def _tail(b, n=1500):
+    if not b:
+        return ''
+    return (b.decode(errors='replace') if isinstance(b, bytes) else str(b))[-n:]
+
+
+PRIME = {'ms_per_step': None, 'steps': 0, 'rc': None, 'error': None}
 
 
 def prime_note():
     """config entries describing the prime (every workload's JSON line carries them)"""
-    return {'primed_by_child_process_steps': PRIME['steps'], 'prime_child_ms_per_step': PRIME['ms_per_step']}
+    if not PRIME['steps']:
+        return {'primed_by_child_process_steps': 0}
+    return {'primed_by_child_process_steps': PRIME['steps'], 'prime_child_ms_per_step': PRIME['ms_per_step'],
+            'prime_child_rc': PRIME['rc'], 'prime_child_error': PRIME['error']}
 
 
 def main():
@@ -568,9 +611,16 @@ def main():
     ap.add_argument('--inference', action='store_true',
                     help='DFCNN workloads: time fbank + forward + greedy decode only (the predict / speech_test path: cnn_ctc.py:67-83, '
                          'lm_and_am/test.py:44-61); a separate metric, never the headline')
-    ap.add_argument('--prime-steps', type=int, default=40,
-                    help='untimed steps of the same workload in a child process before this one touches the GPU (0: none); '
-                         'see prime_gpu()')
+    ap.add_argument('--rccl-world1', action='store_true',
+                    help='DFCNN workloads, one rank: run the three gradient all-reduces through a ONE-rank RCCL group anyway (A/B)')
+    ap.add_argument('--single-stream', action='store_true', help='A/B: the whole backward pass on one stream (engine dual_stream=False)')
+    ap.add_argument('--no-wino', action='store_true', help='A/B: direct 3x3 convolutions instead of the Winograd kernels (engine wino=False)')
+    ap.add_argument('--no-compact-pool', action='store_true', help='A/B: max-pooled cells keep their pre-pool activation plane')
+    ap.add_argument('--no-fuse-se', action='store_true', help='A/B: SE backward and its branch cell backward as separate passes')
+    ap.add_argument('--side-priority', type=int, default=0, help='A/B: HIP priority of the second backward stream')
+    ap.add_argument('--prime-steps', type=int, default=0,
+                    help='untimed steps of the same workload in a child process before this one touches the GPU (default 0: none; '
+                         'never with more than one rank); see prime_gpu()')
     args = ap.parse_args()
     if 'WORLD_SIZE' not in os.environ:
         if args.gpus > 1:
@@ -578,9 +628,13 @@ def main():
     elif int(os.environ['WORLD_SIZE']) != args.gpus:
         print('bench.py: --gpus %d but the launcher set WORLD_SIZE=%s' % (args.gpus, os.environ['WORLD_SIZE']), file=sys.stderr)
         return 2
-    if args.prime_steps > 0 and not under_profiler():
-        PRIME['ms_per_step'] = prime_gpu(args.prime_steps)
+    if args.prime_steps > 0 and not under_profiler() and int(os.environ.get('WORLD_SIZE', '1')) == 1:
         PRIME['steps'] = args.prime_steps
+        try:
+            PRIME['ms_per_step'] = prime_gpu(args.prime_steps)
+        except PrimeChildDied as e:
+            print('bench.py: %s\nbench.py: not measuring on a GPU whose last process hung or was killed' % e, file=sys.stderr)
+            return 3
     if args.workload in ('transformer', 'e2e_prenet'):
         return run_transformer(args)
     if args.workload == 'am_lm':
@@ -600,8 +654,16 @@ def main():
     dev = 'cuda'
     variant = 'm1' if args.workload == 'dfcnn' else 'm2'
     B, T, F, V = args.batch, args.tpad, 200, 1536
-    eng = DFCNNEngine(model=variant, vocab=V, B=B, T=T, F=F, seed=0, device=dev)
-    red = BucketedAllReduce(eng.grad, [(eng.n_gamma, eng.dense_end), (0, eng.n_gamma), (eng.dense_end, eng.grad.numel())])
+    eng = DFCNNEngine(model=variant, vocab=V, B=B, T=T, F=F, seed=0, device=dev, **engine_kwargs(args))
+    if args.rccl_world1 and world == 1 and not dist.is_initialized():
+        # A/B (never the headline): the one-rank step WITH its three RCCL all-reduces -- what the collectives' launches, their
+        # stream joins and their kernels cost beside the persistent Winograd kernels, as far as one GPU can show it
+        import socket
+        sk = socket.socket(); sk.bind(('127.0.0.1', 0)); port = sk.getsockname()[1]; sk.close()
+        dist.init_process_group(backend='nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1)
+    red = BucketedAllReduce(eng.grad, [(eng.n_gamma, eng.dense_end), (0, eng.n_gamma), (eng.dense_end, eng.grad.numel())],
+                            always_collective=args.rccl_world1)
+    collectives = world > 1 or red.always
     fb = FbankExtractor(nfilt=F, device=dev)
 
     ns = 160000
@@ -663,7 +725,7 @@ def main():
             else:
                 eng.set_targets(seq, target)
                 eng.loss_and_decode(defer_decode_join=True)
-                if world > 1:
+                if collectives:
                     eng.backward(on_dense_grads_ready=lambda: red.launch(0))
                     red.launch(1); red.launch(2)
                     red.wait()
@@ -759,8 +821,11 @@ def main():
                                           'so this is a rate of useful work, not a utilisation of the fp32 pipe',
                        'backward_streams': 2 if overlapped else 1, 'feature_prefetch': prefetch,
                        'host_input': bool(args.host_input),
-                       'conv_arithmetic': ('fp32 MFMA; 3x3 convs with N % 64 == 0 by Winograd F(2x2,3x3) in fp32, forward + data-gradient '
-                                           '(ASR_WINO=0: direct)' if eng.wt_f else 'fp32 MFMA, direct convolution'),
+                       'conv_arithmetic': ('fp32 MFMA; 3x3 convs with K % 8 == 0 and N % 32 == 0 on column-blocked planes by Winograd '
+                                           'F(2x2,3x3) in fp32 (wino11_kernel: forward, data-gradient, gated data-gradient), their weight '
+                                           'gradients by Winograd F(3x3,2x2) (wino_wgrad4_kernel); other shapes and wino=False: direct'
+                                           if eng.wt_f else 'fp32 MFMA, direct convolution'),
+                       'engine_options': eng.options(), 'gradient_collectives_per_step': 3 if collectives else 0,
                        'mean_loss': round(mean_loss, 4)},
             'roofline': roofline_block(dom, roof, roof_steps),
         }
@@ -782,14 +847,14 @@ def main():
             rf['traffic_unit'] = 'bytes/launch (PMC pass: %s)' % src
         if args.kernel_table:
             for key, r in sorted(table.items(), key=lambda kv: -kv[1]['total_ms']):
-                pk = kernel_peak(key)[0]
-                print('%-56s launches %3d  total %8.3f ms  avg %9.1f us  %7.2f TFLOP/s  %.3f of its bound' %
-                      (key, r['launches'], r['total_ms'], r['avg_us'], r['tflops'], r['tflops'] / pk), file=sys.stderr)
+                pk, ex, _ = kernel_peak(key)
+                print('%-56s launches %3d  total %8.3f ms  avg %9.1f us  %7.2f TFLOP/s algorithmic  %.3f of the fp32 pipe (executed flops)' %
+                      (key, r['launches'], r['total_ms'], r['avg_us'], r['tflops'], r['tflops'] * ex / pk), file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(variant, T, V, batch=B)
         print(json.dumps(out), flush=True)
     barrier()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

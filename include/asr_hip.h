@@ -488,7 +488,9 @@ int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const float* Warrang
  * The 3x3 convolution of asr_tap_gemm (ntaps 9; forward, or data-gradient view with wmode 1) with 16 instead of 36
  * multiplies per 2x2 output tile, input and output channel -- still fp32, results agree with asr_tap_gemm to rounding
  * (tests/test_wino_gpu.py).  Weights are transformed once per optimiser step:
- *   asr_winograd_weights(W HWIO [3][3][Cin][Cout] with pitch ldw, K, N, ldw, wmode, out)
+ *   asr_winograd_weights2(W HWIO [3][3][Cin][Cout] with pitch ldw, K, N, ldw, wmode, out, out_bytes)
+ *     (round 5: replaces asr_winograd_weights, whose output doubled in round 4 under an unchanged name; out_bytes below
+ *     asr_winograd_weights_bytes(K, N) = 2 x 16 K N floats is ASR_ERR_BAD_ARG, nothing is launched)
  *     wmode 0: K = Cin, N = Cout;  wmode 1: the data-gradient view, K = Cout, N = Cin, taps mirrored (as asr_arrange_weights)
  *     out (asr_winograd_weights_bytes(K, N) bytes, round 4: two layouts side by side): [16][K][N], and 16 K N floats further
  *     the chunk-major form [K / 8][16][N / 32][2][2][32][2] (written when K % 8 == 0 and N % 32 == 0) whose 1 KB blocks wino11_kernel
@@ -502,7 +504,7 @@ int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const float* Warrang
  * kernel instantiation) for every shape whose tile columns split into column blocks; wino8_kernel (64 x 64 items, plain tile
  * order) for the rest.  Identical arithmetic per output element up to the order of the inverse transform's additions. */
 size_t asr_winograd_weights_bytes(int K, int N);
-int asr_winograd_weights(const float* W, int K, int N, int ldw, int wmode, float* out, void* stream);
+int asr_winograd_weights2(const float* W, int K, int N, int ldw, int wmode, float* out, size_t out_bytes, void* stream);
 int asr_winograd_supported(const asr_gemm_desc* d);
 int asr_tap_gemm_wino(const asr_gemm_desc* d, const float* A, const float* Wt,
                       const float* bias, const float* scale, const float* shift,
@@ -522,7 +524,7 @@ int asr_tap_gemm_wino_pool(const asr_gemm_desc* d, const float* A, const float* 
  * goes to memory, dZ(k-1) is written directly, and the per-channel sums come out as tile partials folded in a fixed order.
  *   d          the data-gradient descriptor (wmode 1, ntaps 9 or 1, pixel-indexed: H, W = the plane of cell k-1's OUTPUT)
  *   dZ, W      as for asr_tap_gemm (W HWIO), asr_tap_gemm_pw (prearranged == 1: data-gradient view from asr_arrange_weights) or
- *              asr_tap_gemm_wino (prearranged == 2: asr_winograd_weights with wmode 1)
+ *              asr_tap_gemm_wino (prearranged == 2: asr_winograd_weights2 with wmode 1)
  *   pool       0 none, 1 average 2x2, 2 maximum 2x2 (first maximum of bn_scale * a + bn_shift in row-major window order)
  *   gate_H/W   cell k-1's pre-pool plane: H x W for pool 0, 2H x 2W otherwise (odd sizes are not supported: use asr_cell_bwd_pre)
  *   gate_a     cell k-1's post-ReLU pre-BN activations, padded plane [B][gate_H+1][gate_W+1][N]

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared():
     txt = open(os.path.join(ROOT, 'include', 'asr_hip.h')).read()
     txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
-    return sorted(set(re.findall(r'\b(asr_[a-z0-9_]+)\s*\(', txt)))
+    return sorted(set(re.findall(r'\b(asr_[A-Za-z0-9_]+)\s*\(', txt)))
 
 
 def test_library_exports_every_declared_symbol():
@@ -24,6 +24,28 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), 'libasrhip.so does not export %s' % n
         assert n in _lib.SIGNATURES, 'ctypes signature missing for %s' % n
     assert lib.asr_version() >= 100
+
+
+def test_library_exports_nothing_the_header_does_not_declare():
+    """The dynamic symbol table of libasrhip.so == the declarations of include/asr_hip.h: cross-file helpers are hidden
+    (ASR_INTERNAL), development hooks are not in the product build."""
+    import subprocess
+    from asr_dfcnn_transformer_amd import _build
+    out = subprocess.run(['nm', '-D', '--defined-only', _build.LIB], check=True, stdout=subprocess.PIPE).stdout.decode()
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith('asr_'))
+    assert exported == _declared(), (sorted(set(exported) - set(_declared())), sorted(set(_declared()) - set(exported)))
+
+
+def test_winograd_weight_buffer_contract():
+    """asr_winograd_weights2 fills TWO layouts (2 x 16 K N floats, asr_winograd_weights_bytes) and refuses a smaller buffer before
+    anything is launched; the round-4 name, whose contract had changed silently, is gone."""
+    from asr_dfcnn_transformer_amd import _lib
+    lib = _lib.load()
+    for K, N in ((32, 64), (128, 256), (8, 32), (24, 40)):
+        assert lib.asr_winograd_weights_bytes(K, N) == 2 * 16 * K * N * 4
+    assert not hasattr(lib, 'asr_winograd_weights')
+    dummy = 4096                                            # never dereferenced: the size check comes first
+    assert lib.asr_winograd_weights2(dummy, 32, 64, 64, 0, dummy, 16 * 32 * 64 * 4, None) == -1      # ASR_ERR_BAD_ARG
 
 
 def test_banded_filterbank_matches_oracle():

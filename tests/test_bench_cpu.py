@@ -36,7 +36,7 @@ def test_prime_child_gets_the_workload_but_not_the_timing_flags(monkeypatch):
 
     def fake_run(cmd, env=None, stdout=None, stderr=None, timeout=None):
         seen['cmd'], seen['env'] = cmd, env
-        return _Done(0, (json.dumps({'ms_per_step': 6.7}) + '\n').encode())
+        return _DoneErr(0, (json.dumps({'ms_per_step': 6.7}) + '\n').encode())
 
     monkeypatch.setattr(subprocess, 'run', fake_run)
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '20', '--warmup=5', '--workload', 'se_dfcnn', '--tpad', '1000',
@@ -54,16 +54,72 @@ def test_prime_child_gets_the_workload_but_not_the_timing_flags(monkeypatch):
     assert env['ASR_BENCH_DEVICE'] == '3'
 
 
-def test_a_failing_prime_child_is_ignored(monkeypatch):
+class _DoneErr(_Done):
+    def __init__(self, rc, out, err=b''):
+        super().__init__(rc, out)
+        self.stderr = err
+
+
+def test_a_cleanly_failing_prime_child_is_ignored_but_recorded(monkeypatch):
     monkeypatch.setattr(sys, 'argv', ['bench.py'])
-    monkeypatch.setattr(subprocess, 'run', lambda *a, **k: _Done(1, b''))
+    monkeypatch.setattr(subprocess, 'run', lambda *a, **k: _DoneErr(1, b'', b'Traceback ...\nValueError: bad flag\n'))
     assert bench.prime_gpu(40) is None
+    assert bench.PRIME['rc'] == 1 and 'ValueError: bad flag' in bench.PRIME['error']
+    bench.PRIME['steps'] = 40
+    note = bench.prime_note()
+    assert note['prime_child_rc'] == 1 and 'bad flag' in note['prime_child_error']
+    bench.PRIME['steps'] = 0
+    assert bench.prime_note() == {'primed_by_child_process_steps': 0}
+
+
+def test_a_prime_child_that_hung_or_was_killed_stops_the_measurement(monkeypatch):
+    monkeypatch.setattr(sys, 'argv', ['bench.py'])
 
     def boom(*a, **k):
-        raise subprocess.TimeoutExpired('bench.py', 180)
+        raise subprocess.TimeoutExpired('bench.py', 180, stderr=b'HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION')
 
     monkeypatch.setattr(subprocess, 'run', boom)
-    assert bench.prime_gpu(40) is None
+    with pytest.raises(bench.PrimeChildDied) as e:
+        bench.prime_gpu(40)
+    assert 'APERTURE' in str(e.value) and bench.PRIME['rc'] == 'timeout'
+    monkeypatch.setattr(subprocess, 'run', lambda *a, **k: _DoneErr(-6, b'', b'Memory access fault by GPU node-1'))
+    with pytest.raises(bench.PrimeChildDied) as e:
+        bench.prime_gpu(40)
+    assert 'signal 6' in str(e.value) and 'Memory access fault' in str(e.value)
+    # main(): exit code 3, nothing measured
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--prime-steps', '5'])
+    monkeypatch.setattr(bench, 'under_profiler', lambda: False)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    assert bench.main() == 3
+
+
+def test_no_prime_by_default_and_never_with_several_ranks(monkeypatch):
+    calls = []
+    monkeypatch.setattr(bench, 'prime_gpu', lambda n: calls.append(n) or 1.0)
+    monkeypatch.setattr(bench, 'under_profiler', lambda: False)
+
+    class Stop(Exception):
+        pass
+
+    def stop(args):
+        raise Stop()
+
+    monkeypatch.setattr(bench, 'run_lm', stop)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--workload', 'lm'])
+    with pytest.raises(Stop):
+        bench.main()
+    assert calls == []
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--workload', 'lm', '--prime-steps', '7', '--gpus', '2'])
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    with pytest.raises(Stop):
+        bench.main()
+    assert calls == []
+    monkeypatch.delenv('WORLD_SIZE')
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--workload', 'lm', '--prime-steps', '7'])
+    with pytest.raises(Stop):
+        bench.main()
+    assert calls == [7]
 
 
 def test_visible_gpu_count_respects_the_visible_devices_lists(monkeypatch):

@@ -153,3 +153,14 @@ def test_winograd_weight_gradient_equals_direct_at_layer_size(H, W, cin, cout):
     scale = dw0.abs().max().item()
     assert (dw1 - dw0).abs().max().item() < 1e-5 * scale
     assert torch.equal(dw1, dw2)
+    # ... and against float64 (oracle.nn.conv2d_same_bwd) on ONE image of the same planes (B = 1 keeps the host side in seconds)
+    from oracle import nn as onn
+    x1 = ops.Plane(1, H, W, cin); x1.set_interior(x.interior()[:1].contiguous())
+    dz1 = ops.Plane(1, H, W, cout); dz1.set_interior(dz.interior()[:1].contiguous())
+    d1 = ops.gemm_desc(x1.NP, cin, cout, cin, cout, ntaps=9, B=1, H=H, W=W)
+    ws1 = torch.zeros(ops.tap_wgrad_workspace(d1) // 4 + 64, device='cuda')
+    dw3 = torch.zeros(9 * cin * cout, device='cuda')
+    ops.tap_wgrad(d1, x1, dz1, cout, dw3, ws1)
+    _, ref = onn.conv2d_same_bwd(x1.interior().double().cpu().numpy(), np.zeros((3, 3, cin, cout)), dz1.interior().double().cpu().numpy())
+    err = np.abs(dw3.cpu().numpy().astype(np.float64).reshape(3, 3, cin, cout) - ref).max()
+    assert err < 1e-5 * np.abs(ref).max(), err

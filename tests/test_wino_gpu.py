@@ -95,6 +95,10 @@ def test_data_gradient_view_with_accumulation(ops, B, H, W, cin, cout):
     ops.tap_gemm(bd, dz, w, None, None, None, None, dx0)
     ops.tap_gemm_wino(bd, dz, ops.winograd_weights(w, cout, cin, cout, 1), None, None, None, None, dx1)
     assert (dx1.interior() - dx0.interior()).abs().max().item() < 3e-5 * max(1.0, dx0.interior().abs().max().item() / 4)
+    # float64 (oracle.nn.conv2d_same_bwd's rule: correlate dZ with the 180-degree-rotated, in/out-swapped kernel) + what was there
+    ref = conv_ref(dzi, w.flip(0, 1).permute(0, 1, 3, 2).contiguous()) + prev.double()
+    assert (dx1.interior().double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    assert dx1.border_abs_max() == 0.0
 
 
 def test_unsupported_shapes_are_reported(ops):

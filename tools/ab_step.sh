@@ -8,11 +8,11 @@
 WL=$1; R=$2; shift 2
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 cd $ROOT
-python3 bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline --prime-steps 0 > /dev/null 2>&1
+python3 bench.py --workload $WL --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2>&1
 for i in $(seq $R); do
   for L in "$@"; do
     if [ "$L" = "new" ]; then unset LIB; else export LIB=build_ab/libasrhip_$L.so; fi
-    python3 tools/bench_with_lib.py --workload $WL --steps 30 --warmup 3 --no-cpu-baseline --prime-steps 0 2>/dev/null | \
+    python3 tools/bench_with_lib.py --workload $WL --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | \
       python3 -c "import json,sys; print('$L', json.loads(sys.stdin.read().strip().splitlines()[-1])['ms_per_step'])"
   done
 done

@@ -10,7 +10,7 @@ cp $P/libasrhip.so /tmp/libasrhip_good.so
 trap 'cp /tmp/libasrhip_good.so $P/libasrhip.so' EXIT      # the good library comes back even when a compile or a bench fails partway
 objs=$(ls $P/build/*.hip.o | grep -v wino_wgrad.hip.o)
 for m in "$@"; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DWW_ABL=$m -I include -c $P/csrc/wino_wgrad.hip -o /tmp/ww_abl.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DASR_DEV_HOOKS -DWW_ABL=$m -I include -c $P/csrc/wino_wgrad.hip -o /tmp/ww_abl.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $P/libasrhip.so $objs /tmp/ww_abl.o
   echo "== WW_ABL=$m" >> $out
   python tools/bench_wino_wgrad.py 2>&1 | grep -v amdgpu.ids | cut -c1-100 >> $out

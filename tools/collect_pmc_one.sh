@@ -7,11 +7,10 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-export ASR_DUAL_STREAM=0
 i=0
 for ctr in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA"; do
   i=$((i+1))
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_${WL}_$i -o p -- python3 $ROOT/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --prime-steps 0 --no-prefetch "$@" > $OUT/log_pmc_${WL}_$i.txt 2>&1 || echo "pass $i failed"
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_${WL}_$i -o p -- python3 $ROOT/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --single-stream --no-prefetch "$@" > $OUT/log_pmc_${WL}_$i.txt 2>&1 || echo "pass $i failed"
   echo "pmc $WL pass $i done"
 done
 python3 $ROOT/tools/pmc_summary.py $OUT/${WL}_pmc_summary.csv $OUT/pmc_${WL}_1 $OUT/pmc_${WL}_2 $OUT/pmc_${WL}_3 $OUT/pmc_${WL}_4 $OUT/pmc_${WL}_5 --traffic $OUT/${WL}_traffic.json

@@ -12,17 +12,15 @@ PHASE=${PHASE:-all}          # stats | pmc | all  (two gpurun calls of <= 20 min
 if [ "$PHASE" != "pmc" ]; then
 for wl in dfcnn se_dfcnn transformer e2e_prenet am_lm lm; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_$wl -o $wl -- \
-      python3 $ROOT/bench.py --workload $wl --steps 4 --warmup 2 --no-cpu-baseline --prime-steps 0 > $OUT/bench_$wl.log 2>&1
+      python3 $ROOT/bench.py --workload $wl --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_$wl.log 2>&1
   echo "stats $wl done"
 done
 # the same steps with the backward on ONE stream: per-kernel durations that do not overlap
-export ASR_DUAL_STREAM=0
 for wl in dfcnn se_dfcnn; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats1_$wl -o $wl -- \
-      python3 $ROOT/bench.py --workload $wl --steps 4 --warmup 2 --no-cpu-baseline --prime-steps 0 --no-prefetch > $OUT/bench1_$wl.log 2>&1
+      python3 $ROOT/bench.py --workload $wl --steps 4 --warmup 2 --no-cpu-baseline --single-stream --no-prefetch > $OUT/bench1_$wl.log 2>&1
   echo "single-stream stats $wl done"
 done
-unset ASR_DUAL_STREAM
 for wl in dfcnn se_dfcnn transformer e2e_prenet am_lm lm; do
   find $OUT/stats_$wl -name "*kernel_stats.csv" -exec cp {} $OUT/${wl}_kernel_stats.csv \;
 done
@@ -32,7 +30,6 @@ done
 rm -rf $OUT/stats_* $OUT/stats1_*
 fi
 if [ "$PHASE" != "stats" ]; then
-export ASR_DUAL_STREAM=0
 # PMC passes (counters only with --kernel-trace; FETCH_SIZE and WRITE_SIZE in passes of their own): every workload, so
 # that each bench line can carry roofline.traffic for its dominant kernel
 for wl in dfcnn se_dfcnn transformer e2e_prenet am_lm lm; do
@@ -40,7 +37,7 @@ for wl in dfcnn se_dfcnn transformer e2e_prenet am_lm lm; do
   for ctr in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES"; do
     i=$((i+1))
     rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $OUT/pmc_${wl}_$i -o p -- \
-        python3 $ROOT/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --prime-steps 0 --no-prefetch > $OUT/log_pmc_${wl}_$i.txt 2>&1
+        python3 $ROOT/bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --single-stream --no-prefetch > $OUT/log_pmc_${wl}_$i.txt 2>&1
     echo "pmc $wl pass $i done"
   done
   python3 $ROOT/tools/pmc_summary.py $OUT/${wl}_pmc_summary.csv $OUT/pmc_${wl}_1 $OUT/pmc_${wl}_2 $OUT/pmc_${wl}_3 $OUT/pmc_${wl}_4 \

@@ -14,5 +14,5 @@ python3 bench.py --workload dfcnn --tpad 1000 --steps 10 --warmup 3 --no-cpu-bas
 python3 bench.py --workload se_dfcnn --tpad 1000 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_se_dfcnn_t1000.json 2> $OUT/bench_se_dfcnn_t1000.err
 python3 bench.py --workload dfcnn --host-input --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_dfcnn_host_input.json 2> $OUT/bench_dfcnn_host_input.err
 python3 bench.py --workload dfcnn --host-input --no-prefetch --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_dfcnn_host_input_inline.json 2> $OUT/bench_dfcnn_host_input_inline.err
-ASR_DUAL_STREAM=0 python3 bench.py --workload dfcnn --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_dfcnn_single_stream.json 2> $OUT/bench_dfcnn_single_stream.err
+python3 bench.py --workload dfcnn --single-stream --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_dfcnn_single_stream.json 2> $OUT/bench_dfcnn_single_stream.err
 echo "extras done"
