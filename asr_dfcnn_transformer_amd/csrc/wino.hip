@@ -1016,29 +1016,35 @@ __device__ __forceinline__ void wino11_body(float* smem) {
         float* ufree = bufs + (2 + (cur ^ 1)) * W11_SETF;
         float* xch = wm == 0 ? rfree : ufree;        // the four row waves of a tile half meet in one set (4096 floats per phase)
         floatx16 out[1][1];
+        // Exchange layout: [row wave 4][register quarter 4][lane 64][4 registers] -- a wave hands over its sixteen column sums of a
+        // phase with four ds_write_b128 and collects its quarter of the four rows with four ds_read_b128 (round 4: sixteen b32 each)
+        float4* xch4 = (float4*)xch;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             // column combination (M A)[row][j], lane-local, two registers per packed add
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
+            for (int r = 0; r < 16; r += 4) {
                 const wn_f2 a0 = {acc[0][r], acc[0][r + 1]}, a1 = {acc[1][r], acc[1][r + 1]}, a2 = {acc[2][r], acc[2][r + 1]}, a3 = {acc[3][r], acc[3][r + 1]};
+                const wn_f2 b0 = {acc[0][r + 2], acc[0][r + 3]}, b1 = {acc[1][r + 2], acc[1][r + 3]}, b2 = {acc[2][r + 2], acc[2][r + 3]}, b3 = {acc[3][r + 2], acc[3][r + 3]};
                 const wn_f2 pj = j == 0 ? (a0 + a1) + a2 : (a1 - a2) - a3;
-                xch[(rr * 16 + r) * 64 + lane] = pj.x;
-                xch[(rr * 16 + r + 1) * 64 + lane] = pj.y;
+                const wn_f2 qj = j == 0 ? (b0 + b1) + b2 : (b1 - b2) - b3;
+                xch4[(rr * 4 + (r >> 2)) * 64 + lane] = make_float4(pj.x, pj.y, qj.x, qj.y);
             }
             if (j == 0) W11T(2);
             lds_barrier();
             if (j == 0) W11T(3);
             // row combination for this wave's register quarter: Y[i][j] = sum_r A^T[i][r] (M A)[r][j]
+            {
+                const float4 p0 = xch4[(0 * 4 + rr) * 64 + lane], p1 = xch4[(1 * 4 + rr) * 64 + lane];
+                const float4 p2 = xch4[(2 * 4 + rr) * 64 + lane], p3 = xch4[(3 * 4 + rr) * 64 + lane];
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-                const wn_f2 p0 = {xch[(0 * 16 + 4 * rr + i) * 64 + lane], xch[(0 * 16 + 4 * rr + i + 1) * 64 + lane]};
-                const wn_f2 p1 = {xch[(1 * 16 + 4 * rr + i) * 64 + lane], xch[(1 * 16 + 4 * rr + i + 1) * 64 + lane]};
-                const wn_f2 p2 = {xch[(2 * 16 + 4 * rr + i) * 64 + lane], xch[(2 * 16 + 4 * rr + i + 1) * 64 + lane]};
-                const wn_f2 p3 = {xch[(3 * 16 + 4 * rr + i) * 64 + lane], xch[(3 * 16 + 4 * rr + i + 1) * 64 + lane]};
-                const wn_f2 y0 = (p0 + p1) + p2, y1 = (p1 - p2) - p3;
-                out[0][0][4 * (0 * 2 + j) + i] = y0.x; out[0][0][4 * (0 * 2 + j) + i + 1] = y0.y;
-                out[0][0][4 * (1 * 2 + j) + i] = y1.x; out[0][0][4 * (1 * 2 + j) + i + 1] = y1.y;
+                for (int i = 0; i < 4; i += 2) {
+                    const wn_f2 q0 = i ? wn_f2{p0.z, p0.w} : wn_f2{p0.x, p0.y}, q1 = i ? wn_f2{p1.z, p1.w} : wn_f2{p1.x, p1.y};
+                    const wn_f2 q2 = i ? wn_f2{p2.z, p2.w} : wn_f2{p2.x, p2.y}, q3 = i ? wn_f2{p3.z, p3.w} : wn_f2{p3.x, p3.y};
+                    const wn_f2 y0 = (q0 + q1) + q2, y1 = (q1 - q2) - q3;
+                    out[0][0][4 * (0 * 2 + j) + i] = y0.x; out[0][0][4 * (0 * 2 + j) + i + 1] = y0.y;
+                    out[0][0][4 * (1 * 2 + j) + i] = y1.x; out[0][0][4 * (1 * 2 + j) + i + 1] = y1.y;
+                }
             }
             lds_barrier();                           // the set is rewritten (phase 1) / becomes transpose scratch
         }

@@ -23,6 +23,9 @@
 // accumulators), wn the 32-wide half of the 64 output channels, a the 32-wide half of 64 input channels (CINB = 64) or, for 32
 // input channels (CINB = 32), every other tile row (two partials per workgroup).  Two tile pairs are transformed together with
 // packed adds.
+// Round 5: 32 input x 32 OUTPUT channels (acoustic_model2.py:39 `h1_1 = cnn_cell(32, h1)`, the 'small' graph): the block of (ci, co)
+// pairs is a quarter of the 64 x 64 one, so a stage is FOUR tile rows (10 x 32 input pixels, 8 x 32 gradient pixels) and the four waves
+// of a transform row take one tile row each (four partials per workgroup) -- per wave and stage the work of the CINB = 32 form.
 #include "asr_common.h"
 #include <stdint.h>
 
@@ -41,23 +44,28 @@ typedef __attribute__((address_space(3))) char ww_lds_c;
 #define WW_SLOT(i) ((i) == 3 || (i) == 7)
 #endif
 constexpr int WW_MAXW = 13;          // tile columns of a column block
-constexpr int WW_ZP = 28;            // pixel pitch of a staged gradient row (2 w <= 26)
 
-template <int CINB> struct WwCfg {
+// CINB x NB = the workgroup's block of (input, output) channels: 64 x 64, 32 x 64 (stages of two tile rows) or 32 x 32 (four)
+template <int CINB, int NB> struct WwCfg {
+    static constexpr int TR = NB == 64 ? 2 : 4;                 // tile rows of a stage
     static constexpr int XP = CINB == 64 ? 28 : 32;             // pixel pitch of a staged input row (2 w + 2 <= 28), whole pieces
     static constexpr int XPX = 1024 / (CINB * 4);               // pixels per 1 KB piece
     static constexpr int XPPR = XP / XPX;                       // pieces per input row
-    static constexpr int NXP = 6 * XPPR;                        // input pieces per stage
-    static constexpr int NZP = 4 * (WW_ZP / 4);                 // gradient pieces per stage (4 pixels x 64 channels each)
-    static constexpr int XF = 6 * XP * CINB;                    // floats of the input region
-    static constexpr int ZF = 4 * WW_ZP * 64;
+    static constexpr int NXP = (2 * TR + 2) * XPPR;             // input pieces per stage
+    static constexpr int ZP = NB == 64 ? 28 : 32;               // pixel pitch of a staged gradient row (2 w <= 26), whole pieces
+    static constexpr int ZPX = 1024 / (NB * 4);                 // pixels per 1 KB gradient piece
+    static constexpr int ZPPR = ZP / ZPX;
+    static constexpr int NZP = 2 * TR * ZPPR;                   // gradient pieces per stage
+    static constexpr int XF = (2 * TR + 2) * XP * CINB;         // floats of the input region
+    static constexpr int ZF = 2 * TR * ZP * NB;
     static constexpr int SETF = XF + ZF;
+    static constexpr int NTH = CINB == 64 ? 1 : NB == 64 ? 2 : 4;      // partials per workgroup (tile-row classes)
 };
 
 struct WwArgs {
     const float* A; const float* Z; float* part;
     int K, N, lda, ldz, B, H, Wd, WP, HPWP;
-    int SR;                  // stage rows per image = ceil(TH / 2)
+    int SR;                  // stage rows per image = ceil(TH / tile rows of a stage)
     int ncb; int cb_tj0[8]; int cb_w[8];
     int nstages, nsl, nbp, ncob;   // stages in all, slices (workgroups per block pair), block pairs, output-channel blocks (N / 64)
     float inv_per, inv_ncb;        // 1 / (SR * ncb), 1 / ncb: the stage index divisions are a convert, a multiply-add and a convert
@@ -69,6 +77,7 @@ __device__ __forceinline__ void ww_barrier_dma() { asm volatile("s_waitcnt vmcnt
 #if __HIP_DEVICE_COMPILE__
 struct WwStage { int b, row0, tj0, w; };
 
+template <int TR>
 __device__ __forceinline__ WwStage ww_stage(const WwArgs& a, int g) {
     WwStage s;
     // (exact for g < 2^22: floor((x + 0.5) / d) = floor(x / d); every wave of the workgroup pays this once per stage, in lock-step
@@ -77,7 +86,7 @@ __device__ __forceinline__ WwStage ww_stage(const WwArgs& a, int g) {
     s.b = (int)(((float)g + 0.5f) * a.inv_per);
     const int rem = g - s.b * per;
     const int sr = (int)(((float)rem + 0.5f) * a.inv_ncb), cb = rem - sr * a.ncb;
-    s.row0 = 4 * sr;                 // first padded pixel row of the input region; the gradient region starts one row lower
+    s.row0 = 2 * TR * sr;            // first padded pixel row of the input region; the gradient region starts one row lower
     // (from the two numbers the blocks are cut by, not from the tables: an indexed scalar load here sat on every wave's way to the barrier)
     s.w = a.cb_base + (cb < a.cb_rem ? 1 : 0);
     s.tj0 = cb * a.cb_base + (cb < a.cb_rem ? cb : a.cb_rem);
@@ -85,10 +94,10 @@ __device__ __forceinline__ WwStage ww_stage(const WwArgs& a, int g) {
 }
 
 // DMA piece j (pieces wave + 8 j) of stage s into buffer set `set`
-template <int CINB, class R>
+template <int CINB, int NB, class R>
 __device__ __forceinline__ void ww_piece(const WwArgs& a, const WwStage& s, R rx, R rz, float* __restrict__ set, int wave, int j, int cin0,
                                          int co0, unsigned vox, unsigned voz, int pxx, int pxz) {
-    typedef WwCfg<CINB> C;
+    typedef WwCfg<CINB, NB> C;
     const int p = wave + 8 * j;
 #ifdef WW_NO_DMA
     return;
@@ -105,9 +114,9 @@ __device__ __forceinline__ void ww_piece(const WwArgs& a, const WwStage& s, R rx
                                                  (int)((((unsigned)(s.b * a.HPWP + row * a.WP + col0)) * (unsigned)a.lda + (unsigned)cin0) * 4u), 0, 0);
     } else if (p < C::NXP + C::NZP) {
         const int q = p - C::NXP;
-        const int r = q / (WW_ZP / 4), pc = q - r * (WW_ZP / 4);
-        const int row = s.row0 + 1 + r, col0 = 2 * s.tj0 + 1 + pc * 4;
-        int lim = 2 * s.w - pc * 4;
+        const int r = q / C::ZPPR, pc = q - r * C::ZPPR;
+        const int row = s.row0 + 1 + r, col0 = 2 * s.tj0 + 1 + pc * C::ZPX;
+        int lim = 2 * s.w - pc * C::ZPX;
         const int limp = a.Wd + 1 - col0;
         if (limp < lim) lim = limp;
         if (row > a.H) lim = 0;
@@ -126,20 +135,22 @@ __device__ __forceinline__ void ww_piece(const WwArgs& a, const WwStage& s, R rx
 // adds per tile-pair pair instead of 20 for a column pair --, row r of Z = G' y G'^T needs one or both gradient rows (2-4 packed
 // adds instead of 8), and four instruction streams per SIMD cover each other's LDS round trips and the stage barrier.
 #if __HIP_DEVICE_COMPILE__
-template <int RR, int CINB, class R>
+// wa: the tile-row class of the wave (CINB 64: unused -- every wave walks both rows; 32 x 64: 0 / 1; 32 x 32: 0 .. 3)
+template <int RR, int CINB, int NB, class R>
 __device__ __forceinline__ void ww4_compute(const WwArgs& a, const char* __restrict__ xs, const char* __restrict__ zs, float* __restrict__ nxt,
                                             const WwStage& sn, bool more, R rx, R rz, int w, int parity, int wave, int wa, int lh, int xch, int zch,
                                             int cin0, int co0, unsigned vox, unsigned voz, int pxx, int pxz, floatx16 (&acc)[4]) {
-    typedef WwCfg<CINB> C;
+    typedef WwCfg<CINB, NB> C;
     constexpr int NJ = (C::NXP + C::NZP + 15) / 16;    // piece rounds per stage (pieces wave + 16 j)
     constexpr int PXB = CINB * 4;                      // bytes of an input pixel
+    constexpr int ZXB = NB * 4;                        // bytes of a gradient pixel
     constexpr int RA = RR == 0 ? 0 : 1, RB = RR == 3 ? 3 : 2;           // the two patch rows this transform row combines
     int jn = 0;
     auto piece = [&]() {
         if (more && jn < NJ) {
             const int p = wave + 16 * jn;
             // (ww_piece numbers pieces wave + 8 j: hand it the equivalent (wave', j') of piece p)
-            ww_piece<CINB>(a, sn, rx, rz, nxt, p & 7, p >> 3, cin0, co0, vox, voz, pxx, pxz);
+            ww_piece<CINB, NB>(a, sn, rx, rz, nxt, p & 7, p >> 3, cin0, co0, vox, voz, pxx, pxz);
         }
         ++jn;
     };
@@ -151,7 +162,7 @@ __device__ __forceinline__ void ww4_compute(const WwArgs& a, const char* __restr
         asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4" : "=&v"(lo_), "=&v"(hi_) : "v"(ad), "i"(off0), "i"(off1)); \
         dst = ww_f2{lo_, hi_}; }
 #define WW_LDX(dst, r, c) WW_LD2(dst, xad, ((r) * C::XP + (c)) * PXB, ((r) * C::XP + (c) + 4) * PXB)
-#define WW_LDZ(dst, p) WW_LD2(dst, zad, (((p) >> 1) * WW_ZP + ((p) & 1)) * 256, (((p) >> 1) * WW_ZP + ((p) & 1) + 4) * 256)
+#define WW_LDZ(dst, p) WW_LD2(dst, zad, (((p) >> 1) * C::ZP + ((p) & 1)) * ZXB, (((p) >> 1) * C::ZP + ((p) & 1) + 4) * ZXB)
         WW_LDX(da[0], RA, 0) WW_LDX(da[1], RA, 1) WW_LDX(da[2], RA, 2) WW_LDX(da[3], RA, 3)
         WW_LDX(db[0], RB, 0) WW_LDX(db[1], RB, 1) WW_LDX(db[2], RB, 2) WW_LDX(db[3], RB, 3)
         if (RR != 3) { WW_LDZ(y0[0], 0) WW_LDZ(y0[1], 1) }
@@ -183,13 +194,15 @@ __device__ __forceinline__ void ww4_compute(const WwArgs& a, const char* __restr
         }
     };
     const int np = w >> 1;                             // whole pairs per tile row
-    const int xl = xch + lh * 2 * PXB, zl = zch + lh * 2 * 256;       // this lane's tile of a pair: two pixels further for the upper half
+    const int xl = xch + lh * 2 * PXB, zl = zch + lh * 2 * ZXB;       // this lane's tile of a pair: two pixels further for the upper half
     // Wave priority falls as the wave advances through its stage (3 for the first quarter of its steps ... 0 for the last): the four
     // waves of a SIMD then take turns at the matrix pipe instead of finishing one after the other.  In-kernel stamps (s_memtime at the
     // stage barrier and around the steps, 64 -> 128 at 400 x 50): the arbiter serves the oldest wave first -- wave 0 was through a stage
     // after 8 400 cycles and waited 9 200 at the barrier, wave 15 needed 17 100 -- and the last wave of a SIMD, alone, cannot keep the
     // pipe busy; with the falling priority every wave takes 16 000-16 400.
-    const int odd = ((w & 1) && (CINB == 64 || wa == (parity & 1))) ? 1 : 0;
+    // (an odd block width: the last tiles of two neighbouring tile rows form one pair -- lane half = row; of the two waves that own
+    // those rows the one whose class matches the stage parity takes it)
+    const int odd = ((w & 1) && (CINB == 64 || (wa & 1) == (parity & 1))) ? 1 : 0;
     const int nst = (CINB == 64 ? 2 : 1) * ((np + 1) >> 1) + odd;
     const int t1 = (nst + 3) >> 2, t2 = (nst + 1) >> 1, t3 = (3 * nst + 3) >> 2;
     int kst = 0;
@@ -203,36 +216,37 @@ __device__ __forceinline__ void ww4_compute(const WwArgs& a, const char* __restr
     for (int row = (CINB == 64 ? 0 : wa); row < (CINB == 64 ? 2 : wa + 1); ++row)
         for (int q = 0; q < np; q += 2) {
             prio();
-            step(xl + row * (2 * C::XP * PXB) + q * (4 * PXB), zl + row * (2 * WW_ZP * 256) + q * (4 * 256), q + 1 < np);
+            step(xl + row * (2 * C::XP * PXB) + q * (4 * PXB), zl + row * (2 * C::ZP * ZXB) + q * (4 * ZXB), q + 1 < np);
         }
     if (odd) {
         prio();
-        step(xch + lh * (2 * C::XP * PXB) + (w - 1) * 2 * PXB, zch + lh * (2 * WW_ZP * 256) + (w - 1) * 2 * 256, false);
+        const int r0 = CINB == 64 ? 0 : (wa & ~1);      // the row pair whose last tiles meet
+        step(xch + (r0 + lh) * (2 * C::XP * PXB) + (w - 1) * 2 * PXB, zch + (r0 + lh) * (2 * C::ZP * ZXB) + (w - 1) * 2 * ZXB, false);
     }
     // pieces the loop had no slot for (narrow blocks)
     while (more && jn < NJ) piece();
 }
 
-template <int RR, int CINB>
+template <int RR, int CINB, int NB>
 __device__ __forceinline__ void ww4_body(const WwArgs& a, float* smem) {
-    typedef WwCfg<CINB> C;
+    typedef WwCfg<CINB, NB> C;
     const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // = RR * 4 + a * 2 + wn
-    const int wa = (wave >> 1) & 1, wn = wave & 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);           // = RR * 4 + a * 2 + wn  (NB 32: RR * 4 + tile row)
+    const int wa = NB == 64 ? (wave >> 1) & 1 : wave & 3, wn = NB == 64 ? wave & 1 : 0;
     // workgroup -> (block pair, slice): workgroups of one slice differ by multiples of 8 (the same XCD: they read the same pixels)
     const int wg = blockIdx.x;
     const int sl_lo = wg & 7, rest = wg >> 3;
     const int bp = rest % a.nbp, sl = (rest / a.nbp) * 8 + sl_lo;
     if (sl >= a.nsl) return;
     const int cib = bp / a.ncob, cob = bp - cib * a.ncob;
-    const int cin0 = cib * CINB, co0 = cob * 64;
+    const int cin0 = cib * CINB, co0 = cob * NB;
 
     auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, 0x7FFFFFF0, 0x00020000);
     auto rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.Z, 0, 0x7FFFFFF0, 0x00020000);
-    constexpr int LPPX = CINB / 4;
-    const int pxx = lane / LPPX, pxz = lane >> 4;
+    constexpr int LPPX = CINB / 4, LPPZ = NB / 4;               // lanes (16 bytes each) per staged pixel
+    const int pxx = lane / LPPX, pxz = lane / LPPZ;
     const unsigned vox = (unsigned)((pxx * a.lda + (lane % LPPX) * 4) * 4);
-    const unsigned voz = (unsigned)((pxz * a.ldz + (lane & 15) * 4) * 4);
+    const unsigned voz = (unsigned)((pxz * a.ldz + (lane % LPPZ) * 4) * 4);
     constexpr int NJ = (C::NXP + C::NZP + 15) / 16;
 
     floatx16 acc[4];
@@ -243,30 +257,30 @@ __device__ __forceinline__ void ww4_body(const WwArgs& a, float* smem) {
 
     int g = sl;
     {
-        const WwStage s0 = ww_stage(a, g);
+        const WwStage s0 = ww_stage<C::TR>(a, g);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) { const int p = wave + 16 * j; ww_piece<CINB>(a, s0, rx, rz, smem, p & 7, p >> 3, cin0, co0, vox, voz, pxx, pxz); }
+        for (int j = 0; j < NJ; ++j) { const int p = wave + 16 * j; ww_piece<CINB, NB>(a, s0, rx, rz, smem, p & 7, p >> 3, cin0, co0, vox, voz, pxx, pxz); }
     }
     int cur = 0;
     const int xch = ((CINB == 64 ? wa * 32 : 0) + li) * 4;      // byte offset of this lane's input channel inside a pixel
     const int zch = (wn * 32 + li) * 4;
-    WwStage s = ww_stage(a, g);
+    WwStage s = ww_stage<C::TR>(a, g);
     for (; g < a.nstages; g += a.nsl) {
         const int gn = g + a.nsl;
         const bool more = gn < a.nstages;
         WwStage sn = s;
-        if (more) sn = ww_stage(a, gn);
+        if (more) sn = ww_stage<C::TR>(a, gn);
         ww_barrier_dma();                            // this stage has landed; nobody reads the other set any more
         const char* xs = (const char*)(smem + cur * C::SETF);
-        ww4_compute<RR, CINB>(a, xs, xs + C::XF * 4, smem + (cur ^ 1) * C::SETF, sn, more, rx, rz, s.w, s.row0 >> 2, wave, wa, lh, xch, zch, cin0, co0,
+        ww4_compute<RR, CINB, NB>(a, xs, xs + C::XF * 4, smem + (cur ^ 1) * C::SETF, sn, more, rx, rz, s.w, s.row0 / (2 * C::TR), wave, wa, lh, xch, zch, cin0, co0,
                               vox, voz, pxx, pxz, acc);
         cur ^= 1;
         s = sn;
     }
-    // partial of this workgroup (CINB 32: one per tile row of the stages): [16][CINB][64]; acc[c] = position RR * 4 + c,
+    // partial of this workgroup (CINB 32: one per tile-row class of the stages): [16][CINB][NB]; acc[c] = position RR * 4 + c,
     // register = input channel, lane = output channel
-    const int nth = CINB == 64 ? 1 : 2;
-    float* P = a.part + ((long)(sl * a.nbp + bp) * nth + (CINB == 64 ? 0 : wa)) * 16 * CINB * 64;
+    constexpr int nth = C::NTH;
+    float* P = a.part + ((long)(sl * a.nbp + bp) * nth + (CINB == 64 ? 0 : wa)) * 16 * CINB * NB;
     const int ci0 = CINB == 64 ? wa * 32 : 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -274,7 +288,7 @@ __device__ __forceinline__ void ww4_body(const WwArgs& a, float* smem) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            P[((long)xi * CINB + ci) * 64 + wn * 32 + li] = acc[i][r];
+            P[((long)xi * CINB + ci) * NB + wn * 32 + li] = acc[i][r];
         }
     }
 }
@@ -285,10 +299,23 @@ __global__ __launch_bounds__(1024, 4) void wino_wgrad4_kernel(WwArgs a) {
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) float smem[];
     switch (threadIdx.x >> 8) {
-        case 0: ww4_body<0, CINB>(a, smem); break;
-        case 1: ww4_body<1, CINB>(a, smem); break;
-        case 2: ww4_body<2, CINB>(a, smem); break;
-        default: ww4_body<3, CINB>(a, smem); break;
+        case 0: ww4_body<0, CINB, 64>(a, smem); break;
+        case 1: ww4_body<1, CINB, 64>(a, smem); break;
+        case 2: ww4_body<2, CINB, 64>(a, smem); break;
+        default: ww4_body<3, CINB, 64>(a, smem); break;
+    }
+#endif
+}
+
+// 32 input x 32 output channels per workgroup, stages of four tile rows (a kernel name of its own: one rocprof row)
+__global__ __launch_bounds__(1024, 4) void wino_wgrad4n32_kernel(WwArgs a) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    switch (threadIdx.x >> 8) {
+        case 0: ww4_body<0, 32, 32>(a, smem); break;
+        case 1: ww4_body<1, 32, 32>(a, smem); break;
+        case 2: ww4_body<2, 32, 32>(a, smem); break;
+        default: ww4_body<3, 32, 32>(a, smem); break;
     }
 #endif
 }
@@ -300,14 +327,13 @@ __global__ __launch_bounds__(1024, 4) void wino_wgrad4_kernel(WwArgs a) {
 // 32-512 workgroups of dependent loads for 64 MB.)
 constexpr int WW_RG = 16;            // groups of partials per workgroup
 __global__ __launch_bounds__(64 * WW_RG) void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int K, int N,
-                                                                         int cinb, int nparts, int nbp, int ncob) {
+                                                                         int cinb, int nparts, int nbp, int ncob, int nb, int nth) {
     __shared__ float red[WW_RG][16][64];
     const int co = threadIdx.x, g = threadIdx.y;
     const int k = blockIdx.x / ncob, cob = blockIdx.x - k * ncob;
     const int cib = k / cinb, ci = k - cib * cinb;
     const int bp = cib * ncob + cob;
-    const int nth = cinb == 64 ? 1 : 2;
-    const long pstride = (long)16 * cinb * 64;
+    const long pstride = (long)16 * cinb * nb;        // blockDim.x = nb = output channels of a block (64 or 32), nth partials per workgroup
     const int PT = nparts * nth;                                  // partial (p, t) has index p * nth + t: (p * nbp + bp) * nth + t in memory
     const int lo = (int)((long)PT * g / WW_RG), hi = (int)((long)PT * (g + 1) / WW_RG);
     float m[16];
@@ -315,9 +341,9 @@ __global__ __launch_bounds__(64 * WW_RG) void wino_wgrad_reduce_kernel(const flo
     for (int x = 0; x < 16; ++x) m[x] = 0.f;
     for (int i = lo; i < hi; ++i) {
         const int p = i / nth, t = i - p * nth;
-        const float* q = part + ((long)(p * nbp + bp) * nth + t) * pstride + (long)ci * 64 + co;
+        const float* q = part + ((long)(p * nbp + bp) * nth + t) * pstride + (long)ci * nb + co;
 #pragma unroll
-        for (int x = 0; x < 16; ++x) m[x] += q[(long)x * cinb * 64];
+        for (int x = 0; x < 16; ++x) m[x] += q[(long)x * cinb * nb];
     }
 #pragma unroll
     for (int x = 0; x < 16; ++x) red[g][x][co] = m[x];
@@ -329,7 +355,7 @@ __global__ __launch_bounds__(64 * WW_RG) void wino_wgrad_reduce_kernel(const flo
         for (int j = 1; j < WW_RG; ++j) s += red[j][x][co];
         m[x] = s;
     }
-    const int n = cob * 64 + co;
+    const int n = cob * nb + co;
     // rows: t[kh][c] = A'^T m[.][c]
     float t[3][4];
 #pragma unroll
@@ -350,7 +376,7 @@ __global__ __launch_bounds__(64 * WW_RG) void wino_wgrad_reduce_kernel(const flo
     }
 }
 
-struct WwPlan { bool ok; int cinb, ncb, cbw[8], cbt[8], SR, nstages, nbp, ncob, nsl, nparts; size_t ws; };
+struct WwPlan { bool ok; int cinb, nb, nth, ncb, cbw[8], cbt[8], SR, nstages, nbp, ncob, nsl, nparts; size_t ws; };
 
 WwPlan ww_plan(const asr_gemm_desc* d, int ldz) {
     WwPlan p;
@@ -359,10 +385,13 @@ WwPlan ww_plan(const asr_gemm_desc* d, int ldz) {
     // out of range -- ww_piece's `row > a.H` -- so the phantom pixels contribute exact zeros)
     if (!d || d->ntaps != 9 || d->wmode != 0 || d->H < 2 || d->W < 2) return p;
     if (d->K != 32 && (d->K % 64) != 0) return p;
-    if ((d->N % 64) != 0 || (d->lda & 3) || (ldz & 3) || d->M != d->B * (d->H + 1) * (d->W + 1)) return p;
+    const bool n32 = d->K == 32 && d->N == 32;                  // round 5: the 32 -> 32 layers (32 x 32 blocks, stages of four tile rows)
+    if (((d->N % 64) != 0 && !n32) || (d->lda & 3) || (ldz & 3) || d->M != d->B * (d->H + 1) * (d->W + 1)) return p;
     if ((long)d->M * d->lda * 4 >= 0x7FFFFFF0L || (long)d->M * ldz * 4 >= 0x7FFFFFF0L) return p;
     const int TH = (d->H + 1) / 2, TW = (d->W + 1) / 2;
     p.cinb = d->K == 32 ? 32 : 64;
+    p.nb = n32 ? 32 : 64;
+    p.nth = p.cinb == 64 ? 1 : n32 ? 4 : 2;
     p.ncb = asr_cdiv(TW, WW_MAXW);
     if (p.ncb > 8) return p;
     int tj = 0;
@@ -370,10 +399,10 @@ WwPlan ww_plan(const asr_gemm_desc* d, int ldz) {
         p.cbw[c] = TW / p.ncb + (c < TW % p.ncb ? 1 : 0);
         p.cbt[c] = tj; tj += p.cbw[c];
     }
-    p.SR = asr_cdiv(TH, 2);
+    p.SR = asr_cdiv(TH, n32 ? 4 : 2);
     p.nstages = d->B * p.SR * p.ncb;
     if ((long)d->B * p.SR * p.ncb >= (1L << 22)) return p;      // ww_stage's index divisions are exact below 2^22
-    p.ncob = d->N / 64;
+    p.ncob = d->N / p.nb;
     p.nbp = (d->K / p.cinb) * p.ncob;
     static int ncu = 0;
     if (!ncu) {
@@ -387,7 +416,7 @@ WwPlan ww_plan(const asr_gemm_desc* d, int ldz) {
     if (nsl < 1) return p;                       // too small a problem: the direct kernels
     p.nsl = nsl;
     p.nparts = nsl;
-    p.ws = (size_t)nsl * p.nbp * (p.cinb == 64 ? 1 : 2) * 16 * p.cinb * 64 * sizeof(float);
+    p.ws = (size_t)nsl * p.nbp * p.nth * 16 * p.cinb * p.nb * sizeof(float);
     p.ok = true;
     return p;
 }
@@ -414,15 +443,23 @@ int asr_wino_wgrad_launch(const asr_gemm_desc* d, const float* A, const float* d
     // grid: slices rounded up to whole groups of 8, times block pairs (see ww_body)
     const int grid = asr_cdiv(p.nsl, 8) * 8 * p.nbp;
     hipStream_t st = (hipStream_t)stream;
-    if (p.cinb == 64) {
-        const size_t lds = (size_t)2 * WwCfg<64>::SETF * sizeof(float);
+    if (p.nb == 32) {
+        const size_t lds = (size_t)2 * WwCfg<32, 32>::SETF * sizeof(float);
+        static_assert(2 * WwCfg<32, 32>::SETF * sizeof(float) <= 160 * 1024, "two buffer sets of the four-row stage must fit the CU's LDS");
+        static bool t3232 = false;
+        auto k = wino_wgrad4n32_kernel;
+        if (!t3232) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); t3232 = true; }
+        hipLaunchKernelGGL(k, dim3(grid), dim3(1024), lds, st, a);
+        ASR_NOTE_KERNEL("wino_wgrad4n32_kernel");
+    } else if (p.cinb == 64) {
+        const size_t lds = (size_t)2 * WwCfg<64, 64>::SETF * sizeof(float);
         static bool t64 = false;
         auto k = wino_wgrad4_kernel<64>;
         if (!t64) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); t64 = true; }
         hipLaunchKernelGGL(k, dim3(grid), dim3(1024), lds, st, a);
         ASR_NOTE_KERNEL("wino_wgrad4_kernel<64>");
     } else {
-        const size_t lds = (size_t)2 * WwCfg<32>::SETF * sizeof(float);
+        const size_t lds = (size_t)2 * WwCfg<32, 64>::SETF * sizeof(float);
         static bool t32 = false;
         auto k = wino_wgrad4_kernel<32>;
         if (!t32) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); t32 = true; }
@@ -430,8 +467,8 @@ int asr_wino_wgrad_launch(const asr_gemm_desc* d, const float* A, const float* d
         ASR_NOTE_KERNEL("wino_wgrad4_kernel<32>");
     }
     ASR_CHECK_LAUNCH("wino_wgrad");
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(d->K * p.ncob), dim3(64, WW_RG), 0, st, partials, dW, d->K, d->N, p.cinb, p.nparts,
-                       p.nbp, p.ncob);
+    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(d->K * p.ncob), dim3(p.nb, WW_RG), 0, st, partials, dW, d->K, d->N, p.cinb, p.nparts,
+                       p.nbp, p.ncob, p.nb, p.nth);
     ASR_CHECK_LAUNCH("wino_wgrad_reduce");
     return ASR_OK;
 }

@@ -133,7 +133,7 @@ def test_fbank_full_length_batch_matches_oracle_and_is_ragged_safe():
 
 
 @pytest.mark.parametrize("H,W,cin,cout", [(800, 100, 32, 64), (400, 50, 64, 128), (200, 25, 128, 128), (200, 25, 128, 256),
-                                          (200, 25, 32, 256)])
+                                          (200, 25, 32, 256), (800, 100, 32, 32)])
 def test_winograd_weight_gradient_equals_direct_at_layer_size(H, W, cin, cout):
     """asr_tap_wgrad (Winograd F(3x3,2x2), wino_wgrad.hip) against asr_tap_wgrad_direct (the direct eight-wave kernels: an independent
     implementation) on the plain DFCNN's 3x3 layer shapes at B = 8, plus the properties the training step relies on: bitwise

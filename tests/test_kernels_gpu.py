@@ -137,7 +137,12 @@ def test_conv1x1_forward_and_dgrad(ops):
                                             (4, 20, 50, 64, 64), (2, 16, 100, 32, 64), (3, 22, 27, 128, 64), (2, 36, 2, 64, 64),
                                             (2, 26, 25, 32, 128), (1, 64, 13, 128, 128),
                                             # odd heights on the Winograd route (round 4): the last tile row is half filled
-                                            (2, 125, 25, 64, 64), (3, 7, 50, 32, 64), (2, 25, 25, 128, 128), (16, 1, 25, 64, 64)])
+                                            (2, 125, 25, 64, 64), (3, 7, 50, 32, 64), (2, 25, 25, 128, 128), (16, 1, 25, 64, 64),
+                                            # 32 -> 32 channels (round 5, acoustic_model2.py:39; wino_wgrad4n32_kernel: stages of FOUR tile rows,
+                                            # one per wave class): four column blocks, tile-row counts that are not multiples of four, odd
+                                            # block widths (last tiles of two rows paired), odd heights, a single pixel row
+                                            (2, 16, 100, 32, 32), (3, 22, 27, 32, 32), (2, 125, 25, 32, 32), (4, 30, 52, 32, 32),
+                                            (16, 1, 25, 32, 32), (2, 38, 50, 32, 32)])
 def test_conv3x3_wgrad(ops, B, H, W, cin, cout):
     rng = np.random.default_rng(4)
     x = rng.standard_normal((B, H, W, cin)).astype(np.float32)

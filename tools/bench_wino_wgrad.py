@@ -7,7 +7,7 @@ from asr_dfcnn_transformer_amd import ops
 from asr_dfcnn_transformer_amd.ops import Plane
 
 B = int(os.environ.get('B', 32))
-SHAPES = [('c2 800x100 32->64', 800, 100, 32, 64), ('c2_1 400x50 64->64', 400, 50, 64, 64), ('c3 400x50 64->128', 400, 50, 64, 128),
+SHAPES = [('c1_1 800x100 32->32 (m2)', 800, 100, 32, 32), ('c2 800x100 32->64', 800, 100, 32, 64), ('c2_1 400x50 64->64', 400, 50, 64, 64), ('c3 400x50 64->128', 400, 50, 64, 128),
           ('c4 200x25 128->128', 200, 25, 128, 128), ('c6 200x25 128->256', 200, 25, 128, 256), ('c5 200x25 32->256', 200, 25, 32, 256)]
 if os.environ.get('ONLY'):
     SHAPES = [s for s in SHAPES if s[0].startswith(os.environ['ONLY'])]

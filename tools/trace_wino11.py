@@ -8,7 +8,7 @@ import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from asr_dfcnn_transformer_amd import _lib
-_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libasrhip_trace.so')
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), os.environ.get('TRACE_LIB', 'libasrhip_trace.so'))
 import torch
 from asr_dfcnn_transformer_amd import ops
 from asr_dfcnn_transformer_amd.ops import Plane
@@ -42,12 +42,14 @@ for name, H, W, cin, cout, pool in (('fwd c2 32->64 pooled', 800, 100, 32, 64, 2
     y = Plane(B, H // 2, W // 2, cout) if pool else Plane(B, H, W, cout)
     d = ops.gemm_desc(x.NP, cin, cout, cin, cout, cout, 0 if pool else cout, ntaps=9, B=B, H=H, W=W, relu=1)
     wt = ops.winograd_weights(w, cin, cout, cout, 0)
+    if pool:
+        amax, idx = Plane(B, H // 2, W // 2, cout), ops.poolmax_index(B, H // 2, W // 2, cout)
     for _ in range(3):
-        if pool: ops.tap_gemm_wino_pool(d, x, wt, bias, sc, sh, a, pool, y)
+        if pool: ops.tap_gemm_wino_poolmax(d, x, wt, bias, sc, sh, y, amax, idx)       # the compact form the engine uses
         else: ops.tap_gemm_wino(d, x, wt, bias, sc, sh, a, y)
     dump(name)
     del x, a, y
-for name, H, W, K, N, pool in (('dgrad h3 128->64 gated max-pool', 400, 50, 128, 64, 2), ('dgrad h2 64->32 plain', 800, 100, 64, 32, None)):
+for name, H, W, K, N, pool in (('dgrad h3 128->64 gated compact max-pool', 400, 50, 128, 64, 2), ('dgrad h4 128->128 gated compact max-pool', 200, 25, 128, 128, 2), ('dgrad h2 64->32 plain', 800, 100, 64, 32, None)):
     dz = Plane(B, H, W, K); dz.set_interior(rnd(B, H, W, K))
     w = rnd(3, 3, N, K) * 0.05
     bd = ops.gemm_desc(dz.NP, K, N, K, K, 0, N, ntaps=9, B=B, H=H, W=W, wmode=1)
@@ -62,5 +64,8 @@ for name, H, W, K, N, pool in (('dgrad h3 128->64 gated max-pool', 400, 50, 128,
         dzo = Plane(B, gh, gw, N)
         sums = [torch.zeros(N, device='cuda') for _ in range(3)]
         ws = torch.zeros(ops.tap_gemm_gated_workspace(bd) // 4 + 64, device='cuda')
-        for _ in range(3): ops.tap_gemm_gated(bd, dz, wt, 2, pool, act, sc, sh, None, dzo, sums[0], sums[1], sums[2], ws)
+        amax = Plane(B, H, W, N); amax.set_interior(torch.relu(rnd(B, H, W, N)))
+        idx = ops.poolmax_index(B, H, W, N)
+        idx.copy_(torch.randint(0, 2 ** 31 - 1, idx.shape, device='cuda', generator=g, dtype=torch.int64).to(idx.dtype))
+        for _ in range(3): ops.tap_gemm_gated_poolmax(bd, dz, wt, gh, gw, amax, idx, sc, sh, None, dzo, sums[0], sums[1], sums[2], ws)
     dump(name)
