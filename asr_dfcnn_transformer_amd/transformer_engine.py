@@ -156,8 +156,10 @@ class _Base:
         (asr_layernorm_bwd_fused with NULL outputs) and _ln_reduce folds the partials of ALL sites of a step in one batched reduction
         (two launches instead of two per LayerNorm; the optimiser is the only reader of those gradients)."""
         reg = self.__dict__.setdefault('_ln_sites', {})
-        if name not in reg:
-            nblk = ops.layernorm_bwd_blocks(rows)
+        nblk = ops.layernorm_bwd_blocks(rows)
+        if name not in reg or reg[name][1] != nblk:
+            # (a site called with another row count: a new buffer and a new batch table -- the kernel writes cdiv(rows, rows per
+            # block) partial rows, an old buffer would be overrun or leave stale rows in the fold)
             reg[name] = (self._t(nblk * 2 * self.C), nblk)
             self._ln_batch = None
         return reg[name][0]
