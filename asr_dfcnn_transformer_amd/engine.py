@@ -152,17 +152,20 @@ def param_layout(g):
 class DFCNNEngine:
     def __init__(self, model='m2', vocab=1536, B=32, T=1600, F=200, widths=None, seed=0, device='cuda',
                  lr=7e-4, decay_steps=5000, min_lr=1e-6, beta1=0.9, beta2=0.999, adam_eps=1e-8,
-                 dual_stream=True, wino=True, fuse_prologues=True, fuse_se=True, compact_pool=True, side_priority=0):
+                 dual_stream=True, wino=True, fuse_prologues=True, fuse_se=True, compact_pool=True, side_priority=0,
+                 dense_wgrad_side=True):
         """Options (constructor arguments only -- nothing here reads the environment; `options()` reports them):
         ``dual_stream``: weight gradients / decode on a second stream (``side_priority``: its HIP stream priority);
         ``wino``: Winograd F(2x2,3x3) / F(3x3,2x2) for the 3x3 layers the kernels support instead of the direct tap-GEMM;
         ``fuse_prologues``: cell backward prologues inside the data-gradient epilogues; ``fuse_se``: an SE block's backward also
         runs its branch cell's BN / ReLU backward (asr_se_bwd_cell); ``compact_pool``: max-pooled cells keep the activation at each
-        window's maximum + its position instead of the pre-pool plane.  Each of them leaves the results bitwise (streams, fusions,
+        window's maximum + its position instead of the pre-pool plane; ``dense_wgrad_side``: the dense layers' weight / bias gradients on
+        the second stream beside their data-gradients (False: in front of them on the main stream, as until round 4).  Each of them leaves the results bitwise (streams, fusions,
         compact form) or to rounding (Winograd) unchanged; they exist for A/B measurements and tests."""
         assert T % 8 == 0 and F >= 8
         self.opt_dual, self.opt_wino, self.opt_fuse = bool(dual_stream), bool(wino), bool(fuse_prologues)
         self.opt_fuse_se, self.opt_compact, self.side_priority = bool(fuse_se), bool(compact_pool), int(side_priority)
+        self.opt_dense_side = bool(dense_wgrad_side)
         self.model, self.V, self.B, self.T, self.F = model, vocab, B, T, F
         self.device = device
         self.g = graph(model, vocab, widths, F)
@@ -451,7 +454,7 @@ class DFCNNEngine:
     def options(self):
         """The switches this engine was built with and what they resolved to on this graph (bench.py puts it in its JSON line)."""
         return {'dual_stream': self.opt_dual, 'wino': self.opt_wino, 'fuse_prologues': self.opt_fuse, 'fuse_se': self.opt_fuse_se,
-                'compact_pool': self.opt_compact, 'side_priority': self.side_priority,
+                'compact_pool': self.opt_compact, 'side_priority': self.side_priority, 'dense_wgrad_side': self.opt_dense_side,
                 'winograd_layers_fwd': sorted(self.wt_f), 'winograd_layers_dgrad': sorted(self.wt_b),
                 'fused_prologues': len(self.fuse), 'se_blocks_fused_with_cell_backward': len(self.se_cell),
                 'compact_max_pool_cells': sorted(self.compact)}
@@ -732,14 +735,28 @@ class DFCNNEngine:
                 if act == 'relu':
                     ops.relu_bwd(dz, self.flat[dst], dz)
                 rows = dz.shape[0]
-                ops.tap_wgrad(self.wdesc[dst], self.flat[src], dz, cout, self.gview(dst, 'w'), self.ws)
-                ops.colsum(dz, rows, cout, cout, self.gview(dst, 'b'), self.ws)
+                if self.side is not None and self.opt_dense_side:
+                    # weight and bias gradient of a dense layer beside its data-gradient (round 5: they sat on the main stream in front
+                    # of it -- ~0.1 ms of the critical path of the plain model while the second stream had nothing to do yet)
+                    dz_final = torch.cuda.Event()
+                    dz_final.record()
+                    self.side.wait_event(dz_final)
+                    with torch.cuda.stream(self.side):
+                        ops.tap_wgrad(self.wdesc[dst], self.flat[src], dz, cout, self.gview(dst, 'w'), self.ws_side)
+                        ops.colsum(dz, rows, cout, cout, self.gview(dst, 'b'), self.ws_side)
+                        side_busy = torch.cuda.Event()
+                        side_busy.record()
+                else:
+                    ops.tap_wgrad(self.wdesc[dst], self.flat[src], dz, cout, self.gview(dst, 'w'), self.ws)
+                    ops.colsum(dz, rows, cout, cout, self.gview(dst, 'b'), self.ws)
                 if dst in self.dsplitk and dst in self.wT:
                     ops.tap_gemm_splitk(self.dsplitk[dst], dz, self.wT[dst], None, None, None, None, self.dflat[src], 8, self.ws)
                 else:
                     ops.tap_gemm(self.bdesc[dst], dz, self.p(dst, 'w'), None, None, None, None, self.dflat[src])
                 dense_pending -= 1
                 if dense_pending == 0 and on_dense_grads_ready is not None:
+                    if side_busy is not None:          # the dense gradients are final once the second stream has written them
+                        torch.cuda.current_stream().wait_event(side_busy)
                     on_dense_grads_ready()
             elif op[0] == 'se':
                 _, main, br, dst, Cc, hid, use_bn = op
