@@ -41,6 +41,9 @@ SIGNATURES = {
     'asr_tap_gemm_wino_poolmax': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_gemm_gated_poolmax': (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_gemm_gated': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'asr_tap_gemm_gated_dense_supported': (_I, [C.POINTER(GemmDesc), _I, _I, _I]),
+    'asr_tap_gemm_gated_dense_workspace': (_Z, [C.POINTER(GemmDesc), _I, _I]),
+    'asr_tap_gemm_gated_dense': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_wgrad_workspace': (_Z, [C.POINTER(GemmDesc)]),
     'asr_tap_wgrad': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _P, _P, _P]),
     'asr_tap_wgrad_direct': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _P, _P, _P]),

@@ -41,7 +41,7 @@ __device__ __forceinline__ void dma_barrier() {
 
 }  // namespace
 
-struct Gemm1Gate { int mode, H, W; const float* a; float* dz; float* part; int* rows; };
+struct Gemm1Gate { int mode, H, W; const float* a; float* dz; float* part; int* rows; int C = 0; };
 
 namespace {
 
@@ -158,7 +158,11 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void gemm1_kernel(Gemm1Args a
         const long p = (long)m0 + tid;
         int ra = -1, ry = -1;
         if (p < g.M) {
-            if (g.H == 0) {
+            if (g.gate_mode == 5) {
+                // dense-layout gate: GEMM row = image b, pixel row h of the gated cell; the table holds its plane pixel at column 1
+                const int b = (int)(p / g.gate_H), h = (int)(p - (long)b * g.gate_H);
+                ra = (b * (g.gate_H + 1) + h + 1) * (g.gate_W + 1) + 1; ry = ra;
+            } else if (g.H == 0) {
                 ra = (int)p; ry = (int)p;
             } else {
                 const int b = (int)(p / g.HPWP);
@@ -440,7 +444,8 @@ int asr_gemm1_launch(const asr_gemm_desc* d, const float* A, const float* Bt, in
     a.ntm = asr_cdiv(d->M, 128); a.ntn = asr_cdiv(d->N, 64 * nb);
     if (gate) {
         a.gate_mode = gate->mode; a.gate_H = gate->H; a.gate_W = gate->W; a.gate_a = gate->a; a.gate_dz = gate->dz; a.gate_part = gate->part;
-        if (gate->rows) *gate->rows = a.ntm * 2;           // one partial row per (tile row, wave row)
+        a.gate_C = gate->C;
+        if (gate->rows) *gate->rows = a.ntm * 2 * (gate->mode == 5 ? gate->W : 1);       // one partial row per (tile row, wave row[, pixel column])
     }
     ga.Bt = Bt; ga.ldb = ldb;
     const size_t lds = (size_t)(256 + 2 * (G1_TILE_F + nb * 64 * G1_KC)) * sizeof(float);

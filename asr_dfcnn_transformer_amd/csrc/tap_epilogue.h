@@ -21,7 +21,8 @@ struct TapGemmArgs {
     int ntm, ntn;
     // fused backward prologue of the cell whose gradient this data-gradient completes (asr_tap_gemm_gated): instead of
     // writing dL/dy of that cell, the epilogue routes it through the cell's pool / BN / ReLU backward and writes dZ
-    int gate_mode;       // 0 off, 1 no pool, 2 average pool 2x2, 3 max pool 2x2
+    int gate_mode;       // 0 off, 1 no pool, 2 average pool 2x2, 3 max pool 2x2, 4 compact max pool (wino11_kernel),
+                         // 5 no pool, DENSE layout (asr_tap_gemm_gated_dense): GEMM row = (image, pixel row), column = pixel column * gate_C + channel
     int gate_H, gate_W;  // the gated cell's pre-pool plane (= H, Wd here for mode 1, 2H x 2W for modes 2, 3)
     const float* gate_a; // its post-ReLU pre-BN activations, padded plane [B][gate_H+1][gate_W+1][N]
     float* gate_dz;      // out: dL/d(conv + bias) of that cell, same layout as gate_a (scale / shift = its BN affine)
@@ -32,6 +33,7 @@ struct TapGemmArgs {
     int ksplit = 1;
     float* split_out = nullptr;
     int nt_store = 0;    // non-temporal stores in the plain epilogue (the Winograd launches set it)
+    int gate_C = 0;      // gate mode 5: channels of the gated cell (the GEMM is gate_W * gate_C columns wide)
 };
 
 // Row offset of tap `tap` in the flattened padded plane, and the tap of the weight tensor it multiplies.
@@ -75,9 +77,10 @@ __device__ __forceinline__ void tap_epilogue_gated(const TapGemmArgs& g, const f
                                                    const int* rowa, int* rowf, int row0, int col0, int lane, int part_row) {
     const int li = lane & 31, lh = lane >> 5;
     const int c4 = lane & 7, rsub = lane >> 3;
-    const int C = g.N;
+    const bool dense = g.gate_mode == 5;          // rowa[m] = the plane pixel of GEMM row m at pixel column 0 (the kernel's row table)
+    const int C = dense ? g.gate_C : g.N;
     const int WPf = g.gate_W + 1;
-    if (g.gate_mode >= 2) {
+    if (g.gate_mode >= 2 && !dense) {
         // full-resolution pixel of window position 0 for each of this wave's rows (wave-private slice of the table)
         for (int r = lane; r < TM * 32; r += 64) {
             const int m = row0 + r;
@@ -97,8 +100,11 @@ __device__ __forceinline__ void tap_epilogue_gated(const TapGemmArgs& g, const f
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-        const int n = col0 + b * 32 + c4 * 4;
-        const bool ncol = n < g.N;
+        const int ng = col0 + b * 32 + c4 * 4;          // GEMM column
+        const bool ncol = ng < g.N;
+        // dense layout: the wave's 32 columns are 32 channels of ONE pixel column wq (gate_C % 32 == 0)
+        const int wq = dense ? ng / C : 0;
+        const int n = dense ? ng - wq * C : ng;          // channel
         float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ncol) { sc = *(const float4*)(g.scale + n); sh = *(const float4*)(g.shift + n); }
         ep_touch(sc); ep_touch(sh);
@@ -112,7 +118,7 @@ __device__ __forceinline__ void tap_epilogue_gated(const TapGemmArgs& g, const f
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 8 + rsub;
                 const int m = row0 + a * 32 + row;
-                const int ra = rowa[m];
+                const int ra = rowa[m] < 0 ? -1 : rowa[m] + wq;
                 const float* sp = scratch + row * 33 + c4 * 4;
                 float v[4] = {sp[0], sp[1], sp[2], sp[3]};
                 if (ra < 0 || !ncol) continue;
@@ -120,7 +126,7 @@ __device__ __forceinline__ void tap_epilogue_gated(const TapGemmArgs& g, const f
                     const float4 p = *(const float4*)(g.out_y + (long)ra * g.ldo_y + n);
                     v[0] += p.x; v[1] += p.y; v[2] += p.z; v[3] += p.w;
                 }
-                if (g.gate_mode == 1) {
+                if (g.gate_mode == 1 || dense) {
                     const float4 a4 = *(const float4*)(g.gate_a + (long)ra * C + n);
                     const float av[4] = {a4.x, a4.y, a4.z, a4.w};
                     float d[4];
@@ -173,7 +179,7 @@ __device__ __forceinline__ void tap_epilogue_gated(const TapGemmArgs& g, const f
             }
         }
         if (rsub == 0 && ncol) {
-            float* pr = g.gate_part + (long)part_row * 3 * C + n;
+            float* pr = g.gate_part + ((long)part_row * (dense ? g.gate_W : 1) + wq) * 3 * C + n;
             *(float4*)(pr) = make_float4(s_scale[0], s_scale[1], s_scale[2], s_scale[3]);
             *(float4*)(pr + C) = make_float4(s_shift[0], s_shift[1], s_shift[2], s_shift[3]);
             *(float4*)(pr + 2 * C) = make_float4(s_bias[0], s_bias[1], s_bias[2], s_bias[3]);

@@ -494,7 +494,7 @@ int launch_n(const TapGemmArgs& a, hipStream_t st) {
 struct GateSpec { int mode, H, W; const float* a; float* dz; float* part; int* rows; };
 
 // gemm1.hip: the LDS-DMA "NT" GEMM that takes the large 1-tap data-gradients (dX = dY . W^T: both operands K-contiguous)
-struct Gemm1Gate { int mode, H, W; const float* a; float* dz; float* part; int* rows; };
+struct Gemm1Gate { int mode, H, W; const float* a; float* dz; float* part; int* rows; int C = 0; };
 bool asr_gemm1_eligible(const asr_gemm_desc* d, const float* A, const float* Bt, int ldb);
 int asr_gemm1_launch(const asr_gemm_desc* d, const float* A, const float* Bt, int ldb, const float* bias, const float* scale,
                      const float* shift, float* out_a, float* out_y, int dir, void* stream, const Gemm1Gate* gate);
@@ -719,4 +719,41 @@ extern "C" int asr_tap_gemm_gated(const asr_gemm_desc* d, const float* dZ, const
     m.nseg = 3; m.width[0] = d->N; m.width[1] = d->N; m.width[2] = d->N; m.width[3] = 0;
     m.out[0] = dscale; m.out[1] = dshift; m.out[2] = dbias; m.out[3] = nullptr;
     return asr_reduce::colsum_multi(partials, rows, 3L * d->N, m, partials + (size_t)rows * 3 * d->N, (hipStream_t)stream);
+}
+
+// ---- round 5: the same fusion where the cell in front hands its output to a DENSE layer (acoustic_model.py:48-50 reshape -> dense;
+// acoustic_model2.py:62-66): dL/d(flat) = dZ . W^T is [B * H][W * C] in the dense layout -- row = (image, pixel row), column = pixel
+// column * C + channel -- and used to be written out (164 MB at B = 32, 200 x 25 x 256), read back with the cell's activations by
+// asr_cell_bwd_pre and turned into the cell's dZ plane and channel sums.  Here the GEMM's epilogue does that on the value in the
+// register (gate mode 5 of tap_epilogue_gated: BN / ReLU backward of an un-pooled cell): no dL/d(flat) tensor, no separate pass.
+//   d: the dense layer's data-gradient descriptor (ntaps 1, wmode 1, M = B * gate_H rows, K = its output width, N = gate_W * gate_C)
+//   a_plane / dz_out: the cell's activation / dZ planes [B][gate_H + 1][gate_W + 1][gate_C]; dscale / dshift / dbias [gate_C]
+// dZ is bit for bit what asr_tap_gemm + asr_cell_bwd_pre give; the three channel sums are folded in another fixed order.
+extern "C" int asr_tap_gemm_gated_dense_supported(const asr_gemm_desc* d, int gate_H, int gate_W, int gate_C) {
+    if (!d || d->ntaps != 1 || d->wmode != 1 || d->relu != 0 || d->accumulate || d->H > 0) return 0;
+    if (gate_H < 1 || gate_W < 1 || gate_C < 32 || (gate_C & 31) || d->N != gate_W * gate_C || (d->M % gate_H) != 0) return 0;
+    if ((long)(d->M / gate_H) * (gate_H + 1) * (gate_W + 1) >= (1L << 31) / (long)gate_C) return 0;          // plane pixels x channels in 31 bits
+    return ((d->K & 3) || (d->lda & 3) || (d->ldw & 3) || d->K < 32 ||
+            (long)asr_cdiv(d->M, 128) * asr_cdiv(d->N, 128) < 48) ? 0 : 1;                                      // asr_gemm1_eligible's shape rules
+}
+extern "C" size_t asr_tap_gemm_gated_dense_workspace(const asr_gemm_desc* d, int gate_W, int gate_C) {
+    if (!d || gate_W < 1 || gate_C < 1) return 0;
+    const int rows = asr_cdiv(d->M, 128) * 2 * gate_W;
+    return ((size_t)rows * 3 * gate_C + asr_reduce::colsum_tmp_floats(rows, 3 * gate_C)) * sizeof(float);
+}
+extern "C" int asr_tap_gemm_gated_dense(const asr_gemm_desc* d, const float* dZ, const float* W, int gate_H, int gate_W, int gate_C,
+                                        const float* a_plane, const float* bn_scale, const float* bn_shift, float* dz_out,
+                                        float* dscale, float* dshift, float* dbias, float* partials, void* stream) {
+    if (!d || !dZ || !W || !a_plane || !bn_scale || !bn_shift || !dz_out || !dscale || !dshift || !dbias || !partials) return ASR_ERR_BAD_ARG;
+    if (!asr_tap_gemm_gated_dense_supported(d, gate_H, gate_W, gate_C) || !asr_gemm1_eligible(d, dZ, W, d->ldw)) return ASR_ERR_UNSUPPORTED;
+    int rows = 0;
+    Gemm1Gate gg;
+    gg.mode = 5; gg.H = gate_H; gg.W = gate_W; gg.C = gate_C; gg.a = a_plane; gg.dz = dz_out; gg.part = partials; gg.rows = &rows;
+    const int rc = asr_gemm1_launch(d, dZ, W, d->ldw, nullptr, bn_scale, bn_shift, nullptr, nullptr, 1, stream, &gg);
+    if (rc != ASR_OK) return rc;
+    if (rows <= 0 || (size_t)rows * 3 * gate_C * sizeof(float) > asr_tap_gemm_gated_dense_workspace(d, gate_W, gate_C)) return ASR_ERR_UNSUPPORTED;
+    asr_reduce::Multi m;
+    m.nseg = 3; m.width[0] = gate_C; m.width[1] = gate_C; m.width[2] = gate_C; m.width[3] = 0;
+    m.out[0] = dscale; m.out[1] = dshift; m.out[2] = dbias; m.out[3] = nullptr;
+    return asr_reduce::colsum_multi(partials, rows, 3L * gate_C, m, partials + (size_t)rows * 3 * gate_C, (hipStream_t)stream);
 }

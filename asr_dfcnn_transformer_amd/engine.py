@@ -153,19 +153,20 @@ class DFCNNEngine:
     def __init__(self, model='m2', vocab=1536, B=32, T=1600, F=200, widths=None, seed=0, device='cuda',
                  lr=7e-4, decay_steps=5000, min_lr=1e-6, beta1=0.9, beta2=0.999, adam_eps=1e-8,
                  dual_stream=True, wino=True, fuse_prologues=True, fuse_se=True, compact_pool=True, side_priority=0,
-                 dense_wgrad_side=True):
+                 dense_wgrad_side=True, fuse_dense=True):
         """Options (constructor arguments only -- nothing here reads the environment; `options()` reports them):
         ``dual_stream``: weight gradients / decode on a second stream (``side_priority``: its HIP stream priority);
         ``wino``: Winograd F(2x2,3x3) / F(3x3,2x2) for the 3x3 layers the kernels support instead of the direct tap-GEMM;
         ``fuse_prologues``: cell backward prologues inside the data-gradient epilogues; ``fuse_se``: an SE block's backward also
         runs its branch cell's BN / ReLU backward (asr_se_bwd_cell); ``compact_pool``: max-pooled cells keep the activation at each
         window's maximum + its position instead of the pre-pool plane; ``dense_wgrad_side``: the dense layers' weight / bias gradients on
-        the second stream beside their data-gradients (False: in front of them on the main stream, as until round 4).  Each of them leaves the results bitwise (streams, fusions,
+        the second stream beside their data-gradients (False: in front of them on the main stream, as until round 4); ``fuse_dense``: the
+        data-gradient of a dense layer fed by a cell also runs that cell's BN / ReLU backward (asr_tap_gemm_gated_dense).  Each of them leaves the results bitwise (streams, fusions,
         compact form) or to rounding (Winograd) unchanged; they exist for A/B measurements and tests."""
         assert T % 8 == 0 and F >= 8
         self.opt_dual, self.opt_wino, self.opt_fuse = bool(dual_stream), bool(wino), bool(fuse_prologues)
         self.opt_fuse_se, self.opt_compact, self.side_priority = bool(fuse_se), bool(compact_pool), int(side_priority)
-        self.opt_dense_side = bool(dense_wgrad_side)
+        self.opt_dense_side, self.opt_fuse_dense = bool(dense_wgrad_side), bool(fuse_dense)
         self.model, self.V, self.B, self.T, self.F = model, vocab, B, T, F
         self.device = device
         self.g = graph(model, vocab, widths, F)
@@ -436,6 +437,21 @@ class DFCNNEngine:
                 if cell is not None and cell[1] != 'x' and cell[6] is None and br not in self.dflat and br not in self.fuse.values() \
                         and self.consumers.get(br, []) == [op]:
                     self.se_cell[op[3]] = cell
+        # Dense layers whose input is the flattened output of an un-pooled cell that nothing else reads (the reshape -> dense heads):
+        # the dense data-gradient's epilogue runs that cell's BN / ReLU backward (asr_tap_gemm_gated_dense) -- no dL/d(flat)
+        # tensor, no asr_cell_bwd_pre pass.  {dense layer -> cell op}.  Widths and geometry only.
+        self.dense_gate = {}
+        if self.opt_fuse and self.opt_fuse_dense:
+            for op in self.g:
+                if op[0] != 'dense':
+                    continue
+                cell = next((c for c in self.g if c[0] == 'cell' and c[2] == op[1]), None)
+                if cell is None or cell[1] == 'x' or cell[6] is not None or self.consumers.get(op[1], []) != [op] or op[2] in self.dsplitk:
+                    continue
+                Hc, Wc, _ = self.res[cell[1]]
+                if ops.tap_gemm_gated_dense_supported(self.bdesc[op[2]], Hc, Wc, cell[4]):
+                    self.dense_gate[op[2]] = cell
+                    self.ws_gate = max(self.ws_gate, ops.tap_gemm_gated_dense_workspace(self.bdesc[op[2]], Wc, cell[4]))
         self.compact = {}
         for writer, tgt in (self.fuse.items() if self.opt_compact else ()):
             top = next(o for o in self.g if o[0] == 'cell' and o[2] == tgt)
@@ -454,9 +470,9 @@ class DFCNNEngine:
     def options(self):
         """The switches this engine was built with and what they resolved to on this graph (bench.py puts it in its JSON line)."""
         return {'dual_stream': self.opt_dual, 'wino': self.opt_wino, 'fuse_prologues': self.opt_fuse, 'fuse_se': self.opt_fuse_se,
-                'compact_pool': self.opt_compact, 'side_priority': self.side_priority, 'dense_wgrad_side': self.opt_dense_side,
+                'compact_pool': self.opt_compact, 'side_priority': self.side_priority, 'dense_wgrad_side': self.opt_dense_side, 'fuse_dense': self.opt_fuse_dense,
                 'winograd_layers_fwd': sorted(self.wt_f), 'winograd_layers_dgrad': sorted(self.wt_b),
-                'fused_prologues': len(self.fuse), 'se_blocks_fused_with_cell_backward': len(self.se_cell),
+                'fused_prologues': len(self.fuse), 'dense_gradients_with_cell_backward': sorted(self.dense_gate), 'se_blocks_fused_with_cell_backward': len(self.se_cell),
                 'compact_max_pool_cells': sorted(self.compact)}
 
     def _plan_fused_prologues(self):
@@ -749,7 +765,14 @@ class DFCNNEngine:
                 else:
                     ops.tap_wgrad(self.wdesc[dst], self.flat[src], dz, cout, self.gview(dst, 'w'), self.ws)
                     ops.colsum(dz, rows, cout, cout, self.gview(dst, 'b'), self.ws)
-                if dst in self.dsplitk and dst in self.wT:
+                if dst in self.dense_gate:
+                    cell = self.dense_gate[dst]
+                    Hc, Wc, _ = self.res[cell[1]]
+                    dzt = acquire_dz((Hc, Wc, cell[4]))
+                    ops.tap_gemm_gated_dense(self.bdesc[dst], dz, self.p(dst, 'w'), self.a[src], self.scale_of(src), self.p(src, 'beta'), dzt,
+                                             self.dscale_of(src), self.gview(src, 'beta'), self.gview(src, 'b'), self.ws)
+                    fused_dz[src] = dzt
+                elif dst in self.dsplitk and dst in self.wT:
                     ops.tap_gemm_splitk(self.dsplitk[dst], dz, self.wT[dst], None, None, None, None, self.dflat[src], 8, self.ws)
                 else:
                     ops.tap_gemm(self.bdesc[dst], dz, self.p(dst, 'w'), None, None, None, None, self.dflat[src])

@@ -162,6 +162,24 @@ def tap_gemm_gated(desc, dZ, W, prearranged, pool, gate_a, bn_scale, bn_shift, d
                                _ptr(partials), _stream()), 'asr_tap_gemm_gated'))
 
 
+def tap_gemm_gated_dense_supported(desc, H, W, Cc):
+    return bool(_lib.load().asr_tap_gemm_gated_dense_supported(C.byref(desc), int(H), int(W), int(Cc)))
+
+
+def tap_gemm_gated_dense_workspace(desc, W, Cc):
+    return _lib.load().asr_tap_gemm_gated_dense_workspace(C.byref(desc), int(W), int(Cc))
+
+
+def tap_gemm_gated_dense(desc, dZ, W, gate_a, bn_scale, bn_shift, dz_out, dscale, dshift, dbias, partials):
+    """Data-gradient of a dense layer whose input is the (flattened) output of an un-pooled cell, with that cell's BN / ReLU backward
+    in the epilogue (asr_tap_gemm_gated_dense): gate_a / dz_out are the cell's activation / dZ Planes."""
+    lib = _lib.load()
+    _timed(desc, lambda: check(
+        lib.asr_tap_gemm_gated_dense(C.byref(desc), _ptr(dZ), _ptr(W), gate_a.H, gate_a.W, gate_a.C, gate_a.ptr, _ptr(bn_scale), _ptr(bn_shift),
+                                     dz_out.ptr, _ptr(dscale), _ptr(dshift), _ptr(dbias), _ptr(partials), _stream()),
+        'asr_tap_gemm_gated_dense'))
+
+
 def poolmax_supported(fwd_desc, bwd_desc):
     return bool(_lib.load().asr_winograd_poolmax_supported(C.byref(fwd_desc), C.byref(bwd_desc)))
 

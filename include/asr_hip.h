@@ -537,6 +537,24 @@ int asr_tap_gemm_gated(const asr_gemm_desc* d, const float* dZ, const float* W, 
                        const float* bn_scale, const float* bn_shift, const float* dy_prev,
                        float* dz_out, float* dscale, float* dshift, float* dbias, float* partials, void* stream);
 
+/* Round 5: the same fusion where cell k-1 hands its output to a DENSE layer (the reshape -> tf.layers.dense heads,
+ * acoustic_model.py:48-50, acoustic_model2.py:62-66): the dense layer's data-gradient dL/d(flat) = dZ . W^T is [B * gate_H] x
+ * [gate_W * gate_C] -- row = (image, pixel row), column = pixel column * gate_C + channel -- and its epilogue applies the BN / ReLU
+ * backward of the (un-pooled) cell: no dL/d(flat) tensor and no asr_cell_bwd_pre pass.  dZ(k-1) bit for bit what asr_tap_gemm +
+ * asr_cell_bwd_pre (layout 2) give, the three channel sums folded in another fixed order.
+ *   d          the dense layer's data-gradient descriptor: ntaps 1, wmode 1, H = 0, M = B * gate_H, K = its output width,
+ *              N = gate_W * gate_C, no accumulate
+ *   W          the dense kernel [gate_W * gate_C][K] (row-major, pitch d->ldw)
+ *   a_plane, dz_out   cell k-1's activation / dZ planes [B][gate_H + 1][gate_W + 1][gate_C];  dscale, dshift, dbias [gate_C]
+ *   partials   asr_tap_gemm_gated_dense_workspace(d, gate_W, gate_C) bytes
+ * asr_tap_gemm_gated_dense_supported: gate_C % 32 == 0 and a GEMM large enough for the LDS-DMA kernel (gemm1_kernel); otherwise
+ * ASR_ERR_UNSUPPORTED and the caller keeps the two-pass form. */
+int asr_tap_gemm_gated_dense_supported(const asr_gemm_desc* d, int gate_H, int gate_W, int gate_C);
+size_t asr_tap_gemm_gated_dense_workspace(const asr_gemm_desc* d, int gate_W, int gate_C);
+int asr_tap_gemm_gated_dense(const asr_gemm_desc* d, const float* dZ, const float* W, int gate_H, int gate_W, int gate_C,
+                             const float* a_plane, const float* bn_scale, const float* bn_shift, float* dz_out,
+                             float* dscale, float* dshift, float* dbias, float* partials, void* stream);
+
 /* ------------------------------------------------------------------ maximum pool, compact form (round 4)
  * A max-pooled cell (acoustic_model.py:120-130: conv + bias + ReLU -> BN -> max_pooling2d 2x2) whose forward conv AND the
  * data-gradient that completes its output gradient both run on the Winograd kernel needs no pre-pool activation plane: the forward

@@ -183,3 +183,62 @@ def test_poolmax_compact_form_gives_the_bits_of_the_activation_plane_form(B, H, 
     assert float(dz2.view()[:, 0].abs().max()) == 0 and float(dz2.view()[:, :, 0].abs().max()) == 0
     for u, v in zip(s1, s2):
         assert torch.equal(u, v)
+
+
+@pytest.mark.parametrize("B,H,W,Cc,K", [(4, 40, 25, 256, 128), (2, 200, 25, 256, 128), (8, 50, 25, 64, 1536), (1, 200, 25, 128, 128)])
+def test_dense_data_gradient_with_the_cell_backward_in_its_epilogue(B, H, W, Cc, K):
+    """asr_tap_gemm_gated_dense (round 5): the data-gradient of a dense layer fed by the flattened output of an un-pooled cell
+    (reshape -> tf.layers.dense: acoustic_model.py:48-50, acoustic_model2.py:62-66) with that cell's BN / ReLU backward in the GEMM's
+    epilogue, against the two passes it replaces (asr_tap_gemm data-gradient into the dense layout, then asr_cell_bwd_pre with layout 2):
+    dZ bitwise equal, the three channel sums to 1e-5 of their scale, borders untouched, bitwise reproducible -- and against float64."""
+    from asr_dfcnn_transformer_amd import ops
+    from asr_dfcnn_transformer_amd.ops import Plane
+    g = torch.Generator(device='cuda').manual_seed(3)
+    rnd = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    rows, cin = B * H, W * Cc
+    dzd = rnd(rows, K)                                   # dL/d(dense output)
+    w = rnd(cin, K) * 0.05                               # the dense kernel [cin][cout]
+    a = Plane(B, H, W, Cc); av = torch.relu(rnd(B, H, W, Cc)); a.set_interior(av)
+    sc = 1.0 + 0.2 * rnd(Cc); sh = 0.1 * rnd(Cc); sc[1] = -0.4
+    d = ops.gemm_desc(rows, K, cin, K, K, 0, cin, ntaps=1, wmode=1)
+    assert ops.tap_gemm_gated_dense_supported(d, H, W, Cc)
+    # reference: two passes
+    dflat = torch.zeros(rows, cin, device='cuda')
+    ops.tap_gemm(d, dzd, w, None, None, None, None, dflat)
+    dz_ref = Plane(B, H, W, Cc)
+    r = [torch.zeros(Cc, device='cuda') for _ in range(3)]
+    ws = torch.zeros(ops.cell_bwd_pre_workspace(B, H, W, Cc) // 4 + 64, device='cuda')
+    ops.cell_bwd_pre(dflat, 2, a, sc, sh, 0, dz_ref, r[0], r[1], r[2], ws)
+    # fused
+    dz = Plane(B, H, W, Cc)
+    dz.buf.fill_(7.0)
+    dz.view()[:, 0].zero_(); dz.view()[:, :, 0].zero_(); dz.buf[:dz.G * Cc].zero_(); dz.buf[-dz.G * Cc:].zero_()
+    f = [torch.zeros(Cc, device='cuda') for _ in range(3)]
+    ws2 = torch.zeros(ops.tap_gemm_gated_dense_workspace(d, W, Cc) // 4 + 64, device='cuda')
+    ws2.fill_(float('nan'))                              # every partial the fold reads is written by the launch
+    ops.tap_gemm_gated_dense(d, dzd, w, a, sc, sh, dz, f[0], f[1], f[2], ws2)
+    torch.cuda.synchronize()
+    assert torch.equal(dz.interior(), dz_ref.interior())
+    assert float(dz.view()[:, 0].abs().max()) == 0 and float(dz.view()[:, :, 0].abs().max()) == 0
+    for got, want, name in zip(f, r, ('dscale', 'dshift', 'dbias')):
+        err = (got.double() - want.double()).abs().max().item()
+        assert err <= 1e-5 * max(1.0, want.abs().max().item()), (name, err)
+    # float64: dy = dzd . w^T in the dense layout -> [B, H, W, C]; dZ = dy * scale where a > 0
+    dy64 = (dzd.double() @ w.double().t()).reshape(B, H, W, Cc)
+    dz64 = torch.where(av > 0, dy64 * sc.double(), torch.zeros_like(dy64))
+    assert (dz.interior().double() - dz64).abs().max().item() <= 2e-5 * max(1.0, dz64.abs().max().item())
+    assert (f[1].double() - dy64.sum((0, 1, 2))).abs().max().item() <= 1e-4 * max(1.0, dy64.sum((0, 1, 2)).abs().max().item())
+    assert (f[0].double() - (dy64 * av.double()).sum((0, 1, 2))).abs().max().item() <= 1e-4 * max(1.0, (dy64 * av.double()).sum((0, 1, 2)).abs().max().item())
+    again = Plane(B, H, W, Cc)
+    f2 = [torch.zeros(Cc, device='cuda') for _ in range(3)]
+    ops.tap_gemm_gated_dense(d, dzd, w, a, sc, sh, again, f2[0], f2[1], f2[2], ws2)
+    torch.cuda.synchronize()
+    assert torch.equal(again.interior(), dz.interior()) and all(torch.equal(x, y) for x, y in zip(f, f2))
+
+
+def test_dense_gate_is_refused_where_the_kernel_does_not_apply():
+    from asr_dfcnn_transformer_amd import ops
+    d = ops.gemm_desc(8 * 4, 16, 3 * 24, 16, 16, 0, 3 * 24, ntaps=1, wmode=1)          # 24 channels: not a multiple of 32
+    assert not ops.tap_gemm_gated_dense_supported(d, 4, 3, 24)
+    d = ops.gemm_desc(2 * 4, 64, 2 * 64, 64, 64, 0, 2 * 64, ntaps=1, wmode=1)          # a handful of tiles: the small-GEMM kernel, two passes
+    assert not ops.tap_gemm_gated_dense_supported(d, 4, 2, 64)
