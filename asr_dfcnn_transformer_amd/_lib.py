@@ -56,6 +56,7 @@ SIGNATURES = {
     'asr_se_state_floats': (_Z, [_I, _I, _I]),
     'asr_se_fwd_workspace': (_Z, [_I, _I, _I, _I]),
     'asr_se_fwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'asr_se_fwd_sums': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'asr_se_bwd_workspace': (_Z, [_I, _I, _I, _I, _I]),
     'asr_se_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_se_bwd_cell_workspace': (_Z, [_I, _I, _I, _I, _I]),
@@ -85,6 +86,8 @@ SIGNATURES = {
     'asr_winograd_weights2': (_I, [_P, _I, _I, _I, _I, _P, _Z, _P]),
     'asr_winograd_supported': (_I, [_P]),
     'asr_tap_gemm_wino': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'asr_winograd_sum_rows': (_I, [_P]),
+    'asr_tap_gemm_wino_sums': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_gemm_wino_pool': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'asr_tap_gemm_splitk_workspace': (C.c_size_t, [_P, _I]),
     'asr_tap_gemm_splitk': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),

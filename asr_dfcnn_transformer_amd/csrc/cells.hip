@@ -737,6 +737,21 @@ extern "C" int asr_se_fwd(const float* main_in, const float* x, int B, int H, in
     return ASR_OK;
 }
 
+// asr_se_fwd with the squeeze sums already made by the launch that wrote x (asr_tap_gemm_wino_sums): sums [B][nsplit][C] partial rows
+extern "C" int asr_se_fwd_sums(const float* main_in, const float* x, int B, int H, int W, int C, int hid,
+                               const float* bn_scale, const float* bn_shift, const float* w1, const float* b1,
+                               const float* w2, const float* b2, float* state, const float* sums, int nsplit, float* out, void* stream) {
+    if (!main_in || !x || !bn_scale || !bn_shift || !w1 || !b1 || !w2 || !b2 || !state || !sums || !out || nsplit < 1) return ASR_ERR_BAD_ARG;
+    if (!chan_ok(C) || hid < 1 || hid > 1024) return ASR_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    float* st_s = state; float* st_r = st_s + (size_t)B * C; float* st_e = st_r + (size_t)B * hid;
+    hipLaunchKernelGGL(se_excite_kernel, dim3(B), dim3(256), (size_t)(C + hid + 256) * sizeof(float), st, sums, nsplit, H, W, C, hid, bn_scale, bn_shift, w1, b1, w2, b2, st_s, st_r, st_e);
+    const long total = (long)B * (H + 1) * (W + 1) * (C / 4);
+    hipLaunchKernelGGL(se_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, main_in, x, B, H, W, C, bn_scale, bn_shift, (const float*)st_e, out);
+    ASR_CHECK_LAUNCH("se_fwd_sums");
+    return ASR_OK;
+}
+
 struct SeCell { const float* a; const float* scale; float* dz; float* dscale; float* dshift; float* dbias; };
 
 static int se_bwd_impl(const float* dout, const float* x, int B, int H, int W, int C, int hid,

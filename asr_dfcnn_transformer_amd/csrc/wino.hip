@@ -513,7 +513,7 @@ constexpr int W11_RAW0 = 2 * W11_TABF * 4;      // byte offsets of the four sets
 constexpr int W11_U0 = W11_RAW0 + 2 * W11_SETF * 4;
 // epilogue instantiations (see wino11_body)
 constexpr int W11_EPI_GENERIC = 0, W11_EPI_FWD = 1, W11_EPI_POOLMAX = 2, W11_EPI_POOLAVG = 3, W11_EPI_DGRAD = 4, W11_EPI_DGRAD_ACC = 5,
-              W11_EPI_GATE1 = 6, W11_EPI_GATE2 = 7, W11_EPI_GATE3 = 8, W11_EPI_POOLMAXC = 9, W11_EPI_GATE4 = 10;
+              W11_EPI_GATE1 = 6, W11_EPI_GATE2 = 7, W11_EPI_GATE3 = 8, W11_EPI_POOLMAXC = 9, W11_EPI_GATE4 = 10, W11_EPI_FWD_SUM = 11;
 
 #if __HIP_DEVICE_COMPILE__
 typedef const __attribute__((address_space(4))) WinoArgs* wino_kernarg_p;
@@ -725,9 +725,13 @@ __device__ __forceinline__ void wino11_transpose(const floatx16& blk, float* scr
 // plain epilogue: v = act(x + bias) -> out_a; y = scale v + shift (+ previous) -> out_y.  The lane's channel constants are handed in:
 // requested at the top of the item tail, they arrive behind the exchange.  pa / py: bytes per row of the two outputs, n4: byte
 // offset of the lane's channel quad (W11_OOR beyond N).
-template <bool RELU, bool HAS_A, bool HAS_Y, bool ACC, class R>
+// SUMS (round 5, asr_tap_gemm_wino_sums): the block's per-channel sums of y over its rows inside the plane go to ysum_row[channel] --
+// one partial row per (tile block, wave), which is one image's: the squeeze of a squeeze-excitation block whose branch this cell is
+// (acoustic_model2.py:135-148 Global_Average_Pooling) without a pass of its own over the plane.
+template <bool RELU, bool HAS_A, bool HAS_Y, bool ACC, bool SUMS = false, class R>
 __device__ __forceinline__ void wino11_epilogue_plain(R rA, R rY, unsigned pa, unsigned py, const floatx16& blk, float* scratch, const int* rowa,
-                                                      const int* rowy, unsigned n4, const float4& bs, const float4& sc, const float4& sh, int lane) {
+                                                      const int* rowy, unsigned n4, const float4& bs, const float4& sc, const float4& sh, int lane,
+                                                      float* ysum_row = nullptr) {
     const int c4 = lane & 7, rsub = lane >> 3;
     wino11_transpose(blk, scratch, lane);
     unsigned oa[4], oy[4];
@@ -739,6 +743,7 @@ __device__ __forceinline__ void wino11_epilogue_plain(R rA, R rY, unsigned pa, u
         if (HAS_Y) { const int ry = rowy[it * 8 + rsub]; oy[it] = ok ? __umul24((unsigned)ry, py) + n4 : W11_OOR; }
     }
     float4 prev[4];
+    float4 ys = make_float4(0.f, 0.f, 0.f, 0.f);
     if (HAS_Y && ACC) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) prev[it] = w11_load4(rY, oy[it]);
@@ -753,7 +758,19 @@ __device__ __forceinline__ void wino11_epilogue_plain(R rA, R rY, unsigned pa, u
             float4 y = make_float4(sc.x * v.x + sh.x, sc.y * v.y + sh.y, sc.z * v.z + sh.z, sc.w * v.w + sh.w);
             if (ACC) { y.x += prev[it].x; y.y += prev[it].y; y.z += prev[it].z; y.w += prev[it].w; }
             w11_store4_nt(rY, oy[it], y.x, y.y, y.z, y.w);
+            if (SUMS) {
+                const bool in = oy[it] != W11_OOR;
+                ys.x += in ? y.x : 0.f; ys.y += in ? y.y : 0.f; ys.z += in ? y.z : 0.f; ys.w += in ? y.w : 0.f;
+            }
         }
+    }
+    if (SUMS) {
+        // rows of this wave: lanes with equal c4 differ in bits 3..5 of the lane id; fixed shuffle order
+#pragma unroll
+        for (int o = 8; o < 64; o <<= 1) {
+            ys.x += __shfl_xor(ys.x, o, 64); ys.y += __shfl_xor(ys.y, o, 64); ys.z += __shfl_xor(ys.z, o, 64); ys.w += __shfl_xor(ys.w, o, 64);
+        }
+        if (rsub == 0 && n4 != W11_OOR) *(float4*)(ysum_row + (n4 >> 2)) = ys;
     }
 }
 
@@ -1008,8 +1025,8 @@ __device__ __forceinline__ void wino11_body(float* smem) {
             const TapGemmArgs& g = args.g;
             ncol = ne < g.N;
             if (ncol) {
-                if (EPI == W11_EPI_FWD || POOLED) cbs = *(const float4*)(g.bias + ne);
-                if (EPI == W11_EPI_FWD || GATED) { csc = *(const float4*)(g.scale + ne); csh = *(const float4*)(g.shift + ne); }
+                if (EPI == W11_EPI_FWD || EPI == W11_EPI_FWD_SUM || POOLED) cbs = *(const float4*)(g.bias + ne);
+                if (EPI == W11_EPI_FWD || EPI == W11_EPI_FWD_SUM || GATED) { csc = *(const float4*)(g.scale + ne); csh = *(const float4*)(g.shift + ne); }
             }
         }
         float* rfree = bufs + (cur ^ 1) * W11_SETF;
@@ -1094,7 +1111,7 @@ __device__ __forceinline__ void wino11_body(float* smem) {
             const int N = g.N;
             const unsigned n4 = ncol ? (unsigned)ne * 4u : W11_OOR;
             const unsigned pa = (unsigned)g.ldo_a * 4u, py = (unsigned)g.ldo_y * 4u;
-            auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)(POOLED || EPI == W11_EPI_FWD ? g.out_a : g.out_y), 0, 0xFFFFFFF0, 0x00020000);
+            auto rA = __builtin_amdgcn_make_buffer_rsrc((void*)(POOLED || EPI == W11_EPI_FWD || EPI == W11_EPI_FWD_SUM ? g.out_a : g.out_y), 0, 0xFFFFFFF0, 0x00020000);
             auto rY = __builtin_amdgcn_make_buffer_rsrc((void*)g.out_y, 0, 0xFFFFFFF0, 0x00020000);
             if (POOLED) {
                 // fused 2 x 2 pool: register 4 p + i = pixel p of tile i + 4 lh -- the window is lane-local.  Same arithmetic and
@@ -1153,6 +1170,8 @@ __device__ __forceinline__ void wino11_body(float* smem) {
             }
             W11T(7);
             if (EPI == W11_EPI_FWD) wino11_epilogue_plain<true, true, true, false>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
+            else if (EPI == W11_EPI_FWD_SUM) wino11_epilogue_plain<true, true, true, false, true>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane,
+                                                                                                   g.gate_part + (long)(blk * 8 + wave) * N);
             else if (EPI == W11_EPI_POOLMAXC) { }            // nothing else to store: no activation plane in the compact form
             else if (POOLED) wino11_epilogue_plain<true, true, false, false>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
             else if (EPI == W11_EPI_DGRAD) wino11_epilogue_plain<false, false, true, false>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
@@ -1273,7 +1292,7 @@ extern "C" ASR_INTERNAL int asr_winograd_gate_rows(const asr_gemm_desc* d) { ret
 
 static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale, const float* shift,
                      float* out_a, float* out_y, void* stream, const WinoGate* gs, float* pool_y = nullptr, int pool_mode = 0,
-                     float* pool_amax = nullptr, unsigned* pool_idx = nullptr) {
+                     float* pool_amax = nullptr, unsigned* pool_idx = nullptr, float* y_sums = nullptr) {
     if (!d || !A || !Ut || (!out_a && !out_y && !gs && !pool_amax)) return ASR_ERR_BAD_ARG;
     if (!asr_winograd_supported(d)) return ASR_ERR_UNSUPPORTED;
     if ((((uintptr_t)A) | ((uintptr_t)Ut)) & 15) return ASR_ERR_BAD_ARG;
@@ -1290,6 +1309,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     a.nt_store = 1;       // streaming stores: -2..3 % per layer (the planes do not fit L2 anyway)
     a.gate_mode = 0; a.gate_H = a.gate_W = 0; a.gate_a = nullptr; a.gate_dz = nullptr; a.gate_part = nullptr; a.gate_rows = nullptr;
     if (gs) { a.gate_mode = gs->mode; a.gate_H = gs->H; a.gate_W = gs->W; a.gate_a = gs->a; a.gate_dz = gs->dz; a.gate_part = gs->part; a.gate_rows = gs->rows; }
+    if (y_sums) { if (gs) return ASR_ERR_BAD_ARG; a.gate_part = y_sums; }      // W11_EPI_FWD_SUM: partial rows [tile block x 8][N] of the sums of y
     w.Ut = Ut;
     w.TH = (d->H + 1) / 2; w.TW = (d->W + 1) / 2;
     w.ntiles = (long)d->B * w.TH * w.TW;
@@ -1325,25 +1345,27 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
         if (gs) epi = gs->mode == 1 ? W11_EPI_GATE1 : gs->mode == 2 ? W11_EPI_GATE2 : gs->mode == 3 ? W11_EPI_GATE3 : W11_EPI_GATE4;
         else if (pool_amax) { if (d->wmode || d->relu != 1 || !bias || !aff || !pool_y || !pool_idx || pool_mode != 2) return ASR_ERR_BAD_ARG; epi = W11_EPI_POOLMAXC; }
         else if (!d->wmode && d->relu == 1 && bias && aff && out_a && pool_y) epi = pool_mode == 2 ? W11_EPI_POOLMAX : W11_EPI_POOLAVG;
-        else if (!d->wmode && d->relu == 1 && bias && aff && out_a && out_y && !d->accumulate && !pool_y) epi = W11_EPI_FWD;
+        else if (!d->wmode && d->relu == 1 && bias && aff && out_a && out_y && !d->accumulate && !pool_y) epi = y_sums ? W11_EPI_FWD_SUM : W11_EPI_FWD;
+        if (y_sums && epi != W11_EPI_FWD_SUM) return ASR_ERR_UNSUPPORTED;
         else if (d->wmode && d->relu == 0 && !bias && !scale && !shift && !out_a && out_y && !pool_y) epi = d->accumulate ? W11_EPI_DGRAD_ACC : W11_EPI_DGRAD;
         typedef void (*w11_fn)(WinoArgs);
-        static const w11_fn fns[11] = {nullptr, wino11_kernel<0, 1>, wino11_kernel<0, 2>, wino11_kernel<0, 3>, wino11_kernel<1, 4>, wino11_kernel<1, 5>,
-                                       wino11_kernel<1, 6>, wino11_kernel<1, 7>, wino11_kernel<1, 8>, wino11_kernel<0, 9>, wino11_kernel<1, 10>};
+        static const w11_fn fns[12] = {nullptr, wino11_kernel<0, 1>, wino11_kernel<0, 2>, wino11_kernel<0, 3>, wino11_kernel<1, 4>, wino11_kernel<1, 5>,
+                                       wino11_kernel<1, 6>, wino11_kernel<1, 7>, wino11_kernel<1, 8>, wino11_kernel<0, 9>, wino11_kernel<1, 10>,
+                                       wino11_kernel<0, 11>};
         const w11_fn fn = epi ? fns[epi] : (d->wmode ? (w11_fn)wino11_kernel<1, 0> : (w11_fn)wino11_kernel<0, 0>);
-        static bool attr[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
-        const int slot = epi ? epi : (d->wmode ? 11 : 0);
+        static bool attr[13] = {false, false, false, false, false, false, false, false, false, false, false, false, false};
+        const int slot = epi ? (epi == W11_EPI_FWD_SUM ? 12 : epi) : (d->wmode ? 11 : 0);
         if (!attr[slot]) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr[slot] = true; }
         hipLaunchKernelGGL(fn, dim3(grid11), dim3(512), lds11, st, w);
         ASR_CHECK_LAUNCH("tap_gemm_wino11");
-        static const char* const names[12] = {"wino11_kernel<0, 0>", "wino11_kernel<0, 1>", "wino11_kernel<0, 2>", "wino11_kernel<0, 3>", "wino11_kernel<1, 4>",
+        static const char* const names[13] = {"wino11_kernel<0, 0>", "wino11_kernel<0, 1>", "wino11_kernel<0, 2>", "wino11_kernel<0, 3>", "wino11_kernel<1, 4>",
                                               "wino11_kernel<1, 5>", "wino11_kernel<1, 6>", "wino11_kernel<1, 7>", "wino11_kernel<1, 8>", "wino11_kernel<0, 9>",
-                                              "wino11_kernel<1, 10>", "wino11_kernel<1, 0>"};
+                                              "wino11_kernel<1, 10>", "wino11_kernel<1, 0>", "wino11_kernel<0, 11>"};
         asr_set_last_kernel(names[slot]);
         return ASR_OK;
     }
     // wino8_kernel: 64 x 64 items in the plain tile order (planes whose tile columns do not split into column blocks, N % 64 == 0)
-    if ((d->N % WC) != 0 || compact) return ASR_ERR_UNSUPPORTED;
+    if ((d->N % WC) != 0 || compact || y_sums) return ASR_ERR_UNSUPPORTED;
     w.ncb = 0;
     const int nblk = asr_cdiv(w.ntiles, WT);
     a.ntm = nblk; a.ntn = d->N / WC;
@@ -1371,6 +1393,21 @@ extern "C" int asr_tap_gemm_wino(const asr_gemm_desc* d, const float* A, const f
                                  const float* bias, const float* scale, const float* shift,
                                  float* out_a, float* out_y, void* stream) {
     return wino_impl(d, A, Ut, bias, scale, shift, out_a, out_y, stream, nullptr);
+}
+
+// Forward conv of a cell that is the BRANCH of a squeeze-excitation block (round 5): asr_tap_gemm_wino + the channel sums of its
+// BN output y per image, as partial rows y_sums[rows][N] with rows = asr_winograd_sum_rows(d), the rows of image b being
+// [b * rows / B, (b + 1) * rows / B) -- what the block's global average pool needs (asr_se_fwd_sums), without its pass over the plane.
+// ASR_ERR_UNSUPPORTED where wino11_kernel's forward epilogue does not apply (then: asr_tap_gemm_wino + asr_se_fwd).
+extern "C" int asr_winograd_sum_rows(const asr_gemm_desc* d) {
+    if (!d || d->wmode || !asr_winograd_supported(d) || !wino11_takes(d, false, 0)) return 0;
+    return 8 * wino_tile_blocks(d);
+}
+extern "C" int asr_tap_gemm_wino_sums(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale,
+                                      const float* shift, float* out_a, float* out_y, float* y_sums, void* stream) {
+    if (!d || !bias || !scale || !shift || !out_a || !out_y || !y_sums || d->wmode || d->relu != 1 || d->accumulate || d->y_unpadded) return ASR_ERR_BAD_ARG;
+    if (asr_winograd_sum_rows(d) <= 0) return ASR_ERR_UNSUPPORTED;
+    return wino_impl(d, A, Ut, bias, scale, shift, out_a, out_y, stream, nullptr, nullptr, 0, nullptr, nullptr, y_sums);
 }
 
 extern "C" int asr_pool_fwd(const float* a, int B, int H, int W, int C, const float* bn_scale, const float* bn_shift, int pool,

@@ -153,7 +153,7 @@ class DFCNNEngine:
     def __init__(self, model='m2', vocab=1536, B=32, T=1600, F=200, widths=None, seed=0, device='cuda',
                  lr=7e-4, decay_steps=5000, min_lr=1e-6, beta1=0.9, beta2=0.999, adam_eps=1e-8,
                  dual_stream=True, wino=True, fuse_prologues=True, fuse_se=True, compact_pool=True, side_priority=0,
-                 dense_wgrad_side=True, fuse_dense=True):
+                 dense_wgrad_side=True, fuse_dense=True, se_sums=True):
         """Options (constructor arguments only -- nothing here reads the environment; `options()` reports them):
         ``dual_stream``: weight gradients / decode on a second stream (``side_priority``: its HIP stream priority);
         ``wino``: Winograd F(2x2,3x3) / F(3x3,2x2) for the 3x3 layers the kernels support instead of the direct tap-GEMM;
@@ -161,12 +161,14 @@ class DFCNNEngine:
         runs its branch cell's BN / ReLU backward (asr_se_bwd_cell); ``compact_pool``: max-pooled cells keep the activation at each
         window's maximum + its position instead of the pre-pool plane; ``dense_wgrad_side``: the dense layers' weight / bias gradients on
         the second stream beside their data-gradients (False: in front of them on the main stream, as until round 4); ``fuse_dense``: the
-        data-gradient of a dense layer fed by a cell also runs that cell's BN / ReLU backward (asr_tap_gemm_gated_dense).  Each of them leaves the results bitwise (streams, fusions,
+        data-gradient of a dense layer fed by a cell also runs that cell's BN / ReLU backward (asr_tap_gemm_gated_dense); ``se_sums``: the
+        forward launch of an SE block's branch cell also makes the block's squeeze sums (asr_tap_gemm_wino_sums; the squeeze is then a
+        sum in another order: to rounding).  Each of them leaves the results bitwise (streams, fusions,
         compact form) or to rounding (Winograd) unchanged; they exist for A/B measurements and tests."""
         assert T % 8 == 0 and F >= 8
         self.opt_dual, self.opt_wino, self.opt_fuse = bool(dual_stream), bool(wino), bool(fuse_prologues)
         self.opt_fuse_se, self.opt_compact, self.side_priority = bool(fuse_se), bool(compact_pool), int(side_priority)
-        self.opt_dense_side, self.opt_fuse_dense = bool(dense_wgrad_side), bool(fuse_dense)
+        self.opt_dense_side, self.opt_fuse_dense, self.opt_se_sums = bool(dense_wgrad_side), bool(fuse_dense), bool(se_sums)
         self.model, self.V, self.B, self.T, self.F = model, vocab, B, T, F
         self.device = device
         self.g = graph(model, vocab, widths, F)
@@ -452,6 +454,22 @@ class DFCNNEngine:
                 if ops.tap_gemm_gated_dense_supported(self.bdesc[op[2]], Hc, Wc, cell[4]):
                     self.dense_gate[op[2]] = cell
                     self.ws_gate = max(self.ws_gate, ops.tap_gemm_gated_dense_workspace(self.bdesc[op[2]], Wc, cell[4]))
+        # SE blocks whose branch is a non-pooled Winograd cell that only the block reads: the cell's forward launch also writes the
+        # per-image channel sums of its output (asr_tap_gemm_wino_sums), the block's squeeze takes them (asr_se_fwd_sums) instead of a
+        # pass of its own over the plane.  {branch cell -> (SE block, partial rows buffer, rows per image)}
+        self.se_sums = {}
+        if self.opt_se_sums:
+            for op in self.g:
+                if op[0] != 'se' or op[1] == op[2]:
+                    continue
+                br = op[2]
+                cell = next((c for c in self.g if c[0] == 'cell' and c[2] == br), None)
+                if cell is None or cell[1] == 'x' or cell[6] is not None or br not in self.wt_f or br in self.flat \
+                        or self.consumers.get(br, []) != [op]:
+                    continue
+                rows = ops.winograd_sum_rows(self.fdesc[br])
+                if rows > 0 and rows % B == 0:
+                    self.se_sums[br] = (op[3], torch.zeros(rows * cell[4], dtype=torch.float32, device=dev), rows // B)
         self.compact = {}
         for writer, tgt in (self.fuse.items() if self.opt_compact else ()):
             top = next(o for o in self.g if o[0] == 'cell' and o[2] == tgt)
@@ -470,7 +488,8 @@ class DFCNNEngine:
     def options(self):
         """The switches this engine was built with and what they resolved to on this graph (bench.py puts it in its JSON line)."""
         return {'dual_stream': self.opt_dual, 'wino': self.opt_wino, 'fuse_prologues': self.opt_fuse, 'fuse_se': self.opt_fuse_se,
-                'compact_pool': self.opt_compact, 'side_priority': self.side_priority, 'dense_wgrad_side': self.opt_dense_side, 'fuse_dense': self.opt_fuse_dense,
+                'compact_pool': self.opt_compact, 'side_priority': self.side_priority, 'dense_wgrad_side': self.opt_dense_side, 'fuse_dense': self.opt_fuse_dense, 'se_sums': self.opt_se_sums,
+                'se_squeeze_in_the_branch_conv': sorted(self.se_sums),
                 'winograd_layers_fwd': sorted(self.wt_f), 'winograd_layers_dgrad': sorted(self.wt_b),
                 'fused_prologues': len(self.fuse), 'dense_gradients_with_cell_backward': sorted(self.dense_gate), 'se_blocks_fused_with_cell_backward': len(self.se_cell),
                 'compact_max_pool_cells': sorted(self.compact)}
@@ -600,6 +619,8 @@ class DFCNNEngine:
                     # conv + bias + ReLU -> BN -> 2x2 pool in one launch: a Winograd tile is a pooling window
                     ops.tap_gemm_wino_pool(self.fdesc[dst], self.y[src], self.wt_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], pm, self.y[dst])
                     continue
+                elif dst in self.se_sums:
+                    ops.tap_gemm_wino_sums(self.fdesc[dst], self.y[src], self.wt_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], out_y, self.se_sums[dst][1])
                 elif dst in self.wt_f:
                     ops.tap_gemm_wino(self.fdesc[dst], self.y[src], self.wt_f[dst], self.p(dst, 'b'), sc, sh, self.a[dst], out_y)
                 elif dst in self.wf_f:
@@ -612,6 +633,11 @@ class DFCNNEngine:
             elif op[0] == 'se':
                 _, main, br, dst, Cc, hid, use_bn = op
                 sc, sh = self._se_affine(dst, Cc, use_bn)
+                if br in self.se_sums:
+                    _, sums, per = self.se_sums[br]
+                    ops.se_fwd_sums(self.y[main], self.y[br], hid, sc, sh, self.p(dst, 'w1'), self.p(dst, 'b1'),
+                                    self.p(dst, 'w2'), self.p(dst, 'b2'), self.se_state[dst], sums, per, self.y[dst])
+                    continue
                 ops.se_fwd(self.y[main], self.y[br], hid, sc, sh, self.p(dst, 'w1'), self.p(dst, 'b1'),
                            self.p(dst, 'w2'), self.p(dst, 'b2'), self.se_state[dst], self.ws, self.y[dst])
             elif op[0] == 'dense':

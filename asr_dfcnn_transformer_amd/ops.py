@@ -274,6 +274,11 @@ def se_fwd(main_in, x, hid, sc, sh, w1, b1, w2, b2, state, partials, out):
                                  _ptr(w2), _ptr(b2), _ptr(state), _ptr(partials), out.ptr, _stream()), 'asr_se_fwd')
 
 
+def se_fwd_sums(main_in, x, hid, sc, sh, w1, b1, w2, b2, state, sums, nsplit, out):
+    check(_lib.load().asr_se_fwd_sums(main_in.ptr, x.ptr, x.B, x.H, x.W, x.C, hid, _ptr(sc), _ptr(sh), _ptr(w1), _ptr(b1),
+                                      _ptr(w2), _ptr(b2), _ptr(state), _ptr(sums), int(nsplit), out.ptr, _stream()), 'asr_se_fwd_sums')
+
+
 def se_bwd(dout, x, hid, sc, sh, w1, w2, state, add_dout, dx, dscale, dshift, dw1, db1, dw2, db2, partials):
     check(_lib.load().asr_se_bwd(dout.ptr, x.ptr, x.B, x.H, x.W, x.C, hid, _ptr(sc), _ptr(sh), _ptr(w1), _ptr(w2),
                                  _ptr(state), add_dout, dx.ptr, _ptr(dscale), _ptr(dshift), _ptr(dw1), _ptr(db1),
@@ -663,6 +668,19 @@ def tap_gemm_wino(desc, A, Wt, bias=None, scale=None, shift=None, out_a=None, ou
     po_y = out_y.ptr if isinstance(out_y, Plane) else _ptr(out_y)
     _timed(desc, lambda: check(lib.asr_tap_gemm_wino(C.byref(desc), pa, _ptr(Wt), _ptr(bias), _ptr(scale), _ptr(shift), po_a, po_y,
                                                      _stream()), 'asr_tap_gemm_wino'))
+
+
+def winograd_sum_rows(desc):
+    """partial rows asr_tap_gemm_wino_sums writes (0: not a shape of that launch)"""
+    return _lib.load().asr_winograd_sum_rows(C.byref(desc))
+
+
+def tap_gemm_wino_sums(desc, A, Wt, bias, scale, shift, out_a, out_y, y_sums):
+    """tap_gemm_wino + the per-image channel sums of out_y as partial rows (asr_tap_gemm_wino_sums): the squeeze of the SE block whose
+    branch this cell is."""
+    lib = _lib.load()
+    _timed(desc, lambda: check(lib.asr_tap_gemm_wino_sums(C.byref(desc), A.ptr, _ptr(Wt), _ptr(bias), _ptr(scale), _ptr(shift), out_a.ptr, out_y.ptr,
+                                                          _ptr(y_sums), _stream()), 'asr_tap_gemm_wino_sums'))
 
 
 def tap_gemm_wino_pool(desc, A, Wt, bias, scale, shift, out_a, pool, y_pooled):

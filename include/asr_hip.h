@@ -178,6 +178,10 @@ int asr_se_fwd(const float* main_in, const float* x, int B, int H, int W, int C,
                const float* bn_scale, const float* bn_shift, const float* w1, const float* b1,
                const float* w2, const float* b2, float* state, float* partials, float* out,
                void* stream);
+/* asr_se_fwd with the squeeze sums made by the launch that wrote x (asr_tap_gemm_wino_sums): sums [B][nsplit][C] partial rows. */
+int asr_se_fwd_sums(const float* main_in, const float* x, int B, int H, int W, int C, int hid,
+                    const float* bn_scale, const float* bn_shift, const float* w1, const float* b1,
+                    const float* w2, const float* b2, float* state, const float* sums, int nsplit, float* out, void* stream);
 /* dout = dL/d(out).  dL/d(main) IS dout (identity branch), so it is not produced here: the
  * caller lets later contributions accumulate into the dout buffer.  dx = dL/dx (=; plus dout
  * when add_dout, for the acoustic_model3 wiring where main == x), parameter grads (=). */
@@ -506,6 +510,14 @@ int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const float* Warrang
 size_t asr_winograd_weights_bytes(int K, int N);
 int asr_winograd_weights2(const float* W, int K, int N, int ldw, int wmode, float* out, size_t out_bytes, void* stream);
 int asr_winograd_supported(const asr_gemm_desc* d);
+/* Round 5: the forward conv of a cell that is the BRANCH of a squeeze-excitation block (acoustic_model2.py:40-41 `h1_1 = cnn_cell(..)`,
+ * `squeeze_excitation_layer(h1_1, ..)`): asr_tap_gemm_wino plus the per-image channel sums of the cell's BN output y, written as partial
+ * rows y_sums[rows][N], rows = asr_winograd_sum_rows(d), the rows of image b = [b * rows / B, (b + 1) * rows / B).  asr_se_fwd_sums takes
+ * them in place of its own pass over the plane (Global_Average_Pooling, acoustic_model2.py:135-137).  asr_winograd_sum_rows(d) == 0:
+ * not a shape of wino11_kernel's forward epilogue -- use asr_tap_gemm_wino + asr_se_fwd. */
+int asr_winograd_sum_rows(const asr_gemm_desc* d);
+int asr_tap_gemm_wino_sums(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale,
+                           const float* shift, float* out_a, float* out_y, float* y_sums, void* stream);
 int asr_tap_gemm_wino(const asr_gemm_desc* d, const float* A, const float* Wt,
                       const float* bias, const float* scale, const float* shift,
                       float* out_a, float* out_y, void* stream);

@@ -186,3 +186,27 @@ def test_stream_and_fusion_modes_give_the_same_bits(model, widths):
             assert torch.equal(ga, gb), (layer, key)
         else:
             assert (ga - gb).abs().max().item() <= 1e-6 * max(1e-6, gb.abs().max().item()), (layer, key)
+
+
+def test_se_squeeze_made_by_the_branch_conv_gives_the_same_step():
+    """se_sums=True (default): the forward launch of an SE block's branch cell also writes the block's squeeze sums
+    (asr_tap_gemm_wino_sums -> asr_se_fwd_sums); se_sums=False: the squeeze is a pass of its own over the plane.  The same sum in
+    another order: logits, loss and every gradient agree to rounding; the planes in front of the first SE block are bitwise equal."""
+    from asr_dfcnn_transformer_amd.engine import DFCNNEngine
+    rng = np.random.default_rng(9)
+    B, T, F, V = 2, 64, 200, 20
+    x = torch.tensor(rng.standard_normal((B, T, F)).astype(np.float32), device='cuda')
+    tgt = np.zeros((B, 64), dtype=np.int32); tgt[:, :3] = rng.integers(1, V - 1, (B, 3))
+    out = []
+    for flag in (True, False):
+        eng = DFCNNEngine(model='m2', vocab=V, B=B, T=T, F=F, widths=(32, 64, 64, 64), seed=2, se_sums=flag)
+        assert bool(eng.se_sums) == flag and (not flag or len(eng.se_sums) == 5)
+        logits = eng.forward(x).clone()
+        eng.set_targets([8, 8], tgt); eng.loss_and_decode(); eng.backward()
+        torch.cuda.synchronize()
+        out.append((logits, eng.loss.clone(), eng.grad.clone(), eng.y['h1_1'].buf.clone()))
+    (l0, s0, g0, y0), (l1, s1, g1, y1) = out
+    assert torch.equal(y0, y1)
+    assert (l0 - l1).abs().max().item() < 1e-4
+    assert (s0 - s1).abs().max().item() < 1e-4 * max(1.0, s0.abs().max().item())
+    assert (g0 - g1).abs().max().item() < 1e-4 * max(1e-6, g0.abs().max().item())

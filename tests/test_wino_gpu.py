@@ -131,3 +131,42 @@ def test_engine_opt_in_gives_the_same_step(ops):
     assert (l0 - l1).abs().max().item() < 1e-4
     assert (s0 - s1).abs().max().item() < 1e-4 * max(1.0, s0.abs().max().item())
     assert (g0 - g1).abs().max().item() < 1e-4 * max(1e-6, g0.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,hid", [(3, 20, 50, 32, 32, 32), (2, 40, 25, 64, 64, 32), (4, 25, 25, 128, 128, 64), (2, 16, 100, 32, 32, 32)])
+def test_forward_with_squeeze_sums_feeds_the_se_block(ops, B, H, W, cin, cout, hid):
+    """asr_tap_gemm_wino_sums (round 5): the activation and BN-output planes are those of asr_tap_gemm_wino bit for bit, and the partial
+    rows fold to the per-image channel sums of y (float64, 1e-5 of their scale); asr_se_fwd_sums on them = asr_se_fwd with its own pass
+    over the plane, to rounding (acoustic_model2.py:135-148: Global_Average_Pooling -> dense -> relu -> dense -> sigmoid -> scale)."""
+    g = torch.Generator(device='cuda').manual_seed(23)
+    x = ops.Plane(B, H, W, cin); x.set_interior(torch.randn(B, H, W, cin, device='cuda', generator=g))
+    w = torch.randn(3, 3, cin, cout, device='cuda', generator=g) * (2.0 / (9 * cin)) ** 0.5
+    bias = torch.randn(cout, device='cuda', generator=g) * 0.1
+    sc = 1 + 0.2 * torch.randn(cout, device='cuda', generator=g); sh = 0.1 * torch.randn(cout, device='cuda', generator=g)
+    d = ops.gemm_desc(x.NP, cin, cout, cin, cout, cout, cout, ntaps=9, B=B, H=H, W=W, relu=1)
+    rows = ops.winograd_sum_rows(d)
+    assert rows > 0 and rows % B == 0
+    wt = ops.winograd_weights(w, cin, cout, cout, 0)
+    a0, y0, a1, y1 = (ops.Plane(B, H, W, cout) for _ in range(4))
+    ops.tap_gemm_wino(d, x, wt, bias, sc, sh, a0, y0)
+    sums = torch.full((rows * cout,), float('nan'), device='cuda')          # every partial row is written by the launch
+    ops.tap_gemm_wino_sums(d, x, wt, bias, sc, sh, a1, y1, sums)
+    torch.cuda.synchronize()
+    assert torch.equal(a0.buf, a1.buf) and torch.equal(y0.buf, y1.buf)
+    got = sums.view(B, rows // B, cout).double().sum(1)
+    want = y1.interior().double().sum((1, 2))
+    assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
+    # the SE block on top (main = another plane, branch = y1)
+    main = ops.Plane(B, H, W, cout); main.set_interior(torch.randn(B, H, W, cout, device='cuda', generator=g))
+    ssc = 1 + 0.1 * torch.randn(cout, device='cuda', generator=g); ssh = 0.1 * torch.randn(cout, device='cuda', generator=g)
+    w1 = torch.randn(cout, hid, device='cuda', generator=g) * 0.2; b1 = torch.randn(hid, device='cuda', generator=g) * 0.1
+    w2 = torch.randn(hid, cout, device='cuda', generator=g) * 0.2; b2 = torch.randn(cout, device='cuda', generator=g) * 0.1
+    st0 = torch.zeros(ops.se_state_floats(B, cout, hid), device='cuda'); st1 = torch.zeros_like(st0)
+    ws = torch.zeros(ops.se_fwd_workspace(B, H, W, cout) // 4 + 64, device='cuda')
+    o0, o1 = ops.Plane(B, H, W, cout), ops.Plane(B, H, W, cout)
+    ops.se_fwd(main, y1, hid, ssc, ssh, w1, b1, w2, b2, st0, ws, o0)
+    ops.se_fwd_sums(main, y1, hid, ssc, ssh, w1, b1, w2, b2, st1, sums, rows // B, o1)
+    torch.cuda.synchronize()
+    assert (st0 - st1).abs().max().item() <= 2e-6 * max(1.0, st0.abs().max().item())
+    assert (o0.interior() - o1.interior()).abs().max().item() <= 2e-6 * max(1.0, o0.interior().abs().max().item())
+    assert o1.border_abs_max() == 0.0
