@@ -61,6 +61,7 @@ SIGNATURES = {
     'asr_se_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_se_bwd_cell_workspace': (_Z, [_I, _I, _I, _I, _I]),
     'asr_se_bwd_cell': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'asr_se_bwd_cell_sums': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'asr_axpy': (_I, [_P, _P, _Z, _F, _I, _P]),
     'asr_softmax_log_fwd': (_I, [_P, _I, _I, _I, _F, _P, _P]),
     'asr_softmax_log_bwd': (_I, [_P, _P, _I, _I, _I, _F, _F, _P, _P]),
@@ -88,6 +89,7 @@ SIGNATURES = {
     'asr_tap_gemm_wino': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_winograd_sum_rows': (_I, [_P]),
     'asr_tap_gemm_wino_sums': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'asr_tap_gemm_wino_sesum': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_gemm_wino_pool': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'asr_tap_gemm_splitk_workspace': (C.c_size_t, [_P, _I]),
     'asr_tap_gemm_splitk': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),

@@ -757,7 +757,8 @@ struct SeCell { const float* a; const float* scale; float* dz; float* dscale; fl
 static int se_bwd_impl(const float* dout, const float* x, int B, int H, int W, int C, int hid,
                        const float* bn_scale, const float* bn_shift, const float* w1, const float* w2,
                        const float* state, int add_dout, float* dx, float* dscale, float* dshift,
-                       float* dw1, float* db1, float* dw2, float* db2, float* partials, void* stream, const SeCell* cell) {
+                       float* dw1, float* db1, float* dw2, float* db2, float* partials, void* stream, const SeCell* cell,
+                       const float* xsums = nullptr, int xsplit = 0) {
     if (!dout || !x || !bn_scale || !bn_shift || !w1 || !w2 || !state || (!dx && !cell) || !dscale || !dshift || !dw1 ||
         !db1 || !dw2 || !db2 || !partials)
         return ASR_ERR_BAD_ARG;
@@ -774,8 +775,11 @@ static int se_bwd_impl(const float* dout, const float* x, int B, int H, int W, i
     float* part_apply = dsb + (size_t)B * C;
     float* tmp = part_apply + (size_t)nblk * 2 * C;
     const float* st_s = state; const float* st_r = st_s + (size_t)B * C; const float* st_e = st_r + (size_t)B * hid;
-    hipLaunchKernelGGL(se_reduce_kernel<1>, dim3(ns, B), dim3(256), 0, st, x, dout, H, W, C, bn_scale, bn_shift, part_red);
-    hipLaunchKernelGGL(se_bwd_mlp_kernel, dim3(B), dim3(256), (size_t)(C + hid + 256) * sizeof(float), st, (const float*)part_red, ns, H, W, C, hid, w1, w2, st_s, st_r, st_e, mlp_out, dsb);
+    // sum over the pixels of dout * (sc * x + sh) per image and channel: a pass of its own, or the partial rows the data-gradient launch
+    // that wrote dout left (asr_tap_gemm_wino_sesum)
+    if (!xsums) hipLaunchKernelGGL(se_reduce_kernel<1>, dim3(ns, B), dim3(256), 0, st, x, dout, H, W, C, bn_scale, bn_shift, part_red);
+    hipLaunchKernelGGL(se_bwd_mlp_kernel, dim3(B), dim3(256), (size_t)(C + hid + 256) * sizeof(float), st, xsums ? xsums : (const float*)part_red,
+                       xsums ? xsplit : ns, H, W, C, hid, w1, w2, st_s, st_r, st_e, mlp_out, dsb);
     ASR_CHECK_LAUNCH("se_bwd_mlp");
     int rc;
     {
@@ -833,6 +837,19 @@ extern "C" int asr_se_bwd_cell(const float* dout, const float* x, int B, int H, 
     SeCell c; c.a = cell_a; c.scale = cell_scale; c.dz = cell_dz; c.dscale = cell_dscale; c.dshift = cell_dshift; c.dbias = cell_dbias;
     return se_bwd_impl(dout, x, B, H, W, C, hid, bn_scale, bn_shift, w1, w2, state, add_dout, nullptr, dscale, dshift, dw1, db1, dw2, db2,
                        partials, stream, &c);
+}
+
+// asr_se_bwd_cell with the block's first reduction already made by the launch that wrote dout (asr_tap_gemm_wino_sesum)
+extern "C" int asr_se_bwd_cell_sums(const float* dout, const float* x, int B, int H, int W, int C, int hid,
+                                    const float* bn_scale, const float* bn_shift, const float* w1, const float* w2,
+                                    const float* state, int add_dout, float* dscale, float* dshift,
+                                    float* dw1, float* db1, float* dw2, float* db2,
+                                    const float* cell_a, const float* cell_scale, float* cell_dz, float* cell_dscale, float* cell_dshift,
+                                    float* cell_dbias, const float* xsums, int nsplit, float* partials, void* stream) {
+    if (!cell_a || !cell_scale || !cell_dz || !cell_dscale || !cell_dshift || !cell_dbias || !xsums || nsplit < 1) return ASR_ERR_BAD_ARG;
+    SeCell c; c.a = cell_a; c.scale = cell_scale; c.dz = cell_dz; c.dscale = cell_dscale; c.dshift = cell_dshift; c.dbias = cell_dbias;
+    return se_bwd_impl(dout, x, B, H, W, C, hid, bn_scale, bn_shift, w1, w2, state, add_dout, nullptr, dscale, dshift, dw1, db1, dw2, db2,
+                       partials, stream, &c, xsums, nsplit);
 }
 
 extern "C" int asr_axpy(float* dst, const float* src, size_t n, float alpha, int accumulate, void* stream) {

@@ -513,7 +513,7 @@ constexpr int W11_RAW0 = 2 * W11_TABF * 4;      // byte offsets of the four sets
 constexpr int W11_U0 = W11_RAW0 + 2 * W11_SETF * 4;
 // epilogue instantiations (see wino11_body)
 constexpr int W11_EPI_GENERIC = 0, W11_EPI_FWD = 1, W11_EPI_POOLMAX = 2, W11_EPI_POOLAVG = 3, W11_EPI_DGRAD = 4, W11_EPI_DGRAD_ACC = 5,
-              W11_EPI_GATE1 = 6, W11_EPI_GATE2 = 7, W11_EPI_GATE3 = 8, W11_EPI_POOLMAXC = 9, W11_EPI_GATE4 = 10, W11_EPI_FWD_SUM = 11;
+              W11_EPI_GATE1 = 6, W11_EPI_GATE2 = 7, W11_EPI_GATE3 = 8, W11_EPI_POOLMAXC = 9, W11_EPI_GATE4 = 10, W11_EPI_FWD_SUM = 11, W11_EPI_DGRAD_SESUM = 12;
 
 #if __HIP_DEVICE_COMPILE__
 typedef const __attribute__((address_space(4))) WinoArgs* wino_kernarg_p;
@@ -728,10 +728,13 @@ __device__ __forceinline__ void wino11_transpose(const floatx16& blk, float* scr
 // SUMS (round 5, asr_tap_gemm_wino_sums): the block's per-channel sums of y over its rows inside the plane go to ysum_row[channel] --
 // one partial row per (tile block, wave), which is one image's: the squeeze of a squeeze-excitation block whose branch this cell is
 // (acoustic_model2.py:135-148 Global_Average_Pooling) without a pass of its own over the plane.
-template <bool RELU, bool HAS_A, bool HAS_Y, bool ACC, bool SUMS = false, class R>
+// SUMS 2 (asr_tap_gemm_wino_sesum): the data-gradient that completes dL/d(output of an SE block) also leaves, per (tile block, wave),
+// sum over its rows of y * (sc * x + sh) -- x the block's branch plane (rX, the geometry of y), sc / sh the block's BN affine: the
+// reduction the block's backward needs for its excitation gradient (se_reduce_kernel<1>), without a pass over both planes.
+template <bool RELU, bool HAS_A, bool HAS_Y, bool ACC, int SUMS = 0, class R>
 __device__ __forceinline__ void wino11_epilogue_plain(R rA, R rY, unsigned pa, unsigned py, const floatx16& blk, float* scratch, const int* rowa,
                                                       const int* rowy, unsigned n4, const float4& bs, const float4& sc, const float4& sh, int lane,
-                                                      float* ysum_row = nullptr) {
+                                                      float* ysum_row = nullptr, R rX = R()) {
     const int c4 = lane & 7, rsub = lane >> 3;
     wino11_transpose(blk, scratch, lane);
     unsigned oa[4], oy[4];
@@ -742,11 +745,15 @@ __device__ __forceinline__ void wino11_epilogue_plain(R rA, R rY, unsigned pa, u
         oa[it] = ok ? __umul24((unsigned)ra, pa) + n4 : W11_OOR;
         if (HAS_Y) { const int ry = rowy[it * 8 + rsub]; oy[it] = ok ? __umul24((unsigned)ry, py) + n4 : W11_OOR; }
     }
-    float4 prev[4];
+    float4 prev[4], xv[4];
     float4 ys = make_float4(0.f, 0.f, 0.f, 0.f);
     if (HAS_Y && ACC) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) prev[it] = w11_load4(rY, oy[it]);
+    }
+    if (SUMS == 2) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) xv[it] = w11_load4(rX, oy[it]);         // (rows outside the plane read zeros and are masked below)
     }
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
@@ -755,12 +762,18 @@ __device__ __forceinline__ void wino11_epilogue_plain(R rA, R rY, unsigned pa, u
         if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         if (HAS_A) w11_store4_nt(rA, oa[it], v.x, v.y, v.z, v.w);
         if (HAS_Y) {
-            float4 y = make_float4(sc.x * v.x + sh.x, sc.y * v.y + sh.y, sc.z * v.z + sh.z, sc.w * v.w + sh.w);
+            // (SUMS 2: a data-gradient -- no affine of its own, sc / sh are the SE block's)
+            float4 y = SUMS == 2 ? v : make_float4(sc.x * v.x + sh.x, sc.y * v.y + sh.y, sc.z * v.z + sh.z, sc.w * v.w + sh.w);
             if (ACC) { y.x += prev[it].x; y.y += prev[it].y; y.z += prev[it].z; y.w += prev[it].w; }
             w11_store4_nt(rY, oy[it], y.x, y.y, y.z, y.w);
-            if (SUMS) {
+            if (SUMS == 1) {
                 const bool in = oy[it] != W11_OOR;
                 ys.x += in ? y.x : 0.f; ys.y += in ? y.y : 0.f; ys.z += in ? y.z : 0.f; ys.w += in ? y.w : 0.f;
+            }
+            if (SUMS == 2) {
+                const bool in = oy[it] != W11_OOR;
+                ys.x = fmaf(in ? y.x : 0.f, fmaf(sc.x, xv[it].x, sh.x), ys.x); ys.y = fmaf(in ? y.y : 0.f, fmaf(sc.y, xv[it].y, sh.y), ys.y);
+                ys.z = fmaf(in ? y.z : 0.f, fmaf(sc.z, xv[it].z, sh.z), ys.z); ys.w = fmaf(in ? y.w : 0.f, fmaf(sc.w, xv[it].w, sh.w), ys.w);
             }
         }
     }
@@ -1026,7 +1039,7 @@ __device__ __forceinline__ void wino11_body(float* smem) {
             ncol = ne < g.N;
             if (ncol) {
                 if (EPI == W11_EPI_FWD || EPI == W11_EPI_FWD_SUM || POOLED) cbs = *(const float4*)(g.bias + ne);
-                if (EPI == W11_EPI_FWD || EPI == W11_EPI_FWD_SUM || GATED) { csc = *(const float4*)(g.scale + ne); csh = *(const float4*)(g.shift + ne); }
+                if (EPI == W11_EPI_FWD || EPI == W11_EPI_FWD_SUM || EPI == W11_EPI_DGRAD_SESUM || GATED) { csc = *(const float4*)(g.scale + ne); csh = *(const float4*)(g.shift + ne); }
             }
         }
         float* rfree = bufs + (cur ^ 1) * W11_SETF;
@@ -1170,8 +1183,13 @@ __device__ __forceinline__ void wino11_body(float* smem) {
             }
             W11T(7);
             if (EPI == W11_EPI_FWD) wino11_epilogue_plain<true, true, true, false>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
-            else if (EPI == W11_EPI_FWD_SUM) wino11_epilogue_plain<true, true, true, false, true>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane,
-                                                                                                   g.gate_part + (long)(blk * 8 + wave) * N);
+            else if (EPI == W11_EPI_FWD_SUM) wino11_epilogue_plain<true, true, true, false, 1>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane,
+                                                                                                g.gate_part + (long)(blk * 8 + wave) * N);
+            else if (EPI == W11_EPI_DGRAD_SESUM) {
+                auto rX = __builtin_amdgcn_make_buffer_rsrc((void*)g.gate_a, 0, 0xFFFFFFF0, 0x00020000);
+                wino11_epilogue_plain<false, false, true, false, 2>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane,
+                                                                    g.gate_part + (long)(blk * 8 + wave) * N, rX);
+            }
             else if (EPI == W11_EPI_POOLMAXC) { }            // nothing else to store: no activation plane in the compact form
             else if (POOLED) wino11_epilogue_plain<true, true, false, false>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
             else if (EPI == W11_EPI_DGRAD) wino11_epilogue_plain<false, false, true, false>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
@@ -1292,7 +1310,7 @@ extern "C" ASR_INTERNAL int asr_winograd_gate_rows(const asr_gemm_desc* d) { ret
 
 static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale, const float* shift,
                      float* out_a, float* out_y, void* stream, const WinoGate* gs, float* pool_y = nullptr, int pool_mode = 0,
-                     float* pool_amax = nullptr, unsigned* pool_idx = nullptr, float* y_sums = nullptr) {
+                     float* pool_amax = nullptr, unsigned* pool_idx = nullptr, float* y_sums = nullptr, const float* se_x = nullptr) {
     if (!d || !A || !Ut || (!out_a && !out_y && !gs && !pool_amax)) return ASR_ERR_BAD_ARG;
     if (!asr_winograd_supported(d)) return ASR_ERR_UNSUPPORTED;
     if ((((uintptr_t)A) | ((uintptr_t)Ut)) & 15) return ASR_ERR_BAD_ARG;
@@ -1309,7 +1327,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     a.nt_store = 1;       // streaming stores: -2..3 % per layer (the planes do not fit L2 anyway)
     a.gate_mode = 0; a.gate_H = a.gate_W = 0; a.gate_a = nullptr; a.gate_dz = nullptr; a.gate_part = nullptr; a.gate_rows = nullptr;
     if (gs) { a.gate_mode = gs->mode; a.gate_H = gs->H; a.gate_W = gs->W; a.gate_a = gs->a; a.gate_dz = gs->dz; a.gate_part = gs->part; a.gate_rows = gs->rows; }
-    if (y_sums) { if (gs) return ASR_ERR_BAD_ARG; a.gate_part = y_sums; }      // W11_EPI_FWD_SUM: partial rows [tile block x 8][N] of the sums of y
+    if (y_sums) { if (gs) return ASR_ERR_BAD_ARG; a.gate_part = y_sums; a.gate_a = se_x; }      // W11_EPI_FWD_SUM / _DGRAD_SESUM: partial rows [tile block x 8][N]
     w.Ut = Ut;
     w.TH = (d->H + 1) / 2; w.TW = (d->W + 1) / 2;
     w.ntiles = (long)d->B * w.TH * w.TW;
@@ -1346,21 +1364,22 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
         else if (pool_amax) { if (d->wmode || d->relu != 1 || !bias || !aff || !pool_y || !pool_idx || pool_mode != 2) return ASR_ERR_BAD_ARG; epi = W11_EPI_POOLMAXC; }
         else if (!d->wmode && d->relu == 1 && bias && aff && out_a && pool_y) epi = pool_mode == 2 ? W11_EPI_POOLMAX : W11_EPI_POOLAVG;
         else if (!d->wmode && d->relu == 1 && bias && aff && out_a && out_y && !d->accumulate && !pool_y) epi = y_sums ? W11_EPI_FWD_SUM : W11_EPI_FWD;
-        if (y_sums && epi != W11_EPI_FWD_SUM) return ASR_ERR_UNSUPPORTED;
         else if (d->wmode && d->relu == 0 && !bias && !scale && !shift && !out_a && out_y && !pool_y) epi = d->accumulate ? W11_EPI_DGRAD_ACC : W11_EPI_DGRAD;
+        else if (d->wmode && d->relu == 0 && !bias && aff && !out_a && out_y && !pool_y && !d->accumulate && y_sums && se_x && d->ldo_y == d->N) epi = W11_EPI_DGRAD_SESUM;
+        if (y_sums && epi != W11_EPI_FWD_SUM && epi != W11_EPI_DGRAD_SESUM) return ASR_ERR_UNSUPPORTED;
         typedef void (*w11_fn)(WinoArgs);
-        static const w11_fn fns[12] = {nullptr, wino11_kernel<0, 1>, wino11_kernel<0, 2>, wino11_kernel<0, 3>, wino11_kernel<1, 4>, wino11_kernel<1, 5>,
+        static const w11_fn fns[13] = {nullptr, wino11_kernel<0, 1>, wino11_kernel<0, 2>, wino11_kernel<0, 3>, wino11_kernel<1, 4>, wino11_kernel<1, 5>,
                                        wino11_kernel<1, 6>, wino11_kernel<1, 7>, wino11_kernel<1, 8>, wino11_kernel<0, 9>, wino11_kernel<1, 10>,
-                                       wino11_kernel<0, 11>};
+                                       wino11_kernel<0, 11>, wino11_kernel<1, 12>};
         const w11_fn fn = epi ? fns[epi] : (d->wmode ? (w11_fn)wino11_kernel<1, 0> : (w11_fn)wino11_kernel<0, 0>);
-        static bool attr[13] = {false, false, false, false, false, false, false, false, false, false, false, false, false};
-        const int slot = epi ? (epi == W11_EPI_FWD_SUM ? 12 : epi) : (d->wmode ? 11 : 0);
+        static bool attr[14] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false};
+        const int slot = epi ? (epi >= W11_EPI_FWD_SUM ? epi + 1 : epi) : (d->wmode ? 11 : 0);
         if (!attr[slot]) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr[slot] = true; }
         hipLaunchKernelGGL(fn, dim3(grid11), dim3(512), lds11, st, w);
         ASR_CHECK_LAUNCH("tap_gemm_wino11");
-        static const char* const names[13] = {"wino11_kernel<0, 0>", "wino11_kernel<0, 1>", "wino11_kernel<0, 2>", "wino11_kernel<0, 3>", "wino11_kernel<1, 4>",
+        static const char* const names[14] = {"wino11_kernel<0, 0>", "wino11_kernel<0, 1>", "wino11_kernel<0, 2>", "wino11_kernel<0, 3>", "wino11_kernel<1, 4>",
                                               "wino11_kernel<1, 5>", "wino11_kernel<1, 6>", "wino11_kernel<1, 7>", "wino11_kernel<1, 8>", "wino11_kernel<0, 9>",
-                                              "wino11_kernel<1, 10>", "wino11_kernel<1, 0>", "wino11_kernel<0, 11>"};
+                                              "wino11_kernel<1, 10>", "wino11_kernel<1, 0>", "wino11_kernel<0, 11>", "wino11_kernel<1, 12>"};
         asr_set_last_kernel(names[slot]);
         return ASR_OK;
     }
@@ -1400,7 +1419,7 @@ extern "C" int asr_tap_gemm_wino(const asr_gemm_desc* d, const float* A, const f
 // [b * rows / B, (b + 1) * rows / B) -- what the block's global average pool needs (asr_se_fwd_sums), without its pass over the plane.
 // ASR_ERR_UNSUPPORTED where wino11_kernel's forward epilogue does not apply (then: asr_tap_gemm_wino + asr_se_fwd).
 extern "C" int asr_winograd_sum_rows(const asr_gemm_desc* d) {
-    if (!d || d->wmode || !asr_winograd_supported(d) || !wino11_takes(d, false, 0)) return 0;
+    if (!d || !asr_winograd_supported(d) || !wino11_takes(d, false, 0)) return 0;
     return 8 * wino_tile_blocks(d);
 }
 extern "C" int asr_tap_gemm_wino_sums(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale,
@@ -1408,6 +1427,17 @@ extern "C" int asr_tap_gemm_wino_sums(const asr_gemm_desc* d, const float* A, co
     if (!d || !bias || !scale || !shift || !out_a || !out_y || !y_sums || d->wmode || d->relu != 1 || d->accumulate || d->y_unpadded) return ASR_ERR_BAD_ARG;
     if (asr_winograd_sum_rows(d) <= 0) return ASR_ERR_UNSUPPORTED;
     return wino_impl(d, A, Ut, bias, scale, shift, out_a, out_y, stream, nullptr, nullptr, 0, nullptr, nullptr, y_sums);
+}
+
+// Data-gradient (wmode 1, no accumulate) that completes dL/d(output of an SE block) + the reduction the block's backward starts with:
+// xsums[rows][N] partial rows (rows = asr_winograd_sum_rows(d): 8 per tile block, image-contiguous) of sum dy * (se_scale * x + se_shift),
+// x = the block's branch plane [B][H + 1][W + 1][N].  asr_se_bwd_cell_sums takes them.
+extern "C" int asr_tap_gemm_wino_sesum(const asr_gemm_desc* d, const float* dZ, const float* Ut, const float* x, const float* se_scale,
+                                       const float* se_shift, float* dy, float* xsums, void* stream) {
+    if (!d || !dZ || !Ut || !x || !se_scale || !se_shift || !dy || !xsums || !d->wmode || d->relu || d->accumulate || d->y_unpadded || d->ldo_y != d->N)
+        return ASR_ERR_BAD_ARG;
+    if (!asr_winograd_supported(d) || !wino11_takes(d, false, 0)) return ASR_ERR_UNSUPPORTED;
+    return wino_impl(d, dZ, Ut, nullptr, se_scale, se_shift, nullptr, dy, stream, nullptr, nullptr, 0, nullptr, nullptr, xsums, x);
 }
 
 extern "C" int asr_pool_fwd(const float* a, int B, int H, int W, int C, const float* bn_scale, const float* bn_shift, int pool,

@@ -470,6 +470,21 @@ class DFCNNEngine:
                 rows = ops.winograd_sum_rows(self.fdesc[br])
                 if rows > 0 and rows % B == 0:
                     self.se_sums[br] = (op[3], torch.zeros(rows * cell[4], dtype=torch.float32, device=dev), rows // B)
+        # ... and the mirror in the backward pass: the (plain, first-writer) Winograd data-gradient of the ONE cell that reads an SE block's
+        # output also leaves the block's first backward reduction, sum dout * (sc * x + sh) (asr_tap_gemm_wino_sesum -> asr_se_bwd_cell_sums).
+        # {consumer cell -> (SE block op, partial rows buffer, rows per image)}
+        self.se_xsum = {}
+        if self.opt_se_sums:
+            for op in self.g:
+                if op[0] != 'se' or op[3] not in self.se_cell:
+                    continue
+                cons = self.consumers.get(op[3], [])
+                if len(cons) != 1 or cons[0][0] != 'cell' or cons[0][2] not in self.wt_b or cons[0][2] in self.fuse:
+                    continue
+                rows = ops.winograd_sum_rows(self.bdesc[cons[0][2]])
+                if rows > 0 and rows % B == 0:
+                    self.se_xsum[cons[0][2]] = (op, torch.zeros(rows * op[4], dtype=torch.float32, device=dev), rows // B)
+        self._se_xsum_ready = {}
         self.compact = {}
         for writer, tgt in (self.fuse.items() if self.opt_compact else ()):
             top = next(o for o in self.g if o[0] == 'cell' and o[2] == tgt)
@@ -489,7 +504,7 @@ class DFCNNEngine:
         """The switches this engine was built with and what they resolved to on this graph (bench.py puts it in its JSON line)."""
         return {'dual_stream': self.opt_dual, 'wino': self.opt_wino, 'fuse_prologues': self.opt_fuse, 'fuse_se': self.opt_fuse_se,
                 'compact_pool': self.opt_compact, 'side_priority': self.side_priority, 'dense_wgrad_side': self.opt_dense_side, 'fuse_dense': self.opt_fuse_dense, 'se_sums': self.opt_se_sums,
-                'se_squeeze_in_the_branch_conv': sorted(self.se_sums),
+                'se_squeeze_in_the_branch_conv': sorted(self.se_sums), 'se_backward_reduction_in_the_consumer_dgrad': sorted(self.se_xsum),
                 'winograd_layers_fwd': sorted(self.wt_f), 'winograd_layers_dgrad': sorted(self.wt_b),
                 'fused_prologues': len(self.fuse), 'dense_gradients_with_cell_backward': sorted(self.dense_gate), 'se_blocks_fused_with_cell_backward': len(self.se_cell),
                 'compact_max_pool_cells': sorted(self.compact)}
@@ -823,6 +838,14 @@ class DFCNNEngine:
                     cell = self.se_cell[dst]
                     Hc, Wc, _ = self.res[cell[1]]
                     dzt = acquire_dz((Hc, Wc, cell[4]))
+                    xs = self._se_xsum_ready.pop(dst, None)
+                    if xs is not None:
+                        ops.se_bwd_cell_sums(dout, self.y[br], hid, sc, sh, self.p(dst, 'w1'), self.p(dst, 'w2'), self.se_state[dst],
+                                             1 if same else 0, dsc, dsh, self.gview(dst, 'w1'), self.gview(dst, 'b1'),
+                                             self.gview(dst, 'w2'), self.gview(dst, 'b2'), self.a[br], self.scale_of(br), dzt,
+                                             self.dscale_of(br), self.gview(br, 'beta'), self.gview(br, 'b'), xs[0], xs[1], self.ws[:-2048])
+                        fused_dz[br] = dzt
+                        continue
                     ops.se_bwd_cell(dout, self.y[br], hid, sc, sh, self.p(dst, 'w1'), self.p(dst, 'w2'), self.se_state[dst],
                                     1 if same else 0, dsc, dsh, self.gview(dst, 'w1'), self.gview(dst, 'b1'),
                                     self.gview(dst, 'w2'), self.gview(dst, 'b2'), self.a[br], self.scale_of(br), dzt,
@@ -893,6 +916,11 @@ class DFCNNEngine:
                                            dx if acc else None, dzt, self.dscale_of(tgt), self.gview(tgt, 'beta'),
                                            self.gview(tgt, 'b'), self.ws)
                     fused_dz[tgt] = dzt
+                elif dst in self.se_xsum and not acc:
+                    se_op, xs, per = self.se_xsum[dst]
+                    ssc, ssh = self._se_affine(se_op[3], se_op[4], se_op[6])
+                    ops.tap_gemm_wino_sesum(d, dz, self.wt_b[dst], self.y[se_op[2]], ssc, ssh, dx, xs)
+                    self._se_xsum_ready[se_op[3]] = (xs, per)
                 elif dst in self.wt_b:
                     ops.tap_gemm_wino(d, dz, self.wt_b[dst], None, None, None, None, dx)
                 elif dst in self.wf_b:

@@ -298,6 +298,15 @@ def se_bwd_cell(dout, x, hid, sc, sh, w1, w2, state, add_dout, dscale, dshift, d
                                       _ptr(partials), _stream()), 'asr_se_bwd_cell')
 
 
+def se_bwd_cell_sums(dout, x, hid, sc, sh, w1, w2, state, add_dout, dscale, dshift, dw1, db1, dw2, db2, cell_a, cell_scale, cell_dz,
+                     cell_dscale, cell_dshift, cell_dbias, xsums, nsplit, partials):
+    """se_bwd_cell with the block's first reduction handed in (asr_se_bwd_cell_sums; xsums from tap_gemm_wino_sesum)."""
+    check(_lib.load().asr_se_bwd_cell_sums(dout.ptr, x.ptr, x.B, x.H, x.W, x.C, hid, _ptr(sc), _ptr(sh), _ptr(w1), _ptr(w2),
+                                           _ptr(state), add_dout, _ptr(dscale), _ptr(dshift), _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2),
+                                           cell_a.ptr, _ptr(cell_scale), cell_dz.ptr, _ptr(cell_dscale), _ptr(cell_dshift), _ptr(cell_dbias),
+                                           _ptr(xsums), int(nsplit), _ptr(partials), _stream()), 'asr_se_bwd_cell_sums')
+
+
 def axpy(dst, src, alpha=1.0, accumulate=False):
     check(_lib.load().asr_axpy(_ptr(dst), _ptr(src), dst.numel(), alpha, int(accumulate), _stream()), 'asr_axpy')
 
@@ -681,6 +690,13 @@ def tap_gemm_wino_sums(desc, A, Wt, bias, scale, shift, out_a, out_y, y_sums):
     lib = _lib.load()
     _timed(desc, lambda: check(lib.asr_tap_gemm_wino_sums(C.byref(desc), A.ptr, _ptr(Wt), _ptr(bias), _ptr(scale), _ptr(shift), out_a.ptr, out_y.ptr,
                                                           _ptr(y_sums), _stream()), 'asr_tap_gemm_wino_sums'))
+
+
+def tap_gemm_wino_sesum(desc, dZ, Wt, x, se_scale, se_shift, dy, xsums):
+    """Winograd data-gradient into dy (no accumulate) + partial rows of sum dy * (se_scale * x + se_shift) (asr_tap_gemm_wino_sesum)."""
+    lib = _lib.load()
+    _timed(desc, lambda: check(lib.asr_tap_gemm_wino_sesum(C.byref(desc), dZ.ptr, _ptr(Wt), x.ptr, _ptr(se_scale), _ptr(se_shift), dy.ptr,
+                                                           _ptr(xsums), _stream()), 'asr_tap_gemm_wino_sesum'))
 
 
 def tap_gemm_wino_pool(desc, A, Wt, bias, scale, shift, out_a, pool, y_pooled):

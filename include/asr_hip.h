@@ -203,6 +203,13 @@ int asr_se_bwd_cell(const float* dout, const float* x, int B, int H, int W, int 
                     float* dw1, float* db1, float* dw2, float* db2,
                     const float* cell_a, const float* cell_scale, float* cell_dz, float* cell_dscale, float* cell_dshift,
                     float* cell_dbias, float* partials, void* stream);
+/* asr_se_bwd_cell with that reduction handed in (xsums [B][nsplit][C] partial rows from asr_tap_gemm_wino_sesum). */
+int asr_se_bwd_cell_sums(const float* dout, const float* x, int B, int H, int W, int C, int hid,
+                         const float* bn_scale, const float* bn_shift, const float* w1, const float* w2,
+                         const float* state, int add_dout, float* dscale, float* dshift,
+                         float* dw1, float* db1, float* dw2, float* db2,
+                         const float* cell_a, const float* cell_scale, float* cell_dz, float* cell_dscale, float* cell_dshift,
+                         float* cell_dbias, const float* xsums, int nsplit, float* partials, void* stream);
 /* dst (+)= src over the interior of a padded plane (residual gradient fan-in). */
 int asr_axpy(float* dst, const float* src, size_t n, float alpha, int accumulate, void* stream);
 
@@ -518,6 +525,11 @@ int asr_winograd_supported(const asr_gemm_desc* d);
 int asr_winograd_sum_rows(const asr_gemm_desc* d);
 int asr_tap_gemm_wino_sums(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale,
                            const float* shift, float* out_a, float* out_y, float* y_sums, void* stream);
+/* The mirror in the backward pass: the data-gradient (wmode 1, no accumulate) that completes dL/d(output of an SE block) also leaves the
+ * reduction the block's backward starts with -- xsums[rows][N] partial rows (rows = asr_winograd_sum_rows(d), image-contiguous) of
+ * sum over pixels of dy * (se_scale * x + se_shift), x = the block's branch plane [B][H + 1][W + 1][N] -- for asr_se_bwd_cell_sums. */
+int asr_tap_gemm_wino_sesum(const asr_gemm_desc* d, const float* dZ, const float* Ut, const float* x, const float* se_scale,
+                            const float* se_shift, float* dy, float* xsums, void* stream);
 int asr_tap_gemm_wino(const asr_gemm_desc* d, const float* A, const float* Wt,
                       const float* bias, const float* scale, const float* shift,
                       float* out_a, float* out_y, void* stream);

@@ -190,8 +190,9 @@ def test_stream_and_fusion_modes_give_the_same_bits(model, widths):
 
 def test_se_squeeze_made_by_the_branch_conv_gives_the_same_step():
     """se_sums=True (default): the forward launch of an SE block's branch cell also writes the block's squeeze sums
-    (asr_tap_gemm_wino_sums -> asr_se_fwd_sums); se_sums=False: the squeeze is a pass of its own over the plane.  The same sum in
-    another order: logits, loss and every gradient agree to rounding; the planes in front of the first SE block are bitwise equal."""
+    (asr_tap_gemm_wino_sums -> asr_se_fwd_sums) and the data-gradient of the cell that reads the block's output writes the block's first
+    backward reduction (asr_tap_gemm_wino_sesum -> asr_se_bwd_cell_sums); se_sums=False: both are passes of their own over the plane.
+    The same sums in another order: logits, loss and every gradient agree to rounding; the planes in front of the first SE block are bitwise equal."""
     from asr_dfcnn_transformer_amd.engine import DFCNNEngine
     rng = np.random.default_rng(9)
     B, T, F, V = 2, 64, 200, 20
@@ -200,7 +201,7 @@ def test_se_squeeze_made_by_the_branch_conv_gives_the_same_step():
     out = []
     for flag in (True, False):
         eng = DFCNNEngine(model='m2', vocab=V, B=B, T=T, F=F, widths=(32, 64, 64, 64), seed=2, se_sums=flag)
-        assert bool(eng.se_sums) == flag and (not flag or len(eng.se_sums) == 5)
+        assert bool(eng.se_sums) == flag and (not flag or len(eng.se_sums) == 5) and (not flag or len(eng.se_xsum) == 5)
         logits = eng.forward(x).clone()
         eng.set_targets([8, 8], tgt); eng.loss_and_decode(); eng.backward()
         torch.cuda.synchronize()

@@ -170,3 +170,28 @@ def test_forward_with_squeeze_sums_feeds_the_se_block(ops, B, H, W, cin, cout, h
     assert (st0 - st1).abs().max().item() <= 2e-6 * max(1.0, st0.abs().max().item())
     assert (o0.interior() - o1.interior()).abs().max().item() <= 2e-6 * max(1.0, o0.interior().abs().max().item())
     assert o1.border_abs_max() == 0.0
+
+
+@pytest.mark.parametrize("B,H,W,K,N", [(3, 20, 50, 64, 32), (2, 40, 25, 128, 64), (4, 25, 25, 256, 128), (2, 16, 100, 64, 32)])
+def test_data_gradient_with_the_se_backward_reduction(ops, B, H, W, K, N):
+    """asr_tap_gemm_wino_sesum (round 5): dy is asr_tap_gemm_wino's data-gradient bit for bit, and the partial rows fold to the per-image
+    sums of dy * (sc * x + sh) over the pixels (float64, 1e-5 of their scale) -- se_reduce_kernel<1>'s result, the first step of the
+    backward of squeeze_excitation_layer (acoustic_model2.py:135-148)."""
+    g = torch.Generator(device='cuda').manual_seed(29)
+    w = torch.randn(3, 3, N, K, device='cuda', generator=g) * 0.1
+    dz = ops.Plane(B, H, W, K); dz.set_interior(torch.randn(B, H, W, K, device='cuda', generator=g))
+    x = ops.Plane(B, H, W, N); x.set_interior(torch.randn(B, H, W, N, device='cuda', generator=g))
+    sc = 1 + 0.2 * torch.randn(N, device='cuda', generator=g); sh = 0.1 * torch.randn(N, device='cuda', generator=g)
+    bd = ops.gemm_desc(dz.NP, K, N, K, K, 0, N, ntaps=9, B=B, H=H, W=W, wmode=1)
+    rows = ops.winograd_sum_rows(bd)
+    assert rows > 0 and rows % B == 0
+    wt = ops.winograd_weights(w, K, N, K, 1)
+    dy0, dy1 = ops.Plane(B, H, W, N), ops.Plane(B, H, W, N)
+    ops.tap_gemm_wino(bd, dz, wt, None, None, None, None, dy0)
+    sums = torch.full((rows * N,), float('nan'), device='cuda')
+    ops.tap_gemm_wino_sesum(bd, dz, wt, x, sc, sh, dy1, sums)
+    torch.cuda.synchronize()
+    assert torch.equal(dy0.buf, dy1.buf)
+    got = sums.view(B, rows // B, N).double().sum(1)
+    want = (dy1.interior().double() * (sc.double() * x.interior().double() + sh.double())).sum((1, 2))
+    assert (got - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item())
