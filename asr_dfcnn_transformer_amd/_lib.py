@@ -40,6 +40,9 @@ SIGNATURES = {
     'asr_winograd_poolmax_supported': (_I, [_P, _P]),
     'asr_tap_gemm_wino_poolmax': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_gemm_gated_poolmax': (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'asr_poolavg_index_bytes': (_Z, [_I, _I, _I, _I]),
+    'asr_tap_gemm_wino_poolavg': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'asr_tap_gemm_gated_poolavg': (_I, [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_gemm_gated': (_I, [C.POINTER(GemmDesc), _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'asr_tap_gemm_gated_dense_supported': (_I, [C.POINTER(GemmDesc), _I, _I, _I]),
     'asr_tap_gemm_gated_dense_workspace': (_Z, [C.POINTER(GemmDesc), _I, _I]),

@@ -513,7 +513,7 @@ constexpr int W11_RAW0 = 2 * W11_TABF * 4;      // byte offsets of the four sets
 constexpr int W11_U0 = W11_RAW0 + 2 * W11_SETF * 4;
 // epilogue instantiations (see wino11_body)
 constexpr int W11_EPI_GENERIC = 0, W11_EPI_FWD = 1, W11_EPI_POOLMAX = 2, W11_EPI_POOLAVG = 3, W11_EPI_DGRAD = 4, W11_EPI_DGRAD_ACC = 5,
-              W11_EPI_GATE1 = 6, W11_EPI_GATE2 = 7, W11_EPI_GATE3 = 8, W11_EPI_POOLMAXC = 9, W11_EPI_GATE4 = 10, W11_EPI_FWD_SUM = 11, W11_EPI_DGRAD_SESUM = 12;
+              W11_EPI_GATE1 = 6, W11_EPI_GATE2 = 7, W11_EPI_GATE3 = 8, W11_EPI_POOLMAXC = 9, W11_EPI_GATE4 = 10, W11_EPI_FWD_SUM = 11, W11_EPI_DGRAD_SESUM = 12, W11_EPI_POOLAVGC = 13, W11_EPI_GATE5 = 14;
 
 #if __HIP_DEVICE_COMPILE__
 typedef const __attribute__((address_space(4))) WinoArgs* wino_kernarg_p;
@@ -804,7 +804,11 @@ __device__ __forceinline__ void wino11_epilogue_gated(R rGA, R rGD, R rY, R rGI,
     wino11_transpose(blk, scratch, lane);
     float s_scale[4] = {0.f, 0.f, 0.f, 0.f}, s_shift[4] = {0.f, 0.f, 0.f, 0.f}, s_bias[4] = {0.f, 0.f, 0.f, 0.f};
     const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-    constexpr int NK = (GM == 1 || GM == 4) ? 1 : 4;
+    // GM 5 = the AVERAGE pool in its compact form (asr_tap_gemm_gated_poolavg, round 5): rGA is the plane of the window SUMS of the
+    // activations (pooled geometry), rGI four bit planes with the ReLU sign of each window position.  dZ and the bias / shift sums are those of
+    // GM 2 bit for bit (a position's gradient is 0.25 dy * scale where its activation was positive); the scale sum takes 0.25 dy times the
+    // window's activation sum in ONE multiply-add instead of four (the same value, rounded once).
+    constexpr int NK = (GM == 1 || GM == 4 || GM == 5) ? 1 : 4;
     // One pixel per trip of a ROLLED loop: unrolled, hipcc interleaves the four pixels (and vectorises across them), holds 100 values
     // more than the 128-register budget has and parks them in scratch -- whose reloads wait for every store in flight.  The other
     // three waves of the SIMD cover the round trip of a pixel's loads.
@@ -820,11 +824,15 @@ __device__ __forceinline__ void wino11_epilogue_gated(R rGA, R rGD, R rY, R rGI,
         if (GM != 1) { off[1] = ok ? o0 + c4b : W11_OOR; off[2] = ok ? o0 + wpf4 : W11_OOR; off[3] = ok ? o0 + wpf4 + c4b : W11_OOR; }
         float4 a4[NK];
         unsigned iw0 = 0, iw1 = 0;
+        w11_u4 sg = {0u, 0u, 0u, 0u};
         if (GM == 4) {
             a4[0] = w11_load4(rGA, ok ? __umul24((unsigned)ra, c4b) + n4 : W11_OOR);
             const unsigned io = ok ? __umul24((unsigned)ra, (unsigned)(C >> 5) * 8u) + (unsigned)(n >> 5) * 8u : W11_OOR;
             iw0 = __builtin_amdgcn_raw_buffer_load_b32(rGI, io, 0, 0);
             iw1 = __builtin_amdgcn_raw_buffer_load_b32(rGI, io == W11_OOR ? W11_OOR : io + 4u, 0, 0);
+        } else if (GM == 5) {
+            a4[0] = w11_load4(rGA, ok ? __umul24((unsigned)ra, c4b) + n4 : W11_OOR);
+            sg = __builtin_amdgcn_raw_buffer_load_b128(rGI, ok ? __umul24((unsigned)ra, (unsigned)(C >> 5) * 16u) + (unsigned)(n >> 5) * 16u : W11_OOR, 0, 0);
         } else {
 #pragma unroll
             for (int k = 0; k < NK; ++k) a4[k] = w11_load4(rGA, off[k]);
@@ -847,6 +855,23 @@ __device__ __forceinline__ void wino11_epilogue_gated(R rGA, R rGD, R rY, R rGI,
                 s_bias[e] += d[e];
             }
             w11_store4_nt(rGD, off[0], d[0], d[1], d[2], d[3]);
+        } else if (GM == 5) {
+            const int cb = n & 31;
+            const unsigned sgw[4] = {sg.x, sg.y, sg.z, sg.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s_scale[e] = fmaf(0.25f * v[e], av[0][e], s_scale[e]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float gk = 0.25f * v[e];
+                    s_shift[e] += gk;
+                    d[e] = ((sgw[k] >> (cb + e)) & 1u) ? gk * scv[e] : 0.f;
+                    s_bias[e] += d[e];
+                }
+                w11_store4_nt(rGD, off[k], d[0], d[1], d[2], d[3]);
+            }
         } else if (GM == 4) {
             const int cb = n & 31;
 #pragma unroll
@@ -913,8 +938,8 @@ __device__ __forceinline__ void wino11_epilogue_gated(R rGA, R rGD, R rY, R rGI,
 
 template <int EPI>
 __device__ __forceinline__ void wino11_body(float* smem) {
-    constexpr bool GATED = (EPI >= W11_EPI_GATE1 && EPI <= W11_EPI_GATE3) || EPI == W11_EPI_GATE4;
-    constexpr bool POOLED = EPI == W11_EPI_POOLMAX || EPI == W11_EPI_POOLAVG || EPI == W11_EPI_POOLMAXC;
+    constexpr bool GATED = (EPI >= W11_EPI_GATE1 && EPI <= W11_EPI_GATE3) || EPI == W11_EPI_GATE4 || EPI == W11_EPI_GATE5;
+    constexpr bool POOLED = EPI == W11_EPI_POOLMAX || EPI == W11_EPI_POOLAVG || EPI == W11_EPI_POOLMAXC || EPI == W11_EPI_POOLAVGC;
     const char* lds = (const char*)smem;
     int* tables = (int*)smem;                        // two sets of [rowa 256 | rowy 256 | prow 256]
     float* bufs = smem + 2 * W11_TABF;               // raw0 | raw1 | u0 | u1
@@ -1170,6 +1195,27 @@ __device__ __forceinline__ void wino11_body(float* smem) {
                         __builtin_amdgcn_raw_buffer_store_b32(w0, rPI, io, 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b32(w1, rPI, io == W11_OOR ? W11_OOR : io + 4u, 0, 0);
                     }
+                } else if (EPI == W11_EPI_POOLAVGC) {
+                    // Compact form of the AVERAGE pool (round 5): no activation plane either.  Per window: the pooled value (POOLAVG's
+                    // arithmetic), the SUM of the four activations (all the backward's scale sum needs of them) and the ReLU sign of each
+                    // position -- four ballots per tile slot, one 16-byte store per pooled pixel and 32-channel block.
+                    auto rPA = __builtin_amdgcn_make_buffer_rsrc((void*)args.pool_amax, 0, 0xFFFFFFF0, 0x00020000);
+                    auto rPI = __builtin_amdgcn_make_buffer_rsrc((void*)args.pool_idx, 0, 0xFFFFFFF0, 0x00020000);
+                    const unsigned nb16 = (unsigned)(N >> 5) * 16u, cb16 = (unsigned)(n0 >> 5) * 16u;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float x0 = fmaxf(out[0][0][i] + bs, 0.f), x1 = fmaxf(out[0][0][4 + i] + bs, 0.f);
+                        const float x2 = fmaxf(out[0][0][8 + i] + bs, 0.f), x3 = fmaxf(out[0][0][12 + i] + bs, 0.f);
+                        const float v0 = fmaf(scv, x0, shv), v1 = fmaf(scv, x1, shv), v2 = fmaf(scv, x2, shv), v3 = fmaf(scv, x3, shv);
+                        const float pv = 0.25f * ((v0 + v1) + (v2 + v3));
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(pv), rP, po[i], 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint((x0 + x1) + (x2 + x3)), rPA, po[i], 0, 2);
+                        const unsigned long long b0 = __ballot(x0 > 0.f), b1 = __ballot(x1 > 0.f), b2 = __ballot(x2 > 0.f), b3 = __ballot(x3 > 0.f);
+                        const w11_u4 wd = {lh ? (unsigned)(b0 >> 32) : (unsigned)b0, lh ? (unsigned)(b1 >> 32) : (unsigned)b1,
+                                           lh ? (unsigned)(b2 >> 32) : (unsigned)b2, lh ? (unsigned)(b3 >> 32) : (unsigned)b3};
+                        const int pr = prow[wave * 32 + i + 4 * lh];
+                        __builtin_amdgcn_raw_buffer_store_b128(wd, rPI, (pr >= 0 && li == 0) ? __umul24((unsigned)pr, nb16) + cb16 : W11_OOR, 0, 0);
+                    }
                 } else {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -1190,7 +1236,7 @@ __device__ __forceinline__ void wino11_body(float* smem) {
                 wino11_epilogue_plain<false, false, true, false, 2>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane,
                                                                     g.gate_part + (long)(blk * 8 + wave) * N, rX);
             }
-            else if (EPI == W11_EPI_POOLMAXC) { }            // nothing else to store: no activation plane in the compact form
+            else if (EPI == W11_EPI_POOLMAXC || EPI == W11_EPI_POOLAVGC) { }            // nothing else to store: no activation plane in the compact forms
             else if (POOLED) wino11_epilogue_plain<true, true, false, false>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
             else if (EPI == W11_EPI_DGRAD) wino11_epilogue_plain<false, false, true, false>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
             else if (EPI == W11_EPI_DGRAD_ACC) wino11_epilogue_plain<false, false, true, true>(rA, rY, pa, py, out[0][0], scratch, ra_w, ry_w, n4, cbs, csc, csh, lane);
@@ -1200,7 +1246,7 @@ __device__ __forceinline__ void wino11_body(float* smem) {
                 const unsigned c4b = (unsigned)N * 4u, wpf4 = (unsigned)(g.gate_W + 1) * c4b;
                 const bool accu = g.accumulate != 0;
                 float* gpart = g.gate_part;
-                constexpr int GM = EPI == W11_EPI_GATE1 ? 1 : EPI == W11_EPI_GATE2 ? 2 : EPI == W11_EPI_GATE3 ? 3 : 4;
+                constexpr int GM = EPI == W11_EPI_GATE1 ? 1 : EPI == W11_EPI_GATE2 ? 2 : EPI == W11_EPI_GATE3 ? 3 : EPI == W11_EPI_GATE4 ? 4 : 5;
                 auto rGI = __builtin_amdgcn_make_buffer_rsrc((void*)args.pool_idx, 0, 0xFFFFFFF0, 0x00020000);
                 wino11_epilogue_gated<GM>(rGA, rGD, rY, rGI, accu, py, c4b, wpf4, gpart, N, out[0][0], scratch, ra_w, ry_w, ne, n4, csc, csh, lane, blk * 8 + wave);
             }
@@ -1334,7 +1380,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     w.wodd = d->W & 1;
     w.pool_y = pool_y; w.pool_mode = pool_mode; w.H2 = d->H / 2; w.W2 = d->W / 2;
     w.pool_amax = pool_amax; w.pool_idx = pool_idx;
-    const bool compact = pool_amax != nullptr || (gs && gs->mode == 4);
+    const bool compact = pool_amax != nullptr || (gs && (gs->mode == 4 || gs->mode == 6));
     static int ncu8 = 0;
     if (!ncu8) {
         int dev = 0; hipDeviceProp_t pr;
@@ -1360,26 +1406,29 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
         // the epilogue instantiation (wino11_body): decided by the descriptor
         int epi = W11_EPI_GENERIC;
         const bool aff = scale && shift;
-        if (gs) epi = gs->mode == 1 ? W11_EPI_GATE1 : gs->mode == 2 ? W11_EPI_GATE2 : gs->mode == 3 ? W11_EPI_GATE3 : W11_EPI_GATE4;
-        else if (pool_amax) { if (d->wmode || d->relu != 1 || !bias || !aff || !pool_y || !pool_idx || pool_mode != 2) return ASR_ERR_BAD_ARG; epi = W11_EPI_POOLMAXC; }
+        if (gs) epi = gs->mode == 1 ? W11_EPI_GATE1 : gs->mode == 2 ? W11_EPI_GATE2 : gs->mode == 3 ? W11_EPI_GATE3 : gs->mode == 4 ? W11_EPI_GATE4 : W11_EPI_GATE5;
+        else if (pool_amax) {
+            if (d->wmode || d->relu != 1 || !bias || !aff || !pool_y || !pool_idx || (pool_mode != 2 && pool_mode != 1)) return ASR_ERR_BAD_ARG;
+            epi = pool_mode == 2 ? W11_EPI_POOLMAXC : W11_EPI_POOLAVGC;
+        }
         else if (!d->wmode && d->relu == 1 && bias && aff && out_a && pool_y) epi = pool_mode == 2 ? W11_EPI_POOLMAX : W11_EPI_POOLAVG;
         else if (!d->wmode && d->relu == 1 && bias && aff && out_a && out_y && !d->accumulate && !pool_y) epi = y_sums ? W11_EPI_FWD_SUM : W11_EPI_FWD;
         else if (d->wmode && d->relu == 0 && !bias && !scale && !shift && !out_a && out_y && !pool_y) epi = d->accumulate ? W11_EPI_DGRAD_ACC : W11_EPI_DGRAD;
         else if (d->wmode && d->relu == 0 && !bias && aff && !out_a && out_y && !pool_y && !d->accumulate && y_sums && se_x && d->ldo_y == d->N) epi = W11_EPI_DGRAD_SESUM;
         if (y_sums && epi != W11_EPI_FWD_SUM && epi != W11_EPI_DGRAD_SESUM) return ASR_ERR_UNSUPPORTED;
         typedef void (*w11_fn)(WinoArgs);
-        static const w11_fn fns[13] = {nullptr, wino11_kernel<0, 1>, wino11_kernel<0, 2>, wino11_kernel<0, 3>, wino11_kernel<1, 4>, wino11_kernel<1, 5>,
+        static const w11_fn fns[15] = {nullptr, wino11_kernel<0, 1>, wino11_kernel<0, 2>, wino11_kernel<0, 3>, wino11_kernel<1, 4>, wino11_kernel<1, 5>,
                                        wino11_kernel<1, 6>, wino11_kernel<1, 7>, wino11_kernel<1, 8>, wino11_kernel<0, 9>, wino11_kernel<1, 10>,
-                                       wino11_kernel<0, 11>, wino11_kernel<1, 12>};
+                                       wino11_kernel<0, 11>, wino11_kernel<1, 12>, wino11_kernel<0, 13>, wino11_kernel<1, 14>};
         const w11_fn fn = epi ? fns[epi] : (d->wmode ? (w11_fn)wino11_kernel<1, 0> : (w11_fn)wino11_kernel<0, 0>);
-        static bool attr[14] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false};
+        static bool attr[16] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};
         const int slot = epi ? (epi >= W11_EPI_FWD_SUM ? epi + 1 : epi) : (d->wmode ? 11 : 0);
         if (!attr[slot]) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr[slot] = true; }
         hipLaunchKernelGGL(fn, dim3(grid11), dim3(512), lds11, st, w);
         ASR_CHECK_LAUNCH("tap_gemm_wino11");
-        static const char* const names[14] = {"wino11_kernel<0, 0>", "wino11_kernel<0, 1>", "wino11_kernel<0, 2>", "wino11_kernel<0, 3>", "wino11_kernel<1, 4>",
+        static const char* const names[16] = {"wino11_kernel<0, 0>", "wino11_kernel<0, 1>", "wino11_kernel<0, 2>", "wino11_kernel<0, 3>", "wino11_kernel<1, 4>",
                                               "wino11_kernel<1, 5>", "wino11_kernel<1, 6>", "wino11_kernel<1, 7>", "wino11_kernel<1, 8>", "wino11_kernel<0, 9>",
-                                              "wino11_kernel<1, 10>", "wino11_kernel<1, 0>", "wino11_kernel<0, 11>", "wino11_kernel<1, 12>"};
+                                              "wino11_kernel<1, 10>", "wino11_kernel<1, 0>", "wino11_kernel<0, 11>", "wino11_kernel<1, 12>", "wino11_kernel<0, 13>", "wino11_kernel<1, 14>"};
         asr_set_last_kernel(names[slot]);
         return ASR_OK;
     }
@@ -1489,6 +1538,41 @@ extern "C" int asr_tap_gemm_gated_poolmax(const asr_gemm_desc* d, const float* d
     int rows = 0;
     WinoGate gs;
     gs.mode = 4; gs.H = gate_H; gs.W = gate_W; gs.a = a_max; gs.dz = dz_out; gs.part = partials; gs.rows = &rows;
+    const int rc = wino_impl(d, dZ, Ut, nullptr, bn_scale, bn_shift, nullptr, (float*)dy_prev, stream, &gs, nullptr, 0, nullptr, (unsigned*)index);
+    if (rc != ASR_OK) return rc;
+    if (rows <= 0 || (size_t)rows * 3 * d->N * sizeof(float) > asr_tap_gemm_gated_workspace(d)) return ASR_ERR_UNSUPPORTED;
+    asr_reduce::Multi m;
+    m.nseg = 3; m.width[0] = d->N; m.width[1] = d->N; m.width[2] = d->N; m.width[3] = 0;
+    m.out[0] = dscale; m.out[1] = dshift; m.out[2] = dbias; m.out[3] = nullptr;
+    return asr_reduce::colsum_multi(partials, rows, 3L * d->N, m, partials + (size_t)rows * 3 * d->N, (hipStream_t)stream);
+}
+
+// ---- the AVERAGE pool in its compact form (round 5; acoustic_model2.py:116-124 "maxpool" = average pooling): the forward launch of an
+// average-pooled cell writes the pooled output, the SUM of each window's four activations and the ReLU sign of each position (four bit planes
+// of 32 channels per pooled pixel) instead of the pre-pool activation plane; the gated data-gradient that completes the cell's output gradient
+// reads those.  dZ, dshift and dbias are the bits of the activation-plane form, dscale the same value rounded once instead of four times.
+extern "C" size_t asr_poolavg_index_bytes(int B, int H2, int W2, int N) {
+    if (B < 1 || H2 < 1 || W2 < 1 || N < 32 || (N & 31)) return 0;
+    return (size_t)B * (H2 + 1) * (W2 + 1) * (N >> 5) * 4 * sizeof(unsigned);
+}
+
+extern "C" int asr_tap_gemm_wino_poolavg(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale,
+                                         const float* shift, float* y_pooled, float* a_sum, unsigned* index, void* stream) {
+    if (!d || !A || !Ut || !bias || !scale || !shift || !y_pooled || !a_sum || !index) return ASR_ERR_BAD_ARG;
+    if ((d->H & 1) || (d->W & 1) || !asr_winograd_supported(d) || !wino11_takes(d, true, 0)) return ASR_ERR_UNSUPPORTED;
+    return wino_impl(d, A, Ut, bias, scale, shift, nullptr, nullptr, stream, nullptr, y_pooled, 1, a_sum, index);
+}
+
+extern "C" int asr_tap_gemm_gated_poolavg(const asr_gemm_desc* d, const float* dZ, const float* Ut, int gate_H, int gate_W, const float* a_sum,
+                                          const unsigned* index, const float* bn_scale, const float* bn_shift, const float* dy_prev,
+                                          float* dz_out, float* dscale, float* dshift, float* dbias, float* partials, void* stream) {
+    if (!d || !dZ || !Ut || !a_sum || !index || !bn_scale || !bn_shift || !dz_out || !dscale || !dshift || !dbias || !partials) return ASR_ERR_BAD_ARG;
+    if (d->wmode != 1 || d->relu != 0 || d->y_unpadded || d->H <= 0 || d->ldo_y != d->N || (d->accumulate && !dy_prev)) return ASR_ERR_BAD_ARG;
+    if (gate_H != 2 * d->H || gate_W != 2 * d->W) return ASR_ERR_BAD_ARG;
+    if (!asr_winograd_supported(d) || !wino11_takes(d, false, 6)) return ASR_ERR_UNSUPPORTED;
+    int rows = 0;
+    WinoGate gs;
+    gs.mode = 6; gs.H = gate_H; gs.W = gate_W; gs.a = a_sum; gs.dz = dz_out; gs.part = partials; gs.rows = &rows;
     const int rc = wino_impl(d, dZ, Ut, nullptr, bn_scale, bn_shift, nullptr, (float*)dy_prev, stream, &gs, nullptr, 0, nullptr, (unsigned*)index);
     if (rc != ASR_OK) return rc;
     if (rows <= 0 || (size_t)rows * 3 * d->N * sizeof(float) > asr_tap_gemm_gated_workspace(d)) return ASR_ERR_UNSUPPORTED;

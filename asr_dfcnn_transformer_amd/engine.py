@@ -158,8 +158,9 @@ class DFCNNEngine:
         ``dual_stream``: weight gradients / decode on a second stream (``side_priority``: its HIP stream priority);
         ``wino``: Winograd F(2x2,3x3) / F(3x3,2x2) for the 3x3 layers the kernels support instead of the direct tap-GEMM;
         ``fuse_prologues``: cell backward prologues inside the data-gradient epilogues; ``fuse_se``: an SE block's backward also
-        runs its branch cell's BN / ReLU backward (asr_se_bwd_cell); ``compact_pool``: max-pooled cells keep the activation at each
-        window's maximum + its position instead of the pre-pool plane; ``dense_wgrad_side``: the dense layers' weight / bias gradients on
+        runs its branch cell's BN / ReLU backward (asr_se_bwd_cell); ``compact_pool``: pooled cells keep, instead of the pre-pool
+        plane, the activation at each window's maximum + its position (max pool: same bits) or the window's activation sum + the ReLU signs
+        (average pool: dZ the same bits, the BN scale gradient rounded once per window instead of four times); ``dense_wgrad_side``: the dense layers' weight / bias gradients on
         the second stream beside their data-gradients (False: in front of them on the main stream, as until round 4); ``fuse_dense``: the
         data-gradient of a dense layer fed by a cell also runs that cell's BN / ReLU backward (asr_tap_gemm_gated_dense); ``se_sums``: the
         forward launch of an SE block's branch cell also makes the block's squeeze sums (asr_tap_gemm_wino_sums; the squeeze is then a
@@ -485,12 +486,14 @@ class DFCNNEngine:
                 if rows > 0 and rows % B == 0:
                     self.se_xsum[cons[0][2]] = (op, torch.zeros(rows * op[4], dtype=torch.float32, device=dev), rows // B)
         self._se_xsum_ready = {}
-        self.compact = {}
+        self.compact, self.compact_avg = {}, {}
         for writer, tgt in (self.fuse.items() if self.opt_compact else ()):
             top = next(o for o in self.g if o[0] == 'cell' and o[2] == tgt)
-            if top[6] == 'max' and tgt in self.wt_f and writer in self.wt_b and ops.poolmax_supported(self.fdesc[tgt], self.bdesc[writer]):
+            if top[6] in ('max', 'avg') and tgt in self.wt_f and writer in self.wt_b and ops.poolmax_supported(self.fdesc[tgt], self.bdesc[writer]):
                 Ho, Wo, cout = self.res[tgt]
-                self.compact[tgt] = (Plane(B, Ho, Wo, cout, dev), ops.poolmax_index(B, Ho, Wo, cout, dev))
+                index = ops.poolmax_index(B, Ho, Wo, cout, dev) if top[6] == 'max' else ops.poolavg_index(B, Ho, Wo, cout, dev)
+                self.compact[tgt] = (Plane(B, Ho, Wo, cout, dev), index)      # activation at the maximum / sum of the window's activations
+                self.compact_avg[tgt] = top[6] == 'avg'
                 del self.a[tgt]
         if self.fuse and not self.dz_alt:
             # a fused data-gradient reads dZ of its own cell while its epilogue writes dZ of the cell in front: two planes
@@ -507,7 +510,7 @@ class DFCNNEngine:
                 'se_squeeze_in_the_branch_conv': sorted(self.se_sums), 'se_backward_reduction_in_the_consumer_dgrad': sorted(self.se_xsum),
                 'winograd_layers_fwd': sorted(self.wt_f), 'winograd_layers_dgrad': sorted(self.wt_b),
                 'fused_prologues': len(self.fuse), 'dense_gradients_with_cell_backward': sorted(self.dense_gate), 'se_blocks_fused_with_cell_backward': len(self.se_cell),
-                'compact_max_pool_cells': sorted(self.compact)}
+                'compact_pool_cells': sorted(self.compact)}
 
     def _plan_fused_prologues(self):
         """Cells whose backward prologue (pool -> BN -> ReLU backward + the three channel sums, asr_cell_bwd_pre) moves into
@@ -628,7 +631,8 @@ class DFCNNEngine:
                     wf_ready = None
                 out_y = None if pool else (self.flat[dst] if dst in self.flat else self.y[dst])
                 if dst in self.compact:
-                    ops.tap_gemm_wino_poolmax(self.fdesc[dst], self.y[src], self.wt_f[dst], self.p(dst, 'b'), sc, sh, self.y[dst], *self.compact[dst])
+                    (ops.tap_gemm_wino_poolavg if self.compact_avg[dst] else ops.tap_gemm_wino_poolmax)(
+                        self.fdesc[dst], self.y[src], self.wt_f[dst], self.p(dst, 'b'), sc, sh, self.y[dst], *self.compact[dst])
                     continue
                 if dst in self.wt_f and pool:
                     # conv + bias + ReLU -> BN -> 2x2 pool in one launch: a Winograd tile is a pooling window
@@ -906,7 +910,8 @@ class DFCNNEngine:
                     Hf, Wf, _ = self.res[top[1]]
                     dzt = acquire_dz((Hf, Wf, top[4]))
                     if tgt in self.compact:
-                        ops.tap_gemm_gated_poolmax(d, dz, self.wt_b[dst], Hf, Wf, *self.compact[tgt], self.scale_of(tgt), self.p(tgt, 'beta'),
+                        (ops.tap_gemm_gated_poolavg if self.compact_avg[tgt] else ops.tap_gemm_gated_poolmax)(
+                                                   d, dz, self.wt_b[dst], Hf, Wf, *self.compact[tgt], self.scale_of(tgt), self.p(tgt, 'beta'),
                                                    dx if acc else None, dzt, self.dscale_of(tgt), self.gview(tgt, 'beta'),
                                                    self.gview(tgt, 'b'), self.ws)
                     else:

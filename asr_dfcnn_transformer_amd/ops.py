@@ -191,6 +191,33 @@ def poolmax_index(B, H2, W2, N, device='cuda'):
     return torch.zeros(n // 4, dtype=torch.int32, device=device)
 
 
+def poolavg_index(B, H2, W2, N, device='cuda'):
+    """the ReLU-sign planes of asr_tap_gemm_wino_poolavg (uint32 words, held in an int32 tensor)"""
+    n = _lib.load().asr_poolavg_index_bytes(B, H2, W2, N)
+    assert n > 0
+    return torch.zeros(n // 4, dtype=torch.int32, device=device)
+
+
+def tap_gemm_wino_poolavg(desc, A, Wt, bias, scale, shift, y_pooled, a_sum, index):
+    """Forward conv of an AVERAGE-pooled cell in the compact form (asr_tap_gemm_wino_poolavg): no activation plane; y_pooled, the sum of
+    each window's activations (a_sum, a Plane of the pooled geometry) and the ReLU signs of its positions (index)."""
+    lib = _lib.load()
+    pa = A.ptr if isinstance(A, Plane) else _ptr(A)
+    _timed(desc, lambda: check(lib.asr_tap_gemm_wino_poolavg(C.byref(desc), pa, _ptr(Wt), _ptr(bias), _ptr(scale), _ptr(shift),
+                                                             y_pooled.ptr, a_sum.ptr, _ptr(index), _stream()), 'asr_tap_gemm_wino_poolavg'))
+
+
+def tap_gemm_gated_poolavg(desc, dZ, Wt, gate_H, gate_W, a_sum, index, bn_scale, bn_shift, dy_prev, dz_out, dscale, dshift, dbias, partials):
+    """asr_tap_gemm_gated for an average-pooled cell in the compact form: (a_sum, index) in place of the activation plane."""
+    lib = _lib.load()
+    pz = dZ.ptr if isinstance(dZ, Plane) else _ptr(dZ)
+    pp = dy_prev.ptr if isinstance(dy_prev, Plane) else _ptr(dy_prev)
+    _timed(desc, lambda: check(
+        lib.asr_tap_gemm_gated_poolavg(C.byref(desc), pz, _ptr(Wt), int(gate_H), int(gate_W), a_sum.ptr, _ptr(index), _ptr(bn_scale),
+                                       _ptr(bn_shift), pp, dz_out.ptr, _ptr(dscale), _ptr(dshift), _ptr(dbias), _ptr(partials), _stream()),
+        'asr_tap_gemm_gated_poolavg'))
+
+
 def tap_gemm_wino_poolmax(desc, A, Wt, bias, scale, shift, y_pooled, a_max, index):
     """Forward conv of a MAX-pooled cell in the compact form (asr_tap_gemm_wino_poolmax): no activation plane; y_pooled, the
     activation at each window's maximum (a_max, a Plane of the pooled geometry) and its position (index)."""

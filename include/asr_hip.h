@@ -598,6 +598,18 @@ int asr_tap_gemm_gated_poolmax(const asr_gemm_desc* d, const float* dZ, const fl
                                const unsigned* index, const float* bn_scale, const float* bn_shift, const float* dy_prev,
                                float* dz_out, float* dscale, float* dshift, float* dbias, float* partials, void* stream);
 
+/* Round 5: the same for AVERAGE-pooled cells (the "maxpool" of acoustic_model2.py:116-124 is an average pool): a_sum = the sum of each
+ * window's four post-ReLU activations (pooled geometry), index = four bit planes per pooled pixel and 32-channel block with the ReLU sign
+ * of each window position (asr_poolavg_index_bytes).  dZ, dshift, dbias: the bits of asr_tap_gemm_wino_pool (pool 1) + asr_tap_gemm_gated
+ * (pool 1); dscale: the same value with the window's four products folded into one multiply-add.  Same support rule as the maximum form
+ * (asr_winograd_poolmax_supported). */
+size_t asr_poolavg_index_bytes(int B, int H2, int W2, int N);
+int asr_tap_gemm_wino_poolavg(const asr_gemm_desc* d, const float* A, const float* Ut, const float* bias, const float* scale,
+                              const float* shift, float* y_pooled, float* a_sum, unsigned* index, void* stream);
+int asr_tap_gemm_gated_poolavg(const asr_gemm_desc* d, const float* dZ, const float* Ut, int gate_H, int gate_W, const float* a_sum,
+                               const unsigned* index, const float* bn_scale, const float* bn_shift, const float* dy_prev,
+                               float* dz_out, float* dscale, float* dshift, float* dbias, float* partials, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -185,6 +185,67 @@ def test_poolmax_compact_form_gives_the_bits_of_the_activation_plane_form(B, H, 
         assert torch.equal(u, v)
 
 
+@pytest.mark.parametrize("B,H,W,cin,N,K2,acc", [(2, 16, 50, 32, 64, 64, 0), (1, 40, 100, 32, 64, 128, 1), (2, 8, 52, 64, 128, 32, 0), (3, 20, 100, 32, 32, 64, 0)])
+def test_poolavg_compact_form_against_the_activation_plane_form(B, H, W, cin, N, K2, acc):
+    """An AVERAGE-pooled cell (the "maxpool" of acoustic_model2.py:116-124) in the compact form (round 5: asr_tap_gemm_wino_poolavg /
+    asr_tap_gemm_gated_poolavg -- the window's activation sum + the ReLU sign of each position instead of the pre-pool activation plane)
+    against the form it replaces (asr_tap_gemm_wino_pool / asr_tap_gemm_gated with pool = 1): pooled output, dZ, dshift and dbias bit for
+    bit; dscale to 1e-5 of its scale (one multiply-add per window instead of four); the stored sums and signs against the plane."""
+    from asr_dfcnn_transformer_amd import ops
+    from asr_dfcnn_transformer_amd.ops import Plane
+    g = torch.Generator(device='cuda').manual_seed(B + H + W + N + 1)
+    rnd = lambda *s: torch.randn(*s, device='cuda', generator=g)
+    x = Plane(B, H, W, cin); x.set_interior(rnd(B, H, W, cin))
+    w = rnd(3, 3, cin, N) * (2.0 / (9 * cin)) ** 0.5
+    bias = rnd(N) * 0.1 - 0.3                        # plenty of ReLU zeros
+    sc = 1.0 + 0.2 * rnd(N); sh = 0.1 * rnd(N)
+    sc[0] = -0.5
+    fd = ops.gemm_desc(x.NP, cin, N, cin, N, N, 0, ntaps=9, B=B, H=H, W=W, relu=1)
+    H2, W2 = H // 2, W // 2
+    w2 = rnd(3, 3, N, K2) * 0.05
+    dzk = Plane(B, H2, W2, K2); dzk.set_interior(rnd(B, H2, W2, K2))
+    bd = ops.gemm_desc(dzk.NP, K2, N, K2, K2, 0, N, ntaps=9, B=B, H=H2, W=W2, wmode=1, accumulate=acc)
+    assert ops.poolmax_supported(fd, bd)
+    wt = ops.winograd_weights(w, cin, N, N, 0)
+    wtb = ops.winograd_weights(w2, K2, N, K2, 1)
+    a, y1 = Plane(B, H, W, N), Plane(B, H2, W2, N)
+    ops.tap_gemm_wino_pool(fd, x, wt, bias, sc, sh, a, 1, y1)
+    assert ops.last_kernel() == 'wino11_kernel<0, 3>'
+    prev = Plane(B, H2, W2, N)
+    if acc:
+        prev.set_interior(rnd(B, H2, W2, N))
+    ws = torch.zeros(ops.tap_gemm_gated_workspace(bd) // 4 + 64, device='cuda')
+    dz1 = Plane(B, H, W, N)
+    s1 = [torch.zeros(N, device='cuda') for _ in range(3)]
+    ops.tap_gemm_gated(bd, dzk, wtb, 2, 1, a, sc, sh, prev if acc else None, dz1, s1[0], s1[1], s1[2], ws)
+    assert ops.last_kernel() == 'wino11_kernel<1, 7>'
+    y2, asum = Plane(B, H2, W2, N), Plane(B, H2, W2, N)
+    idx = ops.poolavg_index(B, H2, W2, N)
+    ops.tap_gemm_wino_poolavg(fd, x, wt, bias, sc, sh, y2, asum, idx)
+    assert ops.last_kernel() == 'wino11_kernel<0, 13>'
+    assert torch.equal(y1.buf, y2.buf)
+    av = a.interior().reshape(B, H2, 2, W2, 2, N).permute(0, 1, 3, 2, 4, 5).reshape(B, H2, W2, 4, N)
+    want_sum = (av[..., 0, :] + av[..., 1, :]) + (av[..., 2, :] + av[..., 3, :])
+    assert torch.equal(asum.interior(), want_sum)
+    assert asum.border_abs_max() == 0.0
+    words = idx.view(B, H2 + 1, W2 + 1, N // 32, 4)[:, 1:, 1:]
+    shifts = torch.arange(32, device='cuda', dtype=torch.int32)
+    for k in range(4):
+        bits = ((words[..., k].unsqueeze(-1) >> shifts) & 1).reshape(B, H2, W2, N)
+        assert torch.equal(bits.bool(), av[..., k, :] > 0)
+    dz2 = Plane(B, H, W, N)
+    dz2.buf.fill_(7.0)
+    dz2.view()[:, 0].zero_(); dz2.view()[:, :, 0].zero_(); dz2.buf[:dz2.G * N].zero_(); dz2.buf[-dz2.G * N:].zero_()
+    s2 = [torch.zeros(N, device='cuda') for _ in range(3)]
+    ops.tap_gemm_gated_poolavg(bd, dzk, wtb, H, W, asum, idx, sc, sh, prev if acc else None, dz2, s2[0], s2[1], s2[2], ws)
+    assert ops.last_kernel() == 'wino11_kernel<1, 14>'
+    torch.cuda.synchronize()
+    assert torch.equal(dz1.interior(), dz2.interior())
+    assert float(dz2.view()[:, 0].abs().max()) == 0 and float(dz2.view()[:, :, 0].abs().max()) == 0
+    assert torch.equal(s1[1], s2[1]) and torch.equal(s1[2], s2[2])                      # dshift, dbias: the same sums in the same order
+    assert (s1[0].double() - s2[0].double()).abs().max().item() <= 1e-5 * max(1.0, s1[0].abs().max().item())
+
+
 @pytest.mark.parametrize("B,H,W,Cc,K", [(4, 40, 25, 256, 128), (2, 200, 25, 256, 128), (8, 50, 25, 64, 1536), (1, 200, 25, 128, 128)])
 def test_dense_data_gradient_with_the_cell_backward_in_its_epilogue(B, H, W, Cc, K):
     """asr_tap_gemm_gated_dense (round 5): the data-gradient of a dense layer fed by the flattened output of an un-pooled cell

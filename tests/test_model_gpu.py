@@ -211,3 +211,32 @@ def test_se_squeeze_made_by_the_branch_conv_gives_the_same_step():
     assert (l0 - l1).abs().max().item() < 1e-4
     assert (s0 - s1).abs().max().item() < 1e-4 * max(1.0, s0.abs().max().item())
     assert (g0 - g1).abs().max().item() < 1e-4 * max(1e-6, g0.abs().max().item())
+
+
+@pytest.mark.parametrize("model,widths", [('m2', (32, 64, 64, 64)), ('m1', (32, 64, 64, 64, 32, 32))])
+def test_compact_pool_forms_give_the_same_step(model, widths):
+    """compact_pool=True keeps no pre-pool activation plane for pooled Winograd cells (max pool: activation at the maximum + position;
+    average pool, round 5: activation sum + ReLU signs).  Logits, loss and every weight / bias gradient are the bits of the plane form;
+    the BN scale gradient of an AVERAGE-pooled cell is the same sum with one rounding per window instead of four (1e-6)."""
+    from asr_dfcnn_transformer_amd.engine import DFCNNEngine
+    rng = np.random.default_rng(13)
+    B, T, F, V = 2, 64, 200, 20
+    x = torch.tensor(rng.standard_normal((B, T, F)).astype(np.float32), device='cuda')
+    tgt = np.zeros((B, 64), dtype=np.int32); tgt[:, :3] = rng.integers(1, V - 1, (B, 3))
+    out = []
+    for flag in (True, False):
+        eng = DFCNNEngine(model=model, vocab=V, B=B, T=T, F=F, widths=widths, seed=2, compact_pool=flag)
+        assert len(eng.compact) == (2 if flag else 0)
+        logits = eng.forward(x).clone()
+        eng.set_targets([8, 8], tgt); eng.loss_and_decode(); eng.backward()
+        torch.cuda.synchronize()
+        out.append((logits, eng.grad.clone(), eng))
+    (l0, g0, e), (l1, g1, _) = out
+    assert torch.equal(l0, l1)
+    for (layer, key), (off, shape) in e.entries.items():
+        n = int(np.prod(shape))
+        a, b = g0[off:off + n], g1[off:off + n]
+        if key == 'gamma' and model == 'm2':
+            assert (a - b).abs().max().item() <= 1e-6 * max(1e-6, b.abs().max().item()), (layer, key)
+        else:
+            assert torch.equal(a, b), (layer, key)
