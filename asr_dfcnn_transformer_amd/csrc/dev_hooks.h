@@ -1,6 +1,7 @@
 // Development hooks of the Winograd kernels.  The PRODUCT build (asr_dfcnn_transformer_amd/_build.py) never defines
 // ASR_DEV_HOOKS and therefore never includes this file; tools/trace_wino11.sh and tools/ablate_wino_wgrad.sh do.
 //   wino.hip        -DASR_DEV_HOOKS -DW11_TRACE [-DW11_TRACE_WG=<workgroup>]   in-kernel phase stamps of wino11_kernel
+//   wino.hip        -DASR_DEV_HOOKS -DW11_ONE_PER_CU   one persistent workgroup per CU instead of two (launcher only)
 //   wino_wgrad.hip  -DASR_DEV_HOOKS -DWW_ABL=<mask> (1: no DMA -- results wrong by construction, timing only)
 //                   -DWW_SLOT(i)=<expr>  where a DMA piece goes between the eight MFMAs of a tile pair
 #pragma once

@@ -1400,8 +1400,14 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
         a.ntm = nblk11; a.ntn = d->N / W11_C;
         if (a.gate_rows) *a.gate_rows = nblk11 * 8;
         const long nwork11 = (long)nblk11 * a.ntn;
+#if defined(ASR_DEV_HOOKS) && defined(W11_ONE_PER_CU)      // development probe (tools/build_variant.sh one wino.hip -DASR_DEV_HOOKS -DW11_ONE_PER_CU): ONE workgroup per CU,
+                                                           // the LDS request padded so that two cannot share one (profiles/r05_wino11_one_wg_probe.txt)
+        const int grid11 = nwork11 > (long)ncu8 ? ncu8 : (int)nwork11;
+        const size_t lds11 = 82 * 1024;
+#else
         const int grid11 = nwork11 > 2L * ncu8 ? 2 * ncu8 : (int)nwork11;     // persistent: two workgroups per CU
         const size_t lds11 = (size_t)(2 * W11_TABF + 4 * W11_SETF + (pool_y ? 3 * d->N : 0)) * sizeof(float);
+#endif
         static_assert(4096 <= W11_SETF && 4 * 32 * 33 <= W11_SETF, "exchange phase / four transpose scratches must fit in one buffer set");
         // the epilogue instantiation (wino11_body): decided by the descriptor
         int epi = W11_EPI_GENERIC;
@@ -1423,7 +1429,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
         const w11_fn fn = epi ? fns[epi] : (d->wmode ? (w11_fn)wino11_kernel<1, 0> : (w11_fn)wino11_kernel<0, 0>);
         static bool attr[16] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};
         const int slot = epi ? (epi >= W11_EPI_FWD_SUM ? epi + 1 : epi) : (d->wmode ? 11 : 0);
-        if (!attr[slot]) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr[slot] = true; }
+        if (!attr[slot]) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024); attr[slot] = true; }
         hipLaunchKernelGGL(fn, dim3(grid11), dim3(512), lds11, st, w);
         ASR_CHECK_LAUNCH("tap_gemm_wino11");
         static const char* const names[16] = {"wino11_kernel<0, 0>", "wino11_kernel<0, 1>", "wino11_kernel<0, 2>", "wino11_kernel<0, 3>", "wino11_kernel<1, 4>",

@@ -455,6 +455,7 @@ class DFCNNEngine:
                 if ops.tap_gemm_gated_dense_supported(self.bdesc[op[2]], Hc, Wc, cell[4]):
                     self.dense_gate[op[2]] = cell
                     self.ws_gate = max(self.ws_gate, ops.tap_gemm_gated_dense_workspace(self.bdesc[op[2]], Wc, cell[4]))
+                    self.dflat[op[1]] = None          # dL/d(flat) of that cell is never materialised (the key stays: "feeds a dense layer")
         # SE blocks whose branch is a non-pooled Winograd cell that only the block reads: the cell's forward launch also writes the
         # per-image channel sums of its output (asr_tap_gemm_wino_sums), the block's squeeze takes them (asr_se_fwd_sums) instead of a
         # pass of its own over the plane.  {branch cell -> (SE block, partial rows buffer, rows per image)}
