@@ -873,22 +873,25 @@ __device__ __forceinline__ void wino11_epilogue_gated(R rGA, R rGD, R rY, R rGI,
                 w11_store4_nt(rGD, off[k], d[0], d[1], d[2], d[3]);
             }
         } else if (GM == 4) {
+            // Exactly one window position receives the gradient.  GM 3 walks the four positions and adds the three zeros as well; adding
+            // +0 and fma(0, ., s) leave a sum as it is, so doing the winner's arithmetic ONCE gives the same bits with a quarter of the
+            // vector instructions (round 5: the kernels are bound by vector instructions per MFMA) -- only the
+            // four stores still look at the position.
             const int cb = n & 31;
+            unsigned pos[4];
+            float dd[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float d[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ag = (int)((iw0 >> (cb + e)) & 1u) | (int)(((iw1 >> (cb + e)) & 1u) << 1);
-                    const bool here = ag == k;
-                    const float gk = here ? v[e] : 0.f;
-                    s_shift[e] += gk;
-                    s_scale[e] = fmaf(gk, here ? av[0][e] : 0.f, s_scale[e]);
-                    d[e] = (here && av[0][e] > 0.f) ? gk * scv[e] : 0.f;
-                    s_bias[e] += d[e];
-                }
-                w11_store4_nt(rGD, off[k], d[0], d[1], d[2], d[3]);
+            for (int e = 0; e < 4; ++e) {
+                pos[e] = ((iw0 >> (cb + e)) & 1u) | (((iw1 >> (cb + e)) & 1u) << 1);
+                s_shift[e] += v[e];
+                s_scale[e] = fmaf(v[e], av[0][e], s_scale[e]);
+                dd[e] = av[0][e] > 0.f ? v[e] * scv[e] : 0.f;
+                s_bias[e] += dd[e];
             }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                w11_store4_nt(rGD, off[k], pos[0] == (unsigned)k ? dd[0] : 0.f, pos[1] == (unsigned)k ? dd[1] : 0.f, pos[2] == (unsigned)k ? dd[2] : 0.f,
+                              pos[3] == (unsigned)k ? dd[3] : 0.f);
         } else {
             int arg[4];
             if (GM == 3) {
@@ -1180,15 +1183,18 @@ __device__ __forceinline__ void wino11_body(float* smem) {
                         const float x0 = fmaxf(out[0][0][i] + bs, 0.f), x1 = fmaxf(out[0][0][4 + i] + bs, 0.f);
                         const float x2 = fmaxf(out[0][0][8 + i] + bs, 0.f), x3 = fmaxf(out[0][0][12 + i] + bs, 0.f);
                         const float v0 = fmaf(scv, x0, shv), v1 = fmaf(scv, x1, shv), v2 = fmaf(scv, x2, shv), v3 = fmaf(scv, x3, shv);
-                        float m = v0, am = x0; int ag = 0;
-                        const bool c1 = v1 > m; m = c1 ? v1 : m; am = c1 ? x1 : am; ag = c1 ? 1 : ag;
-                        asm volatile("" : "+v"(am), "+v"(ag));
-                        const bool c2 = v2 > m; m = c2 ? v2 : m; am = c2 ? x2 : am; ag = c2 ? 2 : ag;
-                        asm volatile("" : "+v"(am), "+v"(ag));
-                        const bool c3 = v3 > m; m = c3 ? v3 : m; am = c3 ? x3 : am; ag = c3 ? 3 : ag;
+                        // first maximum in row-major window order; its position as two lane masks combined on the SCALAR unit
+                        // (position & 1 = c3 | (c1 & ~c2), position >> 1 = c3 | c2): the compare results are the ballots
+                        const bool c1 = v1 > v0;
+                        const float m1 = c1 ? v1 : v0, a1 = c1 ? x1 : x0;
+                        const bool c2 = v2 > m1;
+                        const float m2 = c2 ? v2 : m1, a2 = c2 ? x2 : a1;
+                        const bool c3 = v3 > m2;
+                        const float m = c3 ? v3 : m2, am = c3 ? x3 : a2;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rP, po[i], 0, 2);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(am), rPA, po[i], 0, 2);
-                        const unsigned long long b0 = __ballot(ag & 1), b1 = __ballot(ag >> 1);
+                        const unsigned long long k1 = __ballot(c1), k2 = __ballot(c2), k3 = __ballot(c3);
+                        const unsigned long long b0 = k3 | (k1 & ~k2), b1 = k3 | k2;
                         const unsigned w0 = lh ? (unsigned)(b0 >> 32) : (unsigned)b0, w1 = lh ? (unsigned)(b1 >> 32) : (unsigned)b1;
                         const int pr = prow[wave * 32 + i + 4 * lh];
                         const unsigned io = (pr >= 0 && li == 0) ? __umul24((unsigned)pr, nb8) + cb8 : W11_OOR;
