@@ -133,9 +133,9 @@ __device__ __forceinline__ void g1_chunk(const float* __restrict__ set, float* _
 // NB = 2: 128 x 128 tile, two workgroups per CU.  NB = 1: 128 x 64 tile (waves 2 x 2 of 64 x 32), 49 KB of LDS, three
 // workgroups per CU -- for the problems whose 128 x 128 grid is not a whole number of rounds over 512 slots (the launcher's
 // rule); every output element sums its K products in the same order in both, so the choice changes no bit.
-template <int DIR, int NB>
-__global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void gemm1_kernel(Gemm1Args args) {
 #if __HIP_DEVICE_COMPILE__
+template <int NB, bool GD>
+__device__ __forceinline__ void gemm1_body(const Gemm1Args& args) {
     const TapGemmArgs& g = args.g;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int* rowa = (int*)smem;                              // [128] output row of out_a (or -1), [128] of out_y
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void gemm1_kernel(Gemm1Args a
         const long p = (long)m0 + tid;
         int ra = -1, ry = -1;
         if (p < g.M) {
-            if (g.gate_mode == 5) {
+            if (GD) {
                 // dense-layout gate: GEMM row = image b, pixel row h of the gated cell; the table holds its plane pixel at column 1
                 const int b = (int)(p / g.gate_H), h = (int)(p - (long)b * g.gate_H);
                 ra = (b * (g.gate_H + 1) + h + 1) * (g.gate_W + 1) + 1; ry = ra;
@@ -234,9 +234,28 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void gemm1_kernel(Gemm1Args a
     if (kc < nkc) { dma_barrier(); g1_chunk<2, NB>(set0, set1, rsa, rsb, q, kc, nkc, ktail, arow, brow, xo, acc); ++kc; }
 
     __syncthreads();                                     // the tiles are dead: their space is the epilogue's scratch
-    tap_epilogue<2, NB>(g, acc, bufs + wave * (32 * 33), rowa, rowy, wm * 64, n0 + wn * (32 * NB), lane, tile_m * 2 + wm);
+    if (GD) tap_epilogue_gated<2, NB, true>(g, acc, bufs + wave * (32 * 33), rowa, rowy, wm * 64, n0 + wn * (32 * NB), lane, tile_m * 2 + wm);
+    else tap_epilogue<2, NB>(g, acc, bufs + wave * (32 * 33), rowa, rowy, wm * 64, n0 + wn * (32 * NB), lane, tile_m * 2 + wm);
+}
+#endif
+
+template <int DIR, int NB>
+__global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void gemm1_kernel(Gemm1Args args) {
+#if __HIP_DEVICE_COMPILE__
+    gemm1_body<NB, false>(args);
 #endif
 }
+
+// the data-gradient of a dense head with the backward prologue of the cell in front in its epilogue (gate mode 5, asr_tap_gemm_gated_dense):
+// a symbol of its own, so that gemm1_kernel's code does not carry the mode
+template <int NB>
+__global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void gemm1_dense_gate_kernel(Gemm1Args args) {
+#if __HIP_DEVICE_COMPILE__
+    gemm1_body<NB, true>(args);
+#endif
+}
+
+
 
 // ---- dense weight gradient, "TN" form:  dW[k][n] = sum_m A[m][k] * dZ[m][n]  (tf.layers.dense backward, and the 1x1 conv's)
 // Same machinery as gemm1_kernel -- buffer-form LDS-DMA into two run buffers, pieces between the MFMAs, one barrier per run,
@@ -451,10 +470,11 @@ int asr_gemm1_launch(const asr_gemm_desc* d, const float* A, const float* Bt, in
     const size_t lds = (size_t)(256 + 2 * (G1_TILE_F + nb * 64 * G1_KC)) * sizeof(float);
     static_assert(4 * 32 * 33 <= 2 * (G1_TILE_F + 64 * G1_KC), "epilogue scratch fits the tile buffers");
     typedef void (*kern_t)(Gemm1Args);
-    static const kern_t kerns[4] = {gemm1_kernel<0, 1>, gemm1_kernel<0, 2>, gemm1_kernel<1, 1>, gemm1_kernel<1, 2>};
-    static const char* const names[4] = {"gemm1_kernel<0, 1>", "gemm1_kernel<0, 2>", "gemm1_kernel<1, 1>", "gemm1_kernel<1, 2>"};
-    static bool attr[4] = {false, false, false, false};
-    const int ki = (dir ? 2 : 0) + (nb - 1);
+    static const kern_t kerns[6] = {gemm1_kernel<0, 1>, gemm1_kernel<0, 2>, gemm1_kernel<1, 1>, gemm1_kernel<1, 2>, gemm1_dense_gate_kernel<1>, gemm1_dense_gate_kernel<2>};
+    static const char* const names[6] = {"gemm1_kernel<0, 1>", "gemm1_kernel<0, 2>", "gemm1_kernel<1, 1>", "gemm1_kernel<1, 2>", "gemm1_dense_gate_kernel<1>",
+                                         "gemm1_dense_gate_kernel<2>"};
+    static bool attr[6] = {false, false, false, false, false, false};
+    const int ki = (gate && gate->mode == 5) ? 4 + (nb - 1) : (dir ? 2 : 0) + (nb - 1);
     if (!attr[ki]) { (void)hipFuncSetAttribute((const void*)kerns[ki], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[ki] = true; }
     hipLaunchKernelGGL(kerns[ki], dim3(a.ntm * a.ntn), dim3(256), lds, (hipStream_t)stream, ga);
     asr_set_last_kernel(names[ki]);

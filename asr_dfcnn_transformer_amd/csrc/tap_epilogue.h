@@ -72,12 +72,14 @@ __device__ __forceinline__ float gate_pick(float y0, float y1, float y2, float y
 // a quarter of it to each of four / all of it to the first maximum of scale * a + shift), dZ_k = g_k * scale where
 // a_k > 0, plus the three per-channel sums of asr_cell_bwd_pre -- whose arithmetic this restates -- reduced over the
 // wave's rows in a fixed order and written as one partial row per (tile row, wave row).
-template <int TM, int TN>
+// DENSE (gate mode 5, asr_tap_gemm_gated_dense) is a template parameter -- only gemm1_dense_gate_kernel instantiates it --, so that the
+// code of every other kernel that carries this epilogue is what it was before the mode existed.
+template <int TM, int TN, bool DENSE = false>
 __device__ __forceinline__ void tap_epilogue_gated(const TapGemmArgs& g, const floatx16 (&acc)[TM][TN], float* scratch,
                                                    const int* rowa, int* rowf, int row0, int col0, int lane, int part_row) {
     const int li = lane & 31, lh = lane >> 5;
     const int c4 = lane & 7, rsub = lane >> 3;
-    const bool dense = g.gate_mode == 5;          // rowa[m] = the plane pixel of GEMM row m at pixel column 0 (the kernel's row table)
+    constexpr bool dense = DENSE;                 // rowa[m] = the plane pixel of GEMM row m at pixel column 0 (the kernel's row table)
     const int C = dense ? g.gate_C : g.N;
     const int WPf = g.gate_W + 1;
     if (g.gate_mode >= 2 && !dense) {

@@ -873,25 +873,22 @@ __device__ __forceinline__ void wino11_epilogue_gated(R rGA, R rGD, R rY, R rGI,
                 w11_store4_nt(rGD, off[k], d[0], d[1], d[2], d[3]);
             }
         } else if (GM == 4) {
-            // Exactly one window position receives the gradient.  GM 3 walks the four positions and adds the three zeros as well; adding
-            // +0 and fma(0, ., s) leave a sum as it is, so doing the winner's arithmetic ONCE gives the same bits with a quarter of the
-            // vector instructions (round 5: the kernels are bound by vector instructions per MFMA) -- only the
-            // four stores still look at the position.
             const int cb = n & 31;
-            unsigned pos[4];
-            float dd[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                pos[e] = ((iw0 >> (cb + e)) & 1u) | (((iw1 >> (cb + e)) & 1u) << 1);
-                s_shift[e] += v[e];
-                s_scale[e] = fmaf(v[e], av[0][e], s_scale[e]);
-                dd[e] = av[0][e] > 0.f ? v[e] * scv[e] : 0.f;
-                s_bias[e] += dd[e];
+            for (int k = 0; k < 4; ++k) {
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ag = (int)((iw0 >> (cb + e)) & 1u) | (int)(((iw1 >> (cb + e)) & 1u) << 1);
+                    const bool here = ag == k;
+                    const float gk = here ? v[e] : 0.f;
+                    s_shift[e] += gk;
+                    s_scale[e] = fmaf(gk, here ? av[0][e] : 0.f, s_scale[e]);
+                    d[e] = (here && av[0][e] > 0.f) ? gk * scv[e] : 0.f;
+                    s_bias[e] += d[e];
+                }
+                w11_store4_nt(rGD, off[k], d[0], d[1], d[2], d[3]);
             }
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                w11_store4_nt(rGD, off[k], pos[0] == (unsigned)k ? dd[0] : 0.f, pos[1] == (unsigned)k ? dd[1] : 0.f, pos[2] == (unsigned)k ? dd[2] : 0.f,
-                              pos[3] == (unsigned)k ? dd[3] : 0.f);
         } else {
             int arg[4];
             if (GM == 3) {
@@ -1074,35 +1071,29 @@ __device__ __forceinline__ void wino11_body(float* smem) {
         float* ufree = bufs + (2 + (cur ^ 1)) * W11_SETF;
         float* xch = wm == 0 ? rfree : ufree;        // the four row waves of a tile half meet in one set (4096 floats per phase)
         floatx16 out[1][1];
-        // Exchange layout: [row wave 4][register quarter 4][lane 64][4 registers] -- a wave hands over its sixteen column sums of a
-        // phase with four ds_write_b128 and collects its quarter of the four rows with four ds_read_b128 (round 4: sixteen b32 each)
-        float4* xch4 = (float4*)xch;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             // column combination (M A)[row][j], lane-local, two registers per packed add
 #pragma unroll
-            for (int r = 0; r < 16; r += 4) {
+            for (int r = 0; r < 16; r += 2) {
                 const wn_f2 a0 = {acc[0][r], acc[0][r + 1]}, a1 = {acc[1][r], acc[1][r + 1]}, a2 = {acc[2][r], acc[2][r + 1]}, a3 = {acc[3][r], acc[3][r + 1]};
-                const wn_f2 b0 = {acc[0][r + 2], acc[0][r + 3]}, b1 = {acc[1][r + 2], acc[1][r + 3]}, b2 = {acc[2][r + 2], acc[2][r + 3]}, b3 = {acc[3][r + 2], acc[3][r + 3]};
                 const wn_f2 pj = j == 0 ? (a0 + a1) + a2 : (a1 - a2) - a3;
-                const wn_f2 qj = j == 0 ? (b0 + b1) + b2 : (b1 - b2) - b3;
-                xch4[(rr * 4 + (r >> 2)) * 64 + lane] = make_float4(pj.x, pj.y, qj.x, qj.y);
+                xch[(rr * 16 + r) * 64 + lane] = pj.x;
+                xch[(rr * 16 + r + 1) * 64 + lane] = pj.y;
             }
             if (j == 0) W11T(2);
             lds_barrier();
             if (j == 0) W11T(3);
             // row combination for this wave's register quarter: Y[i][j] = sum_r A^T[i][r] (M A)[r][j]
-            {
-                const float4 p0 = xch4[(0 * 4 + rr) * 64 + lane], p1 = xch4[(1 * 4 + rr) * 64 + lane];
-                const float4 p2 = xch4[(2 * 4 + rr) * 64 + lane], p3 = xch4[(3 * 4 + rr) * 64 + lane];
 #pragma unroll
-                for (int i = 0; i < 4; i += 2) {
-                    const wn_f2 q0 = i ? wn_f2{p0.z, p0.w} : wn_f2{p0.x, p0.y}, q1 = i ? wn_f2{p1.z, p1.w} : wn_f2{p1.x, p1.y};
-                    const wn_f2 q2 = i ? wn_f2{p2.z, p2.w} : wn_f2{p2.x, p2.y}, q3 = i ? wn_f2{p3.z, p3.w} : wn_f2{p3.x, p3.y};
-                    const wn_f2 y0 = (q0 + q1) + q2, y1 = (q1 - q2) - q3;
-                    out[0][0][4 * (0 * 2 + j) + i] = y0.x; out[0][0][4 * (0 * 2 + j) + i + 1] = y0.y;
-                    out[0][0][4 * (1 * 2 + j) + i] = y1.x; out[0][0][4 * (1 * 2 + j) + i + 1] = y1.y;
-                }
+            for (int i = 0; i < 4; i += 2) {
+                const wn_f2 p0 = {xch[(0 * 16 + 4 * rr + i) * 64 + lane], xch[(0 * 16 + 4 * rr + i + 1) * 64 + lane]};
+                const wn_f2 p1 = {xch[(1 * 16 + 4 * rr + i) * 64 + lane], xch[(1 * 16 + 4 * rr + i + 1) * 64 + lane]};
+                const wn_f2 p2 = {xch[(2 * 16 + 4 * rr + i) * 64 + lane], xch[(2 * 16 + 4 * rr + i + 1) * 64 + lane]};
+                const wn_f2 p3 = {xch[(3 * 16 + 4 * rr + i) * 64 + lane], xch[(3 * 16 + 4 * rr + i + 1) * 64 + lane]};
+                const wn_f2 y0 = (p0 + p1) + p2, y1 = (p1 - p2) - p3;
+                out[0][0][4 * (0 * 2 + j) + i] = y0.x; out[0][0][4 * (0 * 2 + j) + i + 1] = y0.y;
+                out[0][0][4 * (1 * 2 + j) + i] = y1.x; out[0][0][4 * (1 * 2 + j) + i + 1] = y1.y;
             }
             lds_barrier();                           // the set is rewritten (phase 1) / becomes transpose scratch
         }
@@ -1183,18 +1174,15 @@ __device__ __forceinline__ void wino11_body(float* smem) {
                         const float x0 = fmaxf(out[0][0][i] + bs, 0.f), x1 = fmaxf(out[0][0][4 + i] + bs, 0.f);
                         const float x2 = fmaxf(out[0][0][8 + i] + bs, 0.f), x3 = fmaxf(out[0][0][12 + i] + bs, 0.f);
                         const float v0 = fmaf(scv, x0, shv), v1 = fmaf(scv, x1, shv), v2 = fmaf(scv, x2, shv), v3 = fmaf(scv, x3, shv);
-                        // first maximum in row-major window order; its position as two lane masks combined on the SCALAR unit
-                        // (position & 1 = c3 | (c1 & ~c2), position >> 1 = c3 | c2): the compare results are the ballots
-                        const bool c1 = v1 > v0;
-                        const float m1 = c1 ? v1 : v0, a1 = c1 ? x1 : x0;
-                        const bool c2 = v2 > m1;
-                        const float m2 = c2 ? v2 : m1, a2 = c2 ? x2 : a1;
-                        const bool c3 = v3 > m2;
-                        const float m = c3 ? v3 : m2, am = c3 ? x3 : a2;
+                        float m = v0, am = x0; int ag = 0;
+                        const bool c1 = v1 > m; m = c1 ? v1 : m; am = c1 ? x1 : am; ag = c1 ? 1 : ag;
+                        asm volatile("" : "+v"(am), "+v"(ag));
+                        const bool c2 = v2 > m; m = c2 ? v2 : m; am = c2 ? x2 : am; ag = c2 ? 2 : ag;
+                        asm volatile("" : "+v"(am), "+v"(ag));
+                        const bool c3 = v3 > m; m = c3 ? v3 : m; am = c3 ? x3 : am; ag = c3 ? 3 : ag;
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m), rP, po[i], 0, 2);
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(am), rPA, po[i], 0, 2);
-                        const unsigned long long k1 = __ballot(c1), k2 = __ballot(c2), k3 = __ballot(c3);
-                        const unsigned long long b0 = k3 | (k1 & ~k2), b1 = k3 | k2;
+                        const unsigned long long b0 = __ballot(ag & 1), b1 = __ballot(ag >> 1);
                         const unsigned w0 = lh ? (unsigned)(b0 >> 32) : (unsigned)b0, w1 = lh ? (unsigned)(b1 >> 32) : (unsigned)b1;
                         const int pr = prow[wave * 32 + i + 4 * lh];
                         const unsigned io = (pr >= 0 && li == 0) ? __umul24((unsigned)pr, nb8) + cb8 : W11_OOR;
@@ -1435,7 +1423,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
         const w11_fn fn = epi ? fns[epi] : (d->wmode ? (w11_fn)wino11_kernel<1, 0> : (w11_fn)wino11_kernel<0, 0>);
         static bool attr[16] = {false, false, false, false, false, false, false, false, false, false, false, false, false, false, false, false};
         const int slot = epi ? (epi >= W11_EPI_FWD_SUM ? epi + 1 : epi) : (d->wmode ? 11 : 0);
-        if (!attr[slot]) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 84 * 1024); attr[slot] = true; }
+        if (!attr[slot]) { (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds11 > 80 * 1024 ? (int)lds11 : 80 * 1024); attr[slot] = true; }
         hipLaunchKernelGGL(fn, dim3(grid11), dim3(512), lds11, st, w);
         ASR_CHECK_LAUNCH("tap_gemm_wino11");
         static const char* const names[16] = {"wino11_kernel<0, 0>", "wino11_kernel<0, 1>", "wino11_kernel<0, 2>", "wino11_kernel<0, 3>", "wino11_kernel<1, 4>",

@@ -202,7 +202,7 @@ __device__ __forceinline__ void ww4_compute(const WwArgs& a, const char* __restr
     // pipe busy; with the falling priority every wave takes 16 000-16 400.
     // (an odd block width: the last tiles of two neighbouring tile rows form one pair -- lane half = row; of the two waves that own
     // those rows the one whose class matches the stage parity takes it)
-    const int odd = ((w & 1) && (CINB == 64 || (wa & 1) == (parity & 1))) ? 1 : 0;
+    const int odd = ((w & 1) && (CINB == 64 || (NB == 64 ? wa : (wa & 1)) == (parity & 1))) ? 1 : 0;
     const int nst = (CINB == 64 ? 2 : 1) * ((np + 1) >> 1) + odd;
     const int t1 = (nst + 3) >> 2, t2 = (nst + 1) >> 1, t3 = (3 * nst + 3) >> 2;
     int kst = 0;
@@ -220,7 +220,7 @@ __device__ __forceinline__ void ww4_compute(const WwArgs& a, const char* __restr
         }
     if (odd) {
         prio();
-        const int r0 = CINB == 64 ? 0 : (wa & ~1);      // the row pair whose last tiles meet
+        const int r0 = NB == 64 ? 0 : (wa & ~1);        // the row pair whose last tiles meet (two-row stages: rows 0 and 1)
         step(xch + (r0 + lh) * (2 * C::XP * PXB) + (w - 1) * 2 * PXB, zch + (r0 + lh) * (2 * C::ZP * ZXB) + (w - 1) * 2 * ZXB, false);
     }
     // pieces the loop had no slot for (narrow blocks)
@@ -244,9 +244,9 @@ __device__ __forceinline__ void ww4_body(const WwArgs& a, float* smem) {
     auto rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, 0x7FFFFFF0, 0x00020000);
     auto rz = __builtin_amdgcn_make_buffer_rsrc((void*)a.Z, 0, 0x7FFFFFF0, 0x00020000);
     constexpr int LPPX = CINB / 4, LPPZ = NB / 4;               // lanes (16 bytes each) per staged pixel
-    const int pxx = lane / LPPX, pxz = lane / LPPZ;
+    const int pxx = lane / LPPX, pxz = lane >> (NB == 64 ? 4 : 3);
     const unsigned vox = (unsigned)((pxx * a.lda + (lane % LPPX) * 4) * 4);
-    const unsigned voz = (unsigned)((pxz * a.ldz + (lane % LPPZ) * 4) * 4);
+    const unsigned voz = (unsigned)((pxz * a.ldz + (lane & (LPPZ - 1)) * 4) * 4);
     constexpr int NJ = (C::NXP + C::NZP + 15) / 16;
 
     floatx16 acc[4];
@@ -272,7 +272,7 @@ __device__ __forceinline__ void ww4_body(const WwArgs& a, float* smem) {
         if (more) sn = ww_stage<C::TR>(a, gn);
         ww_barrier_dma();                            // this stage has landed; nobody reads the other set any more
         const char* xs = (const char*)(smem + cur * C::SETF);
-        ww4_compute<RR, CINB, NB>(a, xs, xs + C::XF * 4, smem + (cur ^ 1) * C::SETF, sn, more, rx, rz, s.w, s.row0 / (2 * C::TR), wave, wa, lh, xch, zch, cin0, co0,
+        ww4_compute<RR, CINB, NB>(a, xs, xs + C::XF * 4, smem + (cur ^ 1) * C::SETF, sn, more, rx, rz, s.w, C::TR == 2 ? s.row0 >> 2 : s.row0 >> 3, wave, wa, lh, xch, zch, cin0, co0,
                               vox, voz, pxx, pxz, acc);
         cur ^= 1;
         s = sn;
@@ -326,14 +326,17 @@ __global__ __launch_bounds__(1024, 4) void wino_wgrad4n32_kernel(WwArgs a) {
 // association, bitwise reproducible.  (The first form -- one thread per (k, n) walking all partials -- took 77 us per launch:
 // 32-512 workgroups of dependent loads for 64 MB.)
 constexpr int WW_RG = 16;            // groups of partials per workgroup
+template <int NBW>                   // output channels of a block = blockDim.x: 64, or 32 for the 32 x 32 configuration (four partials per workgroup)
 __global__ __launch_bounds__(64 * WW_RG) void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dW, int K, int N,
-                                                                         int cinb, int nparts, int nbp, int ncob, int nb, int nth) {
+                                                                         int cinb, int nparts, int nbp, int ncob) {
+    constexpr int nb = NBW;
+    const int nth = NBW == 32 ? 4 : (cinb == 64 ? 1 : 2);
     __shared__ float red[WW_RG][16][64];
     const int co = threadIdx.x, g = threadIdx.y;
     const int k = blockIdx.x / ncob, cob = blockIdx.x - k * ncob;
     const int cib = k / cinb, ci = k - cib * cinb;
     const int bp = cib * ncob + cob;
-    const long pstride = (long)16 * cinb * nb;        // blockDim.x = nb = output channels of a block (64 or 32), nth partials per workgroup
+    const long pstride = (long)16 * cinb * nb;
     const int PT = nparts * nth;                                  // partial (p, t) has index p * nth + t: (p * nbp + bp) * nth + t in memory
     const int lo = (int)((long)PT * g / WW_RG), hi = (int)((long)PT * (g + 1) / WW_RG);
     float m[16];
@@ -467,8 +470,10 @@ int asr_wino_wgrad_launch(const asr_gemm_desc* d, const float* A, const float* d
         ASR_NOTE_KERNEL("wino_wgrad4_kernel<32>");
     }
     ASR_CHECK_LAUNCH("wino_wgrad");
-    hipLaunchKernelGGL(wino_wgrad_reduce_kernel, dim3(d->K * p.ncob), dim3(p.nb, WW_RG), 0, st, partials, dW, d->K, d->N, p.cinb, p.nparts,
-                       p.nbp, p.ncob, p.nb, p.nth);
+    if (p.nb == 32)
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<32>, dim3(d->K * p.ncob), dim3(32, WW_RG), 0, st, partials, dW, d->K, d->N, p.cinb, p.nparts, p.nbp, p.ncob);
+    else
+        hipLaunchKernelGGL(wino_wgrad_reduce_kernel<64>, dim3(d->K * p.ncob), dim3(64, WW_RG), 0, st, partials, dW, d->K, d->N, p.cinb, p.nparts, p.nbp, p.ncob);
     ASR_CHECK_LAUNCH("wino_wgrad_reduce");
     return ASR_OK;
 }
