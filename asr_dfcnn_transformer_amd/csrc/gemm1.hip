@@ -463,7 +463,7 @@ int asr_gemm1_launch(const asr_gemm_desc* d, const float* A, const float* Bt, in
     a.ntm = asr_cdiv(d->M, 128); a.ntn = asr_cdiv(d->N, 64 * nb);
     if (gate) {
         a.gate_mode = gate->mode; a.gate_H = gate->H; a.gate_W = gate->W; a.gate_a = gate->a; a.gate_dz = gate->dz; a.gate_part = gate->part;
-        a.gate_C = gate->C;
+        if (gate->mode == 5) a.halo = gate->C;          // the gated cell's channels (TapGemmArgs: gate mode 5)
         if (gate->rows) *gate->rows = a.ntm * 2 * (gate->mode == 5 ? gate->W : 1);       // one partial row per (tile row, wave row[, pixel column])
     }
     ga.Bt = Bt; ga.ldb = ldb;

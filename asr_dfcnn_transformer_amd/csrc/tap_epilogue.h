@@ -33,7 +33,8 @@ struct TapGemmArgs {
     int ksplit = 1;
     float* split_out = nullptr;
     int nt_store = 0;    // non-temporal stores in the plain epilogue (the Winograd launches set it)
-    int gate_C = 0;      // gate mode 5: channels of the gated cell (the GEMM is gate_W * gate_C columns wide)
+    // (gate mode 5 keeps the gated cell's channel count in `halo`, which a 1-tap GEMM does not use: the block stays what it was in round 4,
+    //  so that no kernel's argument loads change -- DESIGN.md section 4 item 26)
 };
 
 // Row offset of tap `tap` in the flattened padded plane, and the tap of the weight tensor it multiplies.
@@ -80,7 +81,7 @@ __device__ __forceinline__ void tap_epilogue_gated(const TapGemmArgs& g, const f
     const int li = lane & 31, lh = lane >> 5;
     const int c4 = lane & 7, rsub = lane >> 3;
     constexpr bool dense = DENSE;                 // rowa[m] = the plane pixel of GEMM row m at pixel column 0 (the kernel's row table)
-    const int C = dense ? g.gate_C : g.N;
+    const int C = dense ? g.halo : g.N;
     const int WPf = g.gate_W + 1;
     if (g.gate_mode >= 2 && !dense) {
         // full-resolution pixel of window position 0 for each of this wave's rows (wave-private slice of the table)
@@ -120,7 +121,7 @@ __device__ __forceinline__ void tap_epilogue_gated(const TapGemmArgs& g, const f
             for (int it = 0; it < 4; ++it) {
                 const int row = it * 8 + rsub;
                 const int m = row0 + a * 32 + row;
-                const int ra = rowa[m] < 0 ? -1 : rowa[m] + wq;
+                const int ra = dense ? (rowa[m] < 0 ? -1 : rowa[m] + wq) : rowa[m];
                 const float* sp = scratch + row * 33 + c4 * 4;
                 float v[4] = {sp[0], sp[1], sp[2], sp[3]};
                 if (ra < 0 || !ncol) continue;

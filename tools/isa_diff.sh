@@ -11,7 +11,7 @@ mkdir -p $tmp/old && git archive $commit asr_dfcnn_transformer_amd/csrc include 
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S $tmp/old/asr_dfcnn_transformer_amd/csrc/$f -o $tmp/old.s 2>/dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -S asr_dfcnn_transformer_amd/csrc/$f -o $tmp/new.s 2>/dev/null
 for k in $(grep -oE "^_Z[A-Za-z0-9_]+" $tmp/old.s $tmp/new.s | sed 's/.*://' | sort -u | grep -E "$pat"); do
-  for v in old new; do awk -v K="$k" 'index($0,K":")==1{f=1} f{print} /s_endpgm/{if(f)exit}' $tmp/$v.s | grep -v "^\s*;" | sed 's/;.*//' > $tmp/k_$v.s; done
+  for v in old new; do awk -v K="$k" 'index($0,K":")==1{f=1} f{print} /s_endpgm/{if(f)exit}' $tmp/$v.s | grep -v "^\s*;" | sed 's/;.*//; s/\.LBB[0-9]*_/.LBB_/g; s/\.Ltmp[0-9]*/.Ltmp/g' > $tmp/k_$v.s; done
   lo=$(wc -l < $tmp/k_old.s); ln=$(wc -l < $tmp/k_new.s)
   if [ "$lo" = "0" ]; then echo "NEW      $k ($ln lines)"; elif [ "$ln" = "0" ]; then echo "GONE     $k"; else
     d=$(diff $tmp/k_old.s $tmp/k_new.s | grep -c "^[<>]" || true); [ "$d" = "0" ] && echo "same     $k ($lo lines)" || echo "DIFFERS  $k ($lo -> $ln lines, $d changed)"; fi
