@@ -93,6 +93,20 @@ __global__ __launch_bounds__(256) void ctc_rows_kernel(const float* __restrict__
     for (int k = lane; k < V; k += 64) gr[k] = expf(x[k] - lf);
 }
 
+// value of the lane below / above across the whole wave (lane 0 / lane 63: zero) by DPP wave shifts, two 32-bit moves per double
+__device__ __forceinline__ double wave_shr1_d(double x) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const int l = __builtin_amdgcn_update_dpp(0, (int)lo, 0x138, 0xF, 0xF, false);      // wave_shr:1
+    const int h = __builtin_amdgcn_update_dpp(0, (int)hi, 0x138, 0xF, 0xF, false);
+    return __hiloint2double(h, l);
+}
+__device__ __forceinline__ double wave_shl1_d(double x) {
+    const unsigned lo = (unsigned)__double2loint(x), hi = (unsigned)__double2hiint(x);
+    const int l = __builtin_amdgcn_update_dpp(0, (int)lo, 0x130, 0xF, 0xF, false);      // wave_shl:1
+    const int h = __builtin_amdgcn_update_dpp(0, (int)hi, 0x130, 0xF, 0xF, false);
+    return __hiloint2double(h, l);
+}
+
 // One workgroup of 512 threads per utterance.  Phase 1: threads 0-255 run the alpha recursion while threads
 // 256-511 run the beta recursion (thread s / s-256 owns lattice state s), one barrier per time step, both
 // lattices go to the float64 workspace.  Phase 2 has no sequential dependency: the eight waves walk the time
@@ -236,15 +250,15 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
                     double nv[NPL];
                     if (fwd) {
                         // neighbours below: states s0 - 1, s0 - 2 live in lane - 1 (its v[3], v[2]); lane 0 has none
-                        double m1 = __shfl_up(v[NPL - 1], 1, 64), m2 = __shfl_up(v[NPL - 2], 1, 64);
-                        if (ln == 0) { m1 = 0.0; m2 = 0.0; }
+                        // (DPP wave shifts -- lane i takes lane i - 1's value, lane 0 the zero -- instead of ds_bpermute round trips: the
+                        //  shift sits on the recursion's serial path, once per frame)
+                        const double m1 = wave_shr1_d(v[NPL - 1]), m2 = wave_shr1_d(v[NPL - 2]);
                         nv[0] = ((v[0] + m1) + (sk[0] ? m2 : 0.0)) * inv * pr[u][0];
                         nv[1] = ((v[1] + v[0]) + (sk[1] ? m1 : 0.0)) * inv * pr[u][1];
                         nv[2] = ((v[2] + v[1]) + (sk[2] ? v[0] : 0.0)) * inv * pr[u][2];
                         nv[3] = ((v[3] + v[2]) + (sk[3] ? v[1] : 0.0)) * inv * pr[u][3];
                     } else {
-                        double p1 = __shfl_down(v[0], 1, 64), p2 = __shfl_down(v[1], 1, 64);
-                        if (ln == 63) { p1 = 0.0; p2 = 0.0; }
+                        const double p1 = wave_shl1_d(v[0]), p2 = wave_shl1_d(v[1]);
                         nv[3] = ((v[3] + p1) + (sk[3] ? p2 : 0.0)) * inv * pr[u][3];
                         nv[2] = ((v[2] + v[3]) + (sk[2] ? p1 : 0.0)) * inv * pr[u][2];
                         nv[1] = ((v[1] + v[2]) + (sk[1] ? v[3] : 0.0)) * inv * pr[u][1];
