@@ -68,6 +68,56 @@ static __global__ __launch_bounds__(256) void colsum_tall_kernel(const float* __
     }
 }
 
+// Wide matrices with a few thousand rows (the bias gradient of a [6400][1536] head, of [32768][2048] feed-forward layers): too
+// wide for the tall form, and the column-per-thread pass runs them on a handful of waves per CU with one 4-byte load per row in
+// flight (35 us for 39 MB).  Here a workgroup owns a strip of 64 columns x one row split: sixteen threads cover the strip's 256
+// bytes of a row, sixteen row lanes stride over the split's rows with four independent float4 chains; the row lanes are folded
+// through LDS in a fixed order.  Split partials go to the two-level pass's second level.
+constexpr int kStripMinRows = 1024;
+
+inline bool colsum_is_strip(int rows, int cols) { return rows >= kStripMinRows && (cols & 63) == 0 && !colsum_is_tall(rows, cols); }
+inline int colsum_strip_splits(int rows, int cols) {
+    int ns = 2048 / (cols / 64);
+    if (ns > kSplits) ns = kSplits;
+    if (ns > rows / 64) ns = rows / 64;
+    return ns < 1 ? 1 : ns;
+}
+
+static __global__ __launch_bounds__(256) void colsum_strip_kernel(const float* __restrict__ x, int rows, int cols, long ldx,
+                                                                  int rows_per_split, float* __restrict__ partial) {
+    __shared__ float red[16 * 64];
+    const int ct = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const float* xc = x + blockIdx.x * 64 + ct * 4;
+    const int r0 = blockIdx.y * rows_per_split;
+    int r1 = r0 + rows_per_split;
+    if (r1 > rows) r1 = rows;
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+    int r = r0 + rl;
+    for (; r + 48 < r1; r += 64) {
+        const float4 a = *(const float4*)(xc + (long)r * ldx);
+        const float4 b = *(const float4*)(xc + (long)(r + 16) * ldx);
+        const float4 c = *(const float4*)(xc + (long)(r + 32) * ldx);
+        const float4 d = *(const float4*)(xc + (long)(r + 48) * ldx);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+        s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+    }
+    for (; r < r1; r += 16) {
+        const float4 a = *(const float4*)(xc + (long)r * ldx);
+        s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+    *(float4*)(red + rl * 64 + ct * 4) = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y),
+                                                     (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k * 64 + threadIdx.x];
+        partial[(long)blockIdx.y * cols + blockIdx.x * 64 + threadIdx.x] = t;
+    }
+}
+
 inline size_t colsum_tmp_floats(int rows, int cols) {
     if (colsum_is_tall(rows, cols)) return (size_t)(colsum_tall_blocks(rows, cols) + kSplits) * cols;
     return rows > kSplits ? (size_t)kSplits * cols : 4;
@@ -77,13 +127,19 @@ inline size_t colsum_tmp_floats(int rows, int cols) {
 inline int colsum(const float* x, int rows, int cols, long ldx, float* out, float* tmp, hipStream_t st) {
     const int threads = 256;
     const int gx = asr_cdiv(cols, threads);
+    const bool strip = colsum_is_strip(rows, cols) && (ldx & 3) == 0 && (((uintptr_t)x) & 15) == 0 && tmp;
     if (colsum_is_tall(rows, cols) && (ldx & 3) == 0 && (((uintptr_t)x) & 15) == 0 && tmp) {
         const int nb = colsum_tall_blocks(rows, cols);
         float* part = tmp + (size_t)kSplits * cols;
         hipLaunchKernelGGL(colsum_tall_kernel, dim3(nb), dim3(256), 0, st, x, rows, cols, ldx, part);
         x = part; rows = nb; ldx = cols;
     }
-    if (rows <= kSplits) {
+    if (strip) {
+        const int rps = asr_cdiv(rows, colsum_strip_splits(rows, cols));
+        const int ns = asr_cdiv(rows, rps);
+        hipLaunchKernelGGL(colsum_strip_kernel, dim3(cols / 64, ns), dim3(256), 0, st, x, rows, cols, ldx, rps, tmp);
+        hipLaunchKernelGGL(colsum_pass_kernel, dim3(gx, 1), dim3(threads), 0, st, (const float*)tmp, ns, cols, (long)cols, ns, out, (long)cols);
+    } else if (rows <= kSplits) {
         hipLaunchKernelGGL(colsum_pass_kernel, dim3(gx, 1), dim3(threads), 0, st, x, rows, cols, ldx, rows, out, (long)cols);
     } else {
         const int rps = asr_cdiv(rows, kSplits);
