@@ -5,6 +5,7 @@
 // reductions, no MFMA.
 #include "asr_common.h"
 #include <math.h>
+#include <type_traits>
 
 namespace {
 
@@ -136,11 +137,26 @@ __global__ void ctc_check_kernel(const int32_t* __restrict__ labels, int max_lab
     status[b] = bad;
 }
 
-// one wave per (t,b) row: lse of the row (TF's own log-softmax) and the dense part of the
-// gradient, softmax(logits); rows at t >= seq_len or of infeasible utterances are zero.
+// one wave per (t,b) row: lse of the row (TF's own log-softmax), the dense part of the gradient, softmax(logits), and the emission
+// probabilities of the utterance's lattice states p_t(s) = exp(logit[ext(s)] - lse) in float64 (ext = blank, l1, blank, l2, ...: two
+// exps per lane here instead of eighteen per thread in front of the lattice's serial part); rows at t >= seq_len or of infeasible
+// utterances are zero.  prob rows: [b][t][SW].
+__device__ __forceinline__ void ctc_row_probs(const float* __restrict__ x, double l, int b, int t, int T, int lane,
+                                               const int32_t* __restrict__ labels, int max_label, int L, int blank, int SW,
+                                               double* __restrict__ prob) {
+    const int S = 2 * L + 1;
+    double* pr = prob + ((long)b * T + t) * SW;
+    for (int q = lane; q < S; q += 64) {
+        const int e = (q & 1) ? labels[(long)b * max_label + (q >> 1)] : blank;
+        pr[q] = exp((double)x[e] - l);
+    }
+}
+
 __global__ __launch_bounds__(256) void ctc_rows_kernel(const float* __restrict__ logits, int T, int B, int V,
                                                        const int32_t* __restrict__ seq_len, const int32_t* __restrict__ status,
-                                                       double* __restrict__ lse, float* __restrict__ grad) {
+                                                       const int32_t* __restrict__ labels, int max_label,
+                                                       const int32_t* __restrict__ label_len, int blank, int SW,
+                                                       double* __restrict__ lse, float* __restrict__ grad, double* __restrict__ prob) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // row = t*B + b
     if (row >= T * B) return;
     const int lane = threadIdx.x & 63;
@@ -162,6 +178,52 @@ __global__ __launch_bounds__(256) void ctc_rows_kernel(const float* __restrict__
     if (lane == 0) lse[row] = l;
     const float lf = (float)l;
     for (int k = lane; k < V; k += 64) gr[k] = expf(x[k] - lf);
+    ctc_row_probs(x, l, b, t, T, lane, labels, max_label, label_len[b], blank, SW, prob);
+}
+
+// the same with the row in registers (V % 4 == 0, V <= 64 x 4 x NV): one 16-byte load per 16 bytes instead of three 4-byte loads
+template <int NV>
+__global__ __launch_bounds__(256) void ctc_rows_vec_kernel(const float* __restrict__ logits, int T, int B, int V,
+                                                           const int32_t* __restrict__ seq_len, const int32_t* __restrict__ status,
+                                                           const int32_t* __restrict__ labels, int max_label,
+                                                           const int32_t* __restrict__ label_len, int blank, int SW,
+                                                           double* __restrict__ lse, float* __restrict__ grad, double* __restrict__ prob) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);      // row = t*B + b
+    if (row >= T * B) return;
+    const int lane = threadIdx.x & 63;
+    const int t = row / B, b = row - t * B;
+    const int n4 = V >> 2;
+    float4* g4 = (float4*)(grad + (long)row * V);
+    if (status[b] != 0 || t >= seq_len[b]) {
+        for (int k4 = lane; k4 < n4; k4 += 64) g4[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 0) lse[row] = 0.0;
+        return;
+    }
+    const float* x = logits + (long)row * V;
+    const float4* x4 = (const float4*)x;
+    float4 v[NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k4 = lane + 64 * i;
+        v[i] = k4 < n4 ? x4[k4] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        m = fmaxf(fmaxf(m, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
+    }
+    m = asr_wave_max(m);
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        s += ((double)expf(v[i].x - m) + (double)expf(v[i].y - m)) + ((double)expf(v[i].z - m) + (double)expf(v[i].w - m));
+    s = asr_wave_sum_d(s);
+    const double l = (double)m + log(s);
+    if (lane == 0) lse[row] = l;
+    const float lf = (float)l;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k4 = lane + 64 * i;
+        if (k4 < n4) g4[k4] = make_float4(expf(v[i].x - lf), expf(v[i].y - lf), expf(v[i].z - lf), expf(v[i].w - lf));
+    }
+    ctc_row_probs(x, l, b, t, T, lane, labels, max_label, label_len[b], blank, SW, prob);
 }
 
 // value of the lane below / above across the whole wave (lane 0 / lane 63: zero) by DPP wave shifts, two 32-bit moves per double
@@ -178,10 +240,30 @@ __device__ __forceinline__ double wave_shl1_d(double x) {
     return __hiloint2double(h, l);
 }
 
-// One workgroup of 512 threads per utterance.  Phase 1: threads 0-255 run the alpha recursion while threads
-// 256-511 run the beta recursion (thread s / s-256 owns lattice state s), one barrier per time step, both
-// lattices go to the float64 workspace.  Phase 2 has no sequential dependency: the eight waves walk the time
-// steps in parallel, form the state occupancies exp(alpha+beta-lp-ll) and subtract their per-label sums from
+// Wave sums of TWO float64 values at once (all 64 lanes active; every lane gets both totals): four DPP butterfly steps inside the
+// rows of sixteen (quad_perm, row_half_mirror, row_mirror: no LDS crossbar round trip as ds_bpermute's, and the two chains fill
+// each other's wait states), then the four row totals through scalar registers.  A fixed order.
+template <int CTRL>
+__device__ __forceinline__ double dpp_perm_d(double x) {
+    const int l = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, true);
+    const int h = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, true);
+    return __hiloint2double(h, l);
+}
+__device__ __forceinline__ double readlane_d(double x, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+__device__ __forceinline__ void wave_sum2_d(double& a, double& b) {
+    a += dpp_perm_d<0xB1>(a); b += dpp_perm_d<0xB1>(b);        // quad_perm [1, 0, 3, 2]
+    a += dpp_perm_d<0x4E>(a); b += dpp_perm_d<0x4E>(b);        // quad_perm [2, 3, 0, 1]
+    a += dpp_perm_d<0x141>(a); b += dpp_perm_d<0x141>(b);      // row_half_mirror
+    a += dpp_perm_d<0x140>(a); b += dpp_perm_d<0x140>(b);      // row_mirror
+    a = (readlane_d(a, 0) + readlane_d(a, 16)) + (readlane_d(a, 32) + readlane_d(a, 48));
+    b = (readlane_d(b, 0) + readlane_d(b, 16)) + (readlane_d(b, 32) + readlane_d(b, 48));
+}
+
+// One workgroup of 512 threads per utterance.  Phase 1: wave 0 runs the alpha recursion while wave 1 runs the beta recursion,
+// both lattices go to the float64 workspace.  Phase 2 has no sequential dependency: the eight waves walk the time
+// steps in parallel, form the state occupancies and subtract their per-label sums from
 // the dense softmax term that ctc_rows_kernel already wrote.
 __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restrict__ logits, int T, int B, int V,
                                                           const int32_t* __restrict__ labels, int max_label,
@@ -190,7 +272,7 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
                                                           const int32_t* __restrict__ status, const double* __restrict__ lse,
                                                           double* __restrict__ alpha_ws, double* __restrict__ beta_ws,
                                                           double* __restrict__ prob_ws,
-                                                          float* __restrict__ loss, float* __restrict__ grad) {
+                                                          float* __restrict__ loss, float* __restrict__ grad, int p_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
     const int b = blockIdx.x, tid = threadIdx.x;
     if (status[b] != 0) {
@@ -204,18 +286,48 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
     double* abuf1 = abuf0 + SMAX + 4;
     double* bbuf0 = abuf1 + SMAX + 4;                   // beta ping/pong with two trailing zero sentinels
     double* bbuf1 = bbuf0 + SMAX + 4;
-    double* occ = bbuf1 + SMAX + 4;                     // [16 wave sums] + [8 waves][SMAX + 1]
+    double* occ = bbuf1 + SMAX + 4;                     // [16: the first four are zeros] + [8 waves][SMAX + 1]
     double* lse_t = occ + 16 + 8 * (SMAX + 1);          // [T]
-    double* sca = lse_t + T;                            // [T] cumulative log scale of alpha per frame
+    double* sca = lse_t + T;                            // [T] cumulative log scale of alpha per frame; later the frame's occupancy factor
     double* scb = sca + T;                              // [T] the same for beta
     double* llp = scb + T;                              // [1] log-likelihood
     int* ext = (int*)(llp + 2);                         // [SMAX + 1]
     int* nxt = ext + SMAX + 1;                          // [SMAX + 1] next state with the same label (or -1)
     int* lead = nxt + SMAX + 1;                         // [SMAX + 1] 1 = first odd state of its label
-    float* lg = (float*)(lead + SMAX + 1);              // [Tb][S] gathered lattice inputs
+    // When the utterance's lattice fits (p_cap doubles): its emission probabilities [Tb][SPL] in float64 (16-byte aligned rows of SPL =
+    // S rounded up to 4, + 4: zeros behind the last state).  The log-domain form puts the gathered lattice inputs [Tb][S] (float) here.
+    // (the offset is rounded, not the pointer: a pointer that went through an integer is a generic one, and its loads are flat loads that
+    //  share the vector-memory counter with the recursion's stores)
+    const int lg_off = (int)(((unsigned char*)(lead + SMAX + 1) - smraw + 15) & ~15);
+    float* lg = (float*)(smraw + lg_off);
+    double* pl = (double*)(smraw + lg_off);
+    const int SW = ((SMAX + 3) & ~3) + 4;               // row pitch of the float64 workspaces
+    const int SP = (S + 3) & ~3, SPL = SP + 4;
+    const bool plds = S <= 256 && (long)Tb * SPL <= (long)p_cap;
+    double* aw = alpha_ws + (long)b * T * SW;
+    double* bw = beta_ws + (long)b * T * SW;
+    double* pw = prob_ws + (long)b * T * SW;            // p_t(s), written by ctc_rows_kernel
 
     if (tid < S) ext[tid] = (tid & 1) ? labels[(long)b * max_label + (tid >> 1)] : blank;
     for (int t = tid; t < Tb; t += 512) lse_t[t] = lse[(long)t * B + b];
+    // ---- phase 0: the probabilities into LDS; the columns behind state S - 1 are zeros, so that the recursion below runs whole groups
+    // of four states without a test
+    if (plds) {
+        for (int i0 = tid; i0 < Tb * SPL; i0 += 512 * 8) {
+            double gv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 512;
+                const int t = i / SPL, q = i - t * SPL;
+                gv[u] = (i < Tb * SPL && q < S) ? pw[(long)t * SW + q] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 512;
+                if (i < Tb * SPL) pl[i] = gv[u];
+            }
+        }
+    }
     __syncthreads();
     int my = blank; bool skip_f = false, skip_b = false;
     if (s < S) {
@@ -232,7 +344,9 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
             nxt[s] = n; lead[s] = ld;
         }
     }
-    // gathered in batches of eight independent loads (one load per iteration left its whole latency exposed: 50 round trips)
+    // the lattice inputs as floats, for the log-domain form only: gathered in batches of eight independent loads (one load per iteration
+    // left its whole latency exposed: 50 round trips)
+    auto gather_lg = [&]() {
     for (int i0 = tid; i0 < Tb * S; i0 += 512 * 8) {
         float gv[8];
 #pragma unroll
@@ -247,18 +361,10 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
             if (i < Tb * S) lg[i] = gv[u];
         }
     }
+    };
     if (tid < 2) { abuf0[tid] = 0.0; abuf1[tid] = 0.0; }                 // linear domain: the sentinels are zeros
+    if (tid >= 64 && tid < 68) occ[tid - 64] = 0.0;                      // a block of four zeros (phase 1's idle lanes read it)
     if (tid >= 2 && tid < 4) { bbuf0[2 + S + tid - 2] = 0.0; bbuf1[2 + S + tid - 2] = 0.0; }
-    __syncthreads();
-
-    double* aw = alpha_ws + (long)b * T * SMAX;
-    double* bw = beta_ws + (long)b * T * SMAX;
-    double* pw = prob_ws + (long)b * T * SMAX;
-    // ---- phase 0: emission probabilities p_t(s) = exp(logit - lse) of the lattice states in float64, all threads
-    for (int i = tid; i < Tb * S; i += 512) {
-        const int t = i / S, q = i - t * S;
-        pw[(long)t * SMAX + q] = exp((double)lg[i] - lse_t[t]);
-    }
     __threadfence_block();
     __syncthreads();
     // ---- phase 1: alpha forward in time (wave 0), beta backward in time (wave 1), concurrently, in the LINEAR domain with
@@ -269,11 +375,117 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
     // Every RS frames the vector is divided by its sum and the log of the divisor is carried along: true alpha_t = stored
     // alpha_t * exp(sca[t]); between two rescalings a state loses at most RS emission factors.
     constexpr int RS = 16, NPL = 4, PD = 8;             // rescale period, states per lane, prefetch distance (frames)
-    const int wv = tid >> 6, ln = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63;
     const bool fast = S <= 64 * NPL;                    // the register-resident form holds 256 states; longer label rows go to the log-domain form
     int* badp = (int*)(llp + 1);
     if (tid == 0) *badp = fast ? 0 : 1;
-    if (fast && wv < 2) {
+    if (fast && plds && wv < 2) {
+        // p from LDS: a frame is two 16-byte LDS reads per lane (issued two frames ahead, two register sets used alternately), two
+        // 16-byte stores of the new vector, the shifts and twelve float64 operations -- no test, no address arithmetic beyond running
+        // offsets.  All 64 lanes run (the wave sums and the DPP shifts read every lane); the lanes behind the last state's run read a
+        // block of zeros and store nothing.  The beta wave stores q_t(s) = beta_t(s) / p_t(s) -- the sum BEFORE the multiplication by
+        // p_t(s) -- which is what the occupancy alpha_t(s) beta_t(s) / p_t(s) needs: phase 2 has no division.
+        const int s0 = ln * NPL;
+        const bool act = s0 < SPL;
+        auto run = [&](auto dir) {
+            constexpr bool fwd = decltype(dir)::value;
+            double* scl = fwd ? sca : scb;
+            bool sk[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const int q = s0 + j;
+                sk[j] = false;
+                if (q < S) {
+                    const int e = ext[q];
+                    sk[j] = fwd ? ((q >= 2) && (e != blank) && (e != ext[q - 2])) : ((q + 2 < S) && (e != blank) && (e != ext[q + 2]));
+                }
+            }
+            const int t0 = fwd ? 0 : Tb - 1;
+            const int dp = act ? (fwd ? SPL : -SPL) : 0, dx = fwd ? SW : -SW;
+            const double* pp = act ? pl + t0 * SPL + s0 : occ;          // occ[0..3]: zeros
+            double* xp = (fwd ? aw : bw) + (long)t0 * SW + s0;
+            double v[NPL], pa[NPL], pb[NPL];
+#pragma unroll
+            for (int j = 0; j < NPL; ++j) {
+                const int q = s0 + j;
+                const bool on = fwd ? (q < 2) : (q >= S - 2);
+                const double p0 = pp[j];                 // (zeros behind S - 1)
+                v[j] = on ? p0 : 0.0;
+                pa[j] = 0.0; pb[j] = 0.0;
+            }
+            if (act) {
+                if (fwd) { *(double2*)(xp) = double2{v[0], v[1]}; *(double2*)(xp + 2) = double2{v[2], v[3]}; }
+                else {
+                    // q at the last frame: 1 on the two final states
+                    *(double2*)(xp) = double2{(s0 >= S - 2 && s0 < S) ? 1.0 : 0.0, (s0 + 1 >= S - 2 && s0 + 1 < S) ? 1.0 : 0.0};
+                    *(double2*)(xp + 2) = double2{(s0 + 2 >= S - 2 && s0 + 2 < S) ? 1.0 : 0.0, (s0 + 3 >= S - 2 && s0 + 3 < S) ? 1.0 : 0.0};
+                }
+            }
+            if (ln == 0) scl[t0] = 0.0;
+            xp += dx;
+            if (Tb > 1) {
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) pa[j] = pp[dp + j];
+            }
+            if (Tb > 2) {
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) pb[j] = pp[2 * dp + j];
+            }
+            pp += 3 * dp;                                // the row of frame k + 2 when frame k is at work
+            double lsc = 0.0;
+            int t = t0;
+            // one frame: the vector times the frame's probabilities pc; then pc is refilled with the probabilities of frame k + 2
+            auto frame = [&](double (&pc)[NPL], int k) {
+                t += fwd ? 1 : -1;
+                double inv = 1.0;
+                const bool resc = (k % RS) == 0;         // uniform: rescale by the sum of the previous frame's vector
+                if (resc) {
+                    double tot = (v[0] + v[1]) + (v[2] + v[3]), dummy = 0.0;
+                    wave_sum2_d(tot, dummy);
+                    if (tot > 0.0) { inv = 1.0 / tot; lsc += log(tot); }
+                }
+                double sm[NPL];
+                if (fwd) {
+                    const double m1 = wave_shr1_d(v[NPL - 1]), m2 = wave_shr1_d(v[NPL - 2]);
+                    sm[0] = (v[0] + m1) + (sk[0] ? m2 : 0.0);
+                    sm[1] = (v[1] + v[0]) + (sk[1] ? m1 : 0.0);
+                    sm[2] = (v[2] + v[1]) + (sk[2] ? v[0] : 0.0);
+                    sm[3] = (v[3] + v[2]) + (sk[3] ? v[1] : 0.0);
+                } else {
+                    const double p1 = wave_shl1_d(v[0]), p2 = wave_shl1_d(v[1]);
+                    sm[3] = (v[3] + p1) + (sk[3] ? p2 : 0.0);
+                    sm[2] = (v[2] + v[3]) + (sk[2] ? p1 : 0.0);
+                    sm[1] = (v[1] + v[2]) + (sk[1] ? v[3] : 0.0);
+                    sm[0] = (v[0] + v[1]) + (sk[0] ? v[2] : 0.0);
+                }
+                if (resc) {
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j) sm[j] *= inv;
+                }
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) v[j] = sm[j] * pc[j];
+                if (act) {
+                    if (fwd) { *(double2*)(xp) = double2{v[0], v[1]}; *(double2*)(xp + 2) = double2{v[2], v[3]}; }
+                    else { *(double2*)(xp) = double2{sm[0], sm[1]}; *(double2*)(xp + 2) = double2{sm[2], sm[3]}; }
+                }
+                xp += dx;
+                if (ln == 0) scl[t] = lsc;
+                if (k + 2 < Tb) {                        // uniform
+#pragma unroll
+                    for (int j = 0; j < NPL; ++j) pc[j] = pp[j];
+                }
+                pp += dp;
+            };
+            int k = 1;
+            for (; k + 1 < Tb; k += 2) { frame(pa, k); frame(pb, k + 1); }
+            if (k < Tb) frame(pa, k);
+            if (fwd) {
+#pragma unroll
+                for (int j = 0; j < NPL; ++j) if (s0 + j < S) abuf0[2 + s0 + j] = v[j];
+            }
+        };
+        if (wv == 0) run(std::true_type{}); else run(std::false_type{});
+    } else if (fast && wv < 2) {
         const bool fwd = wv == 0;
         double* scl = fwd ? sca : scb;
         double* xw = fwd ? aw : bw;
@@ -292,7 +504,7 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
         double v[NPL], pr[PD][NPL];
         auto fetch = [&](double (&dst)[NPL], int k) {
 #pragma unroll
-            for (int j = 0; j < NPL; ++j) dst[j] = (k < Tb && s0 + j < S) ? pw[(long)frame(k) * SMAX + s0 + j] : 0.0;
+            for (int j = 0; j < NPL; ++j) dst[j] = (k < Tb && s0 + j < S) ? pw[(long)frame(k) * SW + s0 + j] : 0.0;
         };
         {
             const int t = frame(0);
@@ -300,8 +512,8 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
             for (int j = 0; j < NPL; ++j) {
                 const int q = s0 + j;
                 const bool on = fwd ? (q < 2) : (q >= S - 2);
-                v[j] = (q < S && on) ? pw[(long)t * SMAX + q] : 0.0;
-                if (q < S) xw[(long)t * SMAX + q] = v[j];
+                v[j] = (q < S && on) ? pw[(long)t * SW + q] : 0.0;
+                if (q < S) xw[(long)t * SW + q] = v[j];
             }
             if (ln == 0) scl[t] = 0.0;
         }
@@ -339,7 +551,7 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
 #pragma unroll
                     for (int j = 0; j < NPL; ++j) {
                         v[j] = nv[j];
-                        if (s0 + j < S) xw[(long)t * SMAX + s0 + j] = nv[j];
+                        if (s0 + j < S) xw[(long)t * SW + s0 + j] = nv[j];
                     }
                     if (ln == 0) scl[t] = lsc;
                     fetch(pr[u], k + PD);
@@ -384,40 +596,71 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
         }
     };
     if (*badp == 0) {
-        const double ll = llp[0];
         // ---- phase 2: occupancies alpha_t(s) beta_t(s) / (p_t(s) P) and the sparse part of the gradient, time steps in
-        // parallel over the waves; the scales of a frame enter as ONE factor exp(sca[t] + scb[t] - ll).  The occupancies of
+        // parallel over the waves; the scales of a frame enter as ONE factor exp(sca[t] + scb[t] - ll) (formed for all frames at once,
+        // a frame per thread, instead of one exp per frame on every wave's path).  The occupancies of
         // a frame are a probability distribution over its states: a sum off 1 means that states the gradient needs were
         // flushed to zero in one of the two recursions -> the utterance is redone in the log domain.
+        const double ll = llp[0];
+        for (int t = tid; t < Tb; t += 512) sca[t] = exp(sca[t] + scb[t] - ll);
+        __syncthreads();
         constexpr int QL = 4;                               // states per lane: S <= 256
+        const int nj = (S + 63) >> 6;                       // (uniform) 64-state groups in use
         double ra[QL], rb[QL], rp[QL];
         auto fetch3 = [&](int t) {
 #pragma unroll
             for (int j = 0; j < QL; ++j) {
                 const int q = lane + 64 * j;
-                const bool ok = t < Tb && q < S;
-                ra[j] = ok ? aw[(long)t * SMAX + q] : 0.0;
-                rb[j] = ok ? bw[(long)t * SMAX + q] : 0.0;
-                rp[j] = ok ? pw[(long)t * SMAX + q] : 1.0;
+                const bool ok = j < nj && t < Tb && q < S;
+                ra[j] = ok ? aw[(long)t * SW + q] : 0.0;
+                rb[j] = ok ? bw[(long)t * SW + q] : 0.0;
+                rp[j] = (ok && !plds) ? pw[(long)t * SW + q] : 1.0;
+            }
+        };
+        // the gradient entries a frame's scatter updates (lane 0: the blank; lanes 0..L-1: a label, if it is the first state of its
+        // label) are fetched a frame ahead as well: the read-modify-write's load was a global round trip per frame on every wave
+        const int ql = 2 * lane + 1;
+        const bool has_l = ql < S && lead[ql];
+        const int el = has_l ? ext[ql] : 0;
+        float gb_n = 0.f, gl_n = 0.f;
+        auto gfetch = [&](int t) {
+            if (t < Tb) {
+                const float* gr = grad + ((long)t * B + b) * V;
+                if (lane == 0) gb_n = gr[blank];
+                if (has_l) gl_n = gr[el];
             }
         };
         bool off = false;
         fetch3(wave);
+        gfetch(wave);
         for (int t = wave; t < Tb; t += 8) {
-            const double ft = exp(sca[t] + scb[t] - ll);
+            const float gb = gb_n, gl = gl_n;
+            const double ft = sca[t];
             double tot = 0.0;
 #pragma unroll
             for (int j = 0; j < QL; ++j) {
                 const int q = lane + 64 * j;
-                const double ab = ra[j] * rb[j];
-                const double o = (ab == 0.0) ? 0.0 : ab / rp[j] * ft;
-                if (q < S) { oc[q] = o; tot += o; }
+                double o;
+                if (plds) o = ra[j] * rb[j] * ft;           // (uniform) rb = beta / p
+                else { const double ab = ra[j] * rb[j]; o = (ab == 0.0) ? 0.0 : ab / rp[j] * ft; }
+                if (j < nj && q < S) { oc[q] = o; tot += o; }
             }
             fetch3(t + 8);                                  // the next frame's values travel while this frame's sums are formed
-            tot = asr_wave_sum_d(tot);
+            gfetch(t + 8);
+            // the frame's total and its blank states' total (state q = lane + 64 j is a blank iff the lane is even) in one pass
+            double bsum = (lane & 1) ? 0.0 : tot;
+            wave_sum2_d(tot, bsum);
             off = off || !(fabs(tot - 1.0) <= 1e-6);
             // (the wave's LDS writes are ordered before its own later reads)
-            scatter_frame(t);
+            {
+                float* gr = grad + ((long)t * B + b) * V;
+                if (lane == 0) gr[blank] = gb - (float)bsum;
+                if (has_l) {                                // (2 * lane + 1 + 128 >= S: one state per lane)
+                    double sum = oc[ql];
+                    for (int j = nxt[ql]; j >= 0; j = nxt[j]) sum += oc[j];
+                    gr[el] = gl - (float)sum;
+                }
+            }
         }
         if (off && lane == 0) *badp = 1;
     }
@@ -434,6 +677,8 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
             if (m == NEG) return NEG;
             return m + log(exp(a - m) + exp(b2 - m) + exp(c - m));
         };
+        gather_lg();                                         // the float inputs (in LDS mode they take the place of the probabilities)
+        __syncthreads();
         auto lpr = [&](int t, int q) { return (double)lg[t * S + q] - lse_t[t]; };
         const int h = tid >> 8, s1 = tid & 255;
         for (int k = 0; k < Tb; ++k) {
@@ -445,7 +690,7 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
                     const bool on = h == 0 ? (q < 2) : (q >= S - 2);
                     val = on ? lpr(t, q) : NEG;
                 } else {
-                    const double* pv = xw + (long)(h == 0 ? t - 1 : t + 1) * SMAX;
+                    const double* pv = xw + (long)(h == 0 ? t - 1 : t + 1) * SW;
                     const int e = ext[q];
                     if (h == 0) {
                         const bool skp = (q >= 2) && (e != blank) && (e != ext[q - 2]);
@@ -455,13 +700,13 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
                         val = lpr(t, q) + lse3(pv[q], q + 1 < S ? pv[q + 1] : NEG, skp ? pv[q + 2] : NEG);
                     }
                 }
-                xw[(long)t * SMAX + q] = val;
+                xw[(long)t * SW + q] = val;
             }
             __threadfence_block();
             __syncthreads();
         }
         if (tid == 0) {
-            const double* la = aw + (long)(Tb - 1) * SMAX;
+            const double* la = aw + (long)(Tb - 1) * SW;
             const double ll = (S > 1) ? lse3(la[S - 1], la[S - 2], NEG) : la[0];
             llp[0] = ll;
             loss[b] = (float)(-ll);
@@ -478,13 +723,14 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
             for (int q = 2 * lane + 1; q < S; q += 128)
                 if (lead[q]) gr[ext[q]] = expf(x[ext[q]] - lf);
             for (int q = lane; q < S; q += 64) {
-                const double e = aw[(long)t * SMAX + q] + bw[(long)t * SMAX + q] - lpr(t, q) - ll;
+                const double e = aw[(long)t * SW + q] + bw[(long)t * SW + q] - lpr(t, q) - ll;
                 oc[q] = (e == e && e > -745.0) ? exp(e) : 0.0;
             }
             scatter_frame(t);
         }
     }
 }
+
 
 // ------------------------------------------------------------------ greedy decode
 // pass 1: one wave per (t,b) row over the whole chip: argmax with the lowest index on ties
@@ -618,10 +864,21 @@ __global__ void adam_tf_kernel(float* __restrict__ theta, const float* __restric
     }
 }
 
+// bytes in front of the region that holds the gathered inputs or the probabilities (rounded up to 16), and the whole request:
+// room for the float inputs [T][SMAX] at least (the form every utterance can fall back to), for the float64 probabilities of a
+// full lattice [T][SMAX rounded up to 4, + 4] at most, capped at 144 KB -- an utterance whose own Tb x (S rounded up to 4, + 4)
+// doubles fit keeps its probabilities in LDS (10 s of audio, 32 labels: 125 x 72 x 8 = 72 KB)
+inline size_t ctc_lds_fixed(int T, int max_label) {
+    const size_t SMAX = 2 * (size_t)max_label + 1;
+    return ((4 * (SMAX + 4) + 16 + 8 * (SMAX + 1) + 3 * (size_t)T + 2) * sizeof(double) + 3 * (SMAX + 1) * sizeof(int) + 15 + 16) & ~(size_t)15;
+}
+inline size_t ctc_ws_pitch(int max_label) { return ((2 * (size_t)max_label + 1 + 3) & ~(size_t)3) + 4; }
 inline size_t ctc_lds_bytes(int T, int max_label) {
     const size_t SMAX = 2 * (size_t)max_label + 1;
-    return (4 * (SMAX + 4) + 16 + 8 * (SMAX + 1) + 3 * (size_t)T + 2) * sizeof(double) + 3 * (SMAX + 1) * sizeof(int) +
-           (size_t)T * SMAX * sizeof(float) + 16;
+    const size_t fixed = ctc_lds_fixed(T, max_label);
+    const size_t lo = fixed + (size_t)T * SMAX * sizeof(float) + 16, hi = fixed + (size_t)T * ctc_ws_pitch(max_label) * sizeof(double);
+    const size_t cap = 144 * 1024;
+    return lo > cap ? lo : (hi < cap ? hi : cap);
 }
 
 }  // namespace
@@ -650,8 +907,7 @@ extern "C" int asr_softmax_log_bwd(const float* logits_tm, const float* g_tm, in
 }
 
 extern "C" size_t asr_ctc_workspace(int T, int B, int max_label) {
-    const size_t SMAX = 2 * (size_t)max_label + 1;
-    return ((size_t)T * B + 3 * (size_t)B * T * SMAX) * sizeof(double) + 64;
+    return (((size_t)T * B + 1) / 2 * 2 + 3 * (size_t)B * T * ctc_ws_pitch(max_label)) * sizeof(double) + 64;
 }
 
 extern "C" int asr_ctc_loss(const float* logits_tm, int T, int B, int V, const int32_t* labels, int max_label,
@@ -664,17 +920,27 @@ extern "C" int asr_ctc_loss(const float* logits_tm, int T, int B, int V, const i
     if (lds > 160 * 1024) return ASR_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     double* lse = (double*)workspace;
-    double* alpha_ws = lse + (size_t)T * B;
-    double* beta_ws = alpha_ws + (size_t)B * T * (2 * (size_t)max_label + 1);
-    double* prob_ws = beta_ws + (size_t)B * T * (2 * (size_t)max_label + 1);
+    if (((uintptr_t)workspace) & 15) return ASR_ERR_BAD_ARG;
+    double* alpha_ws = lse + ((size_t)T * B + 1) / 2 * 2;          // 16-byte aligned rows (pitch: a multiple of four doubles)
+    double* beta_ws = alpha_ws + (size_t)B * T * ctc_ws_pitch(max_label);
+    double* prob_ws = beta_ws + (size_t)B * T * ctc_ws_pitch(max_label);
+    const int p_cap = (int)((lds - ctc_lds_fixed(T, max_label)) / sizeof(double));
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)ctc_lattice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL(ctc_check_kernel, dim3(asr_cdiv(B, 64)), dim3(64), 0, st, labels, max_label, label_len, seq_len, T, B, status);
-    hipLaunchKernelGGL(ctc_rows_kernel, dim3(asr_cdiv((long)T * B, 4)), dim3(256), 0, st, logits_tm, T, B, V, seq_len, (const int32_t*)status, lse, grad);
-    hipLaunchKernelGGL(ctc_lattice_kernel, dim3(B), dim3(512), lds, st, logits_tm, T, B, V, labels, max_label, label_len, seq_len, blank, (const int32_t*)status, (const double*)lse, alpha_ws, beta_ws, prob_ws, loss, grad);
+    const int SW = (int)ctc_ws_pitch(max_label);
+    const dim3 rg(asr_cdiv((long)T * B, 4)), rb(256);
+    const bool vec = (V & 3) == 0 && V <= 64 * 4 * 8 && ((((uintptr_t)logits_tm) | ((uintptr_t)grad)) & 15) == 0;
+#define ASR_CTC_ROWS_ARGS logits_tm, T, B, V, seq_len, (const int32_t*)status, labels, max_label, label_len, blank, SW, lse, grad, prob_ws
+    if (vec && V <= 64 * 4 * 4) hipLaunchKernelGGL(ctc_rows_vec_kernel<4>, rg, rb, 0, st, ASR_CTC_ROWS_ARGS);
+    else if (vec && V <= 64 * 4 * 6) hipLaunchKernelGGL(ctc_rows_vec_kernel<6>, rg, rb, 0, st, ASR_CTC_ROWS_ARGS);
+    else if (vec) hipLaunchKernelGGL(ctc_rows_vec_kernel<8>, rg, rb, 0, st, ASR_CTC_ROWS_ARGS);
+    else hipLaunchKernelGGL(ctc_rows_kernel, rg, rb, 0, st, ASR_CTC_ROWS_ARGS);
+#undef ASR_CTC_ROWS_ARGS
+    hipLaunchKernelGGL(ctc_lattice_kernel, dim3(B), dim3(512), lds, st, logits_tm, T, B, V, labels, max_label, label_len, seq_len, blank, (const int32_t*)status, (const double*)lse, alpha_ws, beta_ws, prob_ws, loss, grad, p_cap);
     ASR_CHECK_LAUNCH("ctc_loss");
     return ASR_OK;
 }

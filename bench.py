@@ -605,6 +605,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dropout', type=float, default=0.2, help='Transformer workloads: dropout_rate (reference default 0.2, model.py:36)')
     ap.add_argument('--no-prefetch', action='store_true', help='compute the fbank features in line instead of one step ahead')
+    ap.add_argument('--prefetch-early', action='store_true', help='A/B: the feature prefetch may start before the forward pass has finished (until round 5)')
     ap.add_argument('--kernel-table', action='store_true', help='also print per-kernel timings to stderr')
     ap.add_argument('--host-input', action='store_true',
                     help='DFCNN workloads: hand every batch over as a (pinned) HOST buffer, i.e. put the PCIe copy of the raw '
@@ -690,10 +691,12 @@ def main():
     consumed = [None, None]
     state = {'i': 0}
 
-    def produce(slot):
+    def produce(slot, after=None):
         with torch.cuda.stream(pf_stream):
             if consumed[slot] is not None:
                 pf_stream.wait_event(consumed[slot])          # the step that read this buffer (incl. its backward) is done
+            if after is not None:
+                pf_stream.wait_event(after)
             if host_pinned is not None:
                 signal.copy_(host_pinned, non_blocking=True)  # the batch arrives from the host: 20.5 MB of audio over PCIe
             fb.batch(signal, nsamp, T, out=feats[slot])
@@ -722,8 +725,14 @@ def main():
             eng.forward(feat)
             if pf:
                 # after the conv stack: the latency-bound fbank fills the chip while the (equally latency-bound) CTC lattice /
-                # decode / small head GEMMs run, and the forward contractions keep the chip to themselves
-                produce(cur ^ 1)
+                # decode run, and the forward contractions keep the chip to themselves.  The prefetch stream WAITS for the forward
+                # pass (an event, not just the enqueue order: the host runs a step ahead, and without the event the fbank kernels
+                # started beside the first Winograd layers -- whose persistent workgroups split the layer statically over the CUs, so
+                # that a CU shared with fbank work made the whole launch late: 125 us of fbank cost the step 0.2 ms)
+                fwd_done = None
+                if not args.prefetch_early:
+                    fwd_done = torch.cuda.Event(); fwd_done.record()
+                produce(cur ^ 1, fwd_done)
             if args.inference:
                 ops.ctc_greedy(eng.logits, eng.T8, B, V, eng.seq_len, V - 1, eng.dec_ids, eng.dec_len, eng.neg_sum, eng.dec_ws)
             else:
@@ -829,7 +838,7 @@ def main():
                        'step_algorithmic_frac_of_fp32_peak': round(utt_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
                        'step_flops_note': 'direct-convolution flops (SURVEY 8d); the Winograd layers execute 1/2.25 of their multiplies, '
                                           'so this is a rate of useful work, not a utilisation of the fp32 pipe',
-                       'backward_streams': 2 if overlapped else 1, 'feature_prefetch': prefetch,
+                       'backward_streams': 2 if overlapped else 1, 'feature_prefetch': prefetch, 'feature_prefetch_starts': ('any time' if args.prefetch_early else 'behind the forward pass (beside the CTC lattice)') if prefetch else None,
                        'host_input': bool(args.host_input),
                        'conv_arithmetic': ('fp32 MFMA; 3x3 convs with K % 8 == 0 and N % 32 == 0 on column-blocked planes by Winograd '
                                            'F(2x2,3x3) in fp32 (wino11_kernel: forward, data-gradient, gated data-gradient), their weight '

@@ -39,6 +39,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--workload', default='dfcnn')
     ap.add_argument('--single-stream', action='store_true')
+    ap.add_argument('--prefetch-early', action='store_true')
     args = ap.parse_args()
     dev = 'cuda'
     B, T, F, V = 32, 1600, 200, 1536
@@ -57,10 +58,12 @@ def main():
     pf = torch.cuda.Stream(device=dev)
     ready, consumed, state = [None, None], [None, None], {'i': 0}
 
-    def produce(slot):
+    def produce(slot, after=None):
         with torch.cuda.stream(pf):
             if consumed[slot] is not None:
                 pf.wait_event(consumed[slot])
+            if after is not None:
+                pf.wait_event(after)
             fb.batch(signal, nsamp, T, out=feats[slot])
             ev = torch.cuda.Event(); ev.record()
             ready[slot] = ev
@@ -71,7 +74,10 @@ def main():
             produce(cur)
         torch.cuda.current_stream().wait_event(ready[cur])
         eng.forward(feats[cur])
-        produce(cur ^ 1)
+        fwd_done = None
+        if not args.prefetch_early:
+            fwd_done = torch.cuda.Event(); fwd_done.record()
+        produce(cur ^ 1, fwd_done)
         eng.set_targets(seq, target)
         eng.loss_and_decode(defer_decode_join=True)
         eng.backward()
