@@ -134,7 +134,9 @@ __device__ __forceinline__ void g1_chunk(const float* __restrict__ set, float* _
 // workgroups per CU -- for the problems whose 128 x 128 grid is not a whole number of rounds over 512 slots (the launcher's
 // rule); every output element sums its K products in the same order in both, so the choice changes no bit.
 #if __HIP_DEVICE_COMPILE__
-template <int NB, bool GD>
+// SK: the contraction split over gridDim.y (asr_tap_gemm_nt_splitk): split z works on columns [z * K, (z + 1) * K) of both operands
+// (K = the split's depth, a multiple of 32) and writes plane z of a [splits][M][N] slab through the row table.
+template <int NB, bool GD, bool SK = false>
 __device__ __forceinline__ void gemm1_body(const Gemm1Args& args) {
     const TapGemmArgs& g = args.g;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -163,7 +165,7 @@ __device__ __forceinline__ void gemm1_body(const Gemm1Args& args) {
                 const int b = (int)(p / g.gate_H), h = (int)(p - (long)b * g.gate_H);
                 ra = (b * (g.gate_H + 1) + h + 1) * (g.gate_W + 1) + 1; ry = ra;
             } else if (g.H == 0) {
-                ra = (int)p; ry = (int)p;
+                ra = (int)p + (SK ? (int)blockIdx.y * g.M : 0); ry = ra;
             } else {
                 const int b = (int)(p / g.HPWP);
                 const int r = (int)(p - (long)b * g.HPWP);
@@ -180,8 +182,9 @@ __device__ __forceinline__ void gemm1_body(const Gemm1Args& args) {
     // ---- DMA side.  Lane l fills LDS slot (row 8p + l / 8, physical chunk l % 8) with the row's LOGICAL chunk
     // (l % 8) ^ ((row >> 1) & 7); (row >> 1) & 7 = (4 (p & 1) + l / 16) & 7 and p & 1 = w & 1 for all of a wave's pieces.
     // buffer resources over exactly the bytes the operands own: [0, ((rows - 1) * pitch + K) * 4)
-    auto rsa = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)((((long)g.M - 1) * g.lda + K) * 4), 0x00020000);
-    auto rsb = __builtin_amdgcn_make_buffer_rsrc((void*)args.Bt, 0, (int)((((long)g.N - 1) * args.ldb + K) * 4), 0x00020000);
+    const long koff = SK ? (long)blockIdx.y * K : 0;
+    auto rsa = __builtin_amdgcn_make_buffer_rsrc((void*)(g.A + koff), 0, (int)((((long)g.M - 1) * g.lda + K) * 4), 0x00020000);
+    auto rsb = __builtin_amdgcn_make_buffer_rsrc((void*)(args.Bt + koff), 0, (int)((((long)g.N - 1) * args.ldb + K) * 4), 0x00020000);
     G1Dma q;
     q.wave = wave; q.K = K;
     q.dchunk = (lane & 7) ^ ((((wave & 1) << 2) + (lane >> 4)) & 7);
@@ -256,6 +259,13 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void gemm1_dense_gate_kernel(
 }
 
 
+
+template <int NB>
+__global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void gemm1_splitk_kernel(Gemm1Args args) {
+#if __HIP_DEVICE_COMPILE__
+    gemm1_body<NB, false, true>(args);
+#endif
+}
 
 // ---- dense weight gradient, "TN" form:  dW[k][n] = sum_m A[m][k] * dZ[m][n]  (tf.layers.dense backward, and the 1x1 conv's)
 // Same machinery as gemm1_kernel -- buffer-form LDS-DMA into two run buffers, pieces between the MFMAs, one barrier per run,
@@ -526,6 +536,53 @@ extern "C" int asr_tap_gemm_nt(const asr_gemm_desc* d, const float* A, const flo
     if (d->M <= 0 || d->K <= 0 || d->N <= 0 || ldwt < d->K) return ASR_ERR_BAD_ARG;
     if (asr_gemm1_eligible(d, A, Wt, ldwt)) return asr_gemm1_launch(d, A, Wt, ldwt, bias, scale, shift, out_a, out_y, 0, stream, nullptr);
     return asr_tap_gemm(d, A, W, bias, scale, shift, out_a, out_y, stream);
+}
+
+// second pass of the split-K forms (tap_gemm.hip)
+int asr_splitk_reduce_launch(const float* slab, int splits, const asr_gemm_desc* d, const float* bias, const float* scale, const float* shift,
+                             float* out_a, float* out_y, void* stream);
+
+// Dense GEMM, both operands K-contiguous (A [M][K], Bt [N][K]), the contraction split `splits` ways over the grid: for a deep K and few
+// output tiles -- the 6400 -> 128 hidden dense of acoustic_model.py:53 (50 tiles of 128 x 128; ten splits of twenty chunks fill the
+// chip's 512 workgroup slots once) and the 1536 -> 128 data-gradient of the layer behind it.  The LDS-DMA kernel of this file per split
+// (gemm1_splitk_kernel), then the fixed-order second pass of asr_tap_gemm_splitk: reproducible; equal to asr_tap_gemm_nt up to the
+// order of the K sum.
+extern "C" size_t asr_tap_gemm_nt_splitk_workspace(const asr_gemm_desc* d, int splits) {
+    return (d && splits > 1) ? (size_t)splits * d->M * d->N * sizeof(float) : 0;
+}
+
+extern "C" int asr_tap_gemm_nt_splitk(const asr_gemm_desc* d, const float* A, const float* Bt, int ldb, const float* bias, const float* scale,
+                                      const float* shift, float* out_a, float* out_y, int splits, void* workspace, void* stream) {
+    if (!d || !A || !Bt || (!out_a && !out_y) || !workspace) return ASR_ERR_BAD_ARG;
+    if (d->ntaps != 1 || d->H > 0 || d->y_unpadded || splits < 2 || splits > 16) return ASR_ERR_BAD_ARG;
+    if ((d->K % (splits * 32)) || (d->N & 3) || (d->lda & 3) || (ldb & 3) || ldb < d->K || d->N < 64 ||
+        (((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)workspace) & 15)) return ASR_ERR_BAD_ARG;
+    if ((long)d->M * d->lda * 4 >= (1L << 31) || (long)d->N * ldb * 4 >= (1L << 31) || (long)splits * d->M >= (1L << 31) / d->N) return ASR_ERR_UNSUPPORTED;
+    Gemm1Args ga;
+    TapGemmArgs& a = ga.g;
+    a.A = A; a.W = nullptr; a.bias = nullptr; a.scale = nullptr; a.shift = nullptr;
+    a.out_a = (float*)workspace; a.out_y = nullptr;
+    a.M = d->M; a.K = d->K / splits; a.N = d->N; a.lda = d->lda; a.ldw = ldb;
+    a.ldo_a = d->N; a.ldo_y = 0;
+    a.H = 0; a.Wd = 0; a.WP = 1; a.HPWP = 1; a.halo = 0; a.rmin = 0; a.rmax = d->M;
+    a.relu = 0; a.accumulate = 0; a.y_unpadded = 0;
+    a.gate_mode = 0; a.gate_H = a.gate_W = 0; a.gate_a = nullptr; a.gate_dz = nullptr; a.gate_part = nullptr; a.gate_rows = nullptr;
+    a.nt_store = 0;
+    // the tile whose grid x splits comes closest to whole rounds of the chip's workgroup slots (512 of 128 x 128, 768 of 128 x 64)
+    const long t2 = (long)asr_cdiv(d->M, 128) * asr_cdiv(d->N, 128) * splits, t1 = (long)asr_cdiv(d->M, 128) * asr_cdiv(d->N, 64) * splits;
+    const double f2 = (double)t2 / (512.0 * ((t2 + 511) / 512)), f1 = (double)t1 / (768.0 * ((t1 + 767) / 768));
+    const int nb = f2 >= f1 ? 2 : 1;
+    a.ntm = asr_cdiv(d->M, 128); a.ntn = asr_cdiv(d->N, 64 * nb);
+    ga.Bt = Bt; ga.ldb = ldb;
+    const size_t lds = (size_t)(256 + 2 * (G1_TILE_F + nb * 64 * G1_KC)) * sizeof(float);
+    typedef void (*kern_t)(Gemm1Args);
+    static const kern_t kerns[2] = {gemm1_splitk_kernel<1>, gemm1_splitk_kernel<2>};
+    static bool attr[2] = {false, false};
+    if (!attr[nb - 1]) { (void)hipFuncSetAttribute((const void*)kerns[nb - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[nb - 1] = true; }
+    hipLaunchKernelGGL(kerns[nb - 1], dim3(a.ntm * a.ntn, splits), dim3(256), lds, (hipStream_t)stream, ga);
+    asr_set_last_kernel(nb == 2 ? "gemm1_splitk_kernel<2>" : "gemm1_splitk_kernel<1>");
+    ASR_CHECK_LAUNCH("gemm1_splitk");
+    return asr_splitk_reduce_launch((const float*)workspace, splits, d, bias, scale, shift, out_a, out_y, stream);
 }
 
 extern "C" int asr_transpose_batch(const asr_copy2d_item* items_dev, int n_items, int max_elems, void* stream) {

@@ -568,6 +568,17 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ part, int splits,
 }
 }  // namespace
 
+// (also the second pass of asr_tap_gemm_nt_splitk, gemm1.hip)
+ASR_INTERNAL int asr_splitk_reduce_launch(const float* slab, int splits, const asr_gemm_desc* d, const float* bias, const float* scale,
+                                          const float* shift, float* out_a, float* out_y, void* stream) {
+    const long MN = (long)d->M * d->N;
+    int blocks = (int)((MN / 4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, slab, splits, MN, d->N, bias, scale, shift,
+                       d->relu, d->accumulate, out_a, d->ldo_a, out_y, d->ldo_y);
+    ASR_CHECK_LAUNCH("splitk_reduce");
+    return ASR_OK;
+}
+
 extern "C" size_t asr_tap_gemm_splitk_workspace(const asr_gemm_desc* d, int splits) {
     return (d && splits > 1) ? (size_t)splits * d->M * d->N * sizeof(float) : 0;
 }

@@ -153,7 +153,7 @@ class DFCNNEngine:
     def __init__(self, model='m2', vocab=1536, B=32, T=1600, F=200, widths=None, seed=0, device='cuda',
                  lr=7e-4, decay_steps=5000, min_lr=1e-6, beta1=0.9, beta2=0.999, adam_eps=1e-8,
                  dual_stream=True, wino=True, fuse_prologues=True, fuse_se=True, compact_pool=True, side_priority=0,
-                 dense_wgrad_side=True, fuse_dense=True, se_sums=True):
+                 dense_wgrad_side=True, fuse_dense=True, se_sums=True, nt_splitk=True):
         """Options (constructor arguments only -- nothing here reads the environment; `options()` reports them):
         ``dual_stream``: weight gradients / decode on a second stream (``side_priority``: its HIP stream priority);
         ``wino``: Winograd F(2x2,3x3) / F(3x3,2x2) for the 3x3 layers the kernels support instead of the direct tap-GEMM;
@@ -164,12 +164,14 @@ class DFCNNEngine:
         the second stream beside their data-gradients (False: in front of them on the main stream, as until round 4); ``fuse_dense``: the
         data-gradient of a dense layer fed by a cell also runs that cell's BN / ReLU backward (asr_tap_gemm_gated_dense); ``se_sums``: the
         forward launch of an SE block's branch cell also makes the block's squeeze sums (asr_tap_gemm_wino_sums; the squeeze is then a
-        sum in another order: to rounding).  Each of them leaves the results bitwise (streams, fusions,
+        sum in another order: to rounding); ``nt_splitk``: the split-K dense layers on the LDS-DMA kernel (asr_tap_gemm_nt_splitk; False: the
+        64 x 64 register-staged tiles of asr_tap_gemm_splitk, eight splits, as until round 4: to rounding).  Each of them leaves the results bitwise (streams, fusions,
         compact form) or to rounding (Winograd) unchanged; they exist for A/B measurements and tests."""
         assert T % 8 == 0 and F >= 8
         self.opt_dual, self.opt_wino, self.opt_fuse = bool(dual_stream), bool(wino), bool(fuse_prologues)
         self.opt_fuse_se, self.opt_compact, self.side_priority = bool(fuse_se), bool(compact_pool), int(side_priority)
         self.opt_dense_side, self.opt_fuse_dense, self.opt_se_sums = bool(dense_wgrad_side), bool(fuse_dense), bool(se_sums)
+        self.opt_nt_splitk = bool(nt_splitk)
         self.model, self.V, self.B, self.T, self.F = model, vocab, B, T, F
         self.device = device
         self.g = graph(model, vocab, widths, F)
@@ -272,7 +274,7 @@ class DFCNNEngine:
         self.fdesc, self.bdesc, self.wdesc = {}, {}, {}
         ws_bytes = 1 << 20
         self.splitk = {}
-        self.dsplitk = {}
+        self.dsplitk, self.dsplitk_n = {}, {}
         consumers = {}
         for op in self.g:
             srcs = [op[1]] if op[0] != 'se' else [op[1], op[2]]
@@ -337,15 +339,23 @@ class DFCNNEngine:
                 # tests/test_gemm1_gpu.py::test_the_tile_choice_changes_no_bit; (3) split-K, here: widths only; (4) the chunk plans
                 # of the weight-gradient kernels depend on batch and CU count, but weight gradients are sums over the batch
                 # anyway and never enter this property)
+                # Round 5: on the LDS-DMA kernel (asr_tap_gemm_nt_splitk, on the transposed kernel the other dense layers use anyway), the
+                # split count the largest whose 128 x 64 tiles of a batch of 32 stay within 512 workgroups (tools/bench_splitk_scan.py:
+                # five splits of forty chunks for 6400 -> 128 at T_pad 1600, 114 -> 85-94 us; eight at T_pad 1000).  A function of the
+                # widths and T only (rule 3 above).
+                def nt_splits(depth, width):
+                    nominal = -(-32 * H // 128) * -(-width // 64)
+                    return next((k for k in range(16, 1, -1) if depth % (32 * k) == 0 and nominal * k <= 512), 2)
                 if cout <= 128 and cin >= 2048 and cin % 256 == 0:
-                    self.splitk[dst] = 8
-                    ws_bytes = max(ws_bytes, ops.tap_gemm_splitk_workspace(self.fdesc[dst], 8))
+                    self.splitk[dst] = nt_splits(cin, cout) if self.opt_nt_splitk else 8
+                    ws_bytes = max(ws_bytes, ops.tap_gemm_nt_splitk_workspace(self.fdesc[dst], self.splitk[dst]))
                 # the mirror case in the backward pass: the data-gradient of a wide layer over a narrow input (128 -> 1536:
                 # dX [rows][128] = dZ [rows][1536] . W^T is 50 tiles of 128 x 128 with a 1536-deep contraction -- 103 us on 50 CUs)
                 # runs as the same split-K GEMM on the transposed kernel the forward pass keeps anyway (self.wT)
                 if cin <= 128 and cout >= 1024 and cout % 256 == 0 and src != 'x':
                     self.dsplitk[dst] = ops.gemm_desc(rows, cout, cin, cout, cin, 0, cin, ntaps=1)
-                    ws_bytes = max(ws_bytes, ops.tap_gemm_splitk_workspace(self.dsplitk[dst], 8))
+                    self.dsplitk_n[dst] = nt_splits(cout, cin) if self.opt_nt_splitk else 8
+                    ws_bytes = max(ws_bytes, ops.tap_gemm_nt_splitk_workspace(self.dsplitk[dst], 8))
         self.T8 = self.res[self.g[-1][2]][0]
         T8, V = self.T8, self.V
         self.logits = torch.zeros(T8, B, V, dtype=torch.float32, device=dev)      # self.logits of the reference
@@ -394,7 +404,7 @@ class DFCNNEngine:
         # 109 -> 125 TFLOP/s); small ones fall through to asr_tap_gemm inside the library
         self.wT, items = {}, []
         for op in self.g:
-            if op[0] == 'dense' and op[2] not in self.splitk:
+            if op[0] == 'dense':
                 _, src, dst, cin, cout, act = op
                 self.wT[dst] = torch.zeros(cout * cin, dtype=torch.float32, device=dev)
                 items.append((self.wT[dst], cin, self.p(dst, 'w'), cout, cin, cout))
@@ -507,7 +517,7 @@ class DFCNNEngine:
     def options(self):
         """The switches this engine was built with and what they resolved to on this graph (bench.py puts it in its JSON line)."""
         return {'dual_stream': self.opt_dual, 'wino': self.opt_wino, 'fuse_prologues': self.opt_fuse, 'fuse_se': self.opt_fuse_se,
-                'compact_pool': self.opt_compact, 'side_priority': self.side_priority, 'dense_wgrad_side': self.opt_dense_side, 'fuse_dense': self.opt_fuse_dense, 'se_sums': self.opt_se_sums,
+                'compact_pool': self.opt_compact, 'side_priority': self.side_priority, 'dense_wgrad_side': self.opt_dense_side, 'fuse_dense': self.opt_fuse_dense, 'se_sums': self.opt_se_sums, 'nt_splitk': self.opt_nt_splitk,
                 'se_squeeze_in_the_branch_conv': sorted(self.se_sums), 'se_backward_reduction_in_the_consumer_dgrad': sorted(self.se_xsum),
                 'winograd_layers_fwd': sorted(self.wt_f), 'winograd_layers_dgrad': sorted(self.wt_b),
                 'fused_prologues': len(self.fuse), 'dense_gradients_with_cell_backward': sorted(self.dense_gate), 'se_blocks_fused_with_cell_backward': len(self.se_cell),
@@ -663,8 +673,12 @@ class DFCNNEngine:
             elif op[0] == 'dense':
                 _, src, dst, cin, cout, act = op
                 if dst in self.splitk:
-                    ops.tap_gemm_splitk(self.fdesc[dst], self.flat[src], self.p(dst, 'w'), self.p(dst, 'b'), None, None,
-                                        None, self.flat[dst], self.splitk[dst], self.ws)
+                    if self.opt_nt_splitk:
+                        ops.tap_gemm_nt_splitk(self.fdesc[dst], self.flat[src], self.wT[dst], cin, self.p(dst, 'b'), None, None,
+                                               None, self.flat[dst], self.splitk[dst], self.ws)
+                    else:
+                        ops.tap_gemm_splitk(self.fdesc[dst], self.flat[src], self.p(dst, 'w'), self.p(dst, 'b'), None, None,
+                                            None, self.flat[dst], self.splitk[dst], self.ws)
                 else:
                     ops.tap_gemm_nt(self.fdesc[dst], self.flat[src], self.p(dst, 'w'), self.wT[dst], cin, self.p(dst, 'b'), None, None,
                                     None, self.flat[dst])
@@ -818,8 +832,13 @@ class DFCNNEngine:
                     ops.tap_gemm_gated_dense(self.bdesc[dst], dz, self.p(dst, 'w'), self.a[src], self.scale_of(src), self.p(src, 'beta'), dzt,
                                              self.dscale_of(src), self.gview(src, 'beta'), self.gview(src, 'b'), self.ws)
                     fused_dz[src] = dzt
-                elif dst in self.dsplitk and dst in self.wT:
-                    ops.tap_gemm_splitk(self.dsplitk[dst], dz, self.wT[dst], None, None, None, None, self.dflat[src], 8, self.ws)
+                elif dst in self.dsplitk:
+                    # dX = dZ . W^T: the kernel W [cin][cout] is the K-contiguous second operand as it lies
+                    if self.opt_nt_splitk:
+                        ops.tap_gemm_nt_splitk(self.dsplitk[dst], dz, self.p(dst, 'w'), cout, None, None, None, None, self.dflat[src],
+                                               self.dsplitk_n[dst], self.ws)
+                    else:
+                        ops.tap_gemm_splitk(self.dsplitk[dst], dz, self.wT[dst], None, None, None, None, self.dflat[src], 8, self.ws)
                 else:
                     ops.tap_gemm(self.bdesc[dst], dz, self.p(dst, 'w'), None, None, None, None, self.dflat[src])
                 dense_pending -= 1

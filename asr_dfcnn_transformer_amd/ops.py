@@ -146,6 +146,17 @@ def tap_gemm_splitk(desc, A, W, bias, scale, shift, out_a, out_y, splits, worksp
                                                        _ptr(out_y), int(splits), _ptr(workspace), _stream()), 'asr_tap_gemm_splitk'))
 
 
+def tap_gemm_nt_splitk_workspace(desc, splits):
+    return _lib.load().asr_tap_gemm_nt_splitk_workspace(C.byref(desc), int(splits))
+
+
+def tap_gemm_nt_splitk(desc, A, Bt, ldb, bias, scale, shift, out_a, out_y, splits, workspace):
+    """Split-K dense GEMM on the LDS-DMA kernel, both operands K-contiguous (asr_tap_gemm_nt_splitk)."""
+    lib = _lib.load()
+    _timed(desc, lambda: check(lib.asr_tap_gemm_nt_splitk(C.byref(desc), _ptr(A), _ptr(Bt), int(ldb), _ptr(bias), _ptr(scale), _ptr(shift),
+                                                          _ptr(out_a), _ptr(out_y), int(splits), _ptr(workspace), _stream()), 'asr_tap_gemm_nt_splitk'))
+
+
 def tap_gemm_gated_workspace(desc):
     return _lib.load().asr_tap_gemm_gated_workspace(C.byref(desc))
 

@@ -430,7 +430,7 @@ def engine_kwargs(args):
     """The A/B switches of DFCNNEngine as command-line flags (the engine itself reads no environment variable)."""
     return dict(dual_stream=not args.single_stream, wino=not args.no_wino, compact_pool=not args.no_compact_pool,
                 fuse_se=not args.no_fuse_se, side_priority=args.side_priority, dense_wgrad_side=not args.dense_wgrad_main,
-                fuse_dense=not args.no_fuse_dense, se_sums=not args.no_se_sums)
+                fuse_dense=not args.no_fuse_dense, se_sums=not args.no_se_sums, nt_splitk=not args.no_nt_splitk)
 
 
 def dp_info():
@@ -621,6 +621,7 @@ def main():
     ap.add_argument('--no-fuse-se', action='store_true', help='A/B: SE backward and its branch cell backward as separate passes')
     ap.add_argument('--no-se-sums', action='store_true', help='A/B: the SE squeeze as a pass of its own over the branch plane')
     ap.add_argument('--no-fuse-dense', action='store_true', help='A/B: dense data-gradient and the backward prologue of the cell in front as two passes')
+    ap.add_argument('--no-nt-splitk', action='store_true', help='A/B: the split-K dense layers on the 64 x 64 register-staged tiles (until round 4)')
     ap.add_argument('--dense-wgrad-main', action='store_true', help='A/B: dense weight gradients on the main stream (round 4)')
     ap.add_argument('--side-priority', type=int, default=0, help='A/B: HIP priority of the second backward stream')
     ap.add_argument('--prime-steps', type=int, default=0,

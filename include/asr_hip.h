@@ -480,6 +480,16 @@ size_t asr_tap_gemm_splitk_workspace(const asr_gemm_desc* d, int splits);
 int asr_tap_gemm_splitk(const asr_gemm_desc* d, const float* A, const float* W, const float* bias, const float* scale,
                         const float* shift, float* out_a, float* out_y, int splits, void* workspace, void* stream);
 
+/* The same split on the LDS-DMA kernel of asr_tap_gemm_nt (gemm1.hip): both operands K-contiguous -- A [M][K] (pitch d->lda) and
+ * Bt [N][K] (pitch ldb): a forward layer's transposed kernel (asr_transpose_batch), or the kernel W [K_out][N_out] itself for a
+ * data-gradient dX = dY . W^T (then d->K = the layer's output width, d->N its input width).  d->wmode is not read.  N >= 64,
+ * K % (32 * splits) == 0, 2 <= splits <= 16; workspace = asr_tap_gemm_nt_splitk_workspace(d, splits) bytes, 16-byte aligned.
+ * Round 5: the 6400 -> 128 hidden dense of acoustic_model.py:53 (ten splits: 500 workgroups for the chip's 512 slots) and the
+ * 1536 -> 128 data-gradient behind it, which asr_tap_gemm_splitk ran on 64 x 64 register-staged tiles. */
+size_t asr_tap_gemm_nt_splitk_workspace(const asr_gemm_desc* d, int splits);
+int asr_tap_gemm_nt_splitk(const asr_gemm_desc* d, const float* A, const float* Bt, int ldb, const float* bias, const float* scale,
+                           const float* shift, float* out_a, float* out_y, int splits, void* workspace, void* stream);
+
 /* fp32 contraction on PRE-ARRANGED weights: same arguments, arithmetic (v_mfma_f32_32x32x2_f32, fp32 accumulate) and
  * epilogue as asr_tap_gemm; the weight tensor is first copied into MFMA fragment order, once per optimiser step:
  *   asr_arrange_weights(W, ntaps, K, N, ldw, wmode, out): out = fp32 [ntaps][ceil(K/8)][ceil(N/32)][64 lanes][4], lane

@@ -182,6 +182,36 @@ def test_dense_forward_split_k(ops, M, K, N, splits):
     assert torch.equal(a1, a2)
 
 
+@pytest.mark.parametrize("M,K,N,splits", [(640, 6400, 128, 10), (300, 512, 64, 2), (129, 1024, 192, 8), (6400, 6400, 128, 10), (6400, 1536, 128, 8),
+                                          (200, 6400, 128, 10)])
+def test_dense_split_k_on_the_lds_dma_kernel(ops, M, K, N, splits):
+    """asr_tap_gemm_nt_splitk (A [M][K], Bt [N][K]) against float64: bias + ReLU on out_a, affine on out_y; equal to asr_tap_gemm to
+    rounding; bitwise reproducible; the rows of a one-utterance problem are bitwise the rows they are inside a batch."""
+    rng = np.random.default_rng(16)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((K, N)) / np.sqrt(K)).astype(np.float32)
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    sc = (1 + 0.2 * rng.standard_normal(N)).astype(np.float32); sh = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    d = ops.gemm_desc(M, K, N, K, N, N, N, ntaps=1, relu=1)
+    a0, y0, a1, y1, a2 = (torch.zeros(M, N, device='cuda') for _ in range(5))
+    ws = torch.zeros(ops.tap_gemm_nt_splitk_workspace(d, splits) // 4 + 4, device='cuda')
+    wt = dev(np.ascontiguousarray(w.T))
+    ops.tap_gemm(d, dev(x), dev(w), dev(b), dev(sc), dev(sh), a0, y0)
+    ops.tap_gemm_nt_splitk(d, dev(x), wt, K, dev(b), dev(sc), dev(sh), a1, y1, splits, ws)
+    ops.tap_gemm_nt_splitk(d, dev(x), wt, K, dev(b), None, None, a2, None, splits, ws)
+    ref = np.maximum(x.astype(np.float64) @ w.astype(np.float64) + b, 0.0)
+    report('split-K (LDS-DMA) a', a1.cpu().numpy(), ref, 2e-5)
+    report('split-K (LDS-DMA) y', y1.cpu().numpy(), ref * sc + sh, 2e-5)
+    assert (a1 - a0).abs().max().item() < 2e-5 * max(1.0, float(np.abs(ref).max()))
+    assert torch.equal(a1, a2)
+    if M > 256:
+        m1 = 200 if M >= 400 else 100
+        d1 = ops.gemm_desc(m1, K, N, K, N, N, N, ntaps=1, relu=1)
+        a3 = torch.zeros(m1, N, device='cuda')
+        ops.tap_gemm_nt_splitk(d1, dev(x[:m1]), wt, K, dev(b), None, None, a3, None, splits, ws)
+        assert torch.equal(a3, a1[:m1]), 'rows must not depend on the batch around them'
+
+
 @pytest.mark.parametrize("M,K,N", [(300, 64, 128), (1000, 256, 32), (640, 6400, 1536)])
 def test_dense_wgrad(ops, M, K, N):
     rng = np.random.default_rng(5)
