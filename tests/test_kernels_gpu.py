@@ -466,6 +466,35 @@ def test_ctc_saturated_logits_fall_back_to_the_log_domain(ops):
     assert np.abs(g[:125].sum(axis=2)).max() < 1e-4
 
 
+def test_ctc_fallback_from_the_lds_resident_form(ops):
+    """Round 5: an utterance whose lattice fits keeps its emission probabilities in LDS (Tb x (S rounded up to 4, + 4) doubles within
+    the launch's budget: 125 frames x 50 labels here), the others read them from the workspace (200 frames x 64 labels).  Both forms must
+    fall back to the log domain when the linear recursion loses states (saturated softmax), the LDS-resident one by gathering the float
+    inputs into the space its probabilities held; repeated labels, an empty label row and a one-frame utterance ride along."""
+    rng = np.random.default_rng(22)
+    T, B, V = 200, 6, 1536
+    labels = [[int(v) for v in rng.integers(1, 40, 50)], list(rng.permutation(np.arange(1, V - 1))[:64]), [4, 4, 9, 4, 4], [], [11],
+              list(rng.integers(1, V - 1, 32))]
+    seq = [125, 200, 125, 60, 1, 125]
+    x, lab, ll, sl, ml = _ctc_inputs(rng, T, B, V, labels, seq)
+    p = np.zeros((T, 2, V)); p[:, :, V - 1] = 1.0
+    x[:, :2] = np.log(p + 1e-7).astype(np.float32)
+    loss_ref, g_ref = octc.ctc_loss_and_grad(x, labels, seq, V - 1)
+    assert np.all(np.isfinite(loss_ref)) and loss_ref[0] > 650
+    loss = torch.zeros(B, device='cuda')
+    grad = torch.full((T, B, V), 7.0, device='cuda')
+    status = torch.zeros(B, dtype=torch.int32, device='cuda')
+    ws = torch.zeros(ops.ctc_workspace(T, B, ml) // 8 + 8, dtype=torch.float64, device='cuda')
+    for _ in range(2):                         # twice: the workspace of the first call is the second call's starting state
+        ops.ctc_loss(dev(x), T, B, V, dev(lab, torch.int32), ml, dev(ll, torch.int32), dev(sl, torch.int32), V - 1,
+                     loss, grad, status, ws)
+    assert status.cpu().tolist() == [0] * B
+    l, g = loss.cpu().numpy(), grad.cpu().numpy()
+    assert np.all(np.isfinite(l)) and np.all(np.isfinite(g))
+    report('ctc loss (LDS form + fallback)', l, loss_ref, 1e-6)
+    report('ctc grad (LDS form + fallback)', g, g_ref, 2e-6)
+
+
 def test_greedy_decode_bit_exact(ops):
     rng = np.random.default_rng(12)
     T, B, V = 60, 6, 1536
