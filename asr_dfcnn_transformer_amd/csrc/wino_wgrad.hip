@@ -158,9 +158,13 @@ __device__ __forceinline__ void ww4_compute(const WwArgs& a, const char* __restr
         // the two values of a packed register are the same pixel of the two tile pairs (one address register, two immediates)
         ww_f2 da[4], db[4], y0[2], y1[2];
         const unsigned xad = (unsigned)(uintptr_t)(const ww_lds_c*)(xs + xa), zad = (unsigned)(uintptr_t)(const ww_lds_c*)(zs + za);
-#define WW_LD2(dst, ad, off0, off1) { float lo_, hi_;                                                                   \
-        asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4" : "=&v"(lo_), "=&v"(hi_) : "v"(ad), "i"(off0), "i"(off1)); \
-        dst = ww_f2{lo_, hi_}; }
+        // (pixels of 256 bytes -- 64 channels --: the pair is ONE ds_read2st64_b32, whose two offsets count 256-byte units)
+#define WW_LD2(dst, ad, off0, off1) {                                                                                      \
+        if (((off0) & 255) == 0 && ((off1) & 255) == 0 && (off1) < 65536) {                                                \
+            asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=&v"(dst) : "v"(ad), "i"((off0) >> 8), "i"((off1) >> 8)); \
+        } else { float lo_, hi_;                                                                                           \
+            asm volatile("ds_read_b32 %0, %2 offset:%3\n\tds_read_b32 %1, %2 offset:%4" : "=&v"(lo_), "=&v"(hi_) : "v"(ad), "i"(off0), "i"(off1)); \
+            dst = ww_f2{lo_, hi_}; } }
 #define WW_LDX(dst, r, c) WW_LD2(dst, xad, ((r) * C::XP + (c)) * PXB, ((r) * C::XP + (c) + 4) * PXB)
 #define WW_LDZ(dst, p) WW_LD2(dst, zad, (((p) >> 1) * C::ZP + ((p) & 1)) * ZXB, (((p) >> 1) * C::ZP + ((p) & 1) + 4) * ZXB)
         WW_LDX(da[0], RA, 0) WW_LDX(da[1], RA, 1) WW_LDX(da[2], RA, 2) WW_LDX(da[3], RA, 3)
