@@ -385,14 +385,17 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
         // offsets.  All 64 lanes run (the wave sums and the DPP shifts read every lane); the lanes behind the last state's run read a
         // block of zeros and store nothing.  The beta wave stores q_t(s) = beta_t(s) / p_t(s) -- the sum BEFORE the multiplication by
         // p_t(s) -- which is what the occupancy alpha_t(s) beta_t(s) / p_t(s) needs: phase 2 has no division.
-        const int s0 = ln * NPL;
-        const bool act = s0 < SPL;
-        auto run = [&](auto dir) {
+        // States per lane NL: two while the lattice has at most 128 states (half the float64 operations per frame on the serial path:
+        // the wave issues ~25 instead of ~45 instructions per frame), four above.
+        auto run = [&](auto dir, auto npl) {
             constexpr bool fwd = decltype(dir)::value;
+            constexpr int NL = decltype(npl)::value;
+            const int s0 = ln * NL;
+            const bool act = s0 < SPL;
             double* scl = fwd ? sca : scb;
-            bool sk[NPL];
+            bool sk[NL];
 #pragma unroll
-            for (int j = 0; j < NPL; ++j) {
+            for (int j = 0; j < NL; ++j) {
                 const int q = s0 + j;
                 sk[j] = false;
                 if (q < S) {
@@ -404,75 +407,82 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
             const int dp = act ? (fwd ? SPL : -SPL) : 0, dx = fwd ? SW : -SW;
             const double* pp = act ? pl + t0 * SPL + s0 : occ;          // occ[0..3]: zeros
             double* xp = (fwd ? aw : bw) + (long)t0 * SW + s0;
-            double v[NPL], pa[NPL], pb[NPL];
+            double v[NL], pa[NL], pb[NL];
+            auto put = [&](const double (&x)[NL]) {
+                if (act) {
 #pragma unroll
-            for (int j = 0; j < NPL; ++j) {
+                    for (int j = 0; j < NL; j += 2) *(double2*)(xp + j) = double2{x[j], x[j + 1]};
+                }
+            };
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
                 const int q = s0 + j;
                 const bool on = fwd ? (q < 2) : (q >= S - 2);
                 const double p0 = pp[j];                 // (zeros behind S - 1)
                 v[j] = on ? p0 : 0.0;
                 pa[j] = 0.0; pb[j] = 0.0;
             }
-            if (act) {
-                if (fwd) { *(double2*)(xp) = double2{v[0], v[1]}; *(double2*)(xp + 2) = double2{v[2], v[3]}; }
-                else {
-                    // q at the last frame: 1 on the two final states
-                    *(double2*)(xp) = double2{(s0 >= S - 2 && s0 < S) ? 1.0 : 0.0, (s0 + 1 >= S - 2 && s0 + 1 < S) ? 1.0 : 0.0};
-                    *(double2*)(xp + 2) = double2{(s0 + 2 >= S - 2 && s0 + 2 < S) ? 1.0 : 0.0, (s0 + 3 >= S - 2 && s0 + 3 < S) ? 1.0 : 0.0};
-                }
+            if (fwd) put(v);
+            else {
+                double q1[NL];                           // q at the last frame: 1 on the two final states
+#pragma unroll
+                for (int j = 0; j < NL; ++j) q1[j] = (s0 + j >= S - 2 && s0 + j < S) ? 1.0 : 0.0;
+                put(q1);
             }
             if (ln == 0) scl[t0] = 0.0;
             xp += dx;
             if (Tb > 1) {
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) pa[j] = pp[dp + j];
+                for (int j = 0; j < NL; ++j) pa[j] = pp[dp + j];
             }
             if (Tb > 2) {
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) pb[j] = pp[2 * dp + j];
+                for (int j = 0; j < NL; ++j) pb[j] = pp[2 * dp + j];
             }
             pp += 3 * dp;                                // the row of frame k + 2 when frame k is at work
             double lsc = 0.0;
             int t = t0;
             // one frame: the vector times the frame's probabilities pc; then pc is refilled with the probabilities of frame k + 2
-            auto frame = [&](double (&pc)[NPL], int k) {
+            auto frame = [&](double (&pc)[NL], int k) {
                 t += fwd ? 1 : -1;
                 double inv = 1.0;
                 const bool resc = (k % RS) == 0;         // uniform: rescale by the sum of the previous frame's vector
                 if (resc) {
-                    double tot = (v[0] + v[1]) + (v[2] + v[3]), dummy = 0.0;
+                    double tot = NL == 4 ? (v[0] + v[1]) + (v[NL - 2] + v[NL - 1]) : v[0] + v[1], dummy = 0.0;
                     wave_sum2_d(tot, dummy);
                     if (tot > 0.0) { inv = 1.0 / tot; lsc += log(tot); }
                 }
-                double sm[NPL];
+                double sm[NL];
                 if (fwd) {
-                    const double m1 = wave_shr1_d(v[NPL - 1]), m2 = wave_shr1_d(v[NPL - 2]);
-                    sm[0] = (v[0] + m1) + (sk[0] ? m2 : 0.0);
-                    sm[1] = (v[1] + v[0]) + (sk[1] ? m1 : 0.0);
-                    sm[2] = (v[2] + v[1]) + (sk[2] ? v[0] : 0.0);
-                    sm[3] = (v[3] + v[2]) + (sk[3] ? v[1] : 0.0);
+                    // neighbours below: states s0 - 1, s0 - 2 live in lane - 1 (its last two states); lane 0 has none
+                    const double m1 = wave_shr1_d(v[NL - 1]), m2 = wave_shr1_d(v[NL - 2]);
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) {
+                        const double lo1 = j >= 1 ? v[j >= 1 ? j - 1 : 0] : m1;
+                        const double lo2 = j >= 2 ? v[j >= 2 ? j - 2 : 0] : (j == 1 ? m1 : m2);
+                        sm[j] = (v[j] + lo1) + (sk[j] ? lo2 : 0.0);
+                    }
                 } else {
                     const double p1 = wave_shl1_d(v[0]), p2 = wave_shl1_d(v[1]);
-                    sm[3] = (v[3] + p1) + (sk[3] ? p2 : 0.0);
-                    sm[2] = (v[2] + v[3]) + (sk[2] ? p1 : 0.0);
-                    sm[1] = (v[1] + v[2]) + (sk[1] ? v[3] : 0.0);
-                    sm[0] = (v[0] + v[1]) + (sk[0] ? v[2] : 0.0);
+#pragma unroll
+                    for (int j = NL - 1; j >= 0; --j) {
+                        const double hi1 = j + 1 < NL ? v[j + 1 < NL ? j + 1 : 0] : p1;
+                        const double hi2 = j + 2 < NL ? v[j + 2 < NL ? j + 2 : 0] : (j + 1 < NL ? p1 : p2);
+                        sm[j] = (v[j] + hi1) + (sk[j] ? hi2 : 0.0);
+                    }
                 }
                 if (resc) {
 #pragma unroll
-                    for (int j = 0; j < NPL; ++j) sm[j] *= inv;
+                    for (int j = 0; j < NL; ++j) sm[j] *= inv;
                 }
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) v[j] = sm[j] * pc[j];
-                if (act) {
-                    if (fwd) { *(double2*)(xp) = double2{v[0], v[1]}; *(double2*)(xp + 2) = double2{v[2], v[3]}; }
-                    else { *(double2*)(xp) = double2{sm[0], sm[1]}; *(double2*)(xp + 2) = double2{sm[2], sm[3]}; }
-                }
+                for (int j = 0; j < NL; ++j) v[j] = sm[j] * pc[j];
+                if (fwd) put(v); else put(sm);
                 xp += dx;
                 if (ln == 0) scl[t] = lsc;
                 if (k + 2 < Tb) {                        // uniform
 #pragma unroll
-                    for (int j = 0; j < NPL; ++j) pc[j] = pp[j];
+                    for (int j = 0; j < NL; ++j) pc[j] = pp[j];
                 }
                 pp += dp;
             };
@@ -481,10 +491,11 @@ __global__ __launch_bounds__(512) void ctc_lattice_kernel(const float* __restric
             if (k < Tb) frame(pa, k);
             if (fwd) {
 #pragma unroll
-                for (int j = 0; j < NPL; ++j) if (s0 + j < S) abuf0[2 + s0 + j] = v[j];
+                for (int j = 0; j < NL; ++j) if (s0 + j < S) abuf0[2 + s0 + j] = v[j];
             }
         };
-        if (wv == 0) run(std::true_type{}); else run(std::false_type{});
+        if (S <= 128) { if (wv == 0) run(std::true_type{}, std::integral_constant<int, 2>{}); else run(std::false_type{}, std::integral_constant<int, 2>{}); }
+        else { if (wv == 0) run(std::true_type{}, std::integral_constant<int, 4>{}); else run(std::false_type{}, std::integral_constant<int, 4>{}); }
     } else if (fast && wv < 2) {
         const bool fwd = wv == 0;
         double* scl = fwd ? sca : scb;
