@@ -122,25 +122,30 @@ __global__ __launch_bounds__(256) void softmax_log_bwd_vec_kernel(const float* _
 }
 
 // ------------------------------------------------------------------ CTC
-__global__ void ctc_check_kernel(const int32_t* __restrict__ labels, int max_label, const int32_t* __restrict__ label_len,
-                                 const int32_t* __restrict__ seq_len, int T, int B, int32_t* __restrict__ status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+// one wave per (t,b) row: lse of the row (TF's own log-softmax), the dense part of the gradient, softmax(logits), and the emission
+// probabilities of the utterance's lattice states p_t(s) = exp(logit[ext(s)] - lse) in float64 (ext = blank, l1, blank, l2, ...: two
+// exps per lane here instead of eighteen per thread in front of the lattice's serial part); rows at t >= seq_len or of infeasible
+// utterances are zero.  prob rows: [b][t][SW].
+// asr_ctc_loss's status of utterance b (0 ok, 1 infeasible: no valid alignment / bad lengths, 2 a padding row of a short batch), by every row's
+// wave for itself -- two scalar loads and a ballot per 64 labels instead of a launch of its own in front of the row pass (the lattice
+// kernel reads what the t = 0 row wrote)
+__device__ __forceinline__ int ctc_row_status(const int32_t* __restrict__ labels, int max_label, const int32_t* __restrict__ label_len,
+                                              const int32_t* __restrict__ seq_len, int T, int b, int lane) {
     const int L = label_len[b], Tb = seq_len[b];
     int bad = (L < 0 || L > max_label || Tb <= 0 || Tb > T) ? 1 : 0;
     if (Tb == 0 && L == 0) bad = 2;          // padding row of a short batch: loss 0, gradient 0
     if (!bad) {
         int rep = 0;
-        for (int i = 1; i < L; ++i) rep += labels[(long)b * max_label + i] == labels[(long)b * max_label + i - 1];
+        for (int i0 = 1; i0 < L; i0 += 64) {
+            const int i = i0 + lane;
+            const bool same = i < L && labels[(long)b * max_label + i] == labels[(long)b * max_label + i - 1];
+            rep += __popcll(__ballot(same));
+        }
         if (Tb < L + rep) bad = 1;
     }
-    status[b] = bad;
+    return bad;
 }
 
-// one wave per (t,b) row: lse of the row (TF's own log-softmax), the dense part of the gradient, softmax(logits), and the emission
-// probabilities of the utterance's lattice states p_t(s) = exp(logit[ext(s)] - lse) in float64 (ext = blank, l1, blank, l2, ...: two
-// exps per lane here instead of eighteen per thread in front of the lattice's serial part); rows at t >= seq_len or of infeasible
-// utterances are zero.  prob rows: [b][t][SW].
 __device__ __forceinline__ void ctc_row_probs(const float* __restrict__ x, double l, int b, int t, int T, int lane,
                                                const int32_t* __restrict__ labels, int max_label, int L, int blank, int SW,
                                                double* __restrict__ prob) {
@@ -153,7 +158,7 @@ __device__ __forceinline__ void ctc_row_probs(const float* __restrict__ x, doubl
 }
 
 __global__ __launch_bounds__(256) void ctc_rows_kernel(const float* __restrict__ logits, int T, int B, int V,
-                                                       const int32_t* __restrict__ seq_len, const int32_t* __restrict__ status,
+                                                       const int32_t* __restrict__ seq_len, int32_t* __restrict__ status,
                                                        const int32_t* __restrict__ labels, int max_label,
                                                        const int32_t* __restrict__ label_len, int blank, int SW,
                                                        double* __restrict__ lse, float* __restrict__ grad, double* __restrict__ prob) {
@@ -162,7 +167,9 @@ __global__ __launch_bounds__(256) void ctc_rows_kernel(const float* __restrict__
     const int lane = threadIdx.x & 63;
     const int t = row / B, b = row - t * B;
     float* gr = grad + (long)row * V;
-    if (status[b] != 0 || t >= seq_len[b]) {
+    const int st = ctc_row_status(labels, max_label, label_len, seq_len, T, b, lane);
+    if (t == 0 && lane == 0) status[b] = st;
+    if (st != 0 || t >= seq_len[b]) {
         for (int k = lane; k < V; k += 64) gr[k] = 0.f;
         if (lane == 0) lse[row] = 0.0;
         return;
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256) void ctc_rows_kernel(const float* __restrict__
 // the same with the row in registers (V % 4 == 0, V <= 64 x 4 x NV): one 16-byte load per 16 bytes instead of three 4-byte loads
 template <int NV>
 __global__ __launch_bounds__(256) void ctc_rows_vec_kernel(const float* __restrict__ logits, int T, int B, int V,
-                                                           const int32_t* __restrict__ seq_len, const int32_t* __restrict__ status,
+                                                           const int32_t* __restrict__ seq_len, int32_t* __restrict__ status,
                                                            const int32_t* __restrict__ labels, int max_label,
                                                            const int32_t* __restrict__ label_len, int blank, int SW,
                                                            double* __restrict__ lse, float* __restrict__ grad, double* __restrict__ prob) {
@@ -194,7 +201,9 @@ __global__ __launch_bounds__(256) void ctc_rows_vec_kernel(const float* __restri
     const int t = row / B, b = row - t * B;
     const int n4 = V >> 2;
     float4* g4 = (float4*)(grad + (long)row * V);
-    if (status[b] != 0 || t >= seq_len[b]) {
+    const int st = ctc_row_status(labels, max_label, label_len, seq_len, T, b, lane);
+    if (t == 0 && lane == 0) status[b] = st;
+    if (st != 0 || t >= seq_len[b]) {
         for (int k4 = lane; k4 < n4; k4 += 64) g4[k4] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (lane == 0) lse[row] = 0.0;
         return;
@@ -941,11 +950,10 @@ extern "C" int asr_ctc_loss(const float* logits_tm, int T, int B, int V, const i
         (void)hipFuncSetAttribute((const void*)ctc_lattice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(ctc_check_kernel, dim3(asr_cdiv(B, 64)), dim3(64), 0, st, labels, max_label, label_len, seq_len, T, B, status);
     const int SW = (int)ctc_ws_pitch(max_label);
     const dim3 rg(asr_cdiv((long)T * B, 4)), rb(256);
     const bool vec = (V & 3) == 0 && V <= 64 * 4 * 8 && ((((uintptr_t)logits_tm) | ((uintptr_t)grad)) & 15) == 0;
-#define ASR_CTC_ROWS_ARGS logits_tm, T, B, V, seq_len, (const int32_t*)status, labels, max_label, label_len, blank, SW, lse, grad, prob_ws
+#define ASR_CTC_ROWS_ARGS logits_tm, T, B, V, seq_len, status, labels, max_label, label_len, blank, SW, lse, grad, prob_ws
     if (vec && V <= 64 * 4 * 4) hipLaunchKernelGGL(ctc_rows_vec_kernel<4>, rg, rb, 0, st, ASR_CTC_ROWS_ARGS);
     else if (vec && V <= 64 * 4 * 6) hipLaunchKernelGGL(ctc_rows_vec_kernel<6>, rg, rb, 0, st, ASR_CTC_ROWS_ARGS);
     else if (vec) hipLaunchKernelGGL(ctc_rows_vec_kernel<8>, rg, rb, 0, st, ASR_CTC_ROWS_ARGS);

@@ -757,15 +757,23 @@ class DFCNNEngine:
                 ops.ctc_greedy(self.logits, T8, B, V, self.seq_len, V - 1, self.dec_ids, self.dec_len, self.neg_sum, self.dec_ws)
                 ops.edit_distance(self.dec_ids, T8, self.dec_len, self.labels, MAX_LABEL, self.label_len, B, self.dist)
                 ops.colsum(self.dist, B, 1, 1, self.scalars[1:2], self.ws_side)
-                self._decode_done = torch.cuda.Event()
-                self._decode_done.record()
         ops.ctc_loss(self.logits, T8, B, V, self.labels, MAX_LABEL, self.label_len, self.seq_len, V - 1,
                      self.loss, self.ctc_grad, self.ctc_status, self.ctc_ws)
         if side is None:
             ops.ctc_greedy(self.logits, T8, B, V, self.seq_len, V - 1, self.dec_ids, self.dec_len, self.neg_sum, self.dec_ws)
             ops.edit_distance(self.dec_ids, T8, self.dec_len, self.labels, MAX_LABEL, self.label_len, B, self.dist)
             ops.colsum(self.dist, B, 1, 1, self.scalars[1:2], self.ws)
-        ops.colsum(self.loss, B, 1, 1, self.scalars[0:1], self.ws)
+            ops.colsum(self.loss, B, 1, 1, self.scalars[0:1], self.ws)
+        else:
+            # the sum of the per-utterance losses is a fetch, not an input of the backward pass: on the second stream behind the decode
+            # (one launch and its gap less between the lattice and the head's backward); _decode_done covers both
+            loss_ready = torch.cuda.Event()
+            loss_ready.record()
+            side.wait_event(loss_ready)
+            with torch.cuda.stream(side):
+                ops.colsum(self.loss, B, 1, 1, self.scalars[0:1], self.ws_side)
+                self._decode_done = torch.cuda.Event()
+                self._decode_done.record()
         if side is not None and not defer_decode_join:
             torch.cuda.current_stream().wait_event(self._decode_done)
 
