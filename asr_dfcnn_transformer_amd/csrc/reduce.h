@@ -75,9 +75,9 @@ static __global__ __launch_bounds__(256) void colsum_tall_kernel(const float* __
 // through LDS in a fixed order.  Split partials go to the two-level pass's second level.
 constexpr int kStripMinRows = 1024;
 
-inline bool colsum_is_strip(int rows, int cols) { return rows >= kStripMinRows && (cols & 63) == 0 && !colsum_is_tall(rows, cols); }
+inline bool colsum_is_strip(int rows, int cols) { return rows >= kStripMinRows && (cols & 3) == 0 && cols >= 64 && !colsum_is_tall(rows, cols); }
 inline int colsum_strip_splits(int rows, int cols) {
-    int ns = 2048 / (cols / 64);
+    int ns = 2048 / ((cols + 63) / 64);
     if (ns > kSplits) ns = kSplits;
     if (ns > rows / 64) ns = rows / 64;
     return ns < 1 ? 1 : ns;
@@ -91,6 +91,7 @@ static __global__ __launch_bounds__(256) void colsum_strip_kernel(const float* _
     const int r0 = blockIdx.y * rows_per_split;
     int r1 = r0 + rows_per_split;
     if (r1 > rows) r1 = rows;
+    if (blockIdx.x * 64 + ct * 4 >= cols) r1 = r0;     // the last strip of a width that is no multiple of 64 (cols % 4 == 0): these lanes own no column
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
     int r = r0 + rl;
     for (; r + 48 < r1; r += 64) {
@@ -114,7 +115,7 @@ static __global__ __launch_bounds__(256) void colsum_strip_kernel(const float* _
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += red[k * 64 + threadIdx.x];
-        partial[(long)blockIdx.y * cols + blockIdx.x * 64 + threadIdx.x] = t;
+        if (blockIdx.x * 64 + threadIdx.x < cols) partial[(long)blockIdx.y * cols + blockIdx.x * 64 + threadIdx.x] = t;
     }
 }
 
@@ -137,7 +138,7 @@ inline int colsum(const float* x, int rows, int cols, long ldx, float* out, floa
     if (strip) {
         const int rps = asr_cdiv(rows, colsum_strip_splits(rows, cols));
         const int ns = asr_cdiv(rows, rps);
-        hipLaunchKernelGGL(colsum_strip_kernel, dim3(cols / 64, ns), dim3(256), 0, st, x, rows, cols, ldx, rps, tmp);
+        hipLaunchKernelGGL(colsum_strip_kernel, dim3(asr_cdiv(cols, 64), ns), dim3(256), 0, st, x, rows, cols, ldx, rps, tmp);
         hipLaunchKernelGGL(colsum_pass_kernel, dim3(gx, 1), dim3(threads), 0, st, (const float*)tmp, ns, cols, (long)cols, ns, out, (long)cols);
     } else if (rows <= kSplits) {
         hipLaunchKernelGGL(colsum_pass_kernel, dim3(gx, 1), dim3(threads), 0, st, x, rows, cols, ldx, rows, out, (long)cols);

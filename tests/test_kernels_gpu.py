@@ -575,6 +575,23 @@ def test_colsum_and_relu_bwd(ops):
     assert np.array_equal(dz.cpu().numpy(), dy * (h > 0))
 
 
+@pytest.mark.parametrize("rows,cols,ld", [(6400, 1536, 1536), (4096, 6348, 6348), (1024, 64, 64), (1500, 68, 72), (20000, 2048, 2048),
+                                          (32768, 512, 512), (70, 1000, 1000), (3000, 300, 300), (1030, 132, 136)])
+def test_colsum_forms(ops, rows, cols, ld):
+    """asr_colsum picks one of three forms by shape -- tall (float4 rows, >= 16384 rows), strips of 64 columns x row splits (round 5: wide
+    matrices of a few thousand rows, a last strip may be partial), a column per thread -- each against float64 and bitwise reproducible;
+    a row pitch larger than the width is honoured."""
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((rows, ld)).astype(np.float32)
+    out = torch.full((cols,), 7.0, device='cuda'); out2 = torch.zeros(cols, device='cuda')
+    ws = torch.zeros(ops.colsum_workspace(rows, cols) // 4 + 4, device='cuda')
+    xd = dev(x)
+    ops.colsum(xd, rows, cols, ld, out, ws)
+    ops.colsum(xd, rows, cols, ld, out2, ws)
+    report('colsum %d x %d' % (rows, cols), out.cpu().numpy(), x[:, :cols].astype(np.float64).sum(axis=0), 2e-5 * math.sqrt(rows / 1000.0 + 1))
+    assert torch.equal(out, out2)
+
+
 # ------------------------------------------------------------------ fbank
 def test_fbank_matches_oracle():
     from asr_dfcnn_transformer_amd import wav_util
