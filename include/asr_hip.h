@@ -240,7 +240,12 @@ int asr_colsum(const float* x, int rows, int cols, int ldx, float* out, float* p
  *   2 = padding row: seq_len[b] == 0 and label_len[b] == 0 mark a row that is not part of
  *   the batch (the reference feeds B' <= B surviving rows, lm_and_am/data_loader.py:149-156;
  *   a fixed-size device batch carries the missing rows as padding): loss = 0, grad = 0.
- * workspace: asr_ctc_workspace() bytes.  alpha/beta recursion runs in float64.
+ * workspace: asr_ctc_workspace() bytes, 16-byte aligned.  alpha/beta recursion runs in float64.
+ * Two launches since round 5 (was three): the row pass (log-sum-exp of every frame, the dense softmax term of the gradient, the
+ * emission probabilities of the utterance's lattice states, and the status -- each row's wave checks its own utterance), then one
+ * workgroup per utterance: probabilities into LDS when Tb x (S rounded up to 4, + 4) doubles fit the launch's 144 KB budget, one
+ * wave each for alpha / beta (two states per lane up to 128 states), occupancies without a division (the beta wave stores
+ * beta / p); utterances whose linear-domain lattice loses states are redone in the log domain inside the same launch.
  */
 size_t asr_ctc_workspace(int T, int B, int max_label);
 int asr_ctc_loss(const float* logits_tm, int T, int B, int V, const int32_t* labels, int max_label,
