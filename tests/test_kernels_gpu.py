@@ -495,6 +495,39 @@ def test_ctc_fallback_from_the_lds_resident_form(ops):
     report('ctc grad (LDS form + fallback)', g, g_ref, 2e-6)
 
 
+@pytest.mark.parametrize("seed,T,V", [(101, 200, 1536), (102, 97, 50), (103, 200, 333)])
+def test_ctc_random_batches(ops, seed, T, V):
+    """Twenty-four utterances of random length, label count (0 .. 64) and label repetition per launch, against the float64 oracle: short and
+    long lattices in one batch take different forms inside the kernel (two or four states per lane, probabilities in LDS or in the
+    workspace), utterances at the edge of feasibility (frames = labels + repeats) and single-frame ones included."""
+    rng = np.random.default_rng(seed)
+    B = 24
+    labels, seq = [], []
+    for b in range(B):
+        L = int(rng.integers(0, 65)) if b % 3 else int(rng.choice([0, 1, 2, 31, 32, 33, 63, 64]))
+        L = min(L, T // 2)
+        alphabet = int(rng.choice([2, 5, V - 1]))                  # few symbols: many repeats
+        lab = [int(v) for v in rng.integers(0, min(alphabet, V - 1), L)]
+        rep = sum(1 for i in range(1, L) if lab[i] == lab[i - 1])
+        need = max(1, L + rep)
+        s_ = need if b % 4 == 0 else int(rng.integers(need, T + 1))
+        labels.append(lab); seq.append(min(s_, T))
+    x, lab, ll, sl, ml = _ctc_inputs(rng, T, B, V, labels, seq)
+    loss_ref, g_ref = octc.ctc_loss_and_grad(x, labels, seq, V - 1)
+    loss = torch.zeros(B, device='cuda')
+    grad = torch.full((T, B, V), 7.0, device='cuda')
+    status = torch.zeros(B, dtype=torch.int32, device='cuda')
+    ws = torch.zeros(ops.ctc_workspace(T, B, ml) // 8 + 8, dtype=torch.float64, device='cuda')
+    ops.ctc_loss(dev(x), T, B, V, dev(lab, torch.int32), ml, dev(ll, torch.int32), dev(sl, torch.int32), V - 1,
+                 loss, grad, status, ws)
+    assert status.cpu().tolist() == [0] * B
+    report('ctc loss, random batch', loss.cpu().numpy(), loss_ref, 1e-6)
+    report('ctc grad, random batch', grad.cpu().numpy(), g_ref, 2e-6)
+    g2 = torch.full((T, B, V), 3.0, device='cuda'); l2 = torch.zeros(B, device='cuda')
+    ops.ctc_loss(dev(x), T, B, V, dev(lab, torch.int32), ml, dev(ll, torch.int32), dev(sl, torch.int32), V - 1, l2, g2, status, ws)
+    assert torch.equal(g2, grad) and torch.equal(l2, loss), 'asr_ctc_loss must be bitwise reproducible'
+
+
 def test_greedy_decode_bit_exact(ops):
     rng = np.random.default_rng(12)
     T, B, V = 60, 6, 1536
