@@ -12,6 +12,6 @@ static thread_local const char* g_last_kernel = "";
 
 void asr_set_last_kernel(const char* name) { g_last_kernel = name; }
 
-extern "C" int asr_version(void) { return 101; }
+extern "C" int asr_version(void) { return 102; }          // 102: asr_tap_gemm_nt_splitk, the larger asr_ctc_workspace (round 5)
 extern "C" const char* asr_last_kernel(void) { return g_last_kernel; }
 extern "C" const char* asr_last_error(void) { return g_err; }
