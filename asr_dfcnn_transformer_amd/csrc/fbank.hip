@@ -297,13 +297,15 @@ __global__ __launch_bounds__(256) void fbank_logmel_v2_kernel(const float* __res
 // scale v2: one workgroup per (utterance, 8 columns): 8 columns x 32 time slices; a thread keeps its <= RMAX rows of the
 // column in registers, so the float64 log-energies are read ONCE and the four sklearn passes (mean, variance + first-order
 // correction, re-centre, write) run from registers.  Same arithmetic and summation order per slice as the v1 kernel.
+// (round 5: SIXTEEN columns per workgroup, 512 threads -- a row segment is a whole 128-byte line instead of half of one that a second
+//  workgroup fetched again: 38 -> ~25 us; per column the same slices, rows and summation order as with eight)
 template <int RMAX>
-__global__ __launch_bounds__(256) void fbank_scale_v2_kernel(const double* __restrict__ logfb, const int32_t* __restrict__ frames,
+__global__ __launch_bounds__(512) void fbank_scale_v2_kernel(const double* __restrict__ logfb, const int32_t* __restrict__ frames,
                                                              int max_frames, int nfilt, float* __restrict__ out, int t_pad) {
-    __shared__ double red[32][8];
-    const int tid = threadIdx.x, cl = tid & 7, ts = tid >> 3;
+    __shared__ double red[32][16];
+    const int tid = threadIdx.x, cl = tid & 15, ts = tid >> 4;
     const int b = blockIdx.y;
-    const int col = blockIdx.x * 8 + cl;
+    const int col = blockIdx.x * 16 + cl;
     const bool ok = col < nfilt;
     int nf = frames[b];
     if (nf > t_pad) nf = t_pad;
@@ -422,10 +424,10 @@ extern "C" int asr_fbank(const float* signal, const int32_t* nsamples, int B, in
     }
     const int tmax = max_frames < t_pad ? max_frames : t_pad;          // rows a column can have
     if (tmax <= 32 * 32) {
-        hipLaunchKernelGGL(fbank_scale_v2_kernel<32>, dim3(asr_cdiv(nfilt, 8), B), dim3(256), 0, st, (const double*)logfb,
+        hipLaunchKernelGGL(fbank_scale_v2_kernel<32>, dim3(asr_cdiv(nfilt, 16), B), dim3(512), 0, st, (const double*)logfb,
                            (const int32_t*)frames, max_frames, nfilt, out, t_pad);
     } else if (tmax <= 32 * 64) {
-        hipLaunchKernelGGL(fbank_scale_v2_kernel<64>, dim3(asr_cdiv(nfilt, 8), B), dim3(256), 0, st, (const double*)logfb,
+        hipLaunchKernelGGL(fbank_scale_v2_kernel<64>, dim3(asr_cdiv(nfilt, 16), B), dim3(512), 0, st, (const double*)logfb,
                            (const int32_t*)frames, max_frames, nfilt, out, t_pad);
     } else {
         hipLaunchKernelGGL(fbank_scale_kernel, dim3(asr_cdiv(nfilt, 32), B), dim3(256), 0, st, (const double*)logfb,
