@@ -158,14 +158,33 @@ __global__ __launch_bounds__(256) void fbank_logmel_v2_kernel(const float* __res
     if (blockIdx.x == 0 && tid == 0) frames_out[b] = nf;
     tw[tid].x = twiddle[2 * tid]; tw[tid].y = twiddle[2 * tid + 1];
     for (int i = tid; i < nfilt * fb_width; i += 256) fbw[i] = fb_weight[i];
-    // this lane's filters (j = lane, lane + 64, ...) do not change from frame to frame
+    // This lane's filters do not change from frame to frame.  Round 5: the filters that HAVE taps are dealt to the lanes densely (lane,
+    // lane + 64, ... of their ascending list) -- 157 of 200 at nfilt 200, i.e. three groups of 64 instead of four: a float64 log per
+    // group and frame is half of this kernel's vector work -- and the empty ones only get their constant stored.
     constexpr int JMAX = 4;                                            // nfilt <= 256
-    int fst[JMAX], fcn[JMAX];
+    __shared__ short nzl[256], ezl[256];
+    __shared__ int wcnt[2][4];
+    const bool isf = tid < nfilt;
+    const bool nzf = isf && fb_count[tid] > 0;
+    {
+        const unsigned long long mnz = __ballot(nzf), mez = __ballot(isf && !nzf);
+        if (lane == 0) { wcnt[0][wave] = __popcll(mnz); wcnt[1][wave] = __popcll(mez); }
+        __syncthreads();
+        int onz = 0, oez = 0;
+        for (int w = 0; w < wave; ++w) { onz += wcnt[0][w]; oez += wcnt[1][w]; }
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (nzf) nzl[onz + __popcll(mnz & below)] = (short)tid;
+        else if (isf) ezl[oez + __popcll(mez & below)] = (short)tid;
+    }
+    __syncthreads();
+    const int nnz = wcnt[0][0] + wcnt[0][1] + wcnt[0][2] + wcnt[0][3], nez = wcnt[1][0] + wcnt[1][1] + wcnt[1][2] + wcnt[1][3];
+    int fj[JMAX], fst[JMAX], fcn[JMAX];
 #pragma unroll
     for (int r = 0; r < JMAX; ++r) {
-        const int j = lane + 64 * r;
-        fst[r] = (j < nfilt) ? fb_start[j] : 0;
-        fcn[r] = (j < nfilt) ? fb_count[j] : 0;
+        const int idx = lane + 64 * r;
+        fj[r] = idx < nnz ? (int)nzl[idx] : -1;
+        fst[r] = fj[r] >= 0 ? fb_start[fj[r]] : 0;
+        fcn[r] = fj[r] >= 0 ? fb_count[fj[r]] : 0;
     }
     const double log_eps = log(2.220446049250313e-16);                 // what an empty filter yields (43 of 200 at nfilt 200)
     __syncthreads();
@@ -280,8 +299,9 @@ __global__ __launch_bounds__(256) void fbank_logmel_v2_kernel(const float* __res
         double* o = logfb + ((long)b * max_frames + f) * nfilt;
 #pragma unroll
         for (int r = 0; r < JMAX; ++r) {
-            const int j = lane + 64 * r;
-            if (j < nfilt) {
+            if (64 * r >= nnz) break;                          // (uniform) no filter in this group
+            const int j = fj[r];
+            if (j >= 0) {
                 // the table rows are zero beyond a filter's own taps: a zero weight leaves e unchanged (fma(x, 0, e) == e),
                 // so all fb_width taps are taken, with the bin index clamped to the last one
                 const double* wrow = fbw + j * fb_width;
@@ -290,6 +310,7 @@ __global__ __launch_bounds__(256) void fbank_logmel_v2_kernel(const float* __res
                 o[j] = (e == 0.0) ? log_eps : log(e);
             }
         }
+        for (int idx = lane; idx < nez; idx += 64) o[ezl[idx]] = log_eps;
         wave_lds_sync();                                       // ps / A are rewritten by the next frame
     }
 }

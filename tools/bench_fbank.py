@@ -1,6 +1,9 @@
 """Times asr_fbank (log-mel + standardisation) on the bench batch: 32 x 10 s of 16 kHz audio, 200 mel bins, T_pad 1600."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from asr_dfcnn_transformer_amd import _lib
+if os.environ.get('LIB'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['LIB'])
 import numpy as np, torch
 from asr_dfcnn_transformer_amd.wav_util import FbankExtractor
 B, ns, T = 32, 160000, 1600
