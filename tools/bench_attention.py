@@ -1,6 +1,9 @@
 """Times asr_attention_fwd/bwd (causal and not) on random ReLU'd projections; run on the GPU box."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from asr_dfcnn_transformer_amd import _lib
+if os.environ.get('LIB'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['LIB'])
 import torch
 from asr_dfcnn_transformer_amd import ops
 
