@@ -82,6 +82,10 @@ SIGNATURES = {
     'asr_attention_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint, _P, _P, _P, _P, _P]),
     'asr_attention_fwd_p': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint, _P, _P, _P]),
     'asr_attention_bwd_p': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint, _P, _P, _P, _P, _P]),
+    'asr_attention_stats_floats': (_Z, [_I, _I, _I, _I]),
+    'asr_attention_stats': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P]),
+    'asr_attention_fwd_s': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint, _P, _P, _P, _P]),
+    'asr_attention_bwd_s': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _F, C.c_uint, _P, _P, _P, _P, _P, _P]),
     'asr_copy2d': (_I, [_P, _I, _P, _I, _I, _I, _I, _P]),
     'asr_copy2d_batch': (_I, [_P, _I, _I, _I, _P]),
     'asr_transpose_batch': (_I, [_P, _I, _I, _P]),

@@ -161,6 +161,40 @@ __device__ __forceinline__ void at_row_stats(float* stat, const float* __restric
     }
 }
 
+// The same two statistics for EVERY (sample, head, row) in one pass (asr_attention_stats, round 5): the kernels above recompute them per
+// workgroup -- 4 to 16 workgroups of a (sample, head) each read its whole K (or Q) slice again, 6-12 % of their time
+// (profiles/r05_attention_row_stats_probe.txt) -- or take them from here.  blockIdx.y = 0: query mask of Q, 1: key bias of K; sixteen
+// lanes per (row, head) slice, the reduction order of at_row_stats: the same values.
+__global__ __launch_bounds__(256) void attn_stats_kernel(const float* __restrict__ Q, const float* __restrict__ K, int N, int Tq, int Tk,
+                                                         int H, int ldq, int ldk, float* __restrict__ qm, float* __restrict__ kb) {
+    const bool keys = blockIdx.y == 1;
+    const float* X = keys ? K : Q;
+    const int T = keys ? Tk : Tq, ld = keys ? ldk : ldq;
+    const long total = (long)N * T * H;
+    const long g = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int c4 = threadIdx.x & 15;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int head = 0; long row = 0;
+    if (g < total) {
+        head = (int)(g % H); row = g / H;
+        v = *(const float4*)(X + row * ld + head * DH + c4 * 4);
+    }
+    float s = keys ? (v.x + v.y + v.z + v.w) : (fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w));
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (g < total && c4 == 0) {
+        const int n = (int)(row / T), t = (int)(row - (long)n * T);
+        float* out = keys ? kb : qm;
+        out[((long)n * H + head) * T + t] = keys ? (s != 0.f ? INFINITY : FILL2) : (s != 0.f ? 1.f : 0.f);
+    }
+}
+
+// a (sample, head)'s precomputed statistics into LDS, padded like at_row_stats pads (MODE 0: -inf past the end, MODE 1: 0)
+template <int MODE>
+__device__ __forceinline__ void at_row_stats_load(float* stat, const float* __restrict__ pre, int T, int T64, int tid) {
+    for (int r = tid; r < T64; r += 256) stat[r] = r < T ? pre[r] : (MODE == 0 ? -INFINITY : 0.f);
+}
+
 // ------------------------------------------------------------------ attention forward
 #if __HIP_DEVICE_COMPILE__
 // one 64-key tile out of (Kc, Vc); first the DMA of the next tile into (Kn, Vn).  __restrict__ parameters of an inlined
@@ -249,7 +283,8 @@ template <bool CAUSAL, bool DROP, int TK>
 __global__ __launch_bounds__(256, TK == 64 ? 2 : 3) void attn_fwd_kernel(const float* __restrict__ Q, const float* __restrict__ K,
                                                        const float* __restrict__ V, float* __restrict__ O,
                                                        float* __restrict__ lse, int Tq, int Tk, int C, int H, int ldq, int ldk,
-                                                       uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
+                                                       uint32_t drop_thr, uint32_t drop_seed, float drop_scale,
+                                                       const float* __restrict__ kstat) {
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) float at_smem[];
     constexpr int TF = TK * 64;                          // floats of one tile
@@ -284,7 +319,8 @@ __global__ __launch_bounds__(256, TK == 64 ? 2 : 3) void attn_fwd_kernel(const f
     }
     qabs += __shfl_xor(qabs, 32, 64);
     const float qmask = (qabs != 0.f) ? 1.f : 0.f;
-    at_row_stats<0>(kb, K, kbase, Tk, (Tk + 63) / 64 * 64, ldk, hoff, tid);
+    if (kstat) at_row_stats_load<0>(kb, kstat + ((long)n * H + head) * Tk, Tk, (Tk + 63) / 64 * 64, tid);
+    else at_row_stats<0>(kb, K, kbase, Tk, (Tk + 63) / 64 * 64, ldk, hoff, tid);
 
     floatx16 oacc[2];
 #pragma unroll
@@ -430,7 +466,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
                                                           const float* __restrict__ lse, const float* __restrict__ delta,
                                                           float* __restrict__ dK, float* __restrict__ dV,
                                                           int Tq, int Tk, int C, int H, int ldq, int ldk, int relu_grad,
-                                                          uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
+                                                          uint32_t drop_thr, uint32_t drop_seed, float drop_scale,
+                                                          const float* __restrict__ qstat) {
 #if __HIP_DEVICE_COMPILE__
     constexpr int QT = 32;                       // queries per tile
     constexpr int TF = QT * 64;
@@ -452,7 +489,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
     const long lrow = ((long)n * H + head) * Tq;
 
     // query mask (1 / 0) into del_a for the moment, then the three statistics
-    at_row_stats<1>(del_a, Q, qbase, Tq, Tq64, ldq, hoff, tid);
+    if (qstat) at_row_stats_load<1>(del_a, qstat + lrow, Tq, Tq64, tid);
+    else at_row_stats<1>(del_a, Q, qbase, Tq, Tq64, ldq, hoff, tid);
     __syncthreads();
     bool degenerate = false;                     // a query before this key block whose visible keys were all masked
     const int kfirst_blk = ktile * 128;
@@ -595,7 +633,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
                                                          const float* __restrict__ V, const float* __restrict__ dO,
                                                          const float* __restrict__ lse, const float* __restrict__ delta,
                                                          float* __restrict__ dQ, int Tq, int Tk, int C, int H, int ldq, int ldk, int relu_grad,
-                                                         uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
+                                                         uint32_t drop_thr, uint32_t drop_seed, float drop_scale,
+                                                         const float* __restrict__ kstat) {
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) float at_smem[];
     constexpr int TF = TK * 64;                          // floats of one tile
@@ -639,7 +678,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
     const float my_lse = (q < Tq) ? lse[((long)n * H + head) * Tq + q] : INFINITY;
     const float my_lsl = (q < Tq) ? lse[(long)Nn * H * Tq + ((long)n * H + head) * Tq + q] : 0.f;
     const float my_del = (q < Tq) ? delta[((long)n * H + head) * Tq + q] : 0.f;
-    at_row_stats<0>(kb, K, kbase, Tk, (Tk + 63) / 64 * 64, ldk, hoff, tid);
+    if (kstat) at_row_stats_load<0>(kb, kstat + ((long)n * H + head) * Tk, Tk, (Tk + 63) / 64 * 64, tid);
+    else at_row_stats<0>(kb, K, kbase, Tk, (Tk + 63) / 64 * 64, ldk, hoff, tid);
 
     floatx16 dq[2];
 #pragma unroll
@@ -664,10 +704,25 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
 }  // namespace
 
 // ===================================================================== C ABI
-extern "C" int asr_attention_fwd_p(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
-                                   int ldq, int ldk, int causal, float dropout_rate, unsigned int seed, float* O, float* lse,
+// stats: [N][H][Tq] query masks, then [N][H][Tk] key biases (asr_attention_stats)
+extern "C" size_t asr_attention_stats_floats(int N, int Tq, int Tk, int H) { return (size_t)N * H * ((size_t)Tq + Tk); }
+
+extern "C" int asr_attention_stats(const float* Q, const float* K, int N, int Tq, int Tk, int C, int H, int ldq, int ldk, float* stats,
                                    void* stream) {
+    if (!Q || !K || !stats || N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
+    if (ldq < C || ldk < C || (ldq & 3) || (ldk & 3) || ((((uintptr_t)Q) | ((uintptr_t)K)) & 15)) return ASR_ERR_BAD_ARG;
+    const long groups = (long)N * H * (Tq > Tk ? Tq : Tk);
+    hipLaunchKernelGGL(attn_stats_kernel, dim3(asr_cdiv(groups * 16, 256), 2), dim3(256), 0, (hipStream_t)stream, Q, K, N, Tq, Tk, H, ldq, ldk,
+                       stats, stats + (size_t)N * H * Tq);
+    ASR_CHECK_LAUNCH("attention_stats");
+    return ASR_OK;
+}
+
+extern "C" int asr_attention_fwd_s(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
+                                   int ldq, int ldk, int causal, float dropout_rate, unsigned int seed, float* O, float* lse,
+                                   const float* stats, void* stream) {
     if (!Q || !K || !V || !O || !lse || N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
+    const float* kst = stats ? stats + (size_t)N * H * Tq : nullptr;
     if (ldq < C || ldk < C || (ldq & 3) || (ldk & 3)) return ASR_ERR_BAD_ARG;
     if (dropout_rate < 0.f || dropout_rate >= 1.f || (double)N * H * Tq * Tk >= 4294967296.0) return ASR_ERR_BAD_ARG;
     dim3 grid(asr_cdiv(Tq, 128), H, N), grid_causal(N * H, asr_cdiv(Tq, 128), 1);      // see attn_block_coords
@@ -683,7 +738,7 @@ extern "C" int asr_attention_fwd_p(const float* Q, const float* K, const float* 
         auto kern = attn_fwd_kernel<CA, DR, ATK>;                                                                                \
         static size_t have = 0;           /* a kernel with static LDS too (__syncthreads_and) rejects the 160 KB blanket request */ \
         if (lds > have) { if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { (void)hipGetLastError(); return ASR_ERR_UNSUPPORTED; } have = lds; } \
-        hipLaunchKernelGGL(kern, G, dim3(256), lds, st, Q, K, V, O, lse, Tq, Tk, C, H, ldq, ldk, thr, seed, sc);                \
+        hipLaunchKernelGGL(kern, G, dim3(256), lds, st, Q, K, V, O, lse, Tq, Tk, C, H, ldq, ldk, thr, seed, sc, kst);           \
     } while (0)
     if (dropout_rate > 0.f) {
         if (causal) ASR_ATTN_FWD(true, true, grid_causal); else ASR_ATTN_FWD(false, true, grid);
@@ -695,16 +750,24 @@ extern "C" int asr_attention_fwd_p(const float* Q, const float* K, const float* 
     return ASR_OK;
 }
 
+extern "C" int asr_attention_fwd_p(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
+                                   int ldq, int ldk, int causal, float dropout_rate, unsigned int seed, float* O, float* lse,
+                                   void* stream) {
+    return asr_attention_fwd_s(Q, K, V, N, Tq, Tk, C, H, ldq, ldk, causal, dropout_rate, seed, O, lse, nullptr, stream);
+}
+
 extern "C" int asr_attention_fwd(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
                                  int causal, float dropout_rate, unsigned int seed, float* O, float* lse, void* stream) {
     return asr_attention_fwd_p(Q, K, V, N, Tq, Tk, C, H, C, C, causal, dropout_rate, seed, O, lse, stream);
 }
 
-extern "C" int asr_attention_bwd_p(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+extern "C" int asr_attention_bwd_s(const float* Q, const float* K, const float* V, const float* O, const float* dO,
                                    const float* lse, int N, int Tq, int Tk, int C, int H, int ldq, int ldk, int causal,
                                    int relu_grad, float dropout_rate, unsigned int seed,
-                                   float* dQ, float* dK, float* dV, float* delta_ws, void* stream) {
+                                   float* dQ, float* dK, float* dV, float* delta_ws, const float* stats, void* stream) {
     if (ldq < C || ldk < C || (ldq & 3) || (ldk & 3)) return ASR_ERR_BAD_ARG;
+    const float* qst = stats;
+    const float* kst = stats ? stats + (size_t)N * H * Tq : nullptr;
     if (!Q || !K || !V || !O || !dO || !lse || !dQ || !dK || !dV || !delta_ws) return ASR_ERR_BAD_ARG;
     if (N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
     if (dropout_rate < 0.f || dropout_rate >= 1.f || (double)N * H * Tq * Tk >= 4294967296.0) return ASR_ERR_BAD_ARG;
@@ -728,12 +791,12 @@ extern "C" int asr_attention_bwd_p(const float* Q, const float* K, const float* 
         static size_t havekv = 0;                                                                                              \
         if (ldskv > havekv) { if (hipFuncSetAttribute((const void*)kkv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldskv) != hipSuccess) { (void)hipGetLastError(); return ASR_ERR_UNSUPPORTED; } havekv = ldskv; } \
         hipLaunchKernelGGL(kkv, GKV, dim3(256), ldskv, st, Q, K, V, dO, lse, dl, dK, dV, Tq, Tk, C, H,                          \
-                           ldq, ldk, relu_grad, thr, seed, sc);                                                                          \
+                           ldq, ldk, relu_grad, thr, seed, sc, qst);                                                                     \
         auto kq = attn_bwd_q_kernel<CA, DR, 32>;                                                                               \
         static size_t have = 0;                                                                                                \
         if (ldsq > have) { if (hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess) { (void)hipGetLastError(); return ASR_ERR_UNSUPPORTED; } have = ldsq; } \
         hipLaunchKernelGGL(kq, GQ, dim3(256), ldsq, st, Q, K, V, dO, lse, dl, dQ, Tq, Tk, C, H,                                  \
-                           ldq, ldk, relu_grad, thr, seed, sc);                                                                          \
+                           ldq, ldk, relu_grad, thr, seed, sc, kst);                                                                     \
     } while (0)
     if (dropout_rate > 0.f) {
         if (causal) ASR_ATTN_BWD(true, true, ckv, cq); else ASR_ATTN_BWD(false, true, gkv, gq);
@@ -743,6 +806,14 @@ extern "C" int asr_attention_bwd_p(const float* Q, const float* K, const float* 
 #undef ASR_ATTN_BWD
     ASR_CHECK_LAUNCH("attention_bwd");
     return ASR_OK;
+}
+
+extern "C" int asr_attention_bwd_p(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                                   const float* lse, int N, int Tq, int Tk, int C, int H, int ldq, int ldk, int causal,
+                                   int relu_grad, float dropout_rate, unsigned int seed,
+                                   float* dQ, float* dK, float* dV, float* delta_ws, void* stream) {
+    return asr_attention_bwd_s(Q, K, V, O, dO, lse, N, Tq, Tk, C, H, ldq, ldk, causal, relu_grad, dropout_rate, seed, dQ, dK, dV, delta_ws,
+                               nullptr, stream);
 }
 
 extern "C" int asr_attention_bwd(const float* Q, const float* K, const float* V, const float* O, const float* dO,

@@ -422,18 +422,28 @@ def lfr(feat, frames, m, n, t_out, out=None):
 
 
 # ------------------------------------------------------------------ Transformer path
-def attention_fwd(Q, K, V, N, Tq, Tk, Cc, H, causal, O, lse, dropout_rate=0.0, seed=0, ldq=None, ldk=None):
+def attention_stats_floats(N, Tq, Tk, H):
+    return _lib.load().asr_attention_stats_floats(N, Tq, Tk, H)
+
+
+def attention_stats(Q, K, N, Tq, Tk, Cc, H, stats, ldq=None, ldk=None):
+    """The query masks and key biases of every (sample, head) of an attention call, once (asr_attention_stats): handed to attention_fwd /
+    attention_bwd as ``stats`` they replace what every workgroup of those kernels otherwise recomputes from Q / K (the same values)."""
+    check(_lib.load().asr_attention_stats(_ptr(Q), _ptr(K), N, Tq, Tk, Cc, H, ldq or Cc, ldk or Cc, _ptr(stats), _stream()), 'asr_attention_stats')
+
+
+def attention_fwd(Q, K, V, N, Tq, Tk, Cc, H, causal, O, lse, dropout_rate=0.0, seed=0, ldq=None, ldk=None, stats=None):
     """ldq / ldk: row pitches of Q and of K, V when they are column blocks of a fused projection buffer (default Cc)."""
-    check(_lib.load().asr_attention_fwd_p(_ptr(Q), _ptr(K), _ptr(V), N, Tq, Tk, Cc, H, ldq or Cc, ldk or Cc, int(causal),
-                                          float(dropout_rate), int(seed) & 0xffffffff, _ptr(O), _ptr(lse), _stream()),
+    check(_lib.load().asr_attention_fwd_s(_ptr(Q), _ptr(K), _ptr(V), N, Tq, Tk, Cc, H, ldq or Cc, ldk or Cc, int(causal),
+                                          float(dropout_rate), int(seed) & 0xffffffff, _ptr(O), _ptr(lse), _ptr(stats), _stream()),
           'asr_attention_fwd')
 
 
 def attention_bwd(Q, K, V, O, dO, lse, N, Tq, Tk, Cc, H, causal, dQ, dK, dV, delta_ws, relu_grad=False, dropout_rate=0.0, seed=0,
-                  ldq=None, ldk=None):
-    check(_lib.load().asr_attention_bwd_p(_ptr(Q), _ptr(K), _ptr(V), _ptr(O), _ptr(dO), _ptr(lse), N, Tq, Tk, Cc, H,
+                  ldq=None, ldk=None, stats=None):
+    check(_lib.load().asr_attention_bwd_s(_ptr(Q), _ptr(K), _ptr(V), _ptr(O), _ptr(dO), _ptr(lse), N, Tq, Tk, Cc, H,
                                           ldq or Cc, ldk or Cc, int(causal), int(relu_grad), float(dropout_rate),
-                                          int(seed) & 0xffffffff, _ptr(dQ), _ptr(dK), _ptr(dV), _ptr(delta_ws), _stream()),
+                                          int(seed) & 0xffffffff, _ptr(dQ), _ptr(dK), _ptr(dV), _ptr(delta_ws), _ptr(stats), _stream()),
           'asr_attention_bwd')
 
 

@@ -273,7 +273,7 @@ class _Base:
         # self-attention, [rq][C] followed by [rk][2C] when queries and keys come from different tensors
         return {'QKV': self._t(N * Tq * C + 2 * N * Tk * C), 'W3': self._t(C, 3 * C), 'A': self._t(N * Tq, C),
                 'Z': self._t(N * Tq, C), 'xhat': self._t(N * Tq, C), 'rstd': self._t(N * Tq), 'lse': self._t(2 * N * H * Tq),
-                'out': self._t(N * Tq, C), 'N': N, 'Tq': Tq, 'Tk': Tk}
+                'out': self._t(N * Tq, C), 'N': N, 'Tq': Tq, 'Tk': Tk, 'stats': self._t(ops.attention_stats_floats(N, Tq, Tk, self.H))}
 
     def _qkv_views(self, st, fused3):
         C, rq, rk = self.C, st['N'] * st['Tq'], st['N'] * st['Tk']
@@ -308,7 +308,9 @@ class _Base:
         rate = self._rate
         kind, blk = self._block_site(name)
         st['seed_att'], st['seed_out'] = self._drop_seed((kind, blk, 'att')), self._drop_seed((kind, blk, 'out'))
-        ops.attention_fwd(Q, K, V, N, Tq, Tk, C, self.H, causal, st['A'], st['lse'], rate, st['seed_att'], ldq=ldq, ldk=ldk)
+        # query masks / key biases of the block once (the attention kernels' workgroups each recomputed them from Q / K: 6-12 % of their time)
+        ops.attention_stats(Q, K, N, Tq, Tk, C, self.H, st['stats'], ldq=ldq, ldk=ldk)
+        ops.attention_fwd(Q, K, V, N, Tq, Tk, C, self.H, causal, st['A'], st['lse'], rate, st['seed_att'], ldq=ldq, ldk=ldk, stats=st['stats'])
         self._dense(st['A'], N * Tq, C, C, self.p(name + '/wo'), None, st['Z'], True)
         # dropout(Z) + residual + LayerNorm in one pass; Z itself stays undropped, the backward regenerates the mask
         ops.add_layernorm_fwd_dropout(st['Z'], q_in, self.p(name + '/ln_g'), self.p(name + '/ln_b'), N * Tq, C, LN_EPS,
@@ -379,7 +381,7 @@ class _Base:
             dQ, dK, dV = dbuf[0:], dkv[0:], dkv[C:]
         ops.attention_bwd(Q, K, V, st['A'], dA, st['lse'], N, Tq, Tk, C, self.H, st['causal'],
                           dQ, dK, dV, self.ws, relu_grad=True,      # gradients of the pre-ReLU projections
-                          dropout_rate=self._rate, seed=st['seed_att'], ldq=ldq, ldk=ldk)
+                          dropout_rate=self._rate, seed=st['seed_att'], ldq=ldq, ldk=ldk, stats=st['stats'])
         W3 = st['W3']
         if fused3:
             self._wgrad_packed(st['q_in'], dQ, rq, C, [name + '/wq', name + '/wk', name + '/wv'], 3 * C)

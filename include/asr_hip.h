@@ -310,6 +310,20 @@ int asr_attention_bwd_p(const float* Q, const float* K, const float* V, const fl
                         const float* lse, int N, int Tq, int Tk, int C, int H, int ldq, int ldk, int causal,
                         int relu_grad, float dropout_rate, unsigned int seed,
                         float* dQ, float* dK, float* dV, float* delta_ws, void* stream);
+/* Round 5: the per-row statistics of an attention call taken ONCE.  asr_attention_stats writes, for every (sample, head), the query
+ * mask of its Tq queries (1 / 0: the head slice of the Q row is not / is all zeros) and the key bias of its Tk keys (+inf / the fill value
+ * in min() form: the head slice of the K row sums to something / to zero) -- stats = asr_attention_stats_floats(N, Tq, Tk, H) floats:
+ * [N][H][Tq] masks, then [N][H][Tk] biases.  The _s entry points take them (stats may be NULL: then, as in the _p forms, every workgroup
+ * recomputes them from Q / K -- 4 to 16 times per (sample, head), 6-12 % of the kernels' time); the values are the same, so are all results. */
+size_t asr_attention_stats_floats(int N, int Tq, int Tk, int H);
+int asr_attention_stats(const float* Q, const float* K, int N, int Tq, int Tk, int C, int H, int ldq, int ldk, float* stats, void* stream);
+int asr_attention_fwd_s(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H,
+                        int ldq, int ldk, int causal, float dropout_rate, unsigned int seed, float* O, float* lse,
+                        const float* stats, void* stream);
+int asr_attention_bwd_s(const float* Q, const float* K, const float* V, const float* O, const float* dO,
+                        const float* lse, int N, int Tq, int Tk, int C, int H, int ldq, int ldk, int causal,
+                        int relu_grad, float dropout_rate, unsigned int seed,
+                        float* dQ, float* dK, float* dV, float* delta_ws, const float* stats, void* stream);
 /* dst[r][0..cols) (+)= src[r][0..cols) for r < rows, with row pitches ldd / lds (floats; everything a multiple of 4):
  * packs separate weight matrices into the column blocks of a fused one and scatters its gradient back. */
 int asr_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int cols, int accumulate, void* stream);

@@ -64,6 +64,19 @@ def test_attention_fwd_bwd(ops, N, Tq, Tk, H, causal):
     report('attention dQ (pre-relu)', gq.cpu().numpy(), gq_ref * (Q > 0), 3e-5)
     report('attention dK (pre-relu)', gk.cpu().numpy(), gk_ref * (K > 0), 3e-5)
     report('attention dV (pre-relu)', gv.cpu().numpy(), gv_ref * (V > 0), 3e-5)
+    # round 5: the query masks / key biases taken once (asr_attention_stats) instead of per workgroup -- the same values, the same bits
+    stats = torch.full((ops.attention_stats_floats(N, Tq, Tk, H),), 7.0, device='cuda')
+    ops.attention_stats(dQ, dK, N, Tq, Tk, C, H, stats)
+    qm = stats[:N * H * Tq].view(N, H, Tq).cpu().numpy()
+    kb = stats[N * H * Tq:].view(N, H, Tk).cpu().numpy()
+    assert np.array_equal(qm, (np.abs(Q).reshape(N, Tq, H, 64).sum(-1) != 0).transpose(0, 2, 1).astype(np.float32))
+    assert np.array_equal(np.isinf(kb), (K.reshape(N, Tk, H, 64).sum(-1) != 0).transpose(0, 2, 1))
+    O2, lse2 = torch.zeros_like(O), torch.zeros_like(lse)
+    ops.attention_fwd(dQ, dK, dV, N, Tq, Tk, C, H, causal, O2, lse2, stats=stats)
+    assert torch.equal(O2, O) and torch.equal(lse2, lse)
+    g2 = [torch.zeros_like(dQ), torch.zeros_like(dK), torch.zeros_like(dV)]
+    ops.attention_bwd(dQ, dK, dV, O, dev(dO), lse, N, Tq, Tk, C, H, causal, *g2, ws, relu_grad=True, stats=stats)
+    assert torch.equal(g2[0], gq) and torch.equal(g2[1], gk) and torch.equal(g2[2], gv)
 
 
 @pytest.mark.parametrize("rows,C,with_b", [(10, 512, True), (300, 64, False), (77, 2048, True), (5, 1030, True)])   # 1030: scalar kernels
