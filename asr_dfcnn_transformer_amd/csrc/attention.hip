@@ -170,22 +170,27 @@ __global__ __launch_bounds__(256) void attn_stats_kernel(const float* __restrict
     const bool keys = blockIdx.y == 1;
     const float* X = keys ? K : Q;
     const int T = keys ? Tk : Tq, ld = keys ? ldk : ldq;
-    const long total = (long)N * T * H;
+    const long rows = (long)N * T;
+    // a sixteen-lane group takes the head slice of FOUR consecutive rows: four independent 16-byte loads per lane in flight
     const long g = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int c4 = threadIdx.x & 15;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    int head = 0; long row = 0;
-    if (g < total) {
-        head = (int)(g % H); row = g / H;
-        v = *(const float4*)(X + row * ld + head * DH + c4 * 4);
-    }
-    float s = keys ? (v.x + v.y + v.z + v.w) : (fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w));
+    const int head = (int)(g % H);
+    const long row0 = (g / H) * 4;
+    float4 v[4];
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    if (g < total && c4 == 0) {
-        const int n = (int)(row / T), t = (int)(row - (long)n * T);
-        float* out = keys ? kb : qm;
-        out[((long)n * H + head) * T + t] = keys ? (s != 0.f ? INFINITY : FILL2) : (s != 0.f ? 1.f : 0.f);
+    for (int u = 0; u < 4; ++u)
+        v[u] = (row0 + u < rows) ? *(const float4*)(X + (row0 + u) * ld + head * DH + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* out = keys ? kb : qm;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float s = keys ? (v[u].x + v[u].y + v[u].z + v[u].w) : (fabsf(v[u].x) + fabsf(v[u].y) + fabsf(v[u].z) + fabsf(v[u].w));
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        const long row = row0 + u;
+        if (row < rows && c4 == 0) {
+            const int n = (int)(row / T), t = (int)(row - (long)n * T);
+            out[((long)n * H + head) * T + t] = keys ? (s != 0.f ? INFINITY : FILL2) : (s != 0.f ? 1.f : 0.f);
+        }
     }
 }
 
@@ -711,7 +716,7 @@ extern "C" int asr_attention_stats(const float* Q, const float* K, int N, int Tq
                                    void* stream) {
     if (!Q || !K || !stats || N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
     if (ldq < C || ldk < C || (ldq & 3) || (ldk & 3) || ((((uintptr_t)Q) | ((uintptr_t)K)) & 15)) return ASR_ERR_BAD_ARG;
-    const long groups = (long)N * H * (Tq > Tk ? Tq : Tk);
+    const long groups = (((long)N * (Tq > Tk ? Tq : Tk) + 3) / 4) * H;
     hipLaunchKernelGGL(attn_stats_kernel, dim3(asr_cdiv(groups * 16, 256), 2), dim3(256), 0, (hipStream_t)stream, Q, K, N, Tq, Tk, H, ldq, ldk,
                        stats, stats + (size_t)N * H * Tq);
     ASR_CHECK_LAUNCH("attention_stats");
