@@ -100,6 +100,7 @@ SIGNATURES = {
     'asr_tap_gemm_wino_pool': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'asr_tap_gemm_splitk_workspace': (C.c_size_t, [_P, _I]),
     'asr_tap_gemm_splitk': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'asr_tap_gemm_relu_bwd': (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P]),
     'asr_tap_gemm_nt_splitk_workspace': (C.c_size_t, [_P, _I]),
     'asr_tap_gemm_nt_splitk': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
     'asr_dropout': (_I, [_P, _Z, _F, C.c_uint, _P, _P]),

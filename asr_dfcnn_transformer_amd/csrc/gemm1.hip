@@ -136,7 +136,7 @@ __device__ __forceinline__ void g1_chunk(const float* __restrict__ set, float* _
 #if __HIP_DEVICE_COMPILE__
 // SK: the contraction split over gridDim.y (asr_tap_gemm_nt_splitk): split z works on columns [z * K, (z + 1) * K) of both operands
 // (K = the split's depth, a multiple of 32) and writes plane z of a [splits][M][N] slab through the row table.
-template <int NB, bool GD, bool SK = false>
+template <int NB, bool GD, bool SK = false, bool RM = false>
 __device__ __forceinline__ void gemm1_body(const Gemm1Args& args) {
     const TapGemmArgs& g = args.g;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -238,7 +238,7 @@ __device__ __forceinline__ void gemm1_body(const Gemm1Args& args) {
 
     __syncthreads();                                     // the tiles are dead: their space is the epilogue's scratch
     if (GD) tap_epilogue_gated<2, NB, true>(g, acc, bufs + wave * (32 * 33), rowa, rowy, wm * 64, n0 + wn * (32 * NB), lane, tile_m * 2 + wm);
-    else tap_epilogue<2, NB>(g, acc, bufs + wave * (32 * 33), rowa, rowy, wm * 64, n0 + wn * (32 * NB), lane, tile_m * 2 + wm);
+    else tap_epilogue<2, NB, RM>(g, acc, bufs + wave * (32 * 33), rowa, rowy, wm * 64, n0 + wn * (32 * NB), lane, tile_m * 2 + wm);
 }
 #endif
 
@@ -259,6 +259,15 @@ __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void gemm1_dense_gate_kernel(
 }
 
 
+
+// the data-gradient of a dense layer whose input is a Dense(relu) output: the ReLU backward of that layer in the epilogue
+// (asr_tap_gemm_relu_bwd; tap_epilogue's RMASK)
+template <int NB>
+__global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void gemm1_relumask_kernel(Gemm1Args args) {
+#if __HIP_DEVICE_COMPILE__
+    gemm1_body<NB, false, false, true>(args);
+#endif
+}
 
 template <int NB>
 __global__ __launch_bounds__(256, NB == 2 ? 2 : 3) void gemm1_splitk_kernel(Gemm1Args args) {
@@ -536,6 +545,44 @@ extern "C" int asr_tap_gemm_nt(const asr_gemm_desc* d, const float* A, const flo
     if (d->M <= 0 || d->K <= 0 || d->N <= 0 || ldwt < d->K) return ASR_ERR_BAD_ARG;
     if (asr_gemm1_eligible(d, A, Wt, ldwt)) return asr_gemm1_launch(d, A, Wt, ldwt, bias, scale, shift, out_a, out_y, 0, stream, nullptr);
     return asr_tap_gemm(d, A, W, bias, scale, shift, out_a, out_y, stream);
+}
+
+extern "C" int asr_relu_bwd(const float* dy, const float* h, size_t n, float* dz, void* stream);
+
+// dX[rows][K_in] = (dY[rows][N_out] . W[K_in][N_out]^T) masked by (H[rows][K_in] > 0): the data-gradient of a dense layer (asr_tap_gemm with
+// wmode 1: d->K = the layer's output width, d->N its input width, W the layer's kernel) followed by asr_relu_bwd against the activation H
+// of the Dense(relu) layer in front -- in ONE launch where the LDS-DMA kernel takes the shape (the Transformer's feed-forward blocks:
+// 32768 x 2048 <- 512: no 268 MB pass over the result), as the two calls otherwise.  The same bits either way.  d->accumulate must be 0.
+extern "C" int asr_tap_gemm_relu_bwd(const asr_gemm_desc* d, const float* dY, const float* W, const float* H, float* dX, void* stream) {
+    if (!d || !dY || !W || !H || !dX || d->ntaps != 1 || d->wmode != 1 || d->H > 0 || d->accumulate || d->ldo_y < d->N) return ASR_ERR_BAD_ARG;
+    if (!asr_gemm1_eligible(d, dY, W, d->ldw) || ((((uintptr_t)H) | ((uintptr_t)dX)) & 15) || (d->ldo_y & 3)) {
+        const int rc = asr_tap_gemm(d, dY, W, nullptr, nullptr, nullptr, nullptr, dX, stream);
+        if (rc != ASR_OK) return rc;
+        if (d->ldo_y != d->N) return ASR_ERR_UNSUPPORTED;          // (the mask pass is a flat one)
+        return asr_relu_bwd(dX, H, (size_t)d->M * d->N, dX, stream);
+    }
+    Gemm1Args ga;
+    TapGemmArgs& a = ga.g;
+    a.A = dY; a.W = nullptr; a.bias = nullptr; a.scale = nullptr; a.shift = nullptr;
+    a.out_a = nullptr; a.out_y = dX;
+    a.M = d->M; a.K = d->K; a.N = d->N; a.lda = d->lda; a.ldw = d->ldw;
+    a.ldo_a = 0; a.ldo_y = d->ldo_y;
+    a.H = 0; a.Wd = 0; a.WP = 1; a.HPWP = 1; a.halo = 0; a.rmin = 0; a.rmax = d->M;
+    a.relu = 0; a.accumulate = 0; a.y_unpadded = 0;
+    a.gate_mode = 0; a.gate_H = a.gate_W = 0; a.gate_a = H; a.gate_dz = nullptr; a.gate_part = nullptr; a.gate_rows = nullptr;
+    a.nt_store = 0;
+    const int nb = gemm1_blocks(d->M, d->N);
+    a.ntm = asr_cdiv(d->M, 128); a.ntn = asr_cdiv(d->N, 64 * nb);
+    ga.Bt = W; ga.ldb = d->ldw;
+    const size_t lds = (size_t)(256 + 2 * (G1_TILE_F + nb * 64 * G1_KC)) * sizeof(float);
+    typedef void (*kern_t)(Gemm1Args);
+    static const kern_t kerns[2] = {gemm1_relumask_kernel<1>, gemm1_relumask_kernel<2>};
+    static bool attr[2] = {false, false};
+    if (!attr[nb - 1]) { (void)hipFuncSetAttribute((const void*)kerns[nb - 1], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr[nb - 1] = true; }
+    hipLaunchKernelGGL(kerns[nb - 1], dim3(a.ntm * a.ntn), dim3(256), lds, (hipStream_t)stream, ga);
+    asr_set_last_kernel(nb == 2 ? "gemm1_relumask_kernel<2>" : "gemm1_relumask_kernel<1>");
+    ASR_CHECK_LAUNCH("gemm1_relumask");
+    return ASR_OK;
 }
 
 // second pass of the split-K forms (tap_gemm.hip)

@@ -190,10 +190,13 @@ __device__ __forceinline__ void tap_epilogue_gated(const TapGemmArgs& g, const f
     }
 }
 
-template <int TM, int TN>
+// RMASK (round 5, gemm1_relumask_kernel only -- a template parameter, so that no other kernel's code changes): out_y is the data-gradient
+// of a Dense(relu) layer's OUTPUT side, i.e. it is zeroed where that layer's activation g.gate_a (same rows and pitch as out_y) is not
+// positive -- asr_relu_bwd applied to the value in the register instead of a pass of its own over the result.
+template <int TM, int TN, bool RMASK = false>
 __device__ __forceinline__ void tap_epilogue(const TapGemmArgs& g, const floatx16 (&acc)[TM][TN], float* scratch,
                                              const int* rowa, const int* rowy, int row0, int col0, int lane, int part_row = 0) {
-    if (g.gate_mode) {
+    if (!RMASK && g.gate_mode) {
         tap_epilogue_gated<TM, TN>(g, acc, scratch, rowa, const_cast<int*>(rowy), row0, col0, lane, part_row);
         return;
     }
@@ -232,6 +235,10 @@ __device__ __forceinline__ void tap_epilogue(const TapGemmArgs& g, const floatx1
                 if (g.out_y) {
                     float4 y = make_float4(sc.x * v.x + sh.x, sc.y * v.y + sh.y, sc.z * v.z + sh.z, sc.w * v.w + sh.w);
                     float* o = g.out_y + (long)rowy[m] * g.ldo_y + n;
+                    if (RMASK) {
+                        const float4 h = *(const float4*)(g.gate_a + (long)rowy[m] * g.ldo_y + n);
+                        y.x = h.x > 0.f ? y.x : 0.f; y.y = h.y > 0.f ? y.y : 0.f; y.z = h.z > 0.f ? y.z : 0.f; y.w = h.w > 0.f ? y.w : 0.f;
+                    }
                     if (g.accumulate) { const float4 p = *(const float4*)o; y.x += p.x; y.y += p.y; y.z += p.z; y.w += p.w; }
                     if (g.nt_store) __builtin_nontemporal_store(nt_f4{y.x, y.y, y.z, y.w}, (nt_f4*)o);
                     else *(float4*)o = y;

@@ -146,6 +146,13 @@ def tap_gemm_splitk(desc, A, W, bias, scale, shift, out_a, out_y, splits, worksp
                                                        _ptr(out_y), int(splits), _ptr(workspace), _stream()), 'asr_tap_gemm_splitk'))
 
 
+def tap_gemm_relu_bwd(desc, dY, W, H, dX):
+    """dX = (dY . W^T) where H > 0 else 0: a dense data-gradient with the ReLU backward of the layer in front in its epilogue
+    (asr_tap_gemm_relu_bwd)."""
+    lib = _lib.load()
+    _timed(desc, lambda: check(lib.asr_tap_gemm_relu_bwd(C.byref(desc), _ptr(dY), _ptr(W), _ptr(H), _ptr(dX), _stream()), 'asr_tap_gemm_relu_bwd'))
+
+
 def tap_gemm_nt_splitk_workspace(desc, splits):
     return _lib.load().asr_tap_gemm_nt_splitk_workspace(C.byref(desc), int(splits))
 

@@ -418,8 +418,8 @@ class _Base:
                                 None, None, self._ln_part(name, rows), self._rate, st['seed'])
         self._bgrad(dY, rows, C, name + '/b2')
         self._wgrad(st['H'], dY, rows, 4 * C, C, name + '/w2')
-        self._dense_dgrad(dY, rows, 4 * C, C, self.p(name + '/w2'), dH, False)
-        ops.relu_bwd(dH, st['H'], dH)
+        # dH = (dY . w2^T) where H > 0: the ReLU backward of the first Dense rides in the data-gradient's epilogue (no pass over rows x 4C)
+        ops.tap_gemm_relu_bwd(ops.gemm_desc(rows, C, 4 * C, C, C, 0, 4 * C, ntaps=1, wmode=1), dY, self.p(name + '/w2'), st['H'], dH)
         self._bgrad(dH, rows, 4 * C, name + '/b1')
         self._wgrad(st['x'], dH, rows, C, 4 * C, name + '/w1')
         self._dense_dgrad(dH, rows, C, 4 * C, self.p(name + '/w1'), dx, True)

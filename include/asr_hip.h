@@ -509,6 +509,12 @@ size_t asr_tap_gemm_nt_splitk_workspace(const asr_gemm_desc* d, int splits);
 int asr_tap_gemm_nt_splitk(const asr_gemm_desc* d, const float* A, const float* Bt, int ldb, const float* bias, const float* scale,
                            const float* shift, float* out_a, float* out_y, int splits, void* workspace, void* stream);
 
+/* Data-gradient of a dense layer fed by a Dense(relu) layer, with that layer's ReLU backward in the epilogue (round 5):
+ *   dX[rows][d->N] = (dY[rows][d->K] . W[d->N][d->K]^T) where H[rows][d->N] > 0, else 0        (d: ntaps 1, wmode 1, accumulate 0; H and dX share
+ * the pitch d->ldo_y) -- asr_tap_gemm + asr_relu_bwd in one launch on the LDS-DMA kernel (gemm1_relumask_kernel), as the two calls where that
+ * kernel does not take the shape; the same bits.  `end2end/transformer.py:204-222` feedforward backward: no pass over the 32768 x 2048 result. */
+int asr_tap_gemm_relu_bwd(const asr_gemm_desc* d, const float* dY, const float* W, const float* H, float* dX, void* stream);
+
 /* fp32 contraction on PRE-ARRANGED weights: same arguments, arithmetic (v_mfma_f32_32x32x2_f32, fp32 accumulate) and
  * epilogue as asr_tap_gemm; the weight tensor is first copied into MFMA fragment order, once per optimiser step:
  *   asr_arrange_weights(W, ntaps, K, N, ldw, wmode, out): out = fp32 [ntaps][ceil(K/8)][ceil(N/32)][64 lanes][4], lane

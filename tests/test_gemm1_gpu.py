@@ -182,3 +182,25 @@ def test_dense_weight_gradient_of_a_column_block(ops):
     ops.tap_wgrad(d, x, dqkv.view(-1)[C:], 3 * C, dw, ws)                  # the K block
     ref = _host_ref(x.t(), dqkv[:, C:2 * C])
     assert np.abs(_f64(dw) - ref).max() < 1e-4 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(32768, 512, 2048), (6400, 512, 2048), (300, 64, 128), (129, 96, 40), (1000, 128, 1536)])
+def test_dense_data_gradient_with_the_relu_backward_in_its_epilogue(M, K, N):
+    """asr_tap_gemm_relu_bwd = asr_tap_gemm (wmode 1) followed by asr_relu_bwd, bit for bit -- on the LDS-DMA kernel (gemm1_relumask_kernel)
+    where it takes the shape, as the two calls elsewhere; against float64 as well."""
+    import numpy as np, torch
+    from asr_dfcnn_transformer_amd import ops
+    rng = np.random.default_rng(41)
+    dy = torch.tensor(rng.standard_normal((M, K)).astype(np.float32), device='cuda')
+    w = torch.tensor((rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32), device='cuda')          # the layer's kernel [in N][out K]
+    h = torch.tensor(np.maximum(rng.standard_normal((M, N)), 0).astype(np.float32), device='cuda')
+    d = ops.gemm_desc(M, K, N, K, K, 0, N, ntaps=1, wmode=1)
+    ref = torch.zeros(M, N, device='cuda'); out = torch.full((M, N), 7.0, device='cuda')
+    ops.tap_gemm(d, dy, w, None, None, None, None, ref)
+    ops.relu_bwd(ref, h, ref)
+    ops.tap_gemm_relu_bwd(d, dy, w, h, out)
+    assert torch.equal(out, ref)
+    if M <= 6400:
+        want = (dy.double().cpu().numpy() @ w.double().cpu().numpy().T) * (h.cpu().numpy() > 0)
+        assert np.abs(out.cpu().numpy() - want).max() <= 3e-5 * max(1.0, np.abs(want).max())
