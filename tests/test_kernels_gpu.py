@@ -212,6 +212,28 @@ def test_dense_split_k_on_the_lds_dma_kernel(ops, M, K, N, splits):
         assert torch.equal(a3, a1[:m1]), 'rows must not depend on the batch around them'
 
 
+def test_dense_split_k_argument_checks(ops):
+    """asr_tap_gemm_nt_splitk refuses what it cannot run (split count, depth not a multiple of 32 x splits, narrow outputs, a pitch below
+    the depth, a missing workspace) before anything is launched."""
+    from asr_dfcnn_transformer_amd import _lib
+    import ctypes as C_
+    lib = _lib.load()
+    M, K, N = 256, 1024, 128
+    x = torch.zeros(M, K, device='cuda'); wt = torch.zeros(N, K, device='cuda'); y = torch.zeros(M, N, device='cuda')
+    ws = torch.zeros(16 * M * N, device='cuda')
+    p = lambda t: t.data_ptr()
+    call = lambda d, splits, ldb=K, w=ws: lib.asr_tap_gemm_nt_splitk(C_.byref(d), p(x), p(wt), ldb, None, None, None, None, p(y), splits, p(w) if w is not None else None, None)
+    good = ops.gemm_desc(M, K, N, K, N, 0, N, ntaps=1)
+    assert call(good, 4) == 0
+    assert call(good, 1) == -1 and call(good, 17) == -1          # 2 <= splits <= 16
+    assert call(good, 3) == -1                                   # 1024 % (32 * 3) != 0
+    assert call(good, 4, ldb=K - 4) == -1
+    assert call(good, 4, w=None) == -1
+    assert call(ops.gemm_desc(M, K, 32, K, 32, 0, 32, ntaps=1), 4) == -1      # N < 64: the 64 x 64 tiles of asr_tap_gemm_splitk take those
+    assert lib.asr_tap_gemm_nt_splitk_workspace(C_.byref(good), 4) == 4 * M * N * 4
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("M,K,N", [(300, 64, 128), (1000, 256, 32), (640, 6400, 1536)])
 def test_dense_wgrad(ops, M, K, N):
     rng = np.random.default_rng(5)

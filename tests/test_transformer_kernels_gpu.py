@@ -79,6 +79,36 @@ def test_attention_fwd_bwd(ops, N, Tq, Tk, H, causal):
     assert torch.equal(g2[0], gq) and torch.equal(g2[1], gk) and torch.equal(g2[2], gv)
 
 
+def test_attention_stats_on_column_blocks_and_its_argument_checks(ops):
+    """asr_attention_stats on Q / K that are column blocks of one fused [rows][3C] projection buffer (row pitches 3C, as the engines call
+    it) gives the statistics of the dense copies; with them the pitched attention gives the bits of the call without; bad arguments are
+    refused before anything is launched."""
+    from asr_dfcnn_transformer_amd import _lib
+    rng = np.random.default_rng(3)
+    N, T, H = 3, 70, 4
+    C = H * 64
+    buf = np.maximum(rng.standard_normal((N * T, 3 * C)), 0).astype(np.float32)
+    buf[5, :C] = 0; buf[9, C:C + 64] = 0; buf[N * T - 1, C:2 * C] = 0
+    bd = dev(buf)
+    Q, K, V = bd[:, :C], bd[:, C:2 * C], bd[:, 2 * C:]
+    stats = torch.zeros(ops.attention_stats_floats(N, T, T, H), device='cuda')
+    ops.attention_stats(Q, K, N, T, T, C, H, stats, ldq=3 * C, ldk=3 * C)
+    dense = torch.zeros_like(stats)
+    ops.attention_stats(Q.contiguous(), K.contiguous(), N, T, T, C, H, dense)
+    assert torch.equal(stats, dense)
+    O1, O2 = torch.zeros(N * T, C, device='cuda'), torch.zeros(N * T, C, device='cuda')
+    l1, l2 = torch.zeros(2, N, H, T, device='cuda'), torch.zeros(2, N, H, T, device='cuda')
+    for causal in (False, True):
+        ops.attention_fwd(Q, K, V, N, T, T, C, H, causal, O1, l1, ldq=3 * C, ldk=3 * C)
+        ops.attention_fwd(Q, K, V, N, T, T, C, H, causal, O2, l2, ldq=3 * C, ldk=3 * C, stats=stats)
+        assert torch.equal(O1, O2) and torch.equal(l1, l2)
+    lib = _lib.load()
+    p = lambda t: t.data_ptr()
+    assert lib.asr_attention_stats(p(Q), p(K), N, T, T, C + 4, H, 3 * C, 3 * C, p(stats), None) == -1        # C != H * 64
+    assert lib.asr_attention_stats(p(Q), p(K), N, T, T, C, H, C - 4, 3 * C, p(stats), None) == -1            # pitch below the width
+    assert lib.asr_attention_stats(p(Q), None, N, T, T, C, H, 3 * C, 3 * C, p(stats), None) == -1
+
+
 @pytest.mark.parametrize("rows,C,with_b", [(10, 512, True), (300, 64, False), (77, 2048, True), (5, 1030, True)])   # 1030: scalar kernels
 def test_add_layernorm(ops, rows, C, with_b):
     rng = np.random.default_rng(1)
