@@ -493,21 +493,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
     const long qbase = (long)n * Tq, kbase = (long)n * Tk;
     const long lrow = ((long)n * H + head) * Tq;
 
-    // query mask (1 / 0) into del_a for the moment, then the three statistics
-    if (qstat) at_row_stats_load<1>(del_a, qstat + lrow, Tq, Tq64, tid);
-    else at_row_stats<1>(del_a, Q, qbase, Tq, Tq64, ldq, hoff, tid);
-    __syncthreads();
     bool degenerate = false;                     // a query before this key block whose visible keys were all masked
     const int kfirst_blk = ktile * 128;
-    for (int q = tid; q < Tq64; q += 256) {
-        const bool live = q < Tq && del_a[q] != 0.f;
-        const float l0 = q < Tq ? lse[lrow + q] : 0.f;
-        if (CAUSAL && q < Tq && q < kfirst_blk && l0 < -1.0e9f) degenerate = true;
-        lse_a[q] = live ? l0 : INFINITY;
-        lsl_a[q] = q < Tq ? lse[(long)Nn * H * Tq + lrow + q] : 0.f;
+    if (qstat) {
+        // the precomputed masks: the three statistics in ONE pass of independent loads (no staging of the mask in LDS, no barrier between)
+        for (int q = tid; q < Tq64; q += 256) {
+            const bool in = q < Tq;
+            const float mk = in ? qstat[lrow + q] : 0.f;
+            const float l0 = in ? lse[lrow + q] : 0.f;
+            const float l1 = in ? lse[(long)Nn * H * Tq + lrow + q] : 0.f;
+            const float dl = in ? delta[lrow + q] : 0.f;
+            if (CAUSAL && in && q < kfirst_blk && l0 < -1.0e9f) degenerate = true;
+            lse_a[q] = (in && mk != 0.f) ? l0 : INFINITY;
+            lsl_a[q] = l1;
+            del_a[q] = dl;
+        }
+    } else {
+        // query mask (1 / 0) into del_a for the moment, then the three statistics
+        at_row_stats<1>(del_a, Q, qbase, Tq, Tq64, ldq, hoff, tid);
+        __syncthreads();
+        for (int q = tid; q < Tq64; q += 256) {
+            const bool live = q < Tq && del_a[q] != 0.f;
+            const float l0 = q < Tq ? lse[lrow + q] : 0.f;
+            if (CAUSAL && q < Tq && q < kfirst_blk && l0 < -1.0e9f) degenerate = true;
+            lse_a[q] = live ? l0 : INFINITY;
+            lsl_a[q] = q < Tq ? lse[(long)Nn * H * Tq + lrow + q] : 0.f;
+        }
+        __syncthreads();                             // del_a (the mask) has been read by every thread
+        for (int q = tid; q < Tq64; q += 256) del_a[q] = q < Tq ? delta[lrow + q] : 0.f;
     }
-    __syncthreads();                             // del_a (the mask) has been read by every thread
-    for (int q = tid; q < Tq64; q += 256) del_a[q] = q < Tq ? delta[lrow + q] : 0.f;
     // causal: query tiles wholly before this key block only matter for such degenerate rows (dV; the common case has none)
     int j0 = 0;
     if (CAUSAL) { const bool any = __syncthreads_or(degenerate); if (!any) j0 = kfirst_blk / QT; }
