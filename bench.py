@@ -248,7 +248,7 @@ def run_am_lm(args):
                       (key, rr['launches'], rr['total_ms'], rr['avg_us'], rr['tflops']), file=sys.stderr)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier(); dist.destroy_process_group()
+        dist.barrier(); shutdown_process_group()
 
 
 def run_lm(args):
@@ -317,7 +317,7 @@ def run_lm(args):
                       (key, rr['launches'], rr['total_ms'], rr['avg_us'], rr['tflops']), file=sys.stderr)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier(); dist.destroy_process_group()
+        dist.barrier(); shutdown_process_group()
 
 
 def run_transformer(args):
@@ -423,7 +423,24 @@ def run_transformer(args):
                       (key, rr['launches'], rr['total_ms'], rr['avg_us'], rr['tflops']), file=sys.stderr)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier(); dist.destroy_process_group()
+        dist.barrier(); shutdown_process_group()
+
+
+def shutdown_process_group(seconds=60):
+    """dist.destroy_process_group() under a deadline.  The measurement is finished and printed when this runs; a rank that then sits in the
+    group's teardown for ever (seen once in a 4-rank gloo rehearsal on one GPU: the JSON line was out, the job never ended) would hold the
+    launcher and the box.  After ``seconds`` the rank says so and exits with 0."""
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(seconds):
+            sys.stderr.write('bench.py: rank %s: destroy_process_group() did not return within %d s; exiting\n' % (os.environ.get('RANK', '0'), seconds))
+            sys.stderr.flush(); sys.stdout.flush()
+            os._exit(0)
+    threading.Thread(target=watchdog, daemon=True).start()
+    dist.destroy_process_group()
+    done.set()
 
 
 def engine_kwargs(args):
@@ -875,7 +892,7 @@ def main():
         print(json.dumps(out), flush=True)
     barrier()
     if dist.is_initialized():
-        dist.destroy_process_group()
+        shutdown_process_group()
 
 
 if __name__ == '__main__':
