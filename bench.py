@@ -439,8 +439,14 @@ def shutdown_process_group(seconds=60):
             sys.stderr.flush(); sys.stdout.flush()
             os._exit(0)
     threading.Thread(target=watchdog, daemon=True).start()
+    world = dist.get_world_size()
     dist.destroy_process_group()
     done.set()
+    if world > 1:
+        # the last statement of a rank: leave at once -- what is still to run (interpreter and HIP runtime teardown of several processes
+        # on a shared device) has nothing to add to a finished measurement
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 def engine_kwargs(args):
