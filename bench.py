@@ -618,6 +618,9 @@ def prime_note():
 
 
 def main():
+    if os.environ.get('ASR_BENCH_TRACEBACK_AFTER'):      # diagnosis of a run that does not end: every thread's stack after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['ASR_BENCH_TRACEBACK_AFTER']), repeat=False, file=sys.stderr)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
@@ -813,6 +816,17 @@ def main():
     torch.cuda.synchronize()
     overlapped = eng.side is not None
     dom = max(table, key=lambda k: table[k]['total_ms'])     # one kernel symbol = one rocprof row
+    if world > 1:
+        # rank 0's choice for every rank: the roofline pass below takes extra steps (with their gradient collectives) only when the
+        # symbol overlaps in the real step, and per-rank timing tables need not agree on the symbol -- ranks that disagreed would
+        # enter different numbers of collectives (seen as a run that never ended: 4 ranks sharing one card over gloo)
+        name = torch.zeros(256, dtype=torch.uint8, device=dev)
+        raw = dom.encode()[:256]
+        name[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8, device=dev)
+        dist.broadcast(name, src=0)
+        dom = bytes(name.cpu().tolist()).rstrip(b'\0').decode()
+        if dom not in table:
+            raise RuntimeError('rank %d never launched %s, the kernel rank 0 chose for the roofline block' % (rank, dom))
     dom_alone = (not overlapped) or is_forward_symbol(dom)   # does it run alone in the real (two-stream) step?
 
     ops.TIMER = ops.KernelTimer(only={dom})
