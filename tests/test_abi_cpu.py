@@ -36,6 +36,14 @@ def test_library_exports_nothing_the_header_does_not_declare():
     assert exported == _declared(), (sorted(set(exported) - set(_declared())), sorted(set(_declared()) - set(exported)))
 
 
+def test_integration_md_lists_every_declared_symbol():
+    """INTEGRATION.md ends with a table generated from the header (tools/gen_entry_point_table.py): every entry point, the reference
+    lines its header comment cites, the ops.py wrapper that binds it.  A symbol added to the header without regenerating it fails here."""
+    txt = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    missing = [n for n in _declared() if '`%s`' % n not in txt]
+    assert not missing, 'run python3 tools/gen_entry_point_table.py: %s' % missing
+
+
 def test_winograd_weight_buffer_contract():
     """asr_winograd_weights2 fills TWO layouts (2 x 16 K N floats, asr_winograd_weights_bytes) and refuses a smaller buffer before
     anything is launched; the round-4 name, whose contract had changed silently, is gone."""
