@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.parametrize('disagree', [False, True])
 def test_two_gloo_ranks_finish_and_report_one_line(disagree):
-    env = dict(os.environ, ASR_DIST_BACKEND='gloo', ASR_BENCH_TRACEBACK_AFTER='500')
+    env = dict(os.environ, ASR_DIST_BACKEND='gloo', ASR_BENCH_TRACEBACK_AFTER='300')
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
@@ -25,7 +25,7 @@ def test_two_gloo_ranks_finish_and_report_one_line(disagree):
         env['ASR_BENCH_TEST_RANKS_DISAGREE'] = '1'
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '2', '--tpad', '1000',
            '--no-cpu-baseline']
-    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=360)
     err = p.stderr.decode(errors='replace')
     assert p.returncode == 0, err[-3000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
