@@ -13,4 +13,12 @@ its docstring and cites the reference call site (file:line under
 /root/reference).  The restatement is float64 numpy; every piece is
 cross-checked in tests/ against an independent implementation available
 offline (torch-CPU autograd, scipy.fft, sklearn.preprocessing.scale).
+
+Pinned to the reference itself since round 5 (the pieces of it that run here
+without TensorFlow, outputs committed under tests/golden/ with the scripts
+that made them): fbank.build_LFR_features and ctc.get_edit_distance_difflib
+against the reference's own util/utils.py functions
+(tests/golden/reference_utils.npz, tests/test_reference_utils_golden.py).
+Everything that is arithmetic of the network, fbank, CTC or Adam stays
+unpinned as said above.
 """
