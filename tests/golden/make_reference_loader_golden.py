@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Golden vectors from the PURE methods of the reference's two data loaders, executed here unmodified on the reference's own dictionary
 files: lm_and_am/data_loader.py `DataLoader.get_acoustic_vocab_list` (:85-92), `get_language_vocab_list` (:95-103), `pny2id` (:43-58),
-`han2id` (:61-82), and end2end/data_loader.py `dataloader.get_acoustic_vocab_list` (:314-321), `get_language_vocab_list` (:324-333),
+`han2id` (:61-82), `get_lm_batch` (:164-193), and end2end/data_loader.py `dataloader.get_acoustic_vocab_list` (:314-321), `get_language_vocab_list` (:324-333),
 `han2id` (:59-80), `wav_padding` (:82-96), `label_padding` (:98-111).
 
 As tests/golden/make_reference_utils_golden.py: both modules stop at `import keras` when imported (ordinary ModuleNotFoundError; nothing is
@@ -51,7 +51,7 @@ def main():
     from util.const import Const                       # imports without TensorFlow
     common = {'np': np, 'pd': pd, 'os': os, 'Path': Path, 'Const': Const, 'home_dir': REF}      # home_dir = os.getcwd() of a run from the checkout root
     am = methods(os.path.join(REF, 'lm_and_am', 'data_loader.py'), 'DataLoader',
-                 ('get_acoustic_vocab_list', 'get_language_vocab_list', 'pny2id', 'han2id'), common)
+                 ('get_acoustic_vocab_list', 'get_language_vocab_list', 'pny2id', 'han2id', 'get_lm_batch'), common)
     e2e = methods(os.path.join(REF, 'end2end', 'data_loader.py'), 'dataloader',
                   ('get_acoustic_vocab_list', 'get_language_vocab_list', 'han2id', 'wav_padding', 'label_padding'), common)
     out = {}
@@ -82,6 +82,32 @@ def main():
     out['pny2id'] = [{'line': l, **outcome(am['pny2id'], me_am, l)} for l in lines_py]
     out['han2id_lm_and_am'] = [{'line': l, **outcome(am['han2id'], me_am, l)} for l in lines_han]
     out['han2id_end2end'] = [{'line': l, **outcome(e2e['han2id'], me_e2e, l)} for l in lines_han]
+    # language-model batches (lm_and_am/data_loader.py:164-193; no audio involved): the lists come from the reference's own DataUtil
+    # (util/data_util.py imports here) reading copies of the committed index fixtures from a scratch directory
+    import contextlib, io, shutil, tempfile
+    work = tempfile.mkdtemp(prefix='refloader_')
+    os.makedirs(os.path.join(work, 'data'))
+    for f in sorted(os.listdir(os.path.join(HERE, 'index'))):
+        if f.endswith('.txt'):
+            shutil.copy(os.path.join(HERE, 'index', f), os.path.join(work, 'data', f))
+    os.chdir(work)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            from util.data_util import DataUtil
+        out['lm_batches'] = []
+        for mode, bs in (('train', 1), ('train', 2), ('train', 3), ('test', 2), ('dev', 4)):
+            with contextlib.redirect_stdout(io.StringIO()):
+                du = DataUtil(types.SimpleNamespace(thchs30=True, aishell=True, stcmd=False, aidatatang=False, aidatatang_1505=False, prime=False,
+                                                    noise=False), batch_size=bs, mode=mode, data_length=None, shuffle=False)
+            me = types.SimpleNamespace(pny_lst=du.pny_lst, han_lst=du.han_lst, shuffle=False, lm_batch_size=bs, pinyin2index=p2i, word2index=w2i)
+            me.pny2id = types.MethodType(am['pny2id'], me)
+            me.han2id = types.MethodType(am['han2id'], me)
+            batches = [{'input_data': np.asarray(a).tolist(), 'input_length': np.asarray(b).tolist(), 'label_data': np.asarray(c).tolist()}
+                       for a, b, c in am['get_lm_batch'](me)]
+            out['lm_batches'].append({'mode': mode, 'batch_size': bs, 'batches': batches})
+    finally:
+        os.chdir(HERE)
+        shutil.rmtree(work, ignore_errors=True)
     rng = np.random.default_rng(7)
     pads = []
     for lens, dim in (((5, 3, 7), 4), ((1,), 2), ((2, 2), 3), ((9, 1, 4, 6), 8)):

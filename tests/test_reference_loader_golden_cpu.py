@@ -77,3 +77,23 @@ def test_padding_layouts_equal_the_reference():
         for pad, key in ((0, 'lab_pad0'), (2, 'lab_pad2')):
             lab, ll = e2e.label_padding(case['labels'], pad)
             assert str(lab.dtype) == case['lab_dtype'] and lab.tolist() == case[key] and ll.tolist() == case['lab_lens']
+
+
+def test_language_model_batches_equal_the_reference():
+    """DataLoader.get_lm_batch (lm_and_am/data_loader.py:164-193) on the index fixtures, lists from DataUtil, no shuffle: the same batches,
+    rows, padding and (character-count) input_length.  The package yields int32 arrays (device ids), the reference int64: values compared."""
+    from asr_dfcnn_transformer_amd import data_loader
+    from asr_dfcnn_transformer_amd.data_util import DataUtil
+    from asr_dfcnn_transformer_amd.hparams import AmLmHparams, TransDataHparams
+    hp = TransDataHparams().args                                             # thchs30 + aishell, as the fixture was generated
+    n = 0
+    for case in GOLD['lm_batches']:
+        tr = AmLmHparams().args
+        tr.lm_batch_size = case['batch_size']
+        du = DataUtil(hp, batch_size=case['batch_size'], mode=case['mode'], data_dir=INDEX)
+        got = list(data_loader.DataLoader(du, hp, tr, device='cpu').get_lm_batch())
+        assert len(got) == len(case['batches']), (case['mode'], case['batch_size'])
+        for (a, b, c), want in zip(got, case['batches']):
+            assert a.tolist() == want['input_data'] and b.tolist() == want['input_length'] and c.tolist() == want['label_data']
+            n += 1
+    assert n >= 15
