@@ -35,5 +35,9 @@ def timed(fn, reps=200):
 ops.attention_stats(Q, K, N, T, T, C, H, stats)
 f = timed(lambda: ops.attention_fwd(Q, K, V, N, T, T, C, H, causal, O, lse, dropout_rate=0.2, seed=7, stats=stats))
 b = timed(lambda: ops.attention_bwd(Q, K, V, O, dO, lse, N, T, T, C, H, causal, gq, gk, gv, ws, relu_grad=1, dropout_rate=0.2, seed=7, stats=stats))
+st = timed(lambda: ops.attention_stats(Q, K, N, T, T, C, H, stats))
+f0 = timed(lambda: ops.attention_fwd(Q, K, V, N, T, T, C, H, causal, O, lse, dropout_rate=0.2, seed=7))
+b0 = timed(lambda: ops.attention_bwd(Q, K, V, O, dO, lse, N, T, T, C, H, causal, gq, gk, gv, ws, relu_grad=1, dropout_rate=0.2, seed=7))
+print('   statistics launch %.1f us; without precomputed statistics: fwd %.1f us  bwd %.1f us   (sum with %.1f, without %.1f)' % (st, f0, b0, st + f + b, f0 + b0))
 print('T %d N %d causal %d: fwd %.1f us  bwd (delta + dK/dV + dQ) %.1f us   checksums %.6e %.6e %.6e' %
       (T, N, causal, f, b, float(O.double().sum()), float(gq.double().sum()), float(gk.double().sum())))
