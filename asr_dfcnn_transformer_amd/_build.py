@@ -38,7 +38,7 @@ def build(force=False, verbose=True):
         o = os.path.join(objdir, os.path.basename(s) + '.o')
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-c', s, '-o', o]
+            cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fvisibility=hidden', '-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -102,7 +102,7 @@ SIGNATURES = {
     'asr_tap_gemm_splitk': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     'asr_tap_gemm_relu_bwd': (_I, [C.POINTER(GemmDesc), _P, _P, _P, _P, _P]),
     'asr_tap_gemm_nt_splitk_workspace': (C.c_size_t, [_P, _I]),
-    'asr_tap_gemm_nt_splitk': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _P]),
+    'asr_tap_gemm_nt_splitk': (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, C.c_size_t, _P]),
     'asr_dropout': (_I, [_P, _Z, _F, C.c_uint, _P, _P]),
     'asr_add_layernorm_fwd': (_I, [_P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
     'asr_layernorm_bwd_workspace': (_Z, [_I, _I]),

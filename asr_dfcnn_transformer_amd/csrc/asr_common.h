@@ -36,6 +36,17 @@ void asr_set_last_kernel(const char* name);
 
 static inline int asr_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Partial rows a gated launch is about to write, against what the caller's partials buffer holds: on entry *rows is that capacity in
+// rows (0: not stated), on success it becomes the number the launch writes.  Called by every launcher BEFORE its hipLaunchKernelGGL, so
+// that a disagreement between a launcher's tiling and the entry point's workspace formula is an ASR_ERR_UNSUPPORTED, never an overrun
+// that is noticed afterwards.
+static inline bool asr_gate_rows_fit(int* rows, int needed) {
+    if (!rows) return true;
+    if (*rows > 0 && needed > *rows) return false;
+    *rows = needed;
+    return true;
+}
+
 // Bijective XCD-aware remap: consecutive logical tiles land on the same XCD (blocks are
 // dealt round-robin over the 8 XCDs), so neighbouring tiles share halo rows / weight
 // panels in that XCD's L2.  Speed only; any placement is correct.

@@ -486,7 +486,8 @@ int asr_gemm1_launch(const asr_gemm_desc* d, const float* A, const float* Bt, in
     if (gate) {
         a.gate_mode = gate->mode; a.gate_H = gate->H; a.gate_W = gate->W; a.gate_a = gate->a; a.gate_dz = gate->dz; a.gate_part = gate->part;
         if (gate->mode == 5) a.halo = gate->C;          // the gated cell's channels (TapGemmArgs: gate mode 5)
-        if (gate->rows) *gate->rows = a.ntm * 2 * (gate->mode == 5 ? gate->W : 1);       // one partial row per (tile row, wave row[, pixel column])
+        // one partial row per (tile row, wave row[, pixel column])
+        if (!asr_gate_rows_fit(gate->rows, a.ntm * 2 * (gate->mode == 5 ? gate->W : 1))) return ASR_ERR_UNSUPPORTED;
     }
     ga.Bt = Bt; ga.ldb = ldb;
     const size_t lds = (size_t)(256 + 2 * (G1_TILE_F + nb * 64 * G1_KC)) * sizeof(float);
@@ -556,9 +557,9 @@ extern "C" int asr_relu_bwd(const float* dy, const float* h, size_t n, float* dz
 extern "C" int asr_tap_gemm_relu_bwd(const asr_gemm_desc* d, const float* dY, const float* W, const float* H, float* dX, void* stream) {
     if (!d || !dY || !W || !H || !dX || d->ntaps != 1 || d->wmode != 1 || d->H > 0 || d->accumulate || d->ldo_y < d->N) return ASR_ERR_BAD_ARG;
     if (!asr_gemm1_eligible(d, dY, W, d->ldw) || ((((uintptr_t)H) | ((uintptr_t)dX)) & 15) || (d->ldo_y & 3)) {
+        if (d->ldo_y != d->N) return ASR_ERR_UNSUPPORTED;          // the mask pass of this route is a flat one: refused BEFORE dX is touched
         const int rc = asr_tap_gemm(d, dY, W, nullptr, nullptr, nullptr, nullptr, dX, stream);
         if (rc != ASR_OK) return rc;
-        if (d->ldo_y != d->N) return ASR_ERR_UNSUPPORTED;          // (the mask pass is a flat one)
         return asr_relu_bwd(dX, H, (size_t)d->M * d->N, dX, stream);
     }
     Gemm1Args ga;
@@ -599,9 +600,10 @@ extern "C" size_t asr_tap_gemm_nt_splitk_workspace(const asr_gemm_desc* d, int s
 }
 
 extern "C" int asr_tap_gemm_nt_splitk(const asr_gemm_desc* d, const float* A, const float* Bt, int ldb, const float* bias, const float* scale,
-                                      const float* shift, float* out_a, float* out_y, int splits, void* workspace, void* stream) {
+                                      const float* shift, float* out_a, float* out_y, int splits, void* workspace, size_t workspace_bytes, void* stream) {
     if (!d || !A || !Bt || (!out_a && !out_y) || !workspace) return ASR_ERR_BAD_ARG;
     if (d->ntaps != 1 || d->H > 0 || d->y_unpadded || splits < 2 || splits > 16) return ASR_ERR_BAD_ARG;
+    if (workspace_bytes < asr_tap_gemm_nt_splitk_workspace(d, splits)) return ASR_ERR_BAD_ARG;      // the slab is splits x M x N floats
     if ((d->K % (splits * 32)) || (d->N & 3) || (d->lda & 3) || (ldb & 3) || ldb < d->K || d->N < 64 ||
         (((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)workspace) & 15)) return ASR_ERR_BAD_ARG;
     if ((long)d->M * d->lda * 4 >= (1L << 31) || (long)d->N * ldb * 4 >= (1L << 31) || (long)splits * d->M >= (1L << 31) / d->N) return ASR_ERR_UNSUPPORTED;

@@ -381,7 +381,7 @@ int launch_v5d(const TapGemmArgs& a, const float* Wf, hipStream_t st) {
     p.g = a; p.Wf = Wf; p.kg = (a.K + 7) / 8; p.nbt = (a.N + 31) / 32;
     p.g.ntm = asr_cdiv(a.M, MT);
     p.g.ntn = asr_cdiv(a.N, NT);
-    if (a.gate_rows) *a.gate_rows = p.g.ntm * WM;
+    if (!asr_gate_rows_fit(a.gate_rows, p.g.ntm * WM)) return ASR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3(p.g.ntm * p.g.ntn), dim3(256), lds, st, p);
     ASR_CHECK_LAUNCH("tap_gemm_pw");
     ASR_NOTE_KERNEL("tap_gemm_kernel_v5<%d, %d, %d, %d, %d, %d, %d, %d, %d>", MT, NT, WM, WN, NTAPS, KCV, D, MINB, DIR);
@@ -441,7 +441,7 @@ int launch_v1(const TapGemmArgs& a, hipStream_t st) {
     TapGemmArgs g = a;
     g.ntm = asr_cdiv(a.M, MT);
     g.ntn = asr_cdiv(a.N, NT);
-    if (a.gate_rows) *a.gate_rows = g.ntm * WM;
+    if (!asr_gate_rows_fit(a.gate_rows, g.ntm * WM)) return ASR_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3(g.ntm * g.ntn, (NTAPS == 1 && WMODE == 0 && g.ksplit > 1) ? g.ksplit : 1), dim3(256), lds, st, g);
     ASR_CHECK_LAUNCH("tap_gemm");
     ASR_NOTE_KERNEL("tap_gemm_kernel_v1<%d, %d, %d, %d, %d, %d, %d>", MT, NT, WM, WN, NTAPS, WMODE, KCV);
@@ -695,14 +695,14 @@ extern "C" ASR_INTERNAL int asr_tap_gemm_wino_gated_launch(const asr_gemm_desc* 
 
 // Data-gradient GEMM whose epilogue IS the backward prologue of the cell in front (tap_epilogue_gated).
 extern "C" ASR_INTERNAL int asr_winograd_gate_rows(const asr_gemm_desc* d);                                              // wino.hip
-static int gated_partial_rows(const asr_gemm_desc* d) {
+extern "C" ASR_INTERNAL int asr_gated_partial_rows(const asr_gemm_desc* d) {      // rows the partials buffer of asr_tap_gemm_gated_workspace holds (wino.hip uses it too)
     int rows = asr_cdiv(d->M, 32) + 4;                        // every direct launch configuration has >= 32 tile rows per wave row (+ the ragged last tile)
     const int wr = asr_winograd_gate_rows(d);                 // the Winograd kernels: 4 per tile block (more on planes of few tile rows)
     return wr > rows ? wr : rows;
 }
 extern "C" size_t asr_tap_gemm_gated_workspace(const asr_gemm_desc* d) {
     if (!d) return 0;
-    const int rows = gated_partial_rows(d);
+    const int rows = asr_gated_partial_rows(d);
     return ((size_t)rows * 3 * d->N + asr_reduce::colsum_tmp_floats(rows, 3 * d->N)) * sizeof(float);
 }
 
@@ -717,7 +717,7 @@ extern "C" int asr_tap_gemm_gated(const asr_gemm_desc* d, const float* dZ, const
     if (d->H <= 0) return ASR_ERR_UNSUPPORTED;                 // pixel-indexed outputs only
     if (pool == 0 ? (gate_H != d->H || gate_W != d->W) : (gate_H != 2 * d->H || gate_W != 2 * d->W)) return ASR_ERR_BAD_ARG;
     if (d->ldo_y != d->N) return ASR_ERR_BAD_ARG;
-    int rows = 0;
+    int rows = asr_gated_partial_rows(d);                         // capacity of `partials` in rows; the launcher refuses to write more
     GateSpec gs;
     gs.mode = pool + 1; gs.H = gate_H; gs.W = gate_W; gs.a = gate_a; gs.dz = dz_out; gs.part = partials; gs.rows = &rows;
     const int rc = prearranged == 2 ? asr_tap_gemm_wino_gated_launch(d, dZ, W, gs.mode, gs.H, gs.W, gs.a, bn_scale, bn_shift, (float*)dy_prev,
@@ -725,7 +725,7 @@ extern "C" int asr_tap_gemm_gated(const asr_gemm_desc* d, const float* dZ, const
                  : prearranged ? tap_gemm_pw_impl(d, dZ, W, nullptr, bn_scale, bn_shift, nullptr, (float*)dy_prev, stream, &gs)
                                : tap_gemm_impl(d, dZ, W, nullptr, bn_scale, bn_shift, nullptr, (float*)dy_prev, stream, &gs);
     if (rc != ASR_OK) return rc;
-    if (rows <= 0 || rows > gated_partial_rows(d)) return ASR_ERR_UNSUPPORTED;
+    if (rows <= 0) return ASR_ERR_UNSUPPORTED;
     asr_reduce::Multi m;
     m.nseg = 3; m.width[0] = d->N; m.width[1] = d->N; m.width[2] = d->N; m.width[3] = 0;
     m.out[0] = dscale; m.out[1] = dshift; m.out[2] = dbias; m.out[3] = nullptr;
@@ -757,12 +757,12 @@ extern "C" int asr_tap_gemm_gated_dense(const asr_gemm_desc* d, const float* dZ,
                                         float* dscale, float* dshift, float* dbias, float* partials, void* stream) {
     if (!d || !dZ || !W || !a_plane || !bn_scale || !bn_shift || !dz_out || !dscale || !dshift || !dbias || !partials) return ASR_ERR_BAD_ARG;
     if (!asr_tap_gemm_gated_dense_supported(d, gate_H, gate_W, gate_C) || !asr_gemm1_eligible(d, dZ, W, d->ldw)) return ASR_ERR_UNSUPPORTED;
-    int rows = 0;
+    int rows = asr_cdiv(d->M, 128) * 2 * gate_W;              // capacity of `partials` (asr_tap_gemm_gated_dense_workspace); checked before the launch
     Gemm1Gate gg;
     gg.mode = 5; gg.H = gate_H; gg.W = gate_W; gg.C = gate_C; gg.a = a_plane; gg.dz = dz_out; gg.part = partials; gg.rows = &rows;
     const int rc = asr_gemm1_launch(d, dZ, W, d->ldw, nullptr, bn_scale, bn_shift, nullptr, nullptr, 1, stream, &gg);
     if (rc != ASR_OK) return rc;
-    if (rows <= 0 || (size_t)rows * 3 * gate_C * sizeof(float) > asr_tap_gemm_gated_dense_workspace(d, gate_W, gate_C)) return ASR_ERR_UNSUPPORTED;
+    if (rows <= 0) return ASR_ERR_UNSUPPORTED;
     asr_reduce::Multi m;
     m.nseg = 3; m.width[0] = gate_C; m.width[1] = gate_C; m.width[2] = gate_C; m.width[3] = 0;
     m.out[0] = dscale; m.out[1] = dshift; m.out[2] = dbias; m.out[3] = nullptr;

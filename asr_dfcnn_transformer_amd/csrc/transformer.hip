@@ -464,6 +464,7 @@ inline int grid_for(long total, int threads) {
 }  // namespace
 
 // ===================================================================== C ABI
+namespace {
 __global__ void copy2d_kernel(float* __restrict__ dst, int ldd, const float* __restrict__ src, int lds, int rows, int c4n,
                               int accumulate) {
     const long total = (long)rows * c4n;
@@ -476,6 +477,7 @@ __global__ void copy2d_kernel(float* __restrict__ dst, int ldd, const float* __r
         *(float4*)d = v;
     }
 }
+}  // namespace
 
 extern "C" int asr_copy2d(float* dst, int ldd, const float* src, int lds, int rows, int cols, int accumulate, void* stream) {
     if (!dst || !src || rows < 1 || cols < 4 || (cols & 3) || (ldd & 3) || (lds & 3) || ldd < cols || lds < cols) return ASR_ERR_BAD_ARG;
@@ -487,6 +489,7 @@ extern "C" int asr_copy2d(float* dst, int ldd, const float* src, int lds, int ro
 }
 
 // several strided copies in ONE launch: the table (asr_copy2d_item, device memory) is built once by the caller
+namespace {
 __global__ void copy2d_batch_kernel(const asr_copy2d_item* __restrict__ items, int accumulate) {
     const asr_copy2d_item it = items[blockIdx.y];
     const int c4n = it.cols >> 2;
@@ -500,6 +503,7 @@ __global__ void copy2d_batch_kernel(const asr_copy2d_item* __restrict__ items, i
         *(float4*)d = v;
     }
 }
+}  // namespace
 
 extern "C" int asr_copy2d_batch(const asr_copy2d_item* items_dev, int n_items, int max_elems, int accumulate, void* stream) {
     if (!items_dev || n_items < 1 || n_items > 65535 || max_elems < 4) return ASR_ERR_BAD_ARG;

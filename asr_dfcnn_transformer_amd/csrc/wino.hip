@@ -1392,7 +1392,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     if (wino11_takes(d, pool_y != nullptr, a.gate_mode)) {
         const int nblk11 = d->B * w.cb_it0[w.ncb];
         a.ntm = nblk11; a.ntn = d->N / W11_C;
-        if (a.gate_rows) *a.gate_rows = nblk11 * 8;
+        if (!asr_gate_rows_fit(a.gate_rows, nblk11 * 8)) return ASR_ERR_UNSUPPORTED;
         const long nwork11 = (long)nblk11 * a.ntn;
 #if defined(ASR_DEV_HOOKS) && defined(W11_ONE_PER_CU)      // development probe (tools/build_variant.sh one wino.hip -DASR_DEV_HOOKS -DW11_ONE_PER_CU): ONE workgroup per CU,
                                                            // the LDS request padded so that two cannot share one (profiles/r05_wino11_one_wg_probe.txt)
@@ -1437,7 +1437,7 @@ static int wino_impl(const asr_gemm_desc* d, const float* A, const float* Ut, co
     w.ncb = 0;
     const int nblk = asr_cdiv(w.ntiles, WT);
     a.ntm = nblk; a.ntn = d->N / WC;
-    if (a.gate_rows) *a.gate_rows = nblk * 4;
+    if (!asr_gate_rows_fit(a.gate_rows, nblk * 4)) return ASR_ERR_UNSUPPORTED;
     const size_t lds8 = (size_t)(576 + 2 * RAW_F + 2 * U_F) * sizeof(float);
     static_assert(4 * 2048 <= RAW_F && 4 * 2048 <= U_F && 4 * 32 * 33 + 2 * 1024 <= RAW_F && 4 * 32 * 33 + 2 * 1024 <= U_F, "exchange / scratch + pool hand-over must fit in one buffer set");
     const int nwork8 = nblk * a.ntn;
@@ -1526,7 +1526,7 @@ extern "C" int asr_tap_gemm_wino_poolmax(const asr_gemm_desc* d, const float* A,
     return wino_impl(d, A, Ut, bias, scale, shift, nullptr, nullptr, stream, nullptr, y_pooled, 2, a_max, index);
 }
 
-extern "C" size_t asr_tap_gemm_gated_workspace(const asr_gemm_desc* d);
+extern "C" ASR_INTERNAL int asr_gated_partial_rows(const asr_gemm_desc* d);       // tap_gemm.hip: rows the partials buffer of asr_tap_gemm_gated_workspace holds
 
 extern "C" int asr_tap_gemm_gated_poolmax(const asr_gemm_desc* d, const float* dZ, const float* Ut, int gate_H, int gate_W, const float* a_max,
                                           const unsigned* index, const float* bn_scale, const float* bn_shift, const float* dy_prev,
@@ -1535,12 +1535,12 @@ extern "C" int asr_tap_gemm_gated_poolmax(const asr_gemm_desc* d, const float* d
     if (d->wmode != 1 || d->relu != 0 || d->y_unpadded || d->H <= 0 || d->ldo_y != d->N || (d->accumulate && !dy_prev)) return ASR_ERR_BAD_ARG;
     if (gate_H != 2 * d->H || gate_W != 2 * d->W) return ASR_ERR_BAD_ARG;
     if (!asr_winograd_supported(d) || !wino11_takes(d, false, 4)) return ASR_ERR_UNSUPPORTED;
-    int rows = 0;
+    int rows = asr_gated_partial_rows(d);                     // capacity of `partials`; wino_impl refuses before its launch when it needs more
     WinoGate gs;
     gs.mode = 4; gs.H = gate_H; gs.W = gate_W; gs.a = a_max; gs.dz = dz_out; gs.part = partials; gs.rows = &rows;
     const int rc = wino_impl(d, dZ, Ut, nullptr, bn_scale, bn_shift, nullptr, (float*)dy_prev, stream, &gs, nullptr, 0, nullptr, (unsigned*)index);
     if (rc != ASR_OK) return rc;
-    if (rows <= 0 || (size_t)rows * 3 * d->N * sizeof(float) > asr_tap_gemm_gated_workspace(d)) return ASR_ERR_UNSUPPORTED;
+    if (rows <= 0) return ASR_ERR_UNSUPPORTED;
     asr_reduce::Multi m;
     m.nseg = 3; m.width[0] = d->N; m.width[1] = d->N; m.width[2] = d->N; m.width[3] = 0;
     m.out[0] = dscale; m.out[1] = dshift; m.out[2] = dbias; m.out[3] = nullptr;
@@ -1570,12 +1570,12 @@ extern "C" int asr_tap_gemm_gated_poolavg(const asr_gemm_desc* d, const float* d
     if (d->wmode != 1 || d->relu != 0 || d->y_unpadded || d->H <= 0 || d->ldo_y != d->N || (d->accumulate && !dy_prev)) return ASR_ERR_BAD_ARG;
     if (gate_H != 2 * d->H || gate_W != 2 * d->W) return ASR_ERR_BAD_ARG;
     if (!asr_winograd_supported(d) || !wino11_takes(d, false, 6)) return ASR_ERR_UNSUPPORTED;
-    int rows = 0;
+    int rows = asr_gated_partial_rows(d);                     // capacity of `partials`; wino_impl refuses before its launch when it needs more
     WinoGate gs;
     gs.mode = 6; gs.H = gate_H; gs.W = gate_W; gs.a = a_sum; gs.dz = dz_out; gs.part = partials; gs.rows = &rows;
     const int rc = wino_impl(d, dZ, Ut, nullptr, bn_scale, bn_shift, nullptr, (float*)dy_prev, stream, &gs, nullptr, 0, nullptr, (unsigned*)index);
     if (rc != ASR_OK) return rc;
-    if (rows <= 0 || (size_t)rows * 3 * d->N * sizeof(float) > asr_tap_gemm_gated_workspace(d)) return ASR_ERR_UNSUPPORTED;
+    if (rows <= 0) return ASR_ERR_UNSUPPORTED;
     asr_reduce::Multi m;
     m.nseg = 3; m.width[0] = d->N; m.width[1] = d->N; m.width[2] = d->N; m.width[3] = 0;
     m.out[0] = dscale; m.out[1] = dshift; m.out[2] = dbias; m.out[3] = nullptr;

@@ -355,7 +355,7 @@ class DFCNNEngine:
                 if cin <= 128 and cout >= 1024 and cout % 256 == 0 and src != 'x':
                     self.dsplitk[dst] = ops.gemm_desc(rows, cout, cin, cout, cin, 0, cin, ntaps=1)
                     self.dsplitk_n[dst] = nt_splits(cout, cin) if self.opt_nt_splitk else 8
-                    ws_bytes = max(ws_bytes, ops.tap_gemm_nt_splitk_workspace(self.dsplitk[dst], 8))
+                    ws_bytes = max(ws_bytes, ops.tap_gemm_nt_splitk_workspace(self.dsplitk[dst], self.dsplitk_n[dst]))
         self.T8 = self.res[self.g[-1][2]][0]
         T8, V = self.T8, self.V
         self.logits = torch.zeros(T8, B, V, dtype=torch.float32, device=dev)      # self.logits of the reference

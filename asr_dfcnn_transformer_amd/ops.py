@@ -161,7 +161,8 @@ def tap_gemm_nt_splitk(desc, A, Bt, ldb, bias, scale, shift, out_a, out_y, split
     """Split-K dense GEMM on the LDS-DMA kernel, both operands K-contiguous (asr_tap_gemm_nt_splitk)."""
     lib = _lib.load()
     _timed(desc, lambda: check(lib.asr_tap_gemm_nt_splitk(C.byref(desc), _ptr(A), _ptr(Bt), int(ldb), _ptr(bias), _ptr(scale), _ptr(shift),
-                                                          _ptr(out_a), _ptr(out_y), int(splits), _ptr(workspace), _stream()), 'asr_tap_gemm_nt_splitk'))
+                                                          _ptr(out_a), _ptr(out_y), int(splits), _ptr(workspace), workspace.numel() * workspace.element_size(),
+                                                          _stream()), 'asr_tap_gemm_nt_splitk'))
 
 
 def tap_gemm_gated_workspace(desc):

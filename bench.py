@@ -428,25 +428,24 @@ def run_transformer(args):
 
 def shutdown_process_group(seconds=60):
     """dist.destroy_process_group() under a deadline.  The measurement is finished and printed when this runs; a rank that then sits in the
-    group's teardown for ever (seen once in a 4-rank gloo rehearsal on one GPU: the JSON line was out, the job never ended) would hold the
-    launcher and the box.  After ``seconds`` the rank says so and exits with 0."""
+    group's teardown for ever would hold the launcher and the box.  After ``seconds`` the rank dumps every thread's stack to stderr and exits
+    with code 4: a stuck teardown is a FAILED run for the launcher (`spawn_ranks` / torch.distributed.run stop the other ranks), never a
+    green one.  When the teardown returns, the rank leaves through the normal interpreter / HIP runtime exit, so that a fault at exit
+    keeps its exit code too."""
+    import faulthandler
     import threading
     done = threading.Event()
 
     def watchdog():
         if not done.wait(seconds):
-            sys.stderr.write('bench.py: rank %s: destroy_process_group() did not return within %d s; exiting\n' % (os.environ.get('RANK', '0'), seconds))
+            sys.stderr.write('bench.py: rank %s: destroy_process_group() did not return within %d s; stacks follow, exit code 4\n'
+                             % (os.environ.get('RANK', '0'), seconds))
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
             sys.stderr.flush(); sys.stdout.flush()
-            os._exit(0)
+            os._exit(4)
     threading.Thread(target=watchdog, daemon=True).start()
-    world = dist.get_world_size()
     dist.destroy_process_group()
     done.set()
-    if world > 1:
-        # the last statement of a rank: leave at once -- what is still to run (interpreter and HIP runtime teardown of several processes
-        # on a shared device) has nothing to add to a finished measurement
-        sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
 
 
 def engine_kwargs(args):

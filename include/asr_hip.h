@@ -32,6 +32,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* Every declaration below is an exported entry point; the library itself is built with -fvisibility=hidden, so its dynamic
+ * symbol table holds these names and nothing else (tests/test_abi_cpu.py). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 typedef enum {
     ASR_OK = 0,
@@ -502,12 +507,13 @@ int asr_tap_gemm_splitk(const asr_gemm_desc* d, const float* A, const float* W, 
 /* The same split on the LDS-DMA kernel of asr_tap_gemm_nt (gemm1.hip): both operands K-contiguous -- A [M][K] (pitch d->lda) and
  * Bt [N][K] (pitch ldb): a forward layer's transposed kernel (asr_transpose_batch), or the kernel W [K_out][N_out] itself for a
  * data-gradient dX = dY . W^T (then d->K = the layer's output width, d->N its input width).  d->wmode is not read.  N >= 64,
- * K % (32 * splits) == 0, 2 <= splits <= 16; workspace = asr_tap_gemm_nt_splitk_workspace(d, splits) bytes, 16-byte aligned.
+ * K % (32 * splits) == 0, 2 <= splits <= 16; workspace = asr_tap_gemm_nt_splitk_workspace(d, splits) bytes, 16-byte aligned;
+ * workspace_bytes = what the caller really holds there: a smaller buffer is refused (ASR_ERR_BAD_ARG) before anything is launched.
  * Round 5: the 6400 -> 128 hidden dense of acoustic_model.py:53 (ten splits: 500 workgroups for the chip's 512 slots) and the
  * 1536 -> 128 data-gradient behind it, which asr_tap_gemm_splitk ran on 64 x 64 register-staged tiles. */
 size_t asr_tap_gemm_nt_splitk_workspace(const asr_gemm_desc* d, int splits);
 int asr_tap_gemm_nt_splitk(const asr_gemm_desc* d, const float* A, const float* Bt, int ldb, const float* bias, const float* scale,
-                           const float* shift, float* out_a, float* out_y, int splits, void* workspace, void* stream);
+                           const float* shift, float* out_a, float* out_y, int splits, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Data-gradient of a dense layer fed by a Dense(relu) layer, with that layer's ReLU backward in the epilogue (round 5):
  *   dX[rows][d->N] = (dY[rows][d->K] . W[d->N][d->K]^T) where H[rows][d->N] > 0, else 0        (d: ntaps 1, wmode 1, accumulate 0; H and dX share
@@ -645,6 +651,9 @@ int asr_tap_gemm_gated_poolavg(const asr_gemm_desc* d, const float* dZ, const fl
                                const unsigned* index, const float* bn_scale, const float* bn_shift, const float* dy_prev,
                                float* dz_out, float* dscale, float* dshift, float* dbias, float* partials, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -27,12 +27,14 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_library_exports_nothing_the_header_does_not_declare():
-    """The dynamic symbol table of libasrhip.so == the declarations of include/asr_hip.h: cross-file helpers are hidden
-    (ASR_INTERNAL), development hooks are not in the product build."""
+    """The dynamic symbol table of libasrhip.so == the declarations of include/asr_hip.h, compared over ALL defined dynamic symbols
+    (C++-mangled ones included; only the `__hip_*` registration objects hipcc emits per translation unit are set aside): the library
+    is built with -fvisibility=hidden and the header's declarations sit inside a `visibility push(default)` region, so cross-file
+    helpers, inline reductions and device stubs stay out."""
     import subprocess
     from asr_dfcnn_transformer_amd import _build
     out = subprocess.run(['nm', '-D', '--defined-only', _build.LIB], check=True, stdout=subprocess.PIPE).stdout.decode()
-    exported = sorted(l.split()[-1] for l in out.splitlines() if l.split() and l.split()[-1].startswith('asr_'))
+    exported = sorted(l.split()[-1] for l in out.splitlines() if l.split() and not l.split()[-1].startswith('__hip_'))
     assert exported == _declared(), (sorted(set(exported) - set(_declared())), sorted(set(_declared()) - set(exported)))
 
 

@@ -58,12 +58,19 @@ def test_one_utterance_full_width_vs_float64_reference(model, T):
     # max-pool graphs (m1): a near-tie inside a 2x2 window can pick a different arg-max in float32 than in the
     # float64 reference, which re-routes single gradient elements; the bar for its conv gradients is 5e-3
     tol = 5e-3 if model == 'm1' else 1e-3
+    beyond, total = 0, 0
     for layer in P:                                       # EVERY layer of the graph
         for key in P[layer]:
             ref = tP[layer][key].grad.numpy()
-            rel = np.abs(G[layer][key] - ref).max() / max(1e-12, np.abs(ref).max())
+            dev = np.abs(G[layer][key] - ref) / max(1e-12, np.abs(ref).max())
+            rel = dev.max()
+            beyond += int((dev >= 1e-3).sum()); total += dev.size
             print(model, layer, key, 'grad rel err %.2e' % rel)
             assert rel < tol, (layer, key, rel)
+    # the 5e-3 ceiling of the max-pool graphs is for SINGLE re-routed elements: counted over every gradient element of the model, those
+    # beyond north_star's 1e-3 (of their tensor's scale) must stay a vanishing fraction
+    print(model, 'gradient elements beyond 1e-3 of their tensor scale: %d of %d' % (beyond, total))
+    assert beyond <= 1e-5 * total, (beyond, total)
 
 
 @pytest.mark.parametrize("model,B", [("m2", 32), ("m1", 32), ("small", 4)])

@@ -222,13 +222,16 @@ def test_dense_split_k_argument_checks(ops):
     x = torch.zeros(M, K, device='cuda'); wt = torch.zeros(N, K, device='cuda'); y = torch.zeros(M, N, device='cuda')
     ws = torch.zeros(16 * M * N, device='cuda')
     p = lambda t: t.data_ptr()
-    call = lambda d, splits, ldb=K, w=ws: lib.asr_tap_gemm_nt_splitk(C_.byref(d), p(x), p(wt), ldb, None, None, None, None, p(y), splits, p(w) if w is not None else None, None)
+    call = lambda d, splits, ldb=K, w=ws: lib.asr_tap_gemm_nt_splitk(C_.byref(d), p(x), p(wt), ldb, None, None, None, None, p(y), splits, p(w) if w is not None else None,
+                                                                     4 * w.numel() if w is not None else 0, None)
     good = ops.gemm_desc(M, K, N, K, N, 0, N, ntaps=1)
     assert call(good, 4) == 0
     assert call(good, 1) == -1 and call(good, 17) == -1          # 2 <= splits <= 16
     assert call(good, 3) == -1                                   # 1024 % (32 * 3) != 0
     assert call(good, 4, ldb=K - 4) == -1
     assert call(good, 4, w=None) == -1
+    assert call(good, 4, w=ws[:4 * M * N - 4]) == -1             # a slab smaller than splits x M x N floats
+    assert call(good, 4, w=ws[:4 * M * N]) == 0
     assert call(ops.gemm_desc(M, K, 32, K, 32, 0, 32, ntaps=1), 4) == -1      # N < 64: the 64 x 64 tiles of asr_tap_gemm_splitk take those
     assert lib.asr_tap_gemm_nt_splitk_workspace(C_.byref(good), 4) == 4 * M * N * 4
     torch.cuda.synchronize()
