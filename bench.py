@@ -625,7 +625,12 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='dfcnn', choices=['dfcnn', 'se_dfcnn', 'transformer', 'e2e_prenet', 'am_lm', 'lm'])
-    ap.add_argument('--batch', type=int, default=32, help='utterances per GPU')
+    ap.add_argument('--batch', type=int, default=32, help='utterances per GPU (weak scaling); the GLOBAL batch with --scaling strong')
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='DFCNN workloads.  weak (default; what the driver\'s command line gets): --batch utterances on EVERY GPU.  strong: '
+                         'SURVEY 8e\'s first partition -- the global batch (--batch, 32 = hparams.py:15 am_batch_size) is split, batch // N '
+                         'utterances per GPU; N must divide it.  The loss is reduce_mean over the batch (acoustic_model2.py:83), so N equal '
+                         'shards + the summed gradient / N are the one-GPU step of the global batch')
     ap.add_argument('--tpad', type=int, default=1600)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dropout', type=float, default=0.2, help='Transformer workloads: dropout_rate (reference default 0.2, model.py:36)')
@@ -653,6 +658,9 @@ def main():
                     help='untimed steps of the same workload in a child process before this one touches the GPU (default 0: none; '
                          'never with more than one rank); see prime_gpu()')
     args = ap.parse_args()
+    if args.scaling == 'strong' and (args.gpus < 1 or args.batch % args.gpus != 0):
+        print('bench.py: --scaling strong splits the global batch %d over %d GPUs: the GPU count must divide it' % (args.batch, args.gpus), file=sys.stderr)
+        return 2
     if 'WORLD_SIZE' not in os.environ:
         if args.gpus > 1:
             return spawn_ranks(args.gpus)
@@ -666,6 +674,9 @@ def main():
         except PrimeChildDied as e:
             print('bench.py: %s\nbench.py: not measuring on a GPU whose last process hung or was killed' % e, file=sys.stderr)
             return 3
+    if args.scaling == 'strong' and args.workload not in ('dfcnn', 'se_dfcnn'):
+        print('bench.py: --scaling strong is the partition of SURVEY 8e (the DFCNN workloads); %s runs weak only' % args.workload, file=sys.stderr)
+        return 2
     if args.workload in ('transformer', 'e2e_prenet'):
         return run_transformer(args)
     if args.workload == 'am_lm':
@@ -684,7 +695,11 @@ def main():
     torch.cuda.set_device(local)
     dev = 'cuda'
     variant = 'm1' if args.workload == 'dfcnn' else 'm2'
-    B, T, F, V = args.batch, args.tpad, 200, 1536
+    strong = args.scaling == 'strong'
+    if strong and (args.batch % world != 0 or args.batch // world < 1):
+        print('bench.py: --scaling strong splits the global batch %d over %d ranks: the rank count must divide it' % (args.batch, world), file=sys.stderr)
+        return 2
+    B, T, F, V = (args.batch // world if strong else args.batch), args.tpad, 200, 1536
     eng = DFCNNEngine(model=variant, vocab=V, B=B, T=T, F=F, seed=0, device=dev, **engine_kwargs(args))
     if args.rccl_world1 and world == 1 and not dist.is_initialized():
         # A/B (never the headline): the one-rank step WITH its three RCCL all-reduces -- what the collectives' launches, their
@@ -703,9 +718,13 @@ def main():
     signal = torch.from_numpy(host).to(dev)
     host_pinned = torch.from_numpy(host).pin_memory() if args.host_input else None
     nsamp = torch.full((B,), ns, dtype=torch.int32, device=dev)
-    lab_rng = np.random.default_rng(99 + rank)
     target = np.zeros((B, 64), dtype=np.int32)
-    target[:, :32] = lab_rng.integers(1, V - 1, (B, 32))
+    if strong:
+        # the SAME global batch whatever N: utterance rank * B + b carries signal seed 1234 + rank * B + b (above) and row rank * B + b of
+        # one label table, so that N ranks of B = G / N take the step one rank takes at B = G (tests/test_bench_gpu.py)
+        target[:, :32] = np.random.default_rng(99).integers(1, V - 1, (world * B, 32))[rank * B:(rank + 1) * B]
+    else:
+        target[:, :32] = np.random.default_rng(99 + rank).integers(1, V - 1, (B, 32))
     seq = np.full(B, min(200, 999 // 8 + 1), dtype=np.int32)
     # Feature prefetch, as a data loader would do it: the fbank of the NEXT batch is computed on a second stream while
     # the model works on the current one (two feature buffers).  Every step still computes exactly one batch of
@@ -801,7 +820,7 @@ def main():
     else:
         plan[len(plan) - 1:len(plan) - 1] = ['single', 'single']
     tables = []
-    for kind in plan:
+    for i_warm, kind in enumerate(plan):
         if kind == 'single':
             torch.cuda.synchronize()
             ops.TIMER = ops.KernelTimer()
@@ -811,6 +830,11 @@ def main():
             ops.TIMER = None
         else:
             step()
+        if i_warm == 0 and rank == 0 and os.environ.get('ASR_BENCH_DUMP_FIRST_GRADIENT'):
+            # test hook (tests/test_bench_gpu.py): the gradient of the FIRST step as Adam saw it -- summed over the ranks and scaled by
+            # 1 / world -- at the seeded initial parameters: N ranks of a strong-scaling run must reproduce the one-rank gradient
+            torch.cuda.synchronize()
+            np.save(os.environ['ASR_BENCH_DUMP_FIRST_GRADIENT'], (eng.grad.double() * red.grad_scale).cpu().numpy())
     table = {k: min((t[k] for t in tables if k in t), key=lambda r: r['total_ms']) for k in set().union(*tables)}
     torch.cuda.synchronize()
     overlapped = eng.side is not None
@@ -868,7 +892,7 @@ def main():
                        else 'utterances/sec (10 s audio, B=32) DFCNN+CTC fwd+bwd'),
             'value': round(utt_s, 3), 'unit': 'utterances/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(step_ms, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
+            'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'fp32', 'data': 'synthetic',
             'config': {'workload': ('plain DFCNN (acoustic_model.py) + CTC' if variant == 'm1' else
                                     'SE-DFCNN (acoustic_model2.py) + CTC') +
                                    (', fbank+fwd+greedy decode' if args.inference else ', fbank+fwd+CTC+greedy+bwd+Adam') + ', 10 s/16 kHz audio, T_pad %d, V %d' % (T, V),

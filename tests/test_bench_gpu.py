@@ -34,3 +34,40 @@ def test_two_gloo_ranks_finish_and_report_one_line(disagree):
     assert out['n_gpus'] == 2 and out['config']['ranks'] == 2 and out['config']['dist_backend'] == 'gloo'
     assert out['config']['global_batch'] == 4 and out['config']['gradient_collectives_per_step'] == 3
     assert out['value'] > 0 and out['roofline']['kernel'] and out['roofline']['achieved'] > 0
+
+
+def _run_bench(extra, env_extra=None, timeout=360):
+    env = dict(os.environ, ASR_DIST_BACKEND='gloo', ASR_BENCH_TRACEBACK_AFTER='300')
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--tpad', '1000', '--no-cpu-baseline'] + extra
+    p = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    return p, [l for l in p.stdout.decode().splitlines() if l.startswith('{')]
+
+
+def test_strong_scaling_splits_the_global_batch_and_reproduces_the_one_rank_gradient(tmp_path):
+    """SURVEY 8e's first partition (global batch -> batch / N per GPU; acoustic_model2.py:83 reduce_mean, hparams.py:15 am_batch_size):
+    `--scaling strong` on two ranks with a global batch of 4 takes the step one rank takes at B = 4 -- same utterances, same labels,
+    the summed gradient / 2 equal to the one-rank gradient to 1e-6 of its scale -- and says so in its line."""
+    import numpy as np
+    g2, g1 = str(tmp_path / 'g2.npy'), str(tmp_path / 'g1.npy')
+    p, lines = _run_bench(['--gpus', '2', '--batch', '4', '--scaling', 'strong'], {'ASR_BENCH_DUMP_FIRST_GRADIENT': g2})
+    assert p.returncode == 0 and len(lines) == 1, p.stderr.decode(errors='replace')[-3000:]
+    out = json.loads(lines[0])
+    assert out['scaling'] == 'strong' and out['n_gpus'] == 2
+    assert out['config']['global_batch'] == 4 and out['config']['batch_per_gpu'] == 2 and out['config']['parallelism'] == 'dp2'
+    assert abs(out['value'] - 4 * out['steps'] / (out['ms_per_step'] * 1e-3 * out['steps'])) <= 1e-2 * out['value']      # GLOBAL batch / step time
+    p, lines = _run_bench(['--gpus', '1', '--batch', '4'], {'ASR_BENCH_DUMP_FIRST_GRADIENT': g1})
+    assert p.returncode == 0 and len(lines) == 1, p.stderr.decode(errors='replace')[-3000:]
+    one = json.loads(lines[0])
+    assert one['scaling'] == 'weak' and one['config']['global_batch'] == 4
+    a, b = np.load(g2), np.load(g1)
+    assert a.shape == b.shape and np.abs(b).max() > 0
+    assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
+
+
+def test_strong_scaling_refuses_a_rank_count_that_does_not_divide_the_batch():
+    p, lines = _run_bench(['--gpus', '3', '--batch', '32', '--scaling', 'strong'])
+    assert p.returncode == 2 and not lines and 'must divide' in p.stderr.decode()
