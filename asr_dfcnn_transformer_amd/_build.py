@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libasrhip.so')
 SOURCES = ['runtime.hip', 'tap_gemm.hip', 'tap_wgrad.hip', 'cells.hip', 'head.hip', 'fbank.hip',
-           'transformer.hip', 'attention.hip', 'prenet.hip', 'attention_nm.hip', 'wino.hip', 'gemm1.hip', 'wino_wgrad.hip']
+           'transformer.hip', 'attention.hip', 'attention_small.hip', 'prenet.hip', 'attention_nm.hip', 'wino.hip', 'gemm1.hip', 'wino_wgrad.hip']
 
 
 def _hipcc():

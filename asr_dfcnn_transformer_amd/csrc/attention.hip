@@ -75,6 +75,19 @@ __device__ __forceinline__ void attn_block_coords(int H, bool longest_is_last, i
     }
 }
 
+// Causal launches: which 32-row block of the workgroup's 128 a wave owns.  The four waves of a workgroup sit on the four SIMDs of the CU in
+// order, and under the causal mask block b walks b + 1 (forward, dQ) or 4 - b (dK / dV) more tiles than block 0 / 3: with wave w on
+// block w EVERY workgroup of a CU put its longest wave on the same SIMD, which then carried 4 + 4 (+ 4) tiles while another carried
+// 1 + 1 (+ 1) -- the kernels ran at the pace of that SIMD (T = 100, one tile row: 1.6x; T = 512: 1.18x, the "0.66 instead of 0.56 of the
+// non-causal time" of round 5).  Round 6: the assignment is rotated by a number that differs between the workgroups a CU holds at the
+// same time (dispatch order i, i + 256, i + 512 at the start of a launch: (i >> 8) steps the rotation; (i >> 3) varies it over time).
+template <bool CAUSAL>
+__device__ __forceinline__ int attn_wave_block(int wave) {
+    if (!CAUSAL) return wave;
+    const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
+    return (wave + (int)(((id >> 3) + (id >> 8)) & 3u)) & 3;
+}
+
 // ------------------------------------------------------------------ LDS-DMA of the streamed tiles (round 3)
 // The K / V (forward, dQ) and Q / dO (dK, dV) tiles are 64 rows x 64 floats of a head slice.  They arrive by buffer-form
 // LDS-DMA (buffer_load_dwordx4 ... lds: resource and row offset scalar, per-lane offset constant -- no vector instruction per
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(256, TK == 64 ? 2 : 3) void attn_fwd_kernel(const f
     int qtile, head, n, Nn;
     attn_block_coords<CAUSAL>(H, true, qtile, head, n, Nn);
     const int hoff = head * DH;
-    const int q0 = qtile * 128 + wave * 32, q = q0 + li;
+    const int q0 = qtile * 128 + attn_wave_block<CAUSAL>(wave) * 32, q = q0 + li;
     const long qbase = (long)n * Tq, kbase = (long)n * Tk;
     const int ntiles = (Tk + TK - 1) / TK;
 
@@ -489,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
     int ktile, head, n, Nn;
     attn_block_coords<CAUSAL>(H, false, ktile, head, n, Nn);      // causal: the first key tile sees every query
     const int hoff = head * DH;
-    const int k0 = ktile * 128 + wave * 32, key = k0 + li;
+    const int k0 = ktile * 128 + attn_wave_block<CAUSAL>(wave) * 32, key = k0 + li;
     const long qbase = (long)n * Tq, kbase = (long)n * Tk;
     const long lrow = ((long)n * H + head) * Tq;
 
@@ -664,7 +677,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
     int qtile, head, n, Nn;
     attn_block_coords<CAUSAL>(H, true, qtile, head, n, Nn);
     const int hoff = head * DH;
-    const int q0 = qtile * 128 + wave * 32, q = q0 + li;
+    const int q0 = qtile * 128 + attn_wave_block<CAUSAL>(wave) * 32, q = q0 + li;
     const long qbase = (long)n * Tq, kbase = (long)n * Tk;
     int ntiles = (Tk + TK - 1) / TK;
     if (CAUSAL) { const int lim = (qtile * 128 + 127) / TK + 1; if (lim < ntiles) ntiles = lim; }     // masked scores get no gradient
@@ -722,6 +735,14 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
 
 }  // namespace
 
+// short sequences (Tq, Tk <= 128): attention_small.hip
+int asr_attention_small_takes(int N, int Tq, int Tk, int C, int ldq, int ldk);
+int asr_attention_small_bwd_launch(const float* Q, const float* K, const float* V, const float* O, const float* dO, const float* lse, int N, int Tq, int Tk,
+                                   int C, int H, int ldq, int ldk, int causal, int relu_grad, int drop, uint32_t thr, uint32_t seed, float scale,
+                                   float* dQ, float* dK, float* dV, const float* qstat, const float* kstat, void* stream);
+int asr_attention_small_fwd_launch(const float* Q, const float* K, const float* V, int N, int Tq, int Tk, int C, int H, int ldq, int ldk, int causal,
+                                   int drop, uint32_t thr, uint32_t seed, float scale, float* O, float* lse, const float* kstat, void* stream);
+
 // ===================================================================== C ABI
 // stats: [N][H][Tq] query masks, then [N][H][Tk] key biases (asr_attention_stats)
 extern "C" size_t asr_attention_stats_floats(int N, int Tq, int Tk, int H) { return (size_t)N * H * ((size_t)Tq + Tk); }
@@ -748,6 +769,8 @@ extern "C" int asr_attention_fwd_s(const float* Q, const float* K, const float* 
     hipStream_t st = (hipStream_t)stream;
     const uint32_t thr = drop_threshold(dropout_rate);
     const float sc = 1.0f / (1.0f - dropout_rate);
+    if (asr_attention_small_takes(N, Tq, Tk, C, ldq, ldk))    // a function of the sequence lengths only
+        return asr_attention_small_fwd_launch(Q, K, V, N, Tq, Tk, C, H, ldq, ldk, causal, dropout_rate > 0.f, thr, seed, sc, O, lse, kst, stream);
     // the tile sets (or the epilogue's scratch) + the key bias of every key of a (sample, head); 32-bit buffer offsets
     constexpr int ATK = 32;
     const size_t lds = (size_t)((4 * ATK * 64 > 4 * 32 * 65 ? 4 * ATK * 64 : 4 * 32 * 65) + asr_cdiv(Tk, 64) * 64) * sizeof(float);
@@ -791,6 +814,9 @@ extern "C" int asr_attention_bwd_s(const float* Q, const float* K, const float* 
     if (N < 1 || Tq < 1 || Tk < 1 || H < 1 || C != H * DH) return ASR_ERR_BAD_ARG;
     if (dropout_rate < 0.f || dropout_rate >= 1.f || (double)N * H * Tq * Tk >= 4294967296.0) return ASR_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (asr_attention_small_takes(N, Tq, Tk, C, ldq, ldk))    // short sequences: two launches, delta formed inside them (delta_ws is not written)
+        return asr_attention_small_bwd_launch(Q, K, V, O, dO, lse, N, Tq, Tk, C, H, ldq, ldk, causal, relu_grad, dropout_rate > 0.f,
+                                              drop_threshold(dropout_rate), seed, 1.0f / (1.0f - dropout_rate), dQ, dK, dV, qst, kst, stream);
     const long groups = (long)N * Tq * H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3(asr_cdiv(groups * 16, 256)), dim3(256), 0, st, O, dO, delta_ws, N, Tq, C, H);
     dim3 gkv(asr_cdiv(Tk, 128), H, N), gq(asr_cdiv(Tq, 128), H, N);

@@ -28,9 +28,11 @@ def ops():
     return _ops
 
 
+# (Tq, Tk <= 128 run on the short-sequence kernels of attention_small.hip since round 6: rows of 16, the whole (sample, head) in LDS)
 @pytest.mark.parametrize("N,Tq,Tk,H,causal", [(2, 7, 7, 2, True), (2, 100, 100, 8, True), (1, 130, 70, 2, False),
                                               (2, 33, 200, 4, True), (1, 512, 512, 8, False),
-                                              (2, 300, 300, 2, True), (2, 520, 520, 2, True)])
+                                              (2, 300, 300, 2, True), (2, 520, 520, 2, True),
+                                              (2, 100, 90, 2, False), (1, 128, 128, 2, True), (2, 17, 113, 2, False), (2, 128, 16, 2, True)])
 def test_attention_fwd_bwd(ops, N, Tq, Tk, H, causal):
     rng = np.random.default_rng(0)
     C = H * 64
@@ -287,7 +289,8 @@ def test_dropout_matches_the_oracle_generator(ops):
     assert not np.array_equal(out.cpu().numpy() != 0, got != 0)
 
 
-@pytest.mark.parametrize("N,Tq,Tk,H,causal", [(2, 70, 70, 2, True), (1, 130, 200, 2, False), (2, 300, 300, 2, True)])
+@pytest.mark.parametrize("N,Tq,Tk,H,causal", [(2, 70, 70, 2, True), (1, 130, 200, 2, False), (2, 300, 300, 2, True), (2, 100, 100, 2, False),
+                                              (2, 128, 128, 2, True)])
 def test_attention_with_weight_dropout(ops, N, Tq, Tk, H, causal):
     """Dropout of the attention weights (transformer.py:111) inside the fused kernels, forward and backward."""
     rng = np.random.default_rng(6)

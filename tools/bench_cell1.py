@@ -1,7 +1,10 @@
-"""First cell (Cin = 1) forward / backward alone at the full size (B 32, 1600 x 200, 32 channels): ASR_CELL1_MFMA=0|1."""
+"""First cell (Cin = 1) forward / backward alone at the full size (B 32, 1600 x 200, 32 channels): LIB=<other build> for an A/B."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from asr_dfcnn_transformer_amd import _lib
+if os.environ.get('LIB'):
+    _lib.LIB_PATH = os.path.abspath(os.environ['LIB'])
 from asr_dfcnn_transformer_amd import ops
 
 B, T, F, C = int(os.environ.get('B', 32)), 1600, 200, 32

@@ -7,6 +7,6 @@ cd "$(dirname "$0")/.."
 name=$1; src=$2; shift 2
 P=asr_dfcnn_transformer_amd
 python3 -c "from asr_dfcnn_transformer_amd import _build; _build.build(verbose=False)"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC "$@" -c $P/csrc/$src -o /tmp/variant_$name.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden "$@" -c $P/csrc/$src -o /tmp/variant_$name.o
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/libasrhip_$name.so $(ls $P/build/*.hip.o | grep -v "/$src.o") /tmp/variant_$name.o
 echo tools/libasrhip_$name.so
