@@ -75,19 +75,6 @@ __device__ __forceinline__ void attn_block_coords(int H, bool longest_is_last, i
     }
 }
 
-// Causal launches: which 32-row block of the workgroup's 128 a wave owns.  The four waves of a workgroup sit on the four SIMDs of the CU in
-// order, and under the causal mask block b walks b + 1 (forward, dQ) or 4 - b (dK / dV) more tiles than block 0 / 3: with wave w on
-// block w EVERY workgroup of a CU put its longest wave on the same SIMD, which then carried 4 + 4 (+ 4) tiles while another carried
-// 1 + 1 (+ 1) -- the kernels ran at the pace of that SIMD (T = 100, one tile row: 1.6x; T = 512: 1.18x, the "0.66 instead of 0.56 of the
-// non-causal time" of round 5).  Round 6: the assignment is rotated by a number that differs between the workgroups a CU holds at the
-// same time (dispatch order i, i + 256, i + 512 at the start of a launch: (i >> 8) steps the rotation; (i >> 3) varies it over time).
-template <bool CAUSAL>
-__device__ __forceinline__ int attn_wave_block(int wave) {
-    if (!CAUSAL) return wave;
-    const unsigned id = blockIdx.y * gridDim.x + blockIdx.x;
-    return (wave + (int)(((id >> 3) + (id >> 8)) & 3u)) & 3;
-}
-
 // ------------------------------------------------------------------ LDS-DMA of the streamed tiles (round 3)
 // The K / V (forward, dQ) and Q / dO (dK, dV) tiles are 64 rows x 64 floats of a head slice.  They arrive by buffer-form
 // LDS-DMA (buffer_load_dwordx4 ... lds: resource and row offset scalar, per-lane offset constant -- no vector instruction per
@@ -313,7 +300,7 @@ __global__ __launch_bounds__(256, TK == 64 ? 2 : 3) void attn_fwd_kernel(const f
     int qtile, head, n, Nn;
     attn_block_coords<CAUSAL>(H, true, qtile, head, n, Nn);
     const int hoff = head * DH;
-    const int q0 = qtile * 128 + attn_wave_block<CAUSAL>(wave) * 32, q = q0 + li;
+    const int q0 = qtile * 128 + wave * 32, q = q0 + li;
     const long qbase = (long)n * Tq, kbase = (long)n * Tk;
     const int ntiles = (Tk + TK - 1) / TK;
 
@@ -502,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const float* __rest
     int ktile, head, n, Nn;
     attn_block_coords<CAUSAL>(H, false, ktile, head, n, Nn);      // causal: the first key tile sees every query
     const int hoff = head * DH;
-    const int k0 = ktile * 128 + attn_wave_block<CAUSAL>(wave) * 32, key = k0 + li;
+    const int k0 = ktile * 128 + wave * 32, key = k0 + li;
     const long qbase = (long)n * Tq, kbase = (long)n * Tk;
     const long lrow = ((long)n * H + head) * Tq;
 
@@ -677,7 +664,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_q_kernel(const float* __restr
     int qtile, head, n, Nn;
     attn_block_coords<CAUSAL>(H, true, qtile, head, n, Nn);
     const int hoff = head * DH;
-    const int q0 = qtile * 128 + attn_wave_block<CAUSAL>(wave) * 32, q = q0 + li;
+    const int q0 = qtile * 128 + wave * 32, q = q0 + li;
     const long qbase = (long)n * Tq, kbase = (long)n * Tk;
     int ntiles = (Tk + TK - 1) / TK;
     if (CAUSAL) { const int lim = (qtile * 128 + 127) / TK + 1; if (lim < ntiles) ntiles = lim; }     // masked scores get no gradient

@@ -646,6 +646,10 @@ def main():
     ap.add_argument('--rccl-world1', action='store_true',
                     help='DFCNN workloads, one rank: run the three gradient all-reduces through a ONE-rank RCCL group anyway (A/B)')
     ap.add_argument('--single-stream', action='store_true', help='A/B: the whole backward pass on one stream (engine dual_stream=False)')
+    ap.add_argument('--streams', default='auto', choices=['auto', 'two'],
+                    help='DFCNN workloads: auto (default) times a few untimed steps with the backward pass on two streams and on one before the '
+                         'warm-up and keeps the faster -- on some boxes every process after the first loses the overlap of the two streams '
+                         '(profiles/r05_bimodal_box.txt: 7.2 ms against 6.5, kernel times equal); two: no calibration (A/B)')
     ap.add_argument('--no-wino', action='store_true', help='A/B: direct 3x3 convolutions instead of the Winograd kernels (engine wino=False)')
     ap.add_argument('--no-compact-pool', action='store_true', help='A/B: max-pooled cells keep their pre-pool activation plane')
     ap.add_argument('--no-fuse-se', action='store_true', help='A/B: SE backward and its branch cell backward as separate passes')
@@ -797,6 +801,12 @@ def main():
             consumed[cur] = ev
             feat_ready[cur] = None
             state['i'] += 1
+        if not state.get('stepped') and rank == 0 and os.environ.get('ASR_BENCH_DUMP_FIRST_GRADIENT'):
+            # test hook (tests/test_bench_gpu.py): the gradient of the FIRST step of the process as Adam saw it -- summed over the ranks and
+            # scaled by 1 / world -- at the seeded initial parameters: N ranks of a strong-scaling run must reproduce the one-rank gradient
+            torch.cuda.synchronize()
+            np.save(os.environ['ASR_BENCH_DUMP_FIRST_GRADIENT'], (eng.grad.double() * red.grad_scale).cpu().numpy())
+        state['stepped'] = True
 
     def barrier():
         if world > 1:
@@ -805,6 +815,34 @@ def main():
     single_feat = torch.empty(B, T, F, dtype=torch.float32, device=dev) if prefetch else None
     if args.inference:
         eng.set_targets(seq, target)                 # the sequence lengths the decoder reads
+    # Stream calibration (untimed set-up, in front of the W warm-up steps): the two-stream backward is worth 0.4 ms of the step where the two
+    # streams overlap -- and COSTS up to 0.5 ms on a box in the state profiles/r05_bimodal_box.txt describes.  A few steps of either kind decide;
+    # with several ranks the slowest rank's figures decide for all (every rank takes the same steps: they carry gradient collectives).
+    calib = None
+    if args.streams == 'auto' and eng.side is not None and not args.inference and not under_profiler():
+        def run(nsteps, one):
+            side = eng.side
+            if one:
+                eng.side = None
+            try:
+                torch.cuda.synchronize(); barrier()
+                t0 = time.perf_counter()
+                for _ in range(nsteps):
+                    step()
+                torch.cuda.synchronize()
+                return 1e3 * (time.perf_counter() - t0) / nsteps
+            finally:
+                eng.side = side
+        run(2, False)
+        t2, t1 = run(4, False), run(4, True)
+        if world > 1:
+            tt = torch.tensor([t2, t1], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t2, t1 = float(tt[0]), float(tt[1])
+        keep_two = t2 <= 1.01 * t1
+        calib = {'two_streams_ms': round(t2, 3), 'one_stream_ms': round(t1, 3), 'kept': 'two' if keep_two else 'one'}
+        if not keep_two:
+            eng.side = None
     # Warm-up: W untimed steps.  Two of them (in front of the last; with W < 3 extra steps in front of the last) run on ONE
     # stream with every contraction kernel between HIP events: their table decides which kernel symbol is the dominant one
     # (most time in the step, forward or backward) -- with the two-stream backward of the real step, durations of
@@ -820,7 +858,7 @@ def main():
     else:
         plan[len(plan) - 1:len(plan) - 1] = ['single', 'single']
     tables = []
-    for i_warm, kind in enumerate(plan):
+    for kind in plan:
         if kind == 'single':
             torch.cuda.synchronize()
             ops.TIMER = ops.KernelTimer()
@@ -830,11 +868,6 @@ def main():
             ops.TIMER = None
         else:
             step()
-        if i_warm == 0 and rank == 0 and os.environ.get('ASR_BENCH_DUMP_FIRST_GRADIENT'):
-            # test hook (tests/test_bench_gpu.py): the gradient of the FIRST step as Adam saw it -- summed over the ranks and scaled by
-            # 1 / world -- at the seeded initial parameters: N ranks of a strong-scaling run must reproduce the one-rank gradient
-            torch.cuda.synchronize()
-            np.save(os.environ['ASR_BENCH_DUMP_FIRST_GRADIENT'], (eng.grad.double() * red.grad_scale).cpu().numpy())
     table = {k: min((t[k] for t in tables if k in t), key=lambda r: r['total_ms']) for k in set().union(*tables)}
     torch.cuda.synchronize()
     overlapped = eng.side is not None
@@ -902,7 +935,7 @@ def main():
                        'step_algorithmic_frac_of_fp32_peak': round(utt_s / world * fstep / 1e12 / FP32_PEAK_TFLOPS, 4),
                        'step_flops_note': 'direct-convolution flops (SURVEY 8d); the Winograd layers execute 1/2.25 of their multiplies, '
                                           'so this is a rate of useful work, not a utilisation of the fp32 pipe',
-                       'backward_streams': 2 if overlapped else 1, 'feature_prefetch': prefetch, 'feature_prefetch_starts': ('any time' if args.prefetch_early else 'behind the forward pass (beside the CTC lattice)') if prefetch else None,
+                       'backward_streams': 2 if overlapped else 1, 'stream_calibration': calib, 'feature_prefetch': prefetch, 'feature_prefetch_starts': ('any time' if args.prefetch_early else 'behind the forward pass (beside the CTC lattice)') if prefetch else None,
                        'host_input': bool(args.host_input),
                        'conv_arithmetic': ('fp32 MFMA; 3x3 convs with K % 8 == 0 and N % 32 == 0 on column-blocked planes by Winograd '
                                            'F(2x2,3x3) in fp32 (wino11_kernel: forward, data-gradient, gated data-gradient), their weight '
