@@ -833,13 +833,16 @@ def main():
                 return 1e3 * (time.perf_counter() - t0) / nsteps
             finally:
                 eng.side = side
-        run(2, False)
-        t2, t1 = run(4, False), run(4, True)
+        run(4, False)
+        t2, t1 = run(6, False), run(6, True)
         if world > 1:
             tt = torch.tensor([t2, t1], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t2, t1 = float(tt[0]), float(tt[1])
-        keep_two = t2 <= 1.01 * t1
+        # one stream must win by a clear margin: a few steps right after a mode switch run 1-4 % faster than that mode's steady state (six
+        # steps of one-stream read 6.46 ms where its steady state is 6.75: profiles/r06w_bench_*), while the state this guards against costs
+        # the two-stream step 7-10 % (7.2 against 6.7 ms)
+        keep_two = t2 <= 1.04 * t1
         calib = {'two_streams_ms': round(t2, 3), 'one_stream_ms': round(t1, 3), 'kept': 'two' if keep_two else 'one'}
         if not keep_two:
             eng.side = None
