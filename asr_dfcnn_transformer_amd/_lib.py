@@ -127,6 +127,9 @@ SIGNATURES = {
     'asr_maxpool_bwd': (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     'asr_conv_s2_expand': (_I, [_P, _I, _I, _P, _P]),
     'asr_conv_s2_gather': (_I, [_P, _I, _I, _P, _P]),
+    'asr_conv_s2_arrange_bytes': (C.c_size_t, [_I]),
+    'asr_conv_s2_arrange': (_I, [_P, _I, _P, C.c_size_t, _P]),
+    'asr_conv_s2_dgrad': (_I, [_P, _P, _P, _P, _P]),
     'asr_plane_to_T': (_I, [_P, _I, _I, _I, _I, _I, _P, _P]),
     'asr_T_to_plane': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P]),
     'asr_attention_nomask_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),

@@ -232,7 +232,9 @@ __global__ __launch_bounds__(256) void tap_gemm_kernel_v1(TapGemmArgs g) {
 // (1 KB per wave), identical for the forward and the data-gradient view.  All ring loads are branch-free (zero padding,
 // clamped tails), so the compiler's s_waitcnt counts stay exact and the ring really runs D units ahead; the unit loop
 // is fully unrolled.  Two barriers per chunk, no weight tile in LDS.
-struct PwArgs { TapGemmArgs g; const float* Wf; int kg, nbt; };
+// toff: pixel-row offsets of the taps of a launch with a tap LIST of its own (NTAPS 2 or 4: the per-phase launches of the stride-2
+// data-gradient, asr_conv_s2_dgrad); 9-tap and 1-tap launches use tap_row_offset
+struct PwArgs { TapGemmArgs g; const float* Wf; int kg, nbt; int toff[4]; };
 
 // DIR (0 forward, 1 data-gradient view) changes no code: it gives the two directions distinct symbols in a profile.
 template <int MT, int NT, int WM, int WN, int NTAPS, int KCV, int D, int MINB, int DIR>
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_v5(PwArgs args) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int tap = u / GK, gk = u - tap * GK;
-            const int toff = halo + tap_row_offset<NTAPS, 0>(tap, g.WP);
+            const int toff = halo + ((NTAPS == 2 || NTAPS == 4) ? args.toff[tap] : tap_row_offset<NTAPS, 0>(tap, g.WP));
             const float* abase = As + (wm * (TM * 32) + li + toff) * AP + 4 * lh + gk * 8;
             float4 av[TM];
 #pragma unroll
@@ -366,7 +368,7 @@ __global__ __launch_bounds__(256, MINB) void tap_gemm_kernel_v5(PwArgs args) {
 }
 
 template <int MT, int NT, int WM, int WN, int NTAPS, int KCV, int D, int MINB, int DIR>
-int launch_v5d(const TapGemmArgs& a, const float* Wf, hipStream_t st) {
+int launch_v5d(const TapGemmArgs& a, const float* Wf, hipStream_t st, const int* toff = nullptr) {
     auto kern = tap_gemm_kernel_v5<MT, NT, WM, WN, NTAPS, KCV, D, MINB, DIR>;
     const int arows = MT + 2 * a.halo;
     size_t lds = (size_t)arows * (KCV + 4) * sizeof(float) + 2 * MT * sizeof(int);
@@ -379,6 +381,7 @@ int launch_v5d(const TapGemmArgs& a, const float* Wf, hipStream_t st) {
     }
     PwArgs p;
     p.g = a; p.Wf = Wf; p.kg = (a.K + 7) / 8; p.nbt = (a.N + 31) / 32;
+    for (int i = 0; i < 4; ++i) p.toff[i] = (toff && i < NTAPS) ? toff[i] : 0;
     p.g.ntm = asr_cdiv(a.M, MT);
     p.g.ntn = asr_cdiv(a.N, NT);
     if (!asr_gate_rows_fit(a.gate_rows, p.g.ntm * WM)) return ASR_ERR_UNSUPPORTED;
@@ -687,6 +690,90 @@ extern "C" int asr_tap_gemm_pw(const asr_gemm_desc* d, const float* A, const flo
                                const float* bias, const float* scale, const float* shift,
                                float* out_a, float* out_y, void* stream) {
     return tap_gemm_pw_impl(d, A, Wf, bias, scale, shift, out_a, out_y, stream, nullptr);
+}
+
+// ---- the stride-2 convolution of the end2end pre-net (end2end/model.py:225-229), data-gradient, one launch per OUTPUT PHASE (round 6).
+// On the phase-split plane the layer is a forward-looking 2 x 2-tap convolution 4C -> C whose (tap, phase) weight blocks are zero when the
+// tap looks one pixel further in a direction whose phase is odd (tap_gemm_kernel_v1's step_valid): phase (rp, cp) of the input gradient
+// receives (rp ? 1 : 2) x (cp ? 1 : 2) taps -- 4 / 2 / 2 / 1 for the phases 0 .. 3.  asr_tap_gemm ran it as ONE 4-tap GEMM with a 64-deep
+// contraction per tap on the register-staged kernel (two barriers per tap, every staged tile re-staged for each of the four 64-column phase
+// blocks: 31 TFLOP/s).  Here each phase is a C -> C convolution with its own tap list on tap_gemm_kernel_v5 (weights in fragment order
+// straight from L2, two barriers per 32-deep chunk).
+//   Wf9 = asr_conv_s2_arrange: the nine non-zero (phase, tap) blocks of W4 in data-gradient view, phase-major, taps in forward order.
+namespace {
+// taps of phase p as (dr, dc) of the FORWARD window, in the order asr_conv_s2_arrange stores their blocks
+inline int s2_phase_taps(int p, int (&dr)[4], int (&dc)[4]) {
+    const int rp = p >> 1, cp = p & 1;
+    int n = 0;
+    for (int t = 0; t < 4; ++t)
+        if (!(((t >> 1) & rp) | ((t & 1) & cp))) { dr[n] = t >> 1; dc[n] = t & 1; ++n; }
+    return n;
+}
+__global__ void s2_arrange_kernel(const float* __restrict__ W4, int C, float* __restrict__ out) {
+    // one thread = one lane's float4 of one (phase, tap) block: B[k][n] = W4[tap][C * phase + n][k], fragment order of arrange_weights_kernel
+    const int KG = C >> 3, NB = C >> 5;
+    const long per = (long)KG * NB * 64;
+    const long total = 9 * per;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int blk = (int)(i / per);
+        long r = i - (long)blk * per;
+        const int lane = (int)(r & 63); r >>= 6;
+        const int nb = (int)(r % NB), g8 = (int)(r / NB);
+        // block -> (phase, tap): phase 0 taps 0 1 2 3 | phase 1 taps 0 2 | phase 2 taps 0 1 | phase 3 tap 0
+        const int phase = blk < 4 ? 0 : blk < 6 ? 1 : blk < 8 ? 2 : 3;
+        const int tap = blk < 4 ? blk : blk < 6 ? 2 * (blk - 4) : blk < 8 ? blk - 6 : 0;
+        const int n = nb * 32 + (lane & 31), k = g8 * 8 + 4 * (lane >> 5);
+        *(float4*)(out + i * 4) = *(const float4*)(W4 + ((long)tap * 4 * C + (long)C * phase + n) * C + k);
+    }
+}
+}  // namespace
+
+extern "C" size_t asr_conv_s2_arrange_bytes(int C) { return (C < 64 || (C & 63)) ? 0 : (size_t)9 * (C / 8) * (C / 32) * 256 * sizeof(float); }
+
+extern "C" int asr_conv_s2_arrange(const float* W4, int C, float* out, size_t out_bytes, void* stream) {
+    if (!W4 || !out || C < 64 || (C & 63) || (((uintptr_t)W4 | (uintptr_t)out) & 15)) return ASR_ERR_BAD_ARG;
+    if (out_bytes < asr_conv_s2_arrange_bytes(C)) return ASR_ERR_BAD_ARG;
+    const long total = 9L * (C / 8) * (C / 32) * 64;
+    hipLaunchKernelGGL(s2_arrange_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W4, C, out);
+    ASR_CHECK_LAUNCH("conv_s2_arrange");
+    return ASR_OK;
+}
+
+extern "C" int asr_conv_s2_dgrad(const asr_gemm_desc* d, const float* dZ, const float* Wf9, float* dx, void* stream) {
+    if (!d || !dZ || !Wf9 || !dx) return ASR_ERR_BAD_ARG;
+    const int C = d->K;
+    // the 4-tap data-gradient descriptor of asr_tap_gemm: K = C gradient channels, N = 4 C phase-split input channels
+    if (d->ntaps != 4 || d->wmode != 1 || C < 64 || (C & 63) || d->N != 4 * C || d->H <= 0 || d->relu || d->accumulate || d->y_unpadded) return ASR_ERR_BAD_ARG;
+    if ((d->lda & 3) || (d->ldo_y & 3) || d->ldo_y < 4 * C || d->M != d->B * (d->H + 1) * (d->W + 1)) return ASR_ERR_BAD_ARG;
+    if (((uintptr_t)dZ | (uintptr_t)Wf9 | (uintptr_t)dx) & 15) return ASR_ERR_BAD_ARG;
+    TapGemmArgs a;
+    a.A = dZ; a.W = nullptr; a.bias = nullptr; a.scale = nullptr; a.shift = nullptr;
+    a.out_a = nullptr;
+    a.M = d->M; a.K = C; a.N = C; a.lda = d->lda; a.ldw = C;
+    a.ldo_a = 0; a.ldo_y = d->ldo_y;
+    a.H = d->H; a.Wd = d->W; a.WP = d->W + 1; a.HPWP = (d->H + 1) * (d->W + 1);
+    a.rmin = -(long)(a.WP + 1); a.rmax = (long)d->M + a.WP + 1;
+    a.relu = 0; a.accumulate = 0; a.y_unpadded = 0;
+    a.ntm = a.ntn = 0;
+    set_gate(a, nullptr);
+    a.nt_store = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t blk = (size_t)(C / 8) * (C / 32) * 256;          // floats of one (phase, tap) block
+    size_t off = 0;
+    for (int p = 0; p < 4; ++p) {
+        int dr[4], dc[4], toff[4] = {0, 0, 0, 0};
+        const int nt = s2_phase_taps(p, dr, dc);
+        for (int i = 0; i < nt; ++i) toff[i] = -(dr[i] * a.WP + dc[i]);      // the gradient pixel a forward tap came from
+        a.out_y = dx + (size_t)p * C;
+        a.halo = nt > 1 ? a.WP + 1 : 0;
+        int rc;
+        if (nt == 4) rc = launch_v5d<128, 64, 2, 2, 4, 32, 4, 3, 1>(a, Wf9 + off, st, toff);
+        else if (nt == 2) rc = launch_v5d<128, 64, 2, 2, 2, 32, 4, 3, 1>(a, Wf9 + off, st, toff);
+        else rc = launch_v5d<128, 64, 2, 2, 1, 32, 4, 3, 1>(a, Wf9 + off, st);
+        if (rc != ASR_OK) return rc;
+        off += (size_t)nt * blk;
+    }
+    return ASR_OK;
 }
 
 extern "C" ASR_INTERNAL int asr_tap_gemm_wino_gated_launch(const asr_gemm_desc* d, const float* dZ, const float* Ut, int mode, int gate_H, int gate_W,

@@ -646,6 +646,23 @@ def conv_s2_gather(dW4, Cin, Cout, dw):
     check(_lib.load().asr_conv_s2_gather(_ptr(dW4), Cin, Cout, _ptr(dw), _stream()), 'asr_conv_s2_gather')
 
 
+def conv_s2_arrange_bytes(Cc):
+    return _lib.load().asr_conv_s2_arrange_bytes(Cc)
+
+
+def conv_s2_arrange(W4, Cc, out):
+    """The nine non-zero (phase, tap) blocks of the expanded stride-2 weights in data-gradient fragment order (asr_conv_s2_arrange)."""
+    check(_lib.load().asr_conv_s2_arrange(_ptr(W4), Cc, _ptr(out), out.numel() * out.element_size(), _stream()), 'asr_conv_s2_arrange')
+
+
+def conv_s2_dgrad(desc, dz, Wf9, dx):
+    """Data-gradient of the phase-split stride-2 conv, one launch per phase of the input gradient (asr_conv_s2_dgrad)."""
+    lib = _lib.load()
+    pz = dz.ptr if isinstance(dz, Plane) else _ptr(dz)
+    px = dx.ptr if isinstance(dx, Plane) else _ptr(dx)
+    _timed(desc, lambda: check(lib.asr_conv_s2_dgrad(C.byref(desc), pz, _ptr(Wf9), px, _stream()), 'asr_conv_s2_dgrad'))
+
+
 def plane_to_T(plane, choff, dst):
     check(_lib.load().asr_plane_to_T(plane.ptr, plane.B, plane.H, plane.W, plane.C, choff, _ptr(dst), _stream()), 'asr_plane_to_T')
 

@@ -36,10 +36,12 @@ def fwd_flops_per_seq(T, F=320):
 
 
 class PreNetEngine:
-    def __init__(self, B, T, F=320, lr=5e-4, beta2=0.98, seed=0, device='cuda', dual_stream=True, wino=True):
+    def __init__(self, B, T, F=320, lr=5e-4, beta2=0.98, seed=0, device='cuda', dual_stream=True, wino=True, s2_per_phase=True):
         assert F == 320, 'the attention kernels are built for 80 frequency bins after the two stride-2 convs (4 x 80 / 4)'
         assert T % 4 == 0 and T >= 4
         self.B, self.T, self.F, self.device = B, T, F, device
+        # A/B switch: the stride-2 layer's data-gradient as one launch per phase (asr_conv_s2_dgrad, round 6) or as one 4-tap GEMM (False)
+        self.opt_s2_per_phase = bool(s2_per_phase)
         self.H1, self.W1, self.H2, self.W2 = T // 2, F // 2, T // 4, F // 4
         self.lr0, self.beta1, self.beta2, self.adam_eps = lr, 0.9, beta2, 1e-8
         self.global_step = 0
@@ -81,6 +83,7 @@ class PreNetEngine:
         self.dS = z(B * CH * W2 * W2)
         self.dz1 = z(B * self.H1 * self.W1 * CH).view(B, self.H1, self.W1, CH)
         self.dW4 = z(4 * 4 * CH * CH)
+        self.Wf9 = z(ops.conv_s2_arrange_bytes(CH) // 4)       # the stride-2 weights per (phase, tap) block, data-gradient fragment order
         NP = self.x2.NP
         self.d_c2 = ops.gemm_desc(NP, 4 * CH, CH, 4 * CH, CH, CH, 0, ntaps=4, B=B, H=H2, W=W2, relu=2)
         self.d_c2_dx = ops.gemm_desc(NP, CH, 4 * CH, CH, CH, 0, 4 * CH, ntaps=4, B=B, H=H2, W=W2, wmode=1)
@@ -239,6 +242,8 @@ class PreNetEngine:
         ops.prenet_conv1_fwd(x, self.p('conv1/w'), self.p('conv1/b'), self.a1)
         self._bn('bn1', self.a1, self.x1s, dst_phase_split=True)
         ops.conv_s2_expand(self.p('conv2/w'), CH, CH, self.W4)
+        if self.opt_s2_per_phase:
+            ops.conv_s2_arrange(self.W4, CH, self.Wf9)
         ops.tap_gemm(self.d_c2, self.x1s, self.W4, self.p('conv2/b'), None, None, self.a2, None)
         self._bn('bn2', self.a2, self.x2)
         for k, dstT in (('q', self.QT), ('k', self.KT), ('v', self.VT)):
@@ -291,7 +296,10 @@ class PreNetEngine:
             ops.conv_s2_gather(self.dW4, CH, CH, self.g('conv2/w'))
             ops.colsum(dz.body, dz.NP, CH, CH, self.g('conv2/b'), ws)
         self._on_side([dz], grads2)
-        ops.tap_gemm(self.d_c2_dx, dz, self.W4, None, None, None, None, self.dx1s)
+        if self.opt_s2_per_phase:
+            ops.conv_s2_dgrad(self.d_c2_dx, dz, self.Wf9, self.dx1s)    # one launch per phase of the input gradient (round 6)
+        else:
+            ops.tap_gemm(self.d_c2_dx, dz, self.W4, None, None, None, None, self.dx1s)
         self._bn_bwd('bn1', self.dx1s, self.a1, 2, self.dz1, dy_phase_split=True)
         ops.prenet_conv1_bwd(self.x, self.dz1, self.g('conv1/w'), self.g('conv1/b'), self.ws)
         if self.side is not None and getattr(self, '_last_side', None) is not None:

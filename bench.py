@@ -337,7 +337,7 @@ def run_transformer(args):
     N, T, C, H, blocks, Vin, Vout = args.batch if args.batch != 32 else 64, 512, 512, 8, 6, 1536, 6347
     rng = np.random.default_rng(7 + rank)
     if prenet:
-        pre = PreNetEngine(N, 4 * T, 320, dual_stream=not args.single_stream, wino=not args.no_wino)
+        pre = PreNetEngine(N, 4 * T, 320, dual_stream=not args.single_stream, wino=not args.no_wino, s2_per_phase=not args.no_s2_phase)
         eng = E2EEngine(din=5120, vout=Vout, N=N, T=T, L=T, C=C, heads=H, blocks=blocks, pos_max=600, tie=True, need_dx=True,
                         dropout_rate=args.dropout, drop_seed=rank)
         gen = torch.Generator(device='cuda').manual_seed(7 + rank)
@@ -650,6 +650,7 @@ def main():
                     help='DFCNN workloads: auto (default) times a few untimed steps with the backward pass on two streams and on one before the '
                          'warm-up and keeps the faster -- on some boxes every process after the first loses the overlap of the two streams '
                          '(profiles/r05_bimodal_box.txt: 7.2 ms against 6.5, kernel times equal); two: no calibration (A/B)')
+    ap.add_argument('--no-s2-phase', action='store_true', help='A/B (e2e_prenet): the stride-2 data-gradient as one 4-tap GEMM (until round 5)')
     ap.add_argument('--no-wino', action='store_true', help='A/B: direct 3x3 convolutions instead of the Winograd kernels (engine wino=False)')
     ap.add_argument('--no-compact-pool', action='store_true', help='A/B: max-pooled cells keep their pre-pool activation plane')
     ap.add_argument('--no-fuse-se', action='store_true', help='A/B: SE backward and its branch cell backward as separate passes')

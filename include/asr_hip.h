@@ -466,6 +466,18 @@ int asr_maxpool_bwd(const float* dy, const float* y, int B, int H, int W, int C,
 /* HWIO [3][3][Cin][Cout] <-> the 2x2-tap weights [4][4*Cin][Cout] of the phase-split stride-2 conv */
 int asr_conv_s2_expand(const float* w, int Cin, int Cout, float* W4, void* stream);
 int asr_conv_s2_gather(const float* dW4, int Cin, int Cout, float* dw, void* stream);
+/* Round 6: the DATA-gradient of that layer (tf.gradients through the stride-2 tanh conv, end2end/model.py:225-229), one launch per
+ * phase of the input gradient instead of one 4-tap GEMM with a 64-deep contraction per tap: phase (rp, cp) receives
+ * (rp ? 1 : 2) x (cp ? 1 : 2) of the four taps (the other (tap, phase) blocks of W4 are structurally zero), so each phase is a C -> C
+ * convolution with its own tap list on weights in MFMA fragment order.
+ *   asr_conv_s2_arrange: W4 [4][4 C][C] (asr_conv_s2_expand with Cin = Cout = C, C % 64 == 0) -> its nine non-zero (phase, tap) blocks in
+ *     data-gradient view, out_bytes >= asr_conv_s2_arrange_bytes(C) (checked before the launch); once per optimiser step.
+ *   asr_conv_s2_dgrad: d = the descriptor asr_tap_gemm takes for this data-gradient (ntaps 4, wmode 1, K = C, N = 4 C, pixel-indexed);
+ *     dZ padded plane [.][lda], dx the phase-split plane [.][ldo_y >= 4 C]: every interior pixel of all 4 C columns is written.
+ *     Equal to asr_tap_gemm(d, dZ, W4, ..., dx) up to the order of the K sums. */
+size_t asr_conv_s2_arrange_bytes(int C);
+int asr_conv_s2_arrange(const float* W4, int C, float* out, size_t out_bytes, void* stream);
+int asr_conv_s2_dgrad(const asr_gemm_desc* d, const float* dZ, const float* Wf9, float* dx, void* stream);
 
 /* tf.transpose(q, [0,3,1,2]) and back (model.py:234-256): 64 channels [choff, choff+64) of a padded plane
  * [B][H+1][W+1][ld] (W = 80) <-> T-layout [B][H][64][W]; the reverse direction can add two sources. */

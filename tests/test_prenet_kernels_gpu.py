@@ -93,6 +93,18 @@ def test_conv_stride2_as_phase_split_taps(ops, B, H, W):
     ops.tap_gemm(bd, dzp, W4, None, None, None, None, dxs)
     got = dxs.interior().view(B, H2, W2, 2, 2, Cc).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, Cc)
     report('conv s2 dX', got, xt.grad, 1e-5)
+    # round 6: the same data-gradient as one launch per phase of the input gradient on fragment-order weights (asr_conv_s2_dgrad)
+    Wf9 = torch.zeros(ops.conv_s2_arrange_bytes(Cc) // 4, device='cuda')
+    ops.conv_s2_arrange(W4, Cc, Wf9)
+    dxs2 = ops.Plane(B, H2, W2, 4 * Cc)
+    ops.conv_s2_dgrad(bd, dzp, Wf9, dxs2)
+    got2 = dxs2.interior().view(B, H2, W2, 2, 2, Cc).permute(0, 1, 3, 2, 4, 5).reshape(B, H, W, Cc)
+    report('conv s2 dX per phase', got2, xt.grad, 1e-5)
+    assert float(dxs2.view()[:, 0].abs().max()) == 0 and float(dxs2.view()[:, :, 0].abs().max()) == 0       # borders stay zero
+    from asr_dfcnn_transformer_amd import _lib
+    lib = _lib.load()
+    assert lib.asr_conv_s2_arrange(W4.data_ptr(), Cc, Wf9.data_ptr(), 4 * Wf9.numel() - 4, None) == -1      # a short buffer is refused before the launch
+    assert lib.asr_conv_s2_arrange_bytes(48) == 0
 
 
 @pytest.mark.parametrize("act", [0, 1, 2])
