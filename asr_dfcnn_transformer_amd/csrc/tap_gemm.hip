@@ -767,9 +767,17 @@ extern "C" int asr_conv_s2_dgrad(const asr_gemm_desc* d, const float* dZ, const 
         a.out_y = dx + (size_t)p * C;
         a.halo = nt > 1 ? a.WP + 1 : 0;
         int rc;
-        if (nt == 4) rc = launch_v5d<128, 64, 2, 2, 4, 32, 4, 3, 1>(a, Wf9 + off, st, toff);
-        else if (nt == 2) rc = launch_v5d<128, 64, 2, 2, 2, 32, 4, 3, 1>(a, Wf9 + off, st, toff);
-        else rc = launch_v5d<128, 64, 2, 2, 1, 32, 4, 3, 1>(a, Wf9 + off, st);
+        // tile: 192 rows x 64 columns, 32-deep chunks, ring of four units (tools/bench_s2_dgrad.py, B 64 x 512 x 80 x 64: 2.25 ms; 128 rows 2.37,
+        // 16-deep chunks 2.31-2.45, 256 rows 2.44; the one 4-tap GEMM of asr_tap_gemm 3.37)
+#ifndef S2_MT
+#define S2_MT 192
+#define S2_KC 32
+#define S2_D 4
+#define S2_MINB 3
+#endif
+        if (nt == 4) rc = launch_v5d<S2_MT, 64, 2, 2, 4, S2_KC, S2_D, S2_MINB, 1>(a, Wf9 + off, st, toff);
+        else if (nt == 2) rc = launch_v5d<S2_MT, 64, 2, 2, 2, S2_KC, S2_D, S2_MINB, 1>(a, Wf9 + off, st, toff);
+        else rc = launch_v5d<S2_MT, 64, 2, 2, 1, S2_KC, S2_D, S2_MINB, 1>(a, Wf9 + off, st);
         if (rc != ASR_OK) return rc;
         off += (size_t)nt * blk;
     }
