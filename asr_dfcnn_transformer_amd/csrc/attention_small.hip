@@ -225,18 +225,115 @@ __device__ __forceinline__ void as_query_stats(float* lse_a, float* lsl_a, float
     }
 }
 
-// dK, dV: a wave owns 16 keys (K, V rows in registers) and walks the 16-query tiles of Q / dO, which sit in LDS whole.
+// dK, dV: a wave owns 16 keys and ONE of the two gradients, and walks the 16-query tiles of Q / dO, which sit in LDS whole.
+// Two roles per key block (round 6, second form): the dV wave recomputes S -> P and accumulates dV += P^T dO (K rows in registers: 32 MFMAs per
+// tile), the dK wave recomputes S and dP -> dS and accumulates dK += dS^T Q (K and V rows in registers: 48 MFMAs per tile).  One wave doing
+// both (64 MFMAs per tile) needed K, V and two accumulator sets = 148 registers -- one 7-wave workgroup per CU, 1.75 waves per SIMD, its
+// LDS round trips exposed (49 us per launch at T = 100); the split pays a second S product (+25 % MFMAs) for twice the waves per CU at under
+// 128 registers each.
+#if __HIP_DEVICE_COMPILE__
+template <bool CAUSAL, bool DROP, int ROLE>          // ROLE 0: dV, 1: dK
+__device__ __forceinline__ void as_bwd_kv_body(const float* __restrict__ K, const float* __restrict__ V, float* __restrict__ dOut,
+                                               const float* __restrict__ Qs, const float* __restrict__ Ds, const float* __restrict__ lse_a,
+                                               const float* __restrict__ lsl_a, const float* __restrict__ del_a, const float* __restrict__ kb,
+                                               int n, int head, int H, int Tq, int Tk, int nqt, int ldk, int hoff, long kbase, int k0, int lane,
+                                               int relu_grad, uint32_t drop_thr, uint32_t drop_seed, float drop_scale) {
+    const int g = lane >> 4, c = lane & 15, key = k0 + c;
+    float kreg[16], vreg[ROLE == 1 ? 16 : 1];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (key < Tk) {
+            a = *(const float4*)(K + (kbase + key) * ldk + hoff + 16 * g + 4 * u);
+            if (ROLE == 1) b = *(const float4*)(V + (kbase + key) * ldk + hoff + 16 * g + 4 * u);
+        }
+        kreg[4 * u + 0] = a.x * QSCALE2; kreg[4 * u + 1] = a.y * QSCALE2; kreg[4 * u + 2] = a.z * QSCALE2; kreg[4 * u + 3] = a.w * QSCALE2;
+        if (ROLE == 1) { vreg[4 * u + 0] = b.x; vreg[4 * u + 1] = b.y; vreg[4 * u + 2] = b.z; vreg[4 * u + 3] = b.w; }
+    }
+    const bool kkeep = kb[key] > 1.0e38f && key < Tk;      // +inf: a real key  (k0 < Tk, so key < Tk16)
+    const float kfill = (key < Tk) ? FILL2 : -INFINITY;
+    floatx4 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int f = as_fk(c);
+    for (int qt = 0; qt < nqt; ++qt) {
+        const int q0 = 16 * qt;
+        // these 16 queries all precede this wave's 16 keys: dS = 0, and P = exp(fill - max) = 0 unless a row's max IS the fill value
+        if (CAUSAL && q0 + 15 < k0 && !__any(lse_a[q0 + c] < -1.0e9f)) continue;
+        floatx4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        const float* qrow = Qs + (q0 + c) * 64;
+        const float* drow = Ds + (q0 + c) * 64;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 qv = *(const float4*)(qrow + (((4 * g + u) ^ f) << 2));
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.x, kreg[4 * u + 0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.y, kreg[4 * u + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.z, kreg[4 * u + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.w, kreg[4 * u + 3], s, 0, 0, 0);
+            if (ROLE == 1) {
+                const float4 dv4 = *(const float4*)(drow + (((4 * g + u) ^ f) << 2));
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(dv4.x, vreg[4 * u + 0], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(dv4.y, vreg[4 * u + 1], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(dv4.z, vreg[4 * u + 2], dp, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(dv4.w, vreg[4 * u + 3], dp, 0, 0, 0);
+            }
+        }
+        // rows of s / dp = queries q0 + 4 g + r, column = this lane's key;  dV wave: s <- P as dV sees it;  dK wave: s <- dS / 0.125
+        const float4 t0 = *(const float4*)(lse_a + q0 + 4 * g), t1 = *(const float4*)(lsl_a + q0 + 4 * g);
+        const float lsv[4] = {t0.x, t0.y, t0.z, t0.w}, llv[4] = {t1.x, t1.y, t1.z, t1.w};
+        float dlv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ROLE == 1) { const float4 t2 = *(const float4*)(del_a + q0 + 4 * g); dlv[0] = t2.x; dlv[1] = t2.y; dlv[2] = t2.z; dlv[3] = t2.w; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int qq = q0 + 4 * g + r;
+            const bool keep = kkeep && (!CAUSAL || key <= qq);
+            const float sv = keep ? s[r] : kfill;
+            const float p = ex2((sv - lsv[r]) - llv[r]);
+            bool dm = true;
+            if (DROP) dm = drop_keep((uint32_t)(((n * H + head) * Tq + qq) * Tk + key), drop_seed, drop_thr);
+            if (ROLE == 0) s[r] = DROP ? (dm ? p * drop_scale : 0.f) : p;
+            else {
+                float dpe = dp[r];
+                if (DROP) dpe = dm ? dpe * drop_scale : 0.f;
+                s[r] = keep ? p * (dpe - dlv[r]) : 0.f;
+            }
+        }
+        const float* Xs = ROLE == 0 ? Ds : Qs;         // dV += P^T dO (dO by column);  dK += dS^T Q (Q by column)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = q0 + 4 * g + j;
+            const int fr = as_fk(row), c4 = c >> 2;
+            const float* xc = Xs + row * 64 + (c & 3);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[((4 * dt + c4) ^ fr) << 2], s[j], acc[dt], 0, 0, 0);
+        }
+    }
+    if (key < Tk) {
+        float* orow = dOut + (kbase + key) * ldk + hoff + 4 * g;
+        const float* src = (ROLE == 0 ? V : K) + (kbase + key) * ldk + hoff + 4 * g;
+        const float mul = ROLE == 0 ? 1.f : 0.125f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            float4 a = make_float4(acc[dt][0] * mul, acc[dt][1] * mul, acc[dt][2] * mul, acc[dt][3] * mul);
+            if (relu_grad) {        // the gradient of the pre-ReLU projection: masked by (projection > 0)
+                const float4 h4 = *(const float4*)(src + 16 * dt);
+                a.x = h4.x > 0.f ? a.x : 0.f; a.y = h4.y > 0.f ? a.y : 0.f; a.z = h4.z > 0.f ? a.z : 0.f; a.w = h4.w > 0.f ? a.w : 0.f;
+            }
+            *(float4*)(orow + 16 * dt) = a;
+        }
+    }
+}
+#endif
+
 template <bool CAUSAL, bool DROP>
-// (148 registers: one workgroup per CU.  Capped at 128 -- two per CU -- hipcc spills 13-43 of them into the tile loop, with or without
-//  scheduling barriers between the phases: measured slower)
-__global__ __launch_bounds__(512) void attn_small_bwd_kv_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-                                                                const float* __restrict__ O, const float* __restrict__ dO, const float* __restrict__ lse,
-                                                                float* __restrict__ dK, float* __restrict__ dV, int Nn, int Tq, int Tk, int C, int H,
-                                                                int ldq, int ldk, int relu_grad, uint32_t drop_thr, uint32_t drop_seed, float drop_scale,
-                                                                const float* __restrict__ qstat, const float* __restrict__ kstat, uint32_t wmap) {
+__global__ __launch_bounds__(1024) void attn_small_bwd_kv_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                                 const float* __restrict__ O, const float* __restrict__ dO, const float* __restrict__ lse,
+                                                                 float* __restrict__ dK, float* __restrict__ dV, int Nn, int Tq, int Tk, int C, int H,
+                                                                 int ldq, int ldk, int relu_grad, uint32_t drop_thr, uint32_t drop_seed, float drop_scale,
+                                                                 const float* __restrict__ qstat, const float* __restrict__ kstat, unsigned long long wmap) {
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) float as_smem[];
-    const int tid = threadIdx.x, lane = tid & 63, g = lane >> 4, c = lane & 15;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
     const int head = blockIdx.x % H, n = blockIdx.x / H;
     const int hoff = head * DH;
@@ -253,101 +350,20 @@ __global__ __launch_bounds__(512) void attn_small_bwd_kv_kernel(const float* __r
     auto rd = __builtin_amdgcn_make_buffer_rsrc((void*)dO, 0, (int)((((long)Nn * Tq - 1) * C + C) * 4), 0x00020000);
     as_stage<0>(rq, Qs, qbase, Tq, Tq16, ldq, hoff, wave, nw, lane);
     as_stage<0>(rd, Ds, qbase, Tq, Tq16, C, hoff, wave, nw, lane);
-
-    const int k0 = (int)((wmap >> (4 * wave)) & 15u) * 16, key = k0 + c;      // the 16-key block of this wave (as_wave_map)
-    float kreg[16], vreg[16];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        if (key < Tk) {
-            a = *(const float4*)(K + (kbase + key) * ldk + hoff + 16 * g + 4 * u);
-            b = *(const float4*)(V + (kbase + key) * ldk + hoff + 16 * g + 4 * u);
-        }
-        kreg[4 * u + 0] = a.x * QSCALE2; kreg[4 * u + 1] = a.y * QSCALE2; kreg[4 * u + 2] = a.z * QSCALE2; kreg[4 * u + 3] = a.w * QSCALE2;
-        vreg[4 * u + 0] = b.x; vreg[4 * u + 1] = b.y; vreg[4 * u + 2] = b.z; vreg[4 * u + 3] = b.w;
-    }
     as_query_stats(lse_a, lsl_a, del_a, qstat ? qstat : nullptr, Q, O, dO, lse, lrow, (long)Nn * H * Tq, qbase, Tq, Tq16, ldq, C, hoff, tid, blockDim.x);
     as_key_bias(kb, kstat ? kstat + ((long)n * H + head) * Tk : nullptr, K, kbase, Tk, Tk16, ldk, hoff, tid, blockDim.x);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (k0 >= Tk) return;                       // (a workgroup has max(query tiles, key tiles) waves)
-    const bool kkeep = kb[key < Tk16 ? key : 0] > 1.0e38f && key < Tk;      // +inf: a real key
-    const float kfill = (key < Tk) ? FILL2 : -INFINITY;
-
-    floatx4 dk[4], dv[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) { dk[dt] = floatx4{0.f, 0.f, 0.f, 0.f}; dv[dt] = floatx4{0.f, 0.f, 0.f, 0.f}; }
-    const int f = as_fk(c);
-    for (int qt = 0; qt < nqt; ++qt) {
-        const int q0 = 16 * qt;
-        // these 16 queries all precede this wave's 16 keys: dS = 0, and P = exp(fill - max) = 0 unless a row's max IS the fill value
-        if (CAUSAL && q0 + 15 < k0 && !__any(lse_a[q0 + c] < -1.0e9f)) continue;
-        floatx4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        const float* qrow = Qs + (q0 + c) * 64;
-        const float* drow = Ds + (q0 + c) * 64;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float4 qv = *(const float4*)(qrow + (((4 * g + u) ^ f) << 2));
-            const float4 dv4 = *(const float4*)(drow + (((4 * g + u) ^ f) << 2));
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.x, kreg[4 * u + 0], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.y, kreg[4 * u + 1], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.z, kreg[4 * u + 2], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_16x16x4f32(qv.w, kreg[4 * u + 3], s, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(dv4.x, vreg[4 * u + 0], dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(dv4.y, vreg[4 * u + 1], dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(dv4.z, vreg[4 * u + 2], dp, 0, 0, 0);
-            dp = __builtin_amdgcn_mfma_f32_16x16x4f32(dv4.w, vreg[4 * u + 3], dp, 0, 0, 0);
-        }
-        // rows of s / dp = queries q0 + 4 g + r, column = this lane's key;  s <- P (as dV sees it), dp <- dS / 0.125
-        const float4 t0 = *(const float4*)(lse_a + q0 + 4 * g), t1 = *(const float4*)(lsl_a + q0 + 4 * g), t2 = *(const float4*)(del_a + q0 + 4 * g);
-        const float lsv[4] = {t0.x, t0.y, t0.z, t0.w}, llv[4] = {t1.x, t1.y, t1.z, t1.w}, dlv[4] = {t2.x, t2.y, t2.z, t2.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qq = q0 + 4 * g + r;
-            const bool keep = kkeep && (!CAUSAL || key <= qq);
-            const float sv = keep ? s[r] : kfill;
-            const float p = ex2((sv - lsv[r]) - llv[r]);
-            float pd = p, dpe = dp[r];
-            if (DROP) {
-                const bool dm = drop_keep((uint32_t)(((n * H + head) * Tq + qq) * Tk + key), drop_seed, drop_thr);
-                pd = dm ? p * drop_scale : 0.f;
-                dpe = dm ? dpe * drop_scale : 0.f;
-            }
-            s[r] = pd;
-            dp[r] = keep ? p * (dpe - dlv[r]) : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = q0 + 4 * g + j;
-            const int fr = as_fk(row), c4 = c >> 2;
-            const float* qc = Qs + row * 64 + (c & 3);
-            const float* dc = Ds + row * 64 + (c & 3);
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const int off = ((4 * dt + c4) ^ fr) << 2;
-                dv[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dc[off], s[j], dv[dt], 0, 0, 0);
-                dk[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(qc[off], dp[j], dk[dt], 0, 0, 0);
-            }
-        }
-    }
-    if (key < Tk) {
-        float* kr = dK + (kbase + key) * ldk + hoff + 4 * g;
-        float* vr = dV + (kbase + key) * ldk + hoff + 4 * g;
-        const float* ks = K + (kbase + key) * ldk + hoff + 4 * g;
-        const float* vs = V + (kbase + key) * ldk + hoff + 4 * g;
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            float4 a = make_float4(dk[dt][0] * 0.125f, dk[dt][1] * 0.125f, dk[dt][2] * 0.125f, dk[dt][3] * 0.125f);
-            float4 b = make_float4(dv[dt][0], dv[dt][1], dv[dt][2], dv[dt][3]);
-            if (relu_grad) {        // the gradient of the pre-ReLU projection: masked by (projection > 0)
-                const float4 hk = *(const float4*)(ks + 16 * dt), hv = *(const float4*)(vs + 16 * dt);
-                a.x = hk.x > 0.f ? a.x : 0.f; a.y = hk.y > 0.f ? a.y : 0.f; a.z = hk.z > 0.f ? a.z : 0.f; a.w = hk.w > 0.f ? a.w : 0.f;
-                b.x = hv.x > 0.f ? b.x : 0.f; b.y = hv.y > 0.f ? b.y : 0.f; b.z = hv.z > 0.f ? b.z : 0.f; b.w = hv.w > 0.f ? b.w : 0.f;
-            }
-            *(float4*)(kr + 16 * dt) = a;
-            *(float4*)(vr + 16 * dt) = b;
-        }
-    }
+    // this wave's unit (as_wave_map over 2 x key blocks units, one per wave): nibble = 16-key block | role << 3 (0 dV, 1 dK)
+    const int unit = (int)((wmap >> (4 * wave)) & 15ull);
+    const int k0 = (unit & 7) * 16, role = unit >> 3;
+    if (k0 >= Tk) return;
+    if (role == 0)
+        as_bwd_kv_body<CAUSAL, DROP, 0>(K, V, dV, Qs, Ds, lse_a, lsl_a, del_a, kb, n, head, H, Tq, Tk, nqt, ldk, hoff, kbase, k0, lane, relu_grad,
+                                        drop_thr, drop_seed, drop_scale);
+    else
+        as_bwd_kv_body<CAUSAL, DROP, 1>(K, V, dK, Qs, Ds, lse_a, lsl_a, del_a, kb, n, head, H, Tq, Tk, nqt, ldk, hoff, kbase, k0, lane, relu_grad,
+                                        drop_thr, drop_seed, drop_scale);
 #endif
 }
 
@@ -468,21 +484,22 @@ __global__ __launch_bounds__(512, 4) void attn_small_bwd_q_kernel(const float* _
 // waves go to the CU's four SIMDs cyclically (MI355X_MICROARCH.md, LDS section), so waves w and w + 4 share a SIMD; under the causal mask block b walks
 // cost[b] tiles, and with wave w on block w the longest waves met on one SIMD (7 + 3 steps against 4 at T = 100).  Longest-processing-
 // time-first over the four wave classes: at T = 100 (costs 1 .. 7) every SIMD gets 7 steps.
-static uint32_t as_wave_map(int nw, int nlive, const int* cost) {
-    int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0}, slots[4] = {0, 0, 0, 0}, order[8], blk_of[8];
-    for (int w = 0; w < nw; ++w) { ++slots[w & 3]; blk_of[w] = 15; }
+static unsigned long long as_wave_map(int nw, int nlive, const int* cost, const int* ids = nullptr) {
+    // nlive units (unit i has id ids[i], default i, and cost cost[i]) over nw <= 16 waves; waves without a unit get id 15
+    int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0}, slots[4] = {0, 0, 0, 0}, order[16], id_of[16];
+    for (int w = 0; w < nw; ++w) { ++slots[w & 3]; id_of[w] = 15; }
     for (int b = 0; b < nlive; ++b) order[b] = b;
-    for (int i = 1; i < nlive; ++i)              // insertion sort, descending cost (stable: ties keep the lower block first)
+    for (int i = 1; i < nlive; ++i)              // insertion sort, descending cost (stable: ties keep the lower unit first)
         for (int j = i; j > 0 && cost[order[j]] > cost[order[j - 1]]; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
     for (int i = 0; i < nlive; ++i) {
         int best = -1;
         for (int k = 0; k < 4; ++k)
             if (used[k] < slots[k] && (best < 0 || load[k] < load[best])) best = k;
-        blk_of[best + 4 * used[best]] = order[i];
+        id_of[best + 4 * used[best]] = ids ? ids[order[i]] : order[i];
         load[best] += cost[order[i]]; ++used[best];
     }
-    uint32_t m = 0;
-    for (int w = 0; w < 8; ++w) m |= (uint32_t)(w < nw ? blk_of[w] : 15) << (4 * w);
+    unsigned long long m = 0;
+    for (int w = 0; w < 16; ++w) m |= (unsigned long long)(w < nw ? id_of[w] : 15) << (4 * w);
     return m;
 }
 
@@ -501,7 +518,7 @@ int asr_attention_small_fwd_launch(const float* Q, const float* K, const float* 
     dim3 grid(N * H), block(64 * nqt);
     int cost[8];
     for (int b = 0; b < nqt; ++b) cost[b] = causal ? (b + 1 < nkt ? b + 1 : nkt) : nkt;          // key tiles block b walks
-    const uint32_t wmap = as_wave_map(nqt, nqt, cost);
+    const uint32_t wmap = (uint32_t)as_wave_map(nqt, nqt, cost);
     hipStream_t st = (hipStream_t)stream;
 #define ASR_AS_FWD(CA, DR)                                                                                                      \
     do {                                                                                                                       \
@@ -523,24 +540,28 @@ int asr_attention_small_bwd_launch(const float* Q, const float* K, const float* 
     const int nqt = asr_cdiv(Tq, 16), nkt = asr_cdiv(Tk, 16);
     const size_t ldskv = (size_t)(2 * nqt * 16 * 64 + 3 * nqt * 16 + nkt * 16) * sizeof(float);
     const size_t ldsq = (size_t)(2 * nkt * 16 * 64 + 3 * nqt * 16 + nkt * 16) * sizeof(float);
-    // both kernels stage with every wave and index statistics of all rows: max(query tiles, key tiles) waves
-    const int nwv = nqt > nkt ? nqt : nkt;
-    dim3 grid(N * H), block(64 * nwv);
-    int ckv[8], cq[8];
-    for (int b = 0; b < nkt; ++b) ckv[b] = causal ? (nqt - b > 0 ? nqt - b : 0) + 1 : nqt;      // query tiles key block b walks (+ its fixed part)
+    // dK / dV: two waves per 16-key block (roles dV: 32 MFMAs per tile, dK: 48); dQ: one wave per 16-query block
+    dim3 grid(N * H), blockkv(64 * 2 * nkt), blockq(64 * nqt);
+    int ckv[16], idkv[16], cq[8];
+    for (int b = 0; b < nkt; ++b) {
+        const int tiles = causal ? (nqt - b > 0 ? nqt - b : 0) : nqt;          // query tiles key block b walks
+        ckv[2 * b] = 32 * tiles + 8; idkv[2 * b] = b;                          // dV wave
+        ckv[2 * b + 1] = 48 * tiles + 8; idkv[2 * b + 1] = b | 8;              // dK wave
+    }
     for (int b = 0; b < nqt; ++b) cq[b] = causal ? (b + 1 < nkt ? b + 1 : nkt) : nkt;
-    const uint32_t mapkv = as_wave_map(nwv, nkt, ckv), mapq = as_wave_map(nwv, nqt, cq);
+    const unsigned long long mapkv = as_wave_map(2 * nkt, 2 * nkt, ckv, idkv);
+    const uint32_t mapq = (uint32_t)as_wave_map(nqt, nqt, cq);
     hipStream_t st = (hipStream_t)stream;
 #define ASR_AS_BWD(CA, DR)                                                                                                     \
     do {                                                                                                                       \
         auto kkv = attn_small_bwd_kv_kernel<CA, DR>;                                                                           \
         static size_t havekv = 0;                                                                                              \
         if (ldskv > havekv) { if (hipFuncSetAttribute((const void*)kkv, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldskv) != hipSuccess) { (void)hipGetLastError(); return ASR_ERR_UNSUPPORTED; } havekv = ldskv; } \
-        hipLaunchKernelGGL(kkv, grid, block, ldskv, st, Q, K, V, O, dO, lse, dK, dV, N, Tq, Tk, C, H, ldq, ldk, relu_grad, thr, seed, scale, qstat, kstat, mapkv); \
+        hipLaunchKernelGGL(kkv, grid, blockkv, ldskv, st, Q, K, V, O, dO, lse, dK, dV, N, Tq, Tk, C, H, ldq, ldk, relu_grad, thr, seed, scale, qstat, kstat, mapkv); \
         auto kq = attn_small_bwd_q_kernel<CA, DR>;                                                                             \
         static size_t haveq = 0;                                                                                               \
         if (ldsq > haveq) { if (hipFuncSetAttribute((const void*)kq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsq) != hipSuccess) { (void)hipGetLastError(); return ASR_ERR_UNSUPPORTED; } haveq = ldsq; } \
-        hipLaunchKernelGGL(kq, grid, block, ldsq, st, Q, K, V, O, dO, lse, dQ, N, Tq, Tk, C, H, ldq, ldk, relu_grad, thr, seed, scale, qstat, kstat, mapq); \
+        hipLaunchKernelGGL(kq, grid, blockq, ldsq, st, Q, K, V, O, dO, lse, dQ, N, Tq, Tk, C, H, ldq, ldk, relu_grad, thr, seed, scale, qstat, kstat, mapq); \
     } while (0)
     if (drop) { if (causal) ASR_AS_BWD(true, true); else ASR_AS_BWD(false, true); }
     else { if (causal) ASR_AS_BWD(true, false); else ASR_AS_BWD(false, false); }
