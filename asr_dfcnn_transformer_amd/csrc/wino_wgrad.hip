@@ -416,10 +416,12 @@ WwPlan ww_plan(const asr_gemm_desc* d, int ldz) {
         int dev = 0; hipDeviceProp_t pr;
         ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
     }
-    // enough work per workgroup to amortise the partial it writes: at least 8 stages
+    // enough work per workgroup to amortise the partial it writes (256 KB: ~1.6 stages' worth of a CU's share of HBM): at least 8 stages --
+    // or 4 where 8 would leave CUs without a workgroup (round 6: the per-GPU batches of a strong-scaling run, B <= 10 on the 200 x 25
+    // planes; at B = 4 the 128 -> 128 launch ran 100 workgroups of 8 stages on 256 CUs: 84 us where an eighth of the B = 32 launch is 44)
     int nsl = ncu / p.nbp;
     if (nsl < 1) nsl = 1;
-    if (nsl > p.nstages / 8) nsl = p.nstages / 8;
+    if (nsl > p.nstages / 8) { const int n4 = p.nstages / 4; nsl = n4 < nsl ? n4 : nsl; if (nsl < p.nstages / 8) nsl = p.nstages / 8; }
     if (nsl < 1) return p;                       // too small a problem: the direct kernels
     p.nsl = nsl;
     p.nparts = nsl;
