@@ -480,10 +480,10 @@ __global__ __launch_bounds__(512, 4) void attn_small_bwd_q_kernel(const float* _
 
 }  // namespace
 
-// Which 16-row block a wave owns, as eight nibbles (wave w: bits 4 w .. 4 w + 3; 15 = none: the wave only helps to stage).  A workgroup's
-// waves go to the CU's four SIMDs cyclically (MI355X_MICROARCH.md, LDS section), so waves w and w + 4 share a SIMD; under the causal mask block b walks
-// cost[b] tiles, and with wave w on block w the longest waves met on one SIMD (7 + 3 steps against 4 at T = 100).  Longest-processing-
-// time-first over the four wave classes: at T = 100 (costs 1 .. 7) every SIMD gets 7 steps.
+// Which unit of work a wave owns, one nibble per wave (wave w: bits 4 w .. 4 w + 3): a 16-row block for the forward and dQ kernels, block | role << 3
+// for the dK / dV kernel.  A workgroup's waves go to the CU's four SIMDs cyclically (MI355X_MICROARCH.md, LDS section), so waves w and w + 4 share
+// a SIMD; under the causal mask block b walks cost[b] tiles, and with wave w on block w the longest waves met on one SIMD (7 + 3 steps against 4 at
+// T = 100).  Longest-processing-time-first over the four wave classes: at T = 100 (costs 1 .. 7) every SIMD gets 7 steps.
 static unsigned long long as_wave_map(int nw, int nlive, const int* cost, const int* ids = nullptr) {
     // nlive units (unit i has id ids[i], default i, and cost cost[i]) over nw <= 16 waves; waves without a unit get id 15
     int load[4] = {0, 0, 0, 0}, used[4] = {0, 0, 0, 0}, slots[4] = {0, 0, 0, 0}, order[16], id_of[16];

@@ -841,7 +841,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t2, t1 = float(tt[0]), float(tt[1])
         # one stream must win by a clear margin: a few steps right after a mode switch run 1-4 % faster than that mode's steady state (six
-        # steps of one-stream read 6.46 ms where its steady state is 6.75: profiles/r06z_bench_*: 6.43-6.44 against 6.69), while the state this guards against costs
+        # steps of one-stream read 6.43-6.44 ms where its steady state is 6.69: profiles/r06z_bench_*), while the state this guards against costs
         # the two-stream step 7-10 % (7.2 against 6.7 ms)
         keep_two = t2 <= 1.04 * t1
         calib = {'two_streams_ms': round(t2, 3), 'one_stream_ms': round(t1, 3), 'kept': 'two' if keep_two else 'one'}
