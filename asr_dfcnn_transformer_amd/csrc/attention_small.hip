@@ -106,7 +106,10 @@ __global__ __launch_bounds__(512) void attn_small_fwd_kernel(const float* __rest
     const float qmask = (qabs != 0.f) ? 1.f : 0.f;
     as_key_bias(kb, kstat ? kstat + ((long)n * H + head) * Tk : nullptr, K, kbase, Tk, T16, ldk, hoff, tid, blockDim.x);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                            // the only barrier: K, V and the key bias are complete
+    __syncthreads();
+#if defined(ASR_DEV_HOOKS) && defined(AS_PROLOGUE_ONLY)      // development probe (tools/build_variant.sh): what a launch costs up to its one barrier
+    return;
+#endif                            // the only barrier: K, V and the key bias are complete
 
     // scores of the whole row: s[kt][r] = key 16 kt + 4 g + r, query q (base-2 units)
     floatx4 s[AS_MAXKT];
@@ -354,6 +357,9 @@ __global__ __launch_bounds__(1024) void attn_small_bwd_kv_kernel(const float* __
     as_key_bias(kb, kstat ? kstat + ((long)n * H + head) * Tk : nullptr, K, kbase, Tk, Tk16, ldk, hoff, tid, blockDim.x);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#if defined(ASR_DEV_HOOKS) && defined(AS_PROLOGUE_ONLY)      // development probe (tools/build_variant.sh): what a launch costs up to its one barrier
+    return;
+#endif
     // this wave's unit (as_wave_map over 2 x key blocks units, one per wave): nibble = 16-key block | role << 3 (0 dV, 1 dK)
     const int unit = (int)((wmap >> (4 * wave)) & 15ull);
     const int k0 = (unit & 7) * 16, role = unit >> 3;
@@ -410,6 +416,9 @@ __global__ __launch_bounds__(512, 4) void attn_small_bwd_q_kernel(const float* _
     as_key_bias(kb, kstat ? kstat + ((long)n * H + head) * Tk : nullptr, K, kbase, Tk, Tk16, ldk, hoff, tid, blockDim.x);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#if defined(ASR_DEV_HOOKS) && defined(AS_PROLOGUE_ONLY)      // development probe (tools/build_variant.sh): what a launch costs up to its one barrier
+    return;
+#endif
     if (q0 >= Tq) return;
     // (a masked query: reference +inf -> P = 0 -> dS = 0: the mask on dO of attention.hip's dQ kernel, folded into the statistic)
     const float my_lse = lse_a[q0 + c], my_lsl = lsl_a[q0 + c], my_del = del_a[q0 + c];
