@@ -448,6 +448,14 @@ def shutdown_process_group(seconds=60):
     done.set()
 
 
+def keep_two_streams(two_ms, one_ms, margin=1.04):
+    """The stream calibration's decision: two streams stay unless one stream wins by a clear margin.  A few steps right after a mode switch
+    run 1-4 % faster than that mode's steady state (six one-stream steps read 6.43-6.44 ms where its steady state is 6.69:
+    profiles/r06z_bench_*), while the box state this guards against costs the two-stream step 7-10 % (7.2 against 6.7 ms,
+    profiles/r05_bimodal_box.txt)."""
+    return two_ms <= margin * one_ms
+
+
 def engine_kwargs(args):
     """The A/B switches of DFCNNEngine as command-line flags (the engine itself reads no environment variable)."""
     return dict(dual_stream=not args.single_stream, wino=not args.no_wino, compact_pool=not args.no_compact_pool,
@@ -840,10 +848,7 @@ def main():
             tt = torch.tensor([t2, t1], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t2, t1 = float(tt[0]), float(tt[1])
-        # one stream must win by a clear margin: a few steps right after a mode switch run 1-4 % faster than that mode's steady state (six
-        # steps of one-stream read 6.43-6.44 ms where its steady state is 6.69: profiles/r06z_bench_*), while the state this guards against costs
-        # the two-stream step 7-10 % (7.2 against 6.7 ms)
-        keep_two = t2 <= 1.04 * t1
+        keep_two = keep_two_streams(t2, t1)
         calib = {'two_streams_ms': round(t2, 3), 'one_stream_ms': round(t1, 3), 'kept': 'two' if keep_two else 'one'}
         if not keep_two:
             eng.side = None

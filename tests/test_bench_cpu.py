@@ -165,3 +165,11 @@ def test_a_teardown_that_returns_leaves_through_the_normal_exit():
                        timeout=120)
     assert r.returncode == 0, r.stderr.decode()[-800:]
     assert b'left through the normal exit' in r.stdout
+
+
+def test_stream_calibration_keeps_two_streams_unless_one_wins_clearly():
+    """bench.py --streams auto: the records of round 6 (profiles/r06z_bench_*: 6.12 vs 6.44, 4.18 vs 4.33 ms) keep two streams, a sample that
+    flatters one stream by 1-3 % (4.39 vs 4.34: the mis-pick of the first version) still keeps two, the bimodal box of round 5 (7.2 vs 6.7) does not."""
+    assert bench.keep_two_streams(6.115, 6.44) and bench.keep_two_streams(4.181, 4.325)
+    assert bench.keep_two_streams(4.387, 4.335) and bench.keep_two_streams(6.911, 6.829)
+    assert not bench.keep_two_streams(7.2, 6.7) and not bench.keep_two_streams(7.3, 6.75)
